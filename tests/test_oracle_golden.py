@@ -1,0 +1,190 @@
+"""CPU: the oracle restatement (oracle/ldm_oracle.py) against the fixtures produced by the REAL
+reference (tools/make_golden.py).  Inputs/weights are regenerated from seeds exactly as the
+generator did; only the reference's outputs are stored."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rnd
+from oracle import ldm_oracle as O
+from oracle import weights as W
+
+torch.set_grad_enabled(False)
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def close(mine, ref, rtol=1e-5, atol=1e-5):
+    torch.testing.assert_close(torch.as_tensor(mine).float(), torch.as_tensor(ref).float(), rtol=rtol, atol=atol)
+
+
+def recipe(shapes, seed=0, gain=1.0):
+    return W.synth_state_dict(shapes, seed=seed, gain=gain)
+
+
+def test_g1_schedules():
+    g = golden("g1_schedules.npz")
+    s = O.register_schedule(**W.SCHEDULE)
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+              "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2",
+              "posterior_log_variance_clipped", "sqrt_one_minus_alphas_cumprod"):
+        assert np.array_equal(s[k].numpy(), g[k]), k
+    for S in (50, 200):
+        ts = O.make_ddim_timesteps(S)
+        assert np.array_equal(ts, g[f"S{S}_timesteps"])
+        for eta in (0.0, 1.0):
+            tab = O.make_ddim_tables(s["alphas_cumprod"], ts, eta)
+            for k, v in tab.items():
+                assert np.array_equal(v, g[f"S{S}_eta{int(eta)}_{k}"]), (S, eta, k)
+    # headline values quoted in SURVEY.md §8(a) A2
+    tab = O.make_ddim_tables(s["alphas_cumprod"], O.make_ddim_timesteps(200), 1.0)
+    assert abs(tab["a_t"][0] - 0.9969941) < 1e-6 and abs(tab["sigma_t"][-1] - 0.31256) < 1e-4
+
+
+def test_g2_timestep_embedding():
+    g = golden("g2_timestep_embedding.npz")
+    assert np.array_equal(O.timestep_embedding(T(g["t"]), 160).numpy(), g["emb"])
+
+
+def test_g3_ops():
+    g = golden("g3_ops.npz")
+    for tag, shape, seed in (("gn160", (2, 160, 8, 8), 11), ("gn480", (1, 480, 4, 4), 12)):
+        sd = recipe({"weight": (shape[1],), "bias": (shape[1],)}, seed=1)
+        x = rnd(seed, *shape) * 1.5 + 0.3
+        close(O.gn_silu(x, sd["weight"], sd["bias"]), g[tag])
+    sd = recipe({"weight": (320, 160, 3, 3), "bias": (320,)}, seed=2)
+    close(torch.nn.functional.conv2d(rnd(13, 1, 160, 8, 8), sd["weight"], sd["bias"], padding=1), g["conv3x3"])
+    keys = {}
+    W._resblock(keys, "", 160, 320, 640)
+    close(O.resblock(recipe(keys, seed=3), "", rnd(14, 2, 160, 8, 8), rnd(15, 2, 640)), g["resblock"], 1e-5, 2e-5)
+    x = rnd(16, 1, 64, 160)
+    ca = {"to_q.weight": (160, 160), "to_k.weight": (160, 160), "to_v.weight": (160, 160),
+          "to_out.0.weight": (160, 160), "to_out.0.bias": (160,)}
+    close(O.cross_attention(recipe(ca, seed=4), "", x, None, 5), g["attn_self"])
+    ca["to_k.weight"] = ca["to_v.weight"] = (160, 512)
+    for L in (1, 3):
+        close(O.cross_attention(recipe(ca, seed=5), "", x, rnd(17 + L, 1, L, 512), 5), g[f"attn_cross_L{L}"])
+    ff = {"net.0.proj.weight": (1280, 160), "net.0.proj.bias": (1280,), "net.2.weight": (160, 640),
+          "net.2.bias": (160,)}
+    close(O.geglu_ff(recipe(ff, seed=6), "", x), g["geglu_ff"])
+    keys = {}
+    W._spatial_transformer(keys, "", 160, 5, 32, 1, 512)
+    sd = recipe(keys, seed=7)
+    x4 = rnd(21, 2, 160, 8, 8)
+    close(O.spatial_transformer(sd, "", x4, rnd(22, 2, 1, 512), 5), g["spatial_transformer"], 1e-5, 2e-5)
+    close(O.spatial_transformer(sd, "", x4, rnd(23, 2, 3, 512), 5), g["spatial_transformer_L3"], 1e-5, 2e-5)
+    sd = recipe({"op.weight": (160, 160, 3, 3), "op.bias": (160,)}, seed=8)
+    close(torch.nn.functional.conv2d(x4, sd["op.weight"], sd["op.bias"], stride=2, padding=1), g["downsample"])
+    sd = recipe({"conv.weight": (160, 160, 3, 3), "conv.bias": (160,)}, seed=9)
+    up = torch.nn.functional.interpolate(x4, scale_factor=2, mode="nearest")
+    close(torch.nn.functional.conv2d(up, sd["conv.weight"], sd["conv.bias"], padding=1), g["upsample"])
+    s = O.register_schedule(**W.SCHEDULE)
+    tab = O.make_ddim_tables(s["alphas_cumprod"], O.make_ddim_timesteps(200), 1.0)
+    x, e = rnd(31, 2, 3, 32, 32), rnd(32, 2, 3, 32, 32)
+    xp, px0 = O.ddim_update(x, e, tab["a_t"][100], tab["a_prev"][100], tab["sigma_t"][100],
+                            tab["sqrt_one_minus_at"][100], T(g["ddim_noise"]))
+    close(xp, g["ddim_x_prev"], 1e-6, 1e-6)
+    close(px0, g["ddim_pred_x0"], 1e-6, 1e-6)
+    close(O.ddpm_update(s, x, e, torch.tensor([0, 700]), T(g["ddpm_noise"])), g["ddpm_x_prev"], 1e-6, 1e-6)
+
+
+def test_g4_unet_fr():
+    g = golden("g4_unet_fr.npz")
+    sd = recipe(W.unet_param_shapes(W.FR_UNET))
+    assert sum(int(np.prod(s)) for s in W.unet_param_shapes(W.FR_UNET).values()) == 156_760_483  # 156.76 M
+    out = O.unet_forward(sd, W.FR_UNET, rnd(41, 2, 3, 32, 32), torch.tensor([3, 981]), rnd(42, 2, 1, 512))
+    close(out, g["fr_eps"], 1e-4, 1e-4)
+
+
+def test_g4_unet_northstar_64():
+    g = golden("g4_unet_fr.npz")
+    sd = recipe(W.unet_param_shapes(W.NS_UNET))
+    out = O.unet_forward(sd, W.NS_UNET, rnd(43, 1, 4, 64, 64), torch.tensor([501]), rnd(44, 1, 1, 512))
+    close(out, g["ns_eps"], 1e-4, 1e-4)
+
+
+def _fr_cond():
+    emb = W.synth_tensor("embedding.weight", (8, 512))
+    unc = W.synth_tensor("uncond_embedding.weight", (1, 512))
+    labels = [1, 6]
+    return T(emb[labels][:, None]), T(unc[[0, 0]][:, None])
+
+
+def test_g5_sampling_fr():
+    g = golden("g5_sampling_fr.npz")
+    sd = recipe(W.unet_param_shapes(W.FR_UNET), gain=0.25)
+    s = O.register_schedule(**W.SCHEDULE)
+    c, uc = _fr_cond()
+    xT = rnd(51, 2, 3, 32, 32)
+    close(O.ddim_sample(sd, W.FR_UNET, s, 4, xT, cond=c), g["sample_S4"], 1e-4, 1e-4)
+    ts = O.make_ddim_timesteps(200)
+
+    def run3(eta, scale, noise):
+        tab = O.make_ddim_tables(s["alphas_cumprod"], ts, eta)
+        img = xT
+        for i, step in enumerate(np.flip(ts)[:3]):
+            idx = 200 - i - 1
+            t = torch.full((2,), int(step), dtype=torch.long)
+            if scale == 1.0:
+                e = O.apply_model(sd, W.FR_UNET, img, t, [c])
+            else:
+                eu, ec = O.apply_model(sd, W.FR_UNET, torch.cat([img] * 2), torch.cat([t] * 2),
+                                       [torch.cat([uc, c])]).chunk(2)
+                e = O.cfg_combine(eu, ec, scale)
+            img, _ = O.ddim_update(img, e, tab["a_t"][idx], tab["a_prev"][idx], tab["sigma_t"][idx],
+                                   tab["sqrt_one_minus_at"][idx], None if noise is None else noise[i])
+        return img
+
+    close(run3(0.0, 1.0, None), g["s200_e0_cfg1"], 1e-4, 1e-4)
+    close(run3(0.0, 3.0, None), g["s200_e0_cfg3"], 1e-4, 1e-4)
+    close(run3(1.0, 1.0, T(g["s200_e1_noise"])), g["s200_e1_cfg1"], 1e-4, 1e-4)
+    out = O.p_sample_loop(sd, W.FR_UNET, s, xT, cond=c, timesteps=3, noise=list(T(g["p_sample_loop_noise"])))
+    close(out, g["p_sample_loop_T3"], 1e-4, 1e-4)
+
+
+def test_g6_vqgan():
+    g = golden("g6_vqgan.npz")
+    sd = recipe(W.vqmodel_param_shapes(W.VQ_F4))
+    z = rnd(61, 1, 3, 32, 32)
+    zq, idx = O.vq_quantize(z, sd["quantize.embedding.weight"])
+    assert np.array_equal(idx.numpy().astype(np.int32), g["vq_idx"].reshape(-1))
+    close(zq, g["vq_zq"], 0, 1e-7)
+    keys = {}
+    W._vq_attn(keys, "", 512)
+    close(O.vq_attn_block(recipe(keys, seed=1), "", rnd(62, 1, 512, 8, 8)), g["attn_block"], 1e-5, 2e-5)
+    keys = {}
+    W._vq_resnet(keys, "", 256, 128)
+    close(O.vq_resnet_block(recipe(keys, seed=2), "", rnd(63, 1, 256, 8, 8)), g["resnet_block"], 1e-5, 2e-5)
+    dec, _ = O.decode_first_stage(sd, W.VQ_F4, z)
+    close(dec, g["decoded"].astype(np.float32), 2e-3, 2e-3)       # stored as fp16
+    st = g["decoded_stats"]
+    assert abs(dec.abs().max().item() - st[0]) < 1e-3 and abs(dec.std().item() - st[2]) < 1e-4
+    img = torch.tanh(rnd(64, 1, 3, 128, 128))
+    close(O.encode_first_stage(sd, W.VQ_F4, img), g["encoded"], 1e-4, 2e-4)
+
+
+def test_g7_talking_face():
+    g = golden("g7_talking_face.npz")
+    usd = recipe(W.unet_param_shapes(W.TF_UNET))
+    out = O.apply_model(usd, W.TF_UNET, rnd(71, 2, 3, 32, 32), torch.tensor([11, 756]),
+                        [rnd(72, 2, 1, 1024)], [rnd(73, 2, 6, 32, 32)])
+    close(out, g["tf_eps"], 1e-4, 1e-4)
+    asd = recipe(W.audio_attention_param_shapes(3))
+    close(O.audio_temporal_attention(asd, rnd(74, 2, 3, 768)), g["audio_att"])
+    vsd = recipe(W.vqmodel_param_shapes(W.VQ_F4))
+    usd = recipe(W.unet_param_shapes(W.TF_UNET), gain=0.25)
+    s = O.register_schedule(**W.SCHEDULE)
+    Tn, S = 3, 4
+    audio = rnd(75, Tn, 768)
+    masked = torch.tanh(rnd(76, Tn, 3, 128, 128))
+    masked[:, :, 70:, :] = -1.0
+    ident = torch.tanh(rnd(77, 1, 3, 128, 128))
+    c1 = T(W.synth_tensor("embedding.weight", (9, 256))[[4]][:, None])
+    xid = O.encode_first_stage(vsd, W.VQ_F4, ident)
+    close(xid, g["xid"], 1e-4, 2e-4)
+    xT = rnd(78, Tn, 1, 3, 32, 32)
+    for fixed, tag in ((False, "autoreg"), (True, "fixed")):
+        fr = torch.cat(O.progressive_sampling(usd, W.TF_UNET, s, vsd, W.VQ_F4, asd, c1, xid, masked, audio, S, 1,
+                                              xT, fixed_identity=fixed))
+        close(fr, g[f"frames_{tag}"], 1e-4, 3e-4)
+    assert not np.allclose(g["frames_autoreg"][1:], g["frames_fixed"][1:])
+    close(g["frames_fixed_batched"], g["frames_fixed"], 1e-4, 3e-4)
