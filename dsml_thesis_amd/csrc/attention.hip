@@ -1,0 +1,244 @@
+// Attention kernels.
+//   ldmk_attn_self  : flash-style self attention, d_head = 32, f32 matrix cores.
+//   ldmk_attn_cross : short-context cross attention (L <= 128), VALU.
+//   ldmk_softmax_rows: row softmax for the VQGAN single-head AttnBlock (d = 512).
+#include "ldmk_common.h"
+
+namespace ldmk {
+
+// ---------------------------------------------------------------------------------------------
+// Self attention.  One workgroup = 4 waves = 128 queries of one (sample, head); K/V tiles of 64
+// keys are staged in LDS and shared by the 4 waves.  Per wave (32 queries):
+//   S^T = K Q^T   (A = K rows from LDS, B = Q held in 16 VGPRs)  -> lane = query, regs = keys,
+//         so the softmax row reduction is 16 in-lane values + one cross-half shuffle;
+//   O^T += V^T P^T (A = V rows from LDS, B = the P registers *as they are*: register r of the
+//         S^T accumulator holds keys {kr, kr+4} on the two half-waves, which is exactly the
+//         k-pair layout of the 32x32x2 B operand) -> no data movement between the two products.
+// The score matrix never exists in memory (the reference materialises 120 MB/sample at 32x32).
+constexpr int AT_D = 32;
+constexpr int AT_KT = 64;            // keys per staged tile
+constexpr int AT_KSTR = AT_D + 1;    // K rows padded: lanes read 32 different keys at fixed d
+
+__global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                        int tokens, int heads, float scale) {
+  __shared__ float Ks[AT_KT * AT_KSTR];
+  __shared__ float Vs[AT_KT * AT_D];
+  __shared__ float Os[4][32 * 33];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int C = heads * AT_D;
+  const int ld = 3 * C;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float* base = qkv + (long long)b * tokens * ld;
+  const bool wave_active = q0 < tokens;     // tokens is a multiple of 32 (checked on the host)
+
+  // Q fragment: B operand of S^T = K Q^T: lane holds Q[query = l31][d = 2s + half], pre-scaled
+  float qf[16];
+  {
+    const float* qp = base + (long long)(wave_active ? q0 + l31 : 0) * ld + h * AT_D;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) qf[s] = wave_active ? qp[2 * s + half] * scale : 0.f;
+  }
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging map: 64 keys x 32 d = 512 float4 for K and for V; thread t -> key t/8 (+32), d4 = (t%8)*4
+  const int skey = tid >> 3, sd = (tid & 7) * 4;
+  const int ntiles = (tokens + AT_KT - 1) / AT_KT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    float4 kr[2], vr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = kt * AT_KT + skey + 32 * i;
+      if (key < tokens) {
+        const float* kp = base + (long long)key * ld + C + h * AT_D + sd;
+        kr[i] = *reinterpret_cast<const float4*>(kp);
+        vr[i] = *reinterpret_cast<const float4*>(kp + C);
+      } else {
+        kr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        vr[i] = kr[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float* kd = Ks + (skey + 32 * i) * AT_KSTR + sd;
+      kd[0] = kr[i].x; kd[1] = kr[i].y; kd[2] = kr[i].z; kd[3] = kr[i].w;
+      *reinterpret_cast<float4*>(Vs + (skey + 32 * i) * AT_D + sd) = vr[i];
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int key0 = kt * AT_KT + sub * 32;
+      if (key0 >= tokens) break;
+      f32x16 s_acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
+      const float* kbase = Ks + (sub * 32 + l31) * AT_KSTR + half;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kbase[2 * s], qf[s], s_acc, 0, 0, 0);
+      // s_acc[r] = S[query l31][key = key0 + (r&3) + 8*(r>>2) + 4*half]
+      float mx = s_acc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_acc[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float corr = __expf(m_run - m_new);     // 0 on the first tile (m_run = -inf)
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s_acc[r] = __expf(s_acc[r] - m_new);
+        psum += s_acc[r];
+      }
+      psum += __shfl_xor(psum, 32, 64);
+      l_run = l_run * corr + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] *= corr;
+      // O^T[d][query] += sum_key V[key][d] * P[query][key]
+      const float* vbase = Vs + (sub * 32 + 4 * half) * AT_D + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int krow = (r & 3) + 8 * (r >> 2);
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(vbase[krow * AT_D], s_acc[r], o, 0, 0, 0);
+      }
+    }
+  }
+  if (!wave_active) return;
+  // o[r] = O[query l31][d = (r&3) + 8*(r>>2) + 4*half]; transpose through LDS for 128-B row stores
+  const float inv = 1.0f / l_run;
+  float* ow = Os[wave];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+    ow[l31 * 33 + d] = o[r] * inv;
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed
+  __builtin_amdgcn_wave_barrier();
+  float* op = out + ((long long)b * tokens + q0) * C + h * AT_D;
+#pragma unroll
+  for (int q = 0; q < 32; q += 2) op[(long long)(q + half) * C + l31] = ow[(q + half) * 33 + l31];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross attention with a short context (L <= 128).  One wave per (query row, head-group): lane l
+// handles head l/ (64/hpw)...  Simple mapping: thread <-> (query, head); K/V of the sample's
+// context for that head are read through L1/L2 (tiny: L*C floats per sample).
+__global__ __launch_bounds__(256) void attn_cross_kernel(const float* __restrict__ q, int ldq,
+                                                         const float* __restrict__ k, const float* __restrict__ v,
+                                                         int ldkv, float* __restrict__ out, int ldo, int tokens, int L,
+                                                         int heads, float scale, long long total) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (sample, token, head)
+  if (idx >= total) return;
+  const int h = (int)(idx % heads);
+  const long long row = idx / heads;                 // sample*tokens + token
+  const int b = (int)(row / tokens);
+  const float* qp = q + row * ldq + h * AT_D;
+  float qv[AT_D];
+#pragma unroll
+  for (int d = 0; d < AT_D; d += 4) {
+    float4 t = *reinterpret_cast<const float4*>(qp + d);
+    qv[d] = t.x; qv[d + 1] = t.y; qv[d + 2] = t.z; qv[d + 3] = t.w;
+  }
+  const float* kb = k + (long long)b * L * ldkv + h * AT_D;
+  const float* vb = v + (long long)b * L * ldkv + h * AT_D;
+  float m = -INFINITY, l = 0.f;
+  float acc[AT_D];
+#pragma unroll
+  for (int d = 0; d < AT_D; ++d) acc[d] = 0.f;
+  for (int j = 0; j < L; ++j) {
+    const float* kp = kb + (long long)j * ldkv;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < AT_D; ++d) s = fmaf(qv[d], kp[d], s);
+    s *= scale;
+    const float mn = fmaxf(m, s);
+    const float corr = __expf(m - mn), pj = __expf(s - mn);
+    l = l * corr + pj;
+    const float* vp = vb + (long long)j * ldkv;
+#pragma unroll
+    for (int d = 0; d < AT_D; ++d) acc[d] = fmaf(pj, vp[d], acc[d] * corr);
+    m = mn;
+  }
+  const float inv = 1.0f / l;
+  float* op = out + row * ldo + h * AT_D;
+#pragma unroll
+  for (int d = 0; d < AT_D; d += 4)
+    *reinterpret_cast<float4*>(op + d) = make_float4(acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax of x*scale, in place.  One workgroup per row, row cached in registers (cols <= 256*32).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int cols, float scale) {
+  __shared__ float red[4];
+  float* p = x + (long long)blockIdx.x * cols;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float v[32];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    int c = tid + 256 * i;
+    v[i] = c < cols ? p[c] * scale : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    int c = tid + 256 * i;
+    v[i] = c < cols ? __expf(v[i] - mx) : 0.f;
+    s += v[i];
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  const float inv = 1.0f / s;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    int c = tid + 256 * i;
+    if (c < cols) p[c] = v[i] * inv;
+  }
+}
+
+}  // namespace ldmk
+
+extern "C" int ldmk_attn_self(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream) {
+  using namespace ldmk;
+  LDMK_REQUIRE(qkv && out && n > 0 && heads > 0, "ldmk_attn_self: bad args");
+  LDMK_REQUIRE(tokens > 0 && tokens % 32 == 0, "ldmk_attn_self: tokens=%d must be a multiple of 32", tokens);
+  LDMK_REQUIRE(heads <= 65535 && n <= 65535, "ldmk_attn_self: grid limits");
+  dim3 grid((tokens + 127) / 128, heads, n);
+  hipLaunchKernelGGL(attn_self_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, tokens, heads, scale);
+  return check_launch("ldmk_attn_self");
+}
+
+extern "C" int ldmk_attn_cross(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo,
+                               int n, int tokens, int ctx_len, int heads, float scale, void* stream) {
+  using namespace ldmk;
+  LDMK_REQUIRE(q && k && v && out && n > 0 && tokens > 0 && heads > 0, "ldmk_attn_cross: bad args");
+  LDMK_REQUIRE(ctx_len >= 1 && ctx_len <= 128, "ldmk_attn_cross: ctx_len=%d outside [1,128]", ctx_len);
+  LDMK_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldkv % 4 == 0, "ldmk_attn_cross: leading dims must be multiples of 4");
+  long long total = (long long)n * tokens * heads;
+  hipLaunchKernelGGL(attn_cross_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, ldq,
+                     k, v, ldkv, out, ldo, tokens, ctx_len, heads, scale, total);
+  return check_launch("ldmk_attn_cross");
+}
+
+extern "C" int ldmk_softmax_rows(float* x, long long rows, int cols, float scale, void* stream) {
+  using namespace ldmk;
+  LDMK_REQUIRE(x && rows > 0 && cols > 0 && cols <= 8192, "ldmk_softmax_rows: cols must be in (0, 8192]");
+  LDMK_REQUIRE(rows <= 0x7fffffffLL, "ldmk_softmax_rows: too many rows");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, cols, scale);
+  return check_launch("ldmk_softmax_rows");
+}

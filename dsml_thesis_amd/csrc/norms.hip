@@ -1,0 +1,132 @@
+// GroupNorm / LayerNorm statistics (HBM-bound; the normalisation itself is applied by the
+// consumer while it stages its A operand, see igemm.hip).
+#include "ldmk_common.h"
+
+namespace ldmk {
+
+constexpr int GN_PIX = 64;   // pixels per partial-sum chunk
+
+// pass 1: per-(sample, chunk, channel) sum and sum of squares.  Thread <-> channel, so a wave reads
+// 64 consecutive floats of one NHWC pixel row: fully coalesced, also across the concat seam.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x0, int c0,
+                                                         const float* __restrict__ x1, int c1, int hw, int chunks,
+                                                         float* __restrict__ partial) {
+  const int C = c0 + c1;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int p0 = chunk * GN_PIX;
+  const int p1 = min(hw, p0 + GN_PIX);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float* src;
+    int cs, cl;
+    if (c < c0) { src = x0; cs = c0; cl = c; } else { src = x1; cs = c1; cl = c - c0; }
+    const float* ptr = src + ((long long)n * hw + p0) * cs + cl;
+    // shifted sums (shift = first value of the chunk) keep the fp32 cancellation error small
+    const float shift = ptr[0];
+    float s = 0.f, ss = 0.f;
+    for (int p = p0; p < p1; ++p) {
+      float v = *ptr - shift;
+      s += v;
+      ss = fmaf(v, v, ss);
+      ptr += cs;
+    }
+    float* d = partial + (((long long)n * chunks + chunk) * C + c) * 3;
+    d[0] = shift; d[1] = s; d[2] = ss;
+  }
+}
+
+// pass 2: one workgroup (one wave per group) per sample: combine chunk partials in double,
+// emit per-channel scale/shift planes  y = x*scale + shift  ==  (x-mean)*rstd*gamma + beta.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int C, int hw, int chunks,
+                                                          int groups, float eps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ coef) {
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int cpg = C / groups;
+  for (int g = blockIdx.x * 4 + wave; g < groups; g += gridDim.x * 4) {
+    // items of this group: cpg channels x chunks partials
+    const int items = cpg * chunks;
+    double sum = 0.0, sumsq = 0.0;
+    for (int i = lane; i < items; i += 64) {
+      int ch = i / cpg, cc = i - ch * cpg;
+      const float* d = partial + (((long long)n * chunks + ch) * C + g * cpg + cc) * 3;
+      int cnt = min(hw - ch * GN_PIX, GN_PIX);
+      double sh = d[0], s = d[1], ss = d[2];
+      // sum x = s + cnt*sh ; sum x^2 = ss + 2*sh*s + cnt*sh^2
+      sum += s + cnt * sh;
+      sumsq += ss + 2.0 * sh * s + cnt * sh * sh;
+    }
+    sum = wave_sum_d(sum);
+    sumsq = wave_sum_d(sumsq);
+    const double cnt = (double)cpg * hw;
+    const double mean = sum / cnt;
+    double var = sumsq / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    for (int cc = lane; cc < cpg; cc += 64) {
+      int c = g * cpg + cc;
+      float sc = rstd * gamma[c];
+      coef[((long long)n * 2) * C + c] = sc;
+      coef[((long long)n * 2 + 1) * C + c] = fmaf(-meanf, sc, beta[c]);
+    }
+  }
+}
+
+// LayerNorm statistics: one wave per row, exact two-pass in registers (C <= 64*16).
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int rows, int C, float eps,
+                                                       float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = x + row * C;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int c = lane + 64 * i;
+    v[i] = c < C ? p[c] : 0.f;
+    s += v[i];
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int c = lane + 64 * i;
+    float d = c < C ? v[i] - mean : 0.f;
+    q = fmaf(d, d, q);
+  }
+  q = wave_sum(q);
+  if (lane == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = 1.0f / sqrtf(q / (float)C + eps);
+  }
+}
+
+}  // namespace ldmk
+
+extern "C" int ldmk_gn_chunks(int hw) { return (hw + ldmk::GN_PIX - 1) / ldmk::GN_PIX; }
+
+extern "C" int ldmk_gn_coef(const float* x0, int c0, const float* x1, int c1, int n, int hw, int groups, float eps,
+                            const float* gamma, const float* beta, float* partial, float* coef, void* stream) {
+  using namespace ldmk;
+  const int C = c0 + c1;
+  LDMK_REQUIRE(x0 && c0 > 0 && n > 0 && hw > 0 && groups > 0, "ldmk_gn_coef: bad args");
+  LDMK_REQUIRE((c1 == 0) == (x1 == nullptr), "ldmk_gn_coef: x1/c1 mismatch");
+  LDMK_REQUIRE(C % groups == 0, "ldmk_gn_coef: C=%d not divisible by groups=%d", C, groups);
+  LDMK_REQUIRE(gamma && beta && partial && coef, "ldmk_gn_coef: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = ldmk_gn_chunks(hw);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, n), dim3(256), 0, st, x0, c0, x1, c1, hw, chunks, partial);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((groups + 3) / 4, n), dim3(256), 0, st, partial, C, hw, chunks, groups,
+                     eps, gamma, beta, coef);
+  return check_launch("ldmk_gn_coef");
+}
+
+extern "C" int ldmk_ln_stats(const float* x, int rows, int c, float eps, float* stats, void* stream) {
+  using namespace ldmk;
+  LDMK_REQUIRE(x && stats && rows > 0 && c > 0 && c <= 1024, "ldmk_ln_stats: bad args (C<=1024)");
+  hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats);
+  return check_launch("ldmk_ln_stats");
+}

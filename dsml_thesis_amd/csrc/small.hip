@@ -1,0 +1,424 @@
+// Small / bandwidth-bound kernels of the sampling path: per-sample dense layers, timestep
+// embedding, narrow-channel boundary convolutions, sampler updates, VQ lookup, layout helpers.
+#include "ldmk_common.h"
+#include <string.h>
+
+namespace ldmk {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[b][n] = sum_k act(x[b][k]) * W[k][n] + bias[n].  Thread <-> output column (coalesced W rows),
+// up to DS_ROWS batch rows accumulated per thread; x rows staged in LDS and broadcast.
+constexpr int DS_ROWS = 8;
+constexpr int DS_KT = 256;
+__global__ __launch_bounds__(256) void dense_small_kernel(const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int ldo, int rows, int K, int N,
+                                                          int silu_in) {
+  __shared__ float xs[DS_ROWS][DS_KT];
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * DS_ROWS;
+  const int nr = min(DS_ROWS, rows - r0);
+  float acc[DS_ROWS];
+#pragma unroll
+  for (int r = 0; r < DS_ROWS; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += DS_KT) {
+    const int kn = min(DS_KT, K - k0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < DS_ROWS * DS_KT; i += 256) {
+      int r = i / DS_KT, kk = i - r * DS_KT;
+      float v = 0.f;
+      if (r < nr && kk < kn) {
+        v = x[(long long)(r0 + r) * ldx + k0 + kk];
+        if (silu_in) v = silu_f(v);
+      }
+      xs[r][kk] = v;
+    }
+    __syncthreads();
+    if (n < N) {
+      const float* wp = w + (long long)k0 * N + n;
+      for (int kk = 0; kk < kn; ++kk) {
+        const float wv = wp[(long long)kk * N];
+#pragma unroll
+        for (int r = 0; r < DS_ROWS; ++r) acc[r] = fmaf(xs[r][kk], wv, acc[r]);
+      }
+    }
+  }
+  if (n < N) {
+    const float bv = bias ? bias[n] : 0.f;
+    for (int r = 0; r < nr; ++r) out[(long long)(r0 + r) * ldo + n] = acc[r] + bv;
+  }
+}
+
+__global__ void timestep_embedding_kernel(const long long* __restrict__ t, const float* __restrict__ freqs,
+                                          float* __restrict__ emb, int n, int dim) {
+  const int half = dim / 2;
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * half) return;
+  int b = idx / half, i = idx - b * half;
+  // args = float(t) * freqs  (util.py:161-165); the frequency table is a host-computed constant
+  float arg = (float)t[b] * freqs[i];
+  // evaluated in double and rounded once: |arg| reaches ~1e3 rad where fp32 range reduction costs accuracy
+  emb[(long long)b * dim + i] = (float)cos((double)arg);
+  emb[(long long)b * dim + half + i] = (float)sin((double)arg);
+  if ((dim & 1) && i == 0) emb[(long long)b * dim + dim - 1] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 pad-1 convolution from a narrow NCHW input (<= 16 channels, optionally the concat of two
+// tensors) to a wide NHWC output.  Workgroup = 256 threads = 4 output pixels x 64 couts per pass.
+__global__ __launch_bounds__(256) void conv3x3_in_kernel(const float* __restrict__ x0, int c0,
+                                                         const float* __restrict__ x1, int c1,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int n, int h, int wd, int cout) {
+  __shared__ float patch[4][16 * 9];
+  const int cin = c0 + c1;
+  const int hw = h * wd;
+  const long long pix0 = (long long)blockIdx.x * 4;
+  const long long total = (long long)n * hw;
+  // stage the 4 pixels' 3x3xcin neighbourhoods
+  for (int i = threadIdx.x; i < 4 * cin * 9; i += 256) {
+    int pl = i / (cin * 9), rem = i - pl * (cin * 9);
+    int c = rem / 9, tap = rem - c * 9;
+    long long pix = pix0 + pl;
+    float v = 0.f;
+    if (pix < total) {
+      int b = (int)(pix / hw), p = (int)(pix - (long long)b * hw);
+      int y = p / wd + tap / 3 - 1, xx = p % wd + tap % 3 - 1;
+      if (y >= 0 && y < h && xx >= 0 && xx < wd) {
+        v = c < c0 ? x0[((long long)b * c0 + c) * hw + y * wd + xx] : x1[((long long)b * c1 + (c - c0)) * hw + y * wd + xx];
+      }
+    }
+    patch[pl][c * 9 + tap] = v;
+  }
+  __syncthreads();
+  const int pl = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long pix = pix0 + pl;
+  if (pix >= total) return;
+  for (int co = lane; co < cout; co += 64) {
+    float acc = bias ? bias[co] : 0.f;
+    for (int tap = 0; tap < 9; ++tap)
+      for (int c = 0; c < cin; ++c) acc = fmaf(patch[pl][c * 9 + tap], w[((long long)tap * cin + c) * cout + co], acc);
+    out[pix * cout + co] = acc;
+  }
+}
+
+// GroupNorm+SiLU (coef planes) -> 3x3 pad-1 conv to <= 4 channels, NHWC in -> NCHW out.
+// One wave per output pixel: lanes stride over input channels (coalesced), wave-shuffle reduce.
+__global__ __launch_bounds__(256) void conv3x3_out_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int n, int h, int wd, int cin,
+                                                          int cout) {
+  const int lane = threadIdx.x & 63;
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int hw = h * wd;
+  if (pix >= (long long)n * hw) return;
+  const int b = (int)(pix / hw), p = (int)(pix - (long long)b * hw);
+  const int oy = p / wd, ox = p - oy * wd;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* sc = coef ? coef + ((long long)b * 2) * cin : nullptr;
+  for (int c = lane; c < cin; c += 64) {
+    const float s = sc ? sc[c] : 1.f, t = sc ? sc[cin + c] : 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+      int y = oy + tap / 3 - 1, xx = ox + tap % 3 - 1;
+      if (y < 0 || y >= h || xx < 0 || xx >= wd) continue;
+      float v = x[(((long long)b * h + y) * wd + xx) * cin + c];
+      if (sc) v = silu_f(fmaf(v, s, t));
+      const float* wp = w + ((long long)tap * cin + c) * cout;
+      for (int co = 0; co < cout; ++co) acc[co] = fmaf(v, wp[co], acc[co]);
+    }
+  }
+  for (int co = 0; co < cout; ++co) {
+    float v = wave_sum(acc[co]);
+    if (lane == 0) out[((long long)b * cout + co) * hw + p] = v + (bias ? bias[co] : 0.f);
+  }
+}
+
+__global__ void conv1x1_nchw_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                    const float* __restrict__ bias, float* __restrict__ out, int n, int hw, int cin,
+                                    int cout) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)n * hw) return;
+  int b = (int)(idx / hw), p = (int)(idx - (long long)b * hw);
+  for (int co = 0; co < cout; ++co) {
+    float acc = bias ? bias[co] : 0.f;
+    for (int c = 0; c < cin; ++c) acc = fmaf(x[((long long)b * cin + c) * hw + p], w[co * cin + c], acc);
+    out[((long long)b * cout + co) * hw + p] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// DDIM update (ddim.py:170-203).  Coefficients come from a device table indexed by a device
+// counter, so the same launch replays for every step inside a captured graph.
+__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                 const float* __restrict__ noise, const float* __restrict__ table,
+                                 const int* __restrict__ step_idx, float cfg_scale, int cfg, float* __restrict__ x_prev,
+                                 float* __restrict__ pred_x0, long long total) {
+  const int index = *step_idx;
+  const float a_t = table[4 * index], a_prev = table[4 * index + 1], sigma = table[4 * index + 2],
+              s1m = table[4 * index + 3];
+  // same fp32 operation order as the reference expressions
+  const float sqrt_at = sqrtf(a_t);
+  const float dir_c = sqrtf(1.0f - a_prev - sigma * sigma);
+  const float sqrt_ap = sqrtf(a_prev);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float e;
+    if (cfg) {
+      const float eu = eps[i], ec = eps[total + i];
+      e = eu + cfg_scale * (ec - eu);
+    } else {
+      e = eps[i];
+    }
+    const float xv = x[i];
+    const float p0 = (xv - s1m * e) / sqrt_at;
+    float xp = sqrt_ap * p0 + dir_c * e;
+    if (noise) xp += sigma * noise[i];
+    x_prev[i] = xp;
+    if (pred_x0) pred_x0[i] = p0;
+  }
+}
+
+// runs after ddim_step_kernel on the same stream: index -= 1, ts[:] = timesteps[index]
+__global__ void ddim_advance_kernel(int* step_idx, const long long* __restrict__ timesteps, long long* __restrict__ ts,
+                                    int n_ts) {
+  int index = *step_idx - 1;
+  if (index < 0) index = 0;
+  const long long t = timesteps[index];
+  for (int i = threadIdx.x; i < n_ts; i += blockDim.x) ts[i] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) *step_idx = index;
+}
+
+// ancestral DDPM update (ddpm.py:215-228,1049-1109), per-sample timestep
+__global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                 const float* __restrict__ noise, const float* __restrict__ tables,
+                                 const float* __restrict__ logvar, const long long* __restrict__ t,
+                                 float* __restrict__ x_prev, long long per_sample, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per_sample);
+    const long long tt = t[b];
+    const float c_recip = tables[4 * tt], c_recipm1 = tables[4 * tt + 1], c1 = tables[4 * tt + 2],
+                c2 = tables[4 * tt + 3];
+    const float xv = x[i];
+    const float x0 = c_recip * xv - c_recipm1 * eps[i];
+    const float mean = c1 * x0 + c2 * xv;
+    const float nz = (tt == 0) ? 0.f : 1.f;
+    x_prev[i] = mean + nz * expf(0.5f * logvar[tt]) * (noise ? noise[i] : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// VQ nearest codebook entry (quantize.py:276-285).  One wave per latent vector: the 64 lanes split
+// the codebook (coalesced reads of e), keep (min d, first index), then a wave-wide arg-min that
+// breaks ties towards the smaller index like torch.argmin.  d = (|z|^2 + |e|^2) - 2 z.e in fp32.
+template <int DIM>
+__global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                         float* __restrict__ zq, int* __restrict__ idx_out, int n,
+                                                         int hw, int n_embed) {
+  const int lane = threadIdx.x & 63;
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= (long long)n * hw) return;
+  const int b = (int)(pix / hw), p = (int)(pix - (long long)b * hw);
+  float zv[DIM];
+  float zz = 0.f;
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    zv[d] = z[((long long)b * DIM + d) * hw + p];
+    zz += zv[d] * zv[d];
+  }
+  float best = INFINITY;
+  int besti = 0x7fffffff;
+  for (int j = lane; j < n_embed; j += 64) {
+    float ee = 0.f, ze = 0.f;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      const float e = cb[(long long)j * DIM + d];
+      ee += e * e;
+      ze = fmaf(zv[d], e, ze);
+    }
+    const float dist = (zz + ee) - 2.0f * ze;
+    if (dist < best) { best = dist; besti = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if (lane < DIM) zq[((long long)b * DIM + lane) * hw + p] = cb[(long long)besti * DIM + lane];
+  if (lane == 0 && idx_out) idx_out[pix] = besti;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void permute3_kernel(const float* __restrict__ src, float* __restrict__ dst, int d0, int d1, int d2, int p0,
+                                int p1, int p2, long long total) {
+  const int sd[3] = {d0, d1, d2};
+  const long long ss[3] = {(long long)d1 * d2, d2, 1};
+  const int e0 = sd[p0], e1 = sd[p1], e2 = sd[p2];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int i2 = (int)(i % e2);
+    long long r = i / e2;
+    int i1 = (int)(r % e1);
+    int i0 = (int)(r / e1);
+    (void)e0;
+    dst[i] = src[i0 * ss[p0] + i1 * ss[p1] + i2 * ss[p2]];
+  }
+}
+
+__global__ void postprocess_frames_kernel(const float* __restrict__ x, float* __restrict__ out, int n, int c, int hw,
+                                          long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int ch = (int)(i % c);
+    long long r = i / c;
+    int p = (int)(r % hw);
+    int b = (int)(r / hw);
+    float v = (x[((long long)b * c + ch) * hw + p] + 1.0f) / 2.0f;
+    out[i] = fminf(fmaxf(v, 0.f), 1.f);
+  }
+}
+
+__global__ void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ vec, int vec_ld, long long rows, int c,
+                                  int rps) {
+  const long long total4 = rows * (c / 4);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    long long row = i / (c / 4);
+    int c4 = (int)(i - row * (c / 4)) * 4;
+    float4 v = *reinterpret_cast<float4*>(x + row * c + c4);
+    float4 a = *reinterpret_cast<const float4*>(vec + (row / rps) * vec_ld + c4);
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    *reinterpret_cast<float4*>(x + row * c + c4) = v;
+  }
+}
+
+static inline unsigned grid_for(long long total, int block = 256, int cap = 4096) {
+  long long g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace ldmk
+
+using namespace ldmk;
+
+extern "C" int ldmk_version(void) { return 100; }
+extern "C" const char* ldmk_last_error(void) { return g_err; }
+
+extern "C" int ldmk_dense_small(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                                int rows, int K, int N, int silu_in, void* stream) {
+  LDMK_REQUIRE(x && w && out && rows > 0 && K > 0 && N > 0, "ldmk_dense_small: bad args");
+  LDMK_REQUIRE(ldx >= K && ldo >= N, "ldmk_dense_small: leading dims");
+  dim3 grid((N + 255) / 256, (rows + DS_ROWS - 1) / DS_ROWS);
+  hipLaunchKernelGGL(dense_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, out, ldo, rows, K, N,
+                     silu_in);
+  return check_launch("ldmk_dense_small");
+}
+
+extern "C" int ldmk_timestep_embedding(const long long* t, const float* freqs, float* emb, int n, int dim, void* stream) {
+  LDMK_REQUIRE(t && freqs && emb && n > 0 && dim >= 2, "ldmk_timestep_embedding: bad args");
+  int total = n * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, freqs,
+                     emb, n, dim);
+  return check_launch("ldmk_timestep_embedding");
+}
+
+extern "C" int ldmk_conv3x3_in(const float* x0, int c0, const float* x1, int c1, const float* w, const float* bias,
+                               float* out, int n, int h, int w_, int cout, void* stream) {
+  LDMK_REQUIRE(x0 && w && out && n > 0 && h > 0 && w_ > 0 && cout > 0, "ldmk_conv3x3_in: bad args");
+  LDMK_REQUIRE(c0 > 0 && c0 + c1 <= 16 && (c1 == 0) == (x1 == nullptr), "ldmk_conv3x3_in: c0+c1 must be <= 16");
+  long long total = (long long)n * h * w_;
+  hipLaunchKernelGGL(conv3x3_in_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x0, c0, x1,
+                     c1, w, bias, out, n, h, w_, cout);
+  return check_launch("ldmk_conv3x3_in");
+}
+
+extern "C" int ldmk_conv3x3_out(const float* x, const float* coef, const float* w, const float* bias, float* out, int n,
+                                int h, int w_, int cin, int cout, void* stream) {
+  LDMK_REQUIRE(x && w && out && n > 0 && h > 0 && w_ > 0 && cin > 0, "ldmk_conv3x3_out: bad args");
+  LDMK_REQUIRE(cout >= 1 && cout <= 4, "ldmk_conv3x3_out: cout=%d must be in [1,4]", cout);
+  long long total = (long long)n * h * w_;
+  hipLaunchKernelGGL(conv3x3_out_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, coef, w,
+                     bias, out, n, h, w_, cin, cout);
+  return check_launch("ldmk_conv3x3_out");
+}
+
+extern "C" int ldmk_conv1x1_nchw(const float* x, const float* w, const float* bias, float* out, int n, int hw, int cin,
+                                 int cout, void* stream) {
+  LDMK_REQUIRE(x && w && out && n > 0 && hw > 0 && cin > 0 && cout > 0, "ldmk_conv1x1_nchw: bad args");
+  long long total = (long long)n * hw;
+  hipLaunchKernelGGL(conv1x1_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w,
+                     bias, out, n, hw, cin, cout);
+  return check_launch("ldmk_conv1x1_nchw");
+}
+
+extern "C" int ldmk_ddim_step(const float* x, const float* eps, const float* noise, const float* table,
+                              int* step_idx, float cfg_scale, int cfg, float* x_prev, float* pred_x0,
+                              long long per_sample, int n, const long long* timesteps, long long* ts, int n_ts,
+                              int advance, void* stream) {
+  LDMK_REQUIRE(x && eps && table && step_idx && x_prev && per_sample > 0 && n > 0, "ldmk_ddim_step: bad args");
+  if (advance) LDMK_REQUIRE(timesteps && ts && n_ts > 0, "ldmk_ddim_step: advance needs timesteps/ts");
+  long long total = per_sample * n;
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, eps, noise, table,
+                     step_idx, cfg_scale, cfg, x_prev, pred_x0, total);
+  if (advance)
+    hipLaunchKernelGGL(ddim_advance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_idx,
+                       timesteps, ts, n_ts);
+  return check_launch("ldmk_ddim_step");
+}
+
+extern "C" int ldmk_ddpm_step(const float* x, const float* eps, const float* noise, const float* tables,
+                              const float* logvar, const long long* t, float* x_prev, long long per_sample, int n,
+                              void* stream) {
+  LDMK_REQUIRE(x && eps && tables && logvar && t && x_prev && per_sample > 0 && n > 0, "ldmk_ddpm_step: bad args");
+  long long total = per_sample * n;
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, eps, noise, tables,
+                     logvar, t, x_prev, per_sample, total);
+  return check_launch("ldmk_ddpm_step");
+}
+
+extern "C" int ldmk_vq_nearest(const float* z, const float* codebook, float* zq, int* idx, int n, int hw, int dim,
+                               int n_embed, void* stream) {
+  LDMK_REQUIRE(z && codebook && zq && n > 0 && hw > 0 && n_embed > 0, "ldmk_vq_nearest: bad args");
+  long long total = (long long)n * hw;
+  dim3 grid((unsigned)((total + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  switch (dim) {
+    case 3: hipLaunchKernelGGL(vq_nearest_kernel<3>, grid, dim3(256), 0, st, z, codebook, zq, idx, n, hw, n_embed); break;
+    case 4: hipLaunchKernelGGL(vq_nearest_kernel<4>, grid, dim3(256), 0, st, z, codebook, zq, idx, n, hw, n_embed); break;
+    default: LDMK_REQUIRE(false, "ldmk_vq_nearest: embed dim %d unsupported (3 or 4)", dim);
+  }
+  return check_launch("ldmk_vq_nearest");
+}
+
+extern "C" int ldmk_permute3(const float* src, float* dst, int d0, int d1, int d2, int p0, int p1, int p2, void* stream) {
+  LDMK_REQUIRE(src && dst && d0 > 0 && d1 > 0 && d2 > 0, "ldmk_permute3: bad args");
+  LDMK_REQUIRE(((1 << p0) | (1 << p1) | (1 << p2)) == 7, "ldmk_permute3: perm must be a permutation of 0,1,2");
+  long long total = (long long)d0 * d1 * d2;
+  hipLaunchKernelGGL(permute3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, d0, d1, d2, p0,
+                     p1, p2, total);
+  return check_launch("ldmk_permute3");
+}
+
+extern "C" int ldmk_postprocess_frames(const float* x, float* out, int n, int c, int hw, void* stream) {
+  LDMK_REQUIRE(x && out && n > 0 && c > 0 && hw > 0, "ldmk_postprocess_frames: bad args");
+  long long total = (long long)n * c * hw;
+  hipLaunchKernelGGL(postprocess_frames_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out, n, c,
+                     hw, total);
+  return check_launch("ldmk_postprocess_frames");
+}
+
+extern "C" int ldmk_add_rowvec(float* x, const float* vec, int vec_ld, long long rows, int c, int rows_per_sample,
+                               void* stream) {
+  LDMK_REQUIRE(x && vec && rows > 0 && c > 0 && c % 4 == 0 && vec_ld % 4 == 0 && rows_per_sample > 0,
+               "ldmk_add_rowvec: bad args");
+  hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, vec, vec_ld,
+                     rows, c, rows_per_sample);
+  return check_launch("ldmk_add_rowvec");
+}

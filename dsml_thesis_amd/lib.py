@@ -1,0 +1,95 @@
+"""ctypes binding of libldmk.so (include/ldmk.h).  No CPU fallback: if the library is missing or a
+call fails, this raises -- the product path is the HIP path or nothing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libldmk.so")
+
+A_ROWS, A_CONV3X3 = 0, 1
+TF_NONE, TF_AFFINE, TF_AFFINE_SILU, TF_LAYERNORM = 0, 1, 2, 3
+EPI_NONE, EPI_GEGLU = 0, 1
+
+_fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+
+class IgemmArgs(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("a0", _fp), ("a1", _fp), ("c0", C.c_int), ("c1", C.c_int),
+        ("a_mode", C.c_int), ("in_h", C.c_int), ("in_w", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int),
+        ("stride", C.c_int), ("pad_lo", C.c_int), ("upsample", C.c_int),
+        ("a_tf", C.c_int), ("tf_coef", _fp), ("row_stats", _fp), ("ln_gamma", _fp), ("ln_beta", _fp),
+        ("rows_per_sample", C.c_int),
+        ("w", _fp), ("b_trans", C.c_int), ("ldb", C.c_int),
+        ("bias", _fp), ("batch_vec", _fp), ("batch_vec_ld", C.c_int),
+        ("residual", _fp), ("epi", C.c_int),
+        ("out", _fp), ("ldc", C.c_int), ("batch", C.c_int),
+        ("a_bstride", C.c_longlong), ("w_bstride", C.c_longlong), ("out_bstride", C.c_longlong),
+        ("alpha", C.c_float),
+    ]
+
+
+_SIGS = {
+    "ldmk_version": (C.c_int, []),
+    "ldmk_last_error": (C.c_char_p, []),
+    "ldmk_igemm": (C.c_int, [C.POINTER(IgemmArgs), _fp]),
+    "ldmk_igemm_force_config": (None, [C.c_int]),
+    "ldmk_gn_chunks": (C.c_int, [C.c_int]),
+    "ldmk_gn_coef": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _fp]),
+    "ldmk_ln_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp]),
+    "ldmk_attn_self": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    "ldmk_attn_cross": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_float, _fp]),
+    "ldmk_softmax_rows": (C.c_int, [_fp, C.c_longlong, C.c_int, C.c_float, _fp]),
+    "ldmk_dense_small": (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_timestep_embedding": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp]),
+    "ldmk_conv3x3_in": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_conv3x3_out": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_conv1x1_nchw": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_ddim_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_float, C.c_int, _fp, _fp, C.c_longlong, C.c_int, _fp, _fp,
+                                 C.c_int, C.c_int, _fp]),
+    "ldmk_ddpm_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_longlong, C.c_int, _fp]),
+    "ldmk_vq_nearest": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_permute3": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_postprocess_frames": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_add_rowvec": (C.c_int, [_fp, _fp, C.c_int, C.c_longlong, C.c_int, C.c_int, _fp]),
+}
+# every symbol include/ldmk.h declares (checked by tests/test_abi.py against the header text)
+EXPORTED = [k for k in _SIGS if k != "ldmk_igemm_force_config"]
+
+_lib = None
+
+
+class LdmkError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libldmk.so; raises LdmkError when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LdmkError(f"{LIB_PATH} is missing: run `python -m dsml_thesis_amd.build` (hipcc, gfx950). "
+                        "There is no CPU fallback for the sampling path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ldmk_last_error().decode(errors="replace")
+        raise LdmkError(f"{what or 'ldmk call'} failed (rc={rc}): {msg}")
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on a non-zero code."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        check(rc, name)

@@ -1,0 +1,279 @@
+"""Tensor-level wrappers over the C ABI (include/ldmk.h).  PyTorch is only the allocator and the
+stream provider here; every function enqueues HIP kernels from libldmk.so on torch's current
+stream and never synchronises.  Activations are NHWC float32 CUDA tensors."""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name):
+    if t is None:
+        return
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise L.LdmkError(f"{name}: expected a contiguous float32 CUDA tensor, got {t.dtype} {t.device} "
+                          f"contiguous={t.is_contiguous()}")
+
+
+# ------------------------------------------------------------------------------------------ packing
+def pack_conv3x3(w):
+    """torch OIHW (O,I,3,3) -> [9*I][O] (tap-major K, cout contiguous)."""
+    _chk(w, "pack_conv3x3")
+    o, i, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    out = torch.empty(9 * i, o, device=w.device, dtype=torch.float32)
+    L.call("ldmk_permute3", _ptr(w), _ptr(out), o, i, 9, 2, 1, 0, stream())
+    return out
+
+
+def pack_linear(w):
+    """torch [N][K] (or conv1x1 [N][K][1][1]) -> [K][N]."""
+    _chk(w, "pack_linear")
+    n, k = w.shape[0], w.shape[1]
+    out = torch.empty(k, n, device=w.device, dtype=torch.float32)
+    L.call("ldmk_permute3", _ptr(w), _ptr(out), n, k, 1, 1, 0, 2, stream())
+    return out
+
+
+def pack_geglu(w, b):
+    """GEGLU proj weight [2*inner][K] / bias [2*inner] -> packed [K][2*inner] / [2*inner] where every
+    64-column block is (32 value columns | their 32 gate columns), so that one wave holds both halves."""
+    two_inner, k = w.shape
+    inner = two_inner // 2
+    assert inner % 32 == 0
+    wt = pack_linear(w)                                   # [K][2*inner]
+    val = wt[:, :inner].reshape(k, inner // 32, 1, 32)
+    gate = wt[:, inner:].reshape(k, inner // 32, 1, 32)
+    wp = torch.cat([val, gate], dim=2).reshape(k, two_inner).contiguous()
+    bp = torch.cat([b[:inner].reshape(-1, 1, 32), b[inner:].reshape(-1, 1, 32)], dim=1).reshape(-1).contiguous()
+    return wp, bp
+
+
+# ------------------------------------------------------------------------------------------ norms
+def gn_coef(x0, x1, n, hw, gamma, beta, eps, groups=32, partial=None, coef=None):
+    c0 = x0.shape[-1]
+    c1 = 0 if x1 is None else x1.shape[-1]
+    C_ = c0 + c1
+    chunks = L.load().ldmk_gn_chunks(hw)
+    if partial is None:
+        partial = torch.empty(n * chunks * C_ * 3, device=x0.device, dtype=torch.float32)
+    if coef is None:
+        coef = torch.empty(n, 2, C_, device=x0.device, dtype=torch.float32)
+    L.call("ldmk_gn_coef", _ptr(x0), c0, _ptr(x1), c1, n, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
+           _ptr(partial), _ptr(coef), stream())
+    return coef
+
+
+def ln_stats(x2d, eps=1e-5, out=None):
+    rows, c = x2d.shape
+    if out is None:
+        out = torch.empty(rows, 2, device=x2d.device, dtype=torch.float32)
+    L.call("ldmk_ln_stats", _ptr(x2d), rows, c, float(eps), _ptr(out), stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------ igemm
+def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0, conv=None, tf=L.TF_NONE,
+                    tf_coef=None, row_stats=None, ln_gamma=None, ln_beta=None, b_trans=False, ldb=None, bias=None,
+                    batch_vec=None, batch_vec_ld=0, residual=None, epi=L.EPI_NONE, batch=1, a_bstride=0, w_bstride=0,
+                    out_bstride=0, alpha=1.0):
+    a = L.IgemmArgs()
+    a.M, a.N, a.K = M, N, K
+    a.a0, a.a1, a.c0, a.c1 = _ptr(a0), _ptr(a1), c0, c1
+    if conv is not None:
+        a.a_mode = L.A_CONV3X3
+        a.in_h, a.in_w, a.out_h, a.out_w, a.stride, a.pad_lo, a.upsample = conv
+    else:
+        a.a_mode = L.A_ROWS
+    a.a_tf = tf
+    a.tf_coef, a.row_stats, a.ln_gamma, a.ln_beta = _ptr(tf_coef), _ptr(row_stats), _ptr(ln_gamma), _ptr(ln_beta)
+    a.rows_per_sample = rows_per_sample
+    a.w, a.b_trans = _ptr(w), 1 if b_trans else 0
+    a.ldb = ldb if ldb is not None else (K if b_trans else N)
+    a.bias, a.batch_vec, a.batch_vec_ld = _ptr(bias), _ptr(batch_vec), batch_vec_ld
+    a.residual, a.epi = _ptr(residual), epi
+    a.out, a.ldc, a.batch = _ptr(out), ldc, batch
+    a.a_bstride, a.w_bstride, a.out_bstride = a_bstride, w_bstride, out_bstride
+    a.alpha = alpha
+    return a
+
+
+def igemm(args):
+    L.call("ldmk_igemm", C.byref(args), stream())
+
+
+def conv3x3(x, wp, bias=None, x1=None, stride=1, pad_lo=1, upsample=False, coef=None, silu=True, batch_vec=None,
+            residual=None, out=None, out_hw=None):
+    """x: (n,h,w,c0) [+ x1 (n,h,w,c1) channel-concat]; wp: [9*(c0+c1)][cout] -> (n,oh,ow,cout)."""
+    n, h, w_, c0 = x.shape
+    c1 = 0 if x1 is None else x1.shape[-1]
+    cout = wp.shape[1]
+    if out_hw is None:
+        if upsample:
+            oh, ow = 2 * h, 2 * w_
+        else:
+            oh = (h + 2 * pad_lo - 3) // stride + 1 if pad_lo == 1 else (h + 1 - 3) // stride + 1
+            ow = (w_ + 2 * pad_lo - 3) // stride + 1 if pad_lo == 1 else (w_ + 1 - 3) // stride + 1
+    else:
+        oh, ow = out_hw
+    if out is None:
+        out = torch.empty(n, oh, ow, cout, device=x.device, dtype=torch.float32)
+    tf = L.TF_NONE if coef is None else (L.TF_AFFINE_SILU if silu else L.TF_AFFINE)
+    a = make_igemm_args(n * oh * ow, cout, 9 * (c0 + c1), x, c0, wp, out, cout, oh * ow, a1=x1, c1=c1,
+                        conv=(h, w_, oh, ow, stride, pad_lo, 1 if upsample else 0), tf=tf, tf_coef=coef, bias=bias,
+                        batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0),
+                        residual=residual)
+    igemm(a)
+    return out
+
+
+def linear(x2d, wp, bias=None, x1=None, rows_per_sample=None, coef=None, silu=False, row_stats=None, ln_gamma=None,
+           ln_beta=None, batch_vec=None, residual=None, geglu=False, out=None, b_trans=False):
+    """x2d: [M][c0] (+ x1 [M][c1]); wp: [K][N] (or torch [N][K] with b_trans) -> [M][N] (N/2 for geglu)."""
+    M, c0 = x2d.shape
+    c1 = 0 if x1 is None else x1.shape[-1]
+    K = c0 + c1
+    N = wp.shape[0] if b_trans else wp.shape[1]
+    ncol = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty(M, ncol, device=x2d.device, dtype=torch.float32)
+    tf = L.TF_NONE
+    if coef is not None:
+        tf = L.TF_AFFINE_SILU if silu else L.TF_AFFINE
+    elif row_stats is not None:
+        tf = L.TF_LAYERNORM
+    a = make_igemm_args(M, N, K, x2d, c0, wp, out, ncol, rows_per_sample or M, a1=x1, c1=c1, tf=tf, tf_coef=coef,
+                        row_stats=row_stats, ln_gamma=ln_gamma, ln_beta=ln_beta, b_trans=b_trans, bias=bias,
+                        batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0),
+                        residual=residual, epi=L.EPI_GEGLU if geglu else L.EPI_NONE)
+    igemm(a)
+    return out
+
+
+def bmm(a, b, b_trans, alpha=1.0, out=None):
+    """Batched a[B][M][K] x (b[B][K][N] | b[B][N][K]^T) -> [B][M][N] on the matrix cores."""
+    B, M, K = a.shape
+    N = b.shape[1] if b_trans else b.shape[2]
+    if out is None:
+        out = torch.empty(B, M, N, device=a.device, dtype=torch.float32)
+    args = make_igemm_args(M, N, K, a, K, b, out, N, M, b_trans=b_trans, batch=B, a_bstride=M * K,
+                           w_bstride=b.shape[1] * b.shape[2], out_bstride=M * N, alpha=alpha)
+    igemm(args)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_self(qkv, n, tokens, heads, out=None):
+    C_ = heads * 32
+    if out is None:
+        out = torch.empty(n * tokens, C_, device=qkv.device, dtype=torch.float32)
+    L.call("ldmk_attn_self", _ptr(qkv), _ptr(out), n, tokens, heads, 32 ** -0.5, stream())
+    return out
+
+
+def attn_cross(q, k, v, n, tokens, ctx_len, heads, out=None):
+    C_ = heads * 32
+    if out is None:
+        out = torch.empty(n * tokens, C_, device=q.device, dtype=torch.float32)
+    L.call("ldmk_attn_cross", _ptr(q), q.stride(0), _ptr(k), _ptr(v), k.stride(0), _ptr(out), out.stride(0), n, tokens,
+           ctx_len, heads, 32 ** -0.5, stream())
+    return out
+
+
+def softmax_rows_(x2d, scale):
+    rows, cols = x2d.shape
+    L.call("ldmk_softmax_rows", _ptr(x2d), rows, cols, float(scale), stream())
+    return x2d
+
+
+# ------------------------------------------------------------------------------------------ small ops
+def dense_small(x, wp, bias=None, silu_in=False, out=None):
+    rows, K = x.shape
+    N = wp.shape[1]
+    if out is None:
+        out = torch.empty(rows, N, device=x.device, dtype=torch.float32)
+    L.call("ldmk_dense_small", _ptr(x), x.stride(0), _ptr(wp), _ptr(bias), _ptr(out), out.stride(0), rows, K, N,
+           1 if silu_in else 0, stream())
+    return out
+
+
+def timestep_freqs(dim, max_period=10000, device="cuda"):
+    """Frequency table of timestep_embedding (a per-model constant; the sinusoid formula of
+    "Attention Is All You Need" in the fp32 operation order the reference uses, util.py:161-163)."""
+    import numpy as np
+    half = dim // 2
+    # exponent in the reference's fp32 operation order; exp itself in float64 then rounded once, so the
+    # table is identical on every host (torch's CPU expf differs by 1 ulp between SIMD code paths)
+    e = (np.float32(-math.log(max_period)) * np.arange(half, dtype=np.float32)) / np.float32(half)
+    f = np.exp(e.astype(np.float64)).astype(np.float32)
+    return torch.from_numpy(f).to(device)
+
+
+def timestep_embedding(t, freqs, dim, out=None):
+    n = t.shape[0]
+    if out is None:
+        out = torch.empty(n, dim, device=t.device, dtype=torch.float32)
+    L.call("ldmk_timestep_embedding", _ptr(t), _ptr(freqs), _ptr(out), n, dim, stream())
+    return out
+
+
+def conv3x3_in(x0, wp, bias, cout, x1=None, out=None):
+    """NCHW narrow input(s) -> NHWC (n,h,w,cout).  wp: [9*cin][cout]."""
+    n, c0, h, w_ = x0.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+    if out is None:
+        out = torch.empty(n, h, w_, cout, device=x0.device, dtype=torch.float32)
+    L.call("ldmk_conv3x3_in", _ptr(x0), c0, _ptr(x1), c1, _ptr(wp), _ptr(bias), _ptr(out), n, h, w_, cout, stream())
+    return out
+
+
+def conv3x3_out(x, coef, wp, bias, cout, out=None):
+    """NHWC (n,h,w,cin) -> GN+SiLU -> conv -> NCHW (n,cout,h,w).  wp: [9*cin][cout]."""
+    n, h, w_, cin = x.shape
+    if out is None:
+        out = torch.empty(n, cout, h, w_, device=x.device, dtype=torch.float32)
+    L.call("ldmk_conv3x3_out", _ptr(x), _ptr(coef), _ptr(wp), _ptr(bias), _ptr(out), n, h, w_, cin, cout, stream())
+    return out
+
+
+def conv1x1_nchw(x, w, bias, out=None):
+    n, cin, h, w_ = x.shape
+    cout = w.shape[0]
+    if out is None:
+        out = torch.empty(n, cout, h, w_, device=x.device, dtype=torch.float32)
+    L.call("ldmk_conv1x1_nchw", _ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, h * w_, cin, cout, stream())
+    return out
+
+
+def vq_nearest(z, codebook, zq=None, idx=None):
+    n, dim, h, w_ = z.shape
+    if zq is None:
+        zq = torch.empty_like(z)
+    if idx is None:
+        idx = torch.empty(n * h * w_, device=z.device, dtype=torch.int32)
+    L.call("ldmk_vq_nearest", _ptr(z), _ptr(codebook), _ptr(zq), _ptr(idx), n, h * w_, dim, codebook.shape[0], stream())
+    return zq, idx
+
+
+def postprocess_frames(x, out=None):
+    n, c, h, w_ = x.shape
+    if out is None:
+        out = torch.empty(n, h, w_, c, device=x.device, dtype=torch.float32)
+    L.call("ldmk_postprocess_frames", _ptr(x), _ptr(out), n, c, h * w_, stream())
+    return out
+
+
+def add_rowvec_(x2d, vec, rows_per_sample):
+    rows, c = x2d.shape
+    L.call("ldmk_add_rowvec", _ptr(x2d), _ptr(vec), vec.stride(0), rows, c, rows_per_sample, stream())
+    return x2d

@@ -1,0 +1,178 @@
+/* ldmk.h -- C ABI of libldmk.so: MI355X (gfx950) kernels for the latent-diffusion sampling path.
+ *
+ * The reference (GiannisPikoulis/dsml-thesis) has no FFI: its extension point is the YAML
+ * `target:` factory (ldm/util.py:78-93) and everything below that is torch.nn ops.  This header
+ * is therefore the boundary the *build* defines: one entry point per PyTorch op call-site family
+ * on the hot path.  Each declaration cites the reference code it replaces
+ * (paths relative to /root/reference/face_reenactment).
+ *
+ * Conventions
+ *  - plain pointers + sizes only; all pointers are DEVICE pointers to fp32 unless stated
+ *  - activations are NHWC ("token-major": [n][y][x][c] == [n*H*W][C]); latents at the sampler
+ *    boundary stay NCHW like the reference's tensors
+ *  - every call only enqueues work on `stream` (a hipStream_t passed as void*): no allocation,
+ *    no synchronisation, no host callbacks -> legal inside hipStreamBeginCapture
+ *  - return 0 on success, negative LDMK_E* otherwise; never throws. ldmk_last_error() returns
+ *    a thread-local message for the last failure.
+ */
+#ifndef LDMK_H
+#define LDMK_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDMK_OK 0
+#define LDMK_EINVAL (-1) /* bad shape / alignment / unsupported combination */
+#define LDMK_EHIP (-2)   /* HIP launch error, see ldmk_last_error() */
+
+int ldmk_version(void);
+const char* ldmk_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit GEMM on the f32 matrix cores (v_mfma_f32_32x32x2_f32):
+ *     out[M][N] = epilogue( transform(A)[M][K] * W[K][N] )
+ * replaces every nn.Conv2d 3x3 / 1x1 and nn.Linear on [n*H*W] rows:
+ *   openaimodel.py:204,230 (ResBlock convs) :241 (skip 1x1) :150-153 (Downsample) :107,116-118
+ *   (Upsample: nearest x2 folded into the gather) ; attention.py:161-168,173-177 (to_q/k/v,to_out)
+ *   :37-64 (GEGLU FF) :232-236,244-248 (proj_in/out) ; model.py:95-129 (ResnetBlock convs,
+ *   nin_shortcut) :157-176 (AttnBlock q/k/v/proj) :72-76 (asymmetric-pad stride-2 conv).
+ * A-side prologues fuse GroupNorm(+SiLU) (util.py:214-216, openaimodel.py:201-203) and LayerNorm
+ * (attention.py:203-205) into the operand staging; epilogues fuse bias, the timestep-embedding
+ * add (openaimodel.py:264-273), residual adds (:275, attention.py:211-215,261) and GEGLU.
+ */
+enum { LDMK_A_ROWS = 0, LDMK_A_CONV3X3 = 1 };
+enum { LDMK_TF_NONE = 0, LDMK_TF_AFFINE = 1, LDMK_TF_AFFINE_SILU = 2, LDMK_TF_LAYERNORM = 3 };
+enum { LDMK_EPI_NONE = 0, LDMK_EPI_GEGLU = 1 };
+
+typedef struct ldmk_igemm_args {
+  int M, N, K;               /* K = taps*(c0+c1) for LDMK_A_CONV3X3 (taps = 9), else c0+c1        */
+  const float* a0;           /* first A source, NHWC rows of c0 channels                          */
+  const float* a1;           /* optional second source (channel concat, openaimodel.py:736), c1   */
+  int c0, c1;                /* both multiples of 32                                              */
+  int a_mode;                /* LDMK_A_ROWS | LDMK_A_CONV3X3                                      */
+  int in_h, in_w;            /* conv: stored input spatial size                                   */
+  int out_h, out_w;          /* conv: output spatial size (M = n*out_h*out_w)                     */
+  int stride, pad_lo;        /* conv: iy = oy*stride + dy - pad_lo                                */
+  int upsample;              /* conv: 1 -> input is nearest-x2 upsampled on the fly               */
+  int a_tf;                  /* LDMK_TF_*                                                         */
+  const float* tf_coef;      /* AFFINE: [n][2][c0+c1] (scale plane, shift plane) from ldmk_gn_*   */
+  const float* row_stats;    /* LAYERNORM: [M][2] (mean, rstd) from ldmk_ln_stats                 */
+  const float* ln_gamma;     /* LAYERNORM: [K]                                                    */
+  const float* ln_beta;      /* LAYERNORM: [K]                                                    */
+  int rows_per_sample;       /* rows of A/out per batch item (H*W of the output)                  */
+  const float* w;            /* b_trans=0: [K][ldb] row-major (packed) ; 1: [N][ldb] (torch [out][in]) */
+  int b_trans, ldb;
+  const float* bias;         /* [N] or NULL                                                       */
+  const float* batch_vec;    /* [n][batch_vec_ld] per-sample vector added to every row, or NULL   */
+  int batch_vec_ld;
+  const float* residual;     /* [M][ldc] or NULL (may alias out)                                  */
+  int epi;                   /* LDMK_EPI_*; GEGLU: packed (value,gate) 32-column pairs, out has N/2 cols */
+  float* out;                /* [M][ldc]                                                          */
+  int ldc;
+  int batch;                 /* >1: batched GEMM over blockIdx.z with the strides below           */
+  long long a_bstride, w_bstride, out_bstride;
+  float alpha;               /* scale applied to the product before the epilogue (1.0 default)    */
+} ldmk_igemm_args;
+
+int ldmk_igemm(const ldmk_igemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation statistics (HBM-bound, wave-shuffle reductions).
+ * ldmk_gn_coef: GroupNorm(groups, C) statistics over an NHWC tensor that may be the channel
+ *   concat of two tensors (groups may straddle the seam) -> per-(sample, channel)
+ *   scale/shift planes coef[n][2][C] with  y = x*scale + shift == GroupNorm(x)*gamma + beta.
+ *   util.py:214-216 (eps 1e-5), attention.py:76-77 & model.py:38-39 (eps 1e-6).
+ *   `partial` is a caller-provided scratch of n*chunks*C*3 floats, chunks = ldmk_gn_chunks(hw).
+ * ldmk_ln_stats: LayerNorm row statistics (mean, rstd), attention.py:203-205 (eps 1e-5).
+ */
+int ldmk_gn_chunks(int hw);
+int ldmk_gn_coef(const float* x0, int c0, const float* x1, int c1, int n, int hw, int groups, float eps,
+                 const float* gamma, const float* beta, float* partial, float* coef, void* stream);
+int ldmk_ln_stats(const float* x, int rows, int c, float eps, float* stats, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention.
+ * ldmk_attn_self: flash-style softmax(Q K^T * scale) V for d_head = 32 on the f32 matrix cores;
+ *   qkv is the fused projection [n*tokens][3*C] (q | k | v), out [n*tokens][C].
+ *   attention.py:178-192 (CrossAttention with context=None).
+ * ldmk_attn_cross: same math for a short context (L <= 128 keys), K/V given as [n*L][C] rows;
+ *   attention.py:170-193 with context != None.
+ * ldmk_softmax_rows: in-place row softmax of x*scale; model.py:191-192 (VQGAN AttnBlock).
+ */
+int ldmk_attn_self(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream);
+int ldmk_attn_cross(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo,
+                    int n, int tokens, int ctx_len, int heads, float scale, void* stream);
+int ldmk_softmax_rows(float* x, long long rows, int cols, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small dense layers on per-sample vectors (weight-bandwidth bound):
+ *   out[b][N] = (silu_in ? silu(x[b]) : x[b]) [K] * W[K][N] + bias
+ * time_embed MLP (openaimodel.py:506-511,723-724), all ResBlock emb_layers batched into one call
+ * (:218-224,264), cross-attention to_k/to_v/to_out on a 1-token context (attention.py:175-176).
+ */
+int ldmk_dense_small(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                     int rows, int K, int N, int silu_in, void* stream);
+/* timestep_embedding, util.py:151-171: t int64 [n] -> emb [n][dim] = [cos(t*f) | sin(t*f)];
+ * freqs[dim/2] = exp(-ln(max_period) * i / (dim/2)) is a per-model constant computed once on the host */
+int ldmk_timestep_embedding(const long long* t, const float* freqs, float* emb, int n, int dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Narrow-channel convolutions at the NCHW latent boundary.
+ * ldmk_conv3x3_in : 3x3 pad 1 on an NCHW input that is the channel concat of up to two tensors
+ *   (x and TF's 'motion_&_id' c_concat, ddpm2cond.py:1309) with <= 16 channels in total ->
+ *   NHWC output.  openaimodel.py:519 (input_blocks.0), model.py:497-501 (Decoder.conv_in),
+ *   model.py:382-386 (Encoder.conv_in).  w: [9][cin][cout].
+ * ldmk_conv3x3_out: GroupNorm+SiLU prologue (coef planes) then 3x3 pad 1 to <= 4 channels,
+ *   NHWC input -> NCHW output. openaimodel.py:683-685 (out), model.py:527-531,563-565 (conv_out).
+ *   w: [9][cin][cout].
+ */
+int ldmk_conv3x3_in(const float* x0, int c0, const float* x1, int c1, const float* w, const float* bias,
+                    float* out, int n, int h, int w_, int cout, void* stream);
+int ldmk_conv3x3_out(const float* x, const float* coef, const float* w, const float* bias, float* out,
+                     int n, int h, int w_, int cin, int cout, void* stream);
+/* 1x1 conv between narrow NCHW tensors (quant_conv / post_quant_conv, autoencoder.py:44-45) */
+int ldmk_conv1x1_nchw(const float* x, const float* w, const float* bias, float* out, int n, int hw, int cin,
+                      int cout, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampler updates.  Coefficient tables live in device memory and are indexed by a device-side
+ * step counter so that one captured hipGraph replays for every step.
+ * ldmk_ddim_step: ddim.py:170-203 -- optional CFG combine (eps has 2n items: [uncond | cond]),
+ *   pred_x0, dir_xt, x_prev.  table: [S][4] = (a_t, a_prev, sigma_t, sqrt_one_minus_at) float32;
+ *   step_idx: device int32 holding the CURRENT index (S-1 .. 0); it is decremented by the kernel
+ *   when advance != 0, and ts (int64 [n_ts], the UNet's timestep input) is rewritten with
+ *   timesteps[new index].  noise may be NULL (eta == 0).
+ * ldmk_ddpm_step: ddpm.py:215-228,1049-1109 -- ancestral update with per-sample t (int64).
+ *   tables: [T][4] = (sqrt_recip_ac, sqrt_recipm1_ac, post_mean_coef1, post_mean_coef2) and
+ *   logvar[T] (posterior_log_variance_clipped).
+ */
+int ldmk_ddim_step(const float* x, const float* eps, const float* noise, const float* table, int* step_idx,
+                   float cfg_scale, int cfg, float* x_prev, float* pred_x0, long long per_sample, int n,
+                   const long long* timesteps, long long* ts, int n_ts, int advance, void* stream);
+int ldmk_ddpm_step(const float* x, const float* eps, const float* noise, const float* tables, const float* logvar,
+                   const long long* t, float* x_prev, long long per_sample, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VQ nearest-codebook lookup, taming/modules/vqvae/quantize.py:276-285:
+ *   idx = argmin_j ( |z|^2 + |e_j|^2 - 2 z.e_j ), z_q = e[idx]; z, z_q NCHW [n][dim][hw].
+ */
+int ldmk_vq_nearest(const float* z, const float* codebook, float* zq, int* idx, int n, int hw, int dim, int n_embed,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout helpers: weight repacking (once, after load_state_dict) and boundary transposes.
+ * ldmk_permute3: dst[i2? ...] generic 3-D permutation of a contiguous [d0][d1][d2] tensor;
+ *   perm gives, for each destination axis, the source axis (e.g. conv OIHW viewed as [O][I][9]
+ *   -> [9][I][O] is perm = {2,1,0}).
+ * ldmk_postprocess_frames: sample_affectnet.py:127,132: clamp((x+1)/2,0,1), NCHW -> NHWC.
+ */
+int ldmk_permute3(const float* src, float* dst, int d0, int d1, int d2, int p0, int p1, int p2, void* stream);
+int ldmk_postprocess_frames(const float* x, float* out, int n, int c, int hw, void* stream);
+/* out[m][c] += vec[m / rows_per_sample][c]  (cross-attention with a 1-token context collapses to
+ * a per-sample vector; attention.py:170-193 with L_ctx == 1) */
+int ldmk_add_rowvec(float* x, const float* vec, int vec_ld, long long rows, int c, int rows_per_sample, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDMK_H */
