@@ -32,14 +32,15 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
   const int h = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const float* base = qkv + (long long)b * tokens * ld;
-  const bool wave_active = q0 < tokens;     // tokens is a multiple of 32 (checked on the host)
+  const bool wave_active = q0 < tokens;
+  const bool q_valid = q0 + l31 < tokens;   // ragged tail: lanes past the last query compute but never store
 
   // Q fragment: B operand of S^T = K Q^T: lane holds Q[query = l31][d = 2s + half], pre-scaled
   float qf[16];
   {
-    const float* qp = base + (long long)(wave_active ? q0 + l31 : 0) * ld + h * AT_D;
+    const float* qp = base + (long long)(q_valid ? q0 + l31 : 0) * ld + h * AT_D;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) qf[s] = wave_active ? qp[2 * s + half] * scale : 0.f;
+    for (int s = 0; s < 16; ++s) qf[s] = q_valid ? qp[2 * s + half] * scale : 0.f;
   }
   f32x16 o;
 #pragma unroll
@@ -84,6 +85,11 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
       for (int s = 0; s < 16; ++s)
         s_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kbase[2 * s], qf[s], s_acc, 0, 0, 0);
       // s_acc[r] = S[query l31][key = key0 + (r&3) + 8*(r>>2) + 4*half]
+      if (key0 + 32 > tokens) {   // ragged last sub-tile: keys past the end get -inf (their V rows are zero)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s_acc[r] = -INFINITY;
+      }
       float mx = s_acc[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_acc[r]);
@@ -123,7 +129,8 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
   __builtin_amdgcn_wave_barrier();
   float* op = out + ((long long)b * tokens + q0) * C + h * AT_D;
 #pragma unroll
-  for (int q = 0; q < 32; q += 2) op[(long long)(q + half) * C + l31] = ow[(q + half) * 33 + l31];
+  for (int q = 0; q < 32; q += 2)
+    if (q0 + q + half < tokens) op[(long long)(q + half) * C + l31] = ow[(q + half) * 33 + l31];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
 extern "C" int ldmk_attn_self(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream) {
   using namespace ldmk;
   LDMK_REQUIRE(qkv && out && n > 0 && heads > 0, "ldmk_attn_self: bad args");
-  LDMK_REQUIRE(tokens > 0 && tokens % 32 == 0, "ldmk_attn_self: tokens=%d must be a multiple of 32", tokens);
+  LDMK_REQUIRE(tokens > 0, "ldmk_attn_self: tokens=%d must be positive", tokens);
   LDMK_REQUIRE(heads <= 65535 && n <= 65535, "ldmk_attn_self: grid limits");
   dim3 grid((tokens + 127) / 128, heads, n);
   hipLaunchKernelGGL(attn_self_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, tokens, heads, scale);

@@ -323,17 +323,21 @@ static int launch_cfg(const ldmk_igemm_args& a, hipStream_t st) {
   return check_launch("ldmk_igemm");
 }
 
-template <bool BT>
-static int dispatch(const ldmk_igemm_args& a, hipStream_t st, int force) {
+static int pick_config(const ldmk_igemm_args& a) {
   const long long b = a.batch > 1 ? a.batch : 1;
   auto nb = [&](int bm, int bn) { return b * ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   int cfg;
-  if (force >= 0) cfg = force;
-  else if (nb(128, 128) >= 384) cfg = 0;
+  if (nb(128, 128) >= 384) cfg = 0;
   else if (a.epi == LDMK_EPI_GEGLU) cfg = nb(64, 128) >= 256 ? 1 : 2;
   else if (nb(64, 64) >= 384 || a.K < 512) cfg = 3;
   else cfg = 2;
-  if (a.epi == LDMK_EPI_GEGLU && cfg == 3) cfg = 2;
+  return cfg;
+}
+
+template <bool BT>
+static int dispatch(const ldmk_igemm_args& a, hipStream_t st, int force) {
+  int cfg = force >= 0 ? force : (a.tile_cfg > 0 ? a.tile_cfg - 1 : pick_config(a));
+  if (a.epi == LDMK_EPI_GEGLU && cfg == 3) cfg = 2;   // GEGLU needs an even number of N tiles per wave
   switch (cfg) {
     case 0: return launch_cfg<2, 2, 2, 2, 1, BT>(a, st);   // 128x128
     case 1: return launch_cfg<1, 2, 2, 2, 1, BT>(a, st);   // 64x128
@@ -347,6 +351,11 @@ static int dispatch(const ldmk_igemm_args& a, hipStream_t st, int force) {
 // test hook: force a tile configuration (-1 = heuristic)
 static int g_force_cfg = -1;
 extern "C" void ldmk_igemm_force_config(int cfg) { g_force_cfg = cfg; }
+
+extern "C" int ldmk_igemm_pick_config(const ldmk_igemm_args* args) {
+  if (!args) return LDMK_EINVAL;
+  return ldmk::pick_config(*args) + 1;
+}
 
 extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) {
   using namespace ldmk;
@@ -369,6 +378,7 @@ extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) {
     LDMK_REQUIRE(a.row_stats && a.ln_gamma && a.ln_beta && a.a_mode == LDMK_A_ROWS, "ldmk_igemm: layernorm prologue args");
   }
   if (a.epi == LDMK_EPI_GEGLU) LDMK_REQUIRE(a.N % 64 == 0 && !a.residual && !a.batch_vec, "ldmk_igemm: GEGLU needs N%%64==0 and no residual");
+  LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= 4, "ldmk_igemm: tile_cfg=%d outside [0,4]", a.tile_cfg);
   if (a.alpha == 0.f) a.alpha = 1.f;
   hipStream_t st = (hipStream_t)stream;
   return a.b_trans ? dispatch<true>(a, st, g_force_cfg) : dispatch<false>(a, st, g_force_cfg);

@@ -26,7 +26,7 @@ class IgemmArgs(C.Structure):
         ("residual", _fp), ("epi", C.c_int),
         ("out", _fp), ("ldc", C.c_int), ("batch", C.c_int),
         ("a_bstride", C.c_longlong), ("w_bstride", C.c_longlong), ("out_bstride", C.c_longlong),
-        ("alpha", C.c_float),
+        ("alpha", C.c_float), ("tile_cfg", C.c_int),
     ]
 
 
@@ -34,6 +34,7 @@ _SIGS = {
     "ldmk_version": (C.c_int, []),
     "ldmk_last_error": (C.c_char_p, []),
     "ldmk_igemm": (C.c_int, [C.POINTER(IgemmArgs), _fp]),
+    "ldmk_igemm_pick_config": (C.c_int, [C.POINTER(IgemmArgs)]),
     "ldmk_igemm_force_config": (None, [C.c_int]),
     "ldmk_gn_chunks": (C.c_int, [C.c_int]),
     "ldmk_gn_coef": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _fp]),

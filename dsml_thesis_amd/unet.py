@@ -1,0 +1,529 @@
+"""MI355X-native UNetModel: drop-in for the YAML `target:` of the reference
+(`ldm.modules.diffusionmodules.openaimodel.UNetModel`, openaimodel.py:413-742).
+
+Same constructor kwargs, same parameter tree / state-dict keys, same forward signature
+(`forward(x, timesteps, context)`, NCHW fp32 at the boundary).  Underneath, a forward is a
+`engine.Program`: a flat list of libldmk.so kernel launches over a static NHWC workspace --
+GroupNorm/LayerNorm folded into the consumer GEMM's operand staging, skip-concats as two base
+pointers, nearest-upsample folded into the conv gather, the time-embedding and 1-token
+cross-attention adds folded into GEMM epilogues.  There is no PyTorch fallback path.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from . import ops
+from .engine import Program
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter holders: they only own tensors under the reference's names
+class _Params(nn.Module):
+    def __init__(self, **shapes):
+        super().__init__()
+        for name, shape in shapes.items():
+            self.register_parameter(name, nn.Parameter(torch.empty(*shape), requires_grad=False))
+
+
+class _Slots(nn.Module):
+    """Container whose children are registered under explicit (possibly sparse) integer names, e.g.
+    in_layers.0 / in_layers.2 like the nn.Sequential the reference indexes."""
+
+    def __init__(self, **children):
+        super().__init__()
+        for k, m in children.items():
+            self.add_module(k.lstrip("_"), m)
+
+
+def _conv_params(cin, cout, k):
+    return _Params(weight=(cout, cin, k, k), bias=(cout,))
+
+
+def _lin_params(cin, cout, bias=True):
+    return _Params(weight=(cout, cin), bias=(cout,)) if bias else _Params(weight=(cout, cin))
+
+
+def _norm_params(c):
+    return _Params(weight=(c,), bias=(c,))
+
+
+def _res_block(cin, cout, emb_ch):
+    ch = dict(in_layers=_Slots(_0=_norm_params(cin), _2=_conv_params(cin, cout, 3)),
+              emb_layers=_Slots(_1=_lin_params(emb_ch, cout)),
+              out_layers=_Slots(_0=_norm_params(cout), _3=_conv_params(cout, cout, 3)))
+    if cin != cout:
+        ch["skip_connection"] = _conv_params(cin, cout, 1)
+    m = _Slots(**ch)
+    m.kind, m.cin, m.cout = "res", cin, cout
+    return m
+
+
+def _attn(dim, ctx_dim):
+    return _Slots(to_q=_lin_params(dim, dim, False), to_k=_lin_params(ctx_dim, dim, False),
+                  to_v=_lin_params(ctx_dim, dim, False), to_out=_Slots(_0=_lin_params(dim, dim)))
+
+
+def _spatial_transformer(ch, heads, d_head, depth, context_dim):
+    inner = heads * d_head
+    blocks = nn.ModuleList()
+    for _ in range(depth):
+        blocks.append(_Slots(
+            attn1=_attn(inner, inner),
+            ff=_Slots(net=_Slots(_0=_Slots(proj=_lin_params(inner, inner * 8)), _2=_lin_params(inner * 4, inner))),
+            attn2=_attn(inner, context_dim if context_dim is not None else inner),
+            norm1=_norm_params(inner), norm2=_norm_params(inner), norm3=_norm_params(inner)))
+    m = _Slots(norm=_norm_params(ch), proj_in=_conv_params(ch, inner, 1), transformer_blocks=blocks,
+               proj_out=_conv_params(inner, ch, 1))
+    m.kind, m.ch, m.heads, m.d_head, m.depth = "st", ch, heads, d_head, depth
+    return m
+
+
+def _seq(*mods):
+    s = nn.Module()
+    for i, m in enumerate(mods):
+        s.add_module(str(i), m)
+    s.layers = list(mods)
+    return s
+
+
+class UNetModel(nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks,
+                 attention_resolutions, dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2,
+                 num_classes=None, use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1,
+                 num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
+                 use_new_attention_order=False, use_spatial_transformer=False, transformer_depth=1,
+                 context_dim=None, n_embed=None, legacy=True):
+        super().__init__()
+        # combinations the reference accepts but this path does not implement fail loudly
+        if dims != 2:
+            raise NotImplementedError("UNetModel: only dims=2")
+        if resblock_updown or use_scale_shift_norm or num_classes is not None or n_embed is not None:
+            raise NotImplementedError("UNetModel: resblock_updown / use_scale_shift_norm / num_classes / n_embed "
+                                      "are not part of the sampling path built here")
+        if not use_spatial_transformer:
+            raise NotImplementedError("UNetModel: only the SpatialTransformer attention variant (all shipped configs)")
+        if not conv_resample:
+            raise NotImplementedError("UNetModel: conv_resample=False")
+        if use_fp16:
+            raise NotImplementedError("UNetModel: fp32 only (reference precision)")
+        if dropout != 0 and self.training:
+            pass  # inference path: dropout is the identity
+        assert context_dim is not None, "use_spatial_transformer needs context_dim (openaimodel.py:471-472)"
+        if isinstance(context_dim, (list, tuple)) or type(context_dim).__name__ == "ListConfig":
+            context_dim = list(context_dim)
+            assert len(context_dim) == 1, "a single context dim is supported"
+            context_dim = context_dim[0]
+        if num_heads == -1:
+            assert num_head_channels != -1, "Either num_heads or num_head_channels has to be set"
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        attention_resolutions = list(attention_resolutions)
+        channel_mult = list(channel_mult)
+        self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
+        self.out_channels, self.num_res_blocks = out_channels, num_res_blocks
+        self.attention_resolutions, self.channel_mult = attention_resolutions, channel_mult
+        self.dropout, self.conv_resample, self.num_classes = dropout, conv_resample, num_classes
+        self.use_checkpoint, self.dtype = use_checkpoint, torch.float32
+        self.num_heads, self.num_head_channels, self.num_heads_upsample = num_heads, num_head_channels, num_heads_upsample
+        self.context_dim, self.transformer_depth = context_dim, transformer_depth
+        mc = model_channels
+        emb_ch = 4 * mc
+        self.time_embed = _Slots(_0=_lin_params(mc, emb_ch), _2=_lin_params(emb_ch, emb_ch))
+
+        def heads_for(ch):
+            if num_head_channels == -1:
+                n = num_heads
+            else:
+                n = ch // num_head_channels
+            d = ch // n if legacy else (num_head_channels if num_head_channels != -1 else ch // n)
+            if d != 32:
+                raise NotImplementedError(f"UNetModel: attention head dim {d}; the flash kernel is built for 32")
+            return n, d
+
+        def st(ch):
+            n, d = heads_for(ch)
+            return _spatial_transformer(ch, n, d, transformer_depth, context_dim)
+
+        # ---- same walk as openaimodel.py:513-681
+        first = _conv_params(in_channels, mc, 3)
+        first.kind = "conv_in"
+        self.input_blocks = nn.ModuleList([_seq(first)])
+        chans = [mc]
+        ch, ds = mc, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [_res_block(ch, mult * mc, emb_ch)]
+                ch = mult * mc
+                if ds in attention_resolutions:
+                    layers.append(st(ch))
+                self.input_blocks.append(_seq(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                down = _Slots(op=_conv_params(ch, ch, 3))
+                down.kind, down.ch = "down", ch
+                self.input_blocks.append(_seq(down))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = _seq(_res_block(ch, ch, emb_ch), st(ch), _res_block(ch, ch, emb_ch))
+        self.output_blocks = nn.ModuleList()
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [_res_block(ch + ich, mc * mult, emb_ch)]
+                ch = mc * mult
+                if ds in attention_resolutions:
+                    layers.append(st(ch))
+                if level and i == num_res_blocks:
+                    up = _Slots(conv=_conv_params(ch, ch, 3))
+                    up.kind, up.ch = "up", ch
+                    layers.append(up)
+                    ds //= 2
+                self.output_blocks.append(_seq(*layers))
+        self.out = _Slots(_0=_norm_params(ch), _2=_conv_params(mc, out_channels, 3))
+        self._final_ch = ch
+        self.reset_parameters()
+        self._packed = None
+        self._pack_sig = None
+        self._programs = {}
+        self._ctx_sig = None
+        self.auto_repack = True
+        # tile shapes are chosen from the problem size; set policy_batch = G to choose them as if the batch
+        # were G, which makes per-sample results bitwise identical however a G-sample job is sharded
+        self.policy_batch = None
+
+    # ---- initialisation: PyTorch layer defaults + the reference's zero_module sites ----------------
+    @torch.no_grad()
+    def reset_parameters(self):
+        zero = set()
+        for name, _ in self.named_parameters():
+            if ".out_layers.3." in name or ".proj_out." in name or name.startswith("out.2."):
+                zero.add(name)      # openaimodel.py:229-231,685 ; attention.py:244-248
+        for name, p in self.named_parameters():
+            if name in zero:
+                p.zero_()
+            elif p.dim() >= 2:
+                fan_in = p[0].numel()
+                p.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+            elif name.endswith(".bias"):
+                owner = dict(self.named_parameters()).get(name[:-4] + "weight")
+                if owner is not None and owner.dim() >= 2:
+                    fan_in = owner[0].numel()
+                    p.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+                else:
+                    p.zero_()       # norm bias
+            else:
+                p.fill_(1.0)        # norm weight
+
+    # ---- weight packing (after load_state_dict / EMA swap): torch layouts -> kernel layouts ---------
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    @torch.no_grad()
+    def pack_weights(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise L.LdmkError("UNetModel: parameters must live on a GPU (model.cuda()); there is no CPU path")
+        P = {}
+        sd = {k: v.detach().float().contiguous() for k, v in self.named_parameters()}
+
+        def res(prefix, m):
+            P[prefix + "c1"] = ops.pack_conv3x3(sd[prefix + "in_layers.2.weight"])
+            P[prefix + "c2"] = ops.pack_conv3x3(sd[prefix + "out_layers.3.weight"])
+            if m.cin != m.cout:
+                P[prefix + "skip"] = ops.pack_linear(sd[prefix + "skip_connection.weight"])
+
+        def stp(prefix, m):
+            P[prefix + "pin"] = ops.pack_linear(sd[prefix + "proj_in.weight"])
+            P[prefix + "pout"] = ops.pack_linear(sd[prefix + "proj_out.weight"])
+            for d in range(m.depth):
+                q = f"{prefix}transformer_blocks.{d}."
+                wqkv = torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0)
+                P[q + "qkv"] = ops.pack_linear(wqkv.contiguous())
+                P[q + "o1"] = ops.pack_linear(sd[q + "attn1.to_out.0.weight"])
+                P[q + "q2"] = ops.pack_linear(sd[q + "attn2.to_q.weight"])
+                P[q + "k2"] = ops.pack_linear(sd[q + "attn2.to_k.weight"])
+                P[q + "v2"] = ops.pack_linear(sd[q + "attn2.to_v.weight"])
+                P[q + "o2"] = ops.pack_linear(sd[q + "attn2.to_out.0.weight"])
+                P[q + "ff1"], P[q + "ff1b"] = ops.pack_geglu(sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"])
+                P[q + "ff2"] = ops.pack_linear(sd[q + "ff.net.2.weight"])
+
+        emb_w, emb_b = [], []
+        self._emb_off = {}
+        off = 0
+        for prefix, m in self._walk():
+            if m.kind == "res":
+                res(prefix, m)
+                emb_w.append(sd[prefix + "emb_layers.1.weight"])
+                emb_b.append(sd[prefix + "emb_layers.1.bias"])
+                self._emb_off[prefix] = off
+                off += m.cout
+            elif m.kind == "st":
+                stp(prefix, m)
+            elif m.kind == "conv_in":
+                P[prefix + "w"] = ops.pack_conv3x3(sd[prefix + "weight"])
+            elif m.kind == "down":
+                P[prefix + "w"] = ops.pack_conv3x3(sd[prefix + "op.weight"])
+            elif m.kind == "up":
+                P[prefix + "w"] = ops.pack_conv3x3(sd[prefix + "conv.weight"])
+        # every ResBlock's emb_layers Linear batched into one [4mc][sum cout] matrix
+        P["emb_all"] = ops.pack_linear(torch.cat(emb_w, 0).contiguous())
+        P["emb_all_b"] = torch.cat(emb_b, 0).contiguous()
+        self._emb_total = off
+        P["te0"] = ops.pack_linear(sd["time_embed.0.weight"])
+        P["te2"] = ops.pack_linear(sd["time_embed.2.weight"])
+        P["out"] = ops.pack_conv3x3(sd["out.2.weight"])
+        P["freqs"] = ops.timestep_freqs(self.model_channels, device=dev)
+        self._sd = sd
+        self._packed = P
+        self._pack_sig = self._signature()
+        self._programs = {}
+        self._ctx_sig = None
+
+    def _walk(self):
+        for i, blk in enumerate(self.input_blocks):
+            for j, m in enumerate(blk.layers):
+                yield f"input_blocks.{i}.{j}.", m
+        for j, m in enumerate(self.middle_block.layers):
+            yield f"middle_block.{j}.", m
+        for i, blk in enumerate(self.output_blocks):
+            for j, m in enumerate(blk.layers):
+                yield f"output_blocks.{i}.{j}.", m
+
+    # ---- program construction ---------------------------------------------------------------------
+    def _build(self, n, H, W_, L_ctx, c_concat, policy_n):
+        P, sd = self._packed, self._sd
+        dev = next(self.parameters()).device
+        pg = Program(dev)
+        mc = self.model_channels
+        emb_ch = 4 * mc
+        cx = self.in_channels - c_concat
+        x_in = pg.alloc(n, cx, H, W_)
+        cc_in = pg.alloc(n, c_concat, H, W_) if c_concat else None
+        t_in = pg.alloc(n, dtype=torch.int64)
+        ctx_in = pg.alloc(n * L_ctx, self.context_dim)
+        pg.inputs = dict(x=x_in, c_concat=cc_in, t=t_in, context=ctx_in)
+        ctx_pg = Program(dev)     # context-only work: re-run only when the context changes
+        ctx_pg._all = pg._all     # share accounting
+        p_ = lambda t: 0 if t is None else t.data_ptr()
+        pin = (policy_n, n)
+
+        # -- time embedding MLP + all emb_layers (one launch each)
+        temb = pg.alloc(n, mc)
+        pg.add("ldmk_timestep_embedding", p_(t_in), p_(P["freqs"]), p_(temb), n, mc)
+        e1 = pg.alloc(n, emb_ch)
+        pg.add("ldmk_dense_small", p_(temb), mc, p_(P["te0"]), p_(sd["time_embed.0.bias"]), p_(e1), emb_ch, n, mc, emb_ch, 0)
+        emb = pg.alloc(n, emb_ch)
+        pg.add("ldmk_dense_small", p_(e1), emb_ch, p_(P["te2"]), p_(sd["time_embed.2.bias"]), p_(emb), emb_ch, n, emb_ch, emb_ch, 1)
+        emb_all = pg.alloc(n, self._emb_total)
+        pg.add("ldmk_dense_small", p_(emb), emb_ch, p_(P["emb_all"]), p_(P["emb_all_b"]), p_(emb_all), self._emb_total, n,
+               emb_ch, self._emb_total, 1)
+
+        max_c = 0
+        for _, m in self._walk():
+            if m.kind == "res":
+                max_c = max(max_c, m.cin, m.cout)
+        chunks = pg.lib.ldmk_gn_chunks(H * W_)
+        gn_partial = pg.alloc(n * chunks * max_c * 3)
+
+        def gn(x0, x1, hw, gamma, beta, eps):
+            c = x0.shape[-1] + (0 if x1 is None else x1.shape[-1])
+            coef = pg.alloc(n, 2, c)
+            pg.add("ldmk_gn_coef", p_(x0), x0.shape[-1], p_(x1), 0 if x1 is None else x1.shape[-1], n, hw, 32, eps,
+                   p_(gamma), p_(beta), p_(gn_partial), p_(coef))
+            return coef
+
+        def conv(x0, x1, wp, bias, h, w, coef=None, stride=1, upsample=False, batch_vec=None, bv_ld=0, residual=None,
+                 out=None):
+            c0 = x0.shape[-1]
+            c1 = 0 if x1 is None else x1.shape[-1]
+            cout = wp.shape[1]
+            oh, ow = (2 * h, 2 * w) if upsample else ((h - 1) // stride + 1, (w - 1) // stride + 1)
+            if out is None:
+                out = pg.alloc(n, oh, ow, cout)
+            a = ops.make_igemm_args(n * oh * ow, cout, 9 * (c0 + c1), x0, c0, wp, out, cout, oh * ow, a1=x1, c1=c1,
+                                    conv=(h, w, oh, ow, stride, 1, 1 if upsample else 0),
+                                    tf=L.TF_NONE if coef is None else L.TF_AFFINE_SILU, tf_coef=coef, bias=bias,
+                                    residual=residual)
+            if batch_vec is not None:
+                a.batch_vec, a.batch_vec_ld = batch_vec, bv_ld
+            pg.igemm(a, pin)
+            return out
+
+        def lin(x0, wp, bias, rows_per_sample, x1=None, out=None, **kw):
+            M = x0.shape[0]
+            c0 = x0.shape[-1]
+            c1 = 0 if x1 is None else x1.shape[-1]
+            N = wp.shape[1]
+            geglu = kw.pop("geglu", False)
+            ncol = N // 2 if geglu else N
+            if out is None:
+                out = pg.alloc(M, ncol)
+            a = ops.make_igemm_args(M, N, c0 + c1, x0, c0, wp, out, ncol, rows_per_sample, a1=x1, c1=c1, bias=bias,
+                                    epi=L.EPI_GEGLU if geglu else L.EPI_NONE, **kw)
+            pg.igemm(a, pin)
+            return out
+
+        def res_block(prefix, m, x0, x1, h, w):
+            hw = h * w
+            coef1 = gn(x0, x1, hw, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5)
+            bv = emb_all.data_ptr() + 4 * self._emb_off[prefix]
+            h1 = conv(x0, x1, P[prefix + "c1"], sd[prefix + "in_layers.2.bias"], h, w, coef=coef1, batch_vec=bv,
+                      bv_ld=self._emb_total)
+            pg.release(coef1)
+            coef2 = gn(h1, None, hw, sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"], 1e-5)
+            if m.cin != m.cout:
+                x0r = x0.reshape(n * hw, -1)
+                x1r = None if x1 is None else x1.reshape(n * hw, -1)
+                skip = lin(x0r, P[prefix + "skip"], sd[prefix + "skip_connection.bias"], hw, x1=x1r)
+                out = conv(h1, None, P[prefix + "c2"], sd[prefix + "out_layers.3.bias"], h, w, coef=coef2,
+                           residual=skip, out=skip.view(n, h, w, m.cout))
+            else:
+                assert x1 is None
+                out = conv(h1, None, P[prefix + "c2"], sd[prefix + "out_layers.3.bias"], h, w, coef=coef2, residual=x0)
+            pg.release(coef2, h1)
+            return out
+
+        def spatial_tf(prefix, m, x, h, w):
+            hw = h * w
+            C_ = m.heads * m.d_head
+            rows = n * hw
+            xr = x.reshape(rows, m.ch)
+            coef = gn(x, None, hw, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-6)
+            hcur = lin(xr, P[prefix + "pin"], sd[prefix + "proj_in.bias"], hw, tf=L.TF_AFFINE, tf_coef=coef)
+            pg.release(coef)
+            stats = pg.alloc(rows, 2)
+            for d in range(m.depth):
+                q = f"{prefix}transformer_blocks.{d}."
+                # --- attn1 (self): LN1 folded into the fused QKV GEMM, flash attention, to_out + residual
+                pg.add("ldmk_ln_stats", p_(hcur), rows, C_, 1e-5, p_(stats))
+                qkv = lin(hcur, P[q + "qkv"], None, hw, tf=L.TF_LAYERNORM, row_stats=stats,
+                          ln_gamma=sd[q + "norm1.weight"], ln_beta=sd[q + "norm1.bias"])
+                att = pg.alloc(rows, C_)
+                pg.add("ldmk_attn_self", p_(qkv), p_(att), n, hw, m.heads, m.d_head ** -0.5)
+                pg.release(qkv)
+                if L_ctx == 1:
+                    # --- attn2 with a single context token: softmax over one key == 1, so the block adds
+                    # to_out(to_v(ctx)) to every position (exact); to_q/norm2 are dead.
+                    v = ctx_pg.alloc(n, C_)
+                    ctx_pg.add("ldmk_dense_small", p_(ctx_in), self.context_dim, p_(P[q + "v2"]), 0, p_(v), C_, n,
+                               self.context_dim, C_, 0)
+                    cvec = ctx_pg.alloc(n, C_)
+                    ctx_pg.add("ldmk_dense_small", p_(v), C_, p_(P[q + "o2"]), p_(sd[q + "attn2.to_out.0.bias"]), p_(cvec),
+                               C_, n, C_, C_, 0)
+                    h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur)
+                    pg.add("ldmk_add_rowvec", p_(h1), p_(cvec), C_, rows, C_, hw)
+                    pg.release(att)
+                    h2 = h1
+                else:
+                    h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur)
+                    kk = ctx_pg.alloc(n * L_ctx, C_)
+                    vv = ctx_pg.alloc(n * L_ctx, C_)
+                    ctx_pg.add("ldmk_dense_small", p_(ctx_in), self.context_dim, p_(P[q + "k2"]), 0, p_(kk), C_,
+                               n * L_ctx, self.context_dim, C_, 0)
+                    ctx_pg.add("ldmk_dense_small", p_(ctx_in), self.context_dim, p_(P[q + "v2"]), 0, p_(vv), C_,
+                               n * L_ctx, self.context_dim, C_, 0)
+                    pg.add("ldmk_ln_stats", p_(h1), rows, C_, 1e-5, p_(stats))
+                    q2 = lin(h1, P[q + "q2"], None, hw, tf=L.TF_LAYERNORM, row_stats=stats,
+                             ln_gamma=sd[q + "norm2.weight"], ln_beta=sd[q + "norm2.bias"], out=att)
+                    a2 = pg.alloc(rows, C_)
+                    pg.add("ldmk_attn_cross", p_(q2), C_, p_(kk), p_(vv), C_, p_(a2), C_, n, hw, L_ctx, m.heads,
+                           m.d_head ** -0.5)
+                    h2 = lin(a2, P[q + "o2"], sd[q + "attn2.to_out.0.bias"], hw, residual=h1, out=h1)
+                    pg.release(att, a2)
+                # --- GEGLU feed-forward: LN3 folded into the first GEMM, gate in its epilogue
+                pg.add("ldmk_ln_stats", p_(h2), rows, C_, 1e-5, p_(stats))
+                f = lin(h2, P[q + "ff1"], P[q + "ff1b"], hw, geglu=True, tf=L.TF_LAYERNORM, row_stats=stats,
+                        ln_gamma=sd[q + "norm3.weight"], ln_beta=sd[q + "norm3.bias"])
+                hcur = lin(f, P[q + "ff2"], sd[q + "ff.net.2.bias"], hw, residual=h2, out=h2)
+                pg.release(f)
+            out = lin(hcur, P[prefix + "pout"], sd[prefix + "proj_out.bias"], hw, residual=xr)
+            pg.release(hcur, stats)
+            return out.view(n, h, w, m.ch)
+
+        def run_layers(prefix, layers, x0, x1, h, w, keep_input):
+            """Returns (out, h, w). Releases intermediate tensors that no skip connection holds."""
+            cur0, cur1 = x0, x1
+            owned = not keep_input
+            for j, m in enumerate(layers):
+                p = f"{prefix}{j}."
+                if m.kind == "res":
+                    out = res_block(p, m, cur0, cur1, h, w)
+                elif m.kind == "st":
+                    out = spatial_tf(p, m, cur0, h, w)
+                elif m.kind == "down":
+                    out = conv(cur0, None, P[p + "w"], sd[p + "op.bias"], h, w, stride=2)
+                    h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+                elif m.kind == "up":
+                    out = conv(cur0, None, P[p + "w"], sd[p + "conv.bias"], h, w, upsample=True)
+                    h, w = 2 * h, 2 * w
+                else:
+                    raise AssertionError(m.kind)
+                if owned:
+                    pg.release(cur0)      # cur1 (a skip tensor) is released by the caller
+                cur0, cur1, owned = out, None, True
+            return cur0, h, w
+
+        # ---- the UNet walk (openaimodel.py:729-742)
+        hs = []
+        h0 = pg.alloc(n, H, W_, mc)
+        pg.add("ldmk_conv3x3_in", p_(x_in), cx, p_(cc_in), c_concat, p_(P["input_blocks.0.0.w"]),
+               p_(sd["input_blocks.0.0.bias"]), p_(h0), n, H, W_, mc)
+        hcur, ch_, cw_ = h0, H, W_
+        hs.append((hcur, ch_, cw_))
+        for i in range(1, len(self.input_blocks)):
+            hcur, ch_, cw_ = run_layers(f"input_blocks.{i}.", self.input_blocks[i].layers, hcur, None, ch_, cw_, True)
+            hs.append((hcur, ch_, cw_))
+        hcur, ch_, cw_ = run_layers("middle_block.", self.middle_block.layers, hcur, None, ch_, cw_, True)
+        for i, blk in enumerate(self.output_blocks):
+            skip, sh, sw = hs.pop()
+            assert (sh, sw) == (ch_, cw_)
+            new, ch_, cw_ = run_layers(f"output_blocks.{i}.", blk.layers, hcur, skip, ch_, cw_, True)
+            pg.release(hcur, skip)     # both inputs of the concat are dead once the block has run
+            hcur = new
+        coef = gn(hcur, None, ch_ * cw_, sd["out.0.weight"], sd["out.0.bias"], 1e-5)
+        eps = pg.alloc(n, self.out_channels, H, W_)
+        pg.add("ldmk_conv3x3_out", p_(hcur), p_(coef), p_(P["out"]), p_(sd["out.2.bias"]), p_(eps), n, H, W_,
+               self._final_ch, self.out_channels)
+        pg.outputs = dict(eps=eps)
+        pg.ctx_program = ctx_pg
+        return pg
+
+    # ---- public surface ---------------------------------------------------------------------------
+    def program(self, n, H, W_, L_ctx, c_concat=0):
+        if self._packed is None or (self.auto_repack and self._pack_sig != self._signature()):
+            self.pack_weights()
+        policy_n = self.policy_batch or n
+        key = (n, H, W_, L_ctx, c_concat, policy_n)
+        pg = self._programs.get(key)
+        if pg is None:
+            pg = self._build(n, H, W_, L_ctx, c_concat, policy_n)
+            self._programs[key] = pg
+        return pg
+
+    @torch.no_grad()
+    def forward(self, x, timesteps=None, context=None, y=None, c_concat=None, **kwargs):
+        """x: (N, C, H, W) fp32 NCHW; timesteps: (N,) int64; context: (N, L, context_dim).
+        `c_concat` (N, C2, H, W) is concatenated to x on the channel axis inside the first conv (the TF
+        DiffusionWrapper does `torch.cat([x] + c_concat, 1)`, ddpm2cond.py:1309); passing an already
+        concatenated x works too."""
+        assert y is None, "class-conditional (y) UNets are not part of this path"
+        if context is None:
+            raise L.LdmkError("UNetModel.forward: context is required (the reference raises a shape error for "
+                              "context=None when context_dim != inner dim, attention.py:174-175)")
+        if not x.is_cuda:
+            raise L.LdmkError("UNetModel.forward: input must be a CUDA tensor (no CPU fallback)")
+        n, cx, H, W_ = x.shape
+        cc = 0 if c_concat is None else c_concat.shape[1]
+        assert cx + cc == self.in_channels, f"got {cx}+{cc} input channels, model has {self.in_channels}"
+        assert context.shape[0] == n and context.shape[2] == self.context_dim
+        pg = self.program(n, H, W_, context.shape[1], cc)
+        pg.inputs["x"].copy_(x)
+        if cc:
+            pg.inputs["c_concat"].copy_(c_concat)
+        pg.inputs["t"].copy_(timesteps.to(torch.int64))
+        pg.inputs["context"].copy_(context.reshape(n * context.shape[1], self.context_dim))
+        pg.ctx_program.run()
+        pg.run()
+        return pg.outputs["eps"].clone()

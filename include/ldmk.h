@@ -72,9 +72,14 @@ typedef struct ldmk_igemm_args {
   int batch;                 /* >1: batched GEMM over blockIdx.z with the strides below           */
   long long a_bstride, w_bstride, out_bstride;
   float alpha;               /* scale applied to the product before the epilogue (1.0 default)    */
+  int tile_cfg;              /* 0 = choose from the problem size; 1..4 = pin a tile shape (the K-summation
+                                order depends on the tile shape, so a caller that needs results that are
+                                bitwise independent of the batch size pins it, see ldmk_igemm_pick_config) */
 } ldmk_igemm_args;
 
 int ldmk_igemm(const ldmk_igemm_args* args, void* stream);
+/* the tile shape (1..4) ldmk_igemm would choose for these sizes; only M, N, K, epi, batch are read */
+int ldmk_igemm_pick_config(const ldmk_igemm_args* args);
 
 /* ------------------------------------------------------------------------------------------
  * Normalisation statistics (HBM-bound, wave-shuffle reductions).

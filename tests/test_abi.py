@@ -44,8 +44,8 @@ def test_argument_validation_without_gpu(libpath):
     a = L.IgemmArgs()
     assert lib.ldmk_igemm(ctypes.byref(a), None) == -1
     assert b"empty problem" in lib.ldmk_last_error()
-    assert lib.ldmk_attn_self(1, 1, 1, 33, 5, 0.1, None) == -1
-    assert b"multiple of 32" in lib.ldmk_last_error()
+    assert lib.ldmk_attn_self(1, 1, 1, 0, 5, 0.1, None) == -1
+    assert b"must be positive" in lib.ldmk_last_error()
     assert lib.ldmk_vq_nearest(1, 1, 1, 1, 1, 4, 7, 16, None) == -1
     with pytest.raises(L.LdmkError, match="unsupported"):
         L.call("ldmk_vq_nearest", 1, 1, 1, 1, 1, 4, 7, 16, None)

@@ -159,7 +159,8 @@ def test_geglu_ff_golden(ops):
     close(y, g["geglu_ff"][0], 1e-4, 1e-4)
 
 
-@pytest.mark.parametrize("n,tokens,heads", [(1, 64, 5), (2, 256, 10), (2, 1024, 5), (1, 4096, 5), (3, 96, 2)])
+@pytest.mark.parametrize("n,tokens,heads", [(1, 64, 5), (2, 256, 10), (2, 1024, 5), (1, 4096, 5), (3, 96, 2),
+                                            (2, 16, 3), (1, 77, 2), (1, 130, 1)])
 def test_attn_self(ops, n, tokens, heads):
     C = heads * 32
     qkv = rnd(40, n * tokens, 3 * C)
