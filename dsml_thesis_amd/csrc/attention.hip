@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
 }  // namespace ldmk
 
 extern "C" int ldmk_attn_self(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream) {
+  LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(qkv && out && n > 0 && heads > 0, "ldmk_attn_self: bad args");
   LDMK_REQUIRE(tokens > 0, "ldmk_attn_self: tokens=%d must be positive", tokens);
@@ -232,6 +233,7 @@ extern "C" int ldmk_attn_self(const float* qkv, float* out, int n, int tokens, i
 
 extern "C" int ldmk_attn_cross(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo,
                                int n, int tokens, int ctx_len, int heads, float scale, void* stream) {
+  LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(q && k && v && out && n > 0 && tokens > 0 && heads > 0, "ldmk_attn_cross: bad args");
   LDMK_REQUIRE(ctx_len >= 1 && ctx_len <= 128, "ldmk_attn_cross: ctx_len=%d outside [1,128]", ctx_len);
@@ -243,6 +245,7 @@ extern "C" int ldmk_attn_cross(const float* q, int ldq, const float* k, const fl
 }
 
 extern "C" int ldmk_softmax_rows(float* x, long long rows, int cols, float scale, void* stream) {
+  LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(x && rows > 0 && cols > 0 && cols <= 8192, "ldmk_softmax_rows: cols must be in (0, 8192]");
   LDMK_REQUIRE(rows <= 0x7fffffffLL, "ldmk_softmax_rows: too many rows");

@@ -358,6 +358,7 @@ extern "C" int ldmk_igemm_pick_config(const ldmk_igemm_args* args) {
 }
 
 extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) {
+  LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(args != nullptr, "ldmk_igemm: null args");
   ldmk_igemm_args a = *args;

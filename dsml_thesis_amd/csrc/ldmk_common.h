@@ -19,6 +19,9 @@ inline int check_launch(const char* what) {
   return LDMK_OK;
 }
 
+// a stale error left in the thread by an earlier, unrelated HIP call must not be blamed on this launch
+#define LDMK_ENTER() (void)hipGetLastError()
+
 #define LDMK_REQUIRE(cond, ...)        \
   do {                                 \
     if (!(cond)) {                     \

@@ -110,6 +110,7 @@ extern "C" int ldmk_gn_chunks(int hw) { return (hw + ldmk::GN_PIX - 1) / ldmk::G
 
 extern "C" int ldmk_gn_coef(const float* x0, int c0, const float* x1, int c1, int n, int hw, int groups, float eps,
                             const float* gamma, const float* beta, float* partial, float* coef, void* stream) {
+  LDMK_ENTER();
   using namespace ldmk;
   const int C = c0 + c1;
   LDMK_REQUIRE(x0 && c0 > 0 && n > 0 && hw > 0 && groups > 0, "ldmk_gn_coef: bad args");
@@ -125,6 +126,7 @@ extern "C" int ldmk_gn_coef(const float* x0, int c0, const float* x1, int c1, in
 }
 
 extern "C" int ldmk_ln_stats(const float* x, int rows, int c, float eps, float* stats, void* stream) {
+  LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(x && stats && rows > 0 && c > 0 && c <= 1024, "ldmk_ln_stats: bad args (C<=1024)");
   hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats);

@@ -313,6 +313,7 @@ extern "C" const char* ldmk_last_error(void) { return g_err; }
 
 extern "C" int ldmk_dense_small(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
                                 int rows, int K, int N, int silu_in, void* stream) {
+  LDMK_ENTER();
   LDMK_REQUIRE(x && w && out && rows > 0 && K > 0 && N > 0, "ldmk_dense_small: bad args");
   LDMK_REQUIRE(ldx >= K && ldo >= N, "ldmk_dense_small: leading dims");
   dim3 grid((N + 255) / 256, (rows + DS_ROWS - 1) / DS_ROWS);
@@ -322,6 +323,7 @@ extern "C" int ldmk_dense_small(const float* x, int ldx, const float* w, const f
 }
 
 extern "C" int ldmk_timestep_embedding(const long long* t, const float* freqs, float* emb, int n, int dim, void* stream) {
+  LDMK_ENTER();
   LDMK_REQUIRE(t && freqs && emb && n > 0 && dim >= 2, "ldmk_timestep_embedding: bad args");
   int total = n * (dim / 2);
   hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, freqs,
@@ -331,6 +333,7 @@ extern "C" int ldmk_timestep_embedding(const long long* t, const float* freqs, f
 
 extern "C" int ldmk_conv3x3_in(const float* x0, int c0, const float* x1, int c1, const float* w, const float* bias,
                                float* out, int n, int h, int w_, int cout, void* stream) {
+  LDMK_ENTER();
   LDMK_REQUIRE(x0 && w && out && n > 0 && h > 0 && w_ > 0 && cout > 0, "ldmk_conv3x3_in: bad args");
   LDMK_REQUIRE(c0 > 0 && c0 + c1 <= 16 && (c1 == 0) == (x1 == nullptr), "ldmk_conv3x3_in: c0+c1 must be <= 16");
   long long total = (long long)n * h * w_;
@@ -341,6 +344,7 @@ extern "C" int ldmk_conv3x3_in(const float* x0, int c0, const float* x1, int c1,
 
 extern "C" int ldmk_conv3x3_out(const float* x, const float* coef, const float* w, const float* bias, float* out, int n,
                                 int h, int w_, int cin, int cout, void* stream) {
+  LDMK_ENTER();
   LDMK_REQUIRE(x && w && out && n > 0 && h > 0 && w_ > 0 && cin > 0, "ldmk_conv3x3_out: bad args");
   LDMK_REQUIRE(cout >= 1 && cout <= 4, "ldmk_conv3x3_out: cout=%d must be in [1,4]", cout);
   long long total = (long long)n * h * w_;
@@ -351,6 +355,7 @@ extern "C" int ldmk_conv3x3_out(const float* x, const float* coef, const float* 
 
 extern "C" int ldmk_conv1x1_nchw(const float* x, const float* w, const float* bias, float* out, int n, int hw, int cin,
                                  int cout, void* stream) {
+  LDMK_ENTER();
   LDMK_REQUIRE(x && w && out && n > 0 && hw > 0 && cin > 0 && cout > 0, "ldmk_conv1x1_nchw: bad args");
   long long total = (long long)n * hw;
   hipLaunchKernelGGL(conv1x1_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w,
@@ -362,6 +367,7 @@ extern "C" int ldmk_ddim_step(const float* x, const float* eps, const float* noi
                               int* step_idx, float cfg_scale, int cfg, float* x_prev, float* pred_x0,
                               long long per_sample, int n, const long long* timesteps, long long* ts, int n_ts,
                               int advance, void* stream) {
+  LDMK_ENTER();
   LDMK_REQUIRE(x && eps && table && step_idx && x_prev && per_sample > 0 && n > 0, "ldmk_ddim_step: bad args");
   if (advance) LDMK_REQUIRE(timesteps && ts && n_ts > 0, "ldmk_ddim_step: advance needs timesteps/ts");
   long long total = per_sample * n;
@@ -376,6 +382,7 @@ extern "C" int ldmk_ddim_step(const float* x, const float* eps, const float* noi
 extern "C" int ldmk_ddpm_step(const float* x, const float* eps, const float* noise, const float* tables,
                               const float* logvar, const long long* t, float* x_prev, long long per_sample, int n,
                               void* stream) {
+  LDMK_ENTER();
   LDMK_REQUIRE(x && eps && tables && logvar && t && x_prev && per_sample > 0 && n > 0, "ldmk_ddpm_step: bad args");
   long long total = per_sample * n;
   hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, eps, noise, tables,
@@ -385,6 +392,7 @@ extern "C" int ldmk_ddpm_step(const float* x, const float* eps, const float* noi
 
 extern "C" int ldmk_vq_nearest(const float* z, const float* codebook, float* zq, int* idx, int n, int hw, int dim,
                                int n_embed, void* stream) {
+  LDMK_ENTER();
   LDMK_REQUIRE(z && codebook && zq && n > 0 && hw > 0 && n_embed > 0, "ldmk_vq_nearest: bad args");
   long long total = (long long)n * hw;
   dim3 grid((unsigned)((total + 3) / 4));
@@ -398,6 +406,7 @@ extern "C" int ldmk_vq_nearest(const float* z, const float* codebook, float* zq,
 }
 
 extern "C" int ldmk_permute3(const float* src, float* dst, int d0, int d1, int d2, int p0, int p1, int p2, void* stream) {
+  LDMK_ENTER();
   LDMK_REQUIRE(src && dst && d0 > 0 && d1 > 0 && d2 > 0, "ldmk_permute3: bad args");
   LDMK_REQUIRE(((1 << p0) | (1 << p1) | (1 << p2)) == 7, "ldmk_permute3: perm must be a permutation of 0,1,2");
   long long total = (long long)d0 * d1 * d2;
@@ -407,6 +416,7 @@ extern "C" int ldmk_permute3(const float* src, float* dst, int d0, int d1, int d
 }
 
 extern "C" int ldmk_postprocess_frames(const float* x, float* out, int n, int c, int hw, void* stream) {
+  LDMK_ENTER();
   LDMK_REQUIRE(x && out && n > 0 && c > 0 && hw > 0, "ldmk_postprocess_frames: bad args");
   long long total = (long long)n * c * hw;
   hipLaunchKernelGGL(postprocess_frames_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out, n, c,
@@ -416,6 +426,7 @@ extern "C" int ldmk_postprocess_frames(const float* x, float* out, int n, int c,
 
 extern "C" int ldmk_add_rowvec(float* x, const float* vec, int vec_ld, long long rows, int c, int rows_per_sample,
                                void* stream) {
+  LDMK_ENTER();
   LDMK_REQUIRE(x && vec && rows > 0 && c > 0 && c % 4 == 0 && vec_ld % 4 == 0 && rows_per_sample > 0,
                "ldmk_add_rowvec: bad args");
   hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, vec, vec_ld,

@@ -1,0 +1,264 @@
+"""DDIMSampler: drop-in for the reference samplers
+  face_reenactment/ldm/models/diffusion/ddim.py:11-219      (one cross-attention condition, CFG by batch doubling)
+  talking_face/ldm/models/diffusion/ddim2cond.py:11-308     (dict conditioning {'class_label_&_audio', 'motion_&_id'})
+  talking_face/progressive_sampling_difftalk.py:245-319     (progressive_sampling, autoregressive identity)
+
+Same call surface (`make_schedule`, `sample`, `ddim_sampling`, `p_sample_ddim`, `progressive_sampling`); the
+loop itself is MI355X-native: the latent, the timestep vector, the step counter and the coefficient table stay
+in device memory, one step = the UNet launch program + one fused update kernel, no host sync, and the step can
+be captured once in a hipGraph and replayed S times.  Additions over the reference: `noise=` (pre-generated
+per-step noise for eta>0 parity), `use_graph=`, `policy_batch=` (sharding-invariant tile choice) and
+`fixed_identity=` for progressive sampling.
+"""
+import numpy as np
+import torch
+
+from . import lib as L
+from . import schedule as S_
+from .engine import GraphedProgram
+
+C12, C34 = "class_label_&_audio", "motion_&_id"
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        super().__init__()
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+        self._loops = {}
+        self._tables = {}
+
+    def register_buffer(self, name, attr):
+        if isinstance(attr, torch.Tensor) and attr.device != self.model.device:
+            attr = attr.to(self.model.device)
+        setattr(self, name, attr)
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        self.ddim_timesteps = S_.make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps)
+        ac = self.model.alphas_cumprod
+        assert ac.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        sig, al, alp = S_.make_ddim_sampling_parameters(ac.cpu(), self.ddim_timesteps, ddim_eta)
+        self.register_buffer("ddim_sigmas", torch.as_tensor(np.asarray(sig)))
+        self.register_buffer("ddim_alphas", torch.as_tensor(al))
+        self.ddim_alphas_prev = alp
+        self.ddim_sqrt_one_minus_alphas = np.sqrt(1. - al)
+        # device-resident [S][4] coefficient table + timestep table for the update kernel
+        dev = self.model.device
+        key = (ddim_num_steps, float(ddim_eta), ddim_discretize)
+        if key not in self._tables:     # persistent device tables: captured graphs keep pointing at them
+            self._tables[key] = (torch.from_numpy(S_.ddim_step_table(ac.cpu(), self.ddim_timesteps, ddim_eta)).to(dev),
+                                 torch.from_numpy(self.ddim_timesteps.astype(np.int64)).to(dev))
+        self._table, self._ts_table = self._tables[key]
+        self._sched_key = key
+        self._eta = ddim_eta
+
+    # ------------------------------------------------------------------------------------------
+    def _split_cond(self, cond):
+        """-> (crossattn context (B,L,D), c_concat (B,C,H,W) or None)."""
+        if isinstance(cond, dict):
+            if C12 in cond:                      # TF sampler conditioning, ddim2cond.py:165
+                return cond[C12], cond[C34]
+            cc = cond.get("c_crossattn")
+            ct = cond.get("c_concat")
+            cc = torch.cat(cc, 1) if isinstance(cc, (list, tuple)) else cc
+            ct = torch.cat(ct, 1) if isinstance(ct, (list, tuple)) else ct
+            return cc, ct
+        if isinstance(cond, (list, tuple)):
+            return torch.cat(list(cond), 1), None
+        return cond, None
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None,
+               img_callback=None, quantize_x0=False, eta=0., mask=None, x0=None, temperature=1.,
+               noise_dropout=0., score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None,
+               log_every_t=100, unconditional_guidance_scale=1., unconditional_conditioning=None,
+               noise=None, use_graph=False, policy_batch=None, **kwargs):
+        if conditioning is None:
+            raise L.LdmkError("DDIMSampler.sample: conditioning is required (the shipped UNets are cross-attention "
+                              "conditioned; the reference asserts the same in ddim2cond.py:80)")
+        ctx, _ = self._split_cond(conditioning)
+        if ctx.shape[0] != batch_size:
+            print(f"Warning: Got {ctx.shape[0]} conditionings but batch-size is {batch_size}")
+        if mask is not None or quantize_x0 or score_corrector is not None or noise_dropout > 0. or temperature != 1.:
+            raise NotImplementedError("DDIMSampler.sample: mask/x0, quantize_x0, score_corrector, noise_dropout and "
+                                      "temperature are not used by any shipped script and are not built")
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        C_, H, W_ = shape
+        size = (batch_size, C_, H, W_)
+        return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback, x_T=x_T,
+                                  log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning, noise=noise,
+                                  use_graph=use_graph, policy_batch=policy_batch)
+
+    @torch.no_grad()
+    def ddim_sampling(self, cond, shape, x_T=None, callback=None, img_callback=None, log_every_t=100,
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, noise=None,
+                      use_graph=False, policy_batch=None, return_x_inter_only=False, **kwargs):
+        dev = self.model.device
+        unet = self.model.model.diffusion_model
+        b = shape[0]
+        S = self.ddim_timesteps.shape[0]
+        img0 = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32)
+        ctx, cat = self._split_cond(cond)
+        cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
+        nb = 2 * b if cfg else b
+        if cfg:
+            uc, _ = self._split_cond(unconditional_conditioning)
+            ctx_in = torch.cat([uc, ctx])                  # ddim.py:175: [uncond | cond]
+            cat_in = None if cat is None else torch.cat([cat] * 2)
+        else:
+            ctx_in, cat_in = ctx, cat
+        ncat = 0 if cat_in is None else cat_in.shape[1]
+        unet.policy_batch = None if policy_batch is None else (2 * policy_batch if cfg else policy_batch)
+        pg = unet.program(nb, shape[2], shape[3], ctx_in.shape[1], ncat)
+        lib = pg.lib
+        x_buf = pg.inputs["x"]
+        pg.inputs["context"].copy_(ctx_in.reshape(nb * ctx_in.shape[1], -1))
+        if ncat:
+            pg.inputs["c_concat"].copy_(cat_in)
+        pg.ctx_program.run()                               # context-only projections: once per sample() call
+        img = x_buf[:b]                                    # the latent lives in the UNet's input buffer
+        img.copy_(img0)
+        if cfg:
+            x_buf[b:].copy_(img0)
+        need_noise = self._eta != 0. or noise is not None
+        lkey = (id(pg), cfg, float(unconditional_guidance_scale), self._sched_key, need_noise, bool(use_graph),
+                noise is None)
+        st = self._loops.get(lkey)
+        if st is None:
+            st = dict(pred_x0=torch.empty_like(img0), step_idx=torch.zeros(1, dtype=torch.int32, device=dev),
+                      nz=torch.empty_like(img0) if need_noise else None, graph=None)
+            self._loops[lkey] = st
+        pred_x0, step_idx, nz_buf = st["pred_x0"], st["step_idx"], st["nz"]
+        eps = pg.outputs["eps"]
+        per = img0[0].numel()
+        table, ts_table = self._table, self._ts_table
+        scale = float(unconditional_guidance_scale)
+
+        def reset_state():
+            img.copy_(img0)
+            if cfg:
+                x_buf[b:].copy_(img0)
+            step_idx.fill_(S - 1)
+            pg.inputs["t"].fill_(int(self.ddim_timesteps[S - 1]))
+
+        def one_step():
+            pg.run()
+            rc = lib.ldmk_ddim_step(img.data_ptr(), eps.data_ptr(), 0 if nz_buf is None else nz_buf.data_ptr(),
+                                    table.data_ptr(), step_idx.data_ptr(), scale, 1 if cfg else 0, img.data_ptr(),
+                                    pred_x0.data_ptr(), per, b, ts_table.data_ptr(), pg.inputs["t"].data_ptr(), nb, 1,
+                                    torch.cuda.current_stream().cuda_stream)
+            L.check(rc, "ldmk_ddim_step")
+            if cfg:
+                x_buf[b:].copy_(img)                       # both CFG halves see the same latent (ddim.py:173)
+
+        reset_state()
+        step = one_step
+        if use_graph:
+            if st["graph"] is None:
+                if nz_buf is not None and noise is None:
+                    def step_with_noise():
+                        nz_buf.normal_()
+                        one_step()
+                    st["graph"] = GraphedProgram(step_with_noise)
+                else:
+                    st["graph"] = GraphedProgram(one_step)
+                reset_state()                              # warm-up + capture advanced the device state
+            step = st["graph"].replay
+
+        intermediates = {"x_inter": [img0], "pred_x0": [img0]}
+        for i in range(S):
+            index = S - i - 1
+            if nz_buf is not None:
+                if noise is not None:
+                    nz_buf.copy_(noise[i])
+                elif not use_graph:
+                    nz_buf.normal_()
+            step()
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == S - 1:
+                intermediates["x_inter"].append(img.clone())
+                intermediates["pred_x0"].append(pred_x0.clone())
+        out = img.clone()
+        if return_x_inter_only:                            # TF sampler returns the x_inter list, ddim2cond.py:156
+            return out, intermediates["x_inter"]
+        return out, intermediates
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
+                      temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, noise=None):
+        """Single step with the reference's signature (ddim.py:164-203); returns (x_prev, pred_x0)."""
+        if use_original_steps or quantize_denoised or score_corrector is not None or noise_dropout > 0.:
+            raise NotImplementedError("p_sample_ddim: only the DDIM-subsequence path is built")
+        dev = x.device
+        b = x.shape[0]
+        ctx, cat = self._split_cond(c)
+        cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
+        if cfg:
+            uc, _ = self._split_cond(unconditional_conditioning)
+            e = self.model.apply_model(torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([uc, ctx]),
+                                       None if cat is None else torch.cat([cat] * 2))
+        else:
+            e = self.model.apply_model(x, t, ctx, cat)
+        if noise is None and self._eta != 0.:
+            noise = torch.randn_like(x) * temperature
+        step_idx = torch.full((1,), int(index), dtype=torch.int32, device=dev)
+        x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)
+        L.call("ldmk_ddim_step", x.contiguous().data_ptr(), e.data_ptr(), 0 if noise is None else noise.contiguous().data_ptr(),
+               self._table.data_ptr(), step_idx.data_ptr(), float(unconditional_guidance_scale), 1 if cfg else 0,
+               x_prev.data_ptr(), pred_x0.data_ptr(), x[0].numel(), b, 0, 0, 0, 0,
+               torch.cuda.current_stream().cuda_stream)
+        return x_prev, pred_x0
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def progressive_sampling(self, c1, xid, xmasks, audio_feats, S, batch_size, num_frames, shape, audio_window,
+                             eta=0., verbose=True, unconditional_guidance_scale=1., unconditional_conditioning=None,
+                             x_T=None, fixed_identity=False, use_graph=True, **kwargs):
+        """Talking-face clip generation, progressive_sampling_difftalk.py:245-319.
+
+        fixed_identity=False: the reference's behaviour -- frames are a serial chain, the identity latent of
+          frame k+1 is the latent generated for frame k (:316-317); batch 1, one captured step replayed S times
+          per frame.
+        fixed_identity=True: identity latent = encode(identity image) for every frame, which makes frames
+          independent: the whole clip is ONE batched DDIMSampler.sample call (and shards across GPUs).
+        x_T: optional (T,1,C,H,W) start noise per frame (the reference draws torch.randn per frame).
+        Returns (list of T latents (1,C,H,W), None) like the reference.
+        """
+        assert c1 is not None
+        assert eta in [0., 1.]
+        if unconditional_guidance_scale != 1. and unconditional_conditioning is not None:
+            raise NotImplementedError("progressive_sampling: the reference's CFG branch raises (torch.cat(..., dim=21), "
+                                      "progressive_sampling_difftalk.py:299); only scale=1 is defined")
+        m = self.model
+        if audio_feats.dim() == 3:
+            assert audio_feats.shape[0] == 1
+            audio_feats = audio_feats.squeeze(0)
+        T = audio_feats.shape[0]
+        C_, H, W_ = shape
+        dev = m.device
+        idx = torch.tensor([[min(max(f + i, 0), T - 1) for i in range(-audio_window, audio_window + 1)]
+                            for f in range(T)], device=audio_feats.device)
+        c2_all = m.cond_stage_model_2(audio_feats[idx])                       # (T,1,768): one batched call
+        c12_all = torch.cat([c1.expand(T, -1, -1), c2_all], dim=2)            # (T,1,1024)
+        c3_all = m.encode_first_stage(xmasks)                                  # (T,c,h,w): one batched encode
+        if x_T is None:
+            x_T = torch.randn(T, batch_size, C_, H, W_, device=dev)
+        if fixed_identity:
+            c34 = torch.cat([c3_all, xid.expand(T, -1, -1, -1)], dim=1)
+            out, _ = self.sample(S, T, shape, {C12: c12_all, C34: c34}, eta=eta, x_T=x_T[:, 0], verbose=False,
+                                 use_graph=use_graph)
+            return [out[f:f + 1] for f in range(T)], None
+        zid = xid.clone()
+        frames = []
+        for f in range(T):
+            c = {C12: c12_all[f:f + 1], C34: torch.cat([c3_all[f:f + 1], zid], dim=1)}
+            img, _ = self.sample(S, batch_size, shape, c, eta=eta, x_T=x_T[f], verbose=False, use_graph=use_graph)
+            frames.append(img)
+            zid = img.clone()
+        return frames, None

@@ -1,0 +1,348 @@
+"""LatentDiffusion facade: drop-in for the `pl.LightningModule` the reference's samplers and scripts drive
+  face_reenactment/ldm/models/diffusion/ddpm.py:44-420 (DDPM), :423-1394 (LatentDiffusion), :1397-1423 (DiffusionWrapper)
+  talking_face/ldm/models/diffusion/ddpm2cond.py:430-1297, :1300-1315 (two-condition variant)
+  face_reenactment/ldm/modules/ema.py:5-76 (LitEma)
+
+Only the sampling surface is built: schedules, `apply_model`, `p_sample_loop`/`sample`,
+`sample_log`, `decode_first_stage`/`encode_first_stage`, `q_sample`, `ema_scope`, state-dict key layout
+(`model.diffusion_model.*`, `model_ema.*`, `first_stage_model.*`, `cond_stage_model*.*`).  Training members
+(`p_losses`, `training_step`, optimisers, logging) are the "next" row N1 and raise NotImplementedError.
+The class derives from pytorch_lightning.LightningModule when Lightning is installed, else nn.Module.
+"""
+from contextlib import contextmanager
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from . import schedule as S_
+from .util import instantiate_from_config
+
+try:  # north_star: keep the pl.LightningModule surface when Lightning exists
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # offline image: Lightning absent
+    class _Base(nn.Module):
+        @property
+        def device(self):
+            for p in self.parameters():
+                return p.device
+            for b in self.buffers():
+                return b.device
+            return torch.device("cpu")
+
+        def log(self, *a, **k):
+            pass
+
+        def log_dict(self, *a, **k):
+            pass
+
+
+class LitEma(nn.Module):
+    """Shadow weights under the reference's buffer names (parameter name with the dots removed)."""
+
+    def __init__(self, model, decay=0.9999, use_num_upates=True):
+        super().__init__()
+        if decay < 0.0 or decay > 1.0:
+            raise ValueError("Decay must be between 0 and 1")
+        self.m_name2s_name = {}
+        self.register_buffer("decay", torch.tensor(decay, dtype=torch.float32))
+        self.register_buffer("num_updates", torch.tensor(0 if use_num_upates else -1, dtype=torch.int))
+        for name, p in model.named_parameters():
+            s_name = name.replace(".", "")
+            self.m_name2s_name[name] = s_name
+            self.register_buffer(s_name, p.clone().detach().data)
+        self.collected_params = []
+
+    @torch.no_grad()
+    def copy_to(self, model):
+        shadow = dict(self.named_buffers())
+        for key, p in model.named_parameters():
+            p.data.copy_(shadow[self.m_name2s_name[key]].data)
+
+    def store(self, parameters):
+        self.collected_params = [p.clone() for p in parameters]
+
+    @torch.no_grad()
+    def restore(self, parameters):
+        for c, p in zip(self.collected_params, parameters):
+            p.data.copy_(c.data)
+
+
+class DiffusionWrapper(_Base):
+    """ddpm.py:1397-1423 / ddpm2cond.py:1300-1315: routes c_concat / c_crossattn into the UNet.  The channel
+    concat is not materialised: the UNet's first conv reads both tensors."""
+
+    def __init__(self, diff_model_config, conditioning_key):
+        super().__init__()
+        self.diffusion_model = instantiate_from_config(diff_model_config)
+        self.conditioning_key = conditioning_key
+        assert self.conditioning_key in [None, "concat", "crossattn", "hybrid", "adm"]
+
+    def forward(self, x, t, c_concat: list = None, c_crossattn: list = None):
+        if self.conditioning_key in (None, "concat", "adm"):
+            raise NotImplementedError(f"DiffusionWrapper: conditioning_key={self.conditioning_key!r} is not used by the "
+                                      "shipped configs (all are cross-attention conditioned)")
+        cc = torch.cat(c_crossattn, 1)
+        cat = None
+        if c_concat is not None:
+            cat = c_concat[0] if len(c_concat) == 1 else torch.cat(c_concat, 1)
+        return self.diffusion_model(x, t, context=cc, c_concat=cat)
+
+
+class LatentDiffusion(_Base):
+    def __init__(self, first_stage_config, cond_stage_config, num_timesteps_cond=None, cond_stage_key="image",
+                 cond_stage_trainable=False, concat_mode=True, cond_stage_forward=None, conditioning_key=None,
+                 scale_factor=1.0, scale_by_std=False, unet_config=None, timesteps=1000, beta_schedule="linear",
+                 loss_type="l2", ckpt_path=None, ignore_keys=[], load_only_unet=False, monitor="val/loss",
+                 use_ema=True, first_stage_key="image", image_size=256, channels=3, log_every_t=100,
+                 clip_denoised=True, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3, given_betas=None,
+                 original_elbo_weight=0., v_posterior=0., l_simple_weight=1., parameterization="eps",
+                 scheduler_config=None, use_positional_encodings=False, learn_logvar=False, logvar_init=0., **kw):
+        super().__init__()
+        assert parameterization == "eps", "the shipped configs are eps-prediction"
+        self.num_timesteps_cond = 1 if num_timesteps_cond is None else num_timesteps_cond
+        assert self.num_timesteps_cond <= timesteps
+        if self.num_timesteps_cond != 1:
+            raise NotImplementedError("shorten_cond_schedule (num_timesteps_cond > 1) is unused by the shipped configs")
+        if conditioning_key is None:
+            conditioning_key = "concat" if concat_mode else "crossattn"
+        if cond_stage_config == "__is_unconditional__":
+            conditioning_key = None
+        self.parameterization = parameterization
+        self.cond_stage_model = None
+        self.clip_denoised = False                      # LatentDiffusion overrides DDPM's default, ddpm.py:463
+        self.log_every_t, self.first_stage_key = log_every_t, first_stage_key
+        self.image_size, self.channels = image_size, channels
+        self.model = DiffusionWrapper(unet_config, conditioning_key)
+        self.use_ema = use_ema
+        if self.use_ema:
+            self.model_ema = LitEma(self.model)
+        self.v_posterior = v_posterior
+        if monitor is not None:
+            self.monitor = monitor
+        self.scale_by_std = scale_by_std
+        self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps,
+                               linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        self.logvar = torch.full(fill_value=logvar_init, size=(self.num_timesteps,))
+        self.concat_mode, self.cond_stage_trainable, self.cond_stage_key = concat_mode, cond_stage_trainable, cond_stage_key
+        if not scale_by_std:
+            self.scale_factor = scale_factor
+        else:
+            self.register_buffer("scale_factor", torch.tensor(scale_factor))
+        self.instantiate_first_stage(first_stage_config)
+        self.instantiate_cond_stage(cond_stage_config)
+        self.cond_stage_forward = cond_stage_forward
+        self.restarted_from_ckpt = False
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys)
+            self.restarted_from_ckpt = True
+
+    # ---- construction helpers ----------------------------------------------------------------------
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
+                          linear_end=2e-2, cosine_s=8e-3):
+        betas = given_betas if given_betas is not None else S_.make_beta_schedule(
+            beta_schedule, timesteps, linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        self.num_timesteps = int(np.asarray(betas).shape[0])
+        self.linear_start, self.linear_end = linear_start, linear_end
+        for k, v in S_.schedule_buffers(betas, self.v_posterior).items():
+            self.register_buffer(k, v)
+        self.shorten_cond_schedule = False
+        self._ddpm_tables = None
+
+    def instantiate_first_stage(self, config):
+        self.first_stage_model = instantiate_from_config(config).eval()
+        for p in self.first_stage_model.parameters():
+            p.requires_grad = False
+
+    def instantiate_cond_stage(self, config):
+        if config in ("__is_first_stage__", "__is_unconditional__"):
+            self.cond_stage_model = self.first_stage_model if config == "__is_first_stage__" else None
+            return
+        self.cond_stage_model = instantiate_from_config(config)
+        if not self.cond_stage_trainable:
+            self.cond_stage_model.eval()
+
+    def init_from_ckpt(self, path, ignore_keys=list(), only_model=False):
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                print("Deleting key {} from state_dict.".format(k))
+                del sd[k]
+        missing, unexpected = (self.load_state_dict(sd, strict=False) if not only_model
+                               else self.model.load_state_dict(sd, strict=False))
+        print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
+
+    @contextmanager
+    def ema_scope(self, context=None):
+        """ddpm.py:171-184: swap the EMA shadow weights in for sampling (the packed kernel weights are re-derived
+        automatically because the parameter versions change)."""
+        if self.use_ema:
+            self.model_ema.store(self.model.parameters())
+            self.model_ema.copy_to(self.model)
+            if context is not None:
+                print(f"{context}: Switched to EMA weights")
+        try:
+            yield None
+        finally:
+            if self.use_ema:
+                self.model_ema.restore(self.model.parameters())
+                if context is not None:
+                    print(f"{context}: Restored training weights")
+
+    # ---- model evaluation ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def apply_model(self, x_noisy, t, cond, cond_concat=None, return_ids=False):
+        """ddpm.py:893-994 (`apply_model(x,t,c)`) and ddpm2cond.py:911-945 (`apply_model(x,t,c12,c34)`)."""
+        if isinstance(cond, dict):
+            kwargs = dict(cond)
+        else:
+            if not isinstance(cond, list):
+                cond = [cond]
+            key = "c_concat" if self.model.conditioning_key == "concat" else "c_crossattn"
+            kwargs = {key: cond}
+        if cond_concat is not None:
+            if isinstance(cond_concat, dict):
+                kwargs.update(cond_concat)
+            else:
+                kwargs["c_concat"] = cond_concat if isinstance(cond_concat, list) else [cond_concat]
+        return self.model(x_noisy, t, **kwargs)
+
+    def q_sample(self, x_start, t, noise=None):
+        """ddpm.py:230-233."""
+        noise = torch.randn_like(x_start) if noise is None else noise
+        sh = (x_start.shape[0],) + (1,) * (x_start.dim() - 1)
+        return (self.sqrt_alphas_cumprod.gather(-1, t).reshape(sh) * x_start +
+                self.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(sh) * noise)
+
+    def get_learned_conditioning(self, c):
+        if self.cond_stage_forward is None:
+            if hasattr(self.cond_stage_model, "encode") and callable(self.cond_stage_model.encode):
+                return self.cond_stage_model.encode(c)
+            return self.cond_stage_model(c)
+        return getattr(self.cond_stage_model, self.cond_stage_forward)(c)
+
+    # ---- first stage ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):
+        """ddpm.py:706-764 -> VQModelInterface.decode."""
+        if predict_cids:
+            raise NotImplementedError("decode_first_stage(predict_cids=True) is unused on the sampling path")
+        if hasattr(self, "split_input_params"):
+            raise NotImplementedError("patch-wise (split_input_params) decoding is unused by the shipped configs")
+        z = 1. / self.scale_factor * z
+        return self.first_stage_model.decode(z, force_not_quantize=force_not_quantize)
+
+    @torch.no_grad()
+    def encode_first_stage(self, x):
+        """ddpm.py:826-864 -> VQModelInterface.encode (no quantisation)."""
+        return self.first_stage_model.encode(x)
+
+    def get_first_stage_encoding(self, encoder_posterior):
+        return self.scale_factor * encoder_posterior
+
+    # ---- ancestral sampler -----------------------------------------------------------------------------
+    def _ddpm_device_tables(self):
+        if self._ddpm_tables is None or self._ddpm_tables[0].device != self.betas.device:
+            tab = torch.stack([self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
+                               self.posterior_mean_coef1, self.posterior_mean_coef2], 1).contiguous()
+            self._ddpm_tables = (tab, self.posterior_log_variance_clipped.contiguous())
+        return self._ddpm_tables
+
+    @torch.no_grad()
+    def p_sample(self, x, c, t, clip_denoised=False, repeat_noise=False, return_codebook_ids=False,
+                 quantize_denoised=False, return_x0=False, temperature=1., noise_dropout=0., score_corrector=None,
+                 corrector_kwargs=None, noise=None):
+        """ddpm.py:1080-1109 (with p_mean_variance :1049-1078, q_posterior :221-228) as one fused update kernel."""
+        if clip_denoised or quantize_denoised or return_codebook_ids or score_corrector is not None or noise_dropout > 0.:
+            raise NotImplementedError("p_sample: clip/quantize/score-corrector options are unused on the shipped path")
+        eps = self.apply_model(x, t, c)
+        if noise is None:
+            noise = torch.randn_like(x) * temperature
+        tab, logvar = self._ddpm_device_tables()
+        out = torch.empty_like(x)
+        L.call("ldmk_ddpm_step", x.contiguous().data_ptr(), eps.data_ptr(), noise.contiguous().data_ptr(), tab.data_ptr(),
+               logvar.data_ptr(), t.to(torch.int64).contiguous().data_ptr(), out.data_ptr(), x[0].numel(), x.shape[0],
+               torch.cuda.current_stream().cuda_stream)
+        return out
+
+    @torch.no_grad()
+    def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None,
+                      timesteps=None, quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None,
+                      log_every_t=None, noise=None):
+        """ddpm.py:1167-1216.  `noise`: optional per-step noise list (parity with a seeded reference run)."""
+        if mask is not None or quantize_denoised:
+            raise NotImplementedError("p_sample_loop: mask/x0 and quantize_denoised are unused on the shipped path")
+        log_every_t = log_every_t or self.log_every_t
+        dev = self.betas.device
+        b = shape[0]
+        img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev)
+        intermediates = [img]
+        timesteps = self.num_timesteps if timesteps is None else timesteps
+        if start_T is not None:
+            timesteps = min(timesteps, start_T)
+        for k, i in enumerate(reversed(range(0, timesteps))):
+            ts = torch.full((b,), i, device=dev, dtype=torch.long)
+            img = self.p_sample(img, cond, ts, clip_denoised=self.clip_denoised,
+                                noise=None if noise is None else noise[k])
+            if i % log_every_t == 0 or i == timesteps - 1:
+                intermediates.append(img)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(img, i)
+        return (img, intermediates) if return_intermediates else img
+
+    @torch.no_grad()
+    def sample(self, cond, batch_size=16, return_intermediates=False, x_T=None, verbose=True, timesteps=None,
+               quantize_denoised=False, mask=None, x0=None, shape=None, **kwargs):
+        """ddpm.py:1218-1234."""
+        if shape is None:
+            shape = (batch_size, self.channels, self.image_size, self.image_size)
+        if cond is not None:
+            if isinstance(cond, dict):
+                cond = {k: (v[:batch_size] if not isinstance(v, list) else [x[:batch_size] for x in v])
+                        for k, v in cond.items()}
+            else:
+                cond = [c[:batch_size] for c in cond] if isinstance(cond, list) else cond[:batch_size]
+        return self.p_sample_loop(cond, shape, return_intermediates=return_intermediates, x_T=x_T, verbose=verbose,
+                                  timesteps=timesteps, quantize_denoised=quantize_denoised, mask=mask, x0=x0, **kwargs)
+
+    @torch.no_grad()
+    def sample_log(self, cond, batch_size, ddim, ddim_steps, **kwargs):
+        """ddpm.py:1236-1249 (what ImageLogger drives during training)."""
+        if ddim:
+            from .ddim import DDIMSampler
+            shape = (self.channels, self.image_size, self.image_size)
+            return DDIMSampler(self).sample(ddim_steps, batch_size, shape, cond, verbose=False, **kwargs)
+        return self.sample(cond=cond, batch_size=batch_size, return_intermediates=True, **kwargs)
+
+    # ---- training surface: "next" row N1 ----------------------------------------------------------------
+    def p_losses(self, *a, **k):
+        raise NotImplementedError("training (p_losses / training_step) is SURVEY §8(f) row N1, not built this round")
+
+    training_step = shared_step = p_losses
+
+
+class LatentDiffusion2Cond(LatentDiffusion):
+    """talking_face ddpm2cond.LatentDiffusion: class-label + audio cross-attention tokens concatenated on the
+    feature axis, masked-frame + identity latents concatenated on the channel axis (ddpm2cond.py:430-1297)."""
+
+    def __init__(self, first_stage_config, cond_stage_config_1, cond_stage_config_2, cond_stage_key_1="class_label",
+                 cond_stage_key_2="audio", **kwargs):
+        super().__init__(first_stage_config, cond_stage_config_1, cond_stage_key=cond_stage_key_1, **kwargs)
+        self.cond_stage_key_1, self.cond_stage_key_2 = cond_stage_key_1, cond_stage_key_2
+        self.cond_stage_model_1 = self.cond_stage_model
+        self.cond_stage_model = None
+        self.cond_stage_model_2 = instantiate_from_config(cond_stage_config_2)
+
+    @torch.no_grad()
+    def apply_model(self, x_noisy, t, cond12, cond34=None, return_ids=False):
+        c12 = cond12 if isinstance(cond12, (list, dict)) else [cond12]
+        c34 = cond34 if isinstance(cond34, (list, dict)) or cond34 is None else [cond34]
+        kwargs = dict(c12) if isinstance(c12, dict) else {"c_crossattn": c12}
+        if c34 is not None:
+            kwargs.update(c34 if isinstance(c34, dict) else {"c_concat": c34})
+        return self.model(x_noisy, t, **kwargs)

@@ -67,6 +67,67 @@ class Program:
                 L.check(rc, name)
 
 
+class NetBuilder:
+    """Emits the recurring layer patterns of the UNet / VQGAN into a Program (NHWC activations)."""
+
+    def __init__(self, pg, n, pin=None, gn_partial=None):
+        from . import ops
+        self.pg, self.n, self.pin, self.ops = pg, n, pin, ops
+        self.gn_partial = gn_partial
+
+    @staticmethod
+    def ptr(t):
+        return 0 if t is None else (t if isinstance(t, int) else t.data_ptr())
+
+    def gn(self, x0, x1, hw, gamma, beta, eps):
+        """GroupNorm(32) statistics of (the channel concat of) NHWC tensors -> coef planes [n][2][C]."""
+        pg, p_ = self.pg, self.ptr
+        c0 = x0.shape[-1]
+        c1 = 0 if x1 is None else x1.shape[-1]
+        coef = pg.alloc(self.n, 2, c0 + c1)
+        pg.add("ldmk_gn_coef", p_(x0), c0, p_(x1), c1, self.n, hw, 32, eps, p_(gamma), p_(beta),
+               p_(self.gn_partial), p_(coef))
+        return coef
+
+    def conv(self, x0, x1, wp, bias, h, w, coef=None, stride=1, pad_lo=1, upsample=False, batch_vec=None, bv_ld=0,
+             residual=None, out=None):
+        """3x3 conv (implicit GEMM) with optional GN+SiLU prologue / per-sample vector / residual epilogue."""
+        pg, n, ops = self.pg, self.n, self.ops
+        c0 = x0.shape[-1]
+        c1 = 0 if x1 is None else x1.shape[-1]
+        cout = wp.shape[1]
+        if upsample:
+            oh, ow = 2 * h, 2 * w
+        elif pad_lo == 1:
+            oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+        else:                                   # asymmetric (0,1,0,1) padding, model.py:72-76
+            oh, ow = (h + 1 - 3) // stride + 1, (w + 1 - 3) // stride + 1
+        if out is None:
+            out = pg.alloc(n, oh, ow, cout)
+        a = ops.make_igemm_args(n * oh * ow, cout, 9 * (c0 + c1), x0, c0, wp, out, cout, oh * ow, a1=x1, c1=c1,
+                                conv=(h, w, oh, ow, stride, pad_lo, 1 if upsample else 0),
+                                tf=L.TF_NONE if coef is None else L.TF_AFFINE_SILU, tf_coef=coef, bias=bias,
+                                residual=residual)
+        if batch_vec is not None:
+            a.batch_vec, a.batch_vec_ld = self.ptr(batch_vec), bv_ld
+        pg.igemm(a, self.pin)
+        return out
+
+    def lin(self, x0, wp, bias, rows_per_sample, x1=None, out=None, geglu=False, **kw):
+        """Linear / 1x1 conv on token rows, with the igemm prologue/epilogue options passed through."""
+        pg, ops = self.pg, self.ops
+        M, c0 = x0.shape[0], x0.shape[-1]
+        c1 = 0 if x1 is None else x1.shape[-1]
+        N = wp.shape[1]
+        ncol = N // 2 if geglu else N
+        if out is None:
+            out = pg.alloc(M, ncol)
+        a = ops.make_igemm_args(M, N, c0 + c1, x0, c0, wp, out, ncol, rows_per_sample, a1=x1, c1=c1, bias=bias,
+                                epi=L.EPI_GEGLU if geglu else L.EPI_NONE, **kw)
+        pg.igemm(a, self.pin)
+        return out
+
+
 class GraphedProgram:
     """A Program (or any callable that only enqueues on the current stream) captured into a hipGraph
     through torch.cuda.CUDAGraph (hipStreamBeginCapture/hipGraphLaunch underneath)."""

@@ -74,6 +74,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise LdmkError(f"{LIB_PATH} is missing: run `python -m dsml_thesis_amd.build` (hipcc, gfx950). "
                         "There is no CPU fallback for the sampling path.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64; importing torch first makes the
+    # dynamic loader resolve libldmk.so's libamdhip64 dependency to that same, already-loaded runtime, so the
+    # streams / device pointers torch hands us are valid in our launches.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)

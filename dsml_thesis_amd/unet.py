@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
-from .engine import Program
+from .engine import NetBuilder, Program
 
 
 # ------------------------------------------------------------------------------------------------
@@ -327,43 +327,8 @@ class UNetModel(nn.Module):
         chunks = pg.lib.ldmk_gn_chunks(H * W_)
         gn_partial = pg.alloc(n * chunks * max_c * 3)
 
-        def gn(x0, x1, hw, gamma, beta, eps):
-            c = x0.shape[-1] + (0 if x1 is None else x1.shape[-1])
-            coef = pg.alloc(n, 2, c)
-            pg.add("ldmk_gn_coef", p_(x0), x0.shape[-1], p_(x1), 0 if x1 is None else x1.shape[-1], n, hw, 32, eps,
-                   p_(gamma), p_(beta), p_(gn_partial), p_(coef))
-            return coef
-
-        def conv(x0, x1, wp, bias, h, w, coef=None, stride=1, upsample=False, batch_vec=None, bv_ld=0, residual=None,
-                 out=None):
-            c0 = x0.shape[-1]
-            c1 = 0 if x1 is None else x1.shape[-1]
-            cout = wp.shape[1]
-            oh, ow = (2 * h, 2 * w) if upsample else ((h - 1) // stride + 1, (w - 1) // stride + 1)
-            if out is None:
-                out = pg.alloc(n, oh, ow, cout)
-            a = ops.make_igemm_args(n * oh * ow, cout, 9 * (c0 + c1), x0, c0, wp, out, cout, oh * ow, a1=x1, c1=c1,
-                                    conv=(h, w, oh, ow, stride, 1, 1 if upsample else 0),
-                                    tf=L.TF_NONE if coef is None else L.TF_AFFINE_SILU, tf_coef=coef, bias=bias,
-                                    residual=residual)
-            if batch_vec is not None:
-                a.batch_vec, a.batch_vec_ld = batch_vec, bv_ld
-            pg.igemm(a, pin)
-            return out
-
-        def lin(x0, wp, bias, rows_per_sample, x1=None, out=None, **kw):
-            M = x0.shape[0]
-            c0 = x0.shape[-1]
-            c1 = 0 if x1 is None else x1.shape[-1]
-            N = wp.shape[1]
-            geglu = kw.pop("geglu", False)
-            ncol = N // 2 if geglu else N
-            if out is None:
-                out = pg.alloc(M, ncol)
-            a = ops.make_igemm_args(M, N, c0 + c1, x0, c0, wp, out, ncol, rows_per_sample, a1=x1, c1=c1, bias=bias,
-                                    epi=L.EPI_GEGLU if geglu else L.EPI_NONE, **kw)
-            pg.igemm(a, pin)
-            return out
+        nb_ = NetBuilder(pg, n, pin, gn_partial)
+        gn, conv, lin = nb_.gn, nb_.conv, nb_.lin
 
         def res_block(prefix, m, x0, x1, h, w):
             hw = h * w
