@@ -225,18 +225,20 @@ class VQModelInterface(nn.Module):
     # ---- shared block emitters -----------------------------------------------------------------------
     def _resnet_block(self, nb, prefix, m, x, h, w):
         pg, P, sd, n = nb.pg, self._packed, self._sd, nb.n
-        c1 = nb.gn(x, None, h * w, sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"], 1e-6)
-        h1 = nb.conv(x, None, P[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], h, w, coef=c1)
-        pg.release(c1)
-        c2 = nb.gn(h1, None, h * w, sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"], 1e-6)
+        y1 = nb.gn_act(x, None, h * w, sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"], 1e-6)
+        h1 = nb.conv(y1.view(n, h, w, m.cin), None, P[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], h, w)
+        pg.release(y1)
+        y2 = nb.gn_act(h1, None, h * w, sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"], 1e-6)
+        pg.release(h1)
+        y2 = y2.view(n, h, w, m.cout)
         if m.cin != m.cout:
             sk = nb.lin(x.reshape(n * h * w, m.cin), P[prefix + "nin_shortcut.weight"], sd[prefix + "nin_shortcut.bias"],
                         h * w)
-            out = nb.conv(h1, None, P[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], h, w, coef=c2, residual=sk,
+            out = nb.conv(y2, None, P[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], h, w, residual=sk,
                           out=sk.view(n, h, w, m.cout))
         else:
-            out = nb.conv(h1, None, P[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], h, w, coef=c2, residual=x)
-        pg.release(c2, h1)
+            out = nb.conv(y2, None, P[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], h, w, residual=x)
+        pg.release(y2)
         return out
 
     def _attn(self, nb, prefix, m, x, h, w):

@@ -8,27 +8,24 @@
 //     pixel -> the im2col gather is 8 lanes x 16 B per row, fully coalesced;
 //   * A and B K-slices are staged through LDS (A transposed to [k][m] with an odd row stride so
 //     that the MFMA operand reads -- 32 consecutive m at fixed k -- and the staging writes are
-//     bank-conflict-free); register prefetch of slice i+1 overlaps the MFMAs of slice i;
-//   * GroupNorm(+SiLU) / LayerNorm are applied while staging A (the normalised tensor is never
+//     bank-conflict-free); the raw global loads of slice i+1 are issued before the MFMAs of slice i
+//     and only consumed (transformed + written to LDS) after them;
+//   * LayerNorm / GroupNorm-affine are applied while staging A (the normalised tensor is never
 //     written to HBM); channel-concat skip connections are two base pointers, never a copy;
 //     nearest-x2 upsampling and stride-2 / asymmetric padding are index arithmetic in the gather;
-//   * epilogue fuses bias, per-sample vector (timestep-embedding / 1-token cross-attention),
-//     residual and GEGLU;
-//   * tile shapes: 4 waves as WM x WN x WK, each wave TM x TN MFMA tiles of 32x32.  WK > 1 splits
-//     K inside the workgroup (partials reduced through LDS in a fixed order -> deterministic),
-//     which is what keeps 256 CUs busy on the 8x8-resolution layers (M = 64 rows per sample,
-//     K up to 9*1280).
+//   * epilogue fuses bias, per-sample vector (timestep embedding), residual and GEGLU;
+//   * tile shapes: 4 waves as WM x WN x WK, each wave TM x TN MFMA tiles of 32x32; the BN = 160
+//     family matches this UNet's channel counts (multiples of model_channels = 160) with no padded
+//     columns.  WK > 1 splits K inside the workgroup (LDS reduction), `splitk` > 1 splits K across
+//     workgroups (partial slabs + a reduce/epilogue kernel); both sum in a fixed order, so results
+//     are bitwise reproducible.  That is what keeps 256 CUs busy on the low-resolution layers
+//     (M = 64 rows per sample at 8x8, K up to 9*1280).
 #include "ldmk_common.h"
 
 namespace ldmk {
 
-struct RowInfo {   // decomposition of one A row (output pixel) handled by this thread
-  int n, oy, ox;
-  bool valid;
-};
-
 template <int TM, int TN, int WM, int WN, int WK, bool BT>
-__global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p) {
+__global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws) {
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int KC = 32 * WK;           // K elements staged per iteration
@@ -55,39 +52,52 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p) {
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (bid % tiles_m) * BM;
   const int n0 = (bid / tiles_m) * BN;
+  const int ks = blockIdx.y;            // cross-workgroup K split index
   const int bz = blockIdx.z;
 
   const float* __restrict__ a0 = p.a0 + (long long)bz * p.a_bstride;
   const float* __restrict__ a1 = p.a1;
   const float* __restrict__ wp = p.w + (long long)bz * p.w_bstride;
-  float* __restrict__ outp = p.out + (long long)bz * p.out_bstride;
-  const float* resp = p.residual ? p.residual + (long long)bz * p.out_bstride : nullptr;
 
   const int Cin = p.c0 + p.c1;
   const int cpt = Cin / 32;             // 32-channel sub-chunks per tap
   const int nkc = p.K / 32;             // total sub-chunks
-  const int iters = (nkc + WK - 1) / WK;
+  const int iters_all = (nkc + WK - 1) / WK;
+  const int it_per = (iters_all + splitk - 1) / splitk;
+  const int it_begin = ks * it_per;
+  const int it_end = min(iters_all, it_begin + it_per);
   const bool conv = p.a_mode == LDMK_A_CONV3X3;
   const int tf = p.a_tf;
 
-  // ---- per-thread A row bookkeeping (rows are fixed for the whole K loop)
+  // ---- per-thread A row bookkeeping (rows are fixed for the whole K loop); 32-bit element indices
   const int arow = tid >> 3;            // 0..31
   const int acol = (tid & 7) * 4;       // channel offset inside a 32-wide sub-chunk
-  RowInfo ri[AROWS];
+  int r_n[AROWS], r_y[AROWS], r_x[AROWS];
+  unsigned r_mask[AROWS];               // conv: bit t set <=> tap t reads inside the image
   float ln_mean[AROWS], ln_rstd[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
-    int m = m0 + arow + 32 * i;
-    ri[i].valid = m < p.M;
-    int mm = ri[i].valid ? m : 0;
-    ri[i].n = mm / p.rows_per_sample;
-    int pix = mm - ri[i].n * p.rows_per_sample;
+    const int m = m0 + arow + 32 * i;
+    const bool valid = m < p.M;
+    const int mm = valid ? m : 0;
+    r_n[i] = mm / p.rows_per_sample;
     if (conv) {
-      ri[i].oy = pix / p.out_w;
-      ri[i].ox = pix - ri[i].oy * p.out_w;
+      const int pix = mm - r_n[i] * p.rows_per_sample;
+      const int oy = pix / p.out_w, ox = pix - oy * p.out_w;
+      r_y[i] = oy * p.stride - p.pad_lo;
+      r_x[i] = ox * p.stride - p.pad_lo;
+      unsigned mask = 0;
+      const int lim_h = p.upsample ? 2 * p.in_h : p.in_h, lim_w = p.upsample ? 2 * p.in_w : p.in_w;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = r_y[i] + t / 3, ix = r_x[i] + t % 3;
+        if (valid && iy >= 0 && ix >= 0 && iy < lim_h && ix < lim_w) mask |= 1u << t;
+      }
+      r_mask[i] = mask;
     } else {
-      ri[i].oy = mm;  // row index for LDMK_A_ROWS
-      ri[i].ox = 0;
+      r_y[i] = mm;
+      r_x[i] = 0;
+      r_mask[i] = valid ? 1u : 0u;
     }
     if (tf == LDMK_TF_LAYERNORM) {
       ln_mean[i] = p.row_stats[2 * (long long)mm];
@@ -98,12 +108,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p) {
   float4 areg[WK][AROWS];
   float4 breg[WK][BROWS];
 
+  // raw global loads of one iteration's slices (no arithmetic on the data: nothing here waits for memory)
   auto load_slices = [&](int it) {
 #pragma unroll
     for (int j = 0; j < WK; ++j) {
       const int kc = it * WK + j;
       const bool kvalid = kc < nkc;
-      // ---------------- A
       int tap = 0, cc = kc;
       if (conv) { tap = kc / cpt; cc = kc - tap * cpt; }
       const int c = cc * 32 + acol;                 // channel in the (virtual) concat
@@ -112,57 +122,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p) {
       const int cs = second ? p.c1 : p.c0;
       const int cl = second ? c - p.c0 : c;
       const int dy = tap / 3, dx = tap - dy * 3;
-      float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = g4;
-      if (tf == LDMK_TF_LAYERNORM && kvalid) {
-        g4 = *reinterpret_cast<const float4*>(p.ln_gamma + c);
-        b4 = *reinterpret_cast<const float4*>(p.ln_beta + c);
-      }
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool ok = kvalid && ri[i].valid;
-        long long off = 0;
-        if (conv) {
-          int iy = ri[i].oy * p.stride + dy - p.pad_lo;
-          int ix = ri[i].ox * p.stride + dx - p.pad_lo;
-          if (p.upsample) {
-            ok = ok && iy >= 0 && ix >= 0 && iy < 2 * p.in_h && ix < 2 * p.in_w;
-            iy >>= 1; ix >>= 1;
+        if (kvalid && ((r_mask[i] >> tap) & 1u)) {
+          unsigned off;
+          if (conv) {
+            int iy = r_y[i] + dy, ix = r_x[i] + dx;
+            if (p.upsample) { iy >>= 1; ix >>= 1; }
+            off = ((unsigned)(r_n[i] * p.in_h + iy) * p.in_w + ix) * cs + cl;
           } else {
-            ok = ok && iy >= 0 && ix >= 0 && iy < p.in_h && ix < p.in_w;
+            off = (unsigned)r_y[i] * cs + cl;
           }
-          off = (((long long)ri[i].n * p.in_h + iy) * p.in_w + ix) * cs + cl;
-        } else {
-          off = (long long)ri[i].oy * cs + cl;
-        }
-        if (ok) {
           v = *reinterpret_cast<const float4*>(src + off);
-          if (tf == LDMK_TF_AFFINE || tf == LDMK_TF_AFFINE_SILU) {
-            const float* cf = p.tf_coef + ((long long)ri[i].n * 2) * Cin + c;
-            float4 sc = *reinterpret_cast<const float4*>(cf);
-            float4 sh = *reinterpret_cast<const float4*>(cf + Cin);
-            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-            v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-            if (tf == LDMK_TF_AFFINE_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-          } else if (tf == LDMK_TF_LAYERNORM) {
-            const float mu = ln_mean[i], rs = ln_rstd[i];
-            v.x = (v.x - mu) * rs * g4.x + b4.x; v.y = (v.y - mu) * rs * g4.y + b4.y;
-            v.z = (v.z - mu) * rs * g4.z + b4.z; v.w = (v.w - mu) * rs * g4.w + b4.w;
-          }
         }
         areg[j][i] = v;
       }
-      // ---------------- B
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (BT) {       // W given as [N][ldb]: rows n, contiguous k
-          int n = n0 + arow + 32 * i;
+          const int n = n0 + arow + 32 * i;
           if (kvalid && n < p.N) v = *reinterpret_cast<const float4*>(wp + (long long)n * p.ldb + kc * 32 + acol);
         } else {        // W given as [K][ldb]: rows k, contiguous n
-          int idx = tid + 256 * i;
-          int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
-          int n = n0 + n4 * 4;
+          const int idx = tid + 256 * i;
+          const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
+          const int n = n0 + n4 * 4;
           if (kvalid && n < p.N) v = *reinterpret_cast<const float4*>(wp + (long long)(kc * 32 + kk) * p.ldb + n);
         }
         breg[j][i] = v;
@@ -170,9 +155,44 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p) {
     }
   };
 
-  auto store_slices = [&]() {
+  // A-side prologue (norm) on the loaded registers, then registers -> LDS
+  auto store_slices = [&](int it) {
 #pragma unroll
     for (int j = 0; j < WK; ++j) {
+      if (tf != LDMK_TF_NONE) {
+        const int kc = it * WK + j;
+        int tap = 0, cc = kc;
+        if (conv) { tap = kc / cpt; cc = kc - tap * cpt; }
+        const int c = cc * 32 + acol;
+        if (kc < nkc) {
+          if (tf == LDMK_TF_LAYERNORM) {
+            const float4 g4 = *reinterpret_cast<const float4*>(p.ln_gamma + c);
+            const float4 b4 = *reinterpret_cast<const float4*>(p.ln_beta + c);
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) {
+              float4 v = areg[j][i];
+              const float mu = ln_mean[i], rs = ln_rstd[i];
+              v.x = (v.x - mu) * rs * g4.x + b4.x; v.y = (v.y - mu) * rs * g4.y + b4.y;
+              v.z = (v.z - mu) * rs * g4.z + b4.z; v.w = (v.w - mu) * rs * g4.w + b4.w;
+              areg[j][i] = (r_mask[i] & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) {
+              if ((r_mask[i] >> tap) & 1u) {     // padded taps stay exactly zero
+                const float* cf = p.tf_coef + ((long long)r_n[i] * 2) * Cin + c;
+                const float4 sc = *reinterpret_cast<const float4*>(cf);
+                const float4 sh = *reinterpret_cast<const float4*>(cf + Cin);
+                float4 v = areg[j][i];
+                v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+                v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                if (tf == LDMK_TF_AFFINE_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                areg[j][i] = v;
+              }
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         float* d = As + (j * 32 + acol) * ASTR + arow + 32 * i;
@@ -184,8 +204,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p) {
           float* d = Bs + (j * 32 + acol) * BSTR + arow + 32 * i;
           d[0] = breg[j][i].x; d[BSTR] = breg[j][i].y; d[2 * BSTR] = breg[j][i].z; d[3 * BSTR] = breg[j][i].w;
         } else {
-          int idx = tid + 256 * i;
-          int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
+          const int idx = tid + 256 * i;
+          const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
           *reinterpret_cast<float4*>(Bs + (j * 32 + kk) * BSTR + n4 * 4) = breg[j][i];
         }
       }
@@ -203,12 +223,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p) {
   const float* Aw = As + (wk * 32 + half) * ASTR + wm * (32 * TM) + l31;
   const float* Bw = Bs + (wk * 32 + half) * BSTR + wn * (32 * TN) + l31;
 
-  load_slices(0);
-  for (int it = 0; it < iters; ++it) {
+  if (it_begin < it_end) load_slices(it_begin);
+  for (int it = it_begin; it < it_end; ++it) {
     __syncthreads();                 // previous iteration's MFMA reads are done
-    store_slices();
+    store_slices(it);
     __syncthreads();
-    if (it + 1 < iters) load_slices(it + 1);   // in flight while the matrix cores work
+    if (it + 1 < it_end) load_slices(it + 1);   // in flight while the matrix cores work
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       float a[TM], b[TN];
@@ -257,6 +277,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p) {
   // ---- epilogue.  C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int rowbase = m0 + wm * (32 * TM);
   const int colbase = n0 + wn * (32 * TN);
+  if (splitk > 1) {   // raw partial slab [ks][M][N]; bias/residual/... happen in igemm_reduce_kernel
+    float* slab = ws + ((long long)bz * splitk + ks) * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = colbase + j * 32 + l31;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < p.M) slab[(long long)row * p.N + col] = acc[i][j][r];
+        }
+    }
+    return;
+  }
+  float* __restrict__ outp = p.out + (long long)bz * p.out_bstride;
+  const float* resp = p.residual ? p.residual + (long long)bz * p.out_bstride : nullptr;
   const float alpha = p.alpha;
   if (p.epi == LDMK_EPI_GEGLU) {
     if constexpr (TN % 2 == 0) {
@@ -271,11 +309,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (row < p.M) {
-              float v = acc[i][j][r] * alpha + bv;
-              float g = acc[i][j + 1][r] * alpha + bg;
-              float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));   // exact (erf) GELU
+              const float v = acc[i][j][r] * alpha + bv;
+              const float g = acc[i][j + 1][r] * alpha + bg;
+              const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));   // exact (erf) GELU
               outp[(long long)row * p.ldc + oc] = v * ge;
             }
           }
@@ -292,11 +330,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (row < p.M) {
           float v = acc[i][j][r] * alpha + bv;
           if (p.batch_vec) v += p.batch_vec[(long long)(row / p.rows_per_sample) * p.batch_vec_ld + col];
-          long long o = (long long)row * p.ldc + col;
+          const long long o = (long long)row * p.ldc + col;
           if (resp) v += resp[o];
           outp[o] = v;
         }
@@ -304,57 +342,129 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p) {
   }
 }
 
+// sum of the split-K slabs in a fixed order + the igemm epilogue (bias, per-sample vector, residual)
+__global__ __launch_bounds__(256) void igemm_reduce_kernel(const ldmk_igemm_args p, const int splitk,
+                                                           const float* __restrict__ ws) {
+  const int n4 = p.N / 4;
+  const long long total = (long long)p.M * n4;
+  const int bz = blockIdx.z;
+  const float* slab0 = ws + (long long)bz * splitk * p.M * p.N;
+  float* outp = p.out + (long long)bz * p.out_bstride;
+  const float* resp = p.residual ? p.residual + (long long)bz * p.out_bstride : nullptr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / n4);
+    const int col = (int)(i - (long long)row * n4) * 4;
+    float4 s = *reinterpret_cast<const float4*>(slab0 + (long long)row * p.N + col);
+    for (int k = 1; k < splitk; ++k) {
+      const float4 t = *reinterpret_cast<const float4*>(slab0 + ((long long)k * p.M + row) * p.N + col);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    s.x *= p.alpha; s.y *= p.alpha; s.z *= p.alpha; s.w *= p.alpha;
+    if (p.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    if (p.batch_vec) {
+      const float4 b = *reinterpret_cast<const float4*>(p.batch_vec + (long long)(row / p.rows_per_sample) * p.batch_vec_ld + col);
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    const long long o = (long long)row * p.ldc + col;
+    if (resp) {
+      const float4 b = *reinterpret_cast<const float4*>(resp + o);
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    *reinterpret_cast<float4*>(outp + o) = s;
+  }
+}
+
+struct TileCfg { int bm, bn, wk; bool even_tn; };
+static const TileCfg kCfg[] = {
+    {128, 128, 1, true},   // 1: <2,2,2,2,1>
+    {64, 128, 1, true},    // 2: <1,2,2,2,1>
+    {64, 64, 4, true},     // 3: <2,2,1,1,4>
+    {64, 64, 1, false},    // 4: <1,1,2,2,1>
+    {128, 160, 1, false},  // 5: <1,5,4,1,1>
+    {64, 160, 2, false},   // 6: <1,5,2,1,2>
+};
+constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
+
 template <int TM, int TN, int WM, int WN, int WK, bool BT>
-static int launch_cfg(const ldmk_igemm_args& a, hipStream_t st) {
+static int launch_cfg(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KC = 32 * WK;
   constexpr int ASTR = BM + 1, BSTR = BN + (BT ? 1 : 0);
   size_t stage = (size_t)KC * (ASTR + BSTR) * sizeof(float);
   size_t red = WK > 1 ? (size_t)(WK - 1) * WM * WN * TM * TN * 16 * 64 * sizeof(float) : 0;
   size_t lds = stage > red ? stage : red;
   int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  dim3 grid(tiles, 1, a.batch > 1 ? a.batch : 1);
+  dim3 grid(tiles, splitk, a.batch > 1 ? a.batch : 1);
   auto k = igemm_kernel<TM, TN, WM, WN, WK, BT>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, splitk, ws);
+  if (splitk > 1) {
+    long long total = (long long)a.M * (a.N / 4);
+    int g = (int)((total + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(igemm_reduce_kernel, dim3(g, 1, a.batch > 1 ? a.batch : 1), dim3(256), 0, st, a, splitk, ws);
+  }
   return check_launch("ldmk_igemm");
 }
 
-static int pick_config(const ldmk_igemm_args& a) {
+// Tile shape + cross-workgroup K split for a problem size.  Target: >= 2 workgroups per CU (512) with the
+// largest tile that reaches it; if even the smallest tile cannot, split K across workgroups.
+static void plan(const ldmk_igemm_args& a, int* cfg_out, int* splitk_out, long long ws_elems) {
   const long long b = a.batch > 1 ? a.batch : 1;
-  auto nb = [&](int bm, int bn) { return b * ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-  int cfg;
-  if (nb(128, 128) >= 384) cfg = 0;
-  else if (a.epi == LDMK_EPI_GEGLU) cfg = nb(64, 128) >= 256 ? 1 : 2;
-  else if (nb(64, 64) >= 384 || a.K < 512) cfg = 3;
-  else cfg = 2;
-  return cfg;
+  const bool geglu = a.epi == LDMK_EPI_GEGLU;
+  auto nb = [&](int c) { return b * ((a.M + kCfg[c].bm - 1) / kCfg[c].bm) * ((a.N + kCfg[c].bn - 1) / kCfg[c].bn); };
+  const bool fam160 = (a.N % 160 == 0) && !geglu;
+  const int order160[] = {4, 5, 3};          // indices into kCfg (0-based): 128x160, 64x160(sk2), 64x64
+  const int order128[] = {0, 1, 3};          // 128x128, 64x128, 64x64
+  const int order_geglu[] = {0, 1, 2};       // even TN only
+  const int* order = geglu ? order_geglu : (fam160 ? order160 : order128);
+  int cfg = order[2];
+  for (int i = 0; i < 3; ++i)
+    if (nb(order[i]) >= 512) { cfg = order[i]; break; }
+  int splitk = 1;
+  const long long blocks = nb(cfg);
+  if (blocks < 384 && !geglu && ws_elems > 0) {
+    const int nkc = a.K / 32;
+    int want = (int)((512 + blocks - 1) / blocks);
+    if (want > 8) want = 8;
+    const int iters = (nkc + kCfg[cfg].wk - 1) / kCfg[cfg].wk;
+    while (want > 1 && iters / want < 4) --want;          // keep >= 4 staged iterations per workgroup
+    while (want > 1 && b * want * (long long)a.M * a.N > ws_elems) --want;
+    splitk = want < 1 ? 1 : want;
+  }
+  *cfg_out = cfg + 1;
+  *splitk_out = splitk;
 }
 
 template <bool BT>
-static int dispatch(const ldmk_igemm_args& a, hipStream_t st, int force) {
-  int cfg = force >= 0 ? force : (a.tile_cfg > 0 ? a.tile_cfg - 1 : pick_config(a));
-  if (a.epi == LDMK_EPI_GEGLU && cfg == 3) cfg = 2;   // GEGLU needs an even number of N tiles per wave
+static int dispatch(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hipStream_t st) {
+  if (a.epi == LDMK_EPI_GEGLU && !kCfg[cfg - 1].even_tn) cfg = 3;   // GEGLU needs (value, gate) tile pairs
   switch (cfg) {
-    case 0: return launch_cfg<2, 2, 2, 2, 1, BT>(a, st);   // 128x128
-    case 1: return launch_cfg<1, 2, 2, 2, 1, BT>(a, st);   // 64x128
-    case 2: return launch_cfg<2, 2, 1, 1, 4, BT>(a, st);   // 64x64, K split over the 4 waves
-    default: return launch_cfg<1, 1, 2, 2, 1, BT>(a, st);  // 64x64
+    case 1: return launch_cfg<2, 2, 2, 2, 1, BT>(a, splitk, ws, st);   // 128x128
+    case 2: return launch_cfg<1, 2, 2, 2, 1, BT>(a, splitk, ws, st);   // 64x128
+    case 3: return launch_cfg<2, 2, 1, 1, 4, BT>(a, splitk, ws, st);   // 64x64, K split over the 4 waves
+    case 4: return launch_cfg<1, 1, 2, 2, 1, BT>(a, splitk, ws, st);   // 64x64
+    case 5: return launch_cfg<1, 5, 4, 1, 1, BT>(a, splitk, ws, st);   // 128x160
+    default: return launch_cfg<1, 5, 2, 1, 2, BT>(a, splitk, ws, st);  // 64x160, K split over wave pairs
   }
 }
 
 }  // namespace ldmk
 
-// test hook: force a tile configuration (-1 = heuristic)
-static int g_force_cfg = -1;
+// test hook: force a tile configuration (0 = heuristic)
+static int g_force_cfg = 0;
 extern "C" void ldmk_igemm_force_config(int cfg) { g_force_cfg = cfg; }
 
-extern "C" int ldmk_igemm_pick_config(const ldmk_igemm_args* args) {
-  if (!args) return LDMK_EINVAL;
-  return ldmk::pick_config(*args) + 1;
+extern "C" int ldmk_igemm_plan(const ldmk_igemm_args* args, int* tile_cfg, int* splitk) {
+  if (!args || !tile_cfg || !splitk) return LDMK_EINVAL;
+  ldmk::plan(*args, tile_cfg, splitk, args->splitk_ws ? args->splitk_ws_elems : 0);
+  return LDMK_OK;
 }
 
 extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) {
@@ -369,18 +479,35 @@ extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) {
   LDMK_REQUIRE(a.K == taps * (a.c0 + a.c1), "ldmk_igemm: K=%d != taps*(c0+c1)=%d", a.K, taps * (a.c0 + a.c1));
   LDMK_REQUIRE(a.N % 4 == 0 && a.ldb % 4 == 0, "ldmk_igemm: N and ldb must be multiples of 4");
   LDMK_REQUIRE(a.rows_per_sample > 0, "ldmk_igemm: rows_per_sample");
+  const long long samples = ((long long)a.M + a.rows_per_sample - 1) / a.rows_per_sample;
   if (a.a_mode == LDMK_A_CONV3X3) {
     LDMK_REQUIRE(a.in_h > 0 && a.in_w > 0 && a.out_h > 0 && a.out_w > 0 && a.stride >= 1, "ldmk_igemm: conv geometry");
     LDMK_REQUIRE(a.rows_per_sample == a.out_h * a.out_w, "ldmk_igemm: rows_per_sample != out_h*out_w");
     LDMK_REQUIRE(a.batch <= 1, "ldmk_igemm: batched conv unsupported");
+    LDMK_REQUIRE(samples * a.in_h * a.in_w * (a.c0 > a.c1 ? a.c0 : a.c1) < (1LL << 31),
+                 "ldmk_igemm: conv input exceeds 2^31 elements (32-bit gather indices)");
+  } else {
+    LDMK_REQUIRE((long long)a.M * (a.c0 > a.c1 ? a.c0 : a.c1) < (1LL << 31), "ldmk_igemm: A exceeds 2^31 elements per batch item");
   }
   if (a.a_tf == LDMK_TF_AFFINE || a.a_tf == LDMK_TF_AFFINE_SILU) LDMK_REQUIRE(a.tf_coef, "ldmk_igemm: tf_coef missing");
   if (a.a_tf == LDMK_TF_LAYERNORM) {
     LDMK_REQUIRE(a.row_stats && a.ln_gamma && a.ln_beta && a.a_mode == LDMK_A_ROWS, "ldmk_igemm: layernorm prologue args");
   }
   if (a.epi == LDMK_EPI_GEGLU) LDMK_REQUIRE(a.N % 64 == 0 && !a.residual && !a.batch_vec, "ldmk_igemm: GEGLU needs N%%64==0 and no residual");
-  LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= 4, "ldmk_igemm: tile_cfg=%d outside [0,4]", a.tile_cfg);
+  LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]", a.tile_cfg, kNumCfg);
+  LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 16, "ldmk_igemm: splitk=%d outside [0,16]", a.splitk);
   if (a.alpha == 0.f) a.alpha = 1.f;
+  int cfg = 0, sk = 1;
+  plan(a, &cfg, &sk, a.splitk_ws ? a.splitk_ws_elems : 0);
+  if (a.tile_cfg > 0) cfg = a.tile_cfg;
+  if (g_force_cfg > 0) cfg = g_force_cfg;
+  if (a.splitk > 0) sk = a.splitk;
+  if (a.epi == LDMK_EPI_GEGLU) sk = 1;
+  if (sk > 1) {
+    const long long b = a.batch > 1 ? a.batch : 1;
+    LDMK_REQUIRE(a.splitk_ws && b * sk * (long long)a.M * a.N <= a.splitk_ws_elems,
+                 "ldmk_igemm: splitk=%d needs a workspace of %lld floats", sk, b * sk * (long long)a.M * a.N);
+  }
   hipStream_t st = (hipStream_t)stream;
-  return a.b_trans ? dispatch<true>(a, st, g_force_cfg) : dispatch<false>(a, st, g_force_cfg);
+  return a.b_trans ? dispatch<true>(a, cfg, sk, a.splitk_ws, st) : dispatch<false>(a, cfg, sk, a.splitk_ws, st);
 }

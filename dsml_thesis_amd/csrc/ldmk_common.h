@@ -33,7 +33,8 @@ inline int check_launch(const char* what) {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x); v_exp + v_rcp (1 ulp each) instead of an IEEE division sequence
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // 64-lane butterfly reductions (wave = 64 on CDNA)
 __device__ __forceinline__ float wave_sum(float v) {

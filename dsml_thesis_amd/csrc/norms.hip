@@ -104,7 +104,44 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
   }
 }
 
+// y = act(x*scale + shift) over the channel concat x0|x1 -> one contiguous NHWC tensor (float4 lanes)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x0, int c0, const float* __restrict__ x1,
+                                                       int c1, const float* __restrict__ coef, float* __restrict__ y,
+                                                       int hw, int silu, long long total4) {
+  const int C = c0 + c1;
+  const int c4n = C / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / c4n;
+    const int c = (int)(i - row * c4n) * 4;
+    const int n = (int)(row / hw);
+    const float4 v = c < c0 ? *reinterpret_cast<const float4*>(x0 + row * c0 + c)
+                            : *reinterpret_cast<const float4*>(x1 + row * c1 + (c - c0));
+    const float* cf = coef + ((long long)n * 2) * C + c;
+    const float4 sc = *reinterpret_cast<const float4*>(cf);
+    const float4 sh = *reinterpret_cast<const float4*>(cf + C);
+    float4 o;
+    o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
+    if (silu) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
+    *reinterpret_cast<float4*>(y + row * C + c) = o;
+  }
+}
+
 }  // namespace ldmk
+
+extern "C" int ldmk_gn_apply(const float* x0, int c0, const float* x1, int c1, const float* coef, float* y, int n, int hw,
+                             int silu, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(x0 && coef && y && n > 0 && hw > 0 && c0 > 0, "ldmk_gn_apply: bad args");
+  LDMK_REQUIRE((c1 == 0) == (x1 == nullptr), "ldmk_gn_apply: x1/c1 mismatch");
+  LDMK_REQUIRE(c0 % 4 == 0 && c1 % 4 == 0, "ldmk_gn_apply: channel counts must be multiples of 4");
+  const long long total4 = (long long)n * hw * ((c0 + c1) / 4);
+  long long g = (total4 + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x0, c0, x1, c1, coef, y, hw,
+                     silu, total4);
+  return check_launch("ldmk_gn_apply");
+}
 
 extern "C" int ldmk_gn_chunks(int hw) { return (hw + ldmk::GN_PIX - 1) / ldmk::GN_PIX; }
 

@@ -54,8 +54,22 @@ class Conv1DTemporalAttention(nn.Module):
         self.attentionConvNet = nn.Sequential(*layers)
         self.attentionNet = nn.Sequential(nn.Linear(seq_len, seq_len, bias=True), nn.Softmax(dim=1))
 
+    @staticmethod
+    def _conv1d_k3(x, conv):
+        """Conv1d(k=3, pad=1) as unfold + one GEMM: bitwise run-to-run reproducible (MIOpen's conv1d picks its
+        algorithm by a first-call search and differs in the last bit between calls), same parameters/keys."""
+        b, cin, T = x.shape
+        xp = torch.nn.functional.pad(x, (1, 1))
+        cols = torch.stack([xp[:, :, k:k + T] for k in range(3)], dim=-1)          # (b, cin, T, 3)
+        cols = cols.permute(0, 2, 1, 3).reshape(b * T, cin * 3)
+        out = torch.nn.functional.linear(cols, conv.weight.reshape(conv.out_channels, cin * 3), conv.bias)
+        return out.view(b, T, conv.out_channels).transpose(1, 2)
+
     def forward(self, x):
         b = x.shape[0]
         xt = torch.transpose(x, 1, 2)
-        att = self.attentionNet(self.attentionConvNet(xt).view(b, self.seq_len)).view(b, self.seq_len, 1)
+        h = xt
+        for i in range(0, 10, 2):
+            h = torch.nn.functional.leaky_relu(self._conv1d_k3(h, self.attentionConvNet[i]), 0.02)
+        att = self.attentionNet(h.reshape(b, self.seq_len)).view(b, self.seq_len, 1)
         return torch.bmm(xt, att).view(b, self.subspace_dim).unsqueeze(1)

@@ -49,14 +49,35 @@ class Program:
     def add(self, name, *args, keep=None):
         self.calls.append((getattr(self.lib, name), args, keep, name))
 
-    def igemm(self, args, scale_m=None):
-        """scale_m = (num, den): pin the tile shape this GEMM would get at M*num/den rows, so that results
-        are bitwise independent of how a batch is split across calls / ranks (same K-summation order)."""
+    def splitk_workspace(self, elems):
+        """One scratch for split-K partial slabs, shared by every GEMM of the program (stream-ordered)."""
+        if getattr(self, "_skws", None) is None or self._skws.numel() < elems:
+            self._skws = torch.empty(int(elems), device=self.device, dtype=torch.float32)
+            self._all.append(self._skws)
+            for _, _, a, name in self.calls:          # re-point GEMMs recorded against an older scratch
+                if name == "ldmk_igemm":
+                    a.splitk_ws, a.splitk_ws_elems = self._skws.data_ptr(), self._skws.numel()
+        return self._skws
+
+    def igemm(self, args, scale_m=None, allow_splitk=True):
+        """Record a GEMM.  The (tile shape, K split) pair is planned here, once: for the real M, or -- with
+        scale_m = (num, den) -- for M*num/den rows, which pins the K-summation order so that results are
+        bitwise independent of how a batch is split across calls / ranks."""
+        m = args.M
         if scale_m is not None and scale_m[0] != scale_m[1]:
-            m = args.M
             args.M = max(1, m * scale_m[0] // scale_m[1])
-            args.tile_cfg = self.lib.ldmk_igemm_pick_config(C.byref(args))
-            args.M = m
+        cfg, sk = C.c_int(0), C.c_int(0)
+        if allow_splitk:
+            # plan against a generous virtual scratch, then size the real one to what was chosen
+            args.splitk_ws, args.splitk_ws_elems = 1, 1 << 40
+        self.lib.ldmk_igemm_plan(C.byref(args), C.byref(cfg), C.byref(sk))
+        args.M = m
+        args.tile_cfg, args.splitk = cfg.value, max(1, sk.value)
+        args.splitk_ws, args.splitk_ws_elems = 0, 0
+        if args.splitk > 1:
+            need = max(1, args.batch) * args.splitk * args.M * args.N
+            ws = self.splitk_workspace(need)
+            args.splitk_ws, args.splitk_ws_elems = ws.data_ptr(), ws.numel()
         self.calls.append((self.lib.ldmk_igemm, (C.byref(args),), args, "ldmk_igemm"))
 
     def run(self, stream=None):
@@ -88,6 +109,18 @@ class NetBuilder:
         pg.add("ldmk_gn_coef", p_(x0), c0, p_(x1), c1, self.n, hw, 32, eps, p_(gamma), p_(beta),
                p_(self.gn_partial), p_(coef))
         return coef
+
+    def gn_act(self, x0, x1, hw, gamma, beta, eps, silu=True):
+        """GroupNorm(32) [+SiLU] of (the concat of) NHWC tensors materialised once: statistics pass + one
+        elementwise pass.  Returns a contiguous [n*hw][C] tensor for the consumer GEMM to read raw."""
+        pg, p_ = self.pg, self.ptr
+        c0 = x0.shape[-1]
+        c1 = 0 if x1 is None else x1.shape[-1]
+        coef = self.gn(x0, x1, hw, gamma, beta, eps)
+        y = pg.alloc(self.n * hw, c0 + c1)
+        pg.add("ldmk_gn_apply", p_(x0), c0, p_(x1), c1, p_(coef), p_(y), self.n, hw, 1 if silu else 0)
+        pg.release(coef)
+        return y
 
     def conv(self, x0, x1, wp, bias, h, w, coef=None, stride=1, pad_lo=1, upsample=False, batch_vec=None, bv_ld=0,
              residual=None, out=None):

@@ -26,7 +26,8 @@ class IgemmArgs(C.Structure):
         ("residual", _fp), ("epi", C.c_int),
         ("out", _fp), ("ldc", C.c_int), ("batch", C.c_int),
         ("a_bstride", C.c_longlong), ("w_bstride", C.c_longlong), ("out_bstride", C.c_longlong),
-        ("alpha", C.c_float), ("tile_cfg", C.c_int),
+        ("alpha", C.c_float), ("tile_cfg", C.c_int), ("splitk", C.c_int),
+        ("splitk_ws", _fp), ("splitk_ws_elems", C.c_longlong),
     ]
 
 
@@ -34,11 +35,12 @@ _SIGS = {
     "ldmk_version": (C.c_int, []),
     "ldmk_last_error": (C.c_char_p, []),
     "ldmk_igemm": (C.c_int, [C.POINTER(IgemmArgs), _fp]),
-    "ldmk_igemm_pick_config": (C.c_int, [C.POINTER(IgemmArgs)]),
+    "ldmk_igemm_plan": (C.c_int, [C.POINTER(IgemmArgs), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ldmk_igemm_force_config": (None, [C.c_int]),
     "ldmk_gn_chunks": (C.c_int, [C.c_int]),
     "ldmk_gn_coef": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _fp]),
     "ldmk_ln_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp]),
+    "ldmk_gn_apply": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_attn_self": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_cross": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_float, _fp]),

@@ -74,6 +74,15 @@ def gn_coef(x0, x1, n, hw, gamma, beta, eps, groups=32, partial=None, coef=None)
     return coef
 
 
+def gn_apply(x0, x1, coef, n, hw, silu=True, out=None):
+    c0 = x0.shape[-1]
+    c1 = 0 if x1 is None else x1.shape[-1]
+    if out is None:
+        out = torch.empty(n * hw, c0 + c1, device=x0.device, dtype=torch.float32)
+    L.call("ldmk_gn_apply", _ptr(x0), c0, _ptr(x1), c1, _ptr(coef), _ptr(out), n, hw, 1 if silu else 0, stream())
+    return out
+
+
 def ln_stats(x2d, eps=1e-5, out=None):
     rows, c = x2d.shape
     if out is None:
@@ -86,7 +95,7 @@ def ln_stats(x2d, eps=1e-5, out=None):
 def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0, conv=None, tf=L.TF_NONE,
                     tf_coef=None, row_stats=None, ln_gamma=None, ln_beta=None, b_trans=False, ldb=None, bias=None,
                     batch_vec=None, batch_vec_ld=0, residual=None, epi=L.EPI_NONE, batch=1, a_bstride=0, w_bstride=0,
-                    out_bstride=0, alpha=1.0):
+                    out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None):
     a = L.IgemmArgs()
     a.M, a.N, a.K = M, N, K
     a.a0, a.a1, a.c0, a.c1 = _ptr(a0), _ptr(a1), c0, c1
@@ -105,6 +114,9 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
     a.out, a.ldc, a.batch = _ptr(out), ldc, batch
     a.a_bstride, a.w_bstride, a.out_bstride = a_bstride, w_bstride, out_bstride
     a.alpha = alpha
+    a.splitk = splitk
+    if splitk_ws is not None:
+        a.splitk_ws, a.splitk_ws_elems = splitk_ws.data_ptr(), splitk_ws.numel()
     return a
 
 

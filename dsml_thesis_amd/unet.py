@@ -332,22 +332,26 @@ class UNetModel(nn.Module):
 
         def res_block(prefix, m, x0, x1, h, w):
             hw = h * w
-            coef1 = gn(x0, x1, hw, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5)
+            # GroupNorm+SiLU materialised once (stats pass + one elementwise pass over the concat); the conv
+            # then reads it raw -- cheaper than re-normalising every element 9 x (N/tile) times in the gather
+            y1 = nb_.gn_act(x0, x1, hw, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5)
             bv = emb_all.data_ptr() + 4 * self._emb_off[prefix]
-            h1 = conv(x0, x1, P[prefix + "c1"], sd[prefix + "in_layers.2.bias"], h, w, coef=coef1, batch_vec=bv,
-                      bv_ld=self._emb_total)
-            pg.release(coef1)
-            coef2 = gn(h1, None, hw, sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"], 1e-5)
+            h1 = conv(y1.view(n, h, w, m.cin), None, P[prefix + "c1"], sd[prefix + "in_layers.2.bias"], h, w,
+                      batch_vec=bv, bv_ld=self._emb_total)
+            pg.release(y1)
+            y2 = nb_.gn_act(h1, None, hw, sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"], 1e-5)
+            pg.release(h1)
+            y2 = y2.view(n, h, w, m.cout)
             if m.cin != m.cout:
                 x0r = x0.reshape(n * hw, -1)
                 x1r = None if x1 is None else x1.reshape(n * hw, -1)
                 skip = lin(x0r, P[prefix + "skip"], sd[prefix + "skip_connection.bias"], hw, x1=x1r)
-                out = conv(h1, None, P[prefix + "c2"], sd[prefix + "out_layers.3.bias"], h, w, coef=coef2,
-                           residual=skip, out=skip.view(n, h, w, m.cout))
+                out = conv(y2, None, P[prefix + "c2"], sd[prefix + "out_layers.3.bias"], h, w, residual=skip,
+                           out=skip.view(n, h, w, m.cout))
             else:
                 assert x1 is None
-                out = conv(h1, None, P[prefix + "c2"], sd[prefix + "out_layers.3.bias"], h, w, coef=coef2, residual=x0)
-            pg.release(coef2, h1)
+                out = conv(y2, None, P[prefix + "c2"], sd[prefix + "out_layers.3.bias"], h, w, residual=x0)
+            pg.release(y2)
             return out
 
         def spatial_tf(prefix, m, x, h, w):

@@ -72,14 +72,17 @@ typedef struct ldmk_igemm_args {
   int batch;                 /* >1: batched GEMM over blockIdx.z with the strides below           */
   long long a_bstride, w_bstride, out_bstride;
   float alpha;               /* scale applied to the product before the epilogue (1.0 default)    */
-  int tile_cfg;              /* 0 = choose from the problem size; 1..4 = pin a tile shape (the K-summation
-                                order depends on the tile shape, so a caller that needs results that are
-                                bitwise independent of the batch size pins it, see ldmk_igemm_pick_config) */
+  int tile_cfg;              /* 0 = choose from the problem size; 1..6 = pin a tile shape.  The K-summation
+                                order depends on (tile_cfg, splitk), so a caller that needs results that are
+                                bitwise independent of the batch size pins both (ldmk_igemm_plan)          */
+  int splitk;                /* 0 = choose; 1 = none; 2..16 = split K over that many workgroups            */
+  float* splitk_ws;          /* scratch for split-K partial slabs (batch*splitk*M*N floats) or NULL        */
+  long long splitk_ws_elems; /* capacity of splitk_ws in floats                                           */
 } ldmk_igemm_args;
 
 int ldmk_igemm(const ldmk_igemm_args* args, void* stream);
-/* the tile shape (1..4) ldmk_igemm would choose for these sizes; only M, N, K, epi, batch are read */
-int ldmk_igemm_pick_config(const ldmk_igemm_args* args);
+/* the (tile_cfg, splitk) ldmk_igemm would choose for these sizes; reads M, N, K, epi, batch, splitk_ws* */
+int ldmk_igemm_plan(const ldmk_igemm_args* args, int* tile_cfg, int* splitk);
 
 /* ------------------------------------------------------------------------------------------
  * Normalisation statistics (HBM-bound, wave-shuffle reductions).
@@ -94,6 +97,12 @@ int ldmk_gn_chunks(int hw);
 int ldmk_gn_coef(const float* x0, int c0, const float* x1, int c1, int n, int hw, int groups, float eps,
                  const float* gamma, const float* beta, float* partial, float* coef, void* stream);
 int ldmk_ln_stats(const float* x, int rows, int c, float eps, float* stats, void* stream);
+/* ldmk_gn_apply: y[n][hw][c0+c1] = act(x*scale + shift) with the planes of ldmk_gn_coef, reading the
+ *   (virtual) channel concat of x0|x1 and writing one contiguous NHWC tensor; silu != 0 applies SiLU
+ *   (openaimodel.py:201-203, model.py:118-131).  One HBM-bound pass: each element is normalised once
+ *   instead of 9 x (N / tile) times inside the following 3x3 convolution's operand staging. */
+int ldmk_gn_apply(const float* x0, int c0, const float* x1, int c1, const float* coef, float* y, int n, int hw,
+                  int silu, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Attention.

@@ -91,7 +91,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
 def test_conv3x3(ops, case, cfg):
     from dsml_thesis_amd import lib
     n, cin, cout, h, w, stride, up, pad_lo = case
@@ -107,9 +107,42 @@ def test_conv3x3(ops, case, cfg):
     try:
         y = ops.conv3x3(nhwc(x), ops.pack_conv3x3(wt.cuda()), b.cuda(), stride=stride, pad_lo=pad_lo, upsample=up)
     finally:
-        lib.load().ldmk_igemm_force_config(-1)
+        lib.load().ldmk_igemm_force_config(0)
     assert tuple(y.shape) == (n, ref.shape[2], ref.shape[3], cout)
     close(nchw(y), ref, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("splitk", [2, 3, 8])
+def test_conv3x3_split_k_reduce(ops, splitk):
+    n, cin, cout, h, w = 2, 640, 640, 8, 8
+    x, wt, b = rnd(10, n, cin, h, w), rnd(11, cout, cin, 3, 3) / np.sqrt(9 * cin), 0.1 * rnd(12, cout)
+    vec, res = rnd(13, n, cout), rnd(14, n, cout, h, w)
+    ref = F.conv2d(x, wt, b, padding=1) + vec[:, :, None, None] + res
+    ws = torch.empty(splitk * n * h * w * cout, device="cuda")
+    out = torch.empty(n, h, w, cout, device="cuda")
+    xd, wd, bd, vd, rd = nhwc(x), ops.pack_conv3x3(wt.cuda()), b.cuda(), vec.cuda(), nhwc(res)   # keep alive: raw pointers
+    a = ops.make_igemm_args(n * h * w, cout, 9 * cin, xd, cin, wd, out, cout, h * w,
+                            conv=(h, w, h, w, 1, 1, 0), bias=bd, batch_vec=vd, batch_vec_ld=cout,
+                            residual=rd, splitk=splitk, splitk_ws=ws)
+    ops.igemm(a)
+    close(nchw(out), ref, 1e-4, 1e-4)
+    out2 = torch.empty_like(out)
+    a.out = out2.data_ptr()
+    ops.igemm(a)
+    assert torch.equal(out, out2), "split-K partials are summed in a fixed order"
+
+
+def test_gn_apply_concat(ops):
+    n, c0, c1, h, w = 2, 320, 160, 8, 8
+    x = rnd(20, n, c0 + c1, h, w) * 1.3 + 0.2
+    gamma, beta = 1 + 0.1 * rnd(21, c0 + c1), 0.1 * rnd(22, c0 + c1)
+    xs = nhwc(x)
+    x0, x1 = xs[..., :c0].contiguous(), xs[..., c0:].contiguous()
+    coef = ops.gn_coef(x0, x1, n, h * w, gamma.cuda(), beta.cuda(), 1e-5)
+    y = ops.gn_apply(x0, x1, coef, n, h * w, silu=True).view(n, h, w, c0 + c1)
+    close(nchw(y), F.silu(F.group_norm(x, 32, gamma, beta, 1e-5)), 1e-5, 2e-5)
+    y = ops.gn_apply(x0, x1, coef, n, h * w, silu=False).view(n, h, w, c0 + c1)
+    close(nchw(y), F.group_norm(x, 32, gamma, beta, 1e-5), 1e-5, 2e-5)
 
 
 def test_conv3x3_golden_and_fused_prologue_epilogue(ops):
