@@ -24,11 +24,12 @@
 
 namespace ldmk {
 
-template <int TM, int TN, int WM, int WN, int WK, bool BT>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool BT>
 __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws) {
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
-  constexpr int KC = 32 * WK;           // K elements staged per iteration
+  constexpr int NS = WK * KS;           // 32-wide K slices staged per iteration (KS per wave-group)
+  constexpr int KC = 32 * NS;           // K elements staged per iteration
   constexpr int ASTR = BM + 1;          // odd stride: conflict-free transposed writes + reads
   constexpr int BSTR = BN + (BT ? 1 : 0);
   constexpr int AROWS = BM / 32;        // float4 per thread per 32-wide K sub-chunk (A)
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   const int Cin = p.c0 + p.c1;
   const int cpt = Cin / 32;             // 32-channel sub-chunks per tap
   const int nkc = p.K / 32;             // total sub-chunks
-  const int iters_all = (nkc + WK - 1) / WK;
+  const int iters_all = (nkc + NS - 1) / NS;
   const int it_per = (iters_all + splitk - 1) / splitk;
   const int it_begin = ks * it_per;
   const int it_end = min(iters_all, it_begin + it_per);
@@ -105,14 +106,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
     }
   }
 
-  float4 areg[WK][AROWS];
-  float4 breg[WK][BROWS];
+  float4 areg[NS][AROWS];
+  float4 breg[NS][BROWS];
 
   // raw global loads of one iteration's slices (no arithmetic on the data: nothing here waits for memory)
   auto load_slices = [&](int it) {
 #pragma unroll
-    for (int j = 0; j < WK; ++j) {
-      const int kc = it * WK + j;
+    for (int j = 0; j < NS; ++j) {
+      const int kc = it * NS + j;
       const bool kvalid = kc < nkc;
       int tap = 0, cc = kc;
       if (conv) { tap = kc / cpt; cc = kc - tap * cpt; }
@@ -158,9 +159,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   // A-side prologue (norm) on the loaded registers, then registers -> LDS
   auto store_slices = [&](int it) {
 #pragma unroll
-    for (int j = 0; j < WK; ++j) {
+    for (int j = 0; j < NS; ++j) {
       if (tf != LDMK_TF_NONE) {
-        const int kc = it * WK + j;
+        const int kc = it * NS + j;
         int tap = 0, cc = kc;
         if (conv) { tap = kc / cpt; cc = kc - tap * cpt; }
         const int c = cc * 32 + acol;
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const float* Aw = As + (wk * 32 + half) * ASTR + wm * (32 * TM) + l31;
-  const float* Bw = Bs + (wk * 32 + half) * BSTR + wn * (32 * TN) + l31;
+  const float* Aw = As + (wk * KS * 32 + half) * ASTR + wm * (32 * TM) + l31;
+  const float* Bw = Bs + (wk * KS * 32 + half) * BSTR + wn * (32 * TN) + l31;
 
   if (it_begin < it_end) load_slices(it_begin);
   for (int it = it_begin; it < it_end; ++it) {
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
     __syncthreads();
     if (it + 1 < it_end) load_slices(it + 1);   // in flight while the matrix cores work
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < 16 * KS; ++s) {
       float a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = Aw[2 * s * ASTR + i * 32];
@@ -377,27 +378,28 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const ldmk_igemm_args
   }
 }
 
-struct TileCfg { int bm, bn, wk; bool even_tn; };
+struct TileCfg { int bm, bn, ns; bool even_tn; float eff; };
+// eff: measured sustained fraction of the f32 MFMA peak on long-K problems (profiles/r01_layers*_v2.txt)
 static const TileCfg kCfg[] = {
-    {128, 128, 1, true},   // 1: <2,2,2,2,1>
-    {64, 128, 1, true},    // 2: <1,2,2,2,1>
-    {64, 64, 4, true},     // 3: <2,2,1,1,4>
-    {64, 64, 1, false},    // 4: <1,1,2,2,1>
-    {128, 160, 1, false},  // 5: <1,5,4,1,1>
-    {64, 160, 2, false},   // 6: <1,5,2,1,2>
+    {128, 128, 1, true, 0.60f},   // 1: <2,2,2,2,1,1>
+    {64, 128, 2, true, 0.58f},    // 2: <1,2,2,2,1,2>
+    {64, 64, 4, true, 0.45f},     // 3: <2,2,1,1,4,1>
+    {64, 64, 2, false, 0.52f},    // 4: <1,1,2,2,1,2>
+    {128, 160, 1, false, 0.76f},  // 5: <1,5,4,1,1,1>
+    {64, 160, 2, false, 0.62f},   // 6: <1,5,2,1,2,1>
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
-template <int TM, int TN, int WM, int WN, int WK, bool BT>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool BT>
 static int launch_cfg(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KC = 32 * WK;
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KC = 32 * WK * KS;
   constexpr int ASTR = BM + 1, BSTR = BN + (BT ? 1 : 0);
   size_t stage = (size_t)KC * (ASTR + BSTR) * sizeof(float);
   size_t red = WK > 1 ? (size_t)(WK - 1) * WM * WN * TM * TN * 16 * 64 * sizeof(float) : 0;
   size_t lds = stage > red ? stage : red;
   int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles, splitk, a.batch > 1 ? a.batch : 1);
-  auto k = igemm_kernel<TM, TN, WM, WN, WK, BT>;
+  auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, BT>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -413,45 +415,49 @@ static int launch_cfg(const ldmk_igemm_args& a, int splitk, float* ws, hipStream
   return check_launch("ldmk_igemm");
 }
 
-// Tile shape + cross-workgroup K split for a problem size.  Target: >= 2 workgroups per CU (512) with the
-// largest tile that reaches it; if even the smallest tile cannot, split K across workgroups.
+// Tile shape + cross-workgroup K split for a problem size: maximise (tile efficiency) x (useful columns)
+// x (occupancy of 512 workgroup slots = 2 per CU, counting whole rounds); splitting K costs one extra
+// pass over the partial slabs.
 static void plan(const ldmk_igemm_args& a, int* cfg_out, int* splitk_out, long long ws_elems) {
   const long long b = a.batch > 1 ? a.batch : 1;
   const bool geglu = a.epi == LDMK_EPI_GEGLU;
-  auto nb = [&](int c) { return b * ((a.M + kCfg[c].bm - 1) / kCfg[c].bm) * ((a.N + kCfg[c].bn - 1) / kCfg[c].bn); };
-  const bool fam160 = (a.N % 160 == 0) && !geglu;
-  const int order160[] = {4, 5, 3};          // indices into kCfg (0-based): 128x160, 64x160(sk2), 64x64
-  const int order128[] = {0, 1, 3};          // 128x128, 64x128, 64x64
-  const int order_geglu[] = {0, 1, 2};       // even TN only
-  const int* order = geglu ? order_geglu : (fam160 ? order160 : order128);
-  int cfg = order[2];
-  for (int i = 0; i < 3; ++i)
-    if (nb(order[i]) >= 512) { cfg = order[i]; break; }
-  int splitk = 1;
-  const long long blocks = nb(cfg);
-  if (blocks < 384 && !geglu && ws_elems > 0) {
-    const int nkc = a.K / 32;
-    int want = (int)((512 + blocks - 1) / blocks);
-    if (want > 8) want = 8;
-    const int iters = (nkc + kCfg[cfg].wk - 1) / kCfg[cfg].wk;
-    while (want > 1 && iters / want < 4) --want;          // keep >= 4 staged iterations per workgroup
-    while (want > 1 && b * want * (long long)a.M * a.N > ws_elems) --want;
-    splitk = want < 1 ? 1 : want;
+  const int nkc = a.K / 32;
+  float best = -1.f;
+  int best_cfg = 3, best_sk = 1;
+  static const int sks[] = {1, 2, 3, 4, 6, 8};
+  for (int c = 0; c < kNumCfg; ++c) {
+    if (geglu && !kCfg[c].even_tn) continue;
+    const long long tm = (a.M + kCfg[c].bm - 1) / kCfg[c].bm, tn = (a.N + kCfg[c].bn - 1) / kCfg[c].bn;
+    const long long blocks = b * tm * tn;
+    const float col_use = (float)a.N / (float)(tn * kCfg[c].bn);
+    const float row_use = (float)a.M / (float)(tm * kCfg[c].bm);
+    const int iters = (nkc + kCfg[c].ns - 1) / kCfg[c].ns;
+    for (int si = 0; si < 6; ++si) {
+      const int sk = sks[si];
+      if (sk > 1 && (geglu || ws_elems <= 0 || iters / sk < 4 || b * sk * (long long)a.M * a.N > ws_elems)) continue;
+      const long long w = blocks * sk;
+      const long long rounds = (w + 511) / 512;
+      const float occ = (float)w / (float)(rounds * 512);
+      // short K: the per-workgroup prologue/epilogue weighs more on big tiles
+      const float kpen = (float)(iters / sk) / (float)(iters / sk + 2);
+      const float score = kCfg[c].eff * col_use * row_use * occ * kpen * (sk > 1 ? 0.93f : 1.f);
+      if (score > best) { best = score; best_cfg = c; best_sk = sk; }
+    }
   }
-  *cfg_out = cfg + 1;
-  *splitk_out = splitk;
+  *cfg_out = best_cfg + 1;
+  *splitk_out = best_sk;
 }
 
 template <bool BT>
 static int dispatch(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hipStream_t st) {
   if (a.epi == LDMK_EPI_GEGLU && !kCfg[cfg - 1].even_tn) cfg = 3;   // GEGLU needs (value, gate) tile pairs
   switch (cfg) {
-    case 1: return launch_cfg<2, 2, 2, 2, 1, BT>(a, splitk, ws, st);   // 128x128
-    case 2: return launch_cfg<1, 2, 2, 2, 1, BT>(a, splitk, ws, st);   // 64x128
-    case 3: return launch_cfg<2, 2, 1, 1, 4, BT>(a, splitk, ws, st);   // 64x64, K split over the 4 waves
-    case 4: return launch_cfg<1, 1, 2, 2, 1, BT>(a, splitk, ws, st);   // 64x64
-    case 5: return launch_cfg<1, 5, 4, 1, 1, BT>(a, splitk, ws, st);   // 128x160
-    default: return launch_cfg<1, 5, 2, 1, 2, BT>(a, splitk, ws, st);  // 64x160, K split over wave pairs
+    case 1: return launch_cfg<2, 2, 2, 2, 1, 1, BT>(a, splitk, ws, st);   // 128x128
+    case 2: return launch_cfg<1, 2, 2, 2, 1, 2, BT>(a, splitk, ws, st);   // 64x128, 64 k per stage
+    case 3: return launch_cfg<2, 2, 1, 1, 4, 1, BT>(a, splitk, ws, st);   // 64x64, K split over the 4 waves
+    case 4: return launch_cfg<1, 1, 2, 2, 1, 2, BT>(a, splitk, ws, st);   // 64x64, 64 k per stage
+    case 5: return launch_cfg<1, 5, 4, 1, 1, 1, BT>(a, splitk, ws, st);   // 128x160
+    default: return launch_cfg<1, 5, 2, 1, 2, 1, BT>(a, splitk, ws, st);  // 64x160, K split over wave pairs
   }
 }
 

@@ -4,7 +4,7 @@
 
 namespace ldmk {
 
-constexpr int GN_PIX = 64;   // pixels per partial-sum chunk
+constexpr int GN_PIX = 16;   // pixels per partial-sum chunk (short dependent chains, many workgroups)
 
 // pass 1: per-(sample, chunk, channel) sum and sum of squares.  Thread <-> channel, so a wave reads
 // 64 consecutive floats of one NHWC pixel row: fully coalesced, also across the concat seam.

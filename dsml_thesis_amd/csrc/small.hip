@@ -14,16 +14,20 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// out[b][n] = sum_k act(x[b][k]) * W[k][n] + bias[n].  Thread <-> output column (coalesced W rows),
-// up to DS_ROWS batch rows accumulated per thread; x rows staged in LDS and broadcast.
-constexpr int DS_ROWS = 8;
-constexpr int DS_KT = 256;
+// out[b][n] = sum_k act(x[b][k]) * W[k][n] + bias[n]   (weight-bandwidth bound: W is read once).
+// Workgroup = 64 output columns x 4 K-quarters (one wave each, coalesced 256-B rows of W); up to
+// DS_ROWS batch rows accumulate in registers against x rows broadcast from LDS; the four K-quarter
+// partials are summed through LDS in a fixed order.
+constexpr int DS_ROWS = 16;
+constexpr int DS_KT = 512;
 __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ out, int ldo, int rows, int K, int N,
                                                           int silu_in) {
   __shared__ float xs[DS_ROWS][DS_KT];
-  const int n = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[3][DS_ROWS][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
   const int r0 = blockIdx.y * DS_ROWS;
   const int nr = min(DS_ROWS, rows - r0);
   float acc[DS_ROWS];
@@ -33,7 +37,7 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
     const int kn = min(DS_KT, K - k0);
     __syncthreads();
     for (int i = threadIdx.x; i < DS_ROWS * DS_KT; i += 256) {
-      int r = i / DS_KT, kk = i - r * DS_KT;
+      const int r = i / DS_KT, kk = i - r * DS_KT;
       float v = 0.f;
       if (r < nr && kk < kn) {
         v = x[(long long)(r0 + r) * ldx + k0 + kk];
@@ -43,17 +47,26 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
     }
     __syncthreads();
     if (n < N) {
-      const float* wp = w + (long long)k0 * N + n;
-      for (int kk = 0; kk < kn; ++kk) {
-        const float wv = wp[(long long)kk * N];
+      const int q = (kn + 3) / 4;
+      const int kb = wave * q, ke = min(kn, kb + q);
+      const float* wp = w + (long long)(k0 + kb) * N + n;
+      for (int kk = kb; kk < ke; ++kk) {
+        const float wv = *wp;
+        wp += N;
 #pragma unroll
         for (int r = 0; r < DS_ROWS; ++r) acc[r] = fmaf(xs[r][kk], wv, acc[r]);
       }
     }
   }
-  if (n < N) {
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < DS_ROWS; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0 && n < N) {
     const float bv = bias ? bias[n] : 0.f;
-    for (int r = 0; r < nr; ++r) out[(long long)(r0 + r) * ldo + n] = acc[r] + bv;
+    for (int r = 0; r < nr; ++r)
+      out[(long long)(r0 + r) * ldo + n] = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane] + bv;
   }
 }
 
@@ -316,7 +329,7 @@ extern "C" int ldmk_dense_small(const float* x, int ldx, const float* w, const f
   LDMK_ENTER();
   LDMK_REQUIRE(x && w && out && rows > 0 && K > 0 && N > 0, "ldmk_dense_small: bad args");
   LDMK_REQUIRE(ldx >= K && ldo >= N, "ldmk_dense_small: leading dims");
-  dim3 grid((N + 255) / 256, (rows + DS_ROWS - 1) / DS_ROWS);
+  dim3 grid((N + 63) / 64, (rows + DS_ROWS - 1) / DS_ROWS);
   hipLaunchKernelGGL(dense_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, out, ldo, rows, K, N,
                      silu_in);
   return check_launch("ldmk_dense_small");

@@ -381,8 +381,8 @@ class UNetModel(nn.Module):
                     cvec = ctx_pg.alloc(n, C_)
                     ctx_pg.add("ldmk_dense_small", p_(v), C_, p_(P[q + "o2"]), p_(sd[q + "attn2.to_out.0.bias"]), p_(cvec),
                                C_, n, C_, C_, 0)
-                    h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur)
-                    pg.add("ldmk_add_rowvec", p_(h1), p_(cvec), C_, rows, C_, hw)
+                    h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur,
+                             batch_vec=cvec, batch_vec_ld=C_)      # + the per-sample cross-attention vector
                     pg.release(att)
                     h2 = h1
                 else:
