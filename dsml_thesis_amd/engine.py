@@ -63,15 +63,18 @@ class Program:
         """Record a GEMM.  The (tile shape, K split) pair is planned here, once: for the real M, or -- with
         scale_m = (num, den) -- for M*num/den rows, which pins the K-summation order so that results are
         bitwise independent of how a batch is split across calls / ranks."""
-        m = args.M
+        m, nbatch = args.M, args.batch
         if scale_m is not None and scale_m[0] != scale_m[1]:
-            args.M = max(1, m * scale_m[0] // scale_m[1])
+            if nbatch > 1:        # batched GEMM (one problem per sample): the job-wide view has more problems
+                args.batch = max(1, nbatch * scale_m[0] // scale_m[1])
+            else:
+                args.M = max(1, m * scale_m[0] // scale_m[1])
         cfg, sk = C.c_int(0), C.c_int(0)
         if allow_splitk:
             # plan against a generous virtual scratch, then size the real one to what was chosen
             args.splitk_ws, args.splitk_ws_elems = 1, 1 << 40
         self.lib.ldmk_igemm_plan(C.byref(args), C.byref(cfg), C.byref(sk))
-        args.M = m
+        args.M, args.batch = m, nbatch
         args.tile_cfg, args.splitk = cfg.value, max(1, sk.value)
         args.splitk_ws, args.splitk_ws_elems = 0, 0
         if args.splitk > 1:

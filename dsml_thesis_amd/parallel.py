@@ -1,0 +1,87 @@
+"""Multi-GPU sampling: one process per GPU (torchrun), independent samples / clip frames sharded over
+ranks, ONE collective at the end (RCCL all-gather of the decoded frames over xGMI; gloo on CPU for tests).
+
+The reference has no collective on the sampling path (scripts are single-GPU,
+`CUDA_VISIBLE_DEVICES=$1 python ...`, talking_face/sample.sh:27); sharding is legal because no op of the
+UNet / VQGAN mixes batch items (GroupNorm and attention are per sample).  Per-item start noise is derived from
+(seed, global item index), never from the rank, so results do not depend on the number of GPUs; with
+`policy_batch = global batch` the GEMM tile shapes (hence the K-summation order) are pinned too and the
+sharded result is bitwise equal to the single-GPU one.
+"""
+import numpy as np
+import torch
+
+
+def shard_range(n_items, world_size, rank):
+    """Contiguous partition: rank r owns [r*ceil(N/G), min(N, (r+1)*ceil(N/G)))  (SURVEY §8e)."""
+    per = -(-n_items // world_size)
+    lo = min(n_items, rank * per)
+    hi = min(n_items, lo + per)
+    return lo, hi
+
+
+def item_noise(seed, index, shape):
+    """Start noise of global item `index`: RandomState(seed, index) -> independent of the sharding."""
+    rs = np.random.RandomState([seed & 0x7FFFFFFF, int(index)])
+    return torch.from_numpy(rs.standard_normal(tuple(shape)).astype(np.float32))
+
+
+def batch_noise(seed, lo, hi, shape):
+    if hi <= lo:
+        return torch.empty((0,) + tuple(shape))
+    return torch.stack([item_noise(seed, i, shape) for i in range(lo, hi)])
+
+
+def all_gather_items(local, n_items, group=None):
+    """Gather the per-rank item blocks (dim 0) into the full [n_items, ...] tensor on every rank with a single
+    all_gather (ranks pad to the common block size; the tail is trimmed)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local[:n_items]
+    world = dist.get_world_size(group)
+    per = -(-n_items // world)
+    pad = per - local.shape[0]
+    if pad > 0:
+        local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))])
+    out = local.new_empty((world * per,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out[:n_items]
+
+
+@torch.no_grad()
+def sample_sharded(sampler, S, n_items, shape, conditioning_fn, seed=0, eta=0.0, decode=True, use_graph=True,
+                   rank=0, world_size=1, group=None, postprocess=True, _noise_offset=0, _policy_items=None,
+                   **sample_kw):
+    """Sample `n_items` independent items (class-conditional faces or fixed-identity clip frames) across ranks.
+
+    conditioning_fn(lo, hi) -> conditioning for global items [lo, hi) (tensor or the TF dict).
+    Returns the gathered frames (n_items, H, W, 3) in [0,1] (or latents when decode=False) on every rank.
+    """
+    from . import ops
+    lo, hi = shard_range(n_items, world_size, rank)
+    model = sampler.model
+    dev = model.device
+    policy = _policy_items or n_items          # (test hook: emulate one rank's block of a larger job)
+    if hi > lo:
+        x_T = batch_noise(seed, _noise_offset + lo, _noise_offset + hi, shape).to(dev)
+        z, _ = sampler.sample(S, hi - lo, list(shape), conditioning_fn(lo, hi), eta=eta, x_T=x_T, verbose=False,
+                              use_graph=use_graph, policy_batch=policy, **sample_kw)
+        if decode:
+            model.first_stage_model.policy_batch = policy
+            out = model.decode_first_stage(z)
+            out = ops.postprocess_frames(out) if postprocess else out
+        else:
+            out = z
+    else:
+        out = None
+    if world_size > 1:
+        import torch.distributed as dist
+        # every rank must contribute a block of the common shape, also an idle one
+        probe = torch.zeros(8, dtype=torch.int64, device=dev)
+        if out is not None:
+            probe[:out.dim()] = torch.tensor(out.shape, device=dev)
+        dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
+        tail = tuple(int(v) for v in probe[1:] if v > 0)
+        if out is None:
+            out = torch.zeros((0,) + tail, device=dev)
+    return all_gather_items(out, n_items, group=group)

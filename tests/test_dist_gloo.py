@@ -1,0 +1,56 @@
+"""CPU, world_size 2 (gloo): the N>1 path -- partition, rank-independent noise, single all-gather, and the
+bench's max-over-ranks timing reduction.  The sampler itself needs a GPU, so a deterministic stand-in with the
+same (per-item independent) contract produces the per-rank blocks."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_frames(x_T):
+    # per-item function (no cross-item mixing), like the real sampler + decoder
+    return torch.tanh(x_T * 0.5 + x_T.flatten(1).mean(1).view(-1, 1, 1, 1)).permute(0, 2, 3, 1).contiguous()
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dsml_thesis_amd.parallel import all_gather_items, batch_noise, shard_range
+    lo, hi = shard_range(n_items, world, rank)
+    local = _fake_frames(batch_noise(5, lo, hi, (3, 8, 8))) if hi > lo else torch.zeros(0, 8, 8, 3)
+    full = all_gather_items(local, n_items)
+    t = torch.tensor([0.010 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        q.put((full, t.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [6, 5, 1])
+def test_sharded_equals_unsharded_world2(n_items):
+    from dsml_thesis_amd.parallel import batch_noise
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    full, tmax = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _fake_frames(batch_noise(5, 0, n_items, (3, 8, 8)))
+    assert full.shape == ref.shape and torch.equal(full, ref)
+    assert abs(tmax - 0.020) < 1e-12

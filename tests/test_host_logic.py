@@ -1,0 +1,100 @@
+"""CPU: host-side logic of the product package (no kernels run): schedules against the reference's golden
+tables, the config factory mapping, state-dict key compatibility, sharding arithmetic, loud failure without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import weights as W
+
+
+def test_schedule_tables_match_reference_goldens():
+    from dsml_thesis_amd import schedule as S
+    g = golden("g1_schedules.npz")
+    bufs = S.schedule_buffers(S.make_beta_schedule("linear", 1000, linear_start=0.0015, linear_end=0.0205))
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+              "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2",
+              "posterior_log_variance_clipped", "sqrt_one_minus_alphas_cumprod"):
+        assert np.array_equal(bufs[k].numpy(), g[k]), k
+    for S_ in (50, 200):
+        ts = S.make_ddim_timesteps("uniform", S_, 1000)
+        assert np.array_equal(ts, g[f"S{S_}_timesteps"])
+        for eta in (0.0, 1.0):
+            tab = S.ddim_step_table(bufs["alphas_cumprod"], ts, eta)
+            for j, name in enumerate(("a_t", "a_prev", "sigma_t", "sqrt_one_minus_at")):
+                assert np.array_equal(tab[:, j], g[f"S{S_}_eta{int(eta)}_{name}"]), (S_, eta, name)
+    with pytest.raises(IndexError):      # the reference fails the same way when S does not divide 1000 (util.py:49-57)
+        S.make_ddim_sampling_parameters(bufs["alphas_cumprod"], S.make_ddim_timesteps("uniform", 3, 1000), 0.0)
+
+
+def test_config_factory_maps_reference_targets():
+    from dsml_thesis_amd.util import get_obj_from_str, instantiate_from_config
+    from dsml_thesis_amd.unet import UNetModel
+    from dsml_thesis_amd.ddpm import LatentDiffusion, LatentDiffusion2Cond
+    assert get_obj_from_str("ldm.modules.diffusionmodules.openaimodel.UNetModel") is UNetModel
+    assert get_obj_from_str("ldm.models.diffusion.ddpm.LatentDiffusion") is LatentDiffusion
+    assert get_obj_from_str("ldm.models.diffusion.ddpm2cond.LatentDiffusion") is LatentDiffusion2Cond
+    m = instantiate_from_config({"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                                 "params": dict(W.FR_UNET, model_channels=32, channel_mult=[1, 2])})
+    assert isinstance(m, UNetModel)
+    with pytest.raises(KeyError):
+        instantiate_from_config({"params": {}})
+
+
+def test_state_dict_keys_equal_reference_enumeration():
+    from helpers import fr_config, tf_config
+    from dsml_thesis_amd.ddpm import LatentDiffusion, LatentDiffusion2Cond
+    m = LatentDiffusion(**fr_config())
+    sd = m.state_dict()
+    unet_keys = {"model.diffusion_model." + k: tuple(s) for k, s in W.unet_param_shapes(W.FR_UNET).items()}
+    vq_keys = {"first_stage_model." + k: tuple(s) for k, s in W.vqmodel_param_shapes(W.VQ_F4).items()}
+    for k, shp in {**unet_keys, **vq_keys}.items():
+        assert tuple(sd[k].shape) == shp, k
+    # LitEma shadow names: parameter name with the dots removed (ema.py:16-21)
+    assert "model_ema.diffusion_modelout2weight" in sd and "model_ema.decay" in sd and "model_ema.num_updates" in sd
+    assert sum(1 for k in sd if k.startswith("model_ema.")) == len(unet_keys) + 2
+    for k in ("betas", "alphas_cumprod", "posterior_mean_coef1", "cond_stage_model.embedding.weight",
+              "cond_stage_model.uncond_embedding.weight"):
+        assert k in sd
+    m2 = LatentDiffusion2Cond(**tf_config())
+    sd2 = m2.state_dict()
+    assert sd2["model.diffusion_model.input_blocks.0.0.weight"].shape == (160, 9, 3, 3)
+    assert sd2["cond_stage_model_1.embedding.weight"].shape == (9, 256)
+    assert sd2["cond_stage_model_2.attentionNet.0.weight"].shape == (17, 17)
+    # zero-initialised tensors of a fresh model are the reference's zero_module sites
+    z = [k for k, v in m.model.diffusion_model.state_dict().items() if v.dim() > 1 and float(v.abs().max()) == 0.0]
+    assert len(z) == 34 and all((".out_layers.3." in k) or (".proj_out." in k) or k.startswith("out.2.") for k in z)
+
+
+def test_unsupported_options_fail_loudly():
+    from dsml_thesis_amd.unet import UNetModel
+    from dsml_thesis_amd.autoencoder import VQModelInterface
+    for bad in (dict(dims=3), dict(resblock_updown=True), dict(use_spatial_transformer=False), dict(use_fp16=True),
+                dict(num_head_channels=64)):
+        with pytest.raises(NotImplementedError):
+            UNetModel(**dict(W.FR_UNET, **bad))
+    with pytest.raises(NotImplementedError):
+        VQModelInterface(embed_dim=3, n_embed=16, ddconfig=dict(W.VQ_F4["ddconfig"], attn_type="linear"))
+
+
+def test_no_cpu_fallback():
+    from dsml_thesis_amd import lib as L
+    from dsml_thesis_amd.unet import UNetModel
+    m = UNetModel(**dict(W.FR_UNET, model_channels=32, channel_mult=[1], attention_resolutions=[1]))
+    with pytest.raises(L.LdmkError, match="CUDA|GPU"):
+        m(torch.zeros(1, 3, 8, 8), torch.zeros(1, dtype=torch.long), context=torch.zeros(1, 1, 512))
+
+
+def test_shard_ranges_and_item_noise():
+    from dsml_thesis_amd.parallel import shard_range, item_noise, batch_noise
+    for n in (1, 7, 16, 128, 130):
+        for g in (1, 2, 3, 4, 8):
+            spans = [shard_range(n, g, r) for r in range(g)]
+            covered = [i for lo, hi in spans for i in range(lo, hi)]
+            assert covered == list(range(n)), (n, g, spans)
+            assert max(hi - lo for lo, hi in spans) == -(-n // g)
+    assert shard_range(128, 8, 3) == (48, 64)
+    full = batch_noise(11, 0, 6, (3, 4, 4))
+    parts = torch.cat([batch_noise(11, lo, hi, (3, 4, 4)) for lo, hi in (shard_range(6, 4, r) for r in range(4))])
+    assert torch.equal(full, parts)
+    assert not torch.equal(item_noise(11, 0, (3, 4, 4)), item_noise(12, 0, (3, 4, 4)))

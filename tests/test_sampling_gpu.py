@@ -178,3 +178,29 @@ def test_ema_scope_swaps_weights_and_repacks(fr):
     assert "model.diffusion_model.input_blocks.1.0.in_layers.2.weight" in keys
     assert "model_ema.diffusion_modelinput_blocks10in_layers2weight" in keys
     assert "first_stage_model.decoder.up.2.attn.1.q.weight" in keys and "cond_stage_model.embedding.weight" in keys
+
+
+def test_sharded_sampling_bitwise_equals_single_gpu(fr):
+    """Config 4's invariant on one GPU: the per-rank blocks of an 8-way / 3-way sharded job, computed one after
+    the other with the job-wide tile policy, concatenate to exactly the single-GPU result (latents and frames)."""
+    from dsml_thesis_amd.ddim import DDIMSampler
+    from dsml_thesis_amd.parallel import sample_sharded, shard_range
+    n_items, S = 8, 4          # S must divide 1000 like in the reference
+    s = DDIMSampler(fr)
+    labels = torch.arange(n_items, device="cuda") % 8
+    cond = lambda lo, hi: fr.cond_stage_model.embedding(labels[lo:hi, None])
+    full = sample_sharded(s, S, n_items, (3, 32, 32), cond, seed=3, rank=0, world_size=1)
+    full_z = sample_sharded(s, S, n_items, (3, 32, 32), cond, seed=3, rank=0, world_size=1, decode=False)
+    assert full.shape == (n_items, 128, 128, 3) and float(full.min()) >= 0 and float(full.max()) <= 1
+    for world in (8, 3):
+        parts, parts_z = [], []
+        for r in range(world):
+            lo, hi = shard_range(n_items, world, r)
+            if hi > lo:
+                # what rank r computes (the all-gather itself is covered by the gloo test / RCCL on the node)
+                kw = dict(seed=3, rank=0, world_size=1, _noise_offset=lo, _policy_items=n_items)
+                sub = lambda a, b, lo=lo: cond(lo + a, lo + b)
+                parts_z.append(sample_sharded(s, S, hi - lo, (3, 32, 32), sub, decode=False, **kw))
+                parts.append(sample_sharded(s, S, hi - lo, (3, 32, 32), sub, **kw))
+        assert torch.equal(torch.cat(parts_z), full_z), f"latents, world={world}"
+        assert torch.equal(torch.cat(parts), full), f"frames, world={world}"
