@@ -242,11 +242,13 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"latent{a.latent}_b{a.batch}")
+                traffic = json.load(open(tpath)).get(f"latent{a.latent}_b{a.batch}", {}).get("hbm_bytes_per_step")
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": traffic,
+                           "traffic_note": "bytes per step over the igemm family, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE "
+                                           "passes of this command (profiles/traffic_r01.json); L2<->fabric, Infinity-Cache hits included",
                            "kernel": "ldmk::igemm_kernel<...> (all tile shapes)", "launches_per_step": n_ig,
                            "avg_launch_us": round(1e3 * t_ig / n_ig, 2), "sum_launch_ms_per_step": round(t_ig, 4)}
     del run
