@@ -226,19 +226,20 @@ class VQModelInterface(nn.Module):
     def _resnet_block(self, nb, prefix, m, x, h, w):
         pg, P, sd, n = nb.pg, self._packed, self._sd, nb.n
         y1 = nb.gn_act(x, None, h * w, sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"], 1e-6)
-        h1 = nb.conv(y1.view(n, h, w, m.cin), None, P[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], h, w)
-        pg.release(y1)
+        h1 = nb.conv(y1.view(n, h, w, m.cin), None, P[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], h, w,
+                     stats=True)
+        nb.release(y1)
         y2 = nb.gn_act(h1, None, h * w, sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"], 1e-6)
-        pg.release(h1)
+        nb.release(h1)
         y2 = y2.view(n, h, w, m.cout)
         if m.cin != m.cout:
             sk = nb.lin(x.reshape(n * h * w, m.cin), P[prefix + "nin_shortcut.weight"], sd[prefix + "nin_shortcut.bias"],
                         h * w)
             out = nb.conv(y2, None, P[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], h, w, residual=sk,
-                          out=sk.view(n, h, w, m.cout))
+                          out=sk.view(n, h, w, m.cout), stats=True)
         else:
-            out = nb.conv(y2, None, P[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], h, w, residual=x)
-        pg.release(y2)
+            out = nb.conv(y2, None, P[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], h, w, residual=x, stats=True)
+        nb.release(y2)
         return out
 
     def _attn(self, nb, prefix, m, x, h, w):
@@ -251,7 +252,7 @@ class VQModelInterface(nn.Module):
         q = nb.lin(xr, P[prefix + "q.weight"], sd[prefix + "q.bias"], hw, tf=L.TF_AFFINE, tf_coef=coef)
         k = nb.lin(xr, P[prefix + "k.weight"], sd[prefix + "k.bias"], hw, tf=L.TF_AFFINE, tf_coef=coef)
         v = nb.lin(xr, P[prefix + "v.weight"], sd[prefix + "v.bias"], hw, tf=L.TF_AFFINE, tf_coef=coef)
-        pg.release(coef)
+        nb.release(coef)
         s = pg.alloc(n, hw, hw)
         a = ops.make_igemm_args(hw, hw, c, q, c, k, s, hw, hw, b_trans=True, batch=n, a_bstride=hw * c,
                                 w_bstride=hw * c, out_bstride=hw * hw)
@@ -261,9 +262,9 @@ class VQModelInterface(nn.Module):
         a = ops.make_igemm_args(hw, c, hw, s, hw, v, o, c, hw, batch=n, a_bstride=hw * hw, w_bstride=hw * c,
                                 out_bstride=hw * c)
         pg.igemm(a, nb.pin)
-        pg.release(s, q, k, v)
-        out = nb.lin(o, P[prefix + "proj_out.weight"], sd[prefix + "proj_out.bias"], hw, residual=xr)
-        pg.release(o)
+        nb.release(s, q, k, v)
+        out = nb.lin(o, P[prefix + "proj_out.weight"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True)
+        nb.release(o)
         return out.view(n, h, w, c)
 
     # ---- programs -----------------------------------------------------------------------------------------
@@ -287,9 +288,8 @@ class VQModelInterface(nn.Module):
                sd["post_quant_conv.bias"].data_ptr(), pq.data_ptr(), n, h * w, self.embed_dim, zc)
         top = d.ch * d.ch_mult[-1]
         hw_max = h * w * 4 ** (d.num_resolutions - 1)
-        gn_partial = pg.alloc(n * pg.lib.ldmk_gn_chunks(hw_max) * top * 3)
         pin = None if self.policy_batch in (None, n) else (self.policy_batch, n)
-        nb = NetBuilder(pg, n, pin, gn_partial)
+        nb = NetBuilder(pg, n, pin)
         x = pg.alloc(n, h, w, top)
         pg.add("ldmk_conv3x3_in", pq.data_ptr(), zc, 0, 0, P["decoder.conv_in.weight"].data_ptr(),
                sd["decoder.conv_in.bias"].data_ptr(), x.data_ptr(), n, h, w, top)
@@ -297,7 +297,7 @@ class VQModelInterface(nn.Module):
         def step(fn, *a):
             nonlocal x
             y = fn(nb, *a[:2], x, *a[2:])
-            pg.release(x)
+            nb.release(x)
             x = y
 
         step(self._resnet_block, "decoder.mid.block_1.", d.mid.block_1, h, w)
@@ -312,8 +312,8 @@ class VQModelInterface(nn.Module):
                     step(self._attn, f"decoder.up.{lvl}.attn.{ib}.", up.attn[ib], ch_, cw_)
             if lvl != 0:
                 y = nb.conv(x, None, P[f"decoder.up.{lvl}.upsample.conv.weight"],
-                            sd[f"decoder.up.{lvl}.upsample.conv.bias"], ch_, cw_, upsample=True)
-                pg.release(x)
+                            sd[f"decoder.up.{lvl}.upsample.conv.bias"], ch_, cw_, upsample=True, stats=True)
+                nb.release(x)
                 x = y
                 ch_, cw_ = 2 * ch_, 2 * cw_
         coef = nb.gn(x, None, ch_ * cw_, sd["decoder.norm_out.weight"], sd["decoder.norm_out.bias"], 1e-6)
@@ -330,9 +330,8 @@ class VQModelInterface(nn.Module):
         pg = Program(dev)
         x_in = pg.alloc(n, e.in_channels, H, W_)
         pg.inputs = dict(x=x_in)
-        gn_partial = pg.alloc(n * pg.lib.ldmk_gn_chunks(H * W_) * e._final_ch * 3)
         pin = None if self.policy_batch in (None, n) else (self.policy_batch, n)
-        nb = NetBuilder(pg, n, pin, gn_partial)
+        nb = NetBuilder(pg, n, pin)
         x = pg.alloc(n, H, W_, e.ch)
         pg.add("ldmk_conv3x3_in", x_in.data_ptr(), e.in_channels, 0, 0, P["encoder.conv_in.weight"].data_ptr(),
                sd["encoder.conv_in.bias"].data_ptr(), x.data_ptr(), n, H, W_, e.ch)
@@ -340,7 +339,7 @@ class VQModelInterface(nn.Module):
         def step(fn, *a):
             nonlocal x
             y = fn(nb, *a[:2], x, *a[2:])
-            pg.release(x)
+            nb.release(x)
             x = y
 
         ch_, cw_ = H, W_
@@ -352,8 +351,8 @@ class VQModelInterface(nn.Module):
                     step(self._attn, f"encoder.down.{lvl}.attn.{ib}.", dn.attn[ib], ch_, cw_)
             if lvl != e.num_resolutions - 1:
                 y = nb.conv(x, None, P[f"encoder.down.{lvl}.downsample.conv.weight"],
-                            sd[f"encoder.down.{lvl}.downsample.conv.bias"], ch_, cw_, stride=2, pad_lo=0)
-                pg.release(x)
+                            sd[f"encoder.down.{lvl}.downsample.conv.bias"], ch_, cw_, stride=2, pad_lo=0, stats=True)
+                nb.release(x)
                 x = y
                 ch_, cw_ = (ch_ + 1 - 3) // 2 + 1, (cw_ + 1 - 3) // 2 + 1
         step(self._resnet_block, "encoder.mid.block_1.", e.mid.block_1, ch_, cw_)

@@ -328,18 +328,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
     if (col >= p.N) continue;
     const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+      float vals[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = 0.f;
         if (row < p.M) {
-          float v = acc[i][j][r] * alpha + bv;
+          v = acc[i][j][r] * alpha + bv;
           if (p.batch_vec) v += p.batch_vec[(long long)(row / p.rows_per_sample) * p.batch_vec_ld + col];
           const long long o = (long long)row * p.ldc + col;
           if (resp) v += resp[o];
           outp[o] = v;
         }
+        vals[r] = v;
       }
+      if (p.stats_out && rowbase + i * 32 < p.M) {
+        // GroupNorm partial record of this 32-row tile x column (same record as gn_partial_kernel):
+        // the 32 rows of the tile sit in 16 registers x 2 half-waves of the lane pair (l31, l31+32)
+        const float shift = __shfl(vals[0], l31, 64);      // row 0 of the tile
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = vals[r] - shift;
+          sm += d;
+          sq = fmaf(d, d, sq);
+        }
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if (half == 0) {
+          float* d = p.stats_out + ((long long)((rowbase + i * 32) >> 5) * p.N + col) * 3;
+          d[0] = shift; d[1] = sm; d[2] = sq;
+        }
+      }
+    }
   }
 }
 
@@ -378,6 +400,60 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const ldmk_igemm_args
   }
 }
 
+// split-K reduce + epilogue that also emits the GroupNorm partial records: one workgroup per
+// (32-row tile, 64-column chunk); the reduced tile is kept in LDS for the per-column statistics.
+__global__ __launch_bounds__(256) void igemm_reduce_stats_kernel(const ldmk_igemm_args p, const int splitk,
+                                                                 const float* __restrict__ ws) {
+  __shared__ float tile[32][65];
+  const int rt = blockIdx.x, c0 = blockIdx.y * 64;
+  float* outp = p.out;
+  const float* resp = p.residual;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int idx = threadIdx.x + 256 * pass;        // 512 float4 = 32 rows x 16
+    const int r = idx >> 4, cl = (idx & 15) * 4;
+    const int row = rt * 32 + r, col = c0 + cl;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < p.N) {
+      s = *reinterpret_cast<const float4*>(ws + (long long)row * p.N + col);
+      for (int k = 1; k < splitk; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(ws + ((long long)k * p.M + row) * p.N + col);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      s.x *= p.alpha; s.y *= p.alpha; s.z *= p.alpha; s.w *= p.alpha;
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      }
+      if (p.batch_vec) {
+        const float4 b = *reinterpret_cast<const float4*>(p.batch_vec + (long long)(row / p.rows_per_sample) * p.batch_vec_ld + col);
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      }
+      const long long o = (long long)row * p.ldc + col;
+      if (resp) {
+        const float4 b = *reinterpret_cast<const float4*>(resp + o);
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      }
+      *reinterpret_cast<float4*>(outp + o) = s;
+    }
+    tile[r][cl] = s.x; tile[r][cl + 1] = s.y; tile[r][cl + 2] = s.z; tile[r][cl + 3] = s.w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && c0 + threadIdx.x < p.N) {
+    const int c = threadIdx.x;
+    const float shift = tile[0][c];
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const float d = tile[r][c] - shift;
+      sm += d;
+      sq = fmaf(d, d, sq);
+    }
+    float* d = p.stats_out + ((long long)rt * p.N + c0 + c) * 3;
+    d[0] = shift; d[1] = sm; d[2] = sq;
+  }
+}
+
 struct TileCfg { int bm, bn, ns; bool even_tn; float eff; };
 // eff: measured sustained fraction of the f32 MFMA peak on long-K problems (profiles/r01_layers*_v2.txt)
 static const TileCfg kCfg[] = {
@@ -406,7 +482,9 @@ static int launch_cfg(const ldmk_igemm_args& a, int splitk, float* ws, hipStream
     attr_done = true;
   }
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, splitk, ws);
-  if (splitk > 1) {
+  if (splitk > 1 && a.stats_out) {
+    hipLaunchKernelGGL(igemm_reduce_stats_kernel, dim3(a.M / 32, (a.N + 63) / 64), dim3(256), 0, st, a, splitk, ws);
+  } else if (splitk > 1) {
     long long total = (long long)a.M * (a.N / 4);
     int g = (int)((total + 255) / 256);
     if (g > 2048) g = 2048;
@@ -500,6 +578,9 @@ extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) {
     LDMK_REQUIRE(a.row_stats && a.ln_gamma && a.ln_beta && a.a_mode == LDMK_A_ROWS, "ldmk_igemm: layernorm prologue args");
   }
   if (a.epi == LDMK_EPI_GEGLU) LDMK_REQUIRE(a.N % 64 == 0 && !a.residual && !a.batch_vec, "ldmk_igemm: GEGLU needs N%%64==0 and no residual");
+  if (a.stats_out)
+    LDMK_REQUIRE(a.M % 32 == 0 && a.rows_per_sample % 32 == 0 && a.epi == LDMK_EPI_NONE && a.batch <= 1,
+                 "ldmk_igemm: stats_out needs M%%32==0, rows_per_sample%%32==0, no GEGLU, no batching");
   LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]", a.tile_cfg, kNumCfg);
   LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 16, "ldmk_igemm: splitk=%d outside [0,16]", a.splitk);
   if (a.alpha == 0.f) a.alpha = 1.f;

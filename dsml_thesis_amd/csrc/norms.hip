@@ -4,22 +4,18 @@
 
 namespace ldmk {
 
-constexpr int GN_PIX = 16;   // pixels per partial-sum chunk (short dependent chains, many workgroups)
+constexpr int GN_PIX = 32;   // pixels per partial-sum chunk == the MFMA row-tile, so igemm epilogues can emit partials
 
-// pass 1: per-(sample, chunk, channel) sum and sum of squares.  Thread <-> channel, so a wave reads
-// 64 consecutive floats of one NHWC pixel row: fully coalesced, also across the concat seam.
-__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x0, int c0,
-                                                         const float* __restrict__ x1, int c1, int hw, int chunks,
+// pass 1 (stand-alone form; igemm / its split-K reduce emit the same records from their epilogue):
+// per-(sample, chunk, channel) shifted sum and sum of squares.  Thread <-> channel, so a wave reads
+// 64 consecutive floats of one NHWC pixel row: fully coalesced.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int C, int hw, int chunks,
                                                          float* __restrict__ partial) {
-  const int C = c0 + c1;
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int p0 = chunk * GN_PIX;
   const int p1 = min(hw, p0 + GN_PIX);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float* src;
-    int cs, cl;
-    if (c < c0) { src = x0; cs = c0; cl = c; } else { src = x1; cs = c1; cl = c - c0; }
-    const float* ptr = src + ((long long)n * hw + p0) * cs + cl;
+    const float* ptr = x + ((long long)n * hw + p0) * C + c;
     // shifted sums (shift = first value of the chunk) keep the fp32 cancellation error small
     const float shift = ptr[0];
     float s = 0.f, ss = 0.f;
@@ -27,31 +23,35 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
       float v = *ptr - shift;
       s += v;
       ss = fmaf(v, v, ss);
-      ptr += cs;
+      ptr += C;
     }
     float* d = partial + (((long long)n * chunks + chunk) * C + c) * 3;
     d[0] = shift; d[1] = s; d[2] = ss;
   }
 }
 
-// pass 2: one workgroup (one wave per group) per sample: combine chunk partials in double,
-// emit per-channel scale/shift planes  y = x*scale + shift  ==  (x-mean)*rstd*gamma + beta.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int C, int hw, int chunks,
+// pass 2: one wave per (sample, group): combine the chunk partials of (the channel concat of) up to two
+// tensors in double -- groups may straddle the concat seam -- and emit per-channel scale/shift planes
+//   y = x*scale + shift  ==  (x-mean)*rstd*gamma + beta.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ pa, int c0,
+                                                          const float* __restrict__ pb, int c1, int hw, int chunks,
                                                           int groups, float eps, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ coef) {
+  const int C = c0 + c1;
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int cpg = C / groups;
   for (int g = blockIdx.x * 4 + wave; g < groups; g += gridDim.x * 4) {
-    // items of this group: cpg channels x chunks partials
     const int items = cpg * chunks;
     double sum = 0.0, sumsq = 0.0;
     for (int i = lane; i < items; i += 64) {
-      int ch = i / cpg, cc = i - ch * cpg;
-      const float* d = partial + (((long long)n * chunks + ch) * C + g * cpg + cc) * 3;
-      int cnt = min(hw - ch * GN_PIX, GN_PIX);
-      double sh = d[0], s = d[1], ss = d[2];
+      const int ch = i / cpg, cc = i - ch * cpg;
+      const int c = g * cpg + cc;
+      const float* d = c < c0 ? pa + (((long long)n * chunks + ch) * c0 + c) * 3
+                              : pb + (((long long)n * chunks + ch) * c1 + (c - c0)) * 3;
+      const int cnt = min(hw - ch * GN_PIX, GN_PIX);
+      const double sh = d[0], s = d[1], ss = d[2];
       // sum x = s + cnt*sh ; sum x^2 = ss + 2*sh*s + cnt*sh^2
       sum += s + cnt * sh;
       sumsq += ss + 2.0 * sh * s + cnt * sh * sh;
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float meanf = (float)mean;
     for (int cc = lane; cc < cpg; cc += 64) {
-      int c = g * cpg + cc;
-      float sc = rstd * gamma[c];
+      const int c = g * cpg + cc;
+      const float sc = rstd * gamma[c];
       coef[((long long)n * 2) * C + c] = sc;
       coef[((long long)n * 2 + 1) * C + c] = fmaf(-meanf, sc, beta[c]);
     }
@@ -145,21 +145,40 @@ extern "C" int ldmk_gn_apply(const float* x0, int c0, const float* x1, int c1, c
 
 extern "C" int ldmk_gn_chunks(int hw) { return (hw + ldmk::GN_PIX - 1) / ldmk::GN_PIX; }
 
-extern "C" int ldmk_gn_coef(const float* x0, int c0, const float* x1, int c1, int n, int hw, int groups, float eps,
-                            const float* gamma, const float* beta, float* partial, float* coef, void* stream) {
+extern "C" int ldmk_gn_partial(const float* x, int c, int n, int hw, float* partial, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(x && partial && c > 0 && n > 0 && hw > 0, "ldmk_gn_partial: bad args");
+  const int chunks = ldmk_gn_chunks(hw);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, n), dim3(256), 0, (hipStream_t)stream, x, c, hw, chunks, partial);
+  return check_launch("ldmk_gn_partial");
+}
+
+extern "C" int ldmk_gn_finalize(const float* partial0, int c0, const float* partial1, int c1, int n, int hw, int groups,
+                                float eps, const float* gamma, const float* beta, float* coef, void* stream) {
   LDMK_ENTER();
   using namespace ldmk;
   const int C = c0 + c1;
+  LDMK_REQUIRE(partial0 && c0 > 0 && n > 0 && hw > 0 && groups > 0, "ldmk_gn_finalize: bad args");
+  LDMK_REQUIRE((c1 == 0) == (partial1 == nullptr), "ldmk_gn_finalize: partial1/c1 mismatch");
+  LDMK_REQUIRE(C % groups == 0, "ldmk_gn_finalize: C=%d not divisible by groups=%d", C, groups);
+  LDMK_REQUIRE(gamma && beta && coef, "ldmk_gn_finalize: null buffer");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((groups + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, partial0, c0,
+                     partial1, c1, hw, ldmk_gn_chunks(hw), groups, eps, gamma, beta, coef);
+  return check_launch("ldmk_gn_finalize");
+}
+
+extern "C" int ldmk_gn_coef(const float* x0, int c0, const float* x1, int c1, int n, int hw, int groups, float eps,
+                            const float* gamma, const float* beta, float* partial, float* coef, void* stream) {
+  using namespace ldmk;
   LDMK_REQUIRE(x0 && c0 > 0 && n > 0 && hw > 0 && groups > 0, "ldmk_gn_coef: bad args");
   LDMK_REQUIRE((c1 == 0) == (x1 == nullptr), "ldmk_gn_coef: x1/c1 mismatch");
-  LDMK_REQUIRE(C % groups == 0, "ldmk_gn_coef: C=%d not divisible by groups=%d", C, groups);
-  LDMK_REQUIRE(gamma && beta && partial && coef, "ldmk_gn_coef: null buffer");
-  hipStream_t st = (hipStream_t)stream;
-  const int chunks = ldmk_gn_chunks(hw);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, n), dim3(256), 0, st, x0, c0, x1, c1, hw, chunks, partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((groups + 3) / 4, n), dim3(256), 0, st, partial, C, hw, chunks, groups,
-                     eps, gamma, beta, coef);
-  return check_launch("ldmk_gn_coef");
+  LDMK_REQUIRE(partial, "ldmk_gn_coef: null scratch");
+  float* p1 = x1 ? partial + (long long)n * ldmk_gn_chunks(hw) * c0 * 3 : nullptr;
+  int rc = ldmk_gn_partial(x0, c0, n, hw, partial, stream);
+  if (rc == 0 && x1) rc = ldmk_gn_partial(x1, c1, n, hw, p1, stream);
+  if (rc == 0) rc = ldmk_gn_finalize(partial, c0, p1, c1, n, hw, groups, eps, gamma, beta, coef, stream);
+  return rc;
 }
 
 extern "C" int ldmk_ln_stats(const float* x, int rows, int c, float eps, float* stats, void* stream) {

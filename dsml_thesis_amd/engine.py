@@ -94,23 +94,54 @@ class Program:
 class NetBuilder:
     """Emits the recurring layer patterns of the UNet / VQGAN into a Program (NHWC activations)."""
 
-    def __init__(self, pg, n, pin=None, gn_partial=None):
+    def __init__(self, pg, n, pin=None):
         from . import ops
         self.pg, self.n, self.pin, self.ops = pg, n, pin, ops
-        self.gn_partial = gn_partial
+        self._stats = {}          # tensor data_ptr -> GroupNorm partial records [rows/32][C][3]
 
     @staticmethod
     def ptr(t):
         return 0 if t is None else (t if isinstance(t, int) else t.data_ptr())
+
+    # ---- GroupNorm statistics: partial records are produced by the tensor's producer (igemm epilogue) when
+    # possible and cached per tensor, so a tensor normalised twice (ResBlock output -> SpatialTransformer norm ->
+    # later a skip-concat GroupNorm) is never re-read for statistics.
+    def stats_buffer(self, rows, c):
+        return self.pg.alloc(rows // 32, c, 3)
+
+    def release(self, *tensors):
+        """Return buffers to the pool; statistics cached for them die with them (the pool recycles addresses)."""
+        for t in tensors:
+            if t is not None:
+                self.drop_stats(t)
+        self.pg.release(*tensors)
+
+    def attach_stats(self, t, partial):
+        self._stats[t.data_ptr()] = partial
+
+    def drop_stats(self, t):
+        p = self._stats.pop(t.data_ptr(), None)
+        if p is not None:
+            self.pg.release(p)
+
+    def _partial(self, x, hw):
+        p = self._stats.get(x.data_ptr())
+        if p is None:
+            c = x.shape[-1]
+            p = self.pg.alloc(self.n * self.pg.lib.ldmk_gn_chunks(hw), c, 3)
+            self.pg.add("ldmk_gn_partial", self.ptr(x), c, self.n, hw, self.ptr(p))
+            self._stats[x.data_ptr()] = p
+        return p
 
     def gn(self, x0, x1, hw, gamma, beta, eps):
         """GroupNorm(32) statistics of (the channel concat of) NHWC tensors -> coef planes [n][2][C]."""
         pg, p_ = self.pg, self.ptr
         c0 = x0.shape[-1]
         c1 = 0 if x1 is None else x1.shape[-1]
+        pa = self._partial(x0, hw)
+        pb = None if x1 is None else self._partial(x1, hw)
         coef = pg.alloc(self.n, 2, c0 + c1)
-        pg.add("ldmk_gn_coef", p_(x0), c0, p_(x1), c1, self.n, hw, 32, eps, p_(gamma), p_(beta),
-               p_(self.gn_partial), p_(coef))
+        pg.add("ldmk_gn_finalize", p_(pa), c0, p_(pb), c1, self.n, hw, 32, eps, p_(gamma), p_(beta), p_(coef))
         return coef
 
     def gn_act(self, x0, x1, hw, gamma, beta, eps, silu=True):
@@ -122,11 +153,11 @@ class NetBuilder:
         coef = self.gn(x0, x1, hw, gamma, beta, eps)
         y = pg.alloc(self.n * hw, c0 + c1)
         pg.add("ldmk_gn_apply", p_(x0), c0, p_(x1), c1, p_(coef), p_(y), self.n, hw, 1 if silu else 0)
-        pg.release(coef)
+        self.release(coef)
         return y
 
     def conv(self, x0, x1, wp, bias, h, w, coef=None, stride=1, pad_lo=1, upsample=False, batch_vec=None, bv_ld=0,
-             residual=None, out=None):
+             residual=None, out=None, stats=False):
         """3x3 conv (implicit GEMM) with optional GN+SiLU prologue / per-sample vector / residual epilogue."""
         pg, n, ops = self.pg, self.n, self.ops
         c0 = x0.shape[-1]
@@ -146,10 +177,18 @@ class NetBuilder:
                                 residual=residual)
         if batch_vec is not None:
             a.batch_vec, a.batch_vec_ld = self.ptr(batch_vec), bv_ld
+        self._maybe_stats(a, out.view(-1, cout), oh * ow, stats)
         pg.igemm(a, self.pin)
         return out
 
-    def lin(self, x0, wp, bias, rows_per_sample, x1=None, out=None, geglu=False, **kw):
+    def _maybe_stats(self, a, out2d, rows_per_sample, stats):
+        if stats and a.M % 32 == 0 and rows_per_sample % 32 == 0:
+            self.drop_stats(out2d)
+            part = self.stats_buffer(a.M, a.N)
+            a.stats_out = part.data_ptr()
+            self.attach_stats(out2d, part)
+
+    def lin(self, x0, wp, bias, rows_per_sample, x1=None, out=None, geglu=False, stats=False, **kw):
         """Linear / 1x1 conv on token rows, with the igemm prologue/epilogue options passed through."""
         pg, ops = self.pg, self.ops
         M, c0 = x0.shape[0], x0.shape[-1]
@@ -160,6 +199,7 @@ class NetBuilder:
             out = pg.alloc(M, ncol)
         a = ops.make_igemm_args(M, N, c0 + c1, x0, c0, wp, out, ncol, rows_per_sample, a1=x1, c1=c1, bias=bias,
                                 epi=L.EPI_GEGLU if geglu else L.EPI_NONE, **kw)
+        self._maybe_stats(a, out, rows_per_sample, stats)
         pg.igemm(a, self.pin)
         return out
 

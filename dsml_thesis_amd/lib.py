@@ -27,7 +27,7 @@ class IgemmArgs(C.Structure):
         ("out", _fp), ("ldc", C.c_int), ("batch", C.c_int),
         ("a_bstride", C.c_longlong), ("w_bstride", C.c_longlong), ("out_bstride", C.c_longlong),
         ("alpha", C.c_float), ("tile_cfg", C.c_int), ("splitk", C.c_int),
-        ("splitk_ws", _fp), ("splitk_ws_elems", C.c_longlong),
+        ("splitk_ws", _fp), ("splitk_ws_elems", C.c_longlong), ("stats_out", _fp),
     ]
 
 
@@ -38,6 +38,8 @@ _SIGS = {
     "ldmk_igemm_plan": (C.c_int, [C.POINTER(IgemmArgs), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ldmk_igemm_force_config": (None, [C.c_int]),
     "ldmk_gn_chunks": (C.c_int, [C.c_int]),
+    "ldmk_gn_partial": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ldmk_gn_finalize": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp]),
     "ldmk_gn_coef": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _fp]),
     "ldmk_ln_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp]),
     "ldmk_gn_apply": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),

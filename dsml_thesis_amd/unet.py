@@ -320,14 +320,7 @@ class UNetModel(nn.Module):
         pg.add("ldmk_dense_small", p_(emb), emb_ch, p_(P["emb_all"]), p_(P["emb_all_b"]), p_(emb_all), self._emb_total, n,
                emb_ch, self._emb_total, 1)
 
-        max_c = 0
-        for _, m in self._walk():
-            if m.kind == "res":
-                max_c = max(max_c, m.cin, m.cout)
-        chunks = pg.lib.ldmk_gn_chunks(H * W_)
-        gn_partial = pg.alloc(n * chunks * max_c * 3)
-
-        nb_ = NetBuilder(pg, n, pin, gn_partial)
+        nb_ = NetBuilder(pg, n, pin)
         gn, conv, lin = nb_.gn, nb_.conv, nb_.lin
 
         def res_block(prefix, m, x0, x1, h, w):
@@ -337,21 +330,21 @@ class UNetModel(nn.Module):
             y1 = nb_.gn_act(x0, x1, hw, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5)
             bv = emb_all.data_ptr() + 4 * self._emb_off[prefix]
             h1 = conv(y1.view(n, h, w, m.cin), None, P[prefix + "c1"], sd[prefix + "in_layers.2.bias"], h, w,
-                      batch_vec=bv, bv_ld=self._emb_total)
-            pg.release(y1)
+                      batch_vec=bv, bv_ld=self._emb_total, stats=True)
+            nb_.release(y1)
             y2 = nb_.gn_act(h1, None, hw, sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"], 1e-5)
-            pg.release(h1)
+            nb_.release(h1)
             y2 = y2.view(n, h, w, m.cout)
             if m.cin != m.cout:
                 x0r = x0.reshape(n * hw, -1)
                 x1r = None if x1 is None else x1.reshape(n * hw, -1)
                 skip = lin(x0r, P[prefix + "skip"], sd[prefix + "skip_connection.bias"], hw, x1=x1r)
                 out = conv(y2, None, P[prefix + "c2"], sd[prefix + "out_layers.3.bias"], h, w, residual=skip,
-                           out=skip.view(n, h, w, m.cout))
+                           out=skip.view(n, h, w, m.cout), stats=True)
             else:
                 assert x1 is None
-                out = conv(y2, None, P[prefix + "c2"], sd[prefix + "out_layers.3.bias"], h, w, residual=x0)
-            pg.release(y2)
+                out = conv(y2, None, P[prefix + "c2"], sd[prefix + "out_layers.3.bias"], h, w, residual=x0, stats=True)
+            nb_.release(y2)
             return out
 
         def spatial_tf(prefix, m, x, h, w):
@@ -361,7 +354,7 @@ class UNetModel(nn.Module):
             xr = x.reshape(rows, m.ch)
             coef = gn(x, None, hw, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-6)
             hcur = lin(xr, P[prefix + "pin"], sd[prefix + "proj_in.bias"], hw, tf=L.TF_AFFINE, tf_coef=coef)
-            pg.release(coef)
+            nb_.release(coef)
             stats = pg.alloc(rows, 2)
             for d in range(m.depth):
                 q = f"{prefix}transformer_blocks.{d}."
@@ -371,7 +364,7 @@ class UNetModel(nn.Module):
                           ln_gamma=sd[q + "norm1.weight"], ln_beta=sd[q + "norm1.bias"])
                 att = pg.alloc(rows, C_)
                 pg.add("ldmk_attn_self", p_(qkv), p_(att), n, hw, m.heads, m.d_head ** -0.5)
-                pg.release(qkv)
+                nb_.release(qkv)
                 if L_ctx == 1:
                     # --- attn2 with a single context token: softmax over one key == 1, so the block adds
                     # to_out(to_v(ctx)) to every position (exact); to_q/norm2 are dead.
@@ -383,7 +376,7 @@ class UNetModel(nn.Module):
                                C_, n, C_, C_, 0)
                     h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur,
                              batch_vec=cvec, batch_vec_ld=C_)      # + the per-sample cross-attention vector
-                    pg.release(att)
+                    nb_.release(att)
                     h2 = h1
                 else:
                     h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur)
@@ -400,15 +393,15 @@ class UNetModel(nn.Module):
                     pg.add("ldmk_attn_cross", p_(q2), C_, p_(kk), p_(vv), C_, p_(a2), C_, n, hw, L_ctx, m.heads,
                            m.d_head ** -0.5)
                     h2 = lin(a2, P[q + "o2"], sd[q + "attn2.to_out.0.bias"], hw, residual=h1, out=h1)
-                    pg.release(att, a2)
+                    nb_.release(att, a2)
                 # --- GEGLU feed-forward: LN3 folded into the first GEMM, gate in its epilogue
                 pg.add("ldmk_ln_stats", p_(h2), rows, C_, 1e-5, p_(stats))
                 f = lin(h2, P[q + "ff1"], P[q + "ff1b"], hw, geglu=True, tf=L.TF_LAYERNORM, row_stats=stats,
                         ln_gamma=sd[q + "norm3.weight"], ln_beta=sd[q + "norm3.bias"])
                 hcur = lin(f, P[q + "ff2"], sd[q + "ff.net.2.bias"], hw, residual=h2, out=h2)
-                pg.release(f)
-            out = lin(hcur, P[prefix + "pout"], sd[prefix + "proj_out.bias"], hw, residual=xr)
-            pg.release(hcur, stats)
+                nb_.release(f)
+            out = lin(hcur, P[prefix + "pout"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True)
+            nb_.release(hcur, stats)
             return out.view(n, h, w, m.ch)
 
         def run_layers(prefix, layers, x0, x1, h, w, keep_input):
@@ -422,15 +415,15 @@ class UNetModel(nn.Module):
                 elif m.kind == "st":
                     out = spatial_tf(p, m, cur0, h, w)
                 elif m.kind == "down":
-                    out = conv(cur0, None, P[p + "w"], sd[p + "op.bias"], h, w, stride=2)
+                    out = conv(cur0, None, P[p + "w"], sd[p + "op.bias"], h, w, stride=2, stats=True)
                     h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
                 elif m.kind == "up":
-                    out = conv(cur0, None, P[p + "w"], sd[p + "conv.bias"], h, w, upsample=True)
+                    out = conv(cur0, None, P[p + "w"], sd[p + "conv.bias"], h, w, upsample=True, stats=True)
                     h, w = 2 * h, 2 * w
                 else:
                     raise AssertionError(m.kind)
                 if owned:
-                    pg.release(cur0)      # cur1 (a skip tensor) is released by the caller
+                    nb_.release(cur0)      # cur1 (a skip tensor) is released by the caller
                 cur0, cur1, owned = out, None, True
             return cur0, h, w
 
@@ -449,7 +442,7 @@ class UNetModel(nn.Module):
             skip, sh, sw = hs.pop()
             assert (sh, sw) == (ch_, cw_)
             new, ch_, cw_ = run_layers(f"output_blocks.{i}.", blk.layers, hcur, skip, ch_, cw_, True)
-            pg.release(hcur, skip)     # both inputs of the concat are dead once the block has run
+            nb_.release(hcur, skip)     # both inputs of the concat are dead once the block has run
             hcur = new
         coef = gn(hcur, None, ch_ * cw_, sd["out.0.weight"], sd["out.0.bias"], 1e-5)
         eps = pg.alloc(n, self.out_channels, H, W_)

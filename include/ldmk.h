@@ -78,6 +78,8 @@ typedef struct ldmk_igemm_args {
   int splitk;                /* 0 = choose; 1 = none; 2..16 = split K over that many workgroups            */
   float* splitk_ws;          /* scratch for split-K partial slabs (batch*splitk*M*N floats) or NULL        */
   long long splitk_ws_elems; /* capacity of splitk_ws in floats                                           */
+  float* stats_out;          /* optional [M/32][N][3] GroupNorm partial records of the *output* (after the
+                                epilogue), one per 32-row tile and column; needs M%32==0, rows_per_sample%32==0 */
 } ldmk_igemm_args;
 
 int ldmk_igemm(const ldmk_igemm_args* args, void* stream);
@@ -94,6 +96,12 @@ int ldmk_igemm_plan(const ldmk_igemm_args* args, int* tile_cfg, int* splitk);
  * ldmk_ln_stats: LayerNorm row statistics (mean, rstd), attention.py:203-205 (eps 1e-5).
  */
 int ldmk_gn_chunks(int hw);
+/* the two halves of ldmk_gn_coef, for callers that keep the per-tensor partial records
+ * ([n][chunks][c][3] = shift, sum(x-shift), sum((x-shift)^2) per 32-pixel chunk) -- ldmk_igemm can emit the
+ * same records from its epilogue (`stats_out`), which removes the statistics pass over the activation. */
+int ldmk_gn_partial(const float* x, int c, int n, int hw, float* partial, void* stream);
+int ldmk_gn_finalize(const float* partial0, int c0, const float* partial1, int c1, int n, int hw, int groups,
+                     float eps, const float* gamma, const float* beta, float* coef, void* stream);
 int ldmk_gn_coef(const float* x0, int c0, const float* x1, int c1, int n, int hw, int groups, float eps,
                  const float* gamma, const float* beta, float* partial, float* coef, void* stream);
 int ldmk_ln_stats(const float* x, int rows, int c, float eps, float* stats, void* stream);

@@ -34,7 +34,7 @@ def test_binding_matches_header(libpath):
     assert sorted(L.EXPORTED) == header_symbols()
     lib = L.load()
     assert lib.ldmk_version() >= 100
-    assert lib.ldmk_gn_chunks(1024) == 64 and lib.ldmk_gn_chunks(17) == 2
+    assert lib.ldmk_gn_chunks(1024) == 32 and lib.ldmk_gn_chunks(33) == 2
 
 
 def test_argument_validation_without_gpu(libpath):

@@ -132,6 +132,34 @@ def test_conv3x3_split_k_reduce(ops, splitk):
     assert torch.equal(out, out2), "split-K partials are summed in a fixed order"
 
 
+@pytest.mark.parametrize("splitk", [1, 4])
+def test_igemm_emits_groupnorm_partials(ops, splitk):
+    """The conv epilogue (and the split-K reduce) emit the same per-32-pixel-chunk records as ldmk_gn_partial, so the
+    GroupNorm of the *output* needs no statistics pass."""
+    from dsml_thesis_amd import lib as L
+    n, cin, cout, h, w = 2, 160, 320, 8, 8
+    x, wt, b = rnd(10, n, cin, h, w), rnd(11, cout, cin, 3, 3) / np.sqrt(9 * cin), 0.5 + 0.1 * rnd(12, cout)
+    res = rnd(14, n, cout, h, w)
+    xd, wd, bd, rd = nhwc(x), ops.pack_conv3x3(wt.cuda()), b.cuda(), nhwc(res)
+    out = torch.empty(n, h, w, cout, device="cuda")
+    part = torch.zeros(n * h * w // 32, cout, 3, device="cuda")
+    ws = torch.empty(splitk * n * h * w * cout, device="cuda")
+    a = ops.make_igemm_args(n * h * w, cout, 9 * cin, xd, cin, wd, out, cout, h * w, conv=(h, w, h, w, 1, 1, 0), bias=bd,
+                            residual=rd, splitk=splitk, splitk_ws=ws)
+    a.stats_out = part.data_ptr()
+    ops.igemm(a)
+    gamma, beta = 1 + 0.1 * rnd(21, cout), 0.1 * rnd(22, cout)
+    gd, btd = gamma.cuda(), beta.cuda()                      # keep alive: the ABI takes raw pointers
+    coef = torch.empty(n, 2, cout, device="cuda")
+    L.call("ldmk_gn_finalize", part.data_ptr(), cout, 0, 0, n, h * w, 32, 1e-5, gd.data_ptr(), btd.data_ptr(),
+           coef.data_ptr(), ops.stream())
+    ref = F.group_norm(F.conv2d(x, wt, b, padding=1) + res, 32, gamma, beta, 1e-5)
+    y = out * coef[:, 0].reshape(n, 1, 1, cout) + coef[:, 1].reshape(n, 1, 1, cout)
+    close(nchw(y), ref, 1e-4, 1e-4)
+    coef2 = ops.gn_coef(out, None, n, h * w, gd, btd, 1e-5)
+    close(coef, coef2, 1e-5, 1e-5)
+
+
 def test_gn_apply_concat(ops):
     n, c0, c1, h, w = 2, 320, 160, 8, 8
     x = rnd(20, n, c0 + c1, h, w) * 1.3 + 0.2
