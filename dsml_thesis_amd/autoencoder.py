@@ -211,7 +211,8 @@ class VQModelInterface(nn.Module):
         for k, v in sd.items():
             if k.endswith(".weight") and v.dim() == 4:
                 if v.shape[2] == 3:
-                    P[k] = ops.pack_conv3x3(v)
+                    narrow = v.shape[1] % 32 != 0 or v.shape[0] <= 4      # conv_in / conv_out at the latent / image boundary
+                    P[k] = ops.pack_conv3x3_narrow(v) if narrow else ops.pack_conv3x3(v)
                 elif k.startswith(("quant_conv", "post_quant_conv")):
                     P[k] = v.reshape(v.shape[0], v.shape[1]).contiguous()      # narrow NCHW 1x1: [cout][cin]
                 else:

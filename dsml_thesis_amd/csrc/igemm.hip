@@ -24,7 +24,7 @@
 
 namespace ldmk {
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool BT>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT>
 __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws) {
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int STAGE = KC * (ASTR + BSTR);   // floats per staging buffer (DB: two of them)
   float* As = smem;                     // [KC][ASTR]
   float* Bs = smem + KC * ASTR;         // [KC][BSTR]
 
@@ -61,7 +62,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   const float* __restrict__ wp = p.w + (long long)bz * p.w_bstride;
 
   const int Cin = p.c0 + p.c1;
-  const int cpt = Cin / 32;             // 32-channel sub-chunks per tap
   const int nkc = p.K / 32;             // total sub-chunks
   const int iters_all = (nkc + NS - 1) / NS;
   const int it_per = (iters_all + splitk - 1) / splitk;
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       const int kc = it * NS + j;
       const bool kvalid = kc < nkc;
       int tap = 0, cc = kc;
-      if (conv) { tap = kc / cpt; cc = kc - tap * cpt; }
-      const int c = cc * 32 + acol;                 // channel in the (virtual) concat
+      if (conv) { cc = kc / 9; tap = kc - cc * 9; }  // chunk-major, tap-minor: 9 consecutive slices re-read the
+      const int c = cc * 32 + acol;                 // same pixels' 128-B runs (L1/L2 reuse); channel in the concat
       const bool second = c >= p.c0;
       const float* src = second ? a1 : a0;
       const int cs = second ? p.c1 : p.c0;
@@ -157,13 +157,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   };
 
   // A-side prologue (norm) on the loaded registers, then registers -> LDS
-  auto store_slices = [&](int it) {
+  auto store_slices = [&](int it, int boff) {
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
       if (tf != LDMK_TF_NONE) {
         const int kc = it * NS + j;
         int tap = 0, cc = kc;
-        if (conv) { tap = kc / cpt; cc = kc - tap * cpt; }
+        if (conv) { cc = kc / 9; tap = kc - cc * 9; }
         const int c = cc * 32 + acol;
         if (kc < nkc) {
           if (tf == LDMK_TF_LAYERNORM) {
@@ -196,18 +196,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       }
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
-        float* d = As + (j * 32 + acol) * ASTR + arow + 32 * i;
+        float* d = As + boff + (j * 32 + acol) * ASTR + arow + 32 * i;
         d[0] = areg[j][i].x; d[ASTR] = areg[j][i].y; d[2 * ASTR] = areg[j][i].z; d[3 * ASTR] = areg[j][i].w;
       }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) {
         if (BT) {
-          float* d = Bs + (j * 32 + acol) * BSTR + arow + 32 * i;
+          float* d = Bs + boff + (j * 32 + acol) * BSTR + arow + 32 * i;
           d[0] = breg[j][i].x; d[BSTR] = breg[j][i].y; d[2 * BSTR] = breg[j][i].z; d[3 * BSTR] = breg[j][i].w;
         } else {
           const int idx = tid + 256 * i;
           const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
-          *reinterpret_cast<float4*>(Bs + (j * 32 + kk) * BSTR + n4 * 4) = breg[j][i];
+          *reinterpret_cast<float4*>(Bs + boff + (j * 32 + kk) * BSTR + n4 * 4) = breg[j][i];
         }
       }
     }
@@ -224,24 +224,48 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   const float* Aw = As + (wk * KS * 32 + half) * ASTR + wm * (32 * TM) + l31;
   const float* Bw = Bs + (wk * KS * 32 + half) * BSTR + wn * (32 * TN) + l31;
 
-  if (it_begin < it_end) load_slices(it_begin);
-  for (int it = it_begin; it < it_end; ++it) {
-    __syncthreads();                 // previous iteration's MFMA reads are done
-    store_slices(it);
-    __syncthreads();
-    if (it + 1 < it_end) load_slices(it + 1);   // in flight while the matrix cores work
+  auto compute = [&](int boff) {
 #pragma unroll
     for (int s = 0; s < 16 * KS; ++s) {
       float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = Aw[2 * s * ASTR + i * 32];
+      for (int i = 0; i < TM; ++i) a[i] = Aw[boff + 2 * s * ASTR + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bw[2 * s * BSTR + j * 32];
+      for (int j = 0; j < TN; ++j) b[j] = Bw[boff + 2 * s * BSTR + j * 32];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (it_begin < it_end) load_slices(it_begin);
+  if (DB) {
+    // two LDS buffers: slice i+1 is written while nobody reads its buffer -> one barrier per slice.
+    // Measured on MI355X (round 1): 5 % SLOWER than the two-barrier single buffer on every tile shape (the
+    // doubled LDS footprint and the later store placement cost more than the barrier saves at 2 waves/SIMD),
+    // so no shipped configuration enables it; kept for re-evaluation with deeper pipelines.
+    int cur = 0;
+    if (it_begin < it_end) {
+      store_slices(it_begin, 0);
+      __syncthreads();
+    }
+    for (int it = it_begin; it < it_end; ++it) {
+      const bool more = it + 1 < it_end;
+      if (more) load_slices(it + 1);              // global loads in flight under the MFMAs
+      compute(cur * STAGE);
+      if (more) store_slices(it + 1, (cur ^ 1) * STAGE);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    for (int it = it_begin; it < it_end; ++it) {
+      __syncthreads();                 // previous iteration's MFMA reads are done
+      store_slices(it, 0);
+      __syncthreads();
+      if (it + 1 < it_end) load_slices(it + 1);   // in flight while the matrix cores work
+      compute(0);
     }
   }
 
@@ -466,16 +490,16 @@ static const TileCfg kCfg[] = {
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool BT>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT>
 static int launch_cfg(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KC = 32 * WK * KS;
   constexpr int ASTR = BM + 1, BSTR = BN + (BT ? 1 : 0);
-  size_t stage = (size_t)KC * (ASTR + BSTR) * sizeof(float);
+  size_t stage = (size_t)KC * (ASTR + BSTR) * sizeof(float) * (DB ? 2 : 1);
   size_t red = WK > 1 ? (size_t)(WK - 1) * WM * WN * TM * TN * 16 * 64 * sizeof(float) : 0;
   size_t lds = stage > red ? stage : red;
   int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles, splitk, a.batch > 1 ? a.batch : 1);
-  auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, BT>;
+  auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -530,12 +554,12 @@ template <bool BT>
 static int dispatch(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hipStream_t st) {
   if (a.epi == LDMK_EPI_GEGLU && !kCfg[cfg - 1].even_tn) cfg = 3;   // GEGLU needs (value, gate) tile pairs
   switch (cfg) {
-    case 1: return launch_cfg<2, 2, 2, 2, 1, 1, BT>(a, splitk, ws, st);   // 128x128
-    case 2: return launch_cfg<1, 2, 2, 2, 1, 2, BT>(a, splitk, ws, st);   // 64x128, 64 k per stage
-    case 3: return launch_cfg<2, 2, 1, 1, 4, 1, BT>(a, splitk, ws, st);   // 64x64, K split over the 4 waves
-    case 4: return launch_cfg<1, 1, 2, 2, 1, 2, BT>(a, splitk, ws, st);   // 64x64, 64 k per stage
-    case 5: return launch_cfg<1, 5, 4, 1, 1, 1, BT>(a, splitk, ws, st);   // 128x160
-    default: return launch_cfg<1, 5, 2, 1, 2, 1, BT>(a, splitk, ws, st);  // 64x160, K split over wave pairs
+    case 1: return launch_cfg<2, 2, 2, 2, 1, 1, false, BT>(a, splitk, ws, st);   // 128x128
+    case 2: return launch_cfg<1, 2, 2, 2, 1, 2, false, BT>(a, splitk, ws, st);    // 64x128, 64 k per stage
+    case 3: return launch_cfg<2, 2, 1, 1, 4, 1, false, BT>(a, splitk, ws, st);   // 64x64, K split over the 4 waves
+    case 4: return launch_cfg<1, 1, 2, 2, 1, 2, false, BT>(a, splitk, ws, st);    // 64x64, 64 k per stage
+    case 5: return launch_cfg<1, 5, 4, 1, 1, 1, false, BT>(a, splitk, ws, st);    // 128x160
+    default: return launch_cfg<1, 5, 2, 1, 2, 1, false, BT>(a, splitk, ws, st);  // 64x160, K split over wave pairs
   }
 }
 

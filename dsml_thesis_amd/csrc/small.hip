@@ -285,6 +285,18 @@ __global__ void permute3_kernel(const float* __restrict__ src, float* __restrict
   }
 }
 
+// conv weight OIHW [O][I][3][3] -> igemm K order [I/32][9][32][O] (channel-chunk major, tap minor)
+__global__ void pack_conv3x3_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int I, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int o = (int)(i % O);
+    long long r = i / O;
+    const int kk = (int)(r % 32); r /= 32;
+    const int tap = (int)(r % 9);
+    const int cc = (int)(r / 9);
+    dst[i] = src[((long long)o * I + cc * 32 + kk) * 9 + tap];
+  }
+}
+
 __global__ void postprocess_frames_kernel(const float* __restrict__ x, float* __restrict__ out, int n, int c, int hw,
                                           long long total) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -426,6 +438,14 @@ extern "C" int ldmk_permute3(const float* src, float* dst, int d0, int d1, int d
   hipLaunchKernelGGL(permute3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, d0, d1, d2, p0,
                      p1, p2, total);
   return check_launch("ldmk_permute3");
+}
+
+extern "C" int ldmk_pack_conv3x3(const float* src, float* dst, int cout, int cin, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(src && dst && cout > 0 && cin > 0 && cin % 32 == 0, "ldmk_pack_conv3x3: cin=%d must be a multiple of 32", cin);
+  long long total = (long long)cout * cin * 9;
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, cout, cin, total);
+  return check_launch("ldmk_pack_conv3x3");
 }
 
 extern "C" int ldmk_postprocess_frames(const float* x, float* out, int n, int c, int hw, void* stream) {

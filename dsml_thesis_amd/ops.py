@@ -27,7 +27,17 @@ def _chk(t, name):
 
 # ------------------------------------------------------------------------------------------ packing
 def pack_conv3x3(w):
-    """torch OIHW (O,I,3,3) -> [9*I][O] (tap-major K, cout contiguous)."""
+    """torch OIHW (O,I,3,3) -> the igemm conv K order [I/32][9][32][O] (as a [9*I][O] matrix).  I % 32 == 0."""
+    _chk(w, "pack_conv3x3")
+    o, i, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    out = torch.empty(9 * i, o, device=w.device, dtype=torch.float32)
+    L.call("ldmk_pack_conv3x3", _ptr(w), _ptr(out), o, i, stream())
+    return out
+
+
+def pack_conv3x3_narrow(w):
+    """torch OIHW (O,I,3,3) -> [9][I][O] for the narrow boundary convs (ldmk_conv3x3_in / ldmk_conv3x3_out)."""
     _chk(w, "pack_conv3x3")
     o, i, kh, kw = w.shape
     assert kh == 3 and kw == 3

@@ -262,7 +262,7 @@ class UNetModel(nn.Module):
             elif m.kind == "st":
                 stp(prefix, m)
             elif m.kind == "conv_in":
-                P[prefix + "w"] = ops.pack_conv3x3(sd[prefix + "weight"])
+                P[prefix + "w"] = ops.pack_conv3x3_narrow(sd[prefix + "weight"])
             elif m.kind == "down":
                 P[prefix + "w"] = ops.pack_conv3x3(sd[prefix + "op.weight"])
             elif m.kind == "up":
@@ -273,7 +273,7 @@ class UNetModel(nn.Module):
         self._emb_total = off
         P["te0"] = ops.pack_linear(sd["time_embed.0.weight"])
         P["te2"] = ops.pack_linear(sd["time_embed.2.weight"])
-        P["out"] = ops.pack_conv3x3(sd["out.2.weight"])
+        P["out"] = ops.pack_conv3x3_narrow(sd["out.2.weight"])
         P["freqs"] = ops.timestep_freqs(self.model_channels, device=dev)
         self._sd = sd
         self._packed = P

@@ -45,7 +45,7 @@ enum { LDMK_TF_NONE = 0, LDMK_TF_AFFINE = 1, LDMK_TF_AFFINE_SILU = 2, LDMK_TF_LA
 enum { LDMK_EPI_NONE = 0, LDMK_EPI_GEGLU = 1 };
 
 typedef struct ldmk_igemm_args {
-  int M, N, K;               /* K = taps*(c0+c1) for LDMK_A_CONV3X3 (taps = 9), else c0+c1        */
+  int M, N, K;               /* K = 9*(c0+c1) for LDMK_A_CONV3X3 (weights packed by ldmk_pack_conv3x3), else c0+c1 */
   const float* a0;           /* first A source, NHWC rows of c0 channels                          */
   const float* a1;           /* optional second source (channel concat, openaimodel.py:736), c1   */
   int c0, c1;                /* both multiples of 32                                              */
@@ -189,6 +189,10 @@ int ldmk_vq_nearest(const float* z, const float* codebook, float* zq, int* idx, 
  * ldmk_postprocess_frames: sample_affectnet.py:127,132: clamp((x+1)/2,0,1), NCHW -> NHWC.
  */
 int ldmk_permute3(const float* src, float* dst, int d0, int d1, int d2, int p0, int p1, int p2, void* stream);
+/* ldmk_pack_conv3x3: torch conv weight OIHW [cout][cin][3][3] -> the K order ldmk_igemm's LDMK_A_CONV3X3 mode walks:
+ *   [cin/32][9][32][cout] (32-channel chunk major, tap minor, so that nine consecutive K slices re-read the same
+ *   pixels and hit L1/L2).  cin % 32 == 0.  (The narrow boundary convs ldmk_conv3x3_in/out take [9][cin][cout].) */
+int ldmk_pack_conv3x3(const float* src, float* dst, int cout, int cin, void* stream);
 int ldmk_postprocess_frames(const float* x, float* out, int n, int c, int hw, void* stream);
 /* out[m][c] += vec[m / rows_per_sample][c]  (cross-attention with a 1-token context collapses to
  * a per-sample vector; attention.py:170-193 with L_ctx == 1) */

@@ -283,14 +283,14 @@ def test_dense_small_and_timestep_embedding(ops):
 def test_boundary_convs(ops):
     x0, x1 = rnd(60, 2, 3, 12, 10), rnd(61, 2, 6, 12, 10)
     w, b = rnd(62, 160, 9, 3, 3) / 9.0, rnd(63, 160)
-    y = ops.conv3x3_in(x0.cuda(), ops.pack_conv3x3(w.cuda()), b.cuda(), 160, x1=x1.cuda())
+    y = ops.conv3x3_in(x0.cuda(), ops.pack_conv3x3_narrow(w.cuda()), b.cuda(), 160, x1=x1.cuda())
     close(nchw(y), F.conv2d(torch.cat([x0, x1], 1), w, b, padding=1), 1e-5, 1e-5)
     x = rnd(64, 2, 160, 9, 11) * 1.4
     gamma, beta = 1 + 0.1 * rnd(65, 160), 0.1 * rnd(66, 160)
     w, b = rnd(67, 3, 160, 3, 3) / 38.0, rnd(68, 3)
     xs = nhwc(x)
     coef = ops.gn_coef(xs, None, 2, 99, gamma.cuda(), beta.cuda(), 1e-5)
-    y = ops.conv3x3_out(xs, coef, ops.pack_conv3x3(w.cuda()), b.cuda(), 3)
+    y = ops.conv3x3_out(xs, coef, ops.pack_conv3x3_narrow(w.cuda()), b.cuda(), 3)
     close(y, F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, 1e-5)), w, b, padding=1), 1e-4, 1e-4)
     x, w, b = rnd(69, 2, 3, 8, 8), rnd(70, 3, 3, 1, 1), rnd(71, 3)
     close(ops.conv1x1_nchw(x.cuda(), w.cuda(), b.cuda()), F.conv2d(x, w, b), 1e-6, 1e-6)

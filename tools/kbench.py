@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 from dsml_thesis_amd import ops, lib as L  # noqa: E402
 
 
-def timeit(fn, reps=20, warm=3):
+def timeit(fn, reps=int(os.environ.get('KB_REPS', '20')), warm=3):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -66,6 +66,12 @@ if __name__ == "__main__":
         attn(16, 256, 20)
         attn(16, 1024, 5)
         attn(16, 64, 20)
+    elif what == "pmc":
+        gemm(65536, 160, 1440, conv=(16, 64, 64))
+        gemm(65536, 160, 2880, conv=(16, 64, 64))
+        gemm(4096, 5120, 640, ln=True, geglu=True)
+        gemm(65536, 160, 160, res=True)
+        attn(16, 4096, 5)
     elif what == "gemm":
         gemm(65536, 160, 1440, conv=(16, 64, 64))
         gemm(4096, 5120, 640, ln=True, geglu=True)
