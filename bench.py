@@ -179,13 +179,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("LDMK_BENCH_BACKEND", "nccl")      # "gloo": rehearse the N>1 path on a 1-GPU box
+    if backend == "gloo":
+        local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     from dsml_thesis_amd.build import build_lib
     if rank == 0:
@@ -210,7 +217,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if dist is not None:
-            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            tt = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = tt.item()
         assert torch.isfinite(run.pg.inputs["x"]).all(), "non-finite latent after the timed steps"
