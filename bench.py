@@ -85,7 +85,7 @@ class StepRunner:
         x = pg.inputs["x"]
         rc = pg.lib.ldmk_ddim_step(x.data_ptr(), pg.outputs["eps"].data_ptr(), 0, s._table.data_ptr(),
                                    self.step_idx.data_ptr(), 1.0, 0, x.data_ptr(), self.pred_x0.data_ptr(), self.per,
-                                   self.batch, s._ts_table.data_ptr(), pg.inputs["t"].data_ptr(), self.batch, 1,
+                                   self.batch, s._ts_table.data_ptr(), pg.inputs["t"].data_ptr(), self.batch, 1, self.S,
                                    torch.cuda.current_stream().cuda_stream)
         self.L.check(rc, "ldmk_ddim_step")
 

@@ -198,11 +198,13 @@ __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __res
   }
 }
 
-// runs after ddim_step_kernel on the same stream: index -= 1, ts[:] = timesteps[index]
+// runs after ddim_step_kernel on the same stream: index -= dir (sampling walks down, inversion up),
+// ts[:] = timesteps[index]
 __global__ void ddim_advance_kernel(int* step_idx, const long long* __restrict__ timesteps, long long* __restrict__ ts,
-                                    int n_ts) {
-  int index = *step_idx - 1;
+                                    int n_ts, int dir, int n_steps) {
+  int index = *step_idx - dir;
   if (index < 0) index = 0;
+  if (index > n_steps - 1) index = n_steps - 1;
   const long long t = timesteps[index];
   for (int i = threadIdx.x; i < n_ts; i += blockDim.x) ts[i] = t;
   __syncthreads();
@@ -391,16 +393,17 @@ extern "C" int ldmk_conv1x1_nchw(const float* x, const float* w, const float* bi
 extern "C" int ldmk_ddim_step(const float* x, const float* eps, const float* noise, const float* table,
                               int* step_idx, float cfg_scale, int cfg, float* x_prev, float* pred_x0,
                               long long per_sample, int n, const long long* timesteps, long long* ts, int n_ts,
-                              int advance, void* stream) {
+                              int advance, int n_steps, void* stream) {
   LDMK_ENTER();
   LDMK_REQUIRE(x && eps && table && step_idx && x_prev && per_sample > 0 && n > 0, "ldmk_ddim_step: bad args");
-  if (advance) LDMK_REQUIRE(timesteps && ts && n_ts > 0, "ldmk_ddim_step: advance needs timesteps/ts");
+  if (advance) LDMK_REQUIRE(timesteps && ts && n_ts > 0 && n_steps > 0 && (advance == 1 || advance == -1),
+                            "ldmk_ddim_step: advance (+1 down / -1 up) needs timesteps/ts/n_steps");
   long long total = per_sample * n;
   hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, eps, noise, table,
                      step_idx, cfg_scale, cfg, x_prev, pred_x0, total);
   if (advance)
     hipLaunchKernelGGL(ddim_advance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_idx,
-                       timesteps, ts, n_ts);
+                       timesteps, ts, n_ts, advance, n_steps);
   return check_launch("ldmk_ddim_step");
 }
 

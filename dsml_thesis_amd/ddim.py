@@ -34,8 +34,13 @@ class DDIMSampler(object):
             attr = attr.to(self.model.device)
         setattr(self, name, attr)
 
-    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
-        self.ddim_timesteps = S_.make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps)
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True, strength=None):
+        """`strength` (latent-manipulation scripts only, compute_latents.py:108-112): strength-scaled timesteps."""
+        if strength is None:
+            self.ddim_timesteps = S_.make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps)
+        else:
+            assert ddim_discretize == "uniform"
+            self.ddim_timesteps = S_.make_ddim_timesteps_strength(ddim_num_steps, self.ddpm_num_timesteps, strength)
         ac = self.model.alphas_cumprod
         assert ac.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
         sig, al, alp = S_.make_ddim_sampling_parameters(ac.cpu(), self.ddim_timesteps, ddim_eta)
@@ -45,11 +50,12 @@ class DDIMSampler(object):
         self.ddim_sqrt_one_minus_alphas = np.sqrt(1. - al)
         # device-resident [S][4] coefficient table + timestep table for the update kernel
         dev = self.model.device
-        key = (ddim_num_steps, float(ddim_eta), ddim_discretize)
+        key = (ddim_num_steps, float(ddim_eta), ddim_discretize, strength)
         if key not in self._tables:     # persistent device tables: captured graphs keep pointing at them
             self._tables[key] = (torch.from_numpy(S_.ddim_step_table(ac.cpu(), self.ddim_timesteps, ddim_eta)).to(dev),
-                                 torch.from_numpy(self.ddim_timesteps.astype(np.int64)).to(dev))
-        self._table, self._ts_table = self._tables[key]
+                                 torch.from_numpy(self.ddim_timesteps.astype(np.int64)).to(dev),
+                                 torch.from_numpy(S_.ddim_inversion_table(ac.cpu(), self.ddim_timesteps)).to(dev))
+        self._table, self._ts_table, self._inv_table = self._tables[key]
         self._sched_key = key
         self._eta = ddim_eta
 
@@ -94,7 +100,8 @@ class DDIMSampler(object):
     @torch.no_grad()
     def ddim_sampling(self, cond, shape, x_T=None, callback=None, img_callback=None, log_every_t=100,
                       unconditional_guidance_scale=1., unconditional_conditioning=None, noise=None,
-                      use_graph=False, policy_batch=None, return_x_inter_only=False, **kwargs):
+                      use_graph=False, policy_batch=None, return_x_inter_only=False, invert=False, **kwargs):
+        """invert=True runs the forward DDIM (inversion) direction: index 0 -> S-1 with q_sample_ddim's update."""
         dev = self.model.device
         unet = self.model.model.diffusion_model
         b = shape[0]
@@ -124,7 +131,7 @@ class DDIMSampler(object):
             x_buf[b:].copy_(img0)
         need_noise = self._eta != 0. or noise is not None
         lkey = (id(pg), cfg, float(unconditional_guidance_scale), self._sched_key, need_noise, bool(use_graph),
-                noise is None)
+                noise is None, bool(invert))
         st = self._loops.get(lkey)
         if st is None:
             st = dict(pred_x0=torch.empty_like(img0), step_idx=torch.zeros(1, dtype=torch.int32, device=dev),
@@ -133,21 +140,23 @@ class DDIMSampler(object):
         pred_x0, step_idx, nz_buf = st["pred_x0"], st["step_idx"], st["nz"]
         eps = pg.outputs["eps"]
         per = img0[0].numel()
-        table, ts_table = self._table, self._ts_table
+        table, ts_table = (self._inv_table if invert else self._table), self._ts_table
         scale = float(unconditional_guidance_scale)
+        first = 0 if invert else S - 1
+        adv = -1 if invert else 1
 
         def reset_state():
             img.copy_(img0)
             if cfg:
                 x_buf[b:].copy_(img0)
-            step_idx.fill_(S - 1)
-            pg.inputs["t"].fill_(int(self.ddim_timesteps[S - 1]))
+            step_idx.fill_(first)
+            pg.inputs["t"].fill_(int(self.ddim_timesteps[first]))
 
         def one_step():
             pg.run()
             rc = lib.ldmk_ddim_step(img.data_ptr(), eps.data_ptr(), 0 if nz_buf is None else nz_buf.data_ptr(),
                                     table.data_ptr(), step_idx.data_ptr(), scale, 1 if cfg else 0, img.data_ptr(),
-                                    pred_x0.data_ptr(), per, b, ts_table.data_ptr(), pg.inputs["t"].data_ptr(), nb, 1,
+                                    pred_x0.data_ptr(), per, b, ts_table.data_ptr(), pg.inputs["t"].data_ptr(), nb, adv, S,
                                     torch.cuda.current_stream().cuda_stream)
             L.check(rc, "ldmk_ddim_step")
             if cfg:
@@ -211,9 +220,36 @@ class DDIMSampler(object):
         x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)
         L.call("ldmk_ddim_step", x.contiguous().data_ptr(), e.data_ptr(), 0 if noise is None else noise.contiguous().data_ptr(),
                self._table.data_ptr(), step_idx.data_ptr(), float(unconditional_guidance_scale), 1 if cfg else 0,
-               x_prev.data_ptr(), pred_x0.data_ptr(), x[0].numel(), b, 0, 0, 0, 0,
+               x_prev.data_ptr(), pred_x0.data_ptr(), x[0].numel(), b, 0, 0, 0, 0, 0,
                torch.cuda.current_stream().cuda_stream)
         return x_prev, pred_x0
+
+    # ------------------------------------------------------------------------------------------ latent manipulation
+    @torch.no_grad()
+    def compute_latents(self, S, batch_size, shape, conditioning=None, x0=None, eta=0., unconditional_guidance_scale=1.,
+                        unconditional_conditioning=None, strength=0.5, verbose=True, use_graph=False, **kwargs):
+        """DDIM inversion followed by regeneration (face_reenactment/compute_latents.py:297-362):
+        returns (img, x_latent, x0).  The forward direction is `q_sample_ddim` (:364-406)."""
+        assert x0 is not None and conditioning is not None
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose, strength=strength)
+        size = (batch_size,) + tuple(shape)
+        kw = dict(unconditional_guidance_scale=unconditional_guidance_scale,
+                  unconditional_conditioning=unconditional_conditioning, use_graph=use_graph)
+        x_lat, _ = self.ddim_sampling(conditioning, size, x_T=x0, invert=True, **kw)
+        img, _ = self.ddim_sampling(conditioning, size, x_T=x_lat, **kw)
+        return img, x_lat, x0
+
+    @torch.no_grad()
+    def ddim_tuned_sampling(self, S, batch_size, shape, x_lat, cond, eta=0., unconditional_guidance_scale=1.,
+                            unconditional_conditioning=None, strength=1.0, verbose=True, use_graph=False, **kwargs):
+        """Reverse DDIM from a precomputed latent on the strength-scaled schedule
+        (face_reenactment/latent_manipulation_tuned.py:493-538)."""
+        assert cond is not None and x_lat is not None and eta == 0
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose, strength=strength)
+        img, _ = self.ddim_sampling(cond, (batch_size,) + tuple(shape), x_T=x_lat,
+                                    unconditional_guidance_scale=unconditional_guidance_scale,
+                                    unconditional_conditioning=unconditional_conditioning, use_graph=use_graph)
+        return img
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -55,6 +55,14 @@ def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timestep
     return steps + 1
 
 
+def make_ddim_timesteps_strength(num_ddim_timesteps, num_ddpm_timesteps, strength=1.0):
+    """Strength-scaled 'uniform' schedule of the latent-manipulation scripts (compute_latents.py:52-73,
+    latent_manipulation_tuned.py:52-72): [1] + int(linspace(0,1,S) * int(T*strength))[1:]."""
+    ts = np.linspace(0, 1, num_ddim_timesteps) * int(num_ddpm_timesteps * strength)
+    ts = [int(s) for s in list(ts)]
+    return np.asarray([1] + ts[1:])
+
+
 def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta):
     """alphacums: float32 CPU tensor.  Returns (sigmas f64 ndarray, alphas f32 ndarray, alphas_prev f64 ndarray)
     with the reference's promotion rules: `ndarray / Tensor` is reciprocal(float32)*float64, `Tensor / ndarray`
@@ -68,6 +76,17 @@ def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta):
     recip = (1 - alphas).reciprocal().double().numpy()
     sigmas = eta * np.sqrt((1 - alphas_prev) * recip * (1 - a64 / alphas_prev))
     return sigmas, alphas.numpy(), alphas_prev
+
+
+def ddim_inversion_table(alphacums, ddim_timesteps):
+    """[S][4] rows for the forward (inversion) DDIM update q_sample_ddim (compute_latents.py:364-406), in the slot
+    order of the sampling table so that the same update kernel serves both directions:
+      slot a_t <- alphas_prev[i], slot a_prev <- alphas[i] (the 'next' level), sigma <- 0,
+      slot sqrt(1-a_t) <- sqrt(1 - alphas_prev[i])  (float64 ndarray math, rounded once like torch.full does)."""
+    _, alphas, alphas_prev = make_ddim_sampling_parameters(alphacums, ddim_timesteps, 0.0)
+    tab = np.stack([alphas_prev.astype(np.float32), alphas.astype(np.float32), np.zeros(len(alphas), np.float32),
+                    np.sqrt(1.0 - alphas_prev).astype(np.float32)], axis=1)
+    return np.ascontiguousarray(tab)
 
 
 def ddim_step_table(alphacums, ddim_timesteps, eta):

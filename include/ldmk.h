@@ -161,16 +161,17 @@ int ldmk_conv1x1_nchw(const float* x, const float* w, const float* bias, float* 
  * step counter so that one captured hipGraph replays for every step.
  * ldmk_ddim_step: ddim.py:170-203 -- optional CFG combine (eps has 2n items: [uncond | cond]),
  *   pred_x0, dir_xt, x_prev.  table: [S][4] = (a_t, a_prev, sigma_t, sqrt_one_minus_at) float32;
- *   step_idx: device int32 holding the CURRENT index (S-1 .. 0); it is decremented by the kernel
- *   when advance != 0, and ts (int64 [n_ts], the UNet's timestep input) is rewritten with
- *   timesteps[new index].  noise may be NULL (eta == 0).
+ *   step_idx: device int32 holding the CURRENT index; advance = +1 walks it down (sampling, S-1 .. 0),
+ *   advance = -1 walks it up (DDIM inversion, compute_latents.py:364-406, which is the same update with
+ *   the table rows (a_prev, a_t, 0, sqrt(1-a_prev))), clamped to [0, n_steps-1]; ts (int64 [n_ts], the
+ *   UNet's timestep input) is rewritten with timesteps[new index].  noise may be NULL (eta == 0).
  * ldmk_ddpm_step: ddpm.py:215-228,1049-1109 -- ancestral update with per-sample t (int64).
  *   tables: [T][4] = (sqrt_recip_ac, sqrt_recipm1_ac, post_mean_coef1, post_mean_coef2) and
  *   logvar[T] (posterior_log_variance_clipped).
  */
 int ldmk_ddim_step(const float* x, const float* eps, const float* noise, const float* table, int* step_idx,
                    float cfg_scale, int cfg, float* x_prev, float* pred_x0, long long per_sample, int n,
-                   const long long* timesteps, long long* ts, int n_ts, int advance, void* stream);
+                   const long long* timesteps, long long* ts, int n_ts, int advance, int n_steps, void* stream);
 int ldmk_ddpm_step(const float* x, const float* eps, const float* noise, const float* tables, const float* logvar,
                    const long long* t, float* x_prev, long long per_sample, int n, void* stream);
 

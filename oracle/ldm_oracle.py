@@ -272,6 +272,47 @@ def ddim_sample(sd, cfg, sched, S, x_T, cond=None, c_concat=None, eta=0.0, scale
     return (img, traj) if return_all else img
 
 
+def make_ddim_timesteps_strength(num_ddim, num_ddpm=1000, strength=1.0):
+    """compute_latents.py:52-73 (strength-scaled 'uniform' schedule of the latent-manipulation scripts)."""
+    ts = np.linspace(0, 1, num_ddim) * int(num_ddpm * strength)
+    return np.asarray([1] + [int(s) for s in list(ts)][1:])
+
+
+def ddim_invert_and_regenerate(sd, cfg, sched, S, x0, cond, strength=0.5, scale=1.0, uncond=None):
+    """DDIMSampler.compute_latents + q_sample_ddim, compute_latents.py:297-406: forward DDIM (inversion) over the
+    strength-scaled timesteps, then the reverse loop.  Returns (img, x_latent)."""
+    ts = make_ddim_timesteps_strength(S, sched["betas"].shape[0], strength)
+    ac = torch.as_tensor(sched["alphas_cumprod"], dtype=torch.float32)
+    alphas = ac[ts]                                                        # f32 tensor
+    alphas_prev = np.asarray([ac[0].item()] + ac[ts[:-1]].tolist())        # f64 ndarray
+    s1m = np.sqrt(1.0 - alphas.numpy())                                    # f32
+    s1m_prev = np.sqrt(1.0 - alphas_prev)                                  # f64
+    b = x0.shape[0]
+
+    def eps_of(x, t):
+        if uncond is None or scale == 1.0:
+            return apply_model(sd, cfg, x, t, [cond])
+        e_u, e_c = apply_model(sd, cfg, torch.cat([x] * 2), torch.cat([t] * 2), [torch.cat([uncond, cond])]).chunk(2)
+        return cfg_combine(e_u, e_c, scale)
+
+    f32 = lambda v: torch.tensor(float(v), dtype=torch.float32)
+    x = x0.clone()
+    for i, step in enumerate(ts):                                          # forward DDIM, :343-349
+        t = torch.full((b,), int(step), dtype=torch.long)
+        e = eps_of(x, t)
+        at, at_next = f32(alphas_prev[i]), f32(alphas[i].item())
+        pred_x0 = (x - f32(s1m_prev[i]) * e) / at.sqrt()
+        x = at_next.sqrt() * pred_x0 + (1.0 - at_next).sqrt() * e
+    x_lat = x.clone()
+    img = x_lat
+    for i, step in enumerate(np.flip(ts)):                                 # reverse DDIM, :351-360 (eta = 0)
+        index = S - i - 1
+        t = torch.full((b,), int(step), dtype=torch.long)
+        e = eps_of(img, t)
+        img, _ = ddim_update(img, e, alphas[index].item(), np.float32(alphas_prev[index]), 0.0, s1m[index])
+    return img, x_lat
+
+
 def p_sample_loop(sd, cfg, sched, x_T, cond=None, timesteps=None, noise=None):
     """LatentDiffusion.p_sample_loop, ddpm.py:1167-1216 (clip_denoised False, ddpm.py:463)."""
     T = sched["betas"].shape[0] if timesteps is None else timesteps

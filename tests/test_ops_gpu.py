@@ -310,14 +310,14 @@ def test_sampler_updates_golden(ops):
     tcur = torch.zeros(2, dtype=torch.int64, device="cuda")
     xp, p0 = torch.empty_like(x), torch.empty_like(x)
     L.call("ldmk_ddim_step", x.data_ptr(), e.data_ptr(), noise.data_ptr(), table.data_ptr(), step.data_ptr(), 1.0, 0,
-           xp.data_ptr(), p0.data_ptr(), 3 * 32 * 32, 2, tsd.data_ptr(), tcur.data_ptr(), 2, 1, ops.stream())
+           xp.data_ptr(), p0.data_ptr(), 3 * 32 * 32, 2, tsd.data_ptr(), tcur.data_ptr(), 2, 1, 200, ops.stream())
     close(xp, g["ddim_x_prev"], 1e-6, 2e-6)
     close(p0, g["ddim_pred_x0"], 1e-6, 4e-6)
     assert step.item() == 99 and tcur.tolist() == [int(ts[99])] * 2
     # CFG combine inside the update: eps = [uncond | cond]
     e2 = torch.cat([rnd(33, 2, 3, 32, 32).cuda(), e])
     L.call("ldmk_ddim_step", x.data_ptr(), e2.data_ptr(), 0, table.data_ptr(), step.data_ptr(), 3.0, 1,
-           xp.data_ptr(), p0.data_ptr(), 3 * 32 * 32, 2, 0, 0, 0, 0, ops.stream())
+           xp.data_ptr(), p0.data_ptr(), 3 * 32 * 32, 2, 0, 0, 0, 0, 0, ops.stream())
     ec = O.cfg_combine(e2[:2].cpu(), e2[2:].cpu(), 3.0)
     rx, _ = O.ddim_update(x.cpu(), ec, tab["a_t"][99], tab["a_prev"][99], 0.0, tab["sqrt_one_minus_at"][99])
     # sigma from the eta=1 table still multiplies zero noise: compare against eta-1 coefficients, no noise

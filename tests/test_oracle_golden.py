@@ -188,3 +188,17 @@ def test_g7_talking_face():
         close(fr, g[f"frames_{tag}"], 1e-4, 3e-4)
     assert not np.allclose(g["frames_autoreg"][1:], g["frames_fixed"][1:])
     close(g["frames_fixed_batched"], g["frames_fixed"], 1e-4, 3e-4)
+
+
+def test_g8_ddim_inversion():
+    g = golden("g8_inversion.npz")
+    sd = recipe(W.unet_param_shapes(W.FR_UNET), gain=0.25)
+    s = O.register_schedule(**W.SCHEDULE)
+    c, uc = _fr_cond()
+    assert np.array_equal(O.make_ddim_timesteps_strength(4, 1000, 0.5), g["timesteps"])
+    x0 = rnd(81, 2, 3, 32, 32)
+    for tag, scale in (("cfg1", 1.0), ("cfg3", 3.0)):
+        img, lat = O.ddim_invert_and_regenerate(sd, W.FR_UNET, s, 4, x0, c, strength=0.5, scale=scale,
+                                                uncond=uc if scale != 1.0 else None)
+        close(lat, g[f"xlat_{tag}"], 1e-4, 1e-4)
+        close(img, g[f"img_{tag}"], 1e-4, 1e-4)

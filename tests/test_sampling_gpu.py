@@ -204,3 +204,26 @@ def test_sharded_sampling_bitwise_equals_single_gpu(fr):
                 parts.append(sample_sharded(s, S, hi - lo, (3, 32, 32), sub, **kw))
         assert torch.equal(torch.cat(parts_z), full_z), f"latents, world={world}"
         assert torch.equal(torch.cat(parts), full), f"frames, world={world}"
+
+
+def test_ddim_inversion_and_tuned_sampling_golden(fr):
+    """forward DDIM (inversion) + regeneration on the strength-scaled schedule, against the
+    reference's compute_latents.DDIMSampler (fixture g8), eager and hipGraph."""
+    from dsml_thesis_amd.ddim import DDIMSampler
+    g = golden("g8_inversion.npz")
+    c, uc = _cond(fr)
+    x0 = rnd(81, 2, 3, 32, 32).cuda()
+    s = DDIMSampler(fr)
+    for tag, scale in (("cfg1", 1.0), ("cfg3", 3.0)):
+        kw = dict(unconditional_guidance_scale=scale, unconditional_conditioning=uc if scale != 1.0 else None)
+        img, lat, _ = s.compute_latents(S=4, batch_size=2, shape=[3, 32, 32], conditioning=c, x0=x0, strength=0.5,
+                                        verbose=False, **kw)
+        assert np.array_equal(s.ddim_timesteps, g["timesteps"])
+        close(lat, g[f"xlat_{tag}"], 3e-4, 3e-4)
+        close(img, g[f"img_{tag}"], 5e-4, 5e-4)
+        img_g, lat_g, _ = s.compute_latents(S=4, batch_size=2, shape=[3, 32, 32], conditioning=c, x0=x0, strength=0.5,
+                                            verbose=False, use_graph=True, **kw)
+        assert torch.equal(lat, lat_g) and torch.equal(img, img_g)
+        # latent_manipulation_tuned.ddim_tuned_sampling == the reverse half started from the stored latent
+        again = s.ddim_tuned_sampling(4, 2, [3, 32, 32], lat, c, strength=0.5, verbose=False, **kw)
+        assert torch.equal(again, img)

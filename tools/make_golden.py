@@ -313,6 +313,30 @@ def gen_fr():
     g5["s200_e1_noise"] = torch.stack([torch.randn(xT.shape) for _ in range(3)])
     save("g5_sampling_fr.npz", **g5)
 
+    # ---- G8 DDIM inversion + regeneration (latent manipulation) ---------------------
+    print("[G8] DDIM inversion (compute_latents.py)")
+    import compute_latents as cl          # the driver script: importable once albumentations/OmegaConf are stubbed
+
+    class CPUInv(cl.DDIMSampler):
+        def register_buffer(self, n, a):
+            setattr(self, n, a)
+
+    inv = CPUInv(ld)
+    x0 = rnd(81, 2, 3, 32, 32)
+    g8 = {}
+    for tag, scale in (("cfg1", 1.0), ("cfg3", 3.0)):
+        img, xlat, _ = inv.compute_latents(S=4, batch_size=2, shape=[3, 32, 32], conditioning=c, x0=x0, eta=0.0,
+                                           verbose=False, strength=0.5, unconditional_guidance_scale=scale,
+                                           unconditional_conditioning=uc if scale != 1.0 else None)
+        assert np.array_equal(inv.ddim_timesteps, O.make_ddim_timesteps_strength(4, 1000, 0.5))
+        mimg, mlat = O.ddim_invert_and_regenerate(usd, W.FR_UNET, sched, 4, x0, c, strength=0.5, scale=scale,
+                                                  uncond=uc if scale != 1.0 else None)
+        check(f"inversion latent {tag}", xlat, mlat, 1e-4, 1e-4)
+        check(f"regenerated {tag}", img, mimg, 1e-4, 1e-4)
+        g8[f"xlat_{tag}"], g8[f"img_{tag}"] = xlat, img
+    g8["timesteps"] = inv.ddim_timesteps
+    save("g8_inversion.npz", **g8)
+
     # ---- G6 VQGAN first stage ----------------------------------------------------------
     print("[G6] VQGAN")
     g6 = {}

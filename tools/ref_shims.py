@@ -38,6 +38,8 @@ def install(tree):
     lc.ListConfig = ListConfig
     oc.listconfig = lc
     oc.ListConfig = ListConfig
+    oc.OmegaConf = type("OmegaConf", (), {})      # name only: the driver scripts import it at module level
+    _mod("albumentations")                        # dataset augmentation library, imported by taming/data/*.py
 
     pl = _mod("pytorch_lightning")
 
