@@ -227,3 +227,13 @@ def test_ddim_inversion_and_tuned_sampling_golden(fr):
         # latent_manipulation_tuned.ddim_tuned_sampling == the reverse half started from the stored latent
         again = s.ddim_tuned_sampling(4, 2, [3, 32, 32], lat, c, strength=0.5, verbose=False, **kw)
         assert torch.equal(again, img)
+
+
+def test_first_stage_non_square_and_batch_vs_oracle():
+    m = make_fr_model()
+    sd = W.synth_state_dict(W.vqmodel_param_shapes(W.VQ_F4))
+    z = rnd(95, 2, 3, 8, 12)
+    ref, _ = O.decode_first_stage(sd, W.VQ_F4, z, force_not_quantize=True)
+    close(m.first_stage_model.decode(z.cuda(), force_not_quantize=True), ref, 3e-4, 3e-4)
+    img = torch.tanh(rnd(96, 2, 3, 32, 48))
+    close(m.encode_first_stage(img.cuda()), O.encode_first_stage(sd, W.VQ_F4, img), 3e-4, 3e-4)

@@ -83,3 +83,14 @@ def test_unet_rejects_unsupported():
     m, _ = make_unet(W.FR_UNET)
     with pytest.raises(L.LdmkError):
         m(torch.zeros(1, 3, 32, 32), torch.zeros(1, dtype=torch.long), context=torch.zeros(1, 1, 512))
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 24, 40), (3, 8, 8), (5, 16, 24)])
+def test_unet_ragged_shapes_vs_oracle(n, h, w):
+    """Non-square / small latents and odd batch sizes: exercises partial tiles, the ragged attention tail (60 and
+    4 tokens at the lowest level), the stand-alone GroupNorm statistics fallback (H*W not a multiple of 32) and
+    split-K plans that differ from the benchmark shapes."""
+    m, sd = make_unet(W.FR_UNET)
+    x, t, ctx = rnd(50, n, 3, h, w), torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(1)), rnd(51, n, 1, 512)
+    ref = O.unet_forward(sd, W.FR_UNET, x, t, ctx)
+    close(m(x.cuda(), t.cuda(), context=ctx.cuda()), ref, 3e-4, 3e-4)
