@@ -17,6 +17,9 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     if torch.cuda.is_available():
+        # GPU box: make sure the in-tree HIP library matches the sources (no-op when it travelled up to date)
+        from dsml_thesis_amd.build import build_lib
+        build_lib(verbose=False)
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:
