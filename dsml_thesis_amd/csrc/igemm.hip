@@ -526,7 +526,7 @@ static void plan(const ldmk_igemm_args& a, int* cfg_out, int* splitk_out, long l
   const int nkc = a.K / 32;
   float best = -1.f;
   int best_cfg = 3, best_sk = 1;
-  static const int sks[] = {1, 2, 3, 4, 6, 8};
+  static const int sks[] = {1, 2, 3, 4, 6, 8, 12, 16};
   for (int c = 0; c < kNumCfg; ++c) {
     if (geglu && !kCfg[c].even_tn) continue;
     const long long tm = (a.M + kCfg[c].bm - 1) / kCfg[c].bm, tn = (a.N + kCfg[c].bn - 1) / kCfg[c].bn;
@@ -534,9 +534,9 @@ static void plan(const ldmk_igemm_args& a, int* cfg_out, int* splitk_out, long l
     const float col_use = (float)a.N / (float)(tn * kCfg[c].bn);
     const float row_use = (float)a.M / (float)(tm * kCfg[c].bm);
     const int iters = (nkc + kCfg[c].ns - 1) / kCfg[c].ns;
-    for (int si = 0; si < 6; ++si) {
+    for (int si = 0; si < 8; ++si) {
       const int sk = sks[si];
-      if (sk > 1 && (geglu || ws_elems <= 0 || iters / sk < 4 || b * sk * (long long)a.M * a.N > ws_elems)) continue;
+      if (sk > 1 && (geglu || ws_elems <= 0 || iters / sk < 2 || b * sk * (long long)a.M * a.N > ws_elems)) continue;
       const long long w = blocks * sk;
       const long long rounds = (w + 511) / 512;
       const float occ = (float)w / (float)(rounds * 512);
