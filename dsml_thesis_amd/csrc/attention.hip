@@ -19,6 +19,9 @@ constexpr int AT_D = 32;
 constexpr int AT_KT = 64;            // keys per staged tile
 constexpr int AT_KSTR = AT_D + 1;    // K rows padded: lanes read 32 different keys at fixed d
 
+// QT = query tiles (of 32) per wave.  QT = 2 lets one K / V operand read from LDS feed two MFMAs and halves the
+// barriers per MFMA (used when there are enough 256-query workgroups to fill the chip).
+template <int QT>
 __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                         int tokens, int heads, float scale) {
   __shared__ float Ks[AT_KT * AT_KSTR];
@@ -30,22 +33,25 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
   const int C = heads * AT_D;
   const int ld = 3 * C;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (128 * QT) + wave * (32 * QT);
   const float* base = qkv + (long long)b * tokens * ld;
   const bool wave_active = q0 < tokens;
-  const bool q_valid = q0 + l31 < tokens;   // ragged tail: lanes past the last query compute but never store
 
-  // Q fragment: B operand of S^T = K Q^T: lane holds Q[query = l31][d = 2s + half], pre-scaled
-  float qf[16];
-  {
-    const float* qp = base + (long long)(q_valid ? q0 + l31 : 0) * ld + h * AT_D;
+  // Q fragments: B operand of S^T = K Q^T: lane holds Q[query = l31][d = 2s + half], pre-scaled
+  float qf[QT][16];
+  f32x16 o[QT];
+  float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) qf[s] = q_valid ? qp[2 * s + half] * scale : 0.f;
+  for (int t = 0; t < QT; ++t) {
+    const bool q_valid = q0 + 32 * t + l31 < tokens;   // ragged tail: lanes past the last query never store
+    const float* qp = base + (long long)(q_valid ? q0 + 32 * t + l31 : 0) * ld + h * AT_D;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) qf[t][s] = q_valid ? qp[2 * s + half] * scale : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    m_run[t] = -INFINITY;
+    l_run[t] = 0.f;
   }
-  f32x16 o;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
 
   // staging map: 64 keys x 32 d = 512 float4 for K and for V; thread t -> key t/8 (+32), d4 = (t%8)*4
   const int skey = tid >> 3, sd = (tid & 7) * 4;
@@ -77,60 +83,76 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
     for (int sub = 0; sub < 2; ++sub) {
       const int key0 = kt * AT_KT + sub * 32;
       if (key0 >= tokens) break;
-      f32x16 s_acc;
+      f32x16 s_acc[QT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[t][r] = 0.f;
       const float* kbase = Ks + (sub * 32 + l31) * AT_KSTR + half;
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        s_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kbase[2 * s], qf[s], s_acc, 0, 0, 0);
-      // s_acc[r] = S[query l31][key = key0 + (r&3) + 8*(r>>2) + 4*half]
-      if (key0 + 32 > tokens) {   // ragged last sub-tile: keys past the end get -inf (their V rows are zero)
+      for (int s = 0; s < 16; ++s) {
+        const float kv = kbase[2 * s];                   // one LDS read feeds QT matrix instructions
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s_acc[r] = -INFINITY;
+        for (int t = 0; t < QT; ++t) s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qf[t][s], s_acc[t], 0, 0, 0);
       }
-      float mx = s_acc[0];
+      // s_acc[t][r] = S[query 32t + l31][key = key0 + (r&3) + 8*(r>>2) + 4*half]
+      const bool ragged = key0 + 32 > tokens;            // last sub-tile: keys past the end get -inf (V rows are zero)
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_acc[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float corr = __expf(m_run - m_new);     // 0 on the first tile (m_run = -inf)
-      float psum = 0.f;
+      for (int t = 0; t < QT; ++t) {
+        if (ragged) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s_acc[r] = __expf(s_acc[r] - m_new);
-        psum += s_acc[r];
+          for (int r = 0; r < 16; ++r)
+            if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s_acc[t][r] = -INFINITY;
+        }
+        float mx = s_acc[t][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_acc[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[t], mx);
+        const float corr = __expf(m_run[t] - m_new);     // 0 on the first tile (m_run = -inf)
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s_acc[t][r] = __expf(s_acc[t][r] - m_new);
+          psum += s_acc[t][r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run[t] = l_run[t] * corr + psum;
+        m_run[t] = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= corr;
       }
-      psum += __shfl_xor(psum, 32, 64);
-      l_run = l_run * corr + psum;
-      m_run = m_new;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] *= corr;
       // O^T[d][query] += sum_key V[key][d] * P[query][key]
       const float* vbase = Vs + (sub * 32 + 4 * half) * AT_D + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int krow = (r & 3) + 8 * (r >> 2);
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(vbase[krow * AT_D], s_acc[r], o, 0, 0, 0);
+        const float vv = vbase[krow * AT_D];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s_acc[t][r], o[t], 0, 0, 0);
       }
     }
   }
   if (!wave_active) return;
-  // o[r] = O[query l31][d = (r&3) + 8*(r>>2) + 4*half]; transpose through LDS for 128-B row stores
-  const float inv = 1.0f / l_run;
+  // o[t][r] = O[query][d = (r&3) + 8*(r>>2) + 4*half]; transpose through LDS for 128-B row stores
   float* ow = Os[wave];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
-    ow[l31 * 33 + d] = o[r] * inv;
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed
-  __builtin_amdgcn_wave_barrier();
-  float* op = out + ((long long)b * tokens + q0) * C + h * AT_D;
+  for (int t = 0; t < QT; ++t) {
+    const float inv = 1.0f / l_run[t];
 #pragma unroll
-  for (int q = 0; q < 32; q += 2)
-    if (q0 + q + half < tokens) op[(long long)(q + half) * C + l31] = ow[(q + half) * 33 + l31];
+    for (int r = 0; r < 16; ++r) {
+      const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+      ow[l31 * 33 + d] = o[t][r] * inv;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    float* op = out + ((long long)b * tokens + q0 + 32 * t) * C + h * AT_D;
+#pragma unroll
+    for (int q = 0; q < 32; q += 2)
+      if (q0 + 32 * t + q + half < tokens) op[(long long)(q + half) * C + l31] = ow[(q + half) * 33 + l31];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();      // the reads are done before the next tile overwrites the buffer
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -220,14 +242,25 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
 
 }  // namespace ldmk
 
+// test hook: 0 = choose, 1 / 2 = force the number of query tiles per wave
+static int g_attn_qt = 0;
+extern "C" void ldmk_attn_force_qt(int qt) { g_attn_qt = qt; }
+
 extern "C" int ldmk_attn_self(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream) {
   LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(qkv && out && n > 0 && heads > 0, "ldmk_attn_self: bad args");
   LDMK_REQUIRE(tokens > 0, "ldmk_attn_self: tokens=%d must be positive", tokens);
   LDMK_REQUIRE(heads <= 65535 && n <= 65535, "ldmk_attn_self: grid limits");
-  dim3 grid((tokens + 127) / 128, heads, n);
-  hipLaunchKernelGGL(attn_self_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, tokens, heads, scale);
+  // QT = 2 (64 queries per wave) measured on MI355X: 108.7 vs 107.7 TFLOP/s at 4096 tokens, slower below -- the
+  // kernel is matrix-pipe/clock bound, not LDS- or barrier-bound -- so it is only selectable through the test hook.
+  if (g_attn_qt == 2) {
+    dim3 grid((tokens + 255) / 256, heads, n);
+    hipLaunchKernelGGL(attn_self_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, tokens, heads, scale);
+  } else {
+    dim3 grid((tokens + 127) / 128, heads, n);
+    hipLaunchKernelGGL(attn_self_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, tokens, heads, scale);
+  }
   return check_launch("ldmk_attn_self");
 }
 

@@ -37,6 +37,7 @@ _SIGS = {
     "ldmk_igemm": (C.c_int, [C.POINTER(IgemmArgs), _fp]),
     "ldmk_igemm_plan": (C.c_int, [C.POINTER(IgemmArgs), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ldmk_igemm_force_config": (None, [C.c_int]),
+    "ldmk_attn_force_qt": (None, [C.c_int]),
     "ldmk_gn_chunks": (C.c_int, [C.c_int]),
     "ldmk_gn_partial": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ldmk_gn_finalize": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp]),
@@ -62,7 +63,7 @@ _SIGS = {
     "ldmk_add_rowvec": (C.c_int, [_fp, _fp, C.c_int, C.c_longlong, C.c_int, C.c_int, _fp]),
 }
 # every symbol include/ldmk.h declares (checked by tests/test_abi.py against the header text)
-EXPORTED = [k for k in _SIGS if k != "ldmk_igemm_force_config"]
+EXPORTED = [k for k in _SIGS if k not in ("ldmk_igemm_force_config", "ldmk_attn_force_qt")]
 
 _lib = None
 

@@ -222,14 +222,20 @@ def test_geglu_ff_golden(ops):
 
 @pytest.mark.parametrize("n,tokens,heads", [(1, 64, 5), (2, 256, 10), (2, 1024, 5), (1, 4096, 5), (3, 96, 2),
                                             (2, 16, 3), (1, 77, 2), (1, 130, 1)])
-def test_attn_self(ops, n, tokens, heads):
+@pytest.mark.parametrize("qt", [1, 2])
+def test_attn_self(ops, n, tokens, heads, qt):
+    from dsml_thesis_amd import lib
+    lib.load().ldmk_attn_force_qt(qt)
     C = heads * 32
     qkv = rnd(40, n * tokens, 3 * C)
     qkv[:, :2 * C] *= 2.0         # make the softmax peaky enough to exercise the running-max rescale
     q, k, v = qkv.view(n, tokens, 3, heads, 32).permute(2, 0, 3, 1, 4).double()
     p = torch.softmax(q @ k.transpose(-1, -2) * 32 ** -0.5, dim=-1)
     ref = (p @ v).permute(0, 2, 1, 3).reshape(n * tokens, C).float()
-    y = ops.attn_self(qkv.cuda(), n, tokens, heads)
+    try:
+        y = ops.attn_self(qkv.cuda(), n, tokens, heads)
+    finally:
+        lib.load().ldmk_attn_force_qt(0)
     close(y, ref, 1e-4, 2e-5)
 
 

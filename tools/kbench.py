@@ -60,7 +60,15 @@ def gemm(M, N, K, conv=None, cfg=0, sk=0, ln=False, geglu=False, res=False):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "attn"
-    if what == "attn":
+    if what == "attnqt":
+        for qt in (1, 2):
+            L.load().ldmk_attn_force_qt(qt)
+            print("qt", qt)
+            attn(16, 4096, 5)
+            attn(16, 1024, 10)
+            attn(16, 1024, 5)
+            attn(16, 256, 20)
+    elif what == "attn":
         attn(16, 4096, 5)
         attn(16, 1024, 10)
         attn(16, 256, 20)
