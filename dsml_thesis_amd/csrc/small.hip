@@ -324,6 +324,100 @@ __global__ void add_rowvec_kernel(float* __restrict__ x, const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Conv1DTemporalAttention (talking_face/ldm/modules/encoders/modules.py:76-113), one workgroup per sample:
+// five Conv1d(k=3, pad=1)+LeakyReLU(0.02) layers 768->192->64->16->4->1 over the T-frame audio window,
+// Linear(T,T)+softmax over time, attention-weighted sum of the input features.  Weights packed [3][cin][cout].
+constexpr int AA_TMAX = 32;
+__global__ __launch_bounds__(256) void audio_attention_kernel(const float* __restrict__ x, int T, int dim,
+                                                              const float* const* __restrict__ w,
+                                                              const float* const* __restrict__ bias,
+                                                              const float* __restrict__ wl, const float* __restrict__ bl,
+                                                              float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int chans[6] = {dim, 192, 64, 16, 4, 1};
+  float* xin = sm;                               // [(T+2)][dim]  rows 0 and T+1 are the zero padding
+  float* bufa = xin + (T + 2) * dim;             // [(T+2)][192]
+  float* bufb = bufa + (T + 2) * 192;            // [(T+2)][64]
+  float* att = bufb + (T + 2) * 64;              // [T]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* xb = x + (long long)b * T * dim;
+  for (int i = tid; i < (T + 2) * dim; i += 256) {
+    const int t = i / dim - 1, c = i - (t + 1) * dim;
+    xin[i] = (t >= 0 && t < T) ? xb[(long long)t * dim + c] : 0.f;
+  }
+  for (int i = tid; i < (T + 2) * 192; i += 256) bufa[i] = 0.f;
+  for (int i = tid; i < (T + 2) * 64; i += 256) bufb[i] = 0.f;
+  __syncthreads();
+  const float* src = xin;
+  float* dst = bufa;
+  for (int l = 0; l < 5; ++l) {
+    const int cin = chans[l], cout = chans[l + 1];
+    const float* wl_ = w[l];
+    if (tid < cout) {
+      float acc[AA_TMAX];
+#pragma unroll
+      for (int t = 0; t < AA_TMAX; ++t) acc[t] = 0.f;
+      for (int k = 0; k < 3; ++k)
+        for (int ci = 0; ci < cin; ++ci) {
+          const float wv = wl_[((long long)k * cin + ci) * cout + tid];
+#pragma unroll
+          for (int t = 0; t < AA_TMAX; ++t)
+            if (t < T) acc[t] = fmaf(src[(t + k) * cin + ci], wv, acc[t]);
+        }
+      const float bv = bias[l][tid];
+#pragma unroll
+      for (int t = 0; t < AA_TMAX; ++t)
+        if (t < T) {
+          const float v = acc[t] + bv;
+          dst[(t + 1) * cout + tid] = v > 0.f ? v : 0.02f * v;
+        }
+    }
+    __syncthreads();
+    // next layer reads what this one wrote; ping-pong between the two scratch buffers (padding rows stay zero
+    // because every layer is narrower than the previous one and rows 0 / T+1 are never written)
+    src = dst;
+    dst = (dst == bufa) ? bufb : bufa;
+    if (l + 2 <= 5) {
+      const int nc = chans[l + 2];
+      for (int i = tid; i < (T + 2) * nc; i += 256) {
+        const int t = i / nc;
+        if (t == 0 || t == T + 1) dst[i] = 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  // src: [(T+2)][1] conv output; attention = softmax(Linear(T,T)(conv))
+  if (tid < T) {
+    float a = bl[tid];
+    for (int j = 0; j < T; ++j) a = fmaf(wl[tid * T + j], src[j + 1], a);
+    att[tid] = a;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mx = -INFINITY, s = 0.f;
+    for (int t = 0; t < T; ++t) mx = fmaxf(mx, att[t]);
+    for (int t = 0; t < T; ++t) { att[t] = expf(att[t] - mx); s += att[t]; }
+    for (int t = 0; t < T; ++t) att[t] /= s;
+  }
+  __syncthreads();
+  for (int c = tid; c < dim; c += 256) {
+    float o = 0.f;
+    for (int t = 0; t < T; ++t) o = fmaf(xin[(t + 1) * dim + c], att[t], o);
+    out[(long long)b * dim + c] = o;
+  }
+}
+
+// masked_img[:, y0:, :] = value on NCHW images with a per-image first masked row (MEADBase3, taming/data/custom.py:375-389)
+__global__ void mask_rows_kernel(float* __restrict__ img, const int* __restrict__ y0, int c, int h, int w, float value,
+                                 long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int y = (int)((i / w) % h);
+    const int n = (int)(i / ((long long)c * h * w));
+    if (y >= y0[n]) img[i] = value;
+  }
+}
+
 static inline unsigned grid_for(long long total, int block = 256, int cap = 4096) {
   long long g = (total + block - 1) / block;
   if (g > cap) g = cap;
@@ -441,6 +535,32 @@ extern "C" int ldmk_permute3(const float* src, float* dst, int d0, int d1, int d
   hipLaunchKernelGGL(permute3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, d0, d1, d2, p0,
                      p1, p2, total);
   return check_launch("ldmk_permute3");
+}
+
+extern "C" int ldmk_audio_attention(const float* x, int n, int T, int dim, const float* const* conv_w,
+                                    const float* const* conv_b, const float* lin_w, const float* lin_b, float* out,
+                                    void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(x && conv_w && conv_b && lin_w && lin_b && out && n > 0 && dim > 0, "ldmk_audio_attention: bad args");
+  LDMK_REQUIRE(T >= 1 && T <= AA_TMAX, "ldmk_audio_attention: window T=%d outside [1,%d]", T, AA_TMAX);
+  size_t lds = ((size_t)(T + 2) * (dim + 192 + 64) + T) * sizeof(float);
+  LDMK_REQUIRE(lds <= 160 * 1024, "ldmk_audio_attention: window too large for LDS");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(audio_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(audio_attention_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, x, T, dim, conv_w, conv_b, lin_w,
+                     lin_b, out);
+  return check_launch("ldmk_audio_attention");
+}
+
+extern "C" int ldmk_mask_rows(float* img, const int* y0, int n, int c, int h, int w, float value, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(img && y0 && n > 0 && c > 0 && h > 0 && w > 0, "ldmk_mask_rows: bad args");
+  long long total = (long long)n * c * h * w;
+  hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, y0, c, h, w, value, total);
+  return check_launch("ldmk_mask_rows");
 }
 
 extern "C" int ldmk_pack_conv3x3(const float* src, float* dst, int cout, int cin, void* stream) {

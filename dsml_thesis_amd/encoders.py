@@ -1,6 +1,5 @@
-"""Condition encoders used by the shipped configs.  They run once per sample()/frame on a handful of rows
-(negligible next to 200 UNet evaluations), so they stay plain PyTorch-ROCm modules with the
-reference's parameter names:
+"""Condition encoders used by the shipped configs, with the reference's parameter names.  The class embedders are
+table lookups (nn.Embedding); the audio window encoder runs as one fused HIP kernel (ldmk_audio_attention):
   ClassEmbedder3            face_reenactment/ldm/modules/encoders/modules.py:68-94
   ClassEmbedder             talking_face/ldm/modules/encoders/modules.py:44-73
   Conv1DTemporalAttention   talking_face/ldm/modules/encoders/modules.py:76-113
@@ -54,22 +53,43 @@ class Conv1DTemporalAttention(nn.Module):
         self.attentionConvNet = nn.Sequential(*layers)
         self.attentionNet = nn.Sequential(nn.Linear(seq_len, seq_len, bias=True), nn.Softmax(dim=1))
 
-    @staticmethod
-    def _conv1d_k3(x, conv):
-        """Conv1d(k=3, pad=1) as unfold + one GEMM: bitwise run-to-run reproducible (MIOpen's conv1d picks its
-        algorithm by a first-call search and differs in the last bit between calls), same parameters/keys."""
-        b, cin, T = x.shape
-        xp = torch.nn.functional.pad(x, (1, 1))
-        cols = torch.stack([xp[:, :, k:k + T] for k in range(3)], dim=-1)          # (b, cin, T, 3)
-        cols = cols.permute(0, 2, 1, 3).reshape(b * T, cin * 3)
-        out = torch.nn.functional.linear(cols, conv.weight.reshape(conv.out_channels, cin * 3), conv.bias)
-        return out.view(b, T, conv.out_channels).transpose(1, 2)
+    def _pack(self):
+        """Conv1d weights [cout][cin][3] -> [3][cin][cout] (coalesced per output channel) + device pointer tables."""
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if getattr(self, "_sig", None) == sig:
+            return
+        convs = [self.attentionConvNet[i] for i in range(0, 10, 2)]
+        self._w = [c.weight.detach().float().permute(2, 1, 0).contiguous() for c in convs]
+        self._b = [c.bias.detach().float().contiguous() for c in convs]
+        dev = self._w[0].device
+        self._wp = torch.tensor([t.data_ptr() for t in self._w], dtype=torch.int64, device=dev)
+        self._bp = torch.tensor([t.data_ptr() for t in self._b], dtype=torch.int64, device=dev)
+        self._lw = self.attentionNet[0].weight.detach().float().contiguous()
+        self._lb = self.attentionNet[0].bias.detach().float().contiguous()
+        self._sig = sig
 
+    @torch.no_grad()
     def forward(self, x):
-        b = x.shape[0]
-        xt = torch.transpose(x, 1, 2)
-        h = xt
-        for i in range(0, 10, 2):
-            h = torch.nn.functional.leaky_relu(self._conv1d_k3(h, self.attentionConvNet[i]), 0.02)
-        att = self.attentionNet(h.reshape(b, self.seq_len)).view(b, self.seq_len, 1)
-        return torch.bmm(xt, att).view(b, self.subspace_dim).unsqueeze(1)
+        """x: (b, T, 768) CUDA float32 -> (b, 1, 768)."""
+        from . import lib as L
+        if not x.is_cuda:
+            raise L.LdmkError("Conv1DTemporalAttention: CUDA tensors only (no CPU fallback)")
+        b, T, dim = x.shape
+        assert T == self.seq_len and dim == self.subspace_dim
+        self._pack()
+        xc = x.float().contiguous()
+        out = torch.empty(b, dim, device=x.device, dtype=torch.float32)
+        L.call("ldmk_audio_attention", xc.data_ptr(), b, T, dim, self._wp.data_ptr(), self._bp.data_ptr(),
+               self._lw.data_ptr(), self._lb.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return out.unsqueeze(1)
+
+
+def mask_lower_face_(images, first_masked_row, value=-1.0):
+    """In place: images[n, :, y >= first_masked_row[n], :] = value (MEADBase3 sampling mask, custom.py:375-389;
+    first_masked_row = int(min(mouth landmark y)) - 5).  images: (n, c, h, w) CUDA float32."""
+    from . import lib as L
+    n, c, h, w = images.shape
+    y0 = torch.as_tensor(first_masked_row, dtype=torch.int32, device=images.device).contiguous()
+    L.call("ldmk_mask_rows", images.data_ptr(), y0.data_ptr(), n, c, h, w, float(value),
+           torch.cuda.current_stream().cuda_stream)
+    return images

@@ -58,6 +58,8 @@ _SIGS = {
     "ldmk_ddpm_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_longlong, C.c_int, _fp]),
     "ldmk_vq_nearest": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_permute3": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_audio_attention": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "ldmk_mask_rows": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_pack_conv3x3": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
     "ldmk_postprocess_frames": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_add_rowvec": (C.c_int, [_fp, _fp, C.c_int, C.c_longlong, C.c_int, C.c_int, _fp]),

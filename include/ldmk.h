@@ -183,6 +183,18 @@ int ldmk_vq_nearest(const float* z, const float* codebook, float* zq, int* idx, 
                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Talking-face per-frame conditioning front-end.
+ * ldmk_audio_attention: Conv1DTemporalAttention.forward, talking_face/ldm/modules/encoders/modules.py:103-113:
+ *   x [n][T][dim] audio window -> out [n][dim]; conv_w[l] is layer l's Conv1d weight packed [3][cin][cout]
+ *   (cin/cout = dim,192,64,16,4,1), conv_b[l] its bias; conv_w / conv_b are DEVICE arrays of 5 device pointers;
+ *   lin_w [T][T], lin_b [T] = attentionNet.0.  T <= 32.
+ * ldmk_mask_rows: img[n][c][y >= y0[n]][:] = value, the lower-face mask of MEADBase3 (taming/data/custom.py:375-389).
+ */
+int ldmk_audio_attention(const float* x, int n, int T, int dim, const float* const* conv_w, const float* const* conv_b,
+                         const float* lin_w, const float* lin_b, float* out, void* stream);
+int ldmk_mask_rows(float* img, const int* y0, int n, int c, int h, int w, float value, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Layout helpers: weight repacking (once, after load_state_dict) and boundary transposes.
  * ldmk_permute3: dst[i2? ...] generic 3-D permutation of a contiguous [d0][d1][d2] tensor;
  *   perm gives, for each destination axis, the source axis (e.g. conv OIHW viewed as [O][I][9]

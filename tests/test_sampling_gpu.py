@@ -237,3 +237,21 @@ def test_first_stage_non_square_and_batch_vs_oracle():
     close(m.first_stage_model.decode(z.cuda(), force_not_quantize=True), ref, 3e-4, 3e-4)
     img = torch.tanh(rnd(96, 2, 3, 32, 48))
     close(m.encode_first_stage(img.cuda()), O.encode_first_stage(sd, W.VQ_F4, img), 3e-4, 3e-4)
+
+
+def test_talking_face_front_end_kernels():
+    """the audio window encoder as one fused kernel (window 17 = the shipped config) and the
+    lower-face mask, against the oracle restatement / the reference's slicing semantics."""
+    from dsml_thesis_amd.encoders import Conv1DTemporalAttention, mask_lower_face_
+    m = Conv1DTemporalAttention(17).cuda()
+    sd = W.synth_state_dict(W.audio_attention_param_shapes(17))
+    m.load_state_dict(sd)
+    x = rnd(97, 5, 17, 768)
+    close(m(x.cuda()), O.audio_temporal_attention(sd, x), 1e-4, 1e-5)
+    img = rnd(98, 3, 3, 16, 12)
+    y0 = [4, 0, 16]
+    ref = img.clone()
+    for i, y in enumerate(y0):
+        ref[i, :, y:, :] = -1.0            # masked_img[min_y:, :, :] = -1 (HWC in the reference, CHW here)
+    out = mask_lower_face_(img.cuda(), y0)
+    assert torch.equal(out.cpu(), ref)

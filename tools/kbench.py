@@ -60,7 +60,14 @@ def gemm(M, N, K, conv=None, cfg=0, sk=0, ln=False, geglu=False, res=False):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "attn"
-    if what == "attnqt":
+    if what == "geglu":
+        for M, N, K in ((65536, 1280, 160), (4096, 5120, 640), (16384, 2560, 320)):
+            for ln in (False, True):
+                for gg in (False, True):
+                    gemm(M, N, K, ln=ln, geglu=gg)
+            for cfg in (1, 2, 5):
+                gemm(M, N, K, cfg=cfg)
+    elif what == "attnqt":
         for qt in (1, 2):
             L.load().ldmk_attn_force_qt(qt)
             print("qt", qt)
