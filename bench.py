@@ -227,9 +227,13 @@ def main():
     run, el = measure(a.latent, a.steps, a.warmup, graph)
     value = world * a.batch * a.steps / el
     ms = 1e3 * el / a.steps
+    try:
+        base_metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        base_metric = "DDIM denoise steps/sec (64\u00d764\u00d74 latent, 256\u00b2 face) at 1/2/4/8 GPUs"
     out = {
-        "metric": "DDIM denoise steps/sec (64x64x4 latent, 256^2 face) at 1/2/4/8 GPUs" if a.latent == 64 else
-                  "DDIM denoise steps/sec (32x32x3 latent, 128^2 face) at 1/2/4/8 GPUs",
+        "metric": base_metric if a.latent == 64 else
+                  "DDIM denoise steps/sec (32\u00d732\u00d73 latent, 128\u00b2 face) at 1/2/4/8 GPUs",
         "value": round(value, 2), "unit": "sample-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -239,7 +243,7 @@ def main():
                    "latent": [int(run.x_T.shape[1]), a.latent, a.latent], "ddim_steps": 200,
                    "hipgraph": graph, "parallelism": f"dp{world} (independent samples per rank, no data-path collective)"},
         "batch_steps_per_s": round(world * a.steps / el, 3),
-        "step_tflops": round(GFLOP_STEP[a.latent] * a.batch * 1e-3 / (ms * 1e-3), 2),
+        "step_tflops": round(world * GFLOP_STEP[a.latent] * a.batch * 1e-3 / (ms * 1e-3), 2),
     }
     if rank == 0:
         t_ig, n_ig = run.igemm_time_per_step()
