@@ -29,6 +29,15 @@ def test_header_symbols_exported(libpath):
         assert hasattr(lib, s), f"{s} declared in include/ldmk.h but not exported"
 
 
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C99 (no C++-isms, no torch types)."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "ldmk.h")
+    subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", hdr])
+    code = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)      # comments may mention PyTorch; signatures may not
+    assert "torch" not in code.lower() and "tensor" not in code.lower()
+
+
 def test_binding_matches_header(libpath):
     from dsml_thesis_amd import lib as L
     assert sorted(L.EXPORTED) == header_symbols()
