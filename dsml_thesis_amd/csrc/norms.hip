@@ -73,9 +73,45 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
-// LayerNorm statistics: one wave per row, exact two-pass in registers (C <= 64*16).
+// LayerNorm statistics: one half-wave (32 lanes x float4 = 512 B per load instruction) per row, exact
+// two-pass in registers (C <= 1024, C % 4 == 0); the generic scalar form handles other widths.
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int rows, int C, float eps,
                                                        float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31;
+  const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  const bool ok = row < rows;
+  const float4* p = reinterpret_cast<const float4*>(x + (ok ? row : 0) * C);
+  const int c4n = C >> 2;
+  float4 v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c4 = l31 + 32 * i;
+    v[i] = (ok && c4 < c4n) ? p[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);     // stays inside the 32-lane half
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c4 = l31 + 32 * i;
+    if (c4 < c4n) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q = fmaf(a, a, q); q = fmaf(b, b, q); q = fmaf(c, c, q); q = fmaf(d, d, q);
+    }
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  if (ok && l31 == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = 1.0f / sqrtf(q / (float)C + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_stats_scalar_kernel(const float* __restrict__ x, int rows, int C, float eps,
+                                                              float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -185,6 +221,9 @@ extern "C" int ldmk_ln_stats(const float* x, int rows, int c, float eps, float* 
   LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(x && stats && rows > 0 && c > 0 && c <= 1024, "ldmk_ln_stats: bad args (C<=1024)");
-  hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats);
+  if (c % 4 == 0)
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats);
+  else
+    hipLaunchKernelGGL(ln_stats_scalar_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats);
   return check_launch("ldmk_ln_stats");
 }

@@ -71,8 +71,9 @@ def test_gn_golden(ops):
         close(nchw(y), g[tag], 1e-5, 2e-5)
 
 
-def test_ln_stats(ops):
-    x = (rnd(5, 300, 320) * 2 + 0.5)
+@pytest.mark.parametrize("rows,c", [(300, 320), (65, 160), (7, 1024), (33, 150), (4096, 640)])
+def test_ln_stats(ops, rows, c):
+    x = (rnd(5, rows, c) * 2 + 0.5)
     st = ops.ln_stats(x.cuda()).cpu()
     close(st[:, 0], x.mean(1), 1e-5, 1e-5)
     close(st[:, 1], 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5), 1e-5, 1e-5)

@@ -60,7 +60,30 @@ def gemm(M, N, K, conv=None, cfg=0, sk=0, ln=False, geglu=False, res=False):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "attn"
-    if what == "geglu":
+    if what == "hbm":
+        n, hw, c = 16, 4096, 320
+        x = torch.randn(n * hw, c, device="cuda")
+        g, b = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda")
+        coef = ops.gn_coef(x, None, n, hw, g, b, 1e-5)
+        y = torch.empty_like(x)
+        us = timeit(lambda: ops.gn_apply(x, None, coef, n, hw, out=y))
+        print(f"gn_apply {n}x{hw}x{c}: {us:8.1f} us  {2 * x.numel() * 4 / us / 1e3:7.1f} GB/s (read+write)")
+        part = torch.empty(n * (hw // 32) * c * 3, device="cuda")
+        us = timeit(lambda: L.call("ldmk_gn_partial", x.data_ptr(), c, n, hw, part.data_ptr(), ops.stream()))
+        print(f"gn_partial {n}x{hw}x{c}: {us:8.1f} us  {x.numel() * 4 / us / 1e3:7.1f} GB/s (read)")
+        x2 = torch.randn(n * hw, 160, device="cuda")
+        st = torch.empty(n * hw, 2, device="cuda")
+        us = timeit(lambda: ops.ln_stats(x2, out=st))
+        print(f"ln_stats {n * hw}x160: {us:8.1f} us  {x2.numel() * 4 / us / 1e3:7.1f} GB/s (read)")
+        z = torch.randn(128, 3, 128, 128, device="cuda")
+        o = torch.empty(128, 128, 128, 3, device="cuda")
+        us = timeit(lambda: ops.postprocess_frames(z, out=o))
+        print(f"postprocess_frames 128x3x128x128: {us:8.1f} us  {2 * z.numel() * 4 / us / 1e3:7.1f} GB/s (read+write)")
+        cb = torch.randn(16384, 3, device="cuda")
+        zz = torch.randn(128, 3, 32, 32, device="cuda")
+        us = timeit(lambda: ops.vq_nearest(zz, cb))
+        print(f"vq_nearest 128x1024 vectors vs 16384 codes: {us:8.1f} us  {128 * 1024 * 16384 / us / 1e6:7.2f} T distance-evals/s")
+    elif what == "geglu":
         for M, N, K in ((65536, 1280, 160), (4096, 5120, 640), (16384, 2560, 320)):
             for ln in (False, True):
                 for gg in (False, True):
