@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ out, int ldo, int rows, int K, int N,
                                                           int silu_in) {
-  __shared__ float xs[DS_ROWS][DS_KT];
+  __shared__ __attribute__((aligned(16))) float xs[DS_KT][DS_ROWS];   // [k][row]: one k = 4 broadcast b128 reads
   __shared__ float red[3][DS_ROWS][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + lane;
@@ -37,24 +37,37 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
     const int kn = min(DS_KT, K - k0);
     __syncthreads();
     for (int i = threadIdx.x; i < DS_ROWS * DS_KT; i += 256) {
-      const int r = i / DS_KT, kk = i - r * DS_KT;
+      const int r = i / DS_KT, kk = i - r * DS_KT;          // consecutive threads read consecutive k of one row
       float v = 0.f;
       if (r < nr && kk < kn) {
         v = x[(long long)(r0 + r) * ldx + k0 + kk];
         if (silu_in) v = silu_f(v);
       }
-      xs[r][kk] = v;
+      xs[kk][r] = v;
     }
     __syncthreads();
     if (n < N) {
       const int q = (kn + 3) / 4;
       const int kb = wave * q, ke = min(kn, kb + q);
       const float* wp = w + (long long)(k0 + kb) * N + n;
-      for (int kk = kb; kk < ke; ++kk) {
-        const float wv = *wp;
-        wp += N;
+      for (int kk = kb; kk < ke; kk += 8) {
+        float wv[8];                       // 8 independent weight loads in flight per lane before any use
 #pragma unroll
-        for (int r = 0; r < DS_ROWS; ++r) acc[r] = fmaf(xs[r][kk], wv, acc[r]);
+        for (int u = 0; u < 8; ++u) wv[u] = (kk + u < ke) ? wp[(long long)u * N] : 0.f;
+        wp += 8LL * N;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (kk + u >= ke) break;
+          const float4* xr = reinterpret_cast<const float4*>(&xs[kk + u][0]);
+#pragma unroll
+          for (int r4 = 0; r4 < DS_ROWS / 4; ++r4) {
+            const float4 xv = xr[r4];
+            acc[4 * r4] = fmaf(xv.x, wv[u], acc[4 * r4]);
+            acc[4 * r4 + 1] = fmaf(xv.y, wv[u], acc[4 * r4 + 1]);
+            acc[4 * r4 + 2] = fmaf(xv.z, wv[u], acc[4 * r4 + 2]);
+            acc[4 * r4 + 3] = fmaf(xv.w, wv[u], acc[4 * r4 + 3]);
+          }
+        }
       }
     }
   }
