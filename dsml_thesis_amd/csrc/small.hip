@@ -514,6 +514,16 @@ extern "C" int ldmk_ddim_step(const float* x, const float* eps, const float* noi
   return check_launch("ldmk_ddim_step");
 }
 
+extern "C" int ldmk_advance_timestep(int* step_idx, const long long* timesteps, long long* ts, int n_ts, int advance,
+                                     int n_steps, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(step_idx && timesteps && ts && n_ts > 0 && n_steps > 0 && (advance == 1 || advance == -1),
+               "ldmk_advance_timestep: bad args (advance is +1 down / -1 up)");
+  hipLaunchKernelGGL(ddim_advance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_idx, timesteps, ts, n_ts, advance,
+                     n_steps);
+  return check_launch("ldmk_advance_timestep");
+}
+
 extern "C" int ldmk_ddpm_step(const float* x, const float* eps, const float* noise, const float* tables,
                               const float* logvar, const long long* t, float* x_prev, long long per_sample, int n,
                               void* stream) {

@@ -271,28 +271,85 @@ class LatentDiffusion(_Base):
     @torch.no_grad()
     def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None,
                       timesteps=None, quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None,
-                      log_every_t=None, noise=None):
-        """ddpm.py:1167-1216.  `noise`: optional per-step noise list (parity with a seeded reference run)."""
+                      log_every_t=None, noise=None, use_graph=False):
+        """ddpm.py:1167-1216.  Device-resident loop: the latent lives in the UNet program's input buffer, the
+        per-sample timestep vector is rewritten by a kernel, one step = UNet program + fused posterior update, and
+        (use_graph=True) the step is captured once in a hipGraph and replayed T times.
+        `noise`: optional per-step noise list (parity with a seeded reference run)."""
         if mask is not None or quantize_denoised:
             raise NotImplementedError("p_sample_loop: mask/x0 and quantize_denoised are unused on the shipped path")
+        from .engine import GraphedProgram
         log_every_t = log_every_t or self.log_every_t
         dev = self.betas.device
         b = shape[0]
-        img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev)
-        intermediates = [img]
+        img0 = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32)
         timesteps = self.num_timesteps if timesteps is None else timesteps
         if start_T is not None:
             timesteps = min(timesteps, start_T)
+        if isinstance(cond, dict):
+            ctx = cond.get("c_crossattn")
+            cat = cond.get("c_concat")
+            ctx = torch.cat(ctx, 1) if isinstance(ctx, (list, tuple)) else ctx
+            cat = torch.cat(cat, 1) if isinstance(cat, (list, tuple)) else cat
+        else:
+            ctx, cat = (torch.cat(cond, 1) if isinstance(cond, (list, tuple)) else cond), None
+        unet = self.model.diffusion_model
+        ncat = 0 if cat is None else cat.shape[1]
+        pg = unet.program(b, shape[2], shape[3], ctx.shape[1], ncat)
+        pg.inputs["context"].copy_(ctx.reshape(b * ctx.shape[1], -1))
+        if ncat:
+            pg.inputs["c_concat"].copy_(cat)
+        pg.ctx_program.run()
+        x_buf, t_buf, eps = pg.inputs["x"], pg.inputs["t"], pg.outputs["eps"]
+        tab, logvar = self._ddpm_device_tables()
+        key = (id(pg), timesteps, bool(use_graph), noise is None)
+        st = self._pl_state.get(key) if hasattr(self, "_pl_state") else None
+        if st is None:
+            if not hasattr(self, "_pl_state"):
+                self._pl_state = {}
+            st = dict(nz=torch.empty_like(img0), idx=torch.zeros(1, dtype=torch.int32, device=dev),
+                      tt=torch.arange(self.num_timesteps, dtype=torch.int64, device=dev), graph=None)
+            self._pl_state[key] = st
+        nz, idx, tt = st["nz"], st["idx"], st["tt"]
+        per = img0[0].numel()
+        lib = pg.lib
+
+        def reset():
+            x_buf.copy_(img0)
+            idx.fill_(timesteps - 1)
+            t_buf.fill_(timesteps - 1)
+
+        def one_step(draw=True):
+            if draw:
+                nz.normal_()
+            pg.run()
+            stream = torch.cuda.current_stream().cuda_stream
+            L.check(lib.ldmk_ddpm_step(x_buf.data_ptr(), eps.data_ptr(), nz.data_ptr(), tab.data_ptr(), logvar.data_ptr(),
+                                       t_buf.data_ptr(), x_buf.data_ptr(), per, b, stream), "ldmk_ddpm_step")
+            L.check(lib.ldmk_advance_timestep(idx.data_ptr(), tt.data_ptr(), t_buf.data_ptr(), b, 1, self.num_timesteps,
+                                              stream), "ldmk_advance_timestep")
+
+        reset()
+        step = one_step
+        if noise is not None:
+            step = lambda: one_step(draw=False)
+        elif use_graph:
+            if st["graph"] is None:
+                st["graph"] = GraphedProgram(one_step)
+                reset()
+            step = st["graph"].replay
+        intermediates = [img0]
         for k, i in enumerate(reversed(range(0, timesteps))):
-            ts = torch.full((b,), i, device=dev, dtype=torch.long)
-            img = self.p_sample(img, cond, ts, clip_denoised=self.clip_denoised,
-                                noise=None if noise is None else noise[k])
+            if noise is not None:
+                nz.copy_(noise[k])
+            step()
             if i % log_every_t == 0 or i == timesteps - 1:
-                intermediates.append(img)
+                intermediates.append(x_buf.clone())
             if callback:
                 callback(i)
             if img_callback:
-                img_callback(img, i)
+                img_callback(x_buf, i)
+        img = x_buf.clone()
         return (img, intermediates) if return_intermediates else img
 
     @torch.no_grad()

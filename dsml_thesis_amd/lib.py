@@ -55,6 +55,7 @@ _SIGS = {
     "ldmk_conv1x1_nchw": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_ddim_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_float, C.c_int, _fp, _fp, C.c_longlong, C.c_int, _fp, _fp,
                                  C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_advance_timestep": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_ddpm_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_longlong, C.c_int, _fp]),
     "ldmk_vq_nearest": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_permute3": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

@@ -172,6 +172,10 @@ int ldmk_conv1x1_nchw(const float* x, const float* w, const float* bias, float* 
 int ldmk_ddim_step(const float* x, const float* eps, const float* noise, const float* table, int* step_idx,
                    float cfg_scale, int cfg, float* x_prev, float* pred_x0, long long per_sample, int n,
                    const long long* timesteps, long long* ts, int n_ts, int advance, int n_steps, void* stream);
+/* the counter/timestep advance of ldmk_ddim_step on its own (used by the ancestral loop): index -= advance,
+ * clamped to [0, n_steps-1]; ts[0..n_ts) = timesteps[index] */
+int ldmk_advance_timestep(int* step_idx, const long long* timesteps, long long* ts, int n_ts, int advance, int n_steps,
+                          void* stream);
 int ldmk_ddpm_step(const float* x, const float* eps, const float* noise, const float* tables, const float* logvar,
                    const long long* t, float* x_prev, long long per_sample, int n, void* stream);
 

@@ -255,3 +255,23 @@ def test_talking_face_front_end_kernels():
         ref[i, :, y:, :] = -1.0            # masked_img[min_y:, :, :] = -1 (HWC in the reference, CHW here)
     out = mask_lower_face_(img.cuda(), y0)
     assert torch.equal(out.cpu(), ref)
+
+
+def test_p_sample_loop_graph_and_full_length(fr):
+    """The ancestral loop as a device-resident program: hipGraph replay is statistically the same process (noise is
+    drawn inside the captured step) and the full 1000-step chain stays finite; eager with injected noise is pinned by
+    the golden above."""
+    c, _ = _cond(fr)
+    xT = rnd(51, 2, 3, 32, 32).cuda()
+    torch.manual_seed(3)
+    a, inter = fr.p_sample_loop(c, (2, 3, 32, 32), x_T=xT, timesteps=20, return_intermediates=True, log_every_t=5)
+    assert len(inter) >= 5 and torch.isfinite(a).all()
+    g1 = fr.p_sample_loop(c, (2, 3, 32, 32), x_T=xT, timesteps=20, use_graph=True)
+    g2 = fr.p_sample_loop(c, (2, 3, 32, 32), x_T=xT, timesteps=20, use_graph=True)
+    assert torch.isfinite(g1).all() and not torch.equal(g1, g2)          # fresh noise on every replay
+    zero = [torch.zeros(2, 3, 32, 32, device="cuda")] * 20
+    d1 = fr.p_sample_loop(c, (2, 3, 32, 32), x_T=xT, timesteps=20, noise=zero)
+    d2 = fr.p_sample_loop(c, (2, 3, 32, 32), x_T=xT, timesteps=20, noise=zero)
+    assert torch.equal(d1, d2)
+    out = fr.sample(c, batch_size=2, x_T=xT, use_graph=True)              # LatentDiffusion.sample -> 1000 steps
+    assert out.shape == (2, 3, 32, 32) and torch.isfinite(out).all()

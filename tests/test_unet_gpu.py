@@ -94,3 +94,11 @@ def test_unet_ragged_shapes_vs_oracle(n, h, w):
     x, t, ctx = rnd(50, n, 3, h, w), torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(1)), rnd(51, n, 1, 512)
     ref = O.unet_forward(sd, W.FR_UNET, x, t, ctx)
     close(m(x.cuda(), t.cuda(), context=ctx.cuda()), ref, 3e-4, 3e-4)
+
+
+def test_unet_empty_batch_fails_loudly():
+    from dsml_thesis_amd import lib as L
+    m, _ = make_unet(W.FR_UNET)
+    with pytest.raises((L.LdmkError, RuntimeError, AssertionError)):
+        m(torch.zeros(0, 3, 32, 32, device="cuda"), torch.zeros(0, dtype=torch.long, device="cuda"),
+          context=torch.zeros(0, 1, 512, device="cuda"))
