@@ -7,10 +7,55 @@ evaluation stays small enough to live in the 256 MiB Infinity Cache / L2 between
 consumer kernels instead of streaming ~1 GB of fresh HBM lines per step.
 """
 import ctypes as C
+import math
 
 import torch
 
 from . import lib as L
+
+
+_PLAN_TABLE = None
+
+
+def plan_key(a, m):
+    """Shape signature of an igemm problem for the tuned-plan table (m = the row count the plan is made for)."""
+    return f"{m},{a.N},{a.K},{a.a_mode},{a.a_tf},{a.epi},{max(1, a.batch)}"
+
+
+def plan_table():
+    """Tuned (tile_cfg, splitk) per problem shape: dsml_thesis_amd/igemm_plans.json, produced offline by
+    tools/autotune.py on an MI355X.  A static file, so plans (hence summation orders) are identical on every rank.
+    Indexed as {(N,K,mode,tf,epi,batch): [(M, cfg, splitk), ...] sorted by M}."""
+    global _PLAN_TABLE
+    if _PLAN_TABLE is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans.json")
+        _PLAN_TABLE = {}
+        if os.path.exists(path) and not os.environ.get("LDMK_NO_PLAN_TABLE"):
+            try:
+                raw = json.load(open(path))
+            except Exception:
+                raw = {}
+            for k, (cfg, sk) in raw.items():
+                m, rest = k.split(",", 1)
+                _PLAN_TABLE.setdefault(rest, []).append((int(m), int(cfg), int(sk)))
+            for v in _PLAN_TABLE.values():
+                v.sort()
+    return _PLAN_TABLE
+
+
+def tuned_plan(a, m):
+    """Plan of the tuned shape with the same (N, K, prologue, epilogue) and the closest row count (log scale, at
+    most a factor 2 away; ties go to the smaller M), or None.  Every plan in a bucket is legal for every M: the
+    split depth is bounded by K and the even-tile rule by the epilogue, both part of the bucket key."""
+    rows = plan_table().get(plan_key(a, m).split(",", 1)[1])
+    if not rows:
+        return None
+    best = min(rows, key=lambda r: (abs(math.log(r[0] / m)), r[0]))
+    if max(best[0], m) > 2 * min(best[0], m):
+        return None
+    return best[1], best[2]
 
 
 class Program:
@@ -70,10 +115,14 @@ class Program:
             else:
                 args.M = max(1, m * scale_m[0] // scale_m[1])
         cfg, sk = C.c_int(0), C.c_int(0)
-        if allow_splitk:
-            # plan against a generous virtual scratch, then size the real one to what was chosen
-            args.splitk_ws, args.splitk_ws_elems = 1, 1 << 40
-        self.lib.ldmk_igemm_plan(C.byref(args), C.byref(cfg), C.byref(sk))
+        tuned = tuned_plan(args, args.M) if nbatch <= 1 and args.M > 0 else None
+        if tuned is not None:
+            cfg.value, sk.value = int(tuned[0]), int(tuned[1])
+        else:
+            if allow_splitk:
+                # plan against a generous virtual scratch, then size the real one to what was chosen
+                args.splitk_ws, args.splitk_ws_elems = 1, 1 << 40
+            self.lib.ldmk_igemm_plan(C.byref(args), C.byref(cfg), C.byref(sk))
         args.M, args.batch = m, nbatch
         args.tile_cfg, args.splitk = cfg.value, max(1, sk.value)
         args.splitk_ws, args.splitk_ws_elems = 0, 0

@@ -98,3 +98,28 @@ def test_shard_ranges_and_item_noise():
     parts = torch.cat([batch_noise(11, lo, hi, (3, 4, 4)) for lo, hi in (shard_range(6, 4, r) for r in range(4))])
     assert torch.equal(full, parts)
     assert not torch.equal(item_noise(11, 0, (3, 4, 4)), item_noise(12, 0, (3, 4, 4)))
+
+
+def test_tuned_plan_table_is_legal_and_nearest():
+    """dsml_thesis_amd/igemm_plans.json (tools/autotune.py): every entry must be launchable for its bucket, and the
+    lookup must be a pure function of the shape (same answer on every rank)."""
+    import ctypes as C
+    from dsml_thesis_amd import engine, lib as L
+    table = engine.plan_table()
+    assert table, "tuned plan table missing"
+    wk = {1: 1, 2: 2, 3: 4, 4: 2, 5: 1, 6: 2}
+    for key, rows in table.items():
+        n, k, mode, tf, epi, nb = (int(v) for v in key.split(","))
+        assert [r[0] for r in rows] == sorted(r[0] for r in rows)
+        for m, cfg, sk in rows:
+            assert 1 <= cfg <= 6 and sk in (1, 2, 3, 4, 6, 8, 12, 16)
+            if epi == 1:
+                assert cfg in (1, 2, 3) and sk == 1
+            if sk > 1:
+                assert (-(-(k // 32) // wk[cfg])) // sk >= 2
+    a = L.IgemmArgs()
+    a.N, a.K, a.a_mode, a.a_tf, a.epi, a.batch = 320, 2880, 1, 0, 0, 1
+    assert engine.tuned_plan(a, 65536) == engine.tuned_plan(a, 65536)
+    near = engine.tuned_plan(a, 49152)            # batch 12: between the tuned 32768 and 65536 buckets
+    assert near in (engine.tuned_plan(a, 32768), engine.tuned_plan(a, 65536))
+    assert engine.tuned_plan(a, 7) is None        # far from anything tuned: the C++ heuristic decides

@@ -1,0 +1,125 @@
+"""Offline tuning of the igemm (tile shape, split-K) plan per problem shape.
+
+    python tools/autotune.py --latent 64 --batch 16 [--latent 32 --batch 16 ...] --out dsml_thesis_amd/igemm_plans.json
+
+For every distinct igemm problem of the UNet launch program (M, N, K, conv/rows, prologue, epilogue) every legal
+(tile_cfg, splitk) pair is timed on the real buffers (HIP events, median of 5) and the fastest is recorded.
+The table is a static, committed artefact: `engine.Program.igemm` looks a shape up there first and falls back to
+the C++ heuristic (`ldmk_igemm_plan`) for shapes it has never seen -- plans stay deterministic, so results remain
+bitwise reproducible across runs and ranks.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CFG_WK = {1: 1, 2: 2, 3: 4, 4: 2, 5: 1, 6: 2}          # K slices of 32 staged per iteration
+EVEN_TN = {1, 2, 3}
+SKS = [1, 2, 3, 4, 6, 8, 12, 16]
+
+
+def time_call(lib, a, st, reps=5):
+    ts = []
+    for _ in range(2):
+        lib.ldmk_igemm(C.byref(a), st)
+    torch.cuda.synchronize()
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = lib.ldmk_igemm(C.byref(a), st)
+        e1.record()
+        torch.cuda.synchronize()
+        if rc != 0:
+            return None
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def tune(kind, latent, batch, table):
+    from bench import StepRunner, build_model
+    model, ucfg = build_model(latent, torch.device("cuda", 0))
+    if kind == "unet":
+        run = StepRunner(model, ucfg, batch, graph=False)
+        run.step()
+        pg = run.pg
+    else:
+        fs = model.first_stage_model
+        if kind == "dec":
+            fs.decode(torch.randn(batch, ucfg["in_channels"], latent, latent, device="cuda"))
+            pg = fs._program("dec", batch, latent, latent, True)
+        else:
+            fs.encode(torch.randn(batch, 3, latent * 4, latent * 4, device="cuda"))
+            pg = fs._program("enc", batch, latent * 4, latent * 4)
+    torch.cuda.synchronize()
+    tune_program(pg, table)
+
+
+def tune_program(pg, table):
+    from dsml_thesis_amd.engine import plan_key
+    lib = pg.lib
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(16 * 1024 * 1024 * 16, device="cuda")      # 1 GiB of split-K scratch for the search
+    seen = {}
+    for fn, args, a, name in pg.calls:
+        if name != "ldmk_igemm":
+            continue
+        key = plan_key(a, a.M)
+        if key in seen or key in table or a.batch > 1:
+            continue
+        saved = (a.tile_cfg, a.splitk, a.splitk_ws, a.splitk_ws_elems, a.out, a.stats_out, a.residual)
+        # time into scratch so that in-place residual / stats outputs of the real program are not disturbed
+        scratch = torch.empty(a.M * max(a.ldc, 1) + 16, device="cuda")
+        a.out = scratch.data_ptr()
+        if a.residual == saved[4]:
+            a.residual = scratch.data_ptr()
+        a.stats_out = 0
+        nkc = a.K // 32
+        best = None
+        for cfg in range(1, 7):
+            if a.epi == 1 and cfg not in EVEN_TN:
+                continue
+            iters = -(-nkc // CFG_WK[cfg])
+            for sk in SKS:
+                if sk > 1 and (a.epi == 1 or iters // sk < 2 or sk * a.M * a.N > ws.numel()):
+                    continue
+                a.tile_cfg, a.splitk = cfg, sk
+                a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
+                t = time_call(lib, a, st)
+                if t is not None and (best is None or t < best[0]):
+                    best = (t, cfg, sk)
+        (a.tile_cfg, a.splitk, a.splitk_ws, a.splitk_ws_elems, a.out, a.stats_out, a.residual) = saved
+        base = time_call(lib, a, st)
+        seen[key] = best
+        table[key] = [best[1], best[2]]
+        print(f"{key:40s} heuristic cfg={saved[0]} sk={saved[1]} {1e3 * base:8.1f} us -> tuned cfg={best[1]} sk={best[2]} "
+              f"{1e3 * best[0]:8.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", action="append", default=[], help="[unet|dec|enc:]latent:batch, e.g. 64:16 or dec:64:16")
+    ap.add_argument("--out", default=os.path.join(ROOT, "dsml_thesis_amd", "igemm_plans.json"))
+    ap.add_argument("--fresh", action="store_true")
+    a = ap.parse_args()
+    table = {}
+    if os.path.exists(a.out) and not a.fresh:
+        table = json.load(open(a.out))
+    os.environ["LDMK_NO_PLAN_TABLE"] = "1"       # the search itself must start from the heuristic plans
+    for c in a.case or ["64:16", "32:16"]:
+        parts = c.split(":")
+        kind = parts[0] if len(parts) == 3 else "unet"
+        lat, b = parts[-2:]
+        print(f"== {kind} latent {lat} batch {b}", flush=True)
+        tune(kind, int(lat), int(b), table)
+        json.dump(table, open(a.out, "w"), indent=0, sort_keys=True)
+        torch.cuda.empty_cache()
+    json.dump(table, open(a.out, "w"), indent=0, sort_keys=True)
+    print(f"wrote {a.out} ({len(table)} shapes)")
