@@ -120,6 +120,6 @@ def test_tuned_plan_table_is_legal_and_nearest():
     a = L.IgemmArgs()
     a.N, a.K, a.a_mode, a.a_tf, a.epi, a.batch = 320, 2880, 1, 0, 0, 1
     assert engine.tuned_plan(a, 65536) == engine.tuned_plan(a, 65536)
-    near = engine.tuned_plan(a, 49152)            # batch 12: between the tuned 32768 and 65536 buckets
-    assert near in (engine.tuned_plan(a, 32768), engine.tuned_plan(a, 65536))
+    near = engine.tuned_plan(a, 57344)            # batch 14: between the tuned 49152 and 65536 buckets
+    assert near in (engine.tuned_plan(a, 49152), engine.tuned_plan(a, 65536))
     assert engine.tuned_plan(a, 7) is None        # far from anything tuned: the C++ heuristic decides
