@@ -1,0 +1,582 @@
+// Backward / optimizer kernels of the UNet training step (ddpm.py:1014-1047 p_losses, :1363-1385
+// AdamW, ema.py:25-44).  Everything here is HBM-bound elementwise or reduction work on NHWC fp32 tensors; the
+// matrix products of the backward pass run in igemm.hip (data gradients) and wgrad.hip (weight gradients).
+// All reductions use fixed partial layouts and fixed summation orders: gradients are bitwise reproducible.
+#include "ldmk_common.h"
+
+namespace ldmk {
+
+constexpr int GB_PIX = 64;   // pixels per GroupNorm-backward partial record
+
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float dsilu_f(float z) {
+  const float s = sigmoid_f(z);
+  return s * (1.0f + z * (1.0f - s));
+}
+
+// ---- GroupNorm group statistics (mean, rstd) from the forward's partial records ------------------------------
+__global__ __launch_bounds__(256) void gn_group_stats_kernel(const float* __restrict__ pa, int c0,
+                                                             const float* __restrict__ pb, int c1, int hw, int chunks,
+                                                             int groups, float eps, float* __restrict__ mr) {
+  const int C = c0 + c1, n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cpg = C / groups;
+  for (int g = blockIdx.x * 4 + wave; g < groups; g += gridDim.x * 4) {
+    const int items = cpg * chunks;
+    double sum = 0.0, sumsq = 0.0;
+    for (int i = lane; i < items; i += 64) {
+      const int ch = i / cpg, cc = i - ch * cpg, c = g * cpg + cc;
+      const float* d = c < c0 ? pa + (((long long)n * chunks + ch) * c0 + c) * 3
+                              : pb + (((long long)n * chunks + ch) * c1 + (c - c0)) * 3;
+      const int cnt = min(hw - ch * 32, 32);
+      const double sh = d[0], s = d[1], ss = d[2];
+      sum += s + cnt * sh;
+      sumsq += ss + 2.0 * sh * s + cnt * sh * sh;
+    }
+    sum = wave_sum_d(sum);
+    sumsq = wave_sum_d(sumsq);
+    const double cnt = (double)cpg * hw, mean = sum / cnt;
+    double var = sumsq / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    if (lane == 0) {
+      mr[((long long)n * groups + g) * 2] = (float)mean;
+      mr[((long long)n * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+}
+
+// ---- GroupNorm(+SiLU) backward, pass 1: per (sample, 64-pixel chunk, channel) sums of dz and dz*xhat ----------
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x0, int c0,
+                                                             const float* __restrict__ x1, int c1,
+                                                             const float* __restrict__ dy, const float* __restrict__ coef,
+                                                             const float* __restrict__ mr, int hw, int groups, int silu,
+                                                             float* __restrict__ partial) {
+  const int C = c0 + c1, cpg = C / groups;
+  const int c = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y, n = blockIdx.z;
+  if (c >= C) return;
+  const int chunks = gridDim.y;
+  const float sc = coef[((long long)n * 2) * C + c], sh = coef[((long long)n * 2 + 1) * C + c];
+  const int g = c / cpg;
+  const float mean = mr[((long long)n * groups + g) * 2], rstd = mr[((long long)n * groups + g) * 2 + 1];
+  const float* xs = c < c0 ? x0 + c : x1 + (c - c0);
+  const int cs = c < c0 ? c0 : c1;
+  const int p0 = chunk * GB_PIX, p1 = min(hw, p0 + GB_PIX);
+  float a = 0.f, b = 0.f;
+  for (int p = p0; p < p1; ++p) {
+    const long long row = (long long)n * hw + p;
+    const float xv = xs[row * cs];
+    float dz = dy[row * C + c];
+    if (silu) dz *= dsilu_f(fmaf(xv, sc, sh));
+    a += dz;
+    b = fmaf(dz, (xv - mean) * rstd, b);
+  }
+  float* d = partial + (((long long)n * chunks + chunk) * C + c) * 2;
+  d[0] = a; d[1] = b;
+}
+
+// pass 2: per (sample, channel) totals over the chunks; per (sample, group) means of dxhat and dxhat*xhat
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partial, int C, int hw, int chunks,
+                                                              int groups, const float* __restrict__ gamma,
+                                                              float* __restrict__ tot, float* __restrict__ gstat) {
+  const int n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cpg = C / groups;
+  for (int g = blockIdx.x * 4 + wave; g < groups; g += gridDim.x * 4) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int cc = lane; cc < cpg; cc += 64) {
+      const int c = g * cpg + cc;
+      float a = 0.f, b = 0.f;
+      for (int ch = 0; ch < chunks; ++ch) {
+        const float* d = partial + (((long long)n * chunks + ch) * C + c) * 2;
+        a += d[0]; b += d[1];
+      }
+      tot[((long long)n * C + c) * 2] = a;
+      tot[((long long)n * C + c) * 2 + 1] = b;
+      s1 = fmaf(gamma[c], a, s1);
+      s2 = fmaf(gamma[c], b, s2);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+      const float inv = 1.0f / ((float)cpg * (float)hw);
+      gstat[((long long)n * groups + g) * 2] = s1 * inv;
+      gstat[((long long)n * groups + g) * 2 + 1] = s2 * inv;
+    }
+  }
+}
+
+// dgamma[c] (+)= sum_n tot[n][c].b ; dbeta[c] (+)= sum_n tot[n][c].a
+__global__ void gn_bwd_params_kernel(const float* __restrict__ tot, int n, int C, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int i = 0; i < n; ++i) {
+    a += tot[((long long)i * C + c) * 2];
+    b += tot[((long long)i * C + c) * 2 + 1];
+  }
+  dgamma[c] = accumulate ? dgamma[c] + b : b;
+  dbeta[c] = accumulate ? dbeta[c] + a : a;
+}
+
+// pass 3: dx = scale*dz - rstd*(m1 + xhat*m2), split back onto the two sources of the channel concat
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x0, int c0, const float* __restrict__ x1,
+                                                           int c1, const float* __restrict__ dy,
+                                                           const float* __restrict__ coef, const float* __restrict__ mr,
+                                                           const float* __restrict__ gstat, int hw, int groups, int silu,
+                                                           float* __restrict__ dx0, int acc0, float* __restrict__ dx1,
+                                                           int acc1, long long total) {
+  const int C = c0 + c1, cpg = C / groups;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / C;
+    const int c = (int)(i - row * C), n = (int)(row / hw), g = c / cpg;
+    const float sc = coef[((long long)n * 2) * C + c], sh = coef[((long long)n * 2 + 1) * C + c];
+    const float mean = mr[((long long)n * groups + g) * 2], rstd = mr[((long long)n * groups + g) * 2 + 1];
+    const float m1 = gstat[((long long)n * groups + g) * 2], m2 = gstat[((long long)n * groups + g) * 2 + 1];
+    const bool first = c < c0;
+    const long long o = first ? row * c0 + c : row * c1 + (c - c0);
+    const float xv = first ? x0[o] : x1[o];
+    float dz = dy[i];
+    if (silu) dz *= dsilu_f(fmaf(xv, sc, sh));
+    const float v = sc * dz - rstd * fmaf((xv - mean) * rstd, m2, m1);
+    float* d = first ? dx0 + o : dx1 + o;
+    const int acc = first ? acc0 : acc1;
+    *d = acc ? *d + v : v;
+  }
+}
+
+// ---- LayerNorm: materialised forward and backward ---------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, int C, long long total4) {
+  const int c4n = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / c4n;
+    const int c = (int)(i - row * c4n) * 4;
+    const float mu = stats[2 * row], rs = stats[2 * row + 1];
+    const float4 v = *reinterpret_cast<const float4*>(x + row * C + c);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+    float4 o;
+    o.x = (v.x - mu) * rs * g.x + b.x; o.y = (v.y - mu) * rs * g.y + b.y;
+    o.z = (v.z - mu) * rs * g.z + b.z; o.w = (v.w - mu) * rs * g.w + b.w;
+    *reinterpret_cast<float4*>(y + row * C + c) = o;
+  }
+}
+
+// one wave per row (looping over a strip of rows); per-workgroup column partials of dgamma / dbeta
+constexpr int LN_ROWS_PER_BLOCK = 64;
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     float* __restrict__ dx, int accumulate, int rows, int C,
+                                                     float* __restrict__ partial) {
+  __shared__ float red[4][1024 * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK, r1 = min(rows, r0 + LN_ROWS_PER_BLOCK);
+  float dg[16], db[16];       // lane owns columns lane + 64*i, C <= 1024
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const float mu = stats[2 * (long long)row], rs = stats[2 * (long long)row + 1];
+    const float* xr = x + (long long)row * C;
+    const float* dyr = dy + (long long)row * C;
+    float xh[16], gv[16];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = lane + 64 * i;
+      xh[i] = 0.f; gv[i] = 0.f;
+      if (c < C) {
+        const float d = dyr[c];
+        xh[i] = (xr[c] - mu) * rs;
+        gv[i] = d * gamma[c];
+        dg[i] = fmaf(d, xh[i], dg[i]);
+        db[i] += d;
+        s1 += gv[i];
+        s2 = fmaf(gv[i], xh[i], s2);
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+    float* dxr = dx + (long long)row * C;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) {
+        const float v = rs * (gv[i] - s1 - xh[i] * s2);
+        dxr[c] = accumulate ? dxr[c] + v : v;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + 64 * i;
+    if (c < C) { red[wave][2 * c] = dg[i]; red[wave][2 * c + 1] = db[i]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { a += red[w][2 * c]; b += red[w][2 * c + 1]; }
+    partial[((long long)blockIdx.x * C + c) * 2] = a;
+    partial[((long long)blockIdx.x * C + c) * 2 + 1] = b;
+  }
+}
+
+__global__ void ln_bwd_params_kernel(const float* __restrict__ partial, int blocks, int C, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int i = 0; i < blocks; ++i) {
+    a += partial[((long long)i * C + c) * 2];
+    b += partial[((long long)i * C + c) * 2 + 1];
+  }
+  dgamma[c] = accumulate ? dgamma[c] + a : a;
+  dbeta[c] = accumulate ? dbeta[c] + b : b;
+}
+
+// ---- GEGLU (attention.py:37-45): pre = [value | gate], f = value * gelu(gate), exact erf GELU ---------------
+__device__ __forceinline__ float gelu_f(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float g) {
+  return 0.5f * (1.0f + erff(g * 0.70710678118654752440f)) + g * 0.39894228040143267794f * __expf(-0.5f * g * g);
+}
+__global__ void geglu_fwd_kernel(const float* __restrict__ pre, float* __restrict__ f, int inner, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / inner;
+    const int c = (int)(i - row * inner);
+    const float* p = pre + row * 2 * inner;
+    f[i] = p[c] * gelu_f(p[inner + c]);
+  }
+}
+__global__ void geglu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ df, float* __restrict__ dpre,
+                                 int inner, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / inner;
+    const int c = (int)(i - row * inner);
+    const float* p = pre + row * 2 * inner;
+    const float v = p[c], g = p[inner + c], d = df[i];
+    dpre[row * 2 * inner + c] = d * gelu_f(g);
+    dpre[row * 2 * inner + inner + c] = d * v * dgelu_f(g);
+  }
+}
+
+// ---- softmax backward on rows: ds = p * (dp - sum_j dp_j p_j) * scale (in place over dp) -----------------------
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ p, float* __restrict__ dp,
+                                                               int cols, float scale) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const float* pr = p + row * cols;
+  float* dr = dp + row * cols;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) s = fmaf(pr[c], dr[c], s);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int c = threadIdx.x; c < cols; c += 256) dr[c] = pr[c] * (dr[c] - tot) * scale;
+}
+
+// ---- column sums over row groups: out[g][n] (+)= sum_{r in group g} x[r][n] (bias and per-sample-vector grads) --
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ldx, int rows_per_group,
+                                                             int N, int splits, float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int g = blockIdx.y, sp = blockIdx.z;
+  const int per = (rows_per_group + splits - 1) / splits;
+  const int r0 = sp * per, r1 = min(rows_per_group, r0 + per);
+  float s = 0.f;
+  if (c < N)
+    for (int r = r0 + rl; r < r1; r += 4) s += x[((long long)g * rows_per_group + r) * ldx + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < N)
+    partial[((long long)g * splits + sp) * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int N, int splits, float* __restrict__ out, int ldo,
+                                    int accumulate, int groups) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)groups * N) return;
+  const int g = (int)(i / N), c = (int)(i - (long long)g * N);
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += partial[((long long)g * splits + k) * N + c];
+  float* d = out + (long long)g * ldo + c;
+  *d = accumulate ? *d + s : s;
+}
+
+// ---- nearest-x2 upsample backward: dx[n][y][x][c] (+)= sum of the 2x2 block of du ---------------------------
+__global__ void sumpool2_kernel(const float* __restrict__ du, float* __restrict__ dx, int h, int w, int C, int accumulate,
+                                long long total4) {
+  const int c4n = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const long long pix = i / c4n;
+    const int xx = (int)(pix % w);
+    const long long t = pix / w;
+    const int yy = (int)(t % h);
+    const long long n = t / h;
+    const float* s = du + (((n * 2 * h + 2 * yy) * 2 * w) + 2 * xx) * C + c;
+    const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + C);
+    const float4 d = *reinterpret_cast<const float4*>(s + (long long)2 * w * C), e = *reinterpret_cast<const float4*>(s + (long long)2 * w * C + C);
+    float4 o = make_float4((a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w));
+    float* dst = dx + pix * C + c;
+    if (accumulate) { o.x += dst[0]; o.y += dst[1]; o.z += dst[2]; o.w += dst[3]; }
+    *reinterpret_cast<float4*>(dst) = o;
+  }
+}
+
+// ---- small elementwise pieces ---------------------------------------------------------------------------
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = silu_f(x[i]);
+}
+__global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dx[i] = dy[i] * dsilu_f(x[i]);
+}
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = fmaf(a, x[i], y[i]);
+}
+
+// q_sample (ddpm.py:1009-1012): x_t = sqrt_ac[t_b]*x0 + sqrt_1mac[t_b]*noise
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,
+                                const float* __restrict__ sqrt_ac, const float* __restrict__ sqrt_1mac, float* __restrict__ xt,
+                                int per, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long tb = t[i / per];
+    xt[i] = sqrt_ac[tb] * x0[i] + sqrt_1mac[tb] * noise[i];
+  }
+}
+
+// mean-squared-error loss (ddpm.py:324-334 get_loss 'l2' + .mean): dpred = 2*(pred-target)/n, loss partials per workgroup
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                       float* __restrict__ dpred, long long n, float gscale,
+                                                       double* __restrict__ partial) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float d = pred[i] - target[i];
+    dpred[i] = d * gscale;
+    s += (double)d * d;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void mse_final_kernel(const double* __restrict__ partial, int blocks, double inv_n, float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < blocks; ++i) s += partial[i];
+    *loss = (float)(s * inv_n);
+  }
+}
+
+// AdamW (torch.optim.AdamW semantics, ddpm.py:1363-1385): decoupled weight decay, bias-corrected moments
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+  }
+}
+// LitEma.forward (ema.py:25-44): shadow -= (1-decay) * (shadow - param)
+__global__ void ema_kernel(float* __restrict__ shadow, const float* __restrict__ p, long long n, float one_minus_decay) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    shadow[i] -= one_minus_decay * (shadow[i] - p[i]);
+}
+
+// packed forward conv weights [Cin/32][9][32][Cout] -> packed data-gradient weights [Cout/32][9][32][Cin] with the
+// taps mirrored: dX = conv3x3(dY, W') (stride-1 'same' convolution) -- one 32x32 LDS transpose per (chunk pair, tap)
+__global__ __launch_bounds__(256) void pack_dgrad3x3_kernel(const float* __restrict__ wf, float* __restrict__ wd, int cin, int cout) {
+  __shared__ float tile[32][33];
+  const int ci_chunk = blockIdx.x, co_chunk = blockIdx.y, tap = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 8 rows per pass
+#pragma unroll
+  for (int r = ty; r < 32; r += 8)
+    tile[r][tx] = wf[(((long long)ci_chunk * 9 + tap) * 32 + r) * cout + co_chunk * 32 + tx];     // [ci32=r][co32=tx]
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8)
+    wd[(((long long)co_chunk * 9 + (8 - tap)) * 32 + r) * cin + ci_chunk * 32 + tx] = tile[tx][r];  // [co32=r][ci32=tx]
+}
+
+static inline int grid_for(long long n) {
+  long long g = (n + 255) / 256;
+  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace ldmk
+
+using namespace ldmk;
+
+extern "C" int ldmk_gn_bwd_chunks(int hw) { return (hw + GB_PIX - 1) / GB_PIX; }
+
+extern "C" int ldmk_gn_group_stats(const float* partial0, int c0, const float* partial1, int c1, int n, int hw, int groups,
+                                   float eps, float* mr, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(partial0 && mr && c0 > 0 && n > 0 && hw > 0 && groups > 0 && (c0 + c1) % groups == 0, "ldmk_gn_group_stats: bad args");
+  LDMK_REQUIRE((c1 == 0) == (partial1 == nullptr), "ldmk_gn_group_stats: partial1/c1 mismatch");
+  hipLaunchKernelGGL(gn_group_stats_kernel, dim3((groups + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, partial0, c0, partial1,
+                     c1, hw, ldmk_gn_chunks(hw), groups, eps, mr);
+  return check_launch("ldmk_gn_group_stats");
+}
+
+extern "C" int ldmk_gn_bwd(const float* x0, int c0, const float* x1, int c1, const float* dy, const float* coef,
+                           const float* mr, const float* gamma, int n, int hw, int groups, int silu, float* dx0, int acc0,
+                           float* dx1, int acc1, float* dgamma, float* dbeta, int acc_params, float* scratch, void* stream) {
+  LDMK_ENTER();
+  const int C = c0 + c1;
+  LDMK_REQUIRE(x0 && dy && coef && mr && gamma && dx0 && dgamma && dbeta && scratch, "ldmk_gn_bwd: null buffer");
+  LDMK_REQUIRE(c0 > 0 && n > 0 && hw > 0 && groups > 0 && C % groups == 0, "ldmk_gn_bwd: bad shape");
+  LDMK_REQUIRE((c1 == 0) == (x1 == nullptr) && (c1 == 0) == (dx1 == nullptr), "ldmk_gn_bwd: second source mismatch");
+  const int chunks = ldmk_gn_bwd_chunks(hw);
+  float* partial = scratch;                                  // [n][chunks][C][2]
+  float* tot = partial + (long long)n * chunks * C * 2;      // [n][C][2]
+  float* gstat = tot + (long long)n * C * 2;                 // [n][groups][2]
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((C + 255) / 256, chunks, n), dim3(256), 0, st, x0, c0, x1, c1, dy, coef, mr, hw,
+                     groups, silu, partial);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((groups + 3) / 4, n), dim3(256), 0, st, partial, C, hw, chunks, groups, gamma,
+                     tot, gstat);
+  hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, st, tot, n, C, dgamma, dbeta, acc_params);
+  const long long total = (long long)n * hw * C;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x0, c0, x1, c1, dy, coef, mr, gstat, hw,
+                     groups, silu, dx0, acc0, dx1, acc1, total);
+  return check_launch("ldmk_gn_bwd");
+}
+extern "C" long long ldmk_gn_bwd_scratch_elems(int n, int hw, int c, int groups) {
+  return (long long)n * ldmk_gn_bwd_chunks(hw) * c * 2 + (long long)n * c * 2 + (long long)n * groups * 2;
+}
+
+extern "C" int ldmk_ln_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int rows,
+                             int c, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(x && stats && gamma && beta && y && rows > 0 && c > 0 && c % 4 == 0, "ldmk_ln_apply: bad args (C%%4==0)");
+  const long long total4 = (long long)rows * (c / 4);
+  hipLaunchKernelGGL(ln_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, y, c, total4);
+  return check_launch("ldmk_ln_apply");
+}
+extern "C" int ldmk_ln_bwd_blocks(int rows) { return (rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK; }
+extern "C" int ldmk_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, float* dx, int acc_dx,
+                           int rows, int c, float* dgamma, float* dbeta, int acc_params, float* scratch, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(dy && x && stats && gamma && dx && dgamma && dbeta && scratch, "ldmk_ln_bwd: null buffer");
+  LDMK_REQUIRE(rows > 0 && c > 0 && c <= 1024, "ldmk_ln_bwd: bad shape (C<=1024)");
+  const int blocks = ldmk_ln_bwd_blocks(rows);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, x, stats, gamma, dx, acc_dx, rows, c, scratch);
+  hipLaunchKernelGGL(ln_bwd_params_kernel, dim3((c + 255) / 256), dim3(256), 0, st, scratch, blocks, c, dgamma, dbeta, acc_params);
+  return check_launch("ldmk_ln_bwd");
+}
+
+extern "C" int ldmk_geglu_fwd(const float* pre, float* f, long long rows, int inner, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(pre && f && rows > 0 && inner > 0, "ldmk_geglu_fwd: bad args");
+  const long long total = rows * inner;
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, pre, f, inner, total);
+  return check_launch("ldmk_geglu_fwd");
+}
+extern "C" int ldmk_geglu_bwd(const float* pre, const float* df, float* dpre, long long rows, int inner, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(pre && df && dpre && rows > 0 && inner > 0, "ldmk_geglu_bwd: bad args");
+  const long long total = rows * inner;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, pre, df, dpre, inner, total);
+  return check_launch("ldmk_geglu_bwd");
+}
+
+extern "C" int ldmk_softmax_bwd_rows(const float* p, float* dp, long long rows, int cols, float scale, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(p && dp && rows > 0 && rows <= 0x7fffffffLL && cols > 0, "ldmk_softmax_bwd_rows: bad args");
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, p, dp, cols, scale);
+  return check_launch("ldmk_softmax_bwd_rows");
+}
+
+extern "C" int ldmk_colsum_splits(int rows_per_group) {
+  int s = rows_per_group / 256;
+  return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+extern "C" int ldmk_colsum(const float* x, int ldx, int rows_per_group, int groups, int n, float* out, int ldo, int accumulate,
+                           float* scratch, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(x && out && scratch && rows_per_group > 0 && groups > 0 && groups <= 65535 && n > 0, "ldmk_colsum: bad args");
+  const int splits = ldmk_colsum_splits(rows_per_group);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((n + 63) / 64, groups, splits), dim3(256), 0, st, x, ldx, rows_per_group, n,
+                     splits, scratch);
+  const long long tot = (long long)groups * n;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, scratch, n, splits, out, ldo,
+                     accumulate, groups);
+  return check_launch("ldmk_colsum");
+}
+
+extern "C" int ldmk_sumpool2(const float* du, float* dx, int n, int h, int w, int c, int accumulate, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(du && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "ldmk_sumpool2: bad args (C%%4==0)");
+  const long long total4 = (long long)n * h * w * (c / 4);
+  hipLaunchKernelGGL(sumpool2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, du, dx, h, w, c, accumulate, total4);
+  return check_launch("ldmk_sumpool2");
+}
+
+extern "C" int ldmk_silu(const float* x, float* y, long long n, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(x && y && n > 0, "ldmk_silu: bad args");
+  hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  return check_launch("ldmk_silu");
+}
+extern "C" int ldmk_silu_bwd(const float* x, const float* dy, float* dx, long long n, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(x && dy && dx && n > 0, "ldmk_silu_bwd: bad args");
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n);
+  return check_launch("ldmk_silu_bwd");
+}
+extern "C" int ldmk_axpy(float* y, const float* x, float a, long long n, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(x && y && n > 0, "ldmk_axpy: bad args");
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, x, a, n);
+  return check_launch("ldmk_axpy");
+}
+
+extern "C" int ldmk_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ac,
+                             const float* sqrt_1mac, float* xt, int n, int per, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(x0 && noise && t && sqrt_ac && sqrt_1mac && xt && n > 0 && per > 0, "ldmk_q_sample: bad args");
+  const long long total = (long long)n * per;
+  hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x0, noise, t, sqrt_ac, sqrt_1mac,
+                     xt, per, total);
+  return check_launch("ldmk_q_sample");
+}
+
+extern "C" int ldmk_mse_grad(const float* pred, const float* target, float* dpred, long long n, float* loss, double* scratch,
+                             void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(pred && target && dpred && loss && scratch && n > 0, "ldmk_mse_grad: bad args");
+  const int blocks = 256;                                    // scratch: 256 doubles
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mse_grad_kernel, dim3(blocks), dim3(256), 0, st, pred, target, dpred, n, 2.0f / (float)n, scratch);
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, st, scratch, blocks, 1.0 / (double)n, loss);
+  return check_launch("ldmk_mse_grad");
+}
+
+extern "C" int ldmk_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int step, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(p && g && m && v && n > 0 && step >= 1, "ldmk_adamw: bad args");
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2s);
+  return check_launch("ldmk_adamw");
+}
+extern "C" int ldmk_ema(float* shadow, const float* p, long long n, float one_minus_decay, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(shadow && p && n > 0, "ldmk_ema: bad args");
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, shadow, p, n, one_minus_decay);
+  return check_launch("ldmk_ema");
+}
+
+extern "C" int ldmk_pack_dgrad3x3(const float* w_fwd, float* w_dgrad, int cin, int cout, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(w_fwd && w_dgrad && cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0, "ldmk_pack_dgrad3x3: channels %%32");
+  LDMK_REQUIRE(cout / 32 <= 65535, "ldmk_pack_dgrad3x3: grid limit");
+  hipLaunchKernelGGL(pack_dgrad3x3_kernel, dim3(cin / 32, cout / 32, 9), dim3(256), 0, (hipStream_t)stream, w_fwd, w_dgrad, cin, cout);
+  return check_launch("ldmk_pack_dgrad3x3");
+}

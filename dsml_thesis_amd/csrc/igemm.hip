@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int iy = r_y[i] + t / 3, ix = r_x[i] + t % 3;
-        if (valid && iy >= 0 && ix >= 0 && iy < lim_h && ix < lim_w) mask |= 1u << t;
+        // upsample == 2: zero-insertion (data gradient of a stride-2 convolution): odd positions are zeros
+        if (valid && iy >= 0 && ix >= 0 && iy < lim_h && ix < lim_w && !(p.upsample == 2 && ((iy | ix) & 1))) mask |= 1u << t;
       }
       r_mask[i] = mask;
     } else {

@@ -1,0 +1,268 @@
+// Weight-gradient GEMM on the f32 matrix cores: dW[Kw][N] = sum over rows r of A[r][kw] * dY[r][n].
+//
+// The transposed-A counterpart of igemm.hip for the training step (ddpm.py:1014-1047 p_losses,
+// backward of every nn.Conv2d 3x3 / 1x1 and nn.Linear of the UNet).  The reduction runs over the n*H*W token
+// rows, so both operands are staged as they lie in HBM -- a 32-row slice of A (rows mode: the saved GEMM input;
+// conv mode: the im2col gather of the saved NHWC input, same index arithmetic as the forward gather including
+// stride, asymmetric pad and nearest-x2 upsampling) and the matching 32 rows of dY -- no transposes anywhere.
+// dW comes out in the packed layout the forward consumes ([Cin/32][9][32][Cout] rows for 3x3 convolutions), so
+// the optimizer updates packed weights in place.  The output is small and the reduction long: the rows are split
+// over blockIdx.y (`splitr`) into partial slabs that a second kernel sums in a fixed order (bitwise reproducible).
+#include "ldmk_common.h"
+
+namespace ldmk {
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const ldmk_wgrad_args p, const int splitr, float* __restrict__ ws) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int ASTR = BM + 4, BSTR = BN + 4;       // 16-B aligned rows for the float4 staging stores
+  constexpr int NA = BM / 32, NB = BN / 32;         // float4 per thread per 32-row slice
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float As[32 * ASTR];
+  __shared__ __attribute__((aligned(16))) float Bs[32 * BSTR];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, half = lane >> 5;
+  const int tiles_m = (p.Kw + BM - 1) / BM;
+  const int m0 = (blockIdx.x % tiles_m) * BM, n0 = (blockIdx.x / tiles_m) * BN;
+  const int ks = blockIdx.y, bz = blockIdx.z;
+  const float* __restrict__ ap = p.a + (long long)bz * p.a_bstride;
+  const float* __restrict__ dyp = p.dy + (long long)bz * p.dy_bstride;
+  const bool conv = p.a_mode == LDMK_A_CONV3X3;
+  const int rps = p.out_h * p.out_w;
+
+  const int iters_all = (p.R + 31) / 32;
+  const int it_per = (iters_all + splitr - 1) / splitr;
+  const int it_begin = ks * it_per, it_end = min(iters_all, it_begin + it_per);
+
+  // per-thread, loop-invariant column bookkeeping of the A slice
+  int a_rl[NA], a_col[NA], a_ch[NA], a_dy[NA], a_dx[NA];
+  bool a_ok[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int idx = tid + 256 * i;
+    a_rl[i] = idx / (BM / 4);
+    a_col[i] = (idx - a_rl[i] * (BM / 4)) * 4;
+    const int kw = m0 + a_col[i];
+    a_ok[i] = kw < p.Kw;
+    if (conv) {
+      const int chunk = kw >> 5, cc = chunk / 9, tap = chunk - cc * 9;
+      a_ch[i] = cc * 32 + (kw & 31);
+      a_dy[i] = tap / 3;
+      a_dx[i] = tap - a_dy[i] * 3;
+    } else {
+      a_ch[i] = kw; a_dy[i] = 0; a_dx[i] = 0;
+    }
+  }
+  int b_rl[NB], b_col[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int idx = tid + 256 * i;
+    b_rl[i] = idx / (BN / 4);
+    b_col[i] = (idx - b_rl[i] * (BN / 4)) * 4;
+  }
+
+  float4 areg[NA], breg[NB];
+  auto load_slice = [&](int it) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int r = it * 32 + a_rl[i];
+      if (a_ok[i] && r < p.R) {
+        if (conv) {
+          const int n = r / rps, pix = r - n * rps;
+          const int oy = pix / p.out_w, ox = pix - oy * p.out_w;
+          int iy = oy * p.stride - p.pad_lo + a_dy[i], ix = ox * p.stride - p.pad_lo + a_dx[i];
+          const int lim_h = p.upsample ? 2 * p.in_h : p.in_h, lim_w = p.upsample ? 2 * p.in_w : p.in_w;
+          if (iy >= 0 && ix >= 0 && iy < lim_h && ix < lim_w) {
+            if (p.upsample) { iy >>= 1; ix >>= 1; }
+            v = *reinterpret_cast<const float4*>(ap + ((long long)(n * p.in_h + iy) * p.in_w + ix) * p.c + a_ch[i]);
+          }
+        } else {
+          v = *reinterpret_cast<const float4*>(ap + (long long)r * p.lda + a_ch[i]);
+        }
+      }
+      areg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int r = it * 32 + b_rl[i], n = n0 + b_col[i];
+      if (r < p.R && n < p.N) v = *reinterpret_cast<const float4*>(dyp + (long long)r * p.ldy + n);
+      breg[i] = v;
+    }
+  };
+  auto store_slice = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<float4*>(As + a_rl[i] * ASTR + a_col[i]) = areg[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(Bs + b_rl[i] * BSTR + b_col[i]) = breg[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* Aw = As + half * ASTR + wm * (32 * TM) + l31;
+  const float* Bw = Bs + half * BSTR + wn * (32 * TN) + l31;
+  if (it_begin < it_end) load_slice(it_begin);
+  for (int it = it_begin; it < it_end; ++it) {
+    __syncthreads();
+    store_slice();
+    __syncthreads();
+    if (it + 1 < it_end) load_slice(it + 1);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Aw[2 * s * ASTR + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bw[2 * s * BSTR + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int rowbase = m0 + wm * (32 * TM), colbase = n0 + wn * (32 * TN);
+  float* dst;
+  long long ld;
+  if (splitr > 1) {
+    dst = ws + ((long long)bz * splitr + ks) * p.Kw * p.N;
+    ld = p.N;
+  } else {
+    dst = p.dw + (long long)bz * p.dw_bstride;
+    ld = p.ldw;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = colbase + j * 32 + l31;
+    if (col >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < p.Kw) {
+          float* d = dst + (long long)row * ld + col;
+          if (splitr > 1) *d = acc[i][j][r];
+          else *d = p.accumulate ? *d + p.alpha * acc[i][j][r] : p.alpha * acc[i][j][r];
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ldmk_wgrad_args p, const int splitr,
+                                                           const float* __restrict__ ws) {
+  const int n4 = p.N / 4;
+  const long long total = (long long)p.Kw * n4;
+  const int bz = blockIdx.z;
+  const float* slab0 = ws + (long long)bz * splitr * p.Kw * p.N;
+  float* outp = p.dw + (long long)bz * p.dw_bstride;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / n4), col = (int)(i - (long long)row * n4) * 4;
+    float4 s = *reinterpret_cast<const float4*>(slab0 + (long long)row * p.N + col);
+    for (int k = 1; k < splitr; ++k) {
+      const float4 t = *reinterpret_cast<const float4*>(slab0 + ((long long)k * p.Kw + row) * p.N + col);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    s.x *= p.alpha; s.y *= p.alpha; s.z *= p.alpha; s.w *= p.alpha;
+    float* d = outp + (long long)row * p.ldw + col;
+    if (p.accumulate) { s.x += d[0]; s.y += d[1]; s.z += d[2]; s.w += d[3]; }
+    d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w;
+  }
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_wgrad(const ldmk_wgrad_args& a, int splitr, hipStream_t st) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  const int tiles = ((a.Kw + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  const int nb = a.batch > 1 ? a.batch : 1;
+  hipLaunchKernelGGL((wgrad_kernel<TM, TN, WM, WN>), dim3(tiles, splitr, nb), dim3(256), 0, st, a, splitr, a.ws);
+  if (splitr > 1) {
+    long long total = (long long)a.Kw * (a.N / 4);
+    int g = (int)((total + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g, 1, nb), dim3(256), 0, st, a, splitr, a.ws);
+  }
+  return check_launch("ldmk_wgrad");
+}
+
+// tile orientation: put the 160-wide side on whichever of (Kw, N) is a multiple of 160
+static int wgrad_cfg(const ldmk_wgrad_args& a) {
+  auto waste = [](int v, int b) { return (float)(((v + b - 1) / b) * b) / (float)v; };
+  const float w1 = waste(a.Kw, 128) * waste(a.N, 160), w2 = waste(a.Kw, 160) * waste(a.N, 128),
+              w3 = waste(a.Kw, 128) * waste(a.N, 128) * 1.08f, w4 = waste(a.Kw, 128) * waste(a.N, 32) * 1.5f;
+  int best = 1;
+  float bw = w1;
+  if (w2 < bw) { bw = w2; best = 2; }
+  if (w3 < bw) { bw = w3; best = 3; }
+  if (w4 < bw) { bw = w4; best = 4; }
+  return best;
+}
+
+static void wgrad_tile(int cfg, int* bm, int* bn) {
+  static const int t[5][2] = {{0, 0}, {128, 160}, {160, 128}, {128, 128}, {128, 32}};
+  *bm = t[cfg][0]; *bn = t[cfg][1];
+}
+
+static int wgrad_plan_splitr(const ldmk_wgrad_args& a, int cfg) {
+  int bm, bn;
+  wgrad_tile(cfg, &bm, &bn);
+  const long long tiles = (long long)((a.Kw + bm - 1) / bm) * ((a.N + bn - 1) / bn) * (a.batch > 1 ? a.batch : 1);
+  const int iters = (a.R + 31) / 32;
+  long long s = (1024 + tiles - 1) / tiles;       // aim at >= 1024 workgroups (2 per CU x 2 rounds)
+  if (s > iters / 4) s = iters / 4;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  const long long per = (long long)(a.batch > 1 ? a.batch : 1) * a.Kw * a.N;
+  if (s > 1 && (!a.ws || per * s > a.ws_elems)) s = a.ws ? a.ws_elems / per : 1;
+  return s < 1 ? 1 : (int)s;
+}
+
+}  // namespace ldmk
+
+extern "C" int ldmk_wgrad_plan(const ldmk_wgrad_args* args, int* splitr) {
+  if (!args || !splitr) return LDMK_EINVAL;
+  ldmk_wgrad_args a = *args;
+  if (!a.ws) { a.ws = reinterpret_cast<float*>(1); a.ws_elems = 1LL << 40; }   // "how much would you like"
+  *splitr = ldmk::wgrad_plan_splitr(a, ldmk::wgrad_cfg(a));
+  return LDMK_OK;
+}
+
+extern "C" int ldmk_wgrad(const ldmk_wgrad_args* args, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(args != nullptr, "ldmk_wgrad: null args");
+  ldmk_wgrad_args a = *args;
+  LDMK_REQUIRE(a.R > 0 && a.Kw > 0 && a.N > 0 && a.a && a.dy && a.dw, "ldmk_wgrad: bad problem R=%d Kw=%d N=%d", a.R, a.Kw, a.N);
+  LDMK_REQUIRE(a.N % 4 == 0 && a.ldy % 4 == 0 && a.ldw % 4 == 0 && a.Kw % 4 == 0, "ldmk_wgrad: N, Kw, ldy, ldw must be multiples of 4");
+  if (a.a_mode == LDMK_A_CONV3X3) {
+    LDMK_REQUIRE(a.c > 0 && a.c % 32 == 0 && a.Kw == 9 * a.c, "ldmk_wgrad: conv needs c%%32==0 and Kw == 9*c (c=%d Kw=%d)", a.c, a.Kw);
+    LDMK_REQUIRE(a.in_h > 0 && a.in_w > 0 && a.out_h > 0 && a.out_w > 0 && a.stride >= 1, "ldmk_wgrad: conv geometry");
+    LDMK_REQUIRE(a.R % (a.out_h * a.out_w) == 0 && a.batch <= 1, "ldmk_wgrad: R must be n*out_h*out_w, no batching");
+  } else {
+    LDMK_REQUIRE(a.a_mode == LDMK_A_ROWS && a.lda >= a.Kw && a.lda % 4 == 0, "ldmk_wgrad: rows mode needs lda >= Kw, lda%%4==0");
+  }
+  LDMK_REQUIRE(a.splitr >= 0 && a.splitr <= 256, "ldmk_wgrad: splitr=%d outside [0,256]", a.splitr);
+  if (a.alpha == 0.f) a.alpha = 1.f;
+  const int cfg = wgrad_cfg(a);
+  int sr = a.splitr > 0 ? a.splitr : wgrad_plan_splitr(a, cfg);
+  if (sr > 1) {
+    const long long need = (long long)(a.batch > 1 ? a.batch : 1) * sr * a.Kw * a.N;
+    LDMK_REQUIRE(a.ws && need <= a.ws_elems, "ldmk_wgrad: splitr=%d needs a workspace of %lld floats", sr, need);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (cfg) {
+    case 1: return launch_wgrad<1, 5, 4, 1>(a, sr, st);    // 128 x 160
+    case 2: return launch_wgrad<5, 1, 1, 4>(a, sr, st);    // 160 x 128
+    case 3: return launch_wgrad<2, 2, 2, 2>(a, sr, st);    // 128 x 128
+    default: return launch_wgrad<1, 1, 4, 1>(a, sr, st);   // 128 x 32 (per-head attention gradients)
+  }
+}

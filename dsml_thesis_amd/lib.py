@@ -31,6 +31,17 @@ class IgemmArgs(C.Structure):
     ]
 
 
+class WgradArgs(C.Structure):
+    _fields_ = [
+        ("R", C.c_int), ("Kw", C.c_int), ("N", C.c_int), ("a", _fp), ("c", C.c_int), ("lda", C.c_int),
+        ("a_mode", C.c_int), ("in_h", C.c_int), ("in_w", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int),
+        ("stride", C.c_int), ("pad_lo", C.c_int), ("upsample", C.c_int),
+        ("dy", _fp), ("ldy", C.c_int), ("dw", _fp), ("ldw", C.c_int), ("accumulate", C.c_int), ("alpha", C.c_float),
+        ("batch", C.c_int), ("a_bstride", C.c_longlong), ("dy_bstride", C.c_longlong), ("dw_bstride", C.c_longlong),
+        ("splitr", C.c_int), ("ws", _fp), ("ws_elems", C.c_longlong),
+    ]
+
+
 _SIGS = {
     "ldmk_version": (C.c_int, []),
     "ldmk_last_error": (C.c_char_p, []),
@@ -64,6 +75,32 @@ _SIGS = {
     "ldmk_pack_conv3x3": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
     "ldmk_postprocess_frames": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_add_rowvec": (C.c_int, [_fp, _fp, C.c_int, C.c_longlong, C.c_int, C.c_int, _fp]),
+    # ---- training step (N1)
+    "ldmk_wgrad": (C.c_int, [C.POINTER(WgradArgs), _fp]),
+    "ldmk_wgrad_plan": (C.c_int, [C.POINTER(WgradArgs), C.POINTER(C.c_int)]),
+    "ldmk_pack_dgrad3x3": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
+    "ldmk_gn_group_stats": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp]),
+    "ldmk_gn_bwd_chunks": (C.c_int, [C.c_int]),
+    "ldmk_gn_bwd_scratch_elems": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ldmk_gn_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp,
+                              C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, _fp, _fp]),
+    "ldmk_ln_apply": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
+    "ldmk_ln_bwd_blocks": (C.c_int, [C.c_int]),
+    "ldmk_ln_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, _fp]),
+    "ldmk_geglu_fwd": (C.c_int, [_fp, _fp, C.c_longlong, C.c_int, _fp]),
+    "ldmk_geglu_bwd": (C.c_int, [_fp, _fp, _fp, C.c_longlong, C.c_int, _fp]),
+    "ldmk_softmax_bwd_rows": (C.c_int, [_fp, _fp, C.c_longlong, C.c_int, C.c_float, _fp]),
+    "ldmk_colsum_splits": (C.c_int, [C.c_int]),
+    "ldmk_colsum": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp]),
+    "ldmk_sumpool2": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_silu": (C.c_int, [_fp, _fp, C.c_longlong, _fp]),
+    "ldmk_silu_bwd": (C.c_int, [_fp, _fp, _fp, C.c_longlong, _fp]),
+    "ldmk_axpy": (C.c_int, [_fp, _fp, C.c_float, C.c_longlong, _fp]),
+    "ldmk_q_sample": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
+    "ldmk_mse_grad": (C.c_int, [_fp, _fp, _fp, C.c_longlong, _fp, _fp, _fp]),
+    "ldmk_adamw": (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                             C.c_int, _fp]),
+    "ldmk_ema": (C.c_int, [_fp, _fp, C.c_longlong, C.c_float, _fp]),
 }
 # every symbol include/ldmk.h declares (checked by tests/test_abi.py against the header text)
 EXPORTED = [k for k in _SIGS if k not in ("ldmk_igemm_force_config", "ldmk_attn_force_qt")]

@@ -53,7 +53,8 @@ typedef struct ldmk_igemm_args {
   int in_h, in_w;            /* conv: stored input spatial size                                   */
   int out_h, out_w;          /* conv: output spatial size (M = n*out_h*out_w)                     */
   int stride, pad_lo;        /* conv: iy = oy*stride + dy - pad_lo                                */
-  int upsample;              /* conv: 1 -> input is nearest-x2 upsampled on the fly               */
+  int upsample;              /* conv: 1 -> input is nearest-x2 upsampled on the fly; 2 -> zero-inserted x2
+                                (data gradient of a stride-2 convolution: odd rows/columns read as 0) */
   int a_tf;                  /* LDMK_TF_*                                                         */
   const float* tf_coef;      /* AFFINE: [n][2][c0+c1] (scale plane, shift plane) from ldmk_gn_*   */
   const float* row_stats;    /* LAYERNORM: [M][2] (mean, rstd) from ldmk_ln_stats                 */
@@ -214,6 +215,77 @@ int ldmk_postprocess_frames(const float* x, float* out, int n, int c, int hw, vo
 /* out[m][c] += vec[m / rows_per_sample][c]  (cross-attention with a 1-token context collapses to
  * a per-sample vector; attention.py:170-193 with L_ctx == 1) */
 int ldmk_add_rowvec(float* x, const float* vec, int vec_ld, long long rows, int c, int rows_per_sample, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training step (SURVEY §8f "next" row N1: LatentDiffusion.p_losses ddpm.py:1014-1047, backward of the UNet,
+ * AdamW ddpm.py:1363-1385, EMA ema.py:25-44).  Data gradients of Conv2d/Linear reuse ldmk_igemm (b_trans for
+ * Linear; ldmk_pack_dgrad3x3 weights for 3x3 convolutions; upsample=2 for stride-2 ones); weight gradients are
+ * ldmk_wgrad; the rest are the HBM-bound kernels below.  Every reduction has a fixed order (reproducible grads).
+ */
+typedef struct ldmk_wgrad_args {
+  int R;                     /* reduction rows: n*out_h*out_w (conv) or token rows                          */
+  int Kw, N;                 /* dW is [Kw][N]; Kw = 9*c in the packed [c/32][9][32] row order for 3x3 convs   */
+  const float* a;            /* what the forward GEMM consumed: NHWC rows of c channels (after norm/activation) */
+  int c, lda;                /* channels (conv: multiple of 32); rows mode: row stride of a (>= Kw)          */
+  int a_mode;                /* LDMK_A_ROWS | LDMK_A_CONV3X3                                                 */
+  int in_h, in_w, out_h, out_w, stride, pad_lo, upsample;   /* conv geometry, as in ldmk_igemm_args          */
+  const float* dy;           /* [R][ldy] gradient of the forward output                                     */
+  int ldy;
+  float* dw;                 /* [Kw][ldw]                                                                    */
+  int ldw;
+  int accumulate;            /* dw += alpha * product                                                        */
+  float alpha;               /* 0 -> 1                                                                       */
+  int batch;                 /* >1: batched over blockIdx.z (per-head attention gradients)                   */
+  long long a_bstride, dy_bstride, dw_bstride;
+  int splitr;                /* 0 = choose (ldmk_wgrad_plan); rows are split over that many workgroups       */
+  float* ws;                 /* scratch for the partial slabs: batch*splitr*Kw*N floats                      */
+  long long ws_elems;
+} ldmk_wgrad_args;
+int ldmk_wgrad(const ldmk_wgrad_args* args, void* stream);
+int ldmk_wgrad_plan(const ldmk_wgrad_args* args, int* splitr);
+/* packed forward 3x3 weights [cin/32][9][32][cout] -> data-gradient weights [cout/32][9][32][cin], taps mirrored */
+int ldmk_pack_dgrad3x3(const float* w_fwd, float* w_dgrad, int cin, int cout, void* stream);
+
+/* GroupNorm(+SiLU) backward (util.py:214-216 + nn.SiLU).  mr = per-(sample, group) (mean, rstd) from the forward's
+ * partial records; scratch = ldmk_gn_bwd_scratch_elems floats; dx0/dx1 follow the two sources of the channel concat. */
+int ldmk_gn_group_stats(const float* partial0, int c0, const float* partial1, int c1, int n, int hw, int groups,
+                        float eps, float* mr, void* stream);
+int ldmk_gn_bwd_chunks(int hw);
+long long ldmk_gn_bwd_scratch_elems(int n, int hw, int c, int groups);
+int ldmk_gn_bwd(const float* x0, int c0, const float* x1, int c1, const float* dy, const float* coef, const float* mr,
+                const float* gamma, int n, int hw, int groups, int silu, float* dx0, int acc0, float* dx1, int acc1,
+                float* dgamma, float* dbeta, int acc_params, float* scratch, void* stream);
+/* LayerNorm materialised forward / backward (attention.py:203-205); scratch = ldmk_ln_bwd_blocks(rows)*c*2 floats */
+int ldmk_ln_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int rows, int c,
+                  void* stream);
+int ldmk_ln_bwd_blocks(int rows);
+int ldmk_ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, float* dx, int acc_dx, int rows,
+                int c, float* dgamma, float* dbeta, int acc_params, float* scratch, void* stream);
+/* GEGLU unfused (attention.py:37-45): pre = [value | gate] of 2*inner columns */
+int ldmk_geglu_fwd(const float* pre, float* f, long long rows, int inner, void* stream);
+int ldmk_geglu_bwd(const float* pre, const float* df, float* dpre, long long rows, int inner, void* stream);
+/* ds = p * (dp - sum_j dp_j p_j) * scale, in place over dp (softmax backward of the materialised attention) */
+int ldmk_softmax_bwd_rows(const float* p, float* dp, long long rows, int cols, float scale, void* stream);
+/* out[g][n] (+)= sum over the rows of group g of x[r][n]: bias gradients (groups = 1) and per-sample timestep-
+ * embedding gradients (groups = batch); scratch = groups * ldmk_colsum_splits(rows_per_group) * n floats */
+int ldmk_colsum_splits(int rows_per_group);
+int ldmk_colsum(const float* x, int ldx, int rows_per_group, int groups, int n, float* out, int ldo, int accumulate,
+                float* scratch, void* stream);
+/* nearest-x2 upsample backward: dx[n][h][w][c] (+)= sum of the 2x2 block of du[n][2h][2w][c] */
+int ldmk_sumpool2(const float* du, float* dx, int n, int h, int w, int c, int accumulate, void* stream);
+int ldmk_silu(const float* x, float* y, long long n, void* stream);
+int ldmk_silu_bwd(const float* x, const float* dy, float* dx, long long n, void* stream);
+int ldmk_axpy(float* y, const float* x, float a, long long n, void* stream);
+/* q_sample (ddpm.py:1009-1012), per = elements per sample; t int64 [n] */
+int ldmk_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ac, const float* sqrt_1mac,
+                  float* xt, int n, int per, void* stream);
+/* loss = mean((pred-target)^2), dpred = 2*(pred-target)/n (ddpm.py:324-334 'l2', :1034); scratch = 256 doubles */
+int ldmk_mse_grad(const float* pred, const float* target, float* dpred, long long n, float* loss, double* scratch,
+                  void* stream);
+/* torch.optim.AdamW step over a flat buffer (step >= 1); LitEma update shadow -= omd * (shadow - p) */
+int ldmk_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int step, void* stream);
+int ldmk_ema(float* shadow, const float* p, long long n, float one_minus_decay, void* stream);
 
 #ifdef __cplusplus
 }
