@@ -400,6 +400,23 @@ __global__ __launch_bounds__(256) void pack_dgrad3x3_kernel(const float* __restr
     wd[(((long long)co_chunk * 9 + (8 - tap)) * 32 + r) * cin + ci_chunk * 32 + tx] = tile[tx][r];  // [co32=r][ci32=tx]
 }
 
+// [n][T][parts][H][32] <-> [parts][n*H][T][32]: per-head contiguous matrices for the batched attention-backward GEMMs
+__global__ void head_permute_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int T, int parts, int H,
+                                    int to_heads, long long total4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const int d4 = (int)(i & 7);
+    long long r = i >> 3;                    // index over (b, t, p, h) in token-major order
+    const int h = (int)(r % H); r /= H;
+    const int p = (int)(r % parts); r /= parts;
+    const int t = (int)(r % T);
+    const int b = (int)(r / T);
+    const long long tok = i * 4;                                                              // token-major offset
+    const long long hd = ((((long long)p * n + b) * H + h) * T + t) * 32 + d4 * 4;            // head-major offset
+    if (to_heads) *reinterpret_cast<float4*>(dst + hd) = *reinterpret_cast<const float4*>(src + tok);
+    else *reinterpret_cast<float4*>(dst + tok) = *reinterpret_cast<const float4*>(src + hd);
+  }
+}
+
 static inline int grid_for(long long n) {
   long long g = (n + 255) / 256;
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -546,15 +563,26 @@ extern "C" int ldmk_q_sample(const float* x0, const float* noise, const long lon
   return check_launch("ldmk_q_sample");
 }
 
-extern "C" int ldmk_mse_grad(const float* pred, const float* target, float* dpred, long long n, float* loss, double* scratch,
-                             void* stream) {
+extern "C" int ldmk_mse_grad(const float* pred, const float* target, float* dpred, long long n, long long denom, float* loss,
+                             double* scratch, void* stream) {
   LDMK_ENTER();
-  LDMK_REQUIRE(pred && target && dpred && loss && scratch && n > 0, "ldmk_mse_grad: bad args");
+  LDMK_REQUIRE(pred && target && dpred && loss && scratch && n > 0 && denom >= 0, "ldmk_mse_grad: bad args");
+  if (denom == 0) denom = n;                                 // channel-padded tensors: mean over the real elements only
   const int blocks = 256;                                    // scratch: 256 doubles
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(mse_grad_kernel, dim3(blocks), dim3(256), 0, st, pred, target, dpred, n, 2.0f / (float)n, scratch);
-  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, st, scratch, blocks, 1.0 / (double)n, loss);
+  hipLaunchKernelGGL(mse_grad_kernel, dim3(blocks), dim3(256), 0, st, pred, target, dpred, n, (float)(2.0 / (double)denom), scratch);
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, st, scratch, blocks, 1.0 / (double)denom, loss);
   return check_launch("ldmk_mse_grad");
+}
+
+extern "C" int ldmk_head_permute(const float* src, float* dst, int n, int tokens, int parts, int heads, int to_heads,
+                                 void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(src && dst && n > 0 && tokens > 0 && parts > 0 && heads > 0, "ldmk_head_permute: bad args");
+  const long long total4 = (long long)n * tokens * parts * heads * 8;
+  hipLaunchKernelGGL(head_permute_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, src, dst, n, tokens, parts,
+                     heads, to_heads, total4);
+  return check_launch("ldmk_head_permute");
 }
 
 extern "C" int ldmk_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,

@@ -1,0 +1,520 @@
+"""UNet training step on the HIP kernels (SURVEY §8f "next" row N1).
+
+Mirrors `LatentDiffusion.p_losses` (ddpm.py:1014-1047: q_sample -> apply_model -> l2 loss .mean()), the backward
+pass autograd would run through `UNetModel.forward` (openaimodel.py:710-742), `configure_optimizers` (AdamW,
+ddpm.py:1363-1385) and `LitEma` (ema.py:25-44).  fp32 throughout.
+
+Design: the forward walks the same module list as the sampling program (unet.py) but keeps what the backward needs
+(normalised GEMM inputs, pre-activations, statistics) and pushes one closure per layer on a tape; the backward pops
+them.  Parameters live in ONE flat fp32 buffer in the *packed* layouts the GEMMs read ([Cin/32][9][32][Cout] for 3x3
+convolutions, [in][out] for Linear), gradients in a second flat buffer of the same layout -- the optimizer and the
+data-parallel all-reduce see two contiguous arrays, and no repacking happens between steps.  Every launch goes to
+libldmk.so on the current stream, so a whole step can be captured in a hipGraph.
+
+Scope: single-token cross-attention context (both shipped configs: (B,1,512) FR, (B,1,1024) TF), dropout 0.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import lib as L
+from . import ops
+from . import train_ops as T
+from .engine import tuned_plan
+
+_SK_WS = {}
+
+
+def _splitk_ws(dev, elems=64 * 1024 * 1024):
+    ws = _SK_WS.get(dev)
+    if ws is None or ws.numel() < elems:
+        ws = torch.empty(elems, device=dev, dtype=torch.float32)
+        _SK_WS[dev] = ws
+    return ws
+
+
+def gemm(a, dev):
+    """ldmk_igemm with the tuned (tile, split-K) plan when the shape is in the table, a shared split-K scratch."""
+    ws = _splitk_ws(dev)
+    plan = tuned_plan(a, a.M) if a.batch <= 1 else None
+    if plan is not None and max(1, a.batch) * plan[1] * a.M * a.N <= ws.numel():
+        a.tile_cfg, a.splitk = plan
+    a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
+    ops.igemm(a)
+
+
+class FlatParams:
+    """name -> view into one flat parameter buffer (+ the matching gradient / AdamW-moment buffers)."""
+
+    def __init__(self):
+        self.specs, self.off = [], 0
+
+    def add(self, name, tensor):
+        n = tensor.numel()
+        pad = (-n) % 64                      # keep every view 256-B aligned
+        self.specs.append((name, tuple(tensor.shape), self.off, n, tensor))
+        self.off += n + pad
+
+    def finalize(self, dev):
+        self.flat = torch.zeros(self.off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(self.off, device=dev, dtype=torch.float32)
+        self.p, self.g = {}, {}
+        for name, shape, off, n, src in self.specs:
+            self.p[name] = self.flat[off:off + n].view(shape)
+            self.g[name] = self.grad[off:off + n].view(shape)
+            self.p[name].copy_(src)
+        self.specs = [(n_, s, o, k) for n_, s, o, k, _ in self.specs]
+        self.m = self.v = None
+        self.step = 0
+
+
+class UNetTrainer:
+    def __init__(self, unet):
+        if unet._packed is None:
+            unet.pack_weights()
+        if unet.context_dim is None:
+            raise NotImplementedError("UNetTrainer: spatial-transformer UNets with a context only")
+        self.unet = unet
+        self.dev = next(unet.parameters()).device
+        self.P = FlatParams()
+        self._collect()
+        self.P.finalize(self.dev)
+        self.freqs = unet._packed["freqs"]
+        self.tape = []
+        self.G = {}            # activation data_ptr -> (grad tensor)
+        self.ginit = set()
+
+    # ---- parameters -----------------------------------------------------------------------------------------
+    def _collect(self):
+        u, P, sd, add = self.unet, self.unet._packed, self.unet._sd, self.P.add
+        for k in ("te0", "te2", "emb_all", "emb_all_b"):
+            add(k, P[k])
+        for k in ("time_embed.0.bias", "time_embed.2.bias", "out.0.weight", "out.0.bias"):
+            add(k, sd[k])
+        cin = u.in_channels
+        assert cin <= 32 and u.out_channels <= 32
+        add("in.wpad", ops.pack_conv3x3(F.pad(sd["input_blocks.0.0.weight"], (0, 0, 0, 0, 0, 32 - cin)).contiguous()))
+        add("input_blocks.0.0.bias", sd["input_blocks.0.0.bias"])
+        add("out.wpad", ops.pack_conv3x3(F.pad(sd["out.2.weight"], (0, 0, 0, 0, 0, 0, 0, 32 - u.out_channels)).contiguous()))
+        add("out.bpad", F.pad(sd["out.2.bias"], (0, 32 - u.out_channels)))
+        for prefix, m in u._walk():
+            if m.kind == "res":
+                for k in ("c1", "c2"):
+                    add(prefix + k, P[prefix + k])
+                for k in ("in_layers.0.weight", "in_layers.0.bias", "in_layers.2.bias", "out_layers.0.weight",
+                          "out_layers.0.bias", "out_layers.3.bias"):
+                    add(prefix + k, sd[prefix + k])
+                if m.cin != m.cout:
+                    add(prefix + "skip", P[prefix + "skip"])
+                    add(prefix + "skip_connection.bias", sd[prefix + "skip_connection.bias"])
+            elif m.kind == "st":
+                for k in ("pin", "pout"):
+                    add(prefix + k, P[prefix + k])
+                for k in ("norm.weight", "norm.bias", "proj_in.bias", "proj_out.bias"):
+                    add(prefix + k, sd[prefix + k])
+                for d in range(m.depth):
+                    q = f"{prefix}transformer_blocks.{d}."
+                    for k in ("qkv", "o1", "v2", "o2", "ff2"):
+                        add(q + k, P[q + k])
+                    add(q + "ff1n", ops.pack_linear(sd[q + "ff.net.0.proj.weight"]))
+                    for k in ("norm1.weight", "norm1.bias", "norm3.weight", "norm3.bias", "attn1.to_out.0.bias",
+                              "attn2.to_out.0.bias", "ff.net.0.proj.bias", "ff.net.2.bias"):
+                        add(q + k, sd[q + k])
+            elif m.kind in ("down", "up"):
+                add(prefix + "w", P[prefix + "w"])
+                bk = "op.bias" if m.kind == "down" else "conv.bias"
+                add(prefix + bk, sd[prefix + bk])
+
+    # ---- gradient bookkeeping for activations -------------------------------------------------------------------
+    def _grad(self, t):
+        """(gradient buffer of activation t, already-written flag); marks it written."""
+        k = t.data_ptr()
+        g = self.G.get(k)
+        if g is None:
+            g = torch.empty_like(t)
+            self.G[k] = g
+        acc = k in self.ginit
+        self.ginit.add(k)
+        return g, acc
+
+    def _alias_grad(self, t, g):
+        self.G[t.data_ptr()] = g
+        self.ginit.add(t.data_ptr())
+
+    def _take(self, t):
+        g = self.G.get(t.data_ptr())
+        assert g is not None and t.data_ptr() in self.ginit, "gradient requested before any consumer wrote it"
+        return g
+
+    # ---- layer primitives (forward; each pushes its backward) -------------------------------------------------------
+    def _lin(self, x2d, wname, bname, rows_per_sample, residual=None, batch_vec=None, x1=None):
+        p = self.P.p
+        w = p[wname]
+        M, N = x2d.shape[0], w.shape[1]
+        out = torch.empty(M, N, device=self.dev)
+        c0 = x2d.shape[1]
+        c1 = 0 if x1 is None else x1.shape[1]
+        a = ops.make_igemm_args(M, N, c0 + c1, x2d, c0, w, out, N, rows_per_sample, a1=x1, c1=c1,
+                                bias=None if bname is None else p[bname], residual=residual,
+                                batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0))
+        gemm(a, self.dev)
+        return out
+
+    def _lin_bwd(self, dy, x2d, wname, bname, x1=None, need_dx=True):
+        """Parameter gradients of out = [x2d|x1] @ W + b and (optionally) the data gradient dy @ W^T."""
+        g, p = self.P.g, self.P.p
+        if bname is not None:
+            T.colsum(dy, out=g[bname].view(1, -1))
+        c0 = x2d.shape[1]
+        T.wgrad_linear(x2d, dy, dw=g[wname][:c0])
+        if x1 is not None:
+            T.wgrad_linear(x1, dy, dw=g[wname][c0:])
+        if not need_dx:
+            return None
+        return self._lin_dx(dy, p[wname][:c0] if x1 is not None else p[wname])
+
+    def _lin_dx(self, dy, w, out=None, residual=None):
+        """dy[M][N] @ w[K][N]^T -> [M][K] (b_trans igemm on the forward weights)."""
+        M, N = dy.shape
+        K = w.shape[0]
+        if out is None:
+            out = torch.empty(M, K, device=self.dev)
+        a = ops.make_igemm_args(M, K, N, dy, N, w, out, K, M, b_trans=True, ldb=w.stride(0), residual=residual)
+        gemm(a, self.dev)
+        return out
+
+    def _conv(self, x4, wname, bname, stride=1, upsample=False, batch_vec=None, residual=None):
+        p = self.P.p
+        n, h, w_, c = x4.shape
+        wp = p[wname]
+        cout = wp.shape[1]
+        oh, ow = (2 * h, 2 * w_) if upsample else ((h - 1) // stride + 1, (w_ - 1) // stride + 1)
+        out = torch.empty(n, oh, ow, cout, device=self.dev)
+        a = ops.make_igemm_args(n * oh * ow, cout, 9 * c, x4, c, wp, out, cout, oh * ow,
+                                conv=(h, w_, oh, ow, stride, 1, 1 if upsample else 0), bias=p[bname], residual=residual,
+                                batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0))
+        gemm(a, self.dev)
+        return out
+
+    def _conv_bwd(self, dy4, x4, wname, bname, stride=1, upsample=False, need_dx=True, dx_out=None, dx_acc=False):
+        g, p = self.P.g, self.P.p
+        n, oh, ow, cout = dy4.shape
+        _, h, w_, c = x4.shape
+        T.colsum(dy4.view(-1, cout), out=g[bname].view(1, -1))
+        T.wgrad_conv3x3(x4, dy4, stride=stride, upsample=upsample, dw=g[wname])
+        if not need_dx:
+            return None
+        wd = T.pack_dgrad3x3(p[wname], c, cout)
+        if upsample:
+            du = T.conv3x3_dgrad(dy4, wd, (2 * h, 2 * w_))
+            out = dx_out if dx_out is not None else torch.empty(n, h, w_, c, device=self.dev)
+            return T.sumpool2(du, out=out, accumulate=dx_acc)
+        if dx_out is None:
+            return T.conv3x3_dgrad(dy4, wd, (h, w_), stride=stride)
+        return T.conv3x3_dgrad(dy4, wd, (h, w_), stride=stride, out=dx_out, residual=dx_out if dx_acc else None)
+
+    def _gn(self, x0, x1, hw, gname, bname, eps, silu):
+        """GroupNorm(32)(+SiLU) of (the concat of) NHWC tensors, materialised; returns (y2d, saved)."""
+        p = self.P.p
+        n = x0.shape[0]
+        c0 = x0.shape[-1]
+        c1 = 0 if x1 is None else x1.shape[-1]
+        chunks = L.load().ldmk_gn_chunks(hw)
+        partial = torch.empty(n * chunks * (c0 + c1) * 3, device=self.dev)
+        coef = torch.empty(n, 2, c0 + c1, device=self.dev)
+        ops.gn_coef(x0, x1, n, hw, p[gname], p[bname], eps, partial=partial, coef=coef)
+        mr = T.gn_group_stats(partial, c0, partial[n * chunks * c0 * 3:] if c1 else None, c1, n, hw, 32, eps)
+        y = ops.gn_apply(x0, x1, coef, n, hw, silu=silu)
+        return y, (coef, mr)
+
+    def _gn_bwd(self, dy2d, x0, x1, hw, saved, gname, bname, silu):
+        coef, mr = saved
+        g, p = self.P.g, self.P.p
+        n = x0.shape[0]
+        dx0, a0 = self._grad(x0)
+        dx1, a1 = (None, False) if x1 is None else self._grad(x1)
+        T.gn_bwd(x0, x1, dy2d, coef, mr, p[gname], n, hw, silu=silu, dx0=dx0, acc0=a0, dx1=dx1, acc1=a1,
+                 dgamma=g[gname], dbeta=g[bname])
+
+    # ---- blocks -------------------------------------------------------------------------------------------
+    def _res_block(self, prefix, m, x0, x1, h, w, emb_all, d_emb_all, emb_off):
+        n, hw = x0.shape[0], h * w
+        y1, s1 = self._gn(x0, x1, hw, prefix + "in_layers.0.weight", prefix + "in_layers.0.bias", 1e-5, True)
+        y1 = y1.view(n, h, w, m.cin)
+        bv = emb_all[:, emb_off:emb_off + m.cout]
+        h1 = self._conv(y1, prefix + "c1", prefix + "in_layers.2.bias", batch_vec=bv)
+        y2, s2 = self._gn(h1, None, hw, prefix + "out_layers.0.weight", prefix + "out_layers.0.bias", 1e-5, True)
+        y2 = y2.view(n, h, w, m.cout)
+        if m.cin != m.cout:
+            x0r = x0.reshape(n * hw, -1)
+            x1r = None if x1 is None else x1.reshape(n * hw, -1)
+            skip = self._lin(x0r, prefix + "skip", prefix + "skip_connection.bias", hw, x1=x1r)
+            out = self._conv(y2, prefix + "c2", prefix + "out_layers.3.bias", residual=skip)
+        else:
+            assert x1 is None
+            out = self._conv(y2, prefix + "c2", prefix + "out_layers.3.bias", residual=x0)
+
+        def bwd():
+            dout = self._take(out)
+            dy2 = self._conv_bwd(dout, y2, prefix + "c2", prefix + "out_layers.3.bias")
+            dh1 = torch.empty_like(h1)
+            self.G[h1.data_ptr()] = dh1
+            self._gn_bwd(dy2.view(n * hw, -1), h1, None, hw, s2, prefix + "out_layers.0.weight", prefix + "out_layers.0.bias", True)
+            del dy2
+            T.colsum(dh1.view(n * hw, -1), rows_per_group=hw, out=d_emb_all[:, emb_off:emb_off + m.cout])
+            dy1 = self._conv_bwd(dh1, y1, prefix + "c1", prefix + "in_layers.2.bias")
+            self._gn_bwd(dy1.view(n * hw, -1), x0, x1, hw, s1, prefix + "in_layers.0.weight", prefix + "in_layers.0.bias", True)
+            dx0 = self._take(x0)
+            d2 = dout.view(n * hw, -1)
+            if m.cin != m.cout:
+                g, p = self.P.g, self.P.p
+                g[prefix + "skip_connection.bias"].copy_(g[prefix + "out_layers.3.bias"])   # same column sums of dout
+                c0 = x0.shape[-1]
+                T.wgrad_linear(x0.view(n * hw, -1), d2, dw=g[prefix + "skip"][:c0])
+                self._lin_dx(d2, p[prefix + "skip"][:c0], out=dx0.view(n * hw, -1), residual=dx0.view(n * hw, -1))
+                if x1 is not None:
+                    dx1 = self._take(x1)
+                    T.wgrad_linear(x1.view(n * hw, -1), d2, dw=g[prefix + "skip"][c0:])
+                    self._lin_dx(d2, p[prefix + "skip"][c0:], out=dx1.view(n * hw, -1), residual=dx1.view(n * hw, -1))
+            else:
+                T.axpy_(dx0, dout, 1.0)
+        self.tape.append(bwd)
+        return out
+
+    def _spatial_tf(self, prefix, m, x, h, w, ctx, dctx):
+        n, hw = x.shape[0], h * w
+        C_ = m.heads * m.d_head
+        rows = n * hw
+        xn, sx = self._gn(x, None, hw, prefix + "norm.weight", prefix + "norm.bias", 1e-6, False)
+        hcur = self._lin(xn, prefix + "pin", prefix + "proj_in.bias", hw)
+        h_first = hcur
+        blocks = []
+        for d in range(m.depth):
+            q = f"{prefix}transformer_blocks.{d}."
+            p = self.P.p
+            st1 = ops.ln_stats(hcur)
+            ln1 = T.ln_apply(hcur, st1, p[q + "norm1.weight"], p[q + "norm1.bias"])
+            qkv = self._lin(ln1, q + "qkv", None, hw)
+            att = ops.attn_self(qkv, n, hw, m.heads)
+            v = self._lin(ctx, q + "v2", None, 1)                                   # single context token (K11)
+            cvec = self._lin(v, q + "o2", q + "attn2.to_out.0.bias", 1)
+            h1 = self._lin(att, q + "o1", q + "attn1.to_out.0.bias", hw, residual=hcur, batch_vec=cvec)
+            st3 = ops.ln_stats(h1)
+            ln3 = T.ln_apply(h1, st3, p[q + "norm3.weight"], p[q + "norm3.bias"])
+            pre = self._lin(ln3, q + "ff1n", q + "ff.net.0.proj.bias", hw)
+            f = T.geglu_fwd(pre)
+            h2 = self._lin(f, q + "ff2", q + "ff.net.2.bias", hw, residual=h1)
+            blocks.append((q, hcur, st1, ln1, qkv, att, v, cvec, h1, st3, ln3, pre, f, h2))
+            hcur = h2
+        h_last = hcur
+        out = self._lin(h_last, prefix + "pout", prefix + "proj_out.bias", hw, residual=x.view(rows, m.ch)).view(n, h, w, m.ch)
+
+        def bwd():
+            g, p = self.P.g, self.P.p
+            dout = self._take(out).view(rows, m.ch)
+            dh = self._lin_bwd(dout, h_last, prefix + "pout", prefix + "proj_out.bias")
+            for (q, hin, st1, ln1, qkv, att, v, cvec, h1, st3, ln3, pre, f, h2) in reversed(blocks):
+                # ---- feed-forward: h2 = h1 + ff2(geglu(ff1(LN3(h1))))
+                df = self._lin_bwd(dh, f, q + "ff2", q + "ff.net.2.bias")
+                dpre = T.geglu_bwd(pre, df)
+                del df
+                dln3 = self._lin_bwd(dpre, ln3, q + "ff1n", q + "ff.net.0.proj.bias")
+                del dpre
+                T.ln_bwd(dln3, h1, st3, p[q + "norm3.weight"], dx=dh, acc_dx=True, dgamma=g[q + "norm3.weight"],
+                         dbeta=g[q + "norm3.bias"])                                # dh is now d(h1)
+                del dln3
+                # ---- attention: h1 = hin + to_out(attn(LN1(hin))) + cvec[sample]
+                dcvec = T.colsum(dh, rows_per_group=hw)
+                datt = self._lin_bwd(dh, att, q + "o1", q + "attn1.to_out.0.bias")
+                dv = self._lin_bwd(dcvec, v, q + "o2", q + "attn2.to_out.0.bias")
+                T.wgrad_linear(ctx, dv, dw=g[q + "v2"])
+                first = not self._dctx_init
+                self._lin_dx(dv, p[q + "v2"], out=dctx, residual=None if first else dctx)
+                self._dctx_init = True
+                dqkv = T.attention_backward(qkv, datt, n, hw, m.heads)
+                del datt
+                dln1 = self._lin_bwd(dqkv, ln1, q + "qkv", None)
+                del dqkv
+                T.ln_bwd(dln1, hin, st1, p[q + "norm1.weight"], dx=dh, acc_dx=True, dgamma=g[q + "norm1.weight"],
+                         dbeta=g[q + "norm1.bias"])                                # dh is now d(hin)
+                del dln1
+            dxn = self._lin_bwd(dh, xn, prefix + "pin", prefix + "proj_in.bias")
+            self._gn_bwd(dxn, x, None, hw, sx, prefix + "norm.weight", prefix + "norm.bias", False)
+            T.axpy_(self._take(x), dout.view_as(x), 1.0)
+        self.tape.append(bwd)
+        return out
+
+    def _down(self, prefix, x, h, w):
+        out = self._conv(x, prefix + "w", prefix + "op.bias", stride=2)
+
+        def bwd():
+            dx, acc = self._grad(x)
+            self._conv_bwd(self._take(out), x, prefix + "w", prefix + "op.bias", stride=2, dx_out=dx, dx_acc=acc)
+        self.tape.append(bwd)
+        return out
+
+    def _up(self, prefix, x, h, w):
+        out = self._conv(x, prefix + "w", prefix + "conv.bias", upsample=True)
+
+        def bwd():
+            dx, acc = self._grad(x)
+            self._conv_bwd(self._take(out), x, prefix + "w", prefix + "conv.bias", upsample=True, dx_out=dx, dx_acc=acc)
+        self.tape.append(bwd)
+        return out
+
+    # ---- whole network -------------------------------------------------------------------------------------
+    def forward(self, x, timesteps, context):
+        """x (n,C_in,H,W) fp32 NCHW (already concatenated with any c_concat), timesteps (n,) int64, context (n,1,ctx_dim).
+        Returns eps (n,C_out,H,W); records the tape for backward()."""
+        u, p, dev = self.unet, self.P.p, self.dev
+        if not x.is_cuda:
+            raise L.LdmkError("UNetTrainer.forward: CUDA tensors only (no CPU fallback)")
+        if context is None or context.shape[1] != 1:
+            raise NotImplementedError("UNetTrainer: single-token context only")
+        n, cin, H, W_ = x.shape
+        self.tape, self.G, self.ginit = [], {}, set()
+        self._dctx_init = False
+        mc = u.model_channels
+        ctx = context.reshape(n, u.context_dim).contiguous().float()
+        self.dctx = torch.zeros_like(ctx)
+        xp = torch.zeros(n, H, W_, 32, device=dev)
+        xp[..., :cin] = x.permute(0, 2, 3, 1)
+        # ---- timestep embedding MLP and every ResBlock's emb_layers in one GEMM (K1)
+        temb = ops.timestep_embedding(timesteps.to(torch.int64), self.freqs, mc)
+        e1 = self._lin(temb, "te0", "time_embed.0.bias", 1)
+        s1 = T.silu(e1)
+        emb = self._lin(s1, "te2", "time_embed.2.bias", 1)
+        s2 = T.silu(emb)
+        emb_all = self._lin(s2, "emb_all", "emb_all_b", 1)
+        d_emb_all = torch.zeros_like(emb_all)
+
+        def bwd_emb():
+            ds2 = self._lin_bwd(d_emb_all, s2, "emb_all", "emb_all_b")
+            demb = T.silu_bwd(emb, ds2)
+            ds1 = self._lin_bwd(demb, s1, "te2", "time_embed.2.bias")
+            de1 = T.silu_bwd(e1, ds1)
+            self._lin_bwd(de1, temb, "te0", "time_embed.0.bias", need_dx=False)
+        self.tape.append(bwd_emb)
+
+        h0 = self._conv(xp, "in.wpad", "input_blocks.0.0.bias")
+
+        def bwd_in():
+            self._conv_bwd(self._take(h0), xp, "in.wpad", "input_blocks.0.0.bias", need_dx=False)
+        self.tape.append(bwd_in)
+
+        def run_layers(prefix, layers, x0, x1, h, w):
+            cur0, cur1 = x0, x1
+            for j, m in enumerate(layers):
+                pf = f"{prefix}{j}."
+                if m.kind == "res":
+                    cur0 = self._res_block(pf, m, cur0, cur1, h, w, emb_all, d_emb_all, u._emb_off[pf])
+                elif m.kind == "st":
+                    cur0 = self._spatial_tf(pf, m, cur0, h, w, ctx, self.dctx)
+                elif m.kind == "down":
+                    cur0 = self._down(pf, cur0, h, w)
+                    h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+                elif m.kind == "up":
+                    cur0 = self._up(pf, cur0, h, w)
+                    h, w = 2 * h, 2 * w
+                else:
+                    raise AssertionError(m.kind)
+                cur1 = None
+            return cur0, h, w
+
+        hs = [(h0, H, W_)]
+        hcur, ch_, cw_ = h0, H, W_
+        for i in range(1, len(u.input_blocks)):
+            hcur, ch_, cw_ = run_layers(f"input_blocks.{i}.", u.input_blocks[i].layers, hcur, None, ch_, cw_)
+            hs.append((hcur, ch_, cw_))
+        hcur, ch_, cw_ = run_layers("middle_block.", u.middle_block.layers, hcur, None, ch_, cw_)
+        for i, blk in enumerate(u.output_blocks):
+            skip, sh, sw = hs.pop()
+            assert (sh, sw) == (ch_, cw_)
+            hcur, ch_, cw_ = run_layers(f"output_blocks.{i}.", blk.layers, hcur, skip, ch_, cw_)
+        hw = ch_ * cw_
+        yo, so = self._gn(hcur, None, hw, "out.0.weight", "out.0.bias", 1e-5, True)
+        yo = yo.view(n, ch_, cw_, -1)
+        eps_pad = self._conv(yo, "out.wpad", "out.bpad")
+        h_final = hcur
+
+        def bwd_out():
+            dyo = self._conv_bwd(self._take(eps_pad), yo, "out.wpad", "out.bpad")
+            self._gn_bwd(dyo.view(n * hw, -1), h_final, None, hw, so, "out.0.weight", "out.0.bias", True)
+        self.tape.append(bwd_out)
+        self.eps_pad = eps_pad
+        return eps_pad[..., :u.out_channels].permute(0, 3, 1, 2).contiguous()
+
+    def backward(self, deps_pad):
+        """deps_pad: gradient w.r.t. the channel-padded NHWC output (n,H,W,32).  Fills P.grad and self.dctx."""
+        self._alias_grad(self.eps_pad, deps_pad)
+        for fn in reversed(self.tape):
+            fn()
+        self.tape, self.G, self.ginit = [], {}, set()
+
+    # ---- p_losses / optimizer -------------------------------------------------------------------------------
+    def p_losses(self, x_start, context, t, noise, sqrt_ac, sqrt_1mac):
+        """ddpm.py:1014-1047 with parameterization 'eps', loss_type 'l2', l_simple_weight 1, no learned logvar,
+        original_elbo_weight 0: loss = mean((eps_theta(q_sample(x0,t,noise), t, c) - noise)^2).  Returns the loss
+        (device scalar) after running forward + backward; gradients are in self.P.grad."""
+        x_noisy = T.q_sample(x_start.contiguous(), noise.contiguous(), t, sqrt_ac, sqrt_1mac)
+        self.forward(x_noisy, t, context)
+        n, co, H, W_ = noise.shape
+        tgt = torch.zeros_like(self.eps_pad)
+        tgt[..., :co] = noise.permute(0, 2, 3, 1)
+        loss, deps = T.mse_grad(self.eps_pad, tgt, denom=noise.numel())
+        self.backward(deps)
+        return loss
+
+    def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        P = self.P
+        if P.m is None:
+            P.m, P.v = torch.zeros_like(P.flat), torch.zeros_like(P.flat)
+        P.step += 1
+        T.adamw_(P.flat, P.grad, P.m, P.v, lr, betas, eps, weight_decay, P.step)
+
+    def ema_update(self, shadow_flat, decay):
+        T.ema_(shadow_flat, self.P.flat, 1.0 - decay)
+
+    def all_reduce_grads(self, world_size):
+        """Data-parallel gradient averaging: one RCCL all-reduce over the flat gradient buffer (main.py:532 DDP)."""
+        import torch.distributed as dist
+        dist.all_reduce(self.P.grad)
+        self.P.grad.mul_(1.0 / world_size)
+
+
+def reference_grad_layout(unet, name, grads):
+    """The gradient `name` of the flat packed layout, computed from reference-layout gradients `grads`
+    (state-dict key -> tensor, e.g. from autograd on the oracle): what tests compare the HIP gradients against."""
+    dev = next(iter(grads.values())).device
+    cat = torch.cat
+    if name in ("te0", "te2"):
+        return grads[f"time_embed.{name[2]}.weight"].t()
+    if name == "emb_all":
+        return cat([grads[p + "emb_layers.1.weight"] for p, m in unet._walk() if m.kind == "res"], 0).t()
+    if name == "emb_all_b":
+        return cat([grads[p + "emb_layers.1.bias"] for p, m in unet._walk() if m.kind == "res"], 0)
+    if name == "in.wpad":
+        return ops.pack_conv3x3(F.pad(grads["input_blocks.0.0.weight"], (0, 0, 0, 0, 0, 32 - unet.in_channels)).contiguous())
+    if name == "out.wpad":
+        return ops.pack_conv3x3(F.pad(grads["out.2.weight"], (0, 0, 0, 0, 0, 0, 0, 32 - unet.out_channels)).contiguous())
+    if name == "out.bpad":
+        return F.pad(grads["out.2.bias"], (0, 32 - unet.out_channels))
+    for suf, key in (("c1", "in_layers.2.weight"), ("c2", "out_layers.3.weight")):
+        if name.endswith("." + suf):
+            return ops.pack_conv3x3(grads[name[:-len(suf)] + key].contiguous())
+    if name.endswith(".w"):
+        base = name[:-1]
+        key = base + ("op.weight" if base + "op.weight" in grads else "conv.weight")
+        return ops.pack_conv3x3(grads[key].contiguous())
+    lin = {"skip": "skip_connection.weight", "pin": "proj_in.weight", "pout": "proj_out.weight", "o1": "attn1.to_out.0.weight",
+           "v2": "attn2.to_v.weight", "o2": "attn2.to_out.0.weight", "ff2": "ff.net.2.weight", "ff1n": "ff.net.0.proj.weight"}
+    for suf, key in lin.items():
+        if name.endswith("." + suf):
+            wgt = grads[name[:-len(suf)] + key]
+            return wgt.reshape(wgt.shape[0], -1).t()
+    if name.endswith(".qkv"):
+        b = name[:-3]
+        return cat([grads[b + f"attn1.to_{c}.weight"] for c in "qkv"], 0).t()
+    return grads[name]

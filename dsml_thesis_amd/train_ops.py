@@ -204,11 +204,11 @@ def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac, out=None):
     return out
 
 
-def mse_grad(pred, target, dpred=None, loss=None):
+def mse_grad(pred, target, dpred=None, loss=None, denom=0):
     dpred = torch.empty_like(pred) if dpred is None else dpred
     loss = _f32(1, device=pred.device) if loss is None else loss
     scratch = torch.empty(256, device=pred.device, dtype=torch.float64)
-    L.call("ldmk_mse_grad", _ptr(pred), _ptr(target), _ptr(dpred), pred.numel(), _ptr(loss), _ptr(scratch), stream())
+    L.call("ldmk_mse_grad", _ptr(pred), _ptr(target), _ptr(dpred), pred.numel(), denom, _ptr(loss), _ptr(scratch), stream())
     return loss, dpred
 
 
@@ -218,3 +218,36 @@ def adamw_(p, g, m, v, lr, betas, eps, weight_decay, step):
 
 def ema_(shadow, p, one_minus_decay):
     L.call("ldmk_ema", _ptr(shadow), _ptr(p), p.numel(), one_minus_decay, stream())
+
+
+def head_permute(src, n, tokens, parts, heads, to_heads, out=None):
+    out = torch.empty_like(src) if out is None else out
+    L.call("ldmk_head_permute", _ptr(src), _ptr(out), n, tokens, parts, heads, 1 if to_heads else 0, stream())
+    return out
+
+
+def attention_backward(qkv, datt, n, tokens, heads):
+    """Gradient of ldmk_attn_self w.r.t. the fused qkv rows: scores re-materialised per head ([n*heads][T][T]) and the
+    five products run as batched GEMMs on the matrix cores (attention.py:178-192 backward)."""
+    Z, T_, scale = n * heads, tokens, 32 ** -0.5
+    dev = qkv.device
+    h = head_permute(qkv, n, T_, 3, heads, True).view(3, Z, T_, 32)
+    q, k, v = h[0], h[1], h[2]
+    do = head_permute(datt, n, T_, 1, heads, True).view(Z, T_, 32)
+    p = ops.bmm(q, k, True, alpha=scale)                               # [Z][T][T]
+    ops.softmax_rows_(p.view(Z * T_, T_), 1.0)
+    dh = torch.empty(3, Z, T_, 32, device=dev)
+    _wgrad_batched(p, do, dh[2], Z, T_, T_, 32)                         # dV = P^T dO
+    dp = ops.bmm(do, v, True)                                          # dP = dO V^T
+    softmax_bwd_rows_(p.view(Z * T_, T_), dp.view(Z * T_, T_), scale)   # dS (scaled)
+    ops.bmm(dp, k, False, out=dh[0])                                   # dQ = dS K
+    _wgrad_batched(dp, q, dh[1], Z, T_, T_, 32)                         # dK = dS^T Q
+    return head_permute(dh, n, T_, 3, heads, False).view(n * T_, 3 * heads * 32)
+
+
+def _wgrad_batched(a, dy, out, Z, R, Kw, N):
+    w = wgrad_args(R, Kw, N, a, dy, out, batch=Z, a_bstride=R * Kw, dy_bstride=R * N, dw_bstride=Kw * N)
+    sr, need = wgrad_workspace_elems(w)
+    ws = _f32(max(need, 1), device=a.device)
+    w.splitr, w.ws, w.ws_elems = sr, ws.data_ptr(), ws.numel()
+    wgrad(w)

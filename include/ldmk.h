@@ -280,8 +280,12 @@ int ldmk_axpy(float* y, const float* x, float a, long long n, void* stream);
 int ldmk_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ac, const float* sqrt_1mac,
                   float* xt, int n, int per, void* stream);
 /* loss = mean((pred-target)^2), dpred = 2*(pred-target)/n (ddpm.py:324-334 'l2', :1034); scratch = 256 doubles */
-int ldmk_mse_grad(const float* pred, const float* target, float* dpred, long long n, float* loss, double* scratch,
-                  void* stream);
+int ldmk_mse_grad(const float* pred, const float* target, float* dpred, long long n, long long denom, float* loss,
+                  double* scratch, void* stream);   /* denom: divisor of the mean (0 -> n); channel-padded tensors pass
+                                                       the real element count */
+/* d_head = 32 layouts: token-major [n][tokens][parts][heads][32] (the fused qkv / attention output rows) <->
+ * head-major [parts][n*heads][tokens][32] (contiguous per-head matrices for the batched backward GEMMs) */
+int ldmk_head_permute(const float* src, float* dst, int n, int tokens, int parts, int heads, int to_heads, void* stream);
 /* torch.optim.AdamW step over a flat buffer (step >= 1); LitEma update shadow -= omd * (shadow - p) */
 int ldmk_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                float weight_decay, int step, void* stream);

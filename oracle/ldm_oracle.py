@@ -126,7 +126,8 @@ def timestep_embedding(t, dim, max_period=10000):
 
 def gn_silu(x, w, b, eps=1e-5, silu=True, groups=32):
     """GroupNorm32 + SiLU: util.py:199-216, openaimodel.py:201-203."""
-    y = F.group_norm(x.float(), groups, w, b, eps)
+    xf = x if x.dtype == torch.float64 else x.float()   # GroupNorm32 computes in float32; float64 = gradient tests
+    y = F.group_norm(xf, groups, w, b, eps)
     return F.silu(y) if silu else y
 
 
@@ -212,11 +213,12 @@ def _run_layers(sd, cfg, prefix, layers, h, emb, context):
 def unet_forward(sd, cfg, x, timesteps, context=None):
     """UNetModel.forward, openaimodel.py:710-742."""
     lay = unet_layout(cfg)
-    t_emb = timestep_embedding(timesteps, cfg["model_channels"])
+    wdt = sd["time_embed.0.weight"].dtype      # float32 (the reference's self.dtype); float64 only in gradient tests
+    t_emb = timestep_embedding(timesteps, cfg["model_channels"]).to(wdt)
     emb = F.linear(t_emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
     emb = F.linear(F.silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
     hs = []
-    h = x.float()
+    h = x.to(wdt)                              # h = x.type(self.dtype), openaimodel.py:728
     for i, layers in enumerate(lay["input"]):
         h = _run_layers(sd, cfg, f"input_blocks.{i}.", layers, h, emb, context)
         hs.append(h)

@@ -213,3 +213,22 @@ def test_q_sample_mse_adamw_ema():
     ref = sh.cpu() - 0.01 * (sh.cpu() - p.detach())
     T.ema_(sh, pd, 0.01)
     _close(sh, ref, 2e-6, "ema")
+
+
+@pytest.mark.parametrize("n,tokens,heads", [(2, 64, 5), (1, 256, 2), (2, 100, 1)])
+def test_attention_backward(n, tokens, heads):
+    """d(qkv) of softmax(QK^T/sqrt(32))V against autograd; ragged token counts included."""
+    from dsml_thesis_amd import ops, train_ops as T
+    C_ = heads * 32
+    qkv = _rand(n * tokens, 3 * C_, seed=50).double().requires_grad_(True)
+    q, k, v = qkv.view(n, tokens, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    p = torch.softmax(q @ k.transpose(-1, -2) * 32 ** -0.5, -1)
+    att = (p @ v).permute(0, 2, 1, 3).reshape(n * tokens, C_)
+    datt = _rand(n * tokens, C_, seed=51)
+    att.backward(datt.double())
+    qd = qkv.detach().float().to(_dev())
+    _close(ops.attn_self(qd, n, tokens, heads), att.detach(), 2e-5, "attention forward")
+    if tokens % 32:
+        pytest.skip("materialised backward needs tokens % 32 == 0 (UNet token counts are 64..4096)")
+    dqkv = T.attention_backward(qd, datt.to(_dev()), n, tokens, heads)
+    _close(dqkv, qkv.grad, 3e-5, "attention backward")

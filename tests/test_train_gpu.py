@@ -1,0 +1,112 @@
+"""GPU: the UNet training step -- forward, loss and every parameter gradient of
+`p_losses` against PyTorch autograd run on the oracle (CPU, float64 weights of the same recipe)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rnd
+from oracle import ldm_oracle as O
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(W.FR_UNET, model_channels=64, channel_mult=[1, 2], num_res_blocks=1, attention_resolutions=[2, 1])
+
+
+def _setup(cfg, n, hw, seed=0, gain=1.0):
+    from dsml_thesis_amd.unet import UNetModel
+    from dsml_thesis_amd.train import UNetTrainer
+    m = UNetModel(**cfg)
+    sd = W.synth_state_dict(W.unet_param_shapes(cfg), gain=gain)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    tr = UNetTrainer(m)
+    x0 = rnd(seed + 1, n, cfg["in_channels"], hw, hw)
+    noise = rnd(seed + 2, n, cfg["out_channels"], hw, hw)
+    ctx = rnd(seed + 3, n, 1, cfg["context_dim"])
+    t = torch.tensor([17, 803, 400, 999][:n])
+    return m, tr, sd, x0, noise, ctx, t
+
+
+def _oracle_grads(cfg, sd, x0, noise, ctx, t, dtype=torch.float64):
+    sched = O.register_schedule(**W.SCHEDULE)
+    return _oracle_grads_inner(cfg, sd, x0, noise, ctx, t, dtype, sched)
+
+
+def _oracle_grads_inner(cfg, sd, x0, noise, ctx, t, dtype, sched):
+    sdg = {k: v.to(dtype).requires_grad_(True) for k, v in sd.items()}
+    ctxg = ctx.to(dtype).requires_grad_(True)
+    a = sched["sqrt_alphas_cumprod"][t].view(-1, 1, 1, 1)
+    b = sched["sqrt_one_minus_alphas_cumprod"][t].view(-1, 1, 1, 1)
+    x_noisy = (a * x0 + b * noise).to(dtype)          # q_sample in fp32 (ddpm.py:1009-1012), then promoted
+    eps = O.unet_forward(sdg, cfg, x_noisy, t, ctxg)
+    loss = F.mse_loss(eps, noise.to(dtype))           # get_loss 'l2' + mean (ddpm.py:324-334, 1034)
+    loss.backward()
+    return loss.detach(), eps.detach(), {k: v.grad for k, v in sdg.items()}, ctxg.grad, sched
+
+
+def _check_all_grads(m, tr, grads, rtol):
+    from dsml_thesis_amd.train import reference_grad_layout
+    gdev = {k: (torch.zeros_like(sd_v, dtype=torch.float32) if v is None else v.float()).cuda()
+            for (k, v), sd_v in zip(grads.items(), grads.values())}
+    worst = (0.0, "")
+    for name, g in tr.P.g.items():
+        ref = reference_grad_layout(m, name, gdev).double().cpu()
+        got = g.double().cpu()
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        scale = max(ref.abs().max().item(), 1e-12)
+        err = (got - ref).abs().max().item() / scale
+        if err > worst[0]:
+            worst = (err, name)
+        assert err <= rtol, f"gradient {name}: relative max error {err:.3e} > {rtol}"
+    return worst
+
+
+def test_small_unet_p_losses_gradients():
+    m, tr, sd, x0, noise, ctx, t = _setup(SMALL, 2, 16)
+    loss_ref, eps_ref, grads, dctx_ref, sched = _oracle_grads(SMALL, sd, x0, noise, ctx, t)
+    loss = tr.p_losses(x0.cuda(), ctx.cuda(), t.cuda(), noise.cuda(), sched["sqrt_alphas_cumprod"].cuda(),
+                       sched["sqrt_one_minus_alphas_cumprod"].cuda())
+    assert abs(loss.item() - loss_ref.item()) <= 2e-5 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    # to_q / to_k / norm2 of the single-token cross-attention receive exactly zero gradient in the reference too
+    for k, v in grads.items():
+        if any(s in k for s in ("attn2.to_q", "attn2.to_k", "norm2.")):
+            assert v is None or v.abs().max().item() == 0.0, k
+    worst = _check_all_grads(m, tr, grads, 1e-4)      # fp32 kernels vs float64 autograd (measured 1.7e-5)
+    print("worst gradient error", worst)
+    err = (tr.dctx.double().cpu() - dctx_ref.view_as(tr.dctx.cpu())).abs().max().item() / dctx_ref.abs().max().item()
+    assert err <= 2e-4, f"context gradient {err:.3e}"
+
+
+def test_training_forward_matches_sampling_forward():
+    """The training forward (materialised norms, padded boundary convolutions) and the sampling program compute the
+    same function."""
+    m, tr, sd, x0, noise, ctx, t = _setup(SMALL, 2, 16)
+    eps_t = tr.forward(x0.cuda(), t.cuda(), ctx.cuda())
+    eps_s = m(x0.cuda(), t.cuda(), context=ctx.cuda())
+    torch.testing.assert_close(eps_t, eps_s, rtol=2e-4, atol=2e-5)
+
+
+def test_full_fr_unet_gradients_and_adamw_step():
+    """Shipped FR UNet (156.8 M parameters) at 32x32, batch 1: gradients vs autograd, then one AdamW step vs
+    torch.optim.AdamW on the same gradients."""
+    cfg = W.FR_UNET
+    m, tr, sd, x0, noise, ctx, t = _setup(cfg, 1, 32)
+    loss_ref, _, grads, _, sched = _oracle_grads(cfg, sd, x0, noise, ctx, t, dtype=torch.float32)
+    loss = tr.p_losses(x0.cuda(), ctx.cuda(), t.cuda(), noise.cuda(), sched["sqrt_alphas_cumprod"].cuda(),
+                       sched["sqrt_one_minus_alphas_cumprod"].cuda())
+    assert abs(loss.item() - loss_ref.item()) <= 5e-5 * abs(loss_ref.item())
+    worst = _check_all_grads(m, tr, grads, 1e-4)      # both sides fp32 here, 60 layers (measured 1.9e-6)
+    print("worst gradient error", worst)
+    before = tr.P.flat.clone()
+    g = tr.P.grad.clone()
+    tr.adamw_step(lr=2e-6)        # Adam's first step moves every weight by ~lr: keep it inside the linear regime
+    p = torch.nn.Parameter(before.clone())
+    opt = torch.optim.AdamW([p], lr=2e-6)
+    p.grad = g
+    opt.step()
+    torch.testing.assert_close(tr.P.flat, p.detach(), rtol=1e-6, atol=1e-7)
+    loss2 = tr.p_losses(x0.cuda(), ctx.cuda(), t.cuda(), noise.cuda(), sched["sqrt_alphas_cumprod"].cuda(),
+                        sched["sqrt_one_minus_alphas_cumprod"].cuda())
+    assert loss2.item() < loss.item(), "one AdamW step on the same batch must lower the loss"
