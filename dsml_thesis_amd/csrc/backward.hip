@@ -159,54 +159,83 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__
   }
 }
 
-// one wave per row (looping over a strip of rows); per-workgroup column partials of dgamma / dbeta
+// LayerNorm backward.  One half-wave per row (32 lanes x float4 = 512 B per load instruction, C <= 1024, C % 4 == 0),
+// a strip of LN_ROWS_PER_BLOCK rows per workgroup; per-workgroup column partials of dgamma / dbeta.
 constexpr int LN_ROWS_PER_BLOCK = 64;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      float* __restrict__ dx, int accumulate, int rows, int C,
                                                      float* __restrict__ partial) {
   __shared__ float red[4][1024 * 2];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
   const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK, r1 = min(rows, r0 + LN_ROWS_PER_BLOCK);
-  float dg[16], db[16];       // lane owns columns lane + 64*i, C <= 1024
+  const int c4n = C >> 2;
+  float4 dg[8], db[8], gam[8];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { dg[i] = 0.f; db[i] = 0.f; }
-  for (int row = r0 + wave; row < r1; row += 4) {
+  for (int i = 0; i < 8; ++i) {
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[i] = dg[i];
+    const int c4 = l31 + 32 * i;
+    gam[i] = c4 < c4n ? reinterpret_cast<const float4*>(gamma)[c4] : dg[i];
+  }
+  const float invC = 1.0f / (float)C;
+  for (int row = r0 + wave * 2 + half; row < r1; row += 8) {
     const float mu = stats[2 * (long long)row], rs = stats[2 * (long long)row + 1];
-    const float* xr = x + (long long)row * C;
-    const float* dyr = dy + (long long)row * C;
-    float xh[16], gv[16];
+    const float4* xr = reinterpret_cast<const float4*>(x + (long long)row * C);
+    const float4* dyr = reinterpret_cast<const float4*>(dy + (long long)row * C);
+    float4 xh[8], gv[8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = lane + 64 * i;
-      xh[i] = 0.f; gv[i] = 0.f;
-      if (c < C) {
-        const float d = dyr[c];
-        xh[i] = (xr[c] - mu) * rs;
-        gv[i] = d * gamma[c];
-        dg[i] = fmaf(d, xh[i], dg[i]);
-        db[i] += d;
-        s1 += gv[i];
-        s2 = fmaf(gv[i], xh[i], s2);
+    for (int i = 0; i < 8; ++i) {
+      const int c4 = l31 + 32 * i;
+      xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      gv[i] = xh[i];
+      if (c4 < c4n) {
+        const float4 d = dyr[c4], xv = xr[c4];
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        gv[i] = make_float4(d.x * gam[i].x, d.y * gam[i].y, d.z * gam[i].z, d.w * gam[i].w);
+        dg[i].x = fmaf(d.x, xh[i].x, dg[i].x); dg[i].y = fmaf(d.y, xh[i].y, dg[i].y);
+        dg[i].z = fmaf(d.z, xh[i].z, dg[i].z); dg[i].w = fmaf(d.w, xh[i].w, dg[i].w);
+        db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+        s1 += (gv[i].x + gv[i].y) + (gv[i].z + gv[i].w);
+        s2 = fmaf(gv[i].x, xh[i].x, s2); s2 = fmaf(gv[i].y, xh[i].y, s2);
+        s2 = fmaf(gv[i].z, xh[i].z, s2); s2 = fmaf(gv[i].w, xh[i].w, s2);
       }
     }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
-    float* dxr = dx + (long long)row * C;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = lane + 64 * i;
-      if (c < C) {
-        const float v = rs * (gv[i] - s1 - xh[i] * s2);
-        dxr[c] = accumulate ? dxr[c] + v : v;
+    for (int o = 16; o > 0; o >>= 1) {        // stays inside the 32-lane half
+      s1 += __shfl_xor(s1, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    s1 *= invC;
+    s2 *= invC;
+    float4* dxr = reinterpret_cast<float4*>(dx + (long long)row * C);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c4 = l31 + 32 * i;
+      if (c4 < c4n) {
+        float4 v = make_float4(rs * (gv[i].x - s1 - xh[i].x * s2), rs * (gv[i].y - s1 - xh[i].y * s2),
+                               rs * (gv[i].z - s1 - xh[i].z * s2), rs * (gv[i].w - s1 - xh[i].w * s2));
+        if (accumulate) {
+          const float4 o = dxr[c4];
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        dxr[c4] = v;
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = lane + 64 * i;
-    if (c < C) { red[wave][2 * c] = dg[i]; red[wave][2 * c + 1] = db[i]; }
+  for (int i = 0; i < 8; ++i) {               // fold the two half-waves, then the four waves through LDS
+    dg[i].x += __shfl_xor(dg[i].x, 32, 64); dg[i].y += __shfl_xor(dg[i].y, 32, 64);
+    dg[i].z += __shfl_xor(dg[i].z, 32, 64); dg[i].w += __shfl_xor(dg[i].w, 32, 64);
+    db[i].x += __shfl_xor(db[i].x, 32, 64); db[i].y += __shfl_xor(db[i].y, 32, 64);
+    db[i].z += __shfl_xor(db[i].z, 32, 64); db[i].w += __shfl_xor(db[i].w, 32, 64);
+    const int c4 = l31 + 32 * i;
+    if (half == 0 && c4 < c4n) {
+      float* d = &red[wave][8 * c4];
+      d[0] = dg[i].x; d[1] = db[i].x; d[2] = dg[i].y; d[3] = db[i].y;
+      d[4] = dg[i].z; d[5] = db[i].z; d[6] = dg[i].w; d[7] = db[i].w;
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -478,7 +507,7 @@ extern "C" int ldmk_ln_bwd(const float* dy, const float* x, const float* stats, 
                            int rows, int c, float* dgamma, float* dbeta, int acc_params, float* scratch, void* stream) {
   LDMK_ENTER();
   LDMK_REQUIRE(dy && x && stats && gamma && dx && dgamma && dbeta && scratch, "ldmk_ln_bwd: null buffer");
-  LDMK_REQUIRE(rows > 0 && c > 0 && c <= 1024, "ldmk_ln_bwd: bad shape (C<=1024)");
+  LDMK_REQUIRE(rows > 0 && c > 0 && c <= 1024 && c % 4 == 0, "ldmk_ln_bwd: bad shape (C<=1024, C%%4==0)");
   const int blocks = ldmk_ln_bwd_blocks(rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, x, stats, gamma, dx, acc_dx, rows, c, scratch);

@@ -109,12 +109,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ldmk_wgrad_args p, con
 
   const float* Aw = As + half * ASTR + wm * (32 * TM) + l31;
   const float* Bw = Bs + half * BSTR + wn * (32 * TN) + l31;
+  // bias gradient = column sums of dY: the workgroups of the first row tile add up the dY slices they stage anyway
+  const bool do_bias = p.dbias != nullptr && m0 == 0 && tid < BN;
+  float bsum = 0.f;
   if (it_begin < it_end) load_slice(it_begin);
   for (int it = it_begin; it < it_end; ++it) {
     __syncthreads();
     store_slice();
     __syncthreads();
     if (it + 1 < it_end) load_slice(it + 1);
+    if (do_bias) {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) bsum += Bs[r * BSTR + tid];
+    }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       float a[TM], b[TN];
@@ -133,8 +140,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ldmk_wgrad_args p, con
   const int rowbase = m0 + wm * (32 * TM), colbase = n0 + wn * (32 * TN);
   float* dst;
   long long ld;
+  const int srows = p.Kw + (p.dbias ? 1 : 0);      // slab rows: dW plus one row of bias partial sums
+  if (do_bias && n0 + tid < p.N) {
+    if (splitr > 1) ws[(((long long)bz * splitr + ks) * srows + p.Kw) * p.N + n0 + tid] = bsum;
+    else p.dbias[n0 + tid] = p.accumulate ? p.dbias[n0 + tid] + p.alpha * bsum : p.alpha * bsum;
+  }
   if (splitr > 1) {
-    dst = ws + ((long long)bz * splitr + ks) * p.Kw * p.N;
+    dst = ws + ((long long)bz * splitr + ks) * srows * p.N;
     ld = p.N;
   } else {
     dst = p.dw + (long long)bz * p.dw_bstride;
@@ -161,19 +173,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ldmk_wgrad_args p, con
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ldmk_wgrad_args p, const int splitr,
                                                            const float* __restrict__ ws) {
   const int n4 = p.N / 4;
-  const long long total = (long long)p.Kw * n4;
+  const int srows = p.Kw + (p.dbias ? 1 : 0);
+  const long long total = (long long)srows * n4;
   const int bz = blockIdx.z;
-  const float* slab0 = ws + (long long)bz * splitr * p.Kw * p.N;
+  const float* slab0 = ws + (long long)bz * splitr * srows * p.N;
   float* outp = p.dw + (long long)bz * p.dw_bstride;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int row = (int)(i / n4), col = (int)(i - (long long)row * n4) * 4;
     float4 s = *reinterpret_cast<const float4*>(slab0 + (long long)row * p.N + col);
     for (int k = 1; k < splitr; ++k) {
-      const float4 t = *reinterpret_cast<const float4*>(slab0 + ((long long)k * p.Kw + row) * p.N + col);
+      const float4 t = *reinterpret_cast<const float4*>(slab0 + ((long long)k * srows + row) * p.N + col);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
     s.x *= p.alpha; s.y *= p.alpha; s.z *= p.alpha; s.w *= p.alpha;
-    float* d = outp + (long long)row * p.ldw + col;
+    float* d = row < p.Kw ? outp + (long long)row * p.ldw + col : p.dbias + col;
     if (p.accumulate) { s.x += d[0]; s.y += d[1]; s.z += d[2]; s.w += d[3]; }
     d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w;
   }
@@ -186,7 +199,7 @@ static int launch_wgrad(const ldmk_wgrad_args& a, int splitr, hipStream_t st) {
   const int nb = a.batch > 1 ? a.batch : 1;
   hipLaunchKernelGGL((wgrad_kernel<TM, TN, WM, WN>), dim3(tiles, splitr, nb), dim3(256), 0, st, a, splitr, a.ws);
   if (splitr > 1) {
-    long long total = (long long)a.Kw * (a.N / 4);
+    long long total = (long long)(a.Kw + (a.dbias ? 1 : 0)) * (a.N / 4);
     int g = (int)((total + 255) / 256);
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g, 1, nb), dim3(256), 0, st, a, splitr, a.ws);
@@ -217,11 +230,11 @@ static int wgrad_plan_splitr(const ldmk_wgrad_args& a, int cfg) {
   wgrad_tile(cfg, &bm, &bn);
   const long long tiles = (long long)((a.Kw + bm - 1) / bm) * ((a.N + bn - 1) / bn) * (a.batch > 1 ? a.batch : 1);
   const int iters = (a.R + 31) / 32;
-  long long s = (1024 + tiles - 1) / tiles;       // aim at >= 1024 workgroups (2 per CU x 2 rounds)
-  if (s > iters / 4) s = iters / 4;
+  long long s = (512 + tiles - 1) / tiles;        // aim at one full round of 2 workgroups per CU ...
+  if (s > iters / 8) s = iters / 8;                // ... but keep >= 8 slices per workgroup (slab write + reduce cost)
   if (s > 256) s = 256;
   if (s < 1) s = 1;
-  const long long per = (long long)(a.batch > 1 ? a.batch : 1) * a.Kw * a.N;
+  const long long per = (long long)(a.batch > 1 ? a.batch : 1) * (a.Kw + (a.dbias ? 1 : 0)) * a.N;
   if (s > 1 && (!a.ws || per * s > a.ws_elems)) s = a.ws ? a.ws_elems / per : 1;
   return s < 1 ? 1 : (int)s;
 }
@@ -250,12 +263,13 @@ extern "C" int ldmk_wgrad(const ldmk_wgrad_args* args, void* stream) {
   } else {
     LDMK_REQUIRE(a.a_mode == LDMK_A_ROWS && a.lda >= a.Kw && a.lda % 4 == 0, "ldmk_wgrad: rows mode needs lda >= Kw, lda%%4==0");
   }
+  LDMK_REQUIRE(!a.dbias || a.batch <= 1, "ldmk_wgrad: dbias is not available for batched problems");
   LDMK_REQUIRE(a.splitr >= 0 && a.splitr <= 256, "ldmk_wgrad: splitr=%d outside [0,256]", a.splitr);
   if (a.alpha == 0.f) a.alpha = 1.f;
   const int cfg = wgrad_cfg(a);
   int sr = a.splitr > 0 ? a.splitr : wgrad_plan_splitr(a, cfg);
   if (sr > 1) {
-    const long long need = (long long)(a.batch > 1 ? a.batch : 1) * sr * a.Kw * a.N;
+    const long long need = (long long)(a.batch > 1 ? a.batch : 1) * sr * (a.Kw + (a.dbias ? 1 : 0)) * a.N;
     LDMK_REQUIRE(a.ws && need <= a.ws_elems, "ldmk_wgrad: splitr=%d needs a workspace of %lld floats", sr, need);
   }
   hipStream_t st = (hipStream_t)stream;

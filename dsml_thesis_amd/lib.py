@@ -38,7 +38,7 @@ class WgradArgs(C.Structure):
         ("stride", C.c_int), ("pad_lo", C.c_int), ("upsample", C.c_int),
         ("dy", _fp), ("ldy", C.c_int), ("dw", _fp), ("ldw", C.c_int), ("accumulate", C.c_int), ("alpha", C.c_float),
         ("batch", C.c_int), ("a_bstride", C.c_longlong), ("dy_bstride", C.c_longlong), ("dw_bstride", C.c_longlong),
-        ("splitr", C.c_int), ("ws", _fp), ("ws_elems", C.c_longlong),
+        ("splitr", C.c_int), ("ws", _fp), ("ws_elems", C.c_longlong), ("dbias", _fp),
     ]
 
 

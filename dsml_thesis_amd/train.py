@@ -85,6 +85,7 @@ class UNetTrainer:
         self.tape = []
         self.G = {}            # activation data_ptr -> (grad tensor)
         self.ginit = set()
+        self._stats = {}       # activation data_ptr -> (tensor, GroupNorm partial records emitted by its producer GEMM)
 
     # ---- parameters -----------------------------------------------------------------------------------------
     def _collect(self):
@@ -149,7 +150,7 @@ class UNetTrainer:
         return g
 
     # ---- layer primitives (forward; each pushes its backward) -------------------------------------------------------
-    def _lin(self, x2d, wname, bname, rows_per_sample, residual=None, batch_vec=None, x1=None):
+    def _lin(self, x2d, wname, bname, rows_per_sample, residual=None, batch_vec=None, x1=None, stats=False):
         p = self.P.p
         w = p[wname]
         M, N = x2d.shape[0], w.shape[1]
@@ -159,16 +160,32 @@ class UNetTrainer:
         a = ops.make_igemm_args(M, N, c0 + c1, x2d, c0, w, out, N, rows_per_sample, a1=x1, c1=c1,
                                 bias=None if bname is None else p[bname], residual=residual,
                                 batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0))
+        self._emit_stats(a, out, rows_per_sample, stats)
         gemm(a, self.dev)
         return out
+
+    def _emit_stats(self, a, out, rows_per_sample, stats):
+        """Let the GEMM epilogue write the GroupNorm partial records of its output (saves a statistics pass)."""
+        if stats and a.M % 32 == 0 and rows_per_sample % 32 == 0:
+            part = torch.empty(a.M // 32, a.N, 3, device=self.dev)
+            a.stats_out = part.data_ptr()
+            self._stats[out.data_ptr()] = (out, part)      # holding `out` keeps its address from being recycled
+
+    def _partial(self, x, n, hw):
+        hit = self._stats.get(x.data_ptr())
+        if hit is not None:
+            return hit[1]
+        c = x.shape[-1]
+        part = torch.empty(n * L.load().ldmk_gn_chunks(hw) * c * 3, device=self.dev)
+        L.call("ldmk_gn_partial", x.data_ptr(), c, n, hw, part.data_ptr(), ops.stream())
+        self._stats[x.data_ptr()] = (x, part)
+        return part
 
     def _lin_bwd(self, dy, x2d, wname, bname, x1=None, need_dx=True):
         """Parameter gradients of out = [x2d|x1] @ W + b and (optionally) the data gradient dy @ W^T."""
         g, p = self.P.g, self.P.p
-        if bname is not None:
-            T.colsum(dy, out=g[bname].view(1, -1))
         c0 = x2d.shape[1]
-        T.wgrad_linear(x2d, dy, dw=g[wname][:c0])
+        T.wgrad_linear(x2d, dy, dw=g[wname][:c0], dbias=None if bname is None else g[bname])
         if x1 is not None:
             T.wgrad_linear(x1, dy, dw=g[wname][c0:])
         if not need_dx:
@@ -185,7 +202,7 @@ class UNetTrainer:
         gemm(a, self.dev)
         return out
 
-    def _conv(self, x4, wname, bname, stride=1, upsample=False, batch_vec=None, residual=None):
+    def _conv(self, x4, wname, bname, stride=1, upsample=False, batch_vec=None, residual=None, stats=True):
         p = self.P.p
         n, h, w_, c = x4.shape
         wp = p[wname]
@@ -195,6 +212,7 @@ class UNetTrainer:
         a = ops.make_igemm_args(n * oh * ow, cout, 9 * c, x4, c, wp, out, cout, oh * ow,
                                 conv=(h, w_, oh, ow, stride, 1, 1 if upsample else 0), bias=p[bname], residual=residual,
                                 batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0))
+        self._emit_stats(a, out, oh * ow, stats)
         gemm(a, self.dev)
         return out
 
@@ -202,8 +220,7 @@ class UNetTrainer:
         g, p = self.P.g, self.P.p
         n, oh, ow, cout = dy4.shape
         _, h, w_, c = x4.shape
-        T.colsum(dy4.view(-1, cout), out=g[bname].view(1, -1))
-        T.wgrad_conv3x3(x4, dy4, stride=stride, upsample=upsample, dw=g[wname])
+        T.wgrad_conv3x3(x4, dy4, stride=stride, upsample=upsample, dw=g[wname], dbias=g[bname])
         if not need_dx:
             return None
         wd = T.pack_dgrad3x3(p[wname], c, cout)
@@ -221,11 +238,12 @@ class UNetTrainer:
         n = x0.shape[0]
         c0 = x0.shape[-1]
         c1 = 0 if x1 is None else x1.shape[-1]
-        chunks = L.load().ldmk_gn_chunks(hw)
-        partial = torch.empty(n * chunks * (c0 + c1) * 3, device=self.dev)
+        pa = self._partial(x0, n, hw)
+        pb = None if x1 is None else self._partial(x1, n, hw)
         coef = torch.empty(n, 2, c0 + c1, device=self.dev)
-        ops.gn_coef(x0, x1, n, hw, p[gname], p[bname], eps, partial=partial, coef=coef)
-        mr = T.gn_group_stats(partial, c0, partial[n * chunks * c0 * 3:] if c1 else None, c1, n, hw, 32, eps)
+        L.call("ldmk_gn_finalize", pa.data_ptr(), c0, ops._ptr(pb), c1, n, hw, 32, eps, p[gname].data_ptr(), p[bname].data_ptr(),
+               coef.data_ptr(), ops.stream())
+        mr = T.gn_group_stats(pa, c0, pb, c1, n, hw, 32, eps)
         y = ops.gn_apply(x0, x1, coef, n, hw, silu=silu)
         return y, (coef, mr)
 
@@ -309,7 +327,8 @@ class UNetTrainer:
             blocks.append((q, hcur, st1, ln1, qkv, att, v, cvec, h1, st3, ln3, pre, f, h2))
             hcur = h2
         h_last = hcur
-        out = self._lin(h_last, prefix + "pout", prefix + "proj_out.bias", hw, residual=x.view(rows, m.ch)).view(n, h, w, m.ch)
+        out = self._lin(h_last, prefix + "pout", prefix + "proj_out.bias", hw, residual=x.view(rows, m.ch),
+                        stats=True).view(n, h, w, m.ch)
 
         def bwd():
             g, p = self.P.g, self.P.p
@@ -374,7 +393,7 @@ class UNetTrainer:
         if context is None or context.shape[1] != 1:
             raise NotImplementedError("UNetTrainer: single-token context only")
         n, cin, H, W_ = x.shape
-        self.tape, self.G, self.ginit = [], {}, set()
+        self.tape, self.G, self.ginit, self._stats = [], {}, set(), {}
         self._dctx_init = False
         mc = u.model_channels
         ctx = context.reshape(n, u.context_dim).contiguous().float()
@@ -436,7 +455,7 @@ class UNetTrainer:
         hw = ch_ * cw_
         yo, so = self._gn(hcur, None, hw, "out.0.weight", "out.0.bias", 1e-5, True)
         yo = yo.view(n, ch_, cw_, -1)
-        eps_pad = self._conv(yo, "out.wpad", "out.bpad")
+        eps_pad = self._conv(yo, "out.wpad", "out.bpad", stats=False)
         h_final = hcur
 
         def bwd_out():
@@ -449,6 +468,7 @@ class UNetTrainer:
     def backward(self, deps_pad):
         """deps_pad: gradient w.r.t. the channel-padded NHWC output (n,H,W,32).  Fills P.grad and self.dctx."""
         self._alias_grad(self.eps_pad, deps_pad)
+        self._stats = {}
         for fn in reversed(self.tape):
             fn()
         self.tape, self.G, self.ginit = [], {}, set()

@@ -14,7 +14,7 @@ def _f32(*shape, device="cuda"):
 
 
 def wgrad_args(R, Kw, N, a, dy, dw, c=0, lda=None, conv=None, ldy=None, ldw=None, accumulate=False, alpha=1.0, batch=1,
-               a_bstride=0, dy_bstride=0, dw_bstride=0, splitr=0, ws=None):
+               a_bstride=0, dy_bstride=0, dw_bstride=0, splitr=0, ws=None, dbias=None):
     w = L.WgradArgs()
     w.R, w.Kw, w.N = R, Kw, N
     w.a, w.dy, w.dw = _ptr(a), _ptr(dy), _ptr(dw)
@@ -32,6 +32,7 @@ def wgrad_args(R, Kw, N, a, dy, dw, c=0, lda=None, conv=None, ldy=None, ldw=None
     w.accumulate, w.alpha = 1 if accumulate else 0, alpha
     w.batch, w.a_bstride, w.dy_bstride, w.dw_bstride = batch, a_bstride, dy_bstride, dw_bstride
     w.splitr = splitr
+    w.dbias = _ptr(dbias)
     if ws is not None:
         w.ws, w.ws_elems = ws.data_ptr(), ws.numel()
     return w
@@ -40,38 +41,50 @@ def wgrad_args(R, Kw, N, a, dy, dw, c=0, lda=None, conv=None, ldy=None, ldw=None
 def wgrad_workspace_elems(w):
     sr = C.c_int(0)
     L.call("ldmk_wgrad_plan", C.byref(w), C.byref(sr))
-    return sr.value, (sr.value * max(1, w.batch) * w.Kw * w.N if sr.value > 1 else 0)
+    return sr.value, (sr.value * max(1, w.batch) * (w.Kw + (1 if w.dbias else 0)) * w.N if sr.value > 1 else 0)
 
 
 def wgrad(w):
     L.call("ldmk_wgrad", C.byref(w), stream())
 
 
-def wgrad_linear(a2d, dy2d, dw=None, accumulate=False, lda=None, splitr=0):
-    """dW[K][N] = a2d[R][K]^T @ dy2d[R][N]."""
+_WS = {}
+
+
+def _workspace(dev, elems):
+    """One grow-only scratch per device for the wgrad partial slabs (stream-ordered reuse)."""
+    ws = _WS.get(dev)
+    if ws is None or ws.numel() < elems:
+        ws = _f32(max(int(elems), 1 << 22), device=dev)
+        _WS[dev] = ws
+    return ws
+
+
+def wgrad_linear(a2d, dy2d, dw=None, accumulate=False, lda=None, splitr=0, dbias=None):
+    """dW[K][N] = a2d[R][K]^T @ dy2d[R][N]  (+ dbias[N] = column sums of dy2d)."""
     R, K = a2d.shape
     N = dy2d.shape[1]
     if dw is None:
         dw = _f32(K, N, device=a2d.device)
     w = wgrad_args(R, K, N, a2d, dy2d, dw, lda=lda if lda is not None else a2d.stride(0), ldy=dy2d.stride(0),
-                   accumulate=accumulate, splitr=splitr)
-    sr, need = wgrad_workspace_elems(w) if splitr == 0 else (splitr, splitr * K * N)
-    ws = _f32(max(need, 1), device=a2d.device)
+                   accumulate=accumulate, splitr=splitr, dbias=dbias)
+    sr, need = wgrad_workspace_elems(w) if splitr == 0 else (splitr, splitr * (K + 1) * N)
+    ws = _workspace(a2d.device, need)
     w.splitr, w.ws, w.ws_elems = sr, ws.data_ptr(), ws.numel()
     wgrad(w)
     return dw
 
 
-def wgrad_conv3x3(x, dy, stride=1, pad_lo=1, upsample=False, dw=None, accumulate=False):
+def wgrad_conv3x3(x, dy, stride=1, pad_lo=1, upsample=False, dw=None, accumulate=False, dbias=None):
     """x: (n,h,w,c) NHWC input the forward conv consumed, dy: (n,oh,ow,cout) -> packed dW [9c][cout]."""
     n, h, w_, c = x.shape
     _, oh, ow, cout = dy.shape
     if dw is None:
         dw = _f32(9 * c, cout, device=x.device)
     w = wgrad_args(n * oh * ow, 9 * c, cout, x, dy, dw, c=c, conv=(h, w_, oh, ow, stride, pad_lo, 1 if upsample else 0),
-                   accumulate=accumulate)
+                   accumulate=accumulate, dbias=dbias)
     sr, need = wgrad_workspace_elems(w)
-    ws = _f32(max(need, 1), device=x.device)
+    ws = _workspace(x.device, need)
     w.splitr, w.ws, w.ws_elems = sr, ws.data_ptr(), ws.numel()
     wgrad(w)
     return dw
@@ -248,6 +261,6 @@ def attention_backward(qkv, datt, n, tokens, heads):
 def _wgrad_batched(a, dy, out, Z, R, Kw, N):
     w = wgrad_args(R, Kw, N, a, dy, out, batch=Z, a_bstride=R * Kw, dy_bstride=R * N, dw_bstride=Kw * N)
     sr, need = wgrad_workspace_elems(w)
-    ws = _f32(max(need, 1), device=a.device)
+    ws = _workspace(a.device, need)
     w.splitr, w.ws, w.ws_elems = sr, ws.data_ptr(), ws.numel()
     wgrad(w)

@@ -238,8 +238,9 @@ typedef struct ldmk_wgrad_args {
   int batch;                 /* >1: batched over blockIdx.z (per-head attention gradients)                   */
   long long a_bstride, dy_bstride, dw_bstride;
   int splitr;                /* 0 = choose (ldmk_wgrad_plan); rows are split over that many workgroups       */
-  float* ws;                 /* scratch for the partial slabs: batch*splitr*Kw*N floats                      */
+  float* ws;                 /* scratch for the partial slabs: batch*splitr*(Kw + (dbias?1:0))*N floats      */
   long long ws_elems;
+  float* dbias;              /* optional [N]: column sums of dy (the bias gradient) from the same pass       */
 } ldmk_wgrad_args;
 int ldmk_wgrad(const ldmk_wgrad_args* args, void* stream);
 int ldmk_wgrad_plan(const ldmk_wgrad_args* args, int* splitr);

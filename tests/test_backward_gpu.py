@@ -38,6 +38,12 @@ def test_wgrad_rows(R, K, N, pad):
     _close(dw, 2 * ref, 2e-5, "wgrad rows accumulate")
     again = T.wgrad_linear(ad[:, :K], dyd)
     assert torch.equal(again, T.wgrad_linear(ad[:, :K], dyd)), "wgrad must be bitwise reproducible"
+    # bias gradient (column sums of dy) from the same pass, with and without a row split
+    for sr in (0, 1):
+        db = torch.empty(N, device=_dev())
+        dwb = T.wgrad_linear(ad[:, :K], dyd, dbias=db, splitr=sr)
+        _close(db, dy.double().sum(0), 2e-5, "fused bias gradient")
+        _close(dwb, ref, 2e-5, "wgrad with fused bias gradient")
 
 
 def test_wgrad_batched_heads():
@@ -73,9 +79,11 @@ def test_conv3x3_backward(cin, cout, h, stride, ups):
     xd = x.detach().float().permute(0, 2, 3, 1).contiguous().to(_dev())
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(_dev())
     # weight gradient, in the packed forward layout
-    dwp = T.wgrad_conv3x3(xd, dyd, stride=stride, upsample=ups)
+    db = torch.empty(cout, device=_dev())
+    dwp = T.wgrad_conv3x3(xd, dyd, stride=stride, upsample=ups, dbias=db)
     ref_dw = ops.pack_conv3x3(w.grad.float().to(_dev()))
     _close(dwp, ref_dw.cpu(), 3e-5, "conv wgrad")
+    _close(db, dy.double().sum((0, 2, 3)), 3e-5, "conv bias gradient")
     # data gradient through the mirrored-tap weights
     wp = ops.pack_conv3x3(w.detach().float().to(_dev()))
     wd = T.pack_dgrad3x3(wp, cin, cout)
