@@ -376,11 +376,119 @@ class LatentDiffusion(_Base):
             return DDIMSampler(self).sample(ddim_steps, batch_size, shape, cond, verbose=False, **kwargs)
         return self.sample(cond=cond, batch_size=batch_size, return_intermediates=True, **kwargs)
 
-    # ---- training surface: "next" row N1 ----------------------------------------------------------------
-    def p_losses(self, *a, **k):
-        raise NotImplementedError("training (p_losses / training_step) is SURVEY §8(f) row N1, not built this round")
+    # ---- training surface -------------------------------------------------------------
+    automatic_optimization = False      # Lightning: the step below runs its own backward + optimizer (no autograd)
 
-    training_step = shared_step = p_losses
+    def trainer(self):
+        """The HIP training engine for the UNet (forward + hand-written backward, flat packed parameters)."""
+        if getattr(self, "_trainer", None) is None:
+            from .train import UNetTrainer
+            self._trainer = UNetTrainer(self.model.diffusion_model)
+            self._ema_flat = self._trainer.P.flat.clone() if self.use_ema else None
+            self._cond_opt = None
+        return self._trainer
+
+    def _context_tensor(self, cond):
+        if isinstance(cond, dict):
+            cond = cond.get("c_crossattn", cond)
+        if isinstance(cond, (list, tuple)):
+            cond = torch.cat(list(cond), 1)
+        return cond
+
+    def p_losses(self, x_start, cond, t, noise=None):
+        """ddpm.py:1014-1047 for the shipped settings (eps-prediction, l2, l_simple_weight 1, fixed logvar 0,
+        original_elbo_weight 0): loss = mean((eps_theta(q_sample(x0, t, noise), t, cond) - noise)^2).
+        Runs forward AND backward on the HIP kernels; gradients are left in `self.trainer().P.grad` (UNet, packed
+        layout) and `self.trainer().dctx` (w.r.t. the context tokens).  Returns (loss, loss_dict) like the reference;
+        the logged-only `loss_vlb` entry is not computed."""
+        if self.model.conditioning_key not in ("crossattn", "hybrid"):
+            raise NotImplementedError("p_losses: cross-attention conditioned UNets only")
+        tr = self.trainer()
+        noise = torch.randn_like(x_start) if noise is None else noise
+        ctx = self._context_tensor(cond)
+        loss = tr.p_losses(x_start.float(), ctx, t, noise.float(), self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
+        prefix = "train" if self.training else "val"
+        return loss, {f"{prefix}_loss_simple": loss, f"{prefix}_loss": loss}
+
+    def forward(self, x, c, *args, **kwargs):
+        """ddpm.py:866-877: draw t, embed the condition when the conditioner is trainable, p_losses."""
+        t = torch.randint(0, self.num_timesteps, (x.shape[0],), device=x.device).long()
+        if self.cond_stage_trainable:
+            c = self.get_learned_conditioning(c)
+        return self.p_losses(x, c, t, *args, **kwargs)
+
+    def training_step_latents(self, z, cond_batch, lr, t=None, noise=None, world_size=1, weight_decay=1e-2):
+        """One optimisation step on already-encoded latents z (what `shared_step` produces from a batch,
+        ddpm.py:879-881): loss + backward on the HIP kernels, gradient all-reduce when world_size > 1 (DDP,
+        main.py:532), AdamW on the UNet (ldmk_adamw over the flat buffer) and on the conditioner (torch, a few KB),
+        then the EMA update of on_train_batch_end (ddpm.py:396-398)."""
+        tr = self.trainer()
+        t = torch.randint(0, self.num_timesteps, (z.shape[0],), device=z.device).long() if t is None else t
+        c = cond_batch
+        if self.cond_stage_trainable:
+            with torch.enable_grad():
+                try:
+                    c = self.cond_stage_model(cond_batch, training=self.training)
+                except TypeError:
+                    c = self.get_learned_conditioning(cond_batch)
+        ctx = self._context_tensor(c)
+        loss, loss_dict = self.p_losses(z, ctx.detach(), t, noise)
+        if world_size > 1:
+            tr.all_reduce_grads(world_size)
+        tr.adamw_step(lr, weight_decay=weight_decay)
+        if self.cond_stage_trainable and ctx.requires_grad:
+            if self._cond_opt is None:
+                self._cond_opt = torch.optim.AdamW(self.cond_stage_model.parameters(), lr=lr, weight_decay=weight_decay)
+            for grp in self._cond_opt.param_groups:
+                grp["lr"] = lr
+            self._cond_opt.zero_grad(set_to_none=True)
+            dctx = tr.dctx.view_as(ctx)
+            if world_size > 1:
+                import torch.distributed as dist
+                dist.all_reduce(dctx)
+                dctx = dctx / world_size
+            ctx.backward(dctx)
+            self._cond_opt.step()
+        if self.use_ema:
+            decay = float(self.model_ema.decay)
+            if int(self.model_ema.num_updates) >= 0:                                    # ema.py:28-31
+                self.model_ema.num_updates += 1
+                n_up = int(self.model_ema.num_updates)
+                decay = min(decay, (1 + n_up) / (10 + n_up))
+            tr.ema_update(self._ema_flat, decay)
+        return loss, loss_dict
+
+    def training_step(self, batch, batch_idx=0):
+        """ddpm.py:341-358 with manual optimisation: batch -> (latents, condition) -> one full step."""
+        z, c = self.get_input(batch, self.first_stage_key)
+        loss, loss_dict = self.training_step_latents(z, c, float(getattr(self, "learning_rate", 1e-4)))
+        self.log_dict(loss_dict, prog_bar=True, logger=True, on_step=True, on_epoch=True)
+        return loss
+
+    shared_step = training_step
+
+    def get_input(self, batch, k):
+        """ddpm.py:667-704 for the shipped keys: images (b,h,w,c) in [-1,1] -> first-stage latents; the raw batch is
+        the condition when the conditioner is trainable (it embeds `batch[cond_stage_key]` itself)."""
+        x = batch[k]
+        if x.dim() == 3:
+            x = x[..., None]
+        x = x.permute(0, 3, 1, 2).contiguous().float().to(self.device)
+        z = self.get_first_stage_encoding(self.encode_first_stage(x)).detach()
+        return z, batch
+
+    def sync_trained_weights(self):
+        """Copy the trained (and EMA) weights from the training engine back into the nn.Module tree, so that
+        `ema_scope()`, `state_dict()` and the samplers see them."""
+        tr = self.trainer()
+        tr.sync_to_module()
+        if self.use_ema:
+            sd = tr.state_dict_reference(self._ema_flat)
+            shadow = dict(self.model_ema.named_buffers())
+            for k, v in sd.items():
+                name = self.model_ema.m_name2s_name.get("diffusion_model." + k)
+                if name is not None:
+                    shadow[name].copy_(v)
 
 
 class LatentDiffusion2Cond(LatentDiffusion):

@@ -497,6 +497,73 @@ class UNetTrainer:
     def ema_update(self, shadow_flat, decay):
         T.ema_(shadow_flat, self.P.flat, 1.0 - decay)
 
+    # ---- back to the reference's state-dict layout -------------------------------------------------------------
+    def state_dict_reference(self, flat=None):
+        """Unpack the flat (packed-layout) parameters into the reference's state-dict keys and shapes
+        (openaimodel.py module tree); `flat` defaults to the live weights, pass an EMA shadow buffer to export that.
+        Parameters that receive no gradient with a single-token context (attn2.to_q/to_k, norm2) are returned
+        unchanged from the wrapped UNetModel."""
+        u = self.unet
+        src = self.P.flat if flat is None else flat
+        view = {name: src[off:off + n].view(shape) for name, shape, off, n in self.P.specs}
+        out = {k: v.detach().clone() for k, v in u._sd.items()}
+
+        def unconv(wp, cin, cout):                 # [cin/32][9][32][cout] -> [cout][cin][3][3]
+            return wp.view(cin // 32, 9, 32, cout).permute(3, 0, 2, 1).reshape(cout, cin, 3, 3).contiguous()
+
+        def unlin(wp, like):                       # [in][out] -> the reference weight's own shape ([out][in] or [out][in][1][1])
+            return wp.t().contiguous().view(like.shape)
+
+        lin = {"skip": "skip_connection.weight", "pin": "proj_in.weight", "pout": "proj_out.weight",
+               "o1": "attn1.to_out.0.weight", "v2": "attn2.to_v.weight", "o2": "attn2.to_out.0.weight",
+               "ff2": "ff.net.2.weight", "ff1n": "ff.net.0.proj.weight"}
+        for name, wp in view.items():
+            if name in ("te0", "te2"):
+                out[f"time_embed.{name[2]}.weight"] = wp.t().contiguous()
+            elif name in ("emb_all", "emb_all_b"):
+                for pf, m in u._walk():
+                    if m.kind == "res":
+                        o = u._emb_off[pf]
+                        if name == "emb_all":
+                            out[pf + "emb_layers.1.weight"] = wp[:, o:o + m.cout].t().contiguous()
+                        else:
+                            out[pf + "emb_layers.1.bias"] = wp[o:o + m.cout].clone()
+            elif name == "in.wpad":
+                out["input_blocks.0.0.weight"] = unconv(wp, 32, wp.shape[1])[:, :u.in_channels].contiguous()
+            elif name == "out.wpad":
+                out["out.2.weight"] = unconv(wp, wp.shape[0] // 9, 32)[:u.out_channels].contiguous()
+            elif name == "out.bpad":
+                out["out.2.bias"] = wp[:u.out_channels].clone()
+            elif name.endswith(".c1"):
+                out[name[:-2] + "in_layers.2.weight"] = unconv(wp, wp.shape[0] // 9, wp.shape[1])
+            elif name.endswith(".c2"):
+                out[name[:-2] + "out_layers.3.weight"] = unconv(wp, wp.shape[0] // 9, wp.shape[1])
+            elif name.endswith(".w"):
+                base = name[:-1]
+                key = base + ("op.weight" if base + "op.weight" in out else "conv.weight")
+                out[key] = unconv(wp, wp.shape[0] // 9, wp.shape[1])
+            elif name.endswith(".qkv"):
+                b, c_ = name[:-3], wp.shape[0]
+                for i, ch in enumerate("qkv"):
+                    out[b + f"attn1.to_{ch}.weight"] = wp[:, i * c_:(i + 1) * c_].t().contiguous()
+            else:
+                for suf, key in lin.items():
+                    if name.endswith("." + suf):
+                        k = name[:-len(suf)] + key
+                        out[k] = unlin(wp, out[k])
+                        break
+                else:
+                    out[name] = wp.clone()
+        return out
+
+    def sync_to_module(self, flat=None):
+        """Write the trained weights back into the wrapped UNetModel's nn.Parameters and re-pack its sampling program."""
+        sd = self.state_dict_reference(flat)
+        with torch.no_grad():
+            for k, prm in self.unet.named_parameters():
+                prm.copy_(sd[k])
+        self.unet.pack_weights()
+
     def all_reduce_grads(self, world_size):
         """Data-parallel gradient averaging: one RCCL all-reduce over the flat gradient buffer (main.py:532 DDP)."""
         import torch.distributed as dist

@@ -54,3 +54,35 @@ def test_sharded_equals_unsharded_world2(n_items):
     ref = _fake_frames(batch_noise(5, 0, n_items, (3, 8, 8)))
     assert full.shape == ref.shape and torch.equal(full, ref)
     assert abs(tmax - 0.020) < 1e-12
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dsml_thesis_amd.train import FlatParams, UNetTrainer
+    tr = UNetTrainer.__new__(UNetTrainer)          # the data-parallel reduction only touches the flat gradient buffer
+    tr.P = FlatParams()
+    tr.P.add("w", torch.zeros(1000))
+    tr.P.add("b", torch.zeros(7))
+    tr.P.finalize("cpu")
+    tr.P.grad.copy_(torch.arange(tr.P.grad.numel(), dtype=torch.float32) * (rank + 1))
+    tr.all_reduce_grads(world)
+    if rank == 0:
+        q.put(tr.P.grad.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_world2():
+    """N1 data parallelism: one all-reduce over the flat packed gradient buffer, averaged (DDP semantics)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(g, torch.arange(g.numel(), dtype=torch.float32) * 1.5)

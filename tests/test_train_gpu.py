@@ -110,3 +110,40 @@ def test_full_fr_unet_gradients_and_adamw_step():
     loss2 = tr.p_losses(x0.cuda(), ctx.cuda(), t.cuda(), noise.cuda(), sched["sqrt_alphas_cumprod"].cuda(),
                         sched["sqrt_one_minus_alphas_cumprod"].cuda())
     assert loss2.item() < loss.item(), "one AdamW step on the same batch must lower the loss"
+
+
+def test_state_dict_round_trip_is_exact():
+    """flat packed parameters -> reference state-dict layout reproduces the loaded weights bit for bit."""
+    m, tr, sd, *_ = _setup(SMALL, 2, 16)
+    back = tr.state_dict_reference()
+    assert set(back) == set(sd)
+    for k, v in sd.items():
+        assert torch.equal(back[k].cpu(), v), k
+
+
+def test_latent_diffusion_training_step_updates_unet_conditioner_and_ema():
+    from helpers import make_fr_model
+    model = make_fr_model(gain=0.5).train()
+    n = 2
+    z = rnd(90, n, 3, 32, 32).cuda()
+    batch = {"class_label": torch.tensor([1, 5]).cuda()}
+    unet = model.model.diffusion_model
+    x, t, ctx = rnd(91, n, 3, 32, 32).cuda(), torch.tensor([100, 700]).cuda(), rnd(92, n, 1, 512).cuda()
+    eps0 = unet(x, t, context=ctx)
+    emb0 = model.cond_stage_model.embedding.weight.detach().clone()
+    model.cond_stage_model.p_uncond = 0.0            # keep the class tokens (the null-class draw is random)
+    losses = []
+    for _ in range(3):
+        loss, ld = model.training_step_latents(z, batch, lr=1e-5, t=torch.tensor([300, 800]).cuda(), noise=rnd(93, n, 3, 32, 32).cuda())
+        losses.append(loss.item())
+        assert set(ld) == {"train_loss_simple", "train_loss"}
+    assert all(np.isfinite(losses)) and losses[2] < losses[0], losses
+    tr = model.trainer()
+    assert not torch.equal(model.cond_stage_model.embedding.weight.detach(), emb0), "conditioner must be optimised too"
+    assert not torch.equal(model._ema_flat, tr.P.flat) and int(model.model_ema.num_updates) == 3
+    model.sync_trained_weights()
+    eps1 = unet(x, t, context=ctx)
+    assert not torch.equal(eps0, eps1), "the sampling program must see the trained weights"
+    with model.ema_scope():
+        eps_ema = unet(x, t, context=ctx)
+    assert not torch.equal(eps_ema, eps1)
