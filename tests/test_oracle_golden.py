@@ -202,3 +202,39 @@ def test_g8_ddim_inversion():
                                                 uncond=uc if scale != 1.0 else None)
         close(lat, g[f"xlat_{tag}"], 1e-4, 1e-4)
         close(img, g[f"img_{tag}"], 1e-4, 1e-4)
+
+
+def test_g9_p_losses_backward_pins_the_oracle_autograd():
+    """Training row N1: loss and gradients of the reference's own LatentDiffusion.p_losses (ddpm.py:1014-1047,
+    autograd through the reference UNet incl. its checkpointed transformer blocks) against autograd through the
+    oracle's functional UNet -- the oracle's backward is what the HIP gradients are then checked against elementwise."""
+    import torch.nn.functional as F
+    g = golden("g9_p_losses.npz")
+    cfg = dict(W.FR_UNET, model_channels=64, channel_mult=[1, 2], num_res_blocks=1, attention_resolutions=[2, 1])
+    sd = W.synth_state_dict(W.unet_param_shapes(cfg))
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x0, noise = rnd(101, 2, 3, 16, 16), rnd(102, 2, 3, 16, 16)
+    c = rnd(103, 2, 1, 512).requires_grad_(True)
+    t = torch.tensor([17, 803])
+    sched = O.register_schedule(**W.SCHEDULE)
+    a = sched["sqrt_alphas_cumprod"][t].view(-1, 1, 1, 1)
+    b = sched["sqrt_one_minus_alphas_cumprod"][t].view(-1, 1, 1, 1)
+    with torch.enable_grad():
+        eps = O.unet_forward(sdg, cfg, a * x0 + b * noise, t, c)
+        loss = F.mse_loss(eps, noise)
+        loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 2e-6 * float(g["loss"])
+    assert float(g["loss"]) == float(g["loss_simple"])
+    torch.testing.assert_close(c.grad, torch.from_numpy(g["dcontext"]), rtol=2e-4, atol=1e-7)
+    stats = dict(zip([str(n) for n in g["names"]], g["stats"]))
+    assert set(stats) == set(sd)
+    for k, (s_ref, n_ref) in stats.items():
+        gr = sdg[k].grad
+        if gr is None:                       # dead parameters of the single-token cross-attention
+            assert n_ref == 0.0, k
+            continue
+        assert abs(gr.double().norm().item() - n_ref) <= 2e-4 * n_ref + 1e-12, (k, gr.double().norm().item(), n_ref)
+        assert abs(gr.double().sum().item() - s_ref) <= 2e-4 * n_ref * gr.numel() ** 0.5 + 1e-12, k
+    for k in g.files:
+        if k.startswith("grad:"):
+            torch.testing.assert_close(sdg[k[5:]].grad, torch.from_numpy(g[k]), rtol=2e-4, atol=1e-6 * float(np.abs(g[k]).max()))

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rnd
+from conftest import golden, rnd
 from oracle import ldm_oracle as O
 from oracle import weights as W
 
@@ -147,3 +147,56 @@ def test_latent_diffusion_training_step_updates_unet_conditioner_and_ema():
     with model.ema_scope():
         eps_ema = unet(x, t, context=ctx)
     assert not torch.equal(eps_ema, eps1)
+
+
+def test_p_losses_against_reference_fixture():
+    """tests/golden/g9_p_losses.npz holds loss and gradients of the reference's own LatentDiffusion.p_losses +
+    autograd (tools/make_golden.py --tree train).  The HIP step must reproduce them."""
+    g = golden("g9_p_losses.npz")
+    m, tr, sd, *_ = _setup(SMALL, 2, 16)
+    x0, noise, ctx, t = rnd(101, 2, 3, 16, 16), rnd(102, 2, 3, 16, 16), rnd(103, 2, 1, 512), torch.tensor([17, 803])
+    sched = O.register_schedule(**W.SCHEDULE)
+    loss = tr.p_losses(x0.cuda(), ctx.cuda(), t.cuda(), noise.cuda(), sched["sqrt_alphas_cumprod"].cuda(),
+                       sched["sqrt_one_minus_alphas_cumprod"].cuda())
+    assert abs(loss.item() - float(g["loss"])) <= 2e-5 * float(g["loss"])
+    torch.testing.assert_close(tr.dctx.cpu().view(2, 1, 512), torch.from_numpy(g["dcontext"]), rtol=5e-4, atol=1e-7)
+    direct = {"out.2.bias": tr.P.g["out.bpad"][:3]}
+    for k in g.files:
+        if k.startswith("grad:"):
+            got = direct.get(k[5:], tr.P.g.get(k[5:]))
+            ref = torch.from_numpy(g[k])
+            torch.testing.assert_close(got.cpu(), ref, rtol=5e-4, atol=2e-6 * float(ref.abs().max()))
+    # every parameter: L2 norm of the gradient (layout independent); fused buffers combine their parts
+    stats = dict(zip([str(n) for n in g["names"]], g["stats"]))
+    sq = lambda keys: sum(stats[k][1] ** 2 for k in keys) ** 0.5
+    res = [p for p, mm in m._walk() if mm.kind == "res"]
+    for name, gr in tr.P.g.items():
+        if name == "emb_all":
+            ref = sq([p + "emb_layers.1.weight" for p in res])
+        elif name == "emb_all_b":
+            ref = sq([p + "emb_layers.1.bias" for p in res])
+        elif name.endswith(".qkv"):
+            ref = sq([name[:-3] + f"attn1.to_{c}.weight" for c in "qkv"])
+        elif name in ("te0", "te2"):
+            ref = stats[f"time_embed.{name[2]}.weight"][1]
+        elif name == "in.wpad":
+            ref = stats["input_blocks.0.0.weight"][1]
+        elif name == "out.wpad":
+            ref = stats["out.2.weight"][1]
+        elif name == "out.bpad":
+            ref = stats["out.2.bias"][1]
+        else:
+            table = {"c1": "in_layers.2.weight", "c2": "out_layers.3.weight", "skip": "skip_connection.weight",
+                     "pin": "proj_in.weight", "pout": "proj_out.weight", "o1": "attn1.to_out.0.weight",
+                     "v2": "attn2.to_v.weight", "o2": "attn2.to_out.0.weight", "ff2": "ff.net.2.weight",
+                     "ff1n": "ff.net.0.proj.weight"}
+            suf = name.rsplit(".", 1)[-1]
+            if suf in table:
+                ref = stats[name[:-len(suf)] + table[suf]][1]
+            elif suf == "w":
+                base = name[:-1]
+                ref = stats[base + ("op.weight" if base + "op.weight" in stats else "conv.weight")][1]
+            else:
+                ref = stats[name][1]
+        got = gr.double().norm().item()
+        assert abs(got - ref) <= 3e-4 * ref + 1e-12, (name, got, ref)

@@ -373,6 +373,53 @@ def gen_fr():
     save("g6_vqgan.npz", **g6)
 
 
+# --------------------------------------------------------------------------- training step (N1)
+TRAIN_UNET = dict(W.FR_UNET, model_channels=64, channel_mult=[1, 2], num_res_blocks=1, attention_resolutions=[2, 1])
+TRAIN_FULL_KEYS = ("out.2.bias", "time_embed.0.bias", "input_blocks.1.1.norm.weight", "input_blocks.0.0.bias",
+                   "middle_block.1.transformer_blocks.0.norm3.bias", "output_blocks.1.0.skip_connection.bias",
+                   "input_blocks.2.0.op.bias", "output_blocks.0.2.conv.bias")
+
+
+def gen_train():
+    """G9: the reference's own LatentDiffusion.p_losses (ddpm.py:1014-1047) + autograd backward on a reduced UNet:
+    loss, per-parameter gradient (sum, L2 norm), a few gradients in full, and the gradient w.r.t. the context."""
+    from tools import ref_shims
+    ref_shims.install("face_reenactment")
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    unet_cfg = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(TRAIN_UNET))
+    fs_cfg = dict(target="ldm.models.autoencoder.VQModelInterface",
+                  params=dict(embed_dim=3, n_embed=16384, ddconfig=dict(W.VQ_F4["ddconfig"]),
+                              lossconfig=dict(target="torch.nn.Identity")))
+    cond_cfg = dict(target="ldm.modules.encoders.modules.ClassEmbedder3",
+                    params=dict(embed_dim=512, n_classes=8, key="class_label", p_uncond=0.2))
+    ld = LatentDiffusion(first_stage_config=fs_cfg, cond_stage_config=cond_cfg, num_timesteps_cond=1,
+                         cond_stage_key="class_label", cond_stage_trainable=True, conditioning_key="crossattn",
+                         unet_config=unet_cfg, image_size=16, channels=3, first_stage_key="image", log_every_t=200,
+                         monitor="val_loss_ema", **W.SCHEDULE)
+    unet = ld.model.diffusion_model
+    load_recipe(unet, seed=0, prefix_check=W.unet_param_shapes(TRAIN_UNET))
+    ld.train()
+    torch.set_grad_enabled(True)
+    n = 2
+    x0, noise = rnd(101, n, 3, 16, 16), rnd(102, n, 3, 16, 16)
+    c = rnd(103, n, 1, 512).requires_grad_(True)
+    t = torch.tensor([17, 803])
+    loss, loss_dict = ld.p_losses(x0, c, t, noise=noise)
+    loss.backward()
+    g9 = dict(loss=loss.detach(), loss_simple=loss_dict["train_loss_simple"].detach(), dcontext=c.grad)
+    names, stats = [], []
+    for k, p_ in unet.named_parameters():
+        g = torch.zeros_like(p_) if p_.grad is None else p_.grad
+        names.append(k)
+        stats.append([g.double().sum().item(), g.double().norm().item()])
+        if k in TRAIN_FULL_KEYS:
+            g9["grad:" + k] = g
+    g9["names"] = np.asarray(names)
+    g9["stats"] = np.asarray(stats, dtype=np.float64)
+    save("g9_p_losses.npz", **g9)
+    torch.set_grad_enabled(False)
+
+
 # --------------------------------------------------------------------------- TF tree
 def gen_tf():
     from tools import ref_shims
@@ -478,14 +525,16 @@ def gen_tf():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["face_reenactment", "talking_face"])
+    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train"])
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    if a.tree == "face_reenactment":
+    if a.tree == "train":
+        gen_train()
+    elif a.tree == "face_reenactment":
         gen_fr()
     elif a.tree == "talking_face":
         gen_tf()
     else:
-        for tree in ("face_reenactment", "talking_face"):
+        for tree in ("face_reenactment", "talking_face", "train"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", tree], cwd=ROOT)
