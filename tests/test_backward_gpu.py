@@ -8,6 +8,13 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _autograd_on():
+    """The reference side of these tests is autograd; other test modules switch it off process-wide."""
+    with torch.enable_grad():
+        yield
+
+
 def _dev():
     return torch.device("cuda", 0)
 

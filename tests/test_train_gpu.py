@@ -11,6 +11,13 @@ from oracle import weights as W
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _autograd_on():
+    """The reference side of these tests is autograd; other test modules switch it off process-wide."""
+    with torch.enable_grad():
+        yield
+
 SMALL = dict(W.FR_UNET, model_channels=64, channel_mult=[1, 2], num_res_blocks=1, attention_resolutions=[2, 1])
 
 
