@@ -395,7 +395,7 @@ class LatentDiffusion(_Base):
             cond = torch.cat(list(cond), 1)
         return cond
 
-    def p_losses(self, x_start, cond, t, noise=None):
+    def p_losses(self, x_start, cond, t, noise=None, c_concat=None):
         """ddpm.py:1014-1047 for the shipped settings (eps-prediction, l2, l_simple_weight 1, fixed logvar 0,
         original_elbo_weight 0): loss = mean((eps_theta(q_sample(x0, t, noise), t, cond) - noise)^2).
         Runs forward AND backward on the HIP kernels; gradients are left in `self.trainer().P.grad` (UNet, packed
@@ -406,7 +406,10 @@ class LatentDiffusion(_Base):
         tr = self.trainer()
         noise = torch.randn_like(x_start) if noise is None else noise
         ctx = self._context_tensor(cond)
-        loss = tr.p_losses(x_start.float(), ctx, t, noise.float(), self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
+        if isinstance(c_concat, (list, tuple)):
+            c_concat = torch.cat(list(c_concat), 1)
+        loss = tr.p_losses(x_start.float(), ctx, t, noise.float(), self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod,
+                           c_concat=c_concat)
         prefix = "train" if self.training else "val"
         return loss, {f"{prefix}_loss_simple": loss, f"{prefix}_loss": loss}
 
@@ -502,6 +505,10 @@ class LatentDiffusion2Cond(LatentDiffusion):
         self.cond_stage_model_1 = self.cond_stage_model
         self.cond_stage_model = None
         self.cond_stage_model_2 = instantiate_from_config(cond_stage_config_2)
+
+    def p_losses(self, x_start, cond12, cond34=None, t=None, noise=None):
+        """ddpm2cond.py p_losses(x_start, cond12, cond34, t): cross-attention tokens + channel-concat latents."""
+        return super().p_losses(x_start, cond12, t, noise=noise, c_concat=cond34)
 
     @torch.no_grad()
     def apply_model(self, x_noisy, t, cond12, cond34=None, return_ids=False):

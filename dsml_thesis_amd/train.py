@@ -474,11 +474,14 @@ class UNetTrainer:
         self.tape, self.G, self.ginit = [], {}, set()
 
     # ---- p_losses / optimizer -------------------------------------------------------------------------------
-    def p_losses(self, x_start, context, t, noise, sqrt_ac, sqrt_1mac):
+    def p_losses(self, x_start, context, t, noise, sqrt_ac, sqrt_1mac, c_concat=None):
         """ddpm.py:1014-1047 with parameterization 'eps', loss_type 'l2', l_simple_weight 1, no learned logvar,
-        original_elbo_weight 0: loss = mean((eps_theta(q_sample(x0,t,noise), t, c) - noise)^2).  Returns the loss
+        original_elbo_weight 0: loss = mean((eps_theta(q_sample(x0,t,noise), t, c) - noise)^2); `c_concat` (masked-frame +
+        identity latents of the talking-face model) is concatenated to the noisy latent on the channel axis.  Returns the loss
         (device scalar) after running forward + backward; gradients are in self.P.grad."""
         x_noisy = T.q_sample(x_start.contiguous(), noise.contiguous(), t, sqrt_ac, sqrt_1mac)
+        if c_concat is not None:         # TF DiffusionWrapper: torch.cat([x] + c_concat, dim=1), ddpm2cond.py:1309
+            x_noisy = torch.cat([x_noisy, c_concat.float()], 1)
         self.forward(x_noisy, t, context)
         n, co, H, W_ = noise.shape
         tgt = torch.zeros_like(self.eps_pad)

@@ -207,3 +207,23 @@ def test_p_losses_against_reference_fixture():
                 ref = stats[name][1]
         got = gr.double().norm().item()
         assert abs(got - ref) <= 3e-4 * ref + 1e-12, (name, got, ref)
+
+
+def test_talking_face_unet_gradients_with_channel_concat():
+    """TF model (ddpm2cond): 3 noisy-latent channels + 6 concat channels in, (B,1,1024) context; gradients of the
+    reduced two-condition UNet against float64 autograd on the oracle."""
+    cfg = dict(SMALL, in_channels=9, context_dim=1024)
+    m, tr, sd, _, noise, ctx, t = _setup(cfg, 2, 16, seed=10)
+    x0, c34 = rnd(21, 2, 3, 16, 16), rnd(22, 2, 6, 16, 16)
+    sched = O.register_schedule(**W.SCHEDULE)
+    sdg = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    a = sched["sqrt_alphas_cumprod"][t].view(-1, 1, 1, 1)
+    b = sched["sqrt_one_minus_alphas_cumprod"][t].view(-1, 1, 1, 1)
+    xin = torch.cat([a * x0 + b * noise, c34], 1).double()
+    eps = O.unet_forward(sdg, cfg, xin, t, ctx.double())
+    loss_ref = F.mse_loss(eps, noise.double())
+    loss_ref.backward()
+    loss = tr.p_losses(x0.cuda(), ctx.cuda(), t.cuda(), noise.cuda(), sched["sqrt_alphas_cumprod"].cuda(),
+                       sched["sqrt_one_minus_alphas_cumprod"].cuda(), c_concat=c34.cuda())
+    assert abs(loss.item() - loss_ref.item()) <= 2e-5 * loss_ref.item()
+    _check_all_grads(m, tr, {k: v.grad for k, v in sdg.items()}, 1e-4)
