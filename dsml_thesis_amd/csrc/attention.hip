@@ -23,7 +23,7 @@ constexpr int AT_KSTR = AT_D + 1;    // K rows padded: lanes read 32 different k
 // barriers per MFMA (used when there are enough 256-query workgroups to fill the chip).
 template <int QT>
 __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                        int tokens, int heads, float scale) {
+                                                        int tokens, int heads, float scale, float* __restrict__ lse) {
   __shared__ float Ks[AT_KT * AT_KSTR];
   __shared__ float Vs[AT_KT * AT_D];
   __shared__ float Os[4][32 * 33];
@@ -134,6 +134,12 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
     }
   }
   if (!wave_active) return;
+  if (lse != nullptr && half == 0) {     // training: log-sum-exp of the scaled scores per query row, [n][heads][tokens]
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+      if (q0 + 32 * t + l31 < tokens)
+        lse[((long long)b * heads + h) * tokens + q0 + 32 * t + l31] = m_run[t] + logf(l_run[t]);
+  }
   // o[t][r] = O[query][d = (r&3) + 8*(r>>2) + 4*half]; transpose through LDS for 128-B row stores
   float* ow = Os[wave];
 #pragma unroll
@@ -246,7 +252,14 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
 static int g_attn_qt = 0;
 extern "C" void ldmk_attn_force_qt(int qt) { g_attn_qt = qt; }
 
+extern "C" int ldmk_attn_self_lse(const float* qkv, float* out, float* lse, int n, int tokens, int heads, float scale,
+                                  void* stream);
 extern "C" int ldmk_attn_self(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream) {
+  return ldmk_attn_self_lse(qkv, out, nullptr, n, tokens, heads, scale, stream);
+}
+
+extern "C" int ldmk_attn_self_lse(const float* qkv, float* out, float* lse, int n, int tokens, int heads, float scale,
+                                  void* stream) {
   LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(qkv && out && n > 0 && heads > 0, "ldmk_attn_self: bad args");
@@ -256,10 +269,10 @@ extern "C" int ldmk_attn_self(const float* qkv, float* out, int n, int tokens, i
   // kernel is matrix-pipe/clock bound, not LDS- or barrier-bound -- so it is only selectable through the test hook.
   if (g_attn_qt == 2) {
     dim3 grid((tokens + 255) / 256, heads, n);
-    hipLaunchKernelGGL(attn_self_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, tokens, heads, scale);
+    hipLaunchKernelGGL(attn_self_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, tokens, heads, scale, lse);
   } else {
     dim3 grid((tokens + 127) / 128, heads, n);
-    hipLaunchKernelGGL(attn_self_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, tokens, heads, scale);
+    hipLaunchKernelGGL(attn_self_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, tokens, heads, scale, lse);
   }
   return check_launch("ldmk_attn_self");
 }

@@ -98,6 +98,8 @@ _SIGS = {
     "ldmk_axpy": (C.c_int, [_fp, _fp, C.c_float, C.c_longlong, _fp]),
     "ldmk_q_sample": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
     "ldmk_mse_grad": (C.c_int, [_fp, _fp, _fp, C.c_longlong, C.c_longlong, _fp, _fp, _fp]),
+    "ldmk_attn_self_lse": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    "ldmk_attn_self_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_head_permute": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_adamw": (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                              C.c_int, _fp]),

@@ -315,7 +315,7 @@ class UNetTrainer:
             st1 = ops.ln_stats(hcur)
             ln1 = T.ln_apply(hcur, st1, p[q + "norm1.weight"], p[q + "norm1.bias"])
             qkv = self._lin(ln1, q + "qkv", None, hw)
-            att = ops.attn_self(qkv, n, hw, m.heads)
+            att, lse = T.attn_self_lse(qkv, n, hw, m.heads)
             v = self._lin(ctx, q + "v2", None, 1)                                   # single context token (K11)
             cvec = self._lin(v, q + "o2", q + "attn2.to_out.0.bias", 1)
             h1 = self._lin(att, q + "o1", q + "attn1.to_out.0.bias", hw, residual=hcur, batch_vec=cvec)
@@ -324,7 +324,7 @@ class UNetTrainer:
             pre = self._lin(ln3, q + "ff1n", q + "ff.net.0.proj.bias", hw)
             f = T.geglu_fwd(pre)
             h2 = self._lin(f, q + "ff2", q + "ff.net.2.bias", hw, residual=h1)
-            blocks.append((q, hcur, st1, ln1, qkv, att, v, cvec, h1, st3, ln3, pre, f, h2))
+            blocks.append((q, hcur, st1, ln1, qkv, att, lse, v, cvec, h1, st3, ln3, pre, f, h2))
             hcur = h2
         h_last = hcur
         out = self._lin(h_last, prefix + "pout", prefix + "proj_out.bias", hw, residual=x.view(rows, m.ch),
@@ -334,7 +334,7 @@ class UNetTrainer:
             g, p = self.P.g, self.P.p
             dout = self._take(out).view(rows, m.ch)
             dh = self._lin_bwd(dout, h_last, prefix + "pout", prefix + "proj_out.bias")
-            for (q, hin, st1, ln1, qkv, att, v, cvec, h1, st3, ln3, pre, f, h2) in reversed(blocks):
+            for (q, hin, st1, ln1, qkv, att, lse, v, cvec, h1, st3, ln3, pre, f, h2) in reversed(blocks):
                 # ---- feed-forward: h2 = h1 + ff2(geglu(ff1(LN3(h1))))
                 df = self._lin_bwd(dh, f, q + "ff2", q + "ff.net.2.bias")
                 dpre = T.geglu_bwd(pre, df)
@@ -352,7 +352,7 @@ class UNetTrainer:
                 first = not self._dctx_init
                 self._lin_dx(dv, p[q + "v2"], out=dctx, residual=None if first else dctx)
                 self._dctx_init = True
-                dqkv = T.attention_backward(qkv, datt, n, hw, m.heads)
+                dqkv = T.attn_self_bwd(qkv, att, datt, lse, n, hw, m.heads)     # flash style: no [T][T] matrix
                 del datt
                 dln1 = self._lin_bwd(dqkv, ln1, q + "qkv", None)
                 del dqkv

@@ -264,3 +264,20 @@ def _wgrad_batched(a, dy, out, Z, R, Kw, N):
     ws = _workspace(a.device, need)
     w.splitr, w.ws, w.ws_elems = sr, ws.data_ptr(), ws.numel()
     wgrad(w)
+
+
+def attn_self_lse(qkv, n, tokens, heads):
+    """Forward attention that also returns the per-row log-sum-exp [n][heads][tokens] (saved for the backward)."""
+    out = _f32(n * tokens, heads * 32, device=qkv.device)
+    lse = _f32(n, heads, tokens, device=qkv.device)
+    L.call("ldmk_attn_self_lse", _ptr(qkv), _ptr(out), _ptr(lse), n, tokens, heads, 32 ** -0.5, stream())
+    return out, lse
+
+
+def attn_self_bwd(qkv, out, dout, lse, n, tokens, heads):
+    """d(qkv) of ldmk_attn_self, flash style (probabilities recomputed from lse; any token count)."""
+    dqkv = torch.empty_like(qkv)
+    dsum = _f32(n * heads * tokens, device=qkv.device)
+    L.call("ldmk_attn_self_bwd", _ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _ptr(dsum), n, tokens, heads,
+           32 ** -0.5, stream())
+    return dqkv

@@ -284,6 +284,12 @@ int ldmk_q_sample(const float* x0, const float* noise, const long long* t, const
 int ldmk_mse_grad(const float* pred, const float* target, float* dpred, long long n, long long denom, float* loss,
                   double* scratch, void* stream);   /* denom: divisor of the mean (0 -> n); channel-padded tensors pass
                                                        the real element count */
+/* Flash-style backward of ldmk_attn_self.  ldmk_attn_self_lse is the forward that also writes the per-row log-sum-exp
+ * of the scaled scores, lse[n][heads][tokens]; ldmk_attn_self_bwd recomputes the probabilities tile by tile from it
+ * (no [tokens][tokens] matrix in memory) and writes dqkv [n*tokens][3*C]; dsum = scratch of n*heads*tokens floats. */
+int ldmk_attn_self_lse(const float* qkv, float* out, float* lse, int n, int tokens, int heads, float scale, void* stream);
+int ldmk_attn_self_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* dsum,
+                       int n, int tokens, int heads, float scale, void* stream);
 /* d_head = 32 layouts: token-major [n][tokens][parts][heads][32] (the fused qkv / attention output rows) <->
  * head-major [parts][n*heads][tokens][32] (contiguous per-head matrices for the batched backward GEMMs) */
 int ldmk_head_permute(const float* src, float* dst, int n, int tokens, int parts, int heads, int to_heads, void* stream);

@@ -230,7 +230,7 @@ def test_q_sample_mse_adamw_ema():
     _close(sh, ref, 2e-6, "ema")
 
 
-@pytest.mark.parametrize("n,tokens,heads", [(2, 64, 5), (1, 256, 2), (2, 100, 1)])
+@pytest.mark.parametrize("n,tokens,heads", [(2, 64, 5), (1, 256, 2), (2, 100, 1), (1, 1024, 3), (1, 37, 2)])
 def test_attention_backward(n, tokens, heads):
     """d(qkv) of softmax(QK^T/sqrt(32))V against autograd; ragged token counts included."""
     from dsml_thesis_amd import ops, train_ops as T
@@ -243,7 +243,13 @@ def test_attention_backward(n, tokens, heads):
     att.backward(datt.double())
     qd = qkv.detach().float().to(_dev())
     _close(ops.attn_self(qd, n, tokens, heads), att.detach(), 2e-5, "attention forward")
-    if tokens % 32:
-        pytest.skip("materialised backward needs tokens % 32 == 0 (UNet token counts are 64..4096)")
-    dqkv = T.attention_backward(qd, datt.to(_dev()), n, tokens, heads)
-    _close(dqkv, qkv.grad, 3e-5, "attention backward")
+    att_d, lse = T.attn_self_lse(qd, n, tokens, heads)
+    _close(att_d, att.detach(), 2e-5, "attention forward (lse variant)")
+    ref_lse = torch.logsumexp(q @ k.transpose(-1, -2) * 32 ** -0.5, -1).detach()      # [n][heads][tokens]
+    _close(lse, ref_lse, 1e-5, "log-sum-exp")
+    dq_flash = T.attn_self_bwd(qd, att_d, datt.to(_dev()), lse, n, tokens, heads)
+    _close(dq_flash, qkv.grad, 3e-5, "flash attention backward")
+    assert torch.equal(dq_flash, T.attn_self_bwd(qd, att_d, datt.to(_dev()), lse, n, tokens, heads)), "must be reproducible"
+    if tokens % 32 == 0:               # the materialised variant (batched GEMMs) needs whole 32-token tiles
+        dqkv = T.attention_backward(qd, datt.to(_dev()), n, tokens, heads)
+        _close(dqkv, qkv.grad, 3e-5, "materialised attention backward")
