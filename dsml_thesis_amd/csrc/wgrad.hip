@@ -30,6 +30,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ldmk_wgrad_args p, con
   const float* __restrict__ dyp = p.dy + (long long)bz * p.dy_bstride;
   const bool conv = p.a_mode == LDMK_A_CONV3X3;
   const int rps = p.out_h * p.out_w;
+  // power-of-two feature maps (every UNet level): row -> (sample, y, x) by shifts instead of integer divisions
+  const int rps_shift = (rps & (rps - 1)) == 0 ? __ffs(rps) - 1 : -1;
+  const int ow_shift = (p.out_w & (p.out_w - 1)) == 0 ? __ffs(p.out_w) - 1 : -1;
 
   const int iters_all = (p.R + 31) / 32;
   const int it_per = (iters_all + splitr - 1) / splitr;
@@ -70,8 +73,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ldmk_wgrad_args p, con
       const int r = it * 32 + a_rl[i];
       if (a_ok[i] && r < p.R) {
         if (conv) {
-          const int n = r / rps, pix = r - n * rps;
-          const int oy = pix / p.out_w, ox = pix - oy * p.out_w;
+          int n, pix, oy, ox;
+          if (rps_shift >= 0) { n = r >> rps_shift; pix = r & (rps - 1); } else { n = r / rps; pix = r - n * rps; }
+          if (ow_shift >= 0) { oy = pix >> ow_shift; ox = pix & (p.out_w - 1); } else { oy = pix / p.out_w; ox = pix - oy * p.out_w; }
           int iy = oy * p.stride - p.pad_lo + a_dy[i], ix = ox * p.stride - p.pad_lo + a_dx[i];
           const int lim_h = p.upsample ? 2 * p.in_h : p.in_h, lim_w = p.upsample ? 2 * p.in_w : p.in_w;
           if (iy >= 0 && ix >= 0 && iy < lim_h && ix < lim_w) {

@@ -227,3 +227,52 @@ def test_talking_face_unet_gradients_with_channel_concat():
                        sched["sqrt_one_minus_alphas_cumprod"].cuda(), c_concat=c34.cuda())
     assert abs(loss.item() - loss_ref.item()) <= 2e-5 * loss_ref.item()
     _check_all_grads(m, tr, {k: v.grad for k, v in sdg.items()}, 1e-4)
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo: both ranks share the one GPU of the box
+    m, tr, sd, _, _, _, _ = _setup(SMALL, 2, 16)
+    x0, noise, ctx = rnd(201, 4, 3, 16, 16), rnd(202, 4, 3, 16, 16), rnd(203, 4, 1, 512)
+    t = torch.tensor([17, 803, 400, 999])
+    lo, hi = 2 * rank, 2 * rank + 2                                   # contiguous shard of the global batch
+    sched = O.register_schedule(**W.SCHEDULE)
+    tr.p_losses(x0[lo:hi].cuda(), ctx[lo:hi].cuda(), t[lo:hi].cuda(), noise[lo:hi].cuda(),
+                sched["sqrt_alphas_cumprod"].cuda(), sched["sqrt_one_minus_alphas_cumprod"].cuda())
+    tr.all_reduce_grads(world)
+    if rank == 0:
+        q.put(tr.P.grad.cpu())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_equal_full_batch_gradients():
+    """N1 multi-GPU contract: shard the batch over ranks, one all-reduce (mean) of the flat gradient buffer ==
+    the gradient of the full batch on one rank (the loss is a mean over samples)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx_mp = mp.get_context("spawn")
+    q = ctx_mp.Queue()
+    procs = [ctx_mp.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g2 = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    m, tr, sd, _, _, _, _ = _setup(SMALL, 2, 16)
+    x0, noise, ctx = rnd(201, 4, 3, 16, 16), rnd(202, 4, 3, 16, 16), rnd(203, 4, 1, 512)
+    t = torch.tensor([17, 803, 400, 999])
+    sched = O.register_schedule(**W.SCHEDULE)
+    tr.p_losses(x0.cuda(), ctx.cuda(), t.cuda(), noise.cuda(), sched["sqrt_alphas_cumprod"].cuda(),
+                sched["sqrt_one_minus_alphas_cumprod"].cuda())
+    g1 = tr.P.grad.cpu()
+    err = (g1 - g2).abs().max().item() / g1.abs().max().item()
+    assert err <= 2e-5, f"sharded-and-averaged vs full-batch gradients: {err:.3e}"
