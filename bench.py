@@ -162,6 +162,87 @@ def cpu_baseline(latent, budget_s=20.0):
                        f"{cfg['in_channels']} latent, FR UNet, {el:.1f} s")
 
 
+def train_mode(a, rank, world, dev, dist, backend, barrier, graph):
+    """BASELINE configs[4]: one optimisation step = q_sample + UNet forward + hand-written backward
+    (hipGraph-captured) + gradient all-reduce over the ranks + AdamW + EMA, fixed batch per GPU (weak scaling)."""
+    from dsml_thesis_amd.train import UNetTrainer
+    from oracle import ldm_oracle as O, weights as W     # schedule constants only (host tables)
+    latent = 32 if a.latent == 64 and "--latent" not in " ".join(sys.argv) else a.latent
+    model, ucfg = build_model(latent, dev)
+    tr = UNetTrainer(model.model.diffusion_model)
+    sched = O.register_schedule(**W.SCHEDULE)
+    sa, sb = sched["sqrt_alphas_cumprod"].to(dev), sched["sqrt_one_minus_alphas_cumprod"].to(dev)
+    n, c = a.batch, ucfg["in_channels"]
+    g = torch.Generator(device="cpu").manual_seed(100 + rank)
+    x0 = torch.randn(n, c, latent, latent, generator=g).to(dev)
+    noise = torch.randn(n, ucfg["out_channels"], latent, latent, generator=g).to(dev)
+    ctx = torch.randn(n, 1, ucfg["context_dim"], generator=g).to(dev)
+    t = torch.randint(0, 1000, (n,), generator=g).to(dev)
+    shadow = tr.P.flat.clone()
+    loss_buf = torch.zeros(1, device=dev)
+
+    def fwd_bwd():
+        loss_buf.copy_(tr.p_losses(x0, ctx, t, noise, sa, sb))
+
+    for _ in range(2):
+        fwd_bwd()
+    torch.cuda.synchronize()
+    run = fwd_bwd
+    if graph:
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            fwd_bwd()
+        run = gr.replay
+
+    def step():
+        run()
+        if dist is not None:
+            if backend == "nccl":
+                tr.all_reduce_grads(world)
+            else:                                  # gloo rehearsal on a shared GPU
+                dist.all_reduce(tr.P.grad)
+                tr.P.grad.mul_(1.0 / world)
+        tr.adamw_step(lr=1e-6)
+        tr.ema_update(shadow, 0.9999)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = tt.item()
+    assert torch.isfinite(loss_buf).all()
+    fwd_gemm = (42.17 if latent == 32 else 168.62) * 1e9 * n
+    fwd_attn = (3.84 if latent == 32 else 61.43) * 1e9 * n
+    flops = world * (3 * fwd_gemm + 3.5 * fwd_attn)
+    ms = 1e3 * el / a.steps
+    out = {"metric": "UNet training samples/sec (p_losses forward+backward+AdamW+EMA), BASELINE configs[4]",
+           "value": round(world * n * a.steps / el, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"face_reenactment UNet fine-tune step (latent_manipulation_tuned.py / main.py -t), "
+                                  f"{n} samples/GPU, {latent}x{latent}x{c} latent, fp32 (BASELINE asks bf16: fp32 is the "
+                                  f"higher precision), AdamW + EMA, random-init weights", "batch_per_gpu": n,
+                      "global_batch": n * world, "hipgraph": graph,
+                      "parallelism": f"dp{world} (one all-reduce of the 627 MB flat gradient buffer per step)"},
+           "step_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+           "roofline": {"bound": "mfma", "achieved": round(flops / world / (ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA,
+                        "unit": "TFLOP/s", "frac": round(flops / world / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA, 4),
+                        "traffic": None, "kernel": "whole step (igemm + wgrad + attention fwd/bwd), 3x forward GEMM FLOPs"},
+           "cpu_baseline": None, "loss": float(loss_buf.item())}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +253,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--train", action="store_true",
+                    help="measure BASELINE configs[4] instead (UNet p_losses forward+backward+AdamW+EMA, fp32, data-"
+                         "parallel with one all-reduce of the flat gradient buffer); not the default metric")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,6 +308,9 @@ def main():
         return run, el
 
     graph = not a.no_graph
+    if a.train:
+        train_mode(a, rank, world, dev, dist, backend, barrier, graph)
+        return
     run, el = measure(a.latent, a.steps, a.warmup, graph)
     value = world * a.batch * a.steps / el
     ms = 1e3 * el / a.steps
