@@ -86,6 +86,8 @@ class UNetTrainer:
         self.G = {}            # activation data_ptr -> (grad tensor)
         self.ginit = set()
         self._stats = {}       # activation data_ptr -> (tensor, GroupNorm partial records emitted by its producer GEMM)
+        self.acc_params = False   # True: backward() adds to P.grad (several passes per step: differentiable DDIM, N2)
+        self.want_dx = False      # True: backward() also returns the gradient w.r.t. the network input
 
     # ---- parameters -----------------------------------------------------------------------------------------
     def _collect(self):
@@ -185,9 +187,9 @@ class UNetTrainer:
         """Parameter gradients of out = [x2d|x1] @ W + b and (optionally) the data gradient dy @ W^T."""
         g, p = self.P.g, self.P.p
         c0 = x2d.shape[1]
-        T.wgrad_linear(x2d, dy, dw=g[wname][:c0], dbias=None if bname is None else g[bname])
+        T.wgrad_linear(x2d, dy, dw=g[wname][:c0], dbias=None if bname is None else g[bname], accumulate=self.acc_params)
         if x1 is not None:
-            T.wgrad_linear(x1, dy, dw=g[wname][c0:])
+            T.wgrad_linear(x1, dy, dw=g[wname][c0:], accumulate=self.acc_params)
         if not need_dx:
             return None
         return self._lin_dx(dy, p[wname][:c0] if x1 is not None else p[wname])
@@ -220,7 +222,7 @@ class UNetTrainer:
         g, p = self.P.g, self.P.p
         n, oh, ow, cout = dy4.shape
         _, h, w_, c = x4.shape
-        T.wgrad_conv3x3(x4, dy4, stride=stride, upsample=upsample, dw=g[wname], dbias=g[bname])
+        T.wgrad_conv3x3(x4, dy4, stride=stride, upsample=upsample, dw=g[wname], dbias=g[bname], accumulate=self.acc_params)
         if not need_dx:
             return None
         wd = T.pack_dgrad3x3(p[wname], c, cout)
@@ -254,7 +256,7 @@ class UNetTrainer:
         dx0, a0 = self._grad(x0)
         dx1, a1 = (None, False) if x1 is None else self._grad(x1)
         T.gn_bwd(x0, x1, dy2d, coef, mr, p[gname], n, hw, silu=silu, dx0=dx0, acc0=a0, dx1=dx1, acc1=a1,
-                 dgamma=g[gname], dbeta=g[bname])
+                 dgamma=g[gname], dbeta=g[bname], acc_params=self.acc_params)
 
     # ---- blocks -------------------------------------------------------------------------------------------
     def _res_block(self, prefix, m, x0, x1, h, w, emb_all, d_emb_all, emb_off):
@@ -290,11 +292,11 @@ class UNetTrainer:
                 g, p = self.P.g, self.P.p
                 g[prefix + "skip_connection.bias"].copy_(g[prefix + "out_layers.3.bias"])   # same column sums of dout
                 c0 = x0.shape[-1]
-                T.wgrad_linear(x0.view(n * hw, -1), d2, dw=g[prefix + "skip"][:c0])
+                T.wgrad_linear(x0.view(n * hw, -1), d2, dw=g[prefix + "skip"][:c0], accumulate=self.acc_params)
                 self._lin_dx(d2, p[prefix + "skip"][:c0], out=dx0.view(n * hw, -1), residual=dx0.view(n * hw, -1))
                 if x1 is not None:
                     dx1 = self._take(x1)
-                    T.wgrad_linear(x1.view(n * hw, -1), d2, dw=g[prefix + "skip"][c0:])
+                    T.wgrad_linear(x1.view(n * hw, -1), d2, dw=g[prefix + "skip"][c0:], accumulate=self.acc_params)
                     self._lin_dx(d2, p[prefix + "skip"][c0:], out=dx1.view(n * hw, -1), residual=dx1.view(n * hw, -1))
             else:
                 T.axpy_(dx0, dout, 1.0)
@@ -342,13 +344,13 @@ class UNetTrainer:
                 dln3 = self._lin_bwd(dpre, ln3, q + "ff1n", q + "ff.net.0.proj.bias")
                 del dpre
                 T.ln_bwd(dln3, h1, st3, p[q + "norm3.weight"], dx=dh, acc_dx=True, dgamma=g[q + "norm3.weight"],
-                         dbeta=g[q + "norm3.bias"])                                # dh is now d(h1)
+                         dbeta=g[q + "norm3.bias"], acc_params=self.acc_params)     # dh is now d(h1)
                 del dln3
                 # ---- attention: h1 = hin + to_out(attn(LN1(hin))) + cvec[sample]
                 dcvec = T.colsum(dh, rows_per_group=hw)
                 datt = self._lin_bwd(dh, att, q + "o1", q + "attn1.to_out.0.bias")
                 dv = self._lin_bwd(dcvec, v, q + "o2", q + "attn2.to_out.0.bias")
-                T.wgrad_linear(ctx, dv, dw=g[q + "v2"])
+                T.wgrad_linear(ctx, dv, dw=g[q + "v2"], accumulate=self.acc_params)
                 first = not self._dctx_init
                 self._lin_dx(dv, p[q + "v2"], out=dctx, residual=None if first else dctx)
                 self._dctx_init = True
@@ -357,7 +359,7 @@ class UNetTrainer:
                 dln1 = self._lin_bwd(dqkv, ln1, q + "qkv", None)
                 del dqkv
                 T.ln_bwd(dln1, hin, st1, p[q + "norm1.weight"], dx=dh, acc_dx=True, dgamma=g[q + "norm1.weight"],
-                         dbeta=g[q + "norm1.bias"])                                # dh is now d(hin)
+                         dbeta=g[q + "norm1.bias"], acc_params=self.acc_params)     # dh is now d(hin)
                 del dln1
             dxn = self._lin_bwd(dh, xn, prefix + "pin", prefix + "proj_in.bias")
             self._gn_bwd(dxn, x, None, hw, sx, prefix + "norm.weight", prefix + "norm.bias", False)
@@ -420,7 +422,9 @@ class UNetTrainer:
         h0 = self._conv(xp, "in.wpad", "input_blocks.0.0.bias")
 
         def bwd_in():
-            self._conv_bwd(self._take(h0), xp, "in.wpad", "input_blocks.0.0.bias", need_dx=False)
+            dxp = self._conv_bwd(self._take(h0), xp, "in.wpad", "input_blocks.0.0.bias", need_dx=self.want_dx)
+            if dxp is not None:
+                self._dx = dxp[..., :cin].permute(0, 3, 1, 2).contiguous()
         self.tape.append(bwd_in)
 
         def run_layers(prefix, layers, x0, x1, h, w):
@@ -463,15 +467,31 @@ class UNetTrainer:
             self._gn_bwd(dyo.view(n * hw, -1), h_final, None, hw, so, "out.0.weight", "out.0.bias", True)
         self.tape.append(bwd_out)
         self.eps_pad = eps_pad
+        self.last_pass = dict(tape=self.tape, G=self.G, ginit=self.ginit, eps_pad=eps_pad, dctx=self.dctx)
         return eps_pad[..., :u.out_channels].permute(0, 3, 1, 2).contiguous()
 
-    def backward(self, deps_pad):
-        """deps_pad: gradient w.r.t. the channel-padded NHWC output (n,H,W,32).  Fills P.grad and self.dctx."""
+    def backward(self, deps_pad, pass_=None):
+        """deps_pad: gradient w.r.t. the channel-padded NHWC output (n,H,W,32) of the pass `pass_` (default: the last
+        forward).  Fills (or, with acc_params, adds to) P.grad, sets self.dctx; returns d(loss)/d(input) when want_dx."""
+        ps = self.last_pass if pass_ is None else pass_
+        self.tape, self.G, self.ginit, self.eps_pad, self.dctx = ps["tape"], ps["G"], ps["ginit"], ps["eps_pad"], ps["dctx"]
+        self._dctx_init = False
         self._alias_grad(self.eps_pad, deps_pad)
         self._stats = {}
+        self._dx = None
         for fn in reversed(self.tape):
             fn()
         self.tape, self.G, self.ginit = [], {}, set()
+        ps["tape"] = ps["G"] = ps["ginit"] = None             # the saved activations die with the closures
+        return self._dx
+
+    @staticmethod
+    def pad_output_grad(deps_nchw):
+        """(n,C_out,H,W) gradient -> the channel-padded NHWC layout backward() takes."""
+        n, co, H, W_ = deps_nchw.shape
+        out = torch.zeros(n, H, W_, 32, device=deps_nchw.device)
+        out[..., :co] = deps_nchw.permute(0, 2, 3, 1)
+        return out
 
     # ---- p_losses / optimizer -------------------------------------------------------------------------------
     def p_losses(self, x_start, context, t, noise, sqrt_ac, sqrt_1mac, c_concat=None):

@@ -276,3 +276,79 @@ def test_data_parallel_gradients_equal_full_batch_gradients():
     g1 = tr.P.grad.cpu()
     err = (g1 - g2).abs().max().item() / g1.abs().max().item()
     assert err <= 2e-5, f"sharded-and-averaged vs full-batch gradients: {err:.3e}"
+
+
+def test_differentiable_decode_first_stage_input_gradient():
+    """N2: VQGAN decode with the straight-through quantiser; d(image)/d(latent) against float64 autograd on the oracle."""
+    from dsml_thesis_amd.autoencoder import VQModelInterface
+    from dsml_thesis_amd.train_decoder import DecoderGrad
+    fs = W.VQ_F4
+    vq = VQModelInterface(embed_dim=fs["embed_dim"], n_embed=fs["n_embed"], ddconfig=dict(fs["ddconfig"]),
+                          lossconfig=dict(target="torch.nn.Identity"))
+    vsd = W.synth_state_dict(W.vqmodel_param_shapes(fs))
+    vq.load_state_dict(vsd, strict=False)
+    vq = vq.cuda().eval()
+    z = rnd(301, 1, 3, 8, 8)
+    dec = DecoderGrad(vq)
+    img = dec.forward(z.cuda())
+    dimg = rnd(302, *img.shape)
+    dz = dec.backward(dimg.cuda())
+    v64 = {k: v.double() for k, v in vsd.items()}
+    zz = z.double().requires_grad_(True)
+    zq, _ = O.vq_quantize(zz.detach().float(), vsd["quantize.embedding.weight"])
+    zst = zz + (zq.double() - zz).detach()                       # straight-through estimator, quantize.py:299
+    ref = O.decoder_forward(v64, fs["ddconfig"], F.conv2d(zst, v64["post_quant_conv.weight"], v64["post_quant_conv.bias"]))
+    ref.backward(dimg.double())
+    torch.testing.assert_close(img.cpu().double(), ref.detach(), rtol=2e-4, atol=2e-4)
+    err = (dz.cpu().double() - zz.grad).abs().max().item() / zz.grad.abs().max().item()
+    assert err <= 1e-4, f"decoder input gradient: {err:.3e}"
+
+
+def test_differentiable_ddim_two_steps_with_guidance():
+    """N2: two eta=0 DDIM steps with classifier-free guidance (batch doubling) + differentiable decode; UNet parameter
+    gradients accumulated over the steps and d(loss)/d(x_T) against float64 autograd on the oracle."""
+    from dsml_thesis_amd.autoencoder import VQModelInterface
+    from dsml_thesis_amd.schedule import ddim_step_table
+    from dsml_thesis_amd.train_decoder import DecoderGrad, DifferentiableDDIM
+    m, tr, sd, *_ = _setup(SMALL, 1, 8)
+    fs = W.VQ_F4
+    vq = VQModelInterface(embed_dim=fs["embed_dim"], n_embed=fs["n_embed"], ddconfig=dict(fs["ddconfig"]),
+                          lossconfig=dict(target="torch.nn.Identity"))
+    vsd = W.synth_state_dict(W.vqmodel_param_shapes(fs))
+    vq.load_state_dict(vsd, strict=False)
+    vq = vq.cuda().eval()
+    sched = O.register_schedule(**W.SCHEDULE)
+    ts = np.asarray([201, 601])
+    table = ddim_step_table(sched["alphas_cumprod"], ts, 0.0)
+    x_T, c, uc = rnd(311, 1, 3, 8, 8), rnd(312, 1, 1, 512), rnd(313, 1, 1, 512)
+    scale = 2.0
+
+    class _M:                                  # the two attributes DifferentiableDDIM reads from the LatentDiffusion
+        scale_factor = 1.0
+    dd = DifferentiableDDIM(_M(), trainer=tr, decoder=DecoderGrad(vq))
+    img = dd.forward(x_T.cuda(), c.cuda(), table, ts, scale=scale, uc=uc.cuda())
+    target = rnd(314, *img.shape)
+    dimg = (2.0 / img.numel()) * (img - target.cuda())          # d mean((img-target)^2) / d img
+    dx = dd.backward(dimg)
+
+    sdg = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    v64 = {k: v.double() for k, v in vsd.items()}
+    x = x_T.double().requires_grad_(True)
+    xi = x
+    for i in reversed(range(len(ts))):
+        a_t, a_prev, sig, s1m = (float(v) for v in table[i])
+        tt = torch.full((1,), int(ts[i]))
+        e2 = O.unet_forward(sdg, SMALL, torch.cat([xi, xi]), torch.cat([tt, tt]), torch.cat([uc, c]).double())
+        e_t = e2[:1] + scale * (e2[1:] - e2[:1])
+        pred_x0 = (xi - s1m * e_t) / a_t ** 0.5                  # ddim2.py:281-289 with sigma = 0
+        xi = a_prev ** 0.5 * pred_x0 + (1.0 - a_prev) ** 0.5 * e_t
+    zq, _ = O.vq_quantize(xi.detach().float(), vsd["quantize.embedding.weight"])
+    zst = xi + (zq.double() - xi).detach()
+    ref = O.decoder_forward(v64, fs["ddconfig"], F.conv2d(zst, v64["post_quant_conv.weight"], v64["post_quant_conv.bias"]))
+    loss = F.mse_loss(ref, target.double())
+    loss.backward()
+    torch.testing.assert_close(img.cpu().double(), ref.detach(), rtol=5e-4, atol=5e-4)
+    err = (dx.cpu().double() - x.grad).abs().max().item() / x.grad.abs().max().item()
+    assert err <= 5e-4, f"d loss / d x_T: {err:.3e}"
+    worst = _check_all_grads(m, tr, {k: v.grad for k, v in sdg.items()}, 5e-4)
+    print("worst accumulated gradient error", worst)
