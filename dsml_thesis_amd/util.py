@@ -10,6 +10,7 @@ TARGET_MAP = {
     "ldm.models.diffusion.ddpm.LatentDiffusion": "dsml_thesis_amd.ddpm.LatentDiffusion",
     "ldm.models.diffusion.ddpm2cond.LatentDiffusion": "dsml_thesis_amd.ddpm.LatentDiffusion2Cond",
     "ldm.models.diffusion.ddpm.DiffusionWrapper": "dsml_thesis_amd.ddpm.DiffusionWrapper",
+    "ldm.models.diffusion.latent_diffclip.LatentDiffusionCLIP": "dsml_thesis_amd.latent_diffclip.LatentDiffusionCLIP",
     "ldm.modules.encoders.modules.ClassEmbedder3": "dsml_thesis_amd.encoders.ClassEmbedder3",
     "ldm.modules.encoders.modules.ClassEmbedder": "dsml_thesis_amd.encoders.ClassEmbedder",
     "ldm.modules.encoders.modules.Conv1DTemporalAttention": "dsml_thesis_amd.encoders.Conv1DTemporalAttention",

@@ -352,3 +352,31 @@ def test_differentiable_ddim_two_steps_with_guidance():
     assert err <= 5e-4, f"d loss / d x_T: {err:.3e}"
     worst = _check_all_grads(m, tr, {k: v.grad for k, v in sdg.items()}, 5e-4)
     print("worst accumulated gradient error", worst)
+
+
+def test_latent_diffusion_clip_finetune_step():
+    """LatentDiffusionCLIP surface (latent_diffclip.py:969-1033) with the l2 image loss: one fine-tune step through
+    3 differentiable DDIM steps (strength 0.3, guidance 2) + decode lowers the loss on the same batch."""
+    from helpers import fr_config
+    from dsml_thesis_amd.util import instantiate_from_config
+    from helpers import load_recipe
+    cfg = fr_config(unet=SMALL)
+    cfg.update(strength=0.3, num_train_steps=3, num_test_steps=4, unconditional_guidance_scale=2.0, cls_loss_w=0.0,
+               clip_loss_w=0.0, id_loss_w=0.0, l2_loss_w=1.0, edit_attr="happy")
+    model = instantiate_from_config({"target": "ldm.models.diffusion.latent_diffclip.LatentDiffusionCLIP", "params": cfg})
+    load_recipe(model.model.diffusion_model)
+    load_recipe(model.first_stage_model)
+    load_recipe(model.cond_stage_model)
+    model = model.cuda().train()
+    assert list(model.train_ddim_timesteps) == [1, 150, 300] and model.trg == 1
+    x = rnd(401, 1, 3, 16, 16).cuda()
+    x0 = torch.tanh(rnd(402, 1, 3, 64, 64)).cuda()
+    l0, ld = model.training_step_latents(x, ["face"], x0, lr=2e-6)
+    assert set(ld) == {"train_l2_loss", "train_loss"} and torch.isfinite(l0)
+    g = model.trainer().P.grad
+    assert torch.isfinite(g).all() and g.abs().max().item() > 0
+    l1, _ = model.training_step_latents(x, ["face"], x0, lr=2e-6)
+    assert l1.item() < l0.item(), (l0.item(), l1.item())
+    model.id_loss_w = 1.0
+    with pytest.raises(NotImplementedError):
+        model(x, ["face"], x0)
