@@ -238,3 +238,52 @@ def test_g9_p_losses_backward_pins_the_oracle_autograd():
     for k in g.files:
         if k.startswith("grad:"):
             torch.testing.assert_close(sdg[k[5:]].grad, torch.from_numpy(g[k]), rtol=2e-4, atol=1e-6 * float(np.abs(g[k]).max()))
+
+
+def _oracle_diffclip(dtype=torch.float32):
+    """The oracle's restatement of G10: 3 differentiable DDIM steps (ddim2.py:252-290, guidance 2 by batch doubling),
+    differentiable decode (straight-through VQ), l2 image loss; returns everything autograd produced."""
+    import torch.nn.functional as F
+    from dsml_thesis_amd.schedule import ddim_step_table, make_ddim_timesteps_strength
+    cfg = dict(W.FR_UNET, model_channels=64, channel_mult=[1, 2], num_res_blocks=1, attention_resolutions=[2, 1])
+    sd = W.synth_state_dict(W.unet_param_shapes(cfg))
+    vsd = W.synth_state_dict(W.vqmodel_param_shapes(W.VQ_F4))
+    sdg = {k: v.to(dtype).requires_grad_(True) for k, v in sd.items()}
+    v = {k: t.to(dtype) for k, t in vsd.items()}
+    sched = O.register_schedule(**W.SCHEDULE)
+    ts = make_ddim_timesteps_strength(3, 1000, 0.3)
+    table = ddim_step_table(sched["alphas_cumprod"], ts, 0.0)
+    x = rnd(401, 1, 3, 16, 16).to(dtype).requires_grad_(True)
+    x0 = torch.tanh(rnd(402, 1, 3, 64, 64)).to(dtype)
+    c, uc = rnd(403, 1, 1, 512).to(dtype), rnd(404, 1, 1, 512).to(dtype)
+    with torch.enable_grad():
+        xi = x
+        for i in reversed(range(len(ts))):
+            a_t, a_prev, _, s1m = (float(q) for q in table[i])
+            tt = torch.full((1,), int(ts[i]))
+            e2 = O.unet_forward(sdg, cfg, torch.cat([xi, xi]), torch.cat([tt, tt]), torch.cat([uc, c]))
+            e_t = e2[:1] + 2.0 * (e2[1:] - e2[:1])
+            pred_x0 = (xi - s1m * e_t) / a_t ** 0.5
+            xi = a_prev ** 0.5 * pred_x0 + (1.0 - a_prev) ** 0.5 * e_t
+        zq, _ = O.vq_quantize(xi.detach().float(), vsd["quantize.embedding.weight"])
+        zst = xi + (zq.to(dtype) - xi).detach()
+        img = O.decoder_forward(v, W.VQ_F4["ddconfig"], F.conv2d(zst, v["post_quant_conv.weight"], v["post_quant_conv.bias"]))
+        loss = F.mse_loss(img, x0)
+        loss.backward()
+    return ts, xi.detach(), img.detach(), loss.detach(), x.grad, {k: t.grad for k, t in sdg.items()}
+
+
+def test_g10_differentiable_ddim_pins_the_oracle():
+    g = golden("g10_diffclip.npz")
+    ts, z, img, loss, dx, grads = _oracle_diffclip()
+    assert list(ts) == list(g["timesteps"])
+    torch.testing.assert_close(z, torch.from_numpy(g["z"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(img, torch.from_numpy(g["image"]).float(), rtol=2e-3, atol=2e-3)      # stored as fp16
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    torch.testing.assert_close(dx, torch.from_numpy(g["dx"]), rtol=1e-3, atol=1e-6 * float(np.abs(g["dx"]).max()) + 1e-9)
+    stats = dict(zip([str(n) for n in g["names"]], g["stats"]))
+    for k, (_, n_ref) in stats.items():
+        if grads[k] is None:
+            assert n_ref == 0.0, k
+        else:
+            assert abs(grads[k].double().norm().item() - n_ref) <= 1e-3 * n_ref + 1e-12, k

@@ -380,3 +380,41 @@ def test_latent_diffusion_clip_finetune_step():
     model.id_loss_w = 1.0
     with pytest.raises(NotImplementedError):
         model(x, ["face"], x0)
+
+
+def test_differentiable_ddim_against_reference_fixture():
+    """tests/golden/g10_diffclip.npz: the reference's ddim2.differentiable_p_sample_ddim x3 (guidance 2) +
+    differentiable_decode_first_stage + l2 loss + autograd (tools/make_golden.py --tree diffclip)."""
+    from dsml_thesis_amd.autoencoder import VQModelInterface
+    from dsml_thesis_amd.schedule import ddim_step_table
+    from dsml_thesis_amd.train_decoder import DecoderGrad, DifferentiableDDIM
+    g = golden("g10_diffclip.npz")
+    m, tr, sd, *_ = _setup(SMALL, 1, 16)
+    fs = W.VQ_F4
+    vq = VQModelInterface(embed_dim=fs["embed_dim"], n_embed=fs["n_embed"], ddconfig=dict(fs["ddconfig"]),
+                          lossconfig=dict(target="torch.nn.Identity"))
+    vq.load_state_dict(W.synth_state_dict(W.vqmodel_param_shapes(fs)), strict=False)
+    vq = vq.cuda().eval()
+    sched = O.register_schedule(**W.SCHEDULE)
+    ts = g["timesteps"]
+    table = ddim_step_table(sched["alphas_cumprod"], ts, 0.0)
+
+    class _M:
+        scale_factor = 1.0
+    dd = DifferentiableDDIM(_M(), trainer=tr, decoder=DecoderGrad(vq))
+    x, x0 = rnd(401, 1, 3, 16, 16).cuda(), torch.tanh(rnd(402, 1, 3, 64, 64)).cuda()
+    img = dd.forward(x, rnd(403, 1, 1, 512).cuda(), table, ts, scale=2.0, uc=rnd(404, 1, 1, 512).cuda())
+    torch.testing.assert_close(dd.z.cpu(), torch.from_numpy(g["z"]), rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(img.cpu(), torch.from_numpy(g["image"]).float(), rtol=2e-3, atol=2e-3)
+    loss = F.mse_loss(img, x0)
+    assert abs(loss.item() - float(g["loss"])) <= 5e-5 * float(g["loss"])
+    dx = dd.backward((2.0 / img.numel()) * (img - x0))
+    ref_dx = torch.from_numpy(g["dx"])
+    assert (dx.cpu() - ref_dx).abs().max().item() <= 1e-3 * ref_dx.abs().max().item()
+    stats = dict(zip([str(n) for n in g["names"]], g["stats"]))
+    for name, ref in (("in.wpad", "input_blocks.0.0.weight"), ("te0", "time_embed.0.weight"),
+                      ("output_blocks.1.0.c1", "output_blocks.1.0.in_layers.2.weight"),
+                      ("middle_block.1.transformer_blocks.0.ff2", "middle_block.1.transformer_blocks.0.ff.net.2.weight"),
+                      ("input_blocks.2.0.w", "input_blocks.2.0.op.weight"), ("out.0.weight", "out.0.weight")):
+        got, want = tr.P.g[name].double().norm().item(), stats[ref][1]
+        assert abs(got - want) <= 1e-3 * want, (name, got, want)

@@ -420,6 +420,60 @@ def gen_train():
     torch.set_grad_enabled(False)
 
 
+def gen_diffclip():
+    """G10 (row N2): the reference's differentiable DDIM (ddim2.DDIMSampler2.differentiable_p_sample_ddim, CFG by batch
+    doubling) + differentiable_decode_first_stage (ddpm.py:767-824) + an l2 image loss, autograd backward:
+    decoded image, loss, d(loss)/d(x), per-parameter UNet gradient norms."""
+    from tools import ref_shims
+    ref_shims.install("face_reenactment")
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.ddim2 import DDIMSampler2
+    unet_cfg = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(TRAIN_UNET))
+    fs_cfg = dict(target="ldm.models.autoencoder.VQModelInterface",
+                  params=dict(embed_dim=3, n_embed=16384, ddconfig=dict(W.VQ_F4["ddconfig"]),
+                              lossconfig=dict(target="torch.nn.Identity")))
+    cond_cfg = dict(target="ldm.modules.encoders.modules.ClassEmbedder3",
+                    params=dict(embed_dim=512, n_classes=8, key="class_label", p_uncond=0.2))
+    ld = LatentDiffusion(first_stage_config=fs_cfg, cond_stage_config=cond_cfg, num_timesteps_cond=1,
+                         cond_stage_key="class_label", cond_stage_trainable=True, conditioning_key="crossattn",
+                         unet_config=unet_cfg, image_size=16, channels=3, first_stage_key="image", log_every_t=200,
+                         monitor="val_loss_ema", **W.SCHEDULE)
+    unet = ld.model.diffusion_model
+    load_recipe(unet, seed=0, prefix_check=W.unet_param_shapes(TRAIN_UNET))
+    load_recipe(ld.first_stage_model, seed=0, prefix_check=W.vqmodel_param_shapes(W.VQ_F4))
+    ld.train()
+
+    class CPU2(DDIMSampler2):
+        def register_buffer(self, n, a):
+            setattr(self, n, a)
+
+    sm = CPU2(ld)
+    sm.make_schedule(ddim_num_steps=3, ddim_eta=0.0, strength=0.3, verbose=False)
+    torch.set_grad_enabled(True)
+    x = rnd(401, 1, 3, 16, 16).requires_grad_(True)
+    x0 = torch.tanh(rnd(402, 1, 3, 64, 64))
+    c, uc = rnd(403, 1, 1, 512), rnd(404, 1, 1, 512)
+    ts = sm.ddim_timesteps
+    xi = x
+    for i, step in enumerate(np.flip(ts)):
+        index = len(ts) - i - 1
+        tt = torch.full((1,), int(step), dtype=torch.long)
+        xi, _ = sm.differentiable_p_sample_ddim(x=xi, c=c, t=tt, index=index, unconditional_guidance_scale=2.0,
+                                                 unconditional_conditioning=uc)
+    img = ld.differentiable_decode_first_stage(xi)
+    loss = torch.nn.functional.mse_loss(img, x0)
+    loss.backward()
+    names, stats = [], []
+    for k, p_ in unet.named_parameters():
+        g = torch.zeros_like(p_) if p_.grad is None else p_.grad
+        names.append(k)
+        stats.append([g.double().sum().item(), g.double().norm().item()])
+    save("g10_diffclip.npz", timesteps=ts, z=xi.detach(), image=img.detach().half(), loss=loss.detach(), dx=x.grad,
+         image_stats=np.asarray([img.abs().max().item(), img.mean().item(), img.std().item()]),
+         names=np.asarray(names), stats=np.asarray(stats, dtype=np.float64))
+    torch.set_grad_enabled(False)
+
+
 # --------------------------------------------------------------------------- TF tree
 def gen_tf():
     from tools import ref_shims
@@ -525,16 +579,18 @@ def gen_tf():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train"])
+    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip"])
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     if a.tree == "train":
         gen_train()
+    elif a.tree == "diffclip":
+        gen_diffclip()
     elif a.tree == "face_reenactment":
         gen_fr()
     elif a.tree == "talking_face":
         gen_tf()
     else:
-        for tree in ("face_reenactment", "talking_face", "train"):
+        for tree in ("face_reenactment", "talking_face", "train", "diffclip"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", tree], cwd=ROOT)
