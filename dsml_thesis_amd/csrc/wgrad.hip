@@ -234,7 +234,7 @@ static int wgrad_plan_splitr(const ldmk_wgrad_args& a, int cfg) {
   wgrad_tile(cfg, &bm, &bn);
   const long long tiles = (long long)((a.Kw + bm - 1) / bm) * ((a.N + bn - 1) / bn) * (a.batch > 1 ? a.batch : 1);
   const int iters = (a.R + 31) / 32;
-  long long s = (512 + tiles - 1) / tiles;        // aim at one full round of 2 workgroups per CU ...
+  long long s = 512 / tiles;                       // fill, but never overflow, one round of 2 workgroups per CU ...
   if (s > iters / 8) s = iters / 8;                // ... but keep >= 8 slices per workgroup (slab write + reduce cost)
   if (s > 256) s = 256;
   if (s < 1) s = 1;
