@@ -19,7 +19,12 @@ _PLAN_TABLE = None
 
 def plan_key(a, m):
     """Shape signature of an igemm problem for the tuned-plan table (m = the row count the plan is made for)."""
-    return f"{m},{a.N},{a.K},{a.a_mode},{a.a_tf},{a.epi},{max(1, a.batch)}"
+    key = f"{m},{a.N},{a.K},{a.a_mode},{a.a_tf},{a.epi},{max(1, a.batch)}"
+    if a.b_trans:                 # data-gradient GEMMs of the training step read W^T: tuned separately
+        key += ",bt"
+    if a.a_mode == L.A_CONV3X3 and (a.stride != 1 or a.upsample):
+        key += f",s{a.stride}u{a.upsample}"
+    return key
 
 
 def plan_table():

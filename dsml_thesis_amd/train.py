@@ -25,6 +25,7 @@ from . import train_ops as T
 from .engine import tuned_plan
 
 _SK_WS = {}
+RECORD = None      # tools/autotune.py --train: list collecting one (args, keepalive tensors) entry per distinct GEMM shape
 
 
 def _splitk_ws(dev, elems=64 * 1024 * 1024):
@@ -38,6 +39,8 @@ def _splitk_ws(dev, elems=64 * 1024 * 1024):
 def gemm(a, dev):
     """ldmk_igemm with the tuned (tile, split-K) plan when the shape is in the table, a shared split-K scratch."""
     ws = _splitk_ws(dev)
+    if RECORD is not None:
+        RECORD.append(a)
     plan = tuned_plan(a, a.M) if a.batch <= 1 else None
     if plan is not None and max(1, a.batch) * plan[1] * a.M * a.N <= ws.numel():
         a.tile_cfg, a.splitk = plan

@@ -109,7 +109,7 @@ def test_tuned_plan_table_is_legal_and_nearest():
     assert table, "tuned plan table missing"
     wk = {1: 1, 2: 2, 3: 4, 4: 2, 5: 1, 6: 2}
     for key, rows in table.items():
-        n, k, mode, tf, epi, nb = (int(v) for v in key.split(","))
+        n, k, mode, tf, epi, nb = (int(v) for v in key.split(",")[:6])      # optional suffixes: ",bt", ",s<stride>u<ups>"
         assert [r[0] for r in rows] == sorted(r[0] for r in rows)
         for m, cfg, sk in rows:
             assert 1 <= cfg <= 6 and sk in (1, 2, 3, 4, 6, 8, 12, 16)

@@ -46,6 +46,38 @@ def time_call(lib, a, st, reps=5):
 def tune(kind, latent, batch, table):
     from bench import StepRunner, build_model
     model, ucfg = build_model(latent, torch.device("cuda", 0))
+    if kind == "train":
+        # the eager training step: record every GEMM it issues (forward, data gradients), then sweep the distinct shapes
+        from dsml_thesis_amd import train as TR
+        from oracle import ldm_oracle as O, weights as W
+        tr = TR.UNetTrainer(model.model.diffusion_model)
+        sched = O.register_schedule(**W.SCHEDULE)
+        dev = torch.device("cuda", 0)
+        g = torch.Generator().manual_seed(0)
+        x0 = torch.randn(batch, ucfg["in_channels"], latent, latent, generator=g).to(dev)
+        noise = torch.randn(batch, ucfg["out_channels"], latent, latent, generator=g).to(dev)
+        ctx = torch.randn(batch, 1, ucfg["context_dim"], generator=g).to(dev)
+        t = torch.randint(0, 1000, (batch,), generator=g).to(dev)
+        TR.RECORD = []
+        # keep every tensor of the step alive so the recorded pointers stay valid during the sweep
+        tr.p_losses(x0, ctx, t, noise, sched["sqrt_alphas_cumprod"].to(dev), sched["sqrt_one_minus_alphas_cumprod"].to(dev))
+        rec, TR.RECORD = TR.RECORD, None
+        torch.cuda.synchronize()
+
+        class _PG:
+            pass
+        pg = _PG()
+        pg.lib = __import__("dsml_thesis_amd.lib", fromlist=["load"]).load()
+        big = torch.empty(512 * 1024 * 1024 // 4, device=dev)      # recorded pointers may be recycled: sweep on scratch operands
+        pg.calls = [(None, None, a, "ldmk_igemm") for a in rec]
+        for a in rec:
+            a.a0 = big.data_ptr()
+            a.a1 = big.data_ptr() if a.c1 else 0
+            a.w = big.data_ptr()
+            a.bias = a.batch_vec = a.residual = a.tf_coef = a.row_stats = a.ln_gamma = a.ln_beta = 0
+            a.a_tf = 0
+        tune_program(pg, table)
+        return
     if kind == "unet":
         run = StepRunner(model, ucfg, batch, graph=False)
         run.step()
