@@ -520,6 +520,21 @@ class UNetTrainer:
         P.step += 1
         T.adamw_(P.flat, P.grad, P.m, P.v, lr, betas, eps, weight_decay, P.step)
 
+    def optimizer_state(self):
+        """Resume point of the optimizer (SURVEY §5 checkpoint/resume): packed weights, AdamW moments, step count."""
+        P = self.P
+        return dict(flat=P.flat.clone(), m=None if P.m is None else P.m.clone(), v=None if P.v is None else P.v.clone(),
+                    step=P.step, layout=[(n_, tuple(s_), o, k) for n_, s_, o, k in P.specs])
+
+    def load_optimizer_state(self, st):
+        P = self.P
+        if [(n_, tuple(s_), o, k) for n_, s_, o, k in P.specs] != list(st["layout"]):
+            raise ValueError("optimizer state was saved for a different UNet configuration (flat layout mismatch)")
+        P.flat.copy_(st["flat"])
+        P.m = None if st["m"] is None else st["m"].to(P.flat.device).clone()
+        P.v = None if st["v"] is None else st["v"].to(P.flat.device).clone()
+        P.step = int(st["step"])
+
     def ema_update(self, shadow_flat, decay):
         T.ema_(shadow_flat, self.P.flat, 1.0 - decay)
 

@@ -418,3 +418,23 @@ def test_differentiable_ddim_against_reference_fixture():
                       ("input_blocks.2.0.w", "input_blocks.2.0.op.weight"), ("out.0.weight", "out.0.weight")):
         got, want = tr.P.g[name].double().norm().item(), stats[ref][1]
         assert abs(got - want) <= 1e-3 * want, (name, got, want)
+
+
+def test_optimizer_state_resume_is_bitwise():
+    """two steps in one go == one step, save, restore into a fresh trainer, one more step."""
+    sched = O.register_schedule(**W.SCHEDULE)
+    sa, sb = sched["sqrt_alphas_cumprod"].cuda(), sched["sqrt_one_minus_alphas_cumprod"].cuda()
+
+    def one(tr, x0, ctx, t, noise):
+        tr.p_losses(x0.cuda(), ctx.cuda(), t.cuda(), noise.cuda(), sa, sb)
+        tr.adamw_step(lr=1e-5)
+
+    m, tr, sd, x0, noise, ctx, t = _setup(SMALL, 2, 16)
+    one(tr, x0, ctx, t, noise)
+    saved = tr.optimizer_state()
+    one(tr, x0, ctx, t, noise)
+    m2, tr2, *_ = _setup(SMALL, 2, 16)
+    tr2.load_optimizer_state(saved)
+    one(tr2, x0, ctx, t, noise)
+    assert tr2.P.step == 2 and torch.equal(tr.P.flat, tr2.P.flat)
+    assert torch.equal(tr.P.m, tr2.P.m) and torch.equal(tr.P.v, tr2.P.v)
