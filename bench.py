@@ -7,7 +7,7 @@ A "step" is one DDIM denoise step (conditioned UNet evaluation + fused DDIM upda
 latents -- BASELINE.json configs[1]: face_reenactment AffectNet emotion-conditioned LDM, DDIM-200 schedule,
 batch 16 per GPU, at the latent size BASELINE.json's metric is quoted on (64x64x4; `--latent 32` selects the
 shipped 32x32x3 shape, which is also measured briefly and reported under "secondary").  Weights are random
-(seeded recipe, oracle/weights.py: no checkpoints exist offline), inputs synthetic and resident in HBM before
+(seeded recipe, dsml_thesis_amd/synth.py: no checkpoints exist offline), inputs synthetic and resident in HBM before
 the timed region.  Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline     -- the igemm (f32 MFMA) kernel family: algorithmic FLOPs of its launches in one step divided by
                   their summed durations, measured with HIP events on the launch stream
@@ -33,11 +33,10 @@ PEAK_F32_MFMA = 157.3  # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32, d
 
 
 def build_model(latent, device):
-    from helpers import make_fr_model
-    from oracle import weights as W
+    from dsml_thesis_amd import synth as W
     unet = W.NS_UNET if latent == 64 else W.FR_UNET
     vq = W.VQ_F4_256 if latent == 64 else W.VQ_F4
-    return make_fr_model(gain=0.25, unet=unet, vq=vq, device=device), unet
+    return W.make_fr_model(gain=0.25, unet=unet, vq=vq, device=device), unet
 
 
 class StepRunner:
@@ -166,12 +165,10 @@ def train_mode(a, rank, world, dev, dist, backend, barrier, graph):
     """BASELINE configs[4]: one optimisation step = q_sample + UNet forward + hand-written backward
     (hipGraph-captured) + gradient all-reduce over the ranks + AdamW + EMA, fixed batch per GPU (weak scaling)."""
     from dsml_thesis_amd.train import UNetTrainer
-    from oracle import ldm_oracle as O, weights as W     # schedule constants only (host tables)
     latent = 32 if a.latent == 64 and "--latent" not in " ".join(sys.argv) else a.latent
     model, ucfg = build_model(latent, dev)
     tr = UNetTrainer(model.model.diffusion_model)
-    sched = O.register_schedule(**W.SCHEDULE)
-    sa, sb = sched["sqrt_alphas_cumprod"].to(dev), sched["sqrt_one_minus_alphas_cumprod"].to(dev)
+    sa, sb = model.sqrt_alphas_cumprod, model.sqrt_one_minus_alphas_cumprod
     n, c = a.batch, ucfg["in_channels"]
     g = torch.Generator(device="cpu").manual_seed(100 + rank)
     x0 = torch.randn(n, c, latent, latent, generator=g).to(dev)

@@ -1,8 +1,9 @@
 """TEST INFRASTRUCTURE ONLY (oracle/) -- synthetic seeded weights + state-dict key enumeration.
 
 Nothing in the product package imports this file.  It is used by tests/, by
-`__graft_entry__.smoke()` and by `bench.py` (to synthesise weights of the reference
-architecture; there are no checkpoints offline).
+`__graft_entry__.smoke()` (the checker side) and by `bench.py`'s cpu_baseline leg.  The timed legs
+build their synthetic models from dsml_thesis_amd/synth.py, which holds its own copy of the recipe and of
+the shipped hyper-parameters (tests/test_host_logic.py checks that the two copies agree bit for bit).
 
 Key enumeration follows the construction order of the reference modules:
   * UNetModel.__init__          /root/reference/face_reenactment/ldm/modules/diffusionmodules/openaimodel.py:443-692

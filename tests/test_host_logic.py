@@ -123,3 +123,15 @@ def test_tuned_plan_table_is_legal_and_nearest():
     near = engine.tuned_plan(a, 57344)            # batch 14: between the tuned 49152 and 65536 buckets
     assert near in (engine.tuned_plan(a, 49152), engine.tuned_plan(a, 65536))
     assert engine.tuned_plan(a, 7) is None        # far from anything tuned: the C++ heuristic decides
+
+
+def test_product_side_recipe_matches_the_oracle_copy():
+    """dsml_thesis_amd/synth.py (benchmarks, tools, smoke) and oracle/weights.py (checker) must describe the same models."""
+    from dsml_thesis_amd import synth as S
+    from oracle import weights as W
+    for name in ("FR_UNET", "TF_UNET", "NS_UNET", "VQ_F4", "VQ_F4_256", "SCHEDULE"):
+        assert getattr(S, name) == getattr(W, name), name
+    for key, shape in (("input_blocks.1.0.in_layers.2.weight", (8, 4, 3, 3)), ("x.bias", (7,)), ("norm.weight", (5,)),
+                       ("embedding.weight", (8, 16)), ("time_embed.0.weight", (6, 3))):
+        for seed, gain in ((0, 1.0), (3, 0.25)):
+            assert np.array_equal(S.synth_tensor(key, shape, seed, gain), W.synth_tensor(key, shape, seed, gain)), key

@@ -49,9 +49,7 @@ def tune(kind, latent, batch, table):
     if kind == "train":
         # the eager training step: record every GEMM it issues (forward, data gradients), then sweep the distinct shapes
         from dsml_thesis_amd import train as TR
-        from oracle import ldm_oracle as O, weights as W
         tr = TR.UNetTrainer(model.model.diffusion_model)
-        sched = O.register_schedule(**W.SCHEDULE)
         dev = torch.device("cuda", 0)
         g = torch.Generator().manual_seed(0)
         x0 = torch.randn(batch, ucfg["in_channels"], latent, latent, generator=g).to(dev)
@@ -60,7 +58,7 @@ def tune(kind, latent, batch, table):
         t = torch.randint(0, 1000, (batch,), generator=g).to(dev)
         TR.RECORD = []
         # keep every tensor of the step alive so the recorded pointers stay valid during the sweep
-        tr.p_losses(x0, ctx, t, noise, sched["sqrt_alphas_cumprod"].to(dev), sched["sqrt_one_minus_alphas_cumprod"].to(dev))
+        tr.p_losses(x0, ctx, t, noise, model.sqrt_alphas_cumprod, model.sqrt_one_minus_alphas_cumprod)
         rec, TR.RECORD = TR.RECORD, None
         torch.cuda.synchronize()
 

@@ -39,7 +39,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-    from helpers import make_tf_model
+    from dsml_thesis_amd.synth import make_tf_model
     from dsml_thesis_amd.ddim import DDIMSampler, C12, C34
     from dsml_thesis_amd import ops
     from dsml_thesis_amd.parallel import sample_sharded

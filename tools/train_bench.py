@@ -25,13 +25,11 @@ def main():
     a = ap.parse_args()
     from bench import build_model
     from dsml_thesis_amd.train import UNetTrainer
-    from oracle import ldm_oracle as O, weights as W
     dev = torch.device("cuda", 0)
     model, ucfg = build_model(a.latent, dev)
     unet = model.model.diffusion_model
     tr = UNetTrainer(unet)
-    sched = O.register_schedule(**W.SCHEDULE)
-    sa, sb = sched["sqrt_alphas_cumprod"].to(dev), sched["sqrt_one_minus_alphas_cumprod"].to(dev)
+    sa, sb = model.sqrt_alphas_cumprod, model.sqrt_one_minus_alphas_cumprod
     n, c, hw = a.batch, ucfg["in_channels"], a.latent
     g = torch.Generator(device="cpu").manual_seed(0)
     x0 = torch.randn(n, c, hw, hw, generator=g).to(dev)
