@@ -395,7 +395,7 @@ class LatentDiffusion(_Base):
             cond = torch.cat(list(cond), 1)
         return cond
 
-    def p_losses(self, x_start, cond, t, noise=None, c_concat=None):
+    def p_losses(self, x_start, cond, t, noise=None, c_concat=None, reduce_world=1):
         """ddpm.py:1014-1047 for the shipped settings (eps-prediction, l2, l_simple_weight 1, fixed logvar 0,
         original_elbo_weight 0): loss = mean((eps_theta(q_sample(x0, t, noise), t, cond) - noise)^2).
         Runs forward AND backward on the HIP kernels; gradients are left in `self.trainer().P.grad` (UNet, packed
@@ -409,7 +409,7 @@ class LatentDiffusion(_Base):
         if isinstance(c_concat, (list, tuple)):
             c_concat = torch.cat(list(c_concat), 1)
         loss = tr.p_losses(x_start.float(), ctx, t, noise.float(), self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod,
-                           c_concat=c_concat)
+                           c_concat=c_concat, reduce_world=reduce_world)
         prefix = "train" if self.training else "val"
         return loss, {f"{prefix}_loss_simple": loss, f"{prefix}_loss": loss}
 
@@ -435,9 +435,7 @@ class LatentDiffusion(_Base):
                 except TypeError:
                     c = self.get_learned_conditioning(cond_batch)
         ctx = self._context_tensor(c)
-        loss, loss_dict = self.p_losses(z, ctx.detach(), t, noise)
-        if world_size > 1:
-            tr.all_reduce_grads(world_size)
+        loss, loss_dict = self.p_losses(z, ctx.detach(), t, noise, reduce_world=world_size)   # bucketed all-reduce inside
         tr.adamw_step(lr, weight_decay=weight_decay)
         if self.cond_stage_trainable and ctx.requires_grad:
             if self._cond_opt is None:

@@ -89,6 +89,7 @@ class UNetTrainer:
         self.G = {}            # activation data_ptr -> (grad tensor)
         self.ginit = set()
         self._stats = {}       # activation data_ptr -> (tensor, GroupNorm partial records emitted by its producer GEMM)
+        self._first_off = {}
         self.acc_params = False   # True: backward() adds to P.grad (several passes per step: differentiable DDIM, N2)
         self.want_dx = False      # True: backward() also returns the gradient w.r.t. the network input
 
@@ -97,14 +98,15 @@ class UNetTrainer:
         u, P, sd, add = self.unet, self.unet._packed, self.unet._sd, self.P.add
         for k in ("te0", "te2", "emb_all", "emb_all_b"):
             add(k, P[k])
-        for k in ("time_embed.0.bias", "time_embed.2.bias", "out.0.weight", "out.0.bias"):
+        for k in ("time_embed.0.bias", "time_embed.2.bias"):
             add(k, sd[k])
         cin = u.in_channels
         assert cin <= 32 and u.out_channels <= 32
         add("in.wpad", ops.pack_conv3x3(F.pad(sd["input_blocks.0.0.weight"], (0, 0, 0, 0, 0, 32 - cin)).contiguous()))
         add("input_blocks.0.0.bias", sd["input_blocks.0.0.bias"])
-        add("out.wpad", ops.pack_conv3x3(F.pad(sd["out.2.weight"], (0, 0, 0, 0, 0, 0, 0, 32 - u.out_channels)).contiguous()))
-        add("out.bpad", F.pad(sd["out.2.bias"], (0, 32 - u.out_channels)))
+        # the flat buffer follows the forward order of the layers: the backward finishes parameter gradients from the
+        # END of the buffer towards its start, so "everything past offset X is final" is a contiguous tail -- that is
+        # what lets backward() hand finished buckets to the all-reduce while earlier layers are still being computed
         for prefix, m in u._walk():
             if m.kind == "res":
                 for k in ("c1", "c2"):
@@ -132,6 +134,18 @@ class UNetTrainer:
                 add(prefix + "w", P[prefix + "w"])
                 bk = "op.bias" if m.kind == "down" else "conv.bias"
                 add(prefix + bk, sd[prefix + bk])
+        for k in ("out.0.weight", "out.0.bias"):
+            add(k, sd[k])
+        add("out.wpad", ops.pack_conv3x3(F.pad(sd["out.2.weight"], (0, 0, 0, 0, 0, 0, 0, 32 - u.out_channels)).contiguous()))
+        add("out.bpad", F.pad(sd["out.2.bias"], (0, 32 - u.out_channels)))
+
+    def _push(self, fn, first_param_prefix):
+        """Record a backward closure together with the flat offset of the first parameter it (or its layer) owns."""
+        off = self._first_off.get(first_param_prefix)
+        if off is None:
+            off = min(o for n_, _, o, _ in self.P.specs if n_.startswith(first_param_prefix))
+            self._first_off[first_param_prefix] = off
+        self.tape.append((fn, off))
 
     # ---- gradient bookkeeping for activations -------------------------------------------------------------------
     def _grad(self, t):
@@ -303,7 +317,7 @@ class UNetTrainer:
                     self._lin_dx(d2, p[prefix + "skip"][c0:], out=dx1.view(n * hw, -1), residual=dx1.view(n * hw, -1))
             else:
                 T.axpy_(dx0, dout, 1.0)
-        self.tape.append(bwd)
+        self._push(bwd, prefix)
         return out
 
     def _spatial_tf(self, prefix, m, x, h, w, ctx, dctx):
@@ -367,7 +381,7 @@ class UNetTrainer:
             dxn = self._lin_bwd(dh, xn, prefix + "pin", prefix + "proj_in.bias")
             self._gn_bwd(dxn, x, None, hw, sx, prefix + "norm.weight", prefix + "norm.bias", False)
             T.axpy_(self._take(x), dout.view_as(x), 1.0)
-        self.tape.append(bwd)
+        self._push(bwd, prefix)
         return out
 
     def _down(self, prefix, x, h, w):
@@ -376,7 +390,7 @@ class UNetTrainer:
         def bwd():
             dx, acc = self._grad(x)
             self._conv_bwd(self._take(out), x, prefix + "w", prefix + "op.bias", stride=2, dx_out=dx, dx_acc=acc)
-        self.tape.append(bwd)
+        self._push(bwd, prefix)
         return out
 
     def _up(self, prefix, x, h, w):
@@ -385,7 +399,7 @@ class UNetTrainer:
         def bwd():
             dx, acc = self._grad(x)
             self._conv_bwd(self._take(out), x, prefix + "w", prefix + "conv.bias", upsample=True, dx_out=dx, dx_acc=acc)
-        self.tape.append(bwd)
+        self._push(bwd, prefix)
         return out
 
     # ---- whole network -------------------------------------------------------------------------------------
@@ -420,7 +434,7 @@ class UNetTrainer:
             ds1 = self._lin_bwd(demb, s1, "te2", "time_embed.2.bias")
             de1 = T.silu_bwd(e1, ds1)
             self._lin_bwd(de1, temb, "te0", "time_embed.0.bias", need_dx=False)
-        self.tape.append(bwd_emb)
+        self._push(bwd_emb, "te0")
 
         h0 = self._conv(xp, "in.wpad", "input_blocks.0.0.bias")
 
@@ -428,7 +442,7 @@ class UNetTrainer:
             dxp = self._conv_bwd(self._take(h0), xp, "in.wpad", "input_blocks.0.0.bias", need_dx=self.want_dx)
             if dxp is not None:
                 self._dx = dxp[..., :cin].permute(0, 3, 1, 2).contiguous()
-        self.tape.append(bwd_in)
+        self._push(bwd_in, "in.wpad")
 
         def run_layers(prefix, layers, x0, x1, h, w):
             cur0, cur1 = x0, x1
@@ -468,22 +482,42 @@ class UNetTrainer:
         def bwd_out():
             dyo = self._conv_bwd(self._take(eps_pad), yo, "out.wpad", "out.bpad")
             self._gn_bwd(dyo.view(n * hw, -1), h_final, None, hw, so, "out.0.weight", "out.0.bias", True)
-        self.tape.append(bwd_out)
+        self._push(bwd_out, "out.0.weight")
         self.eps_pad = eps_pad
         self.last_pass = dict(tape=self.tape, G=self.G, ginit=self.ginit, eps_pad=eps_pad, dctx=self.dctx)
         return eps_pad[..., :u.out_channels].permute(0, 3, 1, 2).contiguous()
 
-    def backward(self, deps_pad, pass_=None):
+    def backward(self, deps_pad, pass_=None, reduce_world=1, bucket_elems=32 * 1024 * 1024):
         """deps_pad: gradient w.r.t. the channel-padded NHWC output (n,H,W,32) of the pass `pass_` (default: the last
-        forward).  Fills (or, with acc_params, adds to) P.grad, sets self.dctx; returns d(loss)/d(input) when want_dx."""
+        forward).  Fills (or, with acc_params, adds to) P.grad, sets self.dctx; returns d(loss)/d(input) when want_dx.
+        reduce_world > 1: data-parallel averaging overlapped with the backward -- as soon as the tail of the flat
+        gradient buffer past some offset is final, that bucket (>= bucket_elems floats, 128 MB by default: few, large
+        collectives suit the xGMI rings) is handed to an asynchronous all-reduce while earlier layers still compute."""
         ps = self.last_pass if pass_ is None else pass_
         self.tape, self.G, self.ginit, self.eps_pad, self.dctx = ps["tape"], ps["G"], ps["ginit"], ps["eps_pad"], ps["dctx"]
         self._dctx_init = False
         self._alias_grad(self.eps_pad, deps_pad)
         self._stats = {}
         self._dx = None
-        for fn in reversed(self.tape):
+        works, hi = [], self.P.grad.numel()
+        order = list(reversed(self.tape))
+        lo = hi
+        for i, (fn, off) in enumerate(order):
             fn()
+            if reduce_world > 1:
+                # layers own contiguous ranges of the flat buffer in forward order and the tape runs backwards: once the
+                # closure owning offset `off` has run, everything from the lowest offset seen so far upwards is final
+                lo = 0 if i + 1 == len(order) else min(lo, off)
+                assert all(o < lo or o == off for _, o in order[i + 1:]) or i + 1 == len(order), "tape out of parameter order"
+                if i + 1 == len(order) or hi - lo >= bucket_elems:
+                    if hi > lo:
+                        import torch.distributed as dist
+                        works.append(dist.all_reduce(self.P.grad[lo:hi], async_op=True))
+                    hi = lo
+        for w in works:
+            w.wait()
+        if reduce_world > 1:
+            self.P.grad.mul_(1.0 / reduce_world)
         self.tape, self.G, self.ginit = [], {}, set()
         ps["tape"] = ps["G"] = ps["ginit"] = None             # the saved activations die with the closures
         return self._dx
@@ -497,7 +531,7 @@ class UNetTrainer:
         return out
 
     # ---- p_losses / optimizer -------------------------------------------------------------------------------
-    def p_losses(self, x_start, context, t, noise, sqrt_ac, sqrt_1mac, c_concat=None):
+    def p_losses(self, x_start, context, t, noise, sqrt_ac, sqrt_1mac, c_concat=None, reduce_world=1):
         """ddpm.py:1014-1047 with parameterization 'eps', loss_type 'l2', l_simple_weight 1, no learned logvar,
         original_elbo_weight 0: loss = mean((eps_theta(q_sample(x0,t,noise), t, c) - noise)^2); `c_concat` (masked-frame +
         identity latents of the talking-face model) is concatenated to the noisy latent on the channel axis.  Returns the loss
@@ -510,7 +544,7 @@ class UNetTrainer:
         tgt = torch.zeros_like(self.eps_pad)
         tgt[..., :co] = noise.permute(0, 2, 3, 1)
         loss, deps = T.mse_grad(self.eps_pad, tgt, denom=noise.numel())
-        self.backward(deps)
+        self.backward(deps, reduce_world=reduce_world)
         return loss
 
     def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):

@@ -229,7 +229,7 @@ def test_talking_face_unet_gradients_with_channel_concat():
     _check_all_grads(m, tr, {k: v.grad for k, v in sdg.items()}, 1e-4)
 
 
-def _ddp_worker(rank, world, port, q):
+def _ddp_worker(rank, world, port, q, overlap=False):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -240,18 +240,31 @@ def _ddp_worker(rank, world, port, q):
     t = torch.tensor([17, 803, 400, 999])
     lo, hi = 2 * rank, 2 * rank + 2                                   # contiguous shard of the global batch
     sched = O.register_schedule(**W.SCHEDULE)
-    tr.p_losses(x0[lo:hi].cuda(), ctx[lo:hi].cuda(), t[lo:hi].cuda(), noise[lo:hi].cuda(),
-                sched["sqrt_alphas_cumprod"].cuda(), sched["sqrt_one_minus_alphas_cumprod"].cuda())
-    tr.all_reduce_grads(world)
+    if overlap:      # buckets of >= 1 M floats handed to the all-reduce while the backward is still running
+        x_noisy = None
+        from dsml_thesis_amd import train_ops as T
+        sa, sb = sched["sqrt_alphas_cumprod"].cuda(), sched["sqrt_one_minus_alphas_cumprod"].cuda()
+        xn = T.q_sample(x0[lo:hi].cuda(), noise[lo:hi].cuda(), t[lo:hi].cuda(), sa, sb)
+        tr.forward(xn, t[lo:hi].cuda(), ctx[lo:hi].cuda())
+        tgt = torch.zeros_like(tr.eps_pad)
+        tgt[..., :3] = noise[lo:hi].cuda().permute(0, 2, 3, 1)
+        _, deps = T.mse_grad(tr.eps_pad, tgt, denom=noise[lo:hi].numel())
+        tr.backward(deps, reduce_world=world, bucket_elems=1 << 20)
+    else:
+        tr.p_losses(x0[lo:hi].cuda(), ctx[lo:hi].cuda(), t[lo:hi].cuda(), noise[lo:hi].cuda(),
+                    sched["sqrt_alphas_cumprod"].cuda(), sched["sqrt_one_minus_alphas_cumprod"].cuda())
+        tr.all_reduce_grads(world)
     if rank == 0:
         q.put(tr.P.grad.cpu())
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_data_parallel_gradients_equal_full_batch_gradients():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_data_parallel_gradients_equal_full_batch_gradients(overlap):
     """N1 multi-GPU contract: shard the batch over ranks, one all-reduce (mean) of the flat gradient buffer ==
-    the gradient of the full batch on one rank (the loss is a mean over samples)."""
+    the gradient of the full batch on one rank (the loss is a mean over samples).  overlap=True: the bucketed
+    reduction that runs inside backward() (tail buckets of the flat buffer are reduced while earlier layers compute)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -260,7 +273,7 @@ def test_data_parallel_gradients_equal_full_batch_gradients():
     s.close()
     ctx_mp = mp.get_context("spawn")
     q = ctx_mp.Queue()
-    procs = [ctx_mp.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx_mp.Process(target=_ddp_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     g2 = q.get(timeout=300)
