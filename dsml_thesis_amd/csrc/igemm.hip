@@ -226,18 +226,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   const float* Bw = Bs + (wk * KS * 32 + half) * BSTR + wn * (32 * TN) + l31;
 
   auto compute = [&](int boff) {
+    // operands of k-step s+1 are read from LDS before the MFMAs of step s are issued (two register sets)
+    float a[2][TM], b[2][TN];
+    auto fetch = [&](int s, int q) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[q][i] = Aw[boff + 2 * s * ASTR + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[q][j] = Bw[boff + 2 * s * BSTR + j * 32];
+    };
+    fetch(0, 0);
 #pragma unroll
     for (int s = 0; s < 16 * KS; ++s) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = Aw[boff + 2 * s * ASTR + i * 32];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bw[boff + 2 * s * BSTR + j * 32];
+      if (s + 1 < 16 * KS) fetch(s + 1, (s + 1) & 1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
+      // pin the interleave: the LDS reads of the next step go out ahead of this step's MFMAs, so their latency is
+      // covered by TM*TN matrix instructions instead of being waited for in front of every pair of them
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
   };
 
