@@ -13,9 +13,6 @@ libldmk.so on the current stream, so a whole step can be captured in a hipGraph.
 
 Scope: single-token cross-attention context (both shipped configs: (B,1,512) FR, (B,1,1024) TF), dropout 0.
 """
-import ctypes as C
-
-import numpy as np
 import torch
 import torch.nn.functional as F
 

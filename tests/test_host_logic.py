@@ -103,7 +103,6 @@ def test_shard_ranges_and_item_noise():
 def test_tuned_plan_table_is_legal_and_nearest():
     """dsml_thesis_amd/igemm_plans.json (tools/autotune.py): every entry must be launchable for its bucket, and the
     lookup must be a pure function of the shape (same answer on every rank)."""
-    import ctypes as C
     from dsml_thesis_amd import engine, lib as L
     table = engine.plan_table()
     assert table, "tuned plan table missing"
