@@ -112,6 +112,88 @@ __global__ __launch_bounds__(256, 2) void splitgemm(const float* __restrict__ A,
     }
 }
 
+
+// Both operands pre-split into bf16 planes in memory (what producer kernels would write): A planes [3][M][K] bf16,
+// W planes [3][K/32][N][32] bf16.  Staging is a pure 16-byte copy; WM = row groups of 64 per workgroup (BM = 64*WM).
+template <int NP, int WMG>
+__global__ __launch_bounds__(128 * WMG, 1) void splitgemm_pre(const uint4* __restrict__ Ap, const uint4* __restrict__ Wp,
+                                                              const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K) {
+  constexpr int BM = 64 * WMG, NT = 128 * WMG;
+  __shared__ __attribute__((aligned(16))) unsigned char As[3][BM * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[3][128 * 64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1, r32 = lane & 31, kh = lane >> 5;
+  const int ntn = N / 128;
+  const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * 128;
+  const int KS = K / 32;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  constexpr int NA = BM * 4 / NT;      // uint4 per thread per plane (A): BM rows x 4 kslots
+  constexpr int NB = 128 * 4 / NT;
+  uint4 ra[3][NA], rb[3][NB];
+  auto gload = [&](int ks) {
+    for (int s = 0; s < 3; s++) {
+      for (int i = 0; i < NA; i++) {
+        int idx = t + NT * i, row = idx >> 2, kslot = idx & 3;
+        ra[s][i] = Ap[((size_t)s * M + m0 + row) * (K / 8) + ks * 4 + kslot];
+      }
+      for (int i = 0; i < NB; i++) {
+        int idx = t + NT * i;
+        rb[s][i] = Wp[((size_t)(s * KS + ks) * N + n0) * 4 + idx];
+      }
+    }
+  };
+  auto lstore = [&]() {
+    for (int s = 0; s < 3; s++) {
+      for (int i = 0; i < NA; i++) { int idx = t + NT * i; *reinterpret_cast<uint4*>(&As[s][swz(idx >> 2, idx & 3)]) = ra[s][i]; }
+      for (int i = 0; i < NB; i++) { int idx = t + NT * i; *reinterpret_cast<uint4*>(&Bs[s][swz(idx >> 2, idx & 3)]) = rb[s][i]; }
+    }
+  };
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int ks = 0; ks < KS; ks++) {
+    if (ks + 1 < KS) gload(ks + 1);
+    for (int kk = 0; kk < 2; kk++) {
+      bf16x8 a[2][3], b[2][3];
+      const int kslot = kk * 2 + kh;
+      for (int i = 0; i < 2; i++)
+        for (int s = 0; s < 3; s++) {
+          a[i][s] = *reinterpret_cast<const bf16x8*>(&As[s][swz(wm * 64 + i * 32 + r32, kslot)]);
+          b[i][s] = *reinterpret_cast<const bf16x8*>(&Bs[s][swz(wn * 64 + i * 32 + r32, kslot)]);
+        }
+      for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++) {
+          f32x16 c = acc[i][j];
+          if (NP >= 6) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+          }
+          if (NP >= 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+    __syncthreads();
+    if (ks + 1 < KS) {
+      lstore();
+      __syncthreads();
+    }
+  }
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + r32;
+      const float bv = bias[col];
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        C[(size_t)row * N + col] = acc[i][j][r] + bv;
+      }
+    }
+}
+
 static unsigned short bf16_rn(float x) {
   unsigned u; memcpy(&u, &x, 4);
   u += 0x7FFF + ((u >> 16) & 1);
@@ -119,17 +201,16 @@ static unsigned short bf16_rn(float x) {
 }
 static float bf16_f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-template <int NS, int NP>
-static void run(const char* name, const float* dA, const uint4* dW, const float* dB, float* dC, int M, int N, int K,
-                const std::vector<float>& A, const std::vector<float>& W, const std::vector<float>& bias) {
-  dim3 grid((M / 128) * (N / 128));
+template <typename F>
+static void run_any(const char* name, F launch, float* dC, int M, int N, int K,
+                    const std::vector<float>& A, const std::vector<float>& W, const std::vector<float>& bias) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; i++) splitgemm<NS, NP><<<grid, 256>>>(dA, dW, dB, dC, M, N, K);
+  for (int i = 0; i < 3; i++) launch();
   CK(hipDeviceSynchronize());
   const int reps = 10;
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; i++) splitgemm<NS, NP><<<grid, 256>>>(dA, dW, dB, dC, M, N, K);
+  for (int i = 0; i < reps; i++) launch();
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
@@ -147,6 +228,13 @@ static void run(const char* name, const float* dA, const uint4* dW, const float*
   }
   printf("%-10s M=%d N=%d K=%d  %8.1f us  %7.1f TFLOP/s  err/sum|ab|: max %.3e rms %.3e   (fp32 fma chain: max %.3e rms %.3e)\n", name, M, N, K,
          ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, emax, sqrt(erms / cnt), fmax, sqrt(frms / cnt));
+}
+
+template <int NS, int NP>
+static void run(const char* name, const float* dA, const uint4* dW, const float* dB, float* dC, int M, int N, int K,
+                const std::vector<float>& A, const std::vector<float>& W, const std::vector<float>& bias) {
+  dim3 grid((M / 128) * (N / 128));
+  run_any(name, [&]() { splitgemm<NS, NP><<<grid, 256>>>(dA, dW, dB, dC, M, N, K); }, dC, M, N, K, A, W, bias);
 }
 
 int main(int argc, char** argv) {
@@ -179,5 +267,18 @@ int main(int argc, char** argv) {
   run<2, 3>("bf16x3", dA, dW, dB, dC, M, N, K, A, W, bias);
   run<3, 6>("bf16x6", dA, dW, dB, dC, M, N, K, A, W, bias);
   run<3, 9>("bf16x9", dA, dW, dB, dC, M, N, K, A, W, bias);
+  // operands pre-split in memory (A planes [3][M][K] bf16)
+  std::vector<unsigned short> Apl((size_t)3 * M * K);
+  for (size_t i = 0; i < (size_t)M * K; i++) {
+    float x = A[i];
+    for (int sp = 0; sp < 3; sp++) { unsigned short h = bf16_rn(x); x -= bf16_f(h); Apl[(size_t)sp * M * K + i] = h; }
+  }
+  uint4* dAp;
+  CK(hipMalloc(&dAp, Apl.size() * 2));
+  CK(hipMemcpy(dAp, Apl.data(), Apl.size() * 2, hipMemcpyHostToDevice));
+  run_any("pre x6 128x128", [&]() { splitgemm_pre<6, 2><<<dim3((M / 128) * (N / 128)), 256>>>(dAp, dW, dB, dC, M, N, K); }, dC, M, N, K, A, W, bias);
+  if (M % 256 == 0)
+    run_any("pre x6 256x128", [&]() { splitgemm_pre<6, 4><<<dim3((M / 256) * (N / 128)), 512>>>(dAp, dW, dB, dC, M, N, K); }, dC, M, N, K, A, W, bias);
+  run_any("pre x1 128x128", [&]() { splitgemm_pre<1, 2><<<dim3((M / 128) * (N / 128)), 256>>>(dAp, dW, dB, dC, M, N, K); }, dC, M, N, K, A, W, bias);
   return 0;
 }
