@@ -1,0 +1,62 @@
+"""Row N2 on one GPU: DiffusionCLIP-style fine-tune step through `LatentDiffusionCLIP` (latent_diffclip.py:969-1033):
+num_train_steps differentiable DDIM steps (guidance by batch doubling) + differentiable decode + l2 image loss +
+backward through everything + AdamW.  fp32.
+
+  python tools/finetune_bench.py --batch 2 --steps 6 --scale 3.0 [--latent 32]
+FLOPs counted: per DDIM step 3x the UNet forward (x2 with guidance), decoder forward + data gradient = 2x its forward."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--scale", type=float, default=3.0)
+    ap.add_argument("--latent", type=int, default=32, choices=[32, 64])
+    ap.add_argument("--iters", type=int, default=5)
+    a = ap.parse_args()
+    from dsml_thesis_amd import synth as S
+    from dsml_thesis_amd.util import instantiate_from_config
+    unet = S.NS_UNET if a.latent == 64 else S.FR_UNET
+    vq = S.VQ_F4_256 if a.latent == 64 else S.VQ_F4
+    cfg = S.fr_config(unet=unet, vq=vq)
+    cfg.update(strength=0.5, num_train_steps=a.steps, num_test_steps=40, unconditional_guidance_scale=a.scale, cls_loss_w=0.0,
+               clip_loss_w=0.0, id_loss_w=0.0, l2_loss_w=1.0, edit_attr="happy")
+    model = instantiate_from_config({"target": "ldm.models.diffusion.latent_diffclip.LatentDiffusionCLIP", "params": cfg})
+    S.load_recipe(model.model.diffusion_model, gain=0.25)
+    S.load_recipe(model.first_stage_model)
+    S.load_recipe(model.cond_stage_model)
+    model = model.cuda().train()
+    g = torch.Generator().manual_seed(0)
+    n, c = a.batch, unet["in_channels"]
+    x = torch.randn(n, c, a.latent, a.latent, generator=g).cuda()
+    x0 = torch.tanh(torch.randn(n, 3, 4 * a.latent, 4 * a.latent, generator=g)).cuda()
+    for _ in range(2):
+        loss, _ = model.training_step_latents(x, ["face"] * n, x0, lr=1e-7)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        loss, _ = model.training_step_latents(x, ["face"] * n, x0, lr=1e-7)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.iters
+    unet_fwd = (46.011 if a.latent == 32 else 230.051) * 1e9
+    dec_fwd = (174.09 if a.latent == 32 else 799.47) * 1e9
+    evals = a.steps * (2 if a.scale > 1.0 else 1)
+    flops = n * (3 * unet_fwd * evals + 2 * dec_fwd)
+    print(json.dumps(dict(workload=f"LatentDiffusionCLIP fine-tune step: {a.steps} differentiable DDIM steps, guidance {a.scale}, "
+                                   f"decode {4 * a.latent}^2, l2 loss, backward, AdamW; batch {n}, latent {a.latent}, fp32",
+                          seconds_per_step=round(dt, 4), images_per_s=round(n / dt, 3), step_tflops=round(flops / dt / 1e12, 1),
+                          loss=float(loss), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))))
+
+
+if __name__ == "__main__":
+    main()
