@@ -13,6 +13,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libldmk.so")
 SOURCES = ["igemm.hip", "norms.hip", "attention.hip", "small.hip", "wgrad.hip", "backward.hip", "attention_bwd.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
+# The attention kernels run their softmax on the MFMA results: keep the accumulators in VGPRs (MFMA VGPR form) instead of
+# AGPRs, otherwise every score / output tile costs a v_accvgpr_read + v_accvgpr_write round trip per register
+# (208 such moves per key tile in the forward kernel).  The GEMM kernels only touch their accumulators in the epilogue.
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attention_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _digest():
@@ -23,6 +27,7 @@ def _digest():
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -36,7 +41,7 @@ def build_lib(force=False, verbose=True):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -45,8 +45,9 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
   for (int t = 0; t < QT; ++t) {
     const bool q_valid = q0 + 32 * t + l31 < tokens;   // ragged tail: lanes past the last query never store
     const float* qp = base + (long long)(q_valid ? q0 + 32 * t + l31 : 0) * ld + h * AT_D;
+    const float qs = q_valid ? scale : 0.f;      // the row pointer is clamped: load unconditionally (16 independent loads)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) qf[t][s] = q_valid ? qp[2 * s + half] * scale : 0.f;
+    for (int s = 0; s < 16; ++s) qf[t][s] = qp[2 * s + half] * qs;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     m_run[t] = -INFINITY;
@@ -89,17 +90,31 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_acc[t][r] = 0.f;
       const float* kbase = Ks + (sub * 32 + l31) * AT_KSTR + half;
+      const float* vbase = Vs + (sub * 32 + 4 * half) * AT_D + l31;
+      // all 16 K operands are read ahead of the 16 S matrix instructions, and the 16 V operands of the P.V product
+      // are read while those run (pinned with sched_group_barrier: the scheduler otherwise parks one read + full
+      // lgkmcnt(0) wait in front of every pair of MFMAs)
+      float kreg[16], vreg[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) kreg[s] = kbase[2 * s];
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vreg[r] = vbase[((r & 3) + 8 * (r >> 2)) * AT_D];
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        const float kv = kbase[2 * s];                   // one LDS read feeds QT matrix instructions
 #pragma unroll
-        for (int t = 0; t < QT; ++t) s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qf[t][s], s_acc[t], 0, 0, 0);
+        for (int t = 0; t < QT; ++t) s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[s], qf[t][s], s_acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
       // s_acc[t][r] = S[query 32t + l31][key = key0 + (r&3) + 8*(r>>2) + 4*half]
       const bool ragged = key0 + 32 > tokens;            // last sub-tile: keys past the end get -inf (V rows are zero)
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
         if (ragged) {
+          // only the last sub-tile of a ragged sequence: keep it a real (scalar) branch -- without the barrier the
+          // compiler if-converts it into ~100 compare/select instructions that run on every tile
+          asm volatile("" ::: "memory");
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s_acc[t][r] = -INFINITY;
@@ -123,13 +138,10 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
         for (int r = 0; r < 16; ++r) o[t][r] *= corr;
       }
       // O^T[d][query] += sum_key V[key][d] * P[query][key]
-      const float* vbase = Vs + (sub * 32 + 4 * half) * AT_D + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int krow = (r & 3) + 8 * (r >> 2);
-        const float vv = vbase[krow * AT_D];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s_acc[t][r], o[t], 0, 0, 0);
+        for (int t = 0; t < QT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r], s_acc[t][r], o[t], 0, 0, 0);
       }
     }
   }

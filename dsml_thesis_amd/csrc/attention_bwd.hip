@@ -84,10 +84,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
   {
     const float* qp = base + (long long)qq * ld + h * AB_D;
     const float* dp = dout + ((long long)b * tokens + qq) * C + h * AB_D;
+    const float qs = q_valid ? scale : 0.f, ds_ = q_valid ? 1.f : 0.f;     // clamped row pointers: unconditional loads
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      qf[s] = q_valid ? qp[2 * s + half] * scale : 0.f;
-      dof[s] = q_valid ? dp[2 * s + half] : 0.f;
+      qf[s] = qp[2 * s + half] * qs;
+      dof[s] = dp[2 * s + half] * ds_;
     }
   }
   const float Lq = q_valid ? lse[((long long)b * heads + h) * tokens + qq] : INFINITY;
@@ -119,11 +120,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
       }
       const bool ragged = key0 + 32 > tokens;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = __expf(sa[r] - Lq);
-        if (ragged && key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) p = 0.f;
-        sa[r] = p * (da[r] - Dq);                                                      // dS^T[key][q]
+      for (int r = 0; r < 16; ++r) sa[r] = __expf(sa[r] - Lq);
+      if (ragged) {                    // last sub-tile of a ragged sequence only (kept a real branch, see attention.hip)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) sa[r] = 0.f;
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[r] *= da[r] - Dq;                                 // dS^T[key][q]
       const float* kc = Ks + (sub * 32 + 4 * half) * AB_STR + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -153,10 +158,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
   float kf[16], vf[16];
   {
     const float* kp = base + (long long)kk * ld + C + h * AB_D;
+    const float ks_ = k_valid ? scale : 0.f, vs_ = k_valid ? 1.f : 0.f;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      kf[s] = k_valid ? kp[2 * s + half] * scale : 0.f;
-      vf[s] = k_valid ? kp[C + 2 * s + half] : 0.f;
+      kf[s] = kp[2 * s + half] * ks_;
+      vf[s] = kp[C + 2 * s + half] * vs_;
     }
   }
   f32x16 dk, dv;
