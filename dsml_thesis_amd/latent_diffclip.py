@@ -40,10 +40,15 @@ class LatentDiffusionCLIP(LatentDiffusion):
         self.train_ddim_timesteps = make_ddim_timesteps_strength(num_train_steps, self.num_timesteps, strength)
         self.test_ddim_timesteps = make_ddim_timesteps_strength(num_test_steps, self.num_timesteps, strength)
         self._ddd = None
+        self._table_cache = {}
 
     def _tables(self, training):
-        ts = self.train_ddim_timesteps if training else self.test_ddim_timesteps
-        return ts, ddim_step_table(self.alphas_cumprod.detach().cpu(), ts, 0.0)
+        """(timesteps, [S][4] coefficient rows), built on the host once per mode (no device sync in the step)."""
+        key = bool(training)
+        if key not in self._table_cache:
+            ts = self.train_ddim_timesteps if training else self.test_ddim_timesteps
+            self._table_cache[key] = (np.asarray(ts), ddim_step_table(self.alphas_cumprod.detach().cpu(), ts, 0.0))
+        return self._table_cache[key]
 
     def differentiable(self):
         if self._ddd is None:
