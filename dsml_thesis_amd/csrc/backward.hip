@@ -49,27 +49,37 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ dy, const float* __restrict__ coef,
                                                              const float* __restrict__ mr, int hw, int groups, int silu,
                                                              float* __restrict__ partial) {
+  // 64 channels x 4 pixel lanes per workgroup: four rows of the chunk are in flight per channel, folded through LDS
+  __shared__ float red[4][64][2];
   const int C = c0 + c1, cpg = C / groups;
-  const int c = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y, n = blockIdx.z;
-  if (c >= C) return;
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, chunk = blockIdx.y, n = blockIdx.z;
   const int chunks = gridDim.y;
-  const float sc = coef[((long long)n * 2) * C + c], sh = coef[((long long)n * 2 + 1) * C + c];
-  const int g = c / cpg;
-  const float mean = mr[((long long)n * groups + g) * 2], rstd = mr[((long long)n * groups + g) * 2 + 1];
-  const float* xs = c < c0 ? x0 + c : x1 + (c - c0);
-  const int cs = c < c0 ? c0 : c1;
-  const int p0 = chunk * GB_PIX, p1 = min(hw, p0 + GB_PIX);
   float a = 0.f, b = 0.f;
-  for (int p = p0; p < p1; ++p) {
-    const long long row = (long long)n * hw + p;
-    const float xv = xs[row * cs];
-    float dz = dy[row * C + c];
-    if (silu) dz *= dsilu_f(fmaf(xv, sc, sh));
-    a += dz;
-    b = fmaf(dz, (xv - mean) * rstd, b);
+  if (c < C) {
+    const float sc = coef[((long long)n * 2) * C + c], sh = coef[((long long)n * 2 + 1) * C + c];
+    const int g = c / cpg;
+    const float mean = mr[((long long)n * groups + g) * 2], rstd = mr[((long long)n * groups + g) * 2 + 1];
+    const float* xs = c < c0 ? x0 + c : x1 + (c - c0);
+    const int cs = c < c0 ? c0 : c1;
+    const int p0 = chunk * GB_PIX, p1 = min(hw, p0 + GB_PIX);
+    for (int p = p0 + pl; p < p1; p += 4) {
+      const long long row = (long long)n * hw + p;
+      const float xv = xs[row * cs];
+      float dz = dy[row * C + c];
+      if (silu) dz *= dsilu_f(fmaf(xv, sc, sh));
+      a += dz;
+      b = fmaf(dz, (xv - mean) * rstd, b);
+    }
   }
-  float* d = partial + (((long long)n * chunks + chunk) * C + c) * 2;
-  d[0] = a; d[1] = b;
+  red[pl][cl][0] = a;
+  red[pl][cl][1] = b;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    float* d = partial + (((long long)n * chunks + chunk) * C + c) * 2;
+    d[0] = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
+    d[1] = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
+  }
 }
 
 // pass 2: per (sample, channel) totals over the chunks; per (sample, group) means of dxhat and dxhat*xhat
@@ -247,17 +257,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-__global__ void ln_bwd_params_kernel(const float* __restrict__ partial, int blocks, int C, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// dgamma/dbeta = column sums of the per-workgroup partials: 64 columns x 4 row lanes per workgroup, LDS fold (fixed order)
+__global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ partial, int blocks, int C,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  __shared__ float red[4][64][2];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   float a = 0.f, b = 0.f;
-  for (int i = 0; i < blocks; ++i) {
-    a += partial[((long long)i * C + c) * 2];
-    b += partial[((long long)i * C + c) * 2 + 1];
+  if (c < C)
+    for (int i = rl; i < blocks; i += 4) {
+      a += partial[((long long)i * C + c) * 2];
+      b += partial[((long long)i * C + c) * 2 + 1];
+    }
+  red[rl][cl][0] = a;
+  red[rl][cl][1] = b;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    a = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
+    b = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
+    dgamma[c] = accumulate ? dgamma[c] + a : a;
+    dbeta[c] = accumulate ? dbeta[c] + b : b;
   }
-  dgamma[c] = accumulate ? dgamma[c] + a : a;
-  dbeta[c] = accumulate ? dbeta[c] + b : b;
 }
 
 // ---- GEGLU (attention.py:37-45): pre = [value | gate], f = value * gelu(gate), exact erf GELU ---------------
@@ -480,7 +499,7 @@ extern "C" int ldmk_gn_bwd(const float* x0, int c0, const float* x1, int c1, con
   float* tot = partial + (long long)n * chunks * C * 2;      // [n][C][2]
   float* gstat = tot + (long long)n * C * 2;                 // [n][groups][2]
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((C + 255) / 256, chunks, n), dim3(256), 0, st, x0, c0, x1, c1, dy, coef, mr, hw,
+  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((C + 63) / 64, chunks, n), dim3(256), 0, st, x0, c0, x1, c1, dy, coef, mr, hw,
                      groups, silu, partial);
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((groups + 3) / 4, n), dim3(256), 0, st, partial, C, hw, chunks, groups, gamma,
                      tot, gstat);
@@ -511,7 +530,7 @@ extern "C" int ldmk_ln_bwd(const float* dy, const float* x, const float* stats, 
   const int blocks = ldmk_ln_bwd_blocks(rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, x, stats, gamma, dx, acc_dx, rows, c, scratch);
-  hipLaunchKernelGGL(ln_bwd_params_kernel, dim3((c + 255) / 256), dim3(256), 0, st, scratch, blocks, c, dgamma, dbeta, acc_params);
+  hipLaunchKernelGGL(ln_bwd_params_kernel, dim3((c + 63) / 64), dim3(256), 0, st, scratch, blocks, c, dgamma, dbeta, acc_params);
   return check_launch("ldmk_ln_bwd");
 }
 
