@@ -18,28 +18,32 @@ __device__ __forceinline__ float dsilu_f(float z) {
 __global__ __launch_bounds__(256) void gn_group_stats_kernel(const float* __restrict__ pa, int c0,
                                                              const float* __restrict__ pb, int c1, int hw, int chunks,
                                                              int groups, float eps, float* __restrict__ mr) {
-  const int C = c0 + c1, n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cpg = C / groups;
-  for (int g = blockIdx.x * 4 + wave; g < groups; g += gridDim.x * 4) {
-    const int items = cpg * chunks;
-    double sum = 0.0, sumsq = 0.0;
-    for (int i = lane; i < items; i += 64) {
-      const int ch = i / cpg, cc = i - ch * cpg, c = g * cpg + cc;
-      const float* d = c < c0 ? pa + (((long long)n * chunks + ch) * c0 + c) * 3
-                              : pb + (((long long)n * chunks + ch) * c1 + (c - c0)) * 3;
-      const int cnt = min(hw - ch * 32, 32);
-      const double sh = d[0], s = d[1], ss = d[2];
-      sum += s + cnt * sh;
-      sumsq += ss + 2.0 * sh * s + cnt * sh * sh;
-    }
-    sum = wave_sum_d(sum);
-    sumsq = wave_sum_d(sumsq);
+  // one workgroup per (sample, group), same reduction as gn_finalize_kernel (norms.hip)
+  __shared__ double red[2][4];
+  const int C = c0 + c1, g = blockIdx.x, n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cpg = C / groups;
+  const int items = cpg * chunks;
+  double sum = 0.0, sumsq = 0.0;
+  for (int i = threadIdx.x; i < items; i += 256) {
+    const int ch = i / cpg, cc = i - ch * cpg, c = g * cpg + cc;
+    const float* d = c < c0 ? pa + (((long long)n * chunks + ch) * c0 + c) * 3
+                            : pb + (((long long)n * chunks + ch) * c1 + (c - c0)) * 3;
+    const int cnt = min(hw - ch * 32, 32);
+    const double sh = d[0], s = d[1], ss = d[2];
+    sum += s + cnt * sh;
+    sumsq += ss + 2.0 * sh * s + cnt * sh * sh;
+  }
+  sum = wave_sum_d(sum);
+  sumsq = wave_sum_d(sumsq);
+  if (lane == 0) { red[0][wave] = sum; red[1][wave] = sumsq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sum = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    sumsq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const double cnt = (double)cpg * hw, mean = sum / cnt;
     double var = sumsq / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
-    if (lane == 0) {
-      mr[((long long)n * groups + g) * 2] = (float)mean;
-      mr[((long long)n * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
+    mr[((long long)n * groups + g) * 2] = (float)mean;
+    mr[((long long)n * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
 
@@ -481,7 +485,7 @@ extern "C" int ldmk_gn_group_stats(const float* partial0, int c0, const float* p
   LDMK_ENTER();
   LDMK_REQUIRE(partial0 && mr && c0 > 0 && n > 0 && hw > 0 && groups > 0 && (c0 + c1) % groups == 0, "ldmk_gn_group_stats: bad args");
   LDMK_REQUIRE((c1 == 0) == (partial1 == nullptr), "ldmk_gn_group_stats: partial1/c1 mismatch");
-  hipLaunchKernelGGL(gn_group_stats_kernel, dim3((groups + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, partial0, c0, partial1,
+  hipLaunchKernelGGL(gn_group_stats_kernel, dim3(groups, n), dim3(256), 0, (hipStream_t)stream, partial0, c0, partial1,
                      c1, hw, ldmk_gn_chunks(hw), groups, eps, mr);
   return check_launch("ldmk_gn_group_stats");
 }
