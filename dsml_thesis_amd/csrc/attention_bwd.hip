@@ -220,7 +220,119 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
   store_rows(Ts[wave], dv, 1.0f, obase + 2 * C, ld, k0, tokens, l31, half);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the short-context cross attention (ldmk_attn_cross, L <= 128 keys; attention.py:170-193 with a context).
+// Pass 1, one thread per (row, head): recompute p over the L keys, dP_j = dO.v_j, dS_j = p_j (dP_j - sum_i p_i dP_i)
+// * scale, dQ = sum_j dS_j k_j; p and dS are kept ([rows][heads][L]) for pass 2.
+__global__ __launch_bounds__(256) void attn_cross_bwd_q_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                               const float* __restrict__ v, int ldkv,
+                                                               const float* __restrict__ dout, int ldo, float* __restrict__ dq,
+                                                               float* __restrict__ pbuf, float* __restrict__ dsbuf, int tokens,
+                                                               int L, int heads, float scale, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (sample, token, head)
+  if (idx >= total) return;
+  const int h = (int)(idx % heads);
+  const long long row = idx / heads;
+  const int b = (int)(row / tokens);
+  float qv[AB_D], dov[AB_D], dqv[AB_D];
+  const float* qp = q + row * ldq + h * AB_D;
+  const float* dp_ = dout + row * ldo + h * AB_D;
+#pragma unroll
+  for (int d = 0; d < AB_D; ++d) { qv[d] = qp[d]; dov[d] = dp_[d]; dqv[d] = 0.f; }
+  const float* kb = k + (long long)b * L * ldkv + h * AB_D;
+  const float* vb = v + (long long)b * L * ldkv + h * AB_D;
+  float* pr = pbuf + idx * L;
+  float* dsr = dsbuf + idx * L;
+  float m = -INFINITY;
+  for (int j = 0; j < L; ++j) {                        // scores (kept in pbuf), running max
+    const float* kp = kb + (long long)j * ldkv;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < AB_D; ++d) s = fmaf(qv[d], kp[d], s);
+    s *= scale;
+    pr[j] = s;
+    m = fmaxf(m, s);
+  }
+  float l = 0.f;
+  for (int j = 0; j < L; ++j) { const float e = __expf(pr[j] - m); pr[j] = e; l += e; }
+  const float inv = 1.0f / l;
+  float dsum = 0.f;
+  for (int j = 0; j < L; ++j) {                        // p, dP (kept in dsbuf), D = sum p dP
+    const float* vp = vb + (long long)j * ldkv;
+    float dpj = 0.f;
+#pragma unroll
+    for (int d = 0; d < AB_D; ++d) dpj = fmaf(dov[d], vp[d], dpj);
+    const float pj = pr[j] * inv;
+    pr[j] = pj;
+    dsr[j] = dpj;
+    dsum = fmaf(pj, dpj, dsum);
+  }
+  for (int j = 0; j < L; ++j) {
+    const float ds = pr[j] * (dsr[j] - dsum) * scale;
+    dsr[j] = ds;
+    const float* kp = kb + (long long)j * ldkv;
+#pragma unroll
+    for (int d = 0; d < AB_D; ++d) dqv[d] = fmaf(ds, kp[d], dqv[d]);
+  }
+  float* dqp = dq + row * ldq + h * AB_D;
+#pragma unroll
+  for (int d = 0; d < AB_D; ++d) dqp[d] = dqv[d];
+}
+
+// Pass 2, one wave per (sample, key, head): dK[j] = sum_q dS[q][j] q[q], dV[j] = sum_q p[q][j] dO[q]; lanes split the
+// queries, d = 32 values per lane folded with a wave reduction (fixed order).
+__global__ __launch_bounds__(256) void attn_cross_bwd_kv_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ dout,
+                                                                int ldo, const float* __restrict__ pbuf,
+                                                                const float* __restrict__ dsbuf, float* __restrict__ dk,
+                                                                float* __restrict__ dv, int ldkv, int tokens, int L, int heads,
+                                                                long long total) {
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);          // (sample, key, head)
+  if (w >= total) return;
+  const int lane = threadIdx.x & 63;
+  const int h = (int)(w % heads);
+  const long long r = w / heads;
+  const int j = (int)(r % L), b = (int)(r / L);
+  float ak[AB_D], av[AB_D];
+#pragma unroll
+  for (int d = 0; d < AB_D; ++d) { ak[d] = 0.f; av[d] = 0.f; }
+  for (int t = lane; t < tokens; t += 64) {
+    const long long row = (long long)b * tokens + t;
+    const float ds = dsbuf[(row * heads + h) * L + j], pj = pbuf[(row * heads + h) * L + j];
+    const float* qp = q + row * ldq + h * AB_D;
+    const float* dp_ = dout + row * ldo + h * AB_D;
+#pragma unroll
+    for (int d = 0; d < AB_D; ++d) { ak[d] = fmaf(ds, qp[d], ak[d]); av[d] = fmaf(pj, dp_[d], av[d]); }
+  }
+  float* dkp = dk + ((long long)b * L + j) * ldkv + h * AB_D;
+  float* dvp = dv + ((long long)b * L + j) * ldkv + h * AB_D;
+#pragma unroll
+  for (int d = 0; d < AB_D; ++d) {
+    const float sk = wave_sum(ak[d]), sv = wave_sum(av[d]);
+    if (lane == 0) { dkp[d] = sk; dvp[d] = sv; }
+  }
+}
+
 }  // namespace ldmk
+
+extern "C" int ldmk_attn_cross_bwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* dout, int ldo,
+                                   float* dq, float* dk, float* dv, float* scratch, int n, int tokens, int ctx_len, int heads,
+                                   float scale, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(q && k && v && dout && dq && dk && dv && scratch, "ldmk_attn_cross_bwd: null buffer");
+  LDMK_REQUIRE(n > 0 && tokens > 0 && heads > 0 && ctx_len >= 1 && ctx_len <= 128, "ldmk_attn_cross_bwd: bad shape (ctx_len in [1,128])");
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)n * tokens * heads;
+  float* pbuf = scratch;                              // [n*tokens][heads][L]
+  float* dsbuf = scratch + total * ctx_len;
+  hipLaunchKernelGGL(attn_cross_bwd_q_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q, ldq, k, v, ldkv, dout,
+                     ldo, dq, pbuf, dsbuf, tokens, ctx_len, heads, scale, total);
+  const long long waves = (long long)n * ctx_len * heads;
+  hipLaunchKernelGGL(attn_cross_bwd_kv_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, q, ldq, dout, ldo, pbuf, dsbuf,
+                     dk, dv, ldkv, tokens, ctx_len, heads, waves);
+  return check_launch("ldmk_attn_cross_bwd");
+}
 
 extern "C" int ldmk_attn_self_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
                                   float* dsum, int n, int tokens, int heads, float scale, void* stream) {

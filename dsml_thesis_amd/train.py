@@ -11,7 +11,8 @@ convolutions, [in][out] for Linear), gradients in a second flat buffer of the sa
 data-parallel all-reduce see two contiguous arrays, and no repacking happens between steps.  Every launch goes to
 libldmk.so on the current stream, so a whole step can be captured in a hipGraph.
 
-Scope: single-token cross-attention context (both shipped configs: (B,1,512) FR, (B,1,1024) TF), dropout 0.
+Scope: cross-attention context of 1 token (both shipped configs: (B,1,512) FR, (B,1,1024) TF; the block collapses to a
+per-sample vector) or up to 128 tokens (general cross-attention forward/backward kernels), dropout 0.
 """
 import torch
 import torch.nn.functional as F
@@ -121,10 +122,10 @@ class UNetTrainer:
                     add(prefix + k, sd[prefix + k])
                 for d in range(m.depth):
                     q = f"{prefix}transformer_blocks.{d}."
-                    for k in ("qkv", "o1", "v2", "o2", "ff2"):
+                    for k in ("qkv", "o1", "q2", "k2", "v2", "o2", "ff2"):
                         add(q + k, P[q + k])
                     add(q + "ff1n", ops.pack_linear(sd[q + "ff.net.0.proj.weight"]))
-                    for k in ("norm1.weight", "norm1.bias", "norm3.weight", "norm3.bias", "attn1.to_out.0.bias",
+                    for k in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "norm3.weight", "norm3.bias", "attn1.to_out.0.bias",
                               "attn2.to_out.0.bias", "ff.net.0.proj.bias", "ff.net.2.bias"):
                         add(q + k, sd[q + k])
             elif m.kind in ("down", "up"):
@@ -317,63 +318,94 @@ class UNetTrainer:
         self._push(bwd, prefix)
         return out
 
-    def _spatial_tf(self, prefix, m, x, h, w, ctx, dctx):
+    def _spatial_tf(self, prefix, m, x, h, w, ctx, dctx, L_ctx):
         n, hw = x.shape[0], h * w
         C_ = m.heads * m.d_head
         rows = n * hw
         xn, sx = self._gn(x, None, hw, prefix + "norm.weight", prefix + "norm.bias", 1e-6, False)
         hcur = self._lin(xn, prefix + "pin", prefix + "proj_in.bias", hw)
-        h_first = hcur
         blocks = []
         for d in range(m.depth):
             q = f"{prefix}transformer_blocks.{d}."
             p = self.P.p
-            st1 = ops.ln_stats(hcur)
-            ln1 = T.ln_apply(hcur, st1, p[q + "norm1.weight"], p[q + "norm1.bias"])
-            qkv = self._lin(ln1, q + "qkv", None, hw)
-            att, lse = T.attn_self_lse(qkv, n, hw, m.heads)
-            v = self._lin(ctx, q + "v2", None, 1)                                   # single context token (K11)
-            cvec = self._lin(v, q + "o2", q + "attn2.to_out.0.bias", 1)
-            h1 = self._lin(att, q + "o1", q + "attn1.to_out.0.bias", hw, residual=hcur, batch_vec=cvec)
-            st3 = ops.ln_stats(h1)
-            ln3 = T.ln_apply(h1, st3, p[q + "norm3.weight"], p[q + "norm3.bias"])
-            pre = self._lin(ln3, q + "ff1n", q + "ff.net.0.proj.bias", hw)
-            f = T.geglu_fwd(pre)
-            h2 = self._lin(f, q + "ff2", q + "ff.net.2.bias", hw, residual=h1)
-            blocks.append((q, hcur, st1, ln1, qkv, att, lse, v, cvec, h1, st3, ln3, pre, f, h2))
-            hcur = h2
+            B = dict(q=q, hin=hcur)
+            B["st1"] = ops.ln_stats(hcur)
+            B["ln1"] = T.ln_apply(hcur, B["st1"], p[q + "norm1.weight"], p[q + "norm1.bias"])
+            B["qkv"] = self._lin(B["ln1"], q + "qkv", None, hw)
+            B["att"], B["lse"] = T.attn_self_lse(B["qkv"], n, hw, m.heads)
+            if L_ctx == 1:
+                # single context token (K11): softmax over one key is 1 -> the block adds to_out(to_v(ctx)) per sample
+                B["v"] = self._lin(ctx, q + "v2", None, 1)
+                cvec = self._lin(B["v"], q + "o2", q + "attn2.to_out.0.bias", 1)
+                h1 = self._lin(B["att"], q + "o1", q + "attn1.to_out.0.bias", hw, residual=hcur, batch_vec=cvec)
+            else:
+                B["h1a"] = self._lin(B["att"], q + "o1", q + "attn1.to_out.0.bias", hw, residual=hcur)
+                B["k2"] = self._lin(ctx, q + "k2", None, L_ctx)
+                B["v2"] = self._lin(ctx, q + "v2", None, L_ctx)
+                B["st2"] = ops.ln_stats(B["h1a"])
+                B["ln2"] = T.ln_apply(B["h1a"], B["st2"], p[q + "norm2.weight"], p[q + "norm2.bias"])
+                B["q2"] = self._lin(B["ln2"], q + "q2", None, hw)
+                B["a2"] = ops.attn_cross(B["q2"], B["k2"], B["v2"], n, hw, L_ctx, m.heads)
+                h1 = self._lin(B["a2"], q + "o2", q + "attn2.to_out.0.bias", hw, residual=B["h1a"])
+            B["h1"] = h1
+            B["st3"] = ops.ln_stats(h1)
+            B["ln3"] = T.ln_apply(h1, B["st3"], p[q + "norm3.weight"], p[q + "norm3.bias"])
+            B["pre"] = self._lin(B["ln3"], q + "ff1n", q + "ff.net.0.proj.bias", hw)
+            B["f"] = T.geglu_fwd(B["pre"])
+            hcur = self._lin(B["f"], q + "ff2", q + "ff.net.2.bias", hw, residual=h1)
+            blocks.append(B)
         h_last = hcur
         out = self._lin(h_last, prefix + "pout", prefix + "proj_out.bias", hw, residual=x.view(rows, m.ch),
                         stats=True).view(n, h, w, m.ch)
 
+        def add_dctx(dy, wname):
+            first = not self._dctx_init
+            self._lin_dx(dy, self.P.p[wname], out=dctx, residual=None if first else dctx)
+            self._dctx_init = True
+
         def bwd():
             g, p = self.P.g, self.P.p
+            acc = self.acc_params
             dout = self._take(out).view(rows, m.ch)
             dh = self._lin_bwd(dout, h_last, prefix + "pout", prefix + "proj_out.bias")
-            for (q, hin, st1, ln1, qkv, att, lse, v, cvec, h1, st3, ln3, pre, f, h2) in reversed(blocks):
+            for B in reversed(blocks):
+                q = B["q"]
                 # ---- feed-forward: h2 = h1 + ff2(geglu(ff1(LN3(h1))))
-                df = self._lin_bwd(dh, f, q + "ff2", q + "ff.net.2.bias")
-                dpre = T.geglu_bwd(pre, df)
+                df = self._lin_bwd(dh, B["f"], q + "ff2", q + "ff.net.2.bias")
+                dpre = T.geglu_bwd(B["pre"], df)
                 del df
-                dln3 = self._lin_bwd(dpre, ln3, q + "ff1n", q + "ff.net.0.proj.bias")
+                dln3 = self._lin_bwd(dpre, B["ln3"], q + "ff1n", q + "ff.net.0.proj.bias")
                 del dpre
-                T.ln_bwd(dln3, h1, st3, p[q + "norm3.weight"], dx=dh, acc_dx=True, dgamma=g[q + "norm3.weight"],
-                         dbeta=g[q + "norm3.bias"], acc_params=self.acc_params)     # dh is now d(h1)
+                T.ln_bwd(dln3, B["h1"], B["st3"], p[q + "norm3.weight"], dx=dh, acc_dx=True, dgamma=g[q + "norm3.weight"],
+                         dbeta=g[q + "norm3.bias"], acc_params=acc)                 # dh is now d(h1)
                 del dln3
-                # ---- attention: h1 = hin + to_out(attn(LN1(hin))) + cvec[sample]
-                dcvec = T.colsum(dh, rows_per_group=hw)
-                datt = self._lin_bwd(dh, att, q + "o1", q + "attn1.to_out.0.bias")
-                dv = self._lin_bwd(dcvec, v, q + "o2", q + "attn2.to_out.0.bias")
-                T.wgrad_linear(ctx, dv, dw=g[q + "v2"], accumulate=self.acc_params)
-                first = not self._dctx_init
-                self._lin_dx(dv, p[q + "v2"], out=dctx, residual=None if first else dctx)
-                self._dctx_init = True
-                dqkv = T.attn_self_bwd(qkv, att, datt, lse, n, hw, m.heads)     # flash style: no [T][T] matrix
+                if L_ctx == 1:
+                    # ---- h1 = hin + to_out(attn(LN1(hin))) + cvec[sample]
+                    dcvec = T.colsum(dh, rows_per_group=hw)
+                    datt = self._lin_bwd(dh, B["att"], q + "o1", q + "attn1.to_out.0.bias")
+                    dv = self._lin_bwd(dcvec, B["v"], q + "o2", q + "attn2.to_out.0.bias")
+                    T.wgrad_linear(ctx, dv, dw=g[q + "v2"], accumulate=acc)
+                    add_dctx(dv, q + "v2")
+                else:
+                    # ---- h1 = h1a + to_out2(cross_attn(LN2(h1a), ctx));  h1a = hin + to_out(attn(LN1(hin)))
+                    da2 = self._lin_bwd(dh, B["a2"], q + "o2", q + "attn2.to_out.0.bias")
+                    dq2, dk2, dv2 = T.attn_cross_bwd(B["q2"], B["k2"], B["v2"], da2, n, hw, L_ctx, m.heads)
+                    del da2
+                    dln2 = self._lin_bwd(dq2, B["ln2"], q + "q2", None)
+                    T.ln_bwd(dln2, B["h1a"], B["st2"], p[q + "norm2.weight"], dx=dh, acc_dx=True, dgamma=g[q + "norm2.weight"],
+                             dbeta=g[q + "norm2.bias"], acc_params=acc)             # dh is now d(h1a)
+                    del dln2, dq2
+                    T.wgrad_linear(ctx, dk2, dw=g[q + "k2"], accumulate=acc)
+                    T.wgrad_linear(ctx, dv2, dw=g[q + "v2"], accumulate=acc)
+                    add_dctx(dk2, q + "k2")
+                    add_dctx(dv2, q + "v2")
+                    datt = self._lin_bwd(dh, B["att"], q + "o1", q + "attn1.to_out.0.bias")
+                dqkv = T.attn_self_bwd(B["qkv"], B["att"], datt, B["lse"], n, hw, m.heads)   # flash style: no [T][T] matrix
                 del datt
-                dln1 = self._lin_bwd(dqkv, ln1, q + "qkv", None)
+                dln1 = self._lin_bwd(dqkv, B["ln1"], q + "qkv", None)
                 del dqkv
-                T.ln_bwd(dln1, hin, st1, p[q + "norm1.weight"], dx=dh, acc_dx=True, dgamma=g[q + "norm1.weight"],
-                         dbeta=g[q + "norm1.bias"], acc_params=self.acc_params)     # dh is now d(hin)
+                T.ln_bwd(dln1, B["hin"], B["st1"], p[q + "norm1.weight"], dx=dh, acc_dx=True, dgamma=g[q + "norm1.weight"],
+                         dbeta=g[q + "norm1.bias"], acc_params=acc)                 # dh is now d(hin)
                 del dln1
             dxn = self._lin_bwd(dh, xn, prefix + "pin", prefix + "proj_in.bias")
             self._gn_bwd(dxn, x, None, hw, sx, prefix + "norm.weight", prefix + "norm.bias", False)
@@ -401,18 +433,22 @@ class UNetTrainer:
 
     # ---- whole network -------------------------------------------------------------------------------------
     def forward(self, x, timesteps, context):
-        """x (n,C_in,H,W) fp32 NCHW (already concatenated with any c_concat), timesteps (n,) int64, context (n,1,ctx_dim).
+        """x (n,C_in,H,W) fp32 NCHW (already concatenated with any c_concat), timesteps (n,) int64, context (n,L,ctx_dim)
+        (L = 1: the shipped configs' fast path; 1 < L <= 128: general cross-attention).
         Returns eps (n,C_out,H,W); records the tape for backward()."""
         u, p, dev = self.unet, self.P.p, self.dev
         if not x.is_cuda:
             raise L.LdmkError("UNetTrainer.forward: CUDA tensors only (no CPU fallback)")
-        if context is None or context.shape[1] != 1:
-            raise NotImplementedError("UNetTrainer: single-token context only")
+        if context is None:
+            raise L.LdmkError("UNetTrainer.forward: context is required")
+        L_ctx = context.shape[1]
+        if L_ctx > 128:
+            raise NotImplementedError("UNetTrainer: context longer than 128 tokens")
         n, cin, H, W_ = x.shape
         self.tape, self.G, self.ginit, self._stats = [], {}, set(), {}
         self._dctx_init = False
         mc = u.model_channels
-        ctx = context.reshape(n, u.context_dim).contiguous().float()
+        ctx = context.reshape(n * L_ctx, u.context_dim).contiguous().float()
         self.dctx = torch.zeros_like(ctx)
         xp = torch.zeros(n, H, W_, 32, device=dev)
         xp[..., :cin] = x.permute(0, 2, 3, 1)
@@ -448,7 +484,7 @@ class UNetTrainer:
                 if m.kind == "res":
                     cur0 = self._res_block(pf, m, cur0, cur1, h, w, emb_all, d_emb_all, u._emb_off[pf])
                 elif m.kind == "st":
-                    cur0 = self._spatial_tf(pf, m, cur0, h, w, ctx, self.dctx)
+                    cur0 = self._spatial_tf(pf, m, cur0, h, w, ctx, self.dctx, L_ctx)
                 elif m.kind == "down":
                     cur0 = self._down(pf, cur0, h, w)
                     h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
@@ -573,8 +609,8 @@ class UNetTrainer:
     def state_dict_reference(self, flat=None):
         """Unpack the flat (packed-layout) parameters into the reference's state-dict keys and shapes
         (openaimodel.py module tree); `flat` defaults to the live weights, pass an EMA shadow buffer to export that.
-        Parameters that receive no gradient with a single-token context (attn2.to_q/to_k, norm2) are returned
-        unchanged from the wrapped UNetModel."""
+        Every parameter of the UNet lives in the flat buffer (attn2.to_q / to_k / norm2 receive exactly zero gradient
+        with a single-token context, as in the reference)."""
         u = self.unet
         src = self.P.flat if flat is None else flat
         view = {name: src[off:off + n].view(shape) for name, shape, off, n in self.P.specs}
@@ -587,8 +623,9 @@ class UNetTrainer:
             return wp.t().contiguous().view(like.shape)
 
         lin = {"skip": "skip_connection.weight", "pin": "proj_in.weight", "pout": "proj_out.weight",
-               "o1": "attn1.to_out.0.weight", "v2": "attn2.to_v.weight", "o2": "attn2.to_out.0.weight",
-               "ff2": "ff.net.2.weight", "ff1n": "ff.net.0.proj.weight"}
+               "o1": "attn1.to_out.0.weight", "q2": "attn2.to_q.weight", "k2": "attn2.to_k.weight",
+               "v2": "attn2.to_v.weight", "o2": "attn2.to_out.0.weight", "ff2": "ff.net.2.weight",
+               "ff1n": "ff.net.0.proj.weight"}
         for name, wp in view.items():
             if name in ("te0", "te2"):
                 out[f"time_embed.{name[2]}.weight"] = wp.t().contiguous()
@@ -668,7 +705,8 @@ def reference_grad_layout(unet, name, grads):
         key = base + ("op.weight" if base + "op.weight" in grads else "conv.weight")
         return ops.pack_conv3x3(grads[key].contiguous())
     lin = {"skip": "skip_connection.weight", "pin": "proj_in.weight", "pout": "proj_out.weight", "o1": "attn1.to_out.0.weight",
-           "v2": "attn2.to_v.weight", "o2": "attn2.to_out.0.weight", "ff2": "ff.net.2.weight", "ff1n": "ff.net.0.proj.weight"}
+           "q2": "attn2.to_q.weight", "k2": "attn2.to_k.weight", "v2": "attn2.to_v.weight", "o2": "attn2.to_out.0.weight",
+           "ff2": "ff.net.2.weight", "ff1n": "ff.net.0.proj.weight"}
     for suf, key in lin.items():
         if name.endswith("." + suf):
             wgt = grads[name[:-len(suf)] + key]

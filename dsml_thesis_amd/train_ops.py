@@ -281,3 +281,12 @@ def attn_self_bwd(qkv, out, dout, lse, n, tokens, heads):
     L.call("ldmk_attn_self_bwd", _ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _ptr(dsum), n, tokens, heads,
            32 ** -0.5, stream())
     return dqkv
+
+
+def attn_cross_bwd(q, k, v, dout, n, tokens, ctx_len, heads):
+    """Gradients of ldmk_attn_cross: q [n*tokens][C], k / v [n*ctx_len][C], dout [n*tokens][C] -> (dq, dk, dv)."""
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    scratch = _f32(2 * n * tokens * heads * ctx_len, device=q.device)
+    L.call("ldmk_attn_cross_bwd", _ptr(q), q.stride(0), _ptr(k), _ptr(v), k.stride(0), _ptr(dout), dout.stride(0), _ptr(dq),
+           _ptr(dk), _ptr(dv), _ptr(scratch), n, tokens, ctx_len, heads, 32 ** -0.5, stream())
+    return dq, dk, dv

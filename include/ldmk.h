@@ -290,6 +290,11 @@ int ldmk_mse_grad(const float* pred, const float* target, float* dpred, long lon
 int ldmk_attn_self_lse(const float* qkv, float* out, float* lse, int n, int tokens, int heads, float scale, void* stream);
 int ldmk_attn_self_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* dsum,
                        int n, int tokens, int heads, float scale, void* stream);
+/* Backward of ldmk_attn_cross (context of ctx_len <= 128 tokens): dq [n*tokens][ldq], dk / dv [n*ctx_len][ldkv];
+ * scratch = 2 * n*tokens*heads*ctx_len floats (probabilities and score gradients kept between the two passes). */
+int ldmk_attn_cross_bwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* dout, int ldo,
+                        float* dq, float* dk, float* dv, float* scratch, int n, int tokens, int ctx_len, int heads,
+                        float scale, void* stream);
 /* d_head = 32 layouts: token-major [n][tokens][parts][heads][32] (the fused qkv / attention output rows) <->
  * head-major [parts][n*heads][tokens][32] (contiguous per-head matrices for the batched backward GEMMs) */
 int ldmk_head_permute(const float* src, float* dst, int n, int tokens, int parts, int heads, int to_heads, void* stream);

@@ -253,3 +253,26 @@ def test_attention_backward(n, tokens, heads):
     if tokens % 32 == 0:               # the materialised variant (batched GEMMs) needs whole 32-token tiles
         dqkv = T.attention_backward(qd, datt.to(_dev()), n, tokens, heads)
         _close(dqkv, qkv.grad, 3e-5, "materialised attention backward")
+
+
+@pytest.mark.parametrize("n,tokens,L_ctx,heads", [(2, 64, 3, 5), (1, 100, 77, 2), (2, 16, 1, 1)])
+def test_cross_attention_backward(n, tokens, L_ctx, heads):
+    from dsml_thesis_amd import ops, train_ops as T
+    C_ = heads * 32
+    q = _rand(n * tokens, C_, seed=60).double().requires_grad_(True)
+    k = _rand(n * L_ctx, C_, seed=61).double().requires_grad_(True)
+    v = _rand(n * L_ctx, C_, seed=62).double().requires_grad_(True)
+    qh = q.view(n, tokens, heads, 32).permute(0, 2, 1, 3)
+    kh = k.view(n, L_ctx, heads, 32).permute(0, 2, 1, 3)
+    vh = v.view(n, L_ctx, heads, 32).permute(0, 2, 1, 3)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * 32 ** -0.5, -1)
+    out = (p @ vh).permute(0, 2, 1, 3).reshape(n * tokens, C_)
+    dout = _rand(n * tokens, C_, seed=63)
+    out.backward(dout.double())
+    dev = _dev()
+    qd, kd, vd = q.detach().float().to(dev), k.detach().float().to(dev), v.detach().float().to(dev)
+    _close(ops.attn_cross(qd, kd, vd, n, tokens, L_ctx, heads), out.detach(), 2e-5, "cross attention forward")
+    dq, dk, dv = T.attn_cross_bwd(qd, kd, vd, dout.to(dev), n, tokens, L_ctx, heads)
+    _close(dq, q.grad, 3e-5, "cross attention dq")
+    _close(dk, k.grad, 3e-5, "cross attention dk")
+    _close(dv, v.grad, 3e-5, "cross attention dv")

@@ -195,6 +195,7 @@ def test_p_losses_against_reference_fixture():
         else:
             table = {"c1": "in_layers.2.weight", "c2": "out_layers.3.weight", "skip": "skip_connection.weight",
                      "pin": "proj_in.weight", "pout": "proj_out.weight", "o1": "attn1.to_out.0.weight",
+                     "q2": "attn2.to_q.weight", "k2": "attn2.to_k.weight",
                      "v2": "attn2.to_v.weight", "o2": "attn2.to_out.0.weight", "ff2": "ff.net.2.weight",
                      "ff1n": "ff.net.0.proj.weight"}
             suf = name.rsplit(".", 1)[-1]
@@ -451,3 +452,26 @@ def test_optimizer_state_resume_is_bitwise():
     one(tr2, x0, ctx, t, noise)
     assert tr2.P.step == 2 and torch.equal(tr.P.flat, tr2.P.flat)
     assert torch.equal(tr.P.m, tr2.P.m) and torch.equal(tr.P.v, tr2.P.v)
+
+
+def test_multi_token_context_gradients():
+    """General cross-attention (context of 3 tokens: attn2.to_q / to_k / norm2 are live): every parameter gradient and
+    d(loss)/d(context) against float64 autograd on the oracle."""
+    m, tr, sd, x0, noise, _, t = _setup(SMALL, 2, 16, seed=20)
+    ctx = rnd(29, 2, 3, 512)
+    sched = O.register_schedule(**W.SCHEDULE)
+    sdg = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    cg = ctx.double().requires_grad_(True)
+    a = sched["sqrt_alphas_cumprod"][t].view(-1, 1, 1, 1)
+    b = sched["sqrt_one_minus_alphas_cumprod"][t].view(-1, 1, 1, 1)
+    eps = O.unet_forward(sdg, SMALL, (a * x0 + b * noise).double(), t, cg)
+    loss_ref = F.mse_loss(eps, noise.double())
+    loss_ref.backward()
+    loss = tr.p_losses(x0.cuda(), ctx.cuda(), t.cuda(), noise.cuda(), sched["sqrt_alphas_cumprod"].cuda(),
+                       sched["sqrt_one_minus_alphas_cumprod"].cuda())
+    assert abs(loss.item() - loss_ref.item()) <= 2e-5 * loss_ref.item()
+    grads = {k: v.grad for k, v in sdg.items()}
+    assert grads["input_blocks.1.1.transformer_blocks.0.attn2.to_q.weight"].abs().max().item() > 0
+    _check_all_grads(m, tr, grads, 1e-4)
+    err = (tr.dctx.double().cpu().view(2, 3, 512) - cg.grad).abs().max().item() / cg.grad.abs().max().item()
+    assert err <= 1e-4, f"context gradient {err:.3e}"
