@@ -277,9 +277,12 @@ extern "C" int ldmk_attn_self_lse(const float* qkv, float* out, float* lse, int 
   LDMK_REQUIRE(qkv && out && n > 0 && heads > 0, "ldmk_attn_self: bad args");
   LDMK_REQUIRE(tokens > 0, "ldmk_attn_self: tokens=%d must be positive", tokens);
   LDMK_REQUIRE(heads <= 65535 && n <= 65535, "ldmk_attn_self: grid limits");
-  // QT = 2 (64 queries per wave) measured on MI355X: 108.7 vs 107.7 TFLOP/s at 4096 tokens, slower below -- the
-  // kernel is matrix-pipe/clock bound, not LDS- or barrier-bound -- so it is only selectable through the test hook.
-  if (g_attn_qt == 2) {
+  // QT = 2 (64 queries per wave: one K / V operand read feeds two MFMAs, half the barriers per MFMA) measured on
+  // MI355X with the VGPR-form build: stand-alone 118.4 vs 111.0 TFLOP/s at 4096 tokens (92 vs 109 at 1024), but inside
+  // the UNet step the 4096-token calls take 1468 us with QT = 2 vs 1430 us with QT = 1 (the chip runs at its sustained
+  // clock there) -- so QT = 1 stays the default and QT = 2 is only selectable through the test hook.
+  const bool qt2 = g_attn_qt == 2;
+  if (qt2) {
     dim3 grid((tokens + 255) / 256, heads, n);
     hipLaunchKernelGGL(attn_self_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, tokens, heads, scale, lse);
   } else {
