@@ -46,6 +46,24 @@ def gemm(a, dev):
     ops.igemm(a)
 
 
+def plan_buckets(offsets, total, bucket_elems):
+    """Which tail slices of the flat gradient buffer become final after which backward closure.
+    offsets[i] = flat offset of the first parameter owned by the i-th closure IN EXECUTION ORDER (the tape reversed);
+    layers own contiguous ranges in forward order, so after closure i everything from min(offsets[:i+1]) upwards is
+    final.  Returns {closure index: (lo, hi)}: the slice to hand to the all-reduce right after that closure; slices are
+    at least bucket_elems long (except the last), disjoint, and cover [0, total)."""
+    out, hi, lo = {}, total, total
+    for i, off in enumerate(offsets):
+        last = i + 1 == len(offsets)
+        lo = 0 if last else min(lo, off)
+        if any(o > lo for o in offsets[i + 1:]):
+            raise ValueError("backward tape is not in reverse parameter order")
+        if (last or hi - lo >= bucket_elems) and hi > lo:
+            out[i] = (lo, hi)
+            hi = lo
+    return out
+
+
 class FlatParams:
     """name -> view into one flat parameter buffer (+ the matching gradient / AdamW-moment buffers)."""
 
@@ -532,21 +550,15 @@ class UNetTrainer:
         self._alias_grad(self.eps_pad, deps_pad)
         self._stats = {}
         self._dx = None
-        works, hi = [], self.P.grad.numel()
+        works = []
         order = list(reversed(self.tape))
-        lo = hi
-        for i, (fn, off) in enumerate(order):
+        buckets = plan_buckets([off for _, off in order], self.P.grad.numel(), bucket_elems) if reduce_world > 1 else {}
+        for i, (fn, _) in enumerate(order):
             fn()
-            if reduce_world > 1:
-                # layers own contiguous ranges of the flat buffer in forward order and the tape runs backwards: once the
-                # closure owning offset `off` has run, everything from the lowest offset seen so far upwards is final
-                lo = 0 if i + 1 == len(order) else min(lo, off)
-                assert all(o < lo or o == off for _, o in order[i + 1:]) or i + 1 == len(order), "tape out of parameter order"
-                if i + 1 == len(order) or hi - lo >= bucket_elems:
-                    if hi > lo:
-                        import torch.distributed as dist
-                        works.append(dist.all_reduce(self.P.grad[lo:hi], async_op=True))
-                    hi = lo
+            if i in buckets:
+                import torch.distributed as dist
+                lo, hi = buckets[i]
+                works.append(dist.all_reduce(self.P.grad[lo:hi], async_op=True))
         for w in works:
             w.wait()
         if reduce_world > 1:

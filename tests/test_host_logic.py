@@ -134,3 +134,20 @@ def test_product_side_recipe_matches_the_oracle_copy():
                        ("embedding.weight", (8, 16)), ("time_embed.0.weight", (6, 3))):
         for seed, gain in ((0, 1.0), (3, 0.25)):
             assert np.array_equal(S.synth_tensor(key, shape, seed, gain), W.synth_tensor(key, shape, seed, gain)), key
+
+
+def test_gradient_bucket_plan():
+    """Bucketed all-reduce overlapped with backward: buckets are disjoint tail slices that cover the flat buffer, each
+    is handed over only after every closure owning part of it has run, and a tape out of parameter order is refused."""
+    from dsml_thesis_amd.train import plan_buckets
+    offs = [900, 700, 650, 400, 100, 0]                      # execution order = reverse forward order
+    b = plan_buckets(offs, 1000, 250)
+    assert b == {1: (700, 1000), 3: (400, 700), 4: (100, 400), 5: (0, 100)}
+    cover = sorted(b.values())
+    assert cover[0][0] == 0 and cover[-1][1] == 1000 and all(a[1] == c[0] for a, c in zip(cover, cover[1:]))
+    for i, (lo, hi) in b.items():                            # nothing still to run owns an offset inside the bucket
+        assert all(o < lo for o in offs[i + 1:])
+    assert plan_buckets(offs, 1000, 10 ** 9) == {5: (0, 1000)}          # one bucket = the plain all-reduce
+    assert plan_buckets([0], 64, 16) == {0: (0, 64)}
+    with pytest.raises(ValueError):
+        plan_buckets([500, 800, 0], 1000, 100)
