@@ -508,6 +508,43 @@ class LatentDiffusion2Cond(LatentDiffusion):
         """ddpm2cond.py p_losses(x_start, cond12, cond34, t): cross-attention tokens + channel-concat latents."""
         return super().p_losses(x_start, cond12, t, noise=noise, c_concat=cond34)
 
+    def training_step_latents(self, z, cond_batch, audio_feat, c34, lr, t=None, noise=None, world_size=1, weight_decay=1e-2):
+        """One optimisation step of the talking-face model on encoded latents (ddpm2cond.py shared_step -> forward ->
+        p_losses): c12 = cat([class embedding (B,1,256), audio feature (B,1,768)], 2) as cross-attention token, c34 =
+        masked-frame + identity latents (B,6,h,w) concatenated on the channel axis.  The UNet and the class embedder
+        are optimised; `audio_feat` is the (already pooled) output of cond_stage_model_2 -- its gradient is returned in
+        the loss dict as `d_audio_feat` for a caller that trains the audio encoder."""
+        tr = self.trainer()
+        t = torch.randint(0, self.num_timesteps, (z.shape[0],), device=z.device).long() if t is None else t
+        with torch.enable_grad():
+            try:
+                c1 = self.cond_stage_model_1(cond_batch, training=self.training)
+            except TypeError:
+                c1 = self.cond_stage_model_1(cond_batch)
+        c12 = torch.cat([c1.detach(), audio_feat.detach().float()], 2)
+        loss, loss_dict = self.p_losses(z, c12, c34, t, noise)
+        if world_size > 1:
+            tr.all_reduce_grads(world_size)
+        tr.adamw_step(lr, weight_decay=weight_decay)
+        dc12 = tr.dctx.view_as(c12)
+        if self.cond_stage_trainable and c1.requires_grad:
+            if getattr(self, "_cond_opt", None) is None:
+                self._cond_opt = torch.optim.AdamW(self.cond_stage_model_1.parameters(), lr=lr, weight_decay=weight_decay)
+            for grp in self._cond_opt.param_groups:
+                grp["lr"] = lr
+            self._cond_opt.zero_grad(set_to_none=True)
+            c1.backward(dc12[..., :c1.shape[2]].contiguous())
+            self._cond_opt.step()
+        if self.use_ema:
+            decay = float(self.model_ema.decay)
+            if int(self.model_ema.num_updates) >= 0:
+                self.model_ema.num_updates += 1
+                n_up = int(self.model_ema.num_updates)
+                decay = min(decay, (1 + n_up) / (10 + n_up))
+            tr.ema_update(self._ema_flat, decay)
+        loss_dict = dict(loss_dict, d_audio_feat=dc12[..., c1.shape[2]:])
+        return loss, loss_dict
+
     @torch.no_grad()
     def apply_model(self, x_noisy, t, cond12, cond34=None, return_ids=False):
         c12 = cond12 if isinstance(cond12, (list, dict)) else [cond12]

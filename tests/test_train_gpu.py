@@ -475,3 +475,24 @@ def test_multi_token_context_gradients():
     _check_all_grads(m, tr, grads, 1e-4)
     err = (tr.dctx.double().cpu().view(2, 3, 512) - cg.grad).abs().max().item() / cg.grad.abs().max().item()
     assert err <= 1e-4, f"context gradient {err:.3e}"
+
+
+def test_talking_face_training_step():
+    """LatentDiffusion2Cond: class token + audio feature as one 1024-wide context token, masked-frame + identity latents
+    on the channel axis; the step updates UNet, class embedder and EMA and returns the gradient of the audio feature."""
+    from helpers import make_tf_model
+    model = make_tf_model(gain=0.5).train()
+    model.cond_stage_model_1.p_uncond = 0.0
+    n = 2
+    z, c34 = rnd(501, n, 3, 32, 32).cuda(), rnd(502, n, 6, 32, 32).cuda()
+    audio = rnd(503, n, 1, 768).cuda()
+    batch = {"class_label": torch.tensor([2, 6]).cuda()}
+    emb0 = model.cond_stage_model_1.embedding.weight.detach().clone()
+    losses = []
+    for _ in range(3):
+        loss, ld = model.training_step_latents(z, batch, audio, c34, lr=1e-5, t=torch.tensor([250, 750]).cuda(),
+                                               noise=rnd(504, n, 3, 32, 32).cuda())
+        losses.append(loss.item())
+    assert losses[2] < losses[0] and ld["d_audio_feat"].shape == (n, 1, 768) and torch.isfinite(ld["d_audio_feat"]).all()
+    assert ld["d_audio_feat"].abs().max().item() > 0
+    assert not torch.equal(model.cond_stage_model_1.embedding.weight.detach(), emb0)
