@@ -469,6 +469,140 @@ __global__ void head_permute_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
+
+// ---- Conv1DTemporalAttention backward (talking_face/ldm/modules/encoders/modules.py:76-113) -----------------------
+// One workgroup per sample: the forward is recomputed into LDS (all five activations kept), then softmax / Linear(T,T) /
+// the five Conv1d(k=3)+LeakyReLU(0.02) layers are walked back.  Parameter gradients are written per sample
+// ([n][AAB_TOTAL(T, dim)] floats, packed [3][cin][cout] like the forward weights) and summed over the batch by the
+// caller with ldmk_colsum; the audio features themselves need no gradient (wav2vec2 is frozen).
+__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : 0.02f * v; }
+
+__global__ __launch_bounds__(256) void audio_attention_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                                  int T, int dim, const float* const* __restrict__ w,
+                                                                  const float* const* __restrict__ bias,
+                                                                  const float* __restrict__ wl, const float* __restrict__ bl,
+                                                                  float* __restrict__ grads, long long gstride) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ float red[4];
+  const int chans[6] = {dim, 192, 64, 16, 4, 1};
+  const int Tp = T + 2, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  float* a[6];
+  float* da[6];
+  float* ptr = sm;
+  for (int l = 0; l < 6; ++l) { a[l] = ptr; ptr += Tp * chans[l]; }
+  da[0] = nullptr;
+  for (int l = 1; l < 6; ++l) { da[l] = ptr; ptr += Tp * chans[l]; }
+  float* att = ptr;            // [T]
+  float* dlog = att + T;       // [T]
+  const float* xb = x + (long long)b * T * dim;
+  float* g = grads + (long long)b * gstride;
+  // ---- forward recompute (padding rows 0 and T+1 are zero)
+  for (int i = tid; i < Tp * dim; i += 256) {
+    const int t = i / dim - 1, c = i - (t + 1) * dim;
+    a[0][i] = (t >= 0 && t < T) ? xb[(long long)t * dim + c] : 0.f;
+  }
+  for (int l = 1; l < 6; ++l)
+    for (int i = tid; i < Tp * chans[l]; i += 256) { a[l][i] = 0.f; da[l][i] = 0.f; }
+  __syncthreads();
+  for (int l = 0; l < 5; ++l) {
+    const int cin = chans[l], cout = chans[l + 1];
+    for (int o = tid; o < T * cout; o += 256) {
+      const int t = o / cout, co = o - t * cout;
+      float acc = bias[l][co];
+      for (int k = 0; k < 3; ++k) {
+        const float* src = a[l] + (t + k) * cin;
+        const float* wk = w[l] + (long long)k * cin * cout + co;
+        for (int ci = 0; ci < cin; ++ci) acc = fmaf(src[ci], wk[(long long)ci * cout], acc);
+      }
+      a[l + 1][(t + 1) * cout + co] = leaky(acc);
+    }
+    __syncthreads();
+  }
+  if (tid < T) {
+    float v = bl[tid];
+    for (int j = 0; j < T; ++j) v = fmaf(wl[tid * T + j], a[5][j + 1], v);
+    att[tid] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mx = -INFINITY, s_ = 0.f;
+    for (int t = 0; t < T; ++t) mx = fmaxf(mx, att[t]);
+    for (int t = 0; t < T; ++t) { att[t] = expf(att[t] - mx); s_ += att[t]; }
+    for (int t = 0; t < T; ++t) att[t] /= s_;
+  }
+  __syncthreads();
+  // ---- d att[t] = sum_c dout[c] x[t][c]
+  const float* db_ = dout + (long long)b * dim;
+  for (int t = 0; t < T; ++t) {
+    float p = 0.f;
+    for (int c = tid; c < dim; c += 256) p = fmaf(db_[c], a[0][(t + 1) * dim + c], p);
+    p = wave_sum(p);
+    if (lane == 0) red[wave] = p;
+    __syncthreads();
+    if (tid == 0) dlog[t] = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
+  if (tid == 0) {              // softmax backward in place: dlog <- att * (datt - sum att*datt)
+    float s_ = 0.f;
+    for (int t = 0; t < T; ++t) s_ = fmaf(att[t], dlog[t], s_);
+    for (int t = 0; t < T; ++t) dlog[t] = att[t] * (dlog[t] - s_);
+  }
+  __syncthreads();
+  // ---- gradient layout per sample: conv weights (packed [3][cin][cout]) l = 0..4, conv biases l = 0..4, Linear W, b
+  long long off = 0;
+  float* gw[5];
+  for (int l = 0; l < 5; ++l) { gw[l] = g + off; off += 3LL * chans[l] * chans[l + 1]; }
+  float* gb[5];
+  for (int l = 0; l < 5; ++l) { gb[l] = g + off; off += chans[l + 1]; }
+  float* gwl = g + off;
+  float* gbl = gwl + T * T;
+  for (int i = tid; i < T * T; i += 256) gwl[i] = dlog[i / T] * a[5][i % T + 1];
+  if (tid < T) {
+    gbl[tid] = dlog[tid];
+    float v = 0.f;
+    for (int t = 0; t < T; ++t) v = fmaf(wl[t * T + tid], dlog[t], v);
+    da[5][tid + 1] = v;                                   // d a5[j], cout = 1
+  }
+  __syncthreads();
+  for (int l = 4; l >= 0; --l) {
+    const int cin = chans[l], cout = chans[l + 1];
+    // dz = da * leaky'(z): the activation output has the sign of its input
+    for (int i = tid; i < T * cout; i += 256) {
+      const int idx = (i / cout + 1) * cout + (i % cout);
+      da[l + 1][idx] *= a[l + 1][idx] > 0.f ? 1.f : 0.02f;
+    }
+    __syncthreads();
+    for (int co = tid; co < cout; co += 256) {
+      float v = 0.f;
+      for (int t = 0; t < T; ++t) v += da[l + 1][(t + 1) * cout + co];
+      gb[l][co] = v;
+    }
+    for (long long i = tid; i < 3LL * cin * cout; i += 256) {       // dW[k][ci][co] = sum_t a_l[t+k][ci] dz[t][co]
+      const int co = (int)(i % cout);
+      const long long r = i / cout;
+      const int ci = (int)(r % cin), k = (int)(r / cin);
+      float v = 0.f;
+      for (int t = 0; t < T; ++t) v = fmaf(a[l][(t + k) * cin + ci], da[l + 1][(t + 1) * cout + co], v);
+      gw[l][i] = v;
+    }
+    if (l > 0) {                                                    // d a_l[s][ci] = sum_k sum_co W[k][ci][co] dz[s-k][co]
+      for (int i = tid; i < T * cin; i += 256) {
+        const int t = i / cin, ci = i - t * cin, s_ = t + 1;         // padded row index of a_l
+        float v = 0.f;
+        for (int k = 0; k < 3; ++k) {
+          const int tz = s_ - k;                                    // output time whose tap k read padded row s_
+          if (tz < 0 || tz >= T) continue;
+          const float* wk = w[l] + ((long long)k * cin + ci) * cout;
+          const float* dz = da[l + 1] + (tz + 1) * cout;
+          for (int co = 0; co < cout; ++co) v = fmaf(wk[co], dz[co], v);
+        }
+        da[l][s_ * cin + ci] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 static inline int grid_for(long long n) {
   long long g = (n + 255) / 256;
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -635,6 +769,32 @@ extern "C" int ldmk_head_permute(const float* src, float* dst, int n, int tokens
   hipLaunchKernelGGL(head_permute_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, src, dst, n, tokens, parts,
                      heads, to_heads, total4);
   return check_launch("ldmk_head_permute");
+}
+
+extern "C" long long ldmk_audio_attention_grad_elems(int T, int dim) {
+  const long long ch[6] = {dim, 192, 64, 16, 4, 1};
+  long long e = 0;
+  for (int l = 0; l < 5; ++l) e += 3 * ch[l] * ch[l + 1] + ch[l + 1];
+  return e + (long long)T * T + T;
+}
+
+extern "C" int ldmk_audio_attention_bwd(const float* x, const float* dout, int n, int T, int dim, const float* const* conv_w,
+                                        const float* const* conv_b, const float* lin_w, const float* lin_b,
+                                        float* grads_per_sample, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(x && dout && conv_w && conv_b && lin_w && lin_b && grads_per_sample && n > 0 && dim > 0, "ldmk_audio_attention_bwd: bad args");
+  LDMK_REQUIRE(T >= 1, "ldmk_audio_attention_bwd: T");
+  const size_t lds = ((size_t)(T + 2) * (dim + 2 * (192 + 64 + 16 + 4 + 1)) + 2 * T) * sizeof(float);
+  const size_t lds_max = 160 * 1024 - 256;       // the kernel also has a few bytes of static LDS
+  LDMK_REQUIRE(lds <= lds_max, "ldmk_audio_attention_bwd: window T=%d too large for LDS (%zu bytes)", T, lds);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(audio_attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    attr = true;
+  }
+  hipLaunchKernelGGL(audio_attention_bwd_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, x, dout, T, dim, conv_w, conv_b,
+                     lin_w, lin_b, grads_per_sample, ldmk_audio_attention_grad_elems(T, dim));
+  return check_launch("ldmk_audio_attention_bwd");
 }
 
 extern "C" int ldmk_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,

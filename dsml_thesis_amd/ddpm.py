@@ -508,13 +508,17 @@ class LatentDiffusion2Cond(LatentDiffusion):
         """ddpm2cond.py p_losses(x_start, cond12, cond34, t): cross-attention tokens + channel-concat latents."""
         return super().p_losses(x_start, cond12, t, noise=noise, c_concat=cond34)
 
-    def training_step_latents(self, z, cond_batch, audio_feat, c34, lr, t=None, noise=None, world_size=1, weight_decay=1e-2):
+    def training_step_latents(self, z, cond_batch, audio_feat, c34, lr, t=None, noise=None, world_size=1, weight_decay=1e-2,
+                              audio_window=None):
         """One optimisation step of the talking-face model on encoded latents (ddpm2cond.py shared_step -> forward ->
         p_losses): c12 = cat([class embedding (B,1,256), audio feature (B,1,768)], 2) as cross-attention token, c34 =
         masked-frame + identity latents (B,6,h,w) concatenated on the channel axis.  The UNet and the class embedder
         are optimised; `audio_feat` is the (already pooled) output of cond_stage_model_2 -- its gradient is returned in
-        the loss dict as `d_audio_feat` for a caller that trains the audio encoder."""
+        the loss dict as `d_audio_feat`.  Pass `audio_window` (B,T,768) instead (audio_feat=None) to run and train
+        cond_stage_model_2 (Conv1DTemporalAttention) as well: forward and backward on its fused HIP kernels."""
         tr = self.trainer()
+        if audio_window is not None:
+            audio_feat = self.cond_stage_model_2(audio_window)
         t = torch.randint(0, self.num_timesteps, (z.shape[0],), device=z.device).long() if t is None else t
         with torch.enable_grad():
             try:
@@ -542,7 +546,18 @@ class LatentDiffusion2Cond(LatentDiffusion):
                 n_up = int(self.model_ema.num_updates)
                 decay = min(decay, (1 + n_up) / (10 + n_up))
             tr.ema_update(self._ema_flat, decay)
-        loss_dict = dict(loss_dict, d_audio_feat=dc12[..., c1.shape[2]:])
+        d_audio = dc12[..., c1.shape[2]:]
+        if audio_window is not None and self.cond_stage_trainable:
+            from .encoders import audio_attention_backward
+            audio_attention_backward(self.cond_stage_model_2, audio_window, d_audio)
+            if getattr(self, "_audio_opt", None) is None:
+                for p_ in self.cond_stage_model_2.parameters():
+                    p_.requires_grad_(True)
+                self._audio_opt = torch.optim.AdamW(self.cond_stage_model_2.parameters(), lr=lr, weight_decay=weight_decay)
+            for grp in self._audio_opt.param_groups:
+                grp["lr"] = lr
+            self._audio_opt.step()
+        loss_dict = dict(loss_dict, d_audio_feat=d_audio)
         return loss, loss_dict
 
     @torch.no_grad()

@@ -84,6 +84,34 @@ class Conv1DTemporalAttention(nn.Module):
         return out.unsqueeze(1)
 
 
+def audio_attention_backward(module, x, dout):
+    """Parameter gradients of `Conv1DTemporalAttention` (x: (b,T,768) window, dout: (b,1,768) gradient of its output)
+    on the HIP kernel `ldmk_audio_attention_bwd`; written to the `.grad` of the module's parameters (torch layouts)."""
+    from . import lib as L
+    from . import train_ops as T_
+    b, T, dim = x.shape
+    module._pack()
+    per = L.load().ldmk_audio_attention_grad_elems(T, dim)
+    gs = torch.empty(b, per, device=x.device, dtype=torch.float32)
+    L.call("ldmk_audio_attention_bwd", x.float().contiguous().data_ptr(), dout.float().contiguous().data_ptr(), b, T, dim,
+           module._wp.data_ptr(), module._bp.data_ptr(), module._lw.data_ptr(), module._lb.data_ptr(), gs.data_ptr(),
+           torch.cuda.current_stream().cuda_stream)
+    g = T_.colsum(gs).view(-1)                     # sum over the batch
+    chans = [dim, 192, 64, 16, 4, 1]
+    convs = [module.attentionConvNet[i] for i in range(0, 10, 2)]
+    off = 0
+    for l, c in enumerate(convs):
+        n_ = 3 * chans[l] * chans[l + 1]
+        c.weight.grad = g[off:off + n_].view(3, chans[l], chans[l + 1]).permute(2, 1, 0).contiguous()
+        off += n_
+    for l, c in enumerate(convs):
+        c.bias.grad = g[off:off + chans[l + 1]].clone()
+        off += chans[l + 1]
+    lin = module.attentionNet[0]
+    lin.weight.grad = g[off:off + T * T].view(T, T).clone()
+    lin.bias.grad = g[off + T * T:off + T * T + T].clone()
+
+
 def mask_lower_face_(images, first_masked_row, value=-1.0):
     """In place: images[n, :, y >= first_masked_row[n], :] = value (MEADBase3 sampling mask, custom.py:375-389;
     first_masked_row = int(min(mouth landmark y)) - 5).  images: (n, c, h, w) CUDA float32."""

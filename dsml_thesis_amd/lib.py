@@ -102,6 +102,8 @@ _SIGS = {
     "ldmk_attn_self_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_cross_bwd": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_float, _fp]),
+    "ldmk_audio_attention_grad_elems": (C.c_longlong, [C.c_int, C.c_int]),
+    "ldmk_audio_attention_bwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "ldmk_head_permute": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_adamw": (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                              C.c_int, _fp]),

@@ -295,6 +295,13 @@ int ldmk_attn_self_bwd(const float* qkv, const float* out, const float* dout, co
 int ldmk_attn_cross_bwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* dout, int ldo,
                         float* dq, float* dk, float* dv, float* scratch, int n, int tokens, int ctx_len, int heads,
                         float scale, void* stream);
+/* Backward of ldmk_audio_attention w.r.t. its parameters (the audio features are frozen wav2vec2 outputs): per-sample
+ * gradients [n][ldmk_audio_attention_grad_elems(T, dim)] = conv weights (packed [3][cin][cout]) x5, conv biases x5,
+ * Linear(T,T) weight, bias; the caller sums over the batch (ldmk_colsum). */
+long long ldmk_audio_attention_grad_elems(int T, int dim);
+int ldmk_audio_attention_bwd(const float* x, const float* dout, int n, int T, int dim, const float* const* conv_w,
+                             const float* const* conv_b, const float* lin_w, const float* lin_b, float* grads_per_sample,
+                             void* stream);
 /* d_head = 32 layouts: token-major [n][tokens][parts][heads][32] (the fused qkv / attention output rows) <->
  * head-major [parts][n*heads][tokens][32] (contiguous per-head matrices for the batched backward GEMMs) */
 int ldmk_head_permute(const float* src, float* dst, int n, int tokens, int parts, int heads, int to_heads, void* stream);

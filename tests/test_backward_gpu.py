@@ -276,3 +276,26 @@ def test_cross_attention_backward(n, tokens, L_ctx, heads):
     _close(dq, q.grad, 3e-5, "cross attention dq")
     _close(dk, k.grad, 3e-5, "cross attention dk")
     _close(dv, v.grad, 3e-5, "cross attention dv")
+
+
+def test_audio_attention_backward():
+    """Conv1DTemporalAttention (9-/17-frame wav2vec2 window -> pooled feature): parameter gradients of the fused HIP
+    kernel pair against autograd through the same nn.Modules on the CPU (float64)."""
+    from dsml_thesis_amd.encoders import Conv1DTemporalAttention, audio_attention_backward
+    from dsml_thesis_amd.synth import load_recipe
+    for T_win in (17, 9):
+        mod = Conv1DTemporalAttention(seq_len=T_win, subspace_dim=768)
+        load_recipe(mod)
+        x = _rand(3, T_win, 768, seed=70)
+        dout = _rand(3, 1, 768, seed=71)
+        ref = Conv1DTemporalAttention(seq_len=T_win, subspace_dim=768).double()
+        ref.load_state_dict({k: v.double() for k, v in mod.state_dict().items()})
+        xt = x.double().transpose(1, 2)
+        attn = ref.attentionNet(ref.attentionConvNet(xt).view(3, T_win)).view(3, T_win, 1)
+        out = torch.bmm(xt, attn).view(3, 768).unsqueeze(1)
+        out.backward(dout.double())
+        mod = mod.cuda()
+        _close(mod(x.cuda()), out.detach(), 2e-5, "audio attention forward")
+        audio_attention_backward(mod, x.cuda(), dout.cuda())
+        for (k, p), (_, pr) in zip(mod.named_parameters(), ref.named_parameters()):
+            _close(p.grad, pr.grad, 5e-5, f"audio attention grad {k}")

@@ -496,3 +496,9 @@ def test_talking_face_training_step():
     assert losses[2] < losses[0] and ld["d_audio_feat"].shape == (n, 1, 768) and torch.isfinite(ld["d_audio_feat"]).all()
     assert ld["d_audio_feat"].abs().max().item() > 0
     assert not torch.equal(model.cond_stage_model_1.embedding.weight.detach(), emb0)
+    # the same step with the raw 17-frame audio window: the window encoder is run and trained too
+    win = rnd(505, n, 17, 768).cuda()
+    w0 = model.cond_stage_model_2.attentionConvNet[0].weight.detach().clone()
+    loss, ld = model.training_step_latents(z, batch, None, c34, lr=1e-5, t=torch.tensor([250, 750]).cuda(),
+                                           noise=rnd(504, n, 3, 32, 32).cuda(), audio_window=win)
+    assert torch.isfinite(loss) and not torch.equal(model.cond_stage_model_2.attentionConvNet[0].weight.detach(), w0)
