@@ -502,3 +502,21 @@ def test_talking_face_training_step():
     loss, ld = model.training_step_latents(z, batch, None, c34, lr=1e-5, t=torch.tensor([250, 750]).cuda(),
                                            noise=rnd(504, n, 3, 32, 32).cuda(), audio_window=win)
     assert torch.isfinite(loss) and not torch.equal(model.cond_stage_model_2.attentionConvNet[0].weight.detach(), w0)
+
+
+def test_non_square_latent_gradients():
+    """12x20 latent (240 / 60 tokens: ragged attention tiles, GroupNorm chunks that straddle the end of the image):
+    every parameter gradient of the reduced UNet against float64 autograd on the oracle."""
+    from dsml_thesis_amd.unet import UNetModel
+    from dsml_thesis_amd.train import UNetTrainer
+    m = UNetModel(**SMALL)
+    sd = W.synth_state_dict(W.unet_param_shapes(SMALL))
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    tr = UNetTrainer(m)
+    x0, noise, ctx, t = rnd(601, 2, 3, 12, 20), rnd(602, 2, 3, 12, 20), rnd(603, 2, 1, 512), torch.tensor([5, 640])
+    loss_ref, _, grads, dctx_ref, sched = _oracle_grads(SMALL, sd, x0, noise, ctx, t)
+    loss = tr.p_losses(x0.cuda(), ctx.cuda(), t.cuda(), noise.cuda(), sched["sqrt_alphas_cumprod"].cuda(),
+                       sched["sqrt_one_minus_alphas_cumprod"].cuda())
+    assert abs(loss.item() - loss_ref.item()) <= 2e-5 * abs(loss_ref.item())
+    _check_all_grads(m, tr, grads, 1e-4)

@@ -102,3 +102,13 @@ def test_unet_empty_batch_fails_loudly():
     with pytest.raises((L.LdmkError, RuntimeError, AssertionError)):
         m(torch.zeros(0, 3, 32, 32, device="cuda"), torch.zeros(0, dtype=torch.long, device="cuda"),
           context=torch.zeros(0, 1, 512, device="cuda"))
+
+
+def test_unet_non_square_ragged_token_counts_vs_oracle():
+    """24x40 latent: 960 / 240 / 60 tokens per level -- none a multiple of the 64-key attention tile, the two deeper levels
+    not multiples of the 32-pixel GroupNorm chunk (stand-alone statistics pass, masked tiles everywhere)."""
+    m, sd = make_unet(W.FR_UNET)
+    x, t, ctx = rnd(47, 2, 3, 24, 40), torch.tensor([10, 990]), rnd(48, 2, 1, 512)
+    eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
+    ref = O.unet_forward(sd, W.FR_UNET, x, t, ctx)
+    close(eps, ref, 3e-4, 3e-4)
