@@ -245,7 +245,22 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __res
 // ---------------------------------------------------------------------------------------------
 // VQ nearest codebook entry (quantize.py:276-285).  One wave per latent vector: the 64 lanes split
 // the codebook (coalesced reads of e), keep (min d, first index), then a wave-wide arg-min that
-// breaks ties towards the smaller index like torch.argmin.  d = (|z|^2 + |e|^2) - 2 z.e in fp32.
+// breaks ties towards the smaller index like torch.argmin.
+// The distance reproduces the reference's fp32 rounding sequence exactly (checked bit for bit against
+// torch-CPU on 6.7e7 distances, tools/make_golden.py --tree vq):
+//   |z|^2, |e|^2 : every square rounded, then added left to right   (torch.sum(x ** 2, dim=1))
+//   z.e          : k-ordered fused multiply-add chain               (einsum -> sgemm)
+//   d            : fl(fl(|z|^2 + |e|^2) - 2 z.e)                    (2 * x is exact)
+// so indices are bit-exact, not "equal up to near-ties".  NaN distances order first (torch.argmin
+// returns the first NaN), and the winner is always a valid row: a diverged latent never turns into an
+// out-of-bounds gather.
+__device__ __forceinline__ bool vq_before(float da, int ia, float db, int ib) {
+  const bool na = da != da, nb = db != db;
+  if (na != nb) return na;
+  if (na || da == db) return ia < ib;
+  return da < db;
+}
+
 template <int DIM>
 __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                          float* __restrict__ zq, int* __restrict__ idx_out, int n,
@@ -255,30 +270,34 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict
   if (pix >= (long long)n * hw) return;
   const int b = (int)(pix / hw), p = (int)(pix - (long long)b * hw);
   float zv[DIM];
-  float zz = 0.f;
 #pragma unroll
-  for (int d = 0; d < DIM; ++d) {
-    zv[d] = z[((long long)b * DIM + d) * hw + p];
-    zz += zv[d] * zv[d];
-  }
+  for (int d = 0; d < DIM; ++d) zv[d] = z[((long long)b * DIM + d) * hw + p];
+  float zz = __fmul_rn(zv[0], zv[0]);
+#pragma unroll
+  for (int d = 1; d < DIM; ++d) zz = __fadd_rn(zz, __fmul_rn(zv[d], zv[d]));
   float best = INFINITY;
-  int besti = 0x7fffffff;
+  int besti = lane < n_embed ? lane : 0;       // always a valid row
   for (int j = lane; j < n_embed; j += 64) {
-    float ee = 0.f, ze = 0.f;
+    float e[DIM];
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) {
-      const float e = cb[(long long)j * DIM + d];
-      ee += e * e;
-      ze = fmaf(zv[d], e, ze);
+    for (int d = 0; d < DIM; ++d) e[d] = cb[(long long)j * DIM + d];
+    float ee = __fmul_rn(e[0], e[0]);
+    float ze = __fmul_rn(zv[0], e[0]);
+#pragma unroll
+    for (int d = 1; d < DIM; ++d) {
+      ee = __fadd_rn(ee, __fmul_rn(e[d], e[d]));
+      ze = __fmaf_rn(zv[d], e[d], ze);
     }
-    const float dist = (zz + ee) - 2.0f * ze;
-    if (dist < best) { best = dist; besti = j; }
+    const float dist = __fsub_rn(__fadd_rn(zz, ee), __fmul_rn(2.0f, ze));
+    if (j == lane || vq_before(dist, j, best, besti)) { best = dist; besti = j; }
   }
+  int has = lane < n_embed ? 1 : 0;            // lanes beyond a tiny codebook hold no candidate
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ob = __shfl_xor(best, o, 64);
     const int oi = __shfl_xor(besti, o, 64);
-    if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    const int oh = __shfl_xor(has, o, 64);
+    if (oh && (!has || vq_before(ob, oi, best, besti))) { best = ob; besti = oi; has = 1; }
   }
   if (lane < DIM) zq[((long long)b * DIM + lane) * hw + p] = cb[(long long)besti * DIM + lane];
   if (lane == 0 && idx_out) idx_out[pix] = besti;

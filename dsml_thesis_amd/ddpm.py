@@ -3,10 +3,10 @@
   talking_face/ldm/models/diffusion/ddpm2cond.py:430-1297, :1300-1315 (two-condition variant)
   face_reenactment/ldm/modules/ema.py:5-76 (LitEma)
 
-Only the sampling surface is built: schedules, `apply_model`, `p_sample_loop`/`sample`,
-`sample_log`, `decode_first_stage`/`encode_first_stage`, `q_sample`, `ema_scope`, state-dict key layout
-(`model.diffusion_model.*`, `model_ema.*`, `first_stage_model.*`, `cond_stage_model*.*`).  Training members
-(`p_losses`, `training_step`, optimisers, logging) are the "next" row N1 and raise NotImplementedError.
+Sampling surface: schedules, `apply_model`, `p_sample_loop`/`sample`, `sample_log`, `log_images`,
+`decode_first_stage`/`encode_first_stage`, `q_sample`, `ema_scope`, state-dict key layout (`model.diffusion_model.*`,
+`model_ema.*`, `first_stage_model.*`, `cond_stage_model*.*`).  Training surface: `p_losses`,
+`forward`, `training_step` (manual optimisation on the HIP training engine), `configure_optimizers`.
 The class derives from pytorch_lightning.LightningModule when Lightning is installed, else nn.Module.
 """
 from contextlib import contextmanager
@@ -40,34 +40,44 @@ except Exception:  # offline image: Lightning absent
 
 
 class LitEma(nn.Module):
-    """Shadow weights under the reference's buffer names (parameter name with the dots removed)."""
+    """EMA shadow of a module's parameters, stored as buffers whose names are the parameter names with the dots
+    removed (the checkpoint layout of ema.py:16-21, so `model_ema.*` keys of reference checkpoints load as they are).
+
+    `swap_in` / `swap_out` write THROUGH the parameters (`Parameter.copy_`, not `.data.copy_`): that bumps the
+    parameters' version counters, which is what tells the packed-weight caches of the HIP models (UNetModel,
+    the encoders, the autoencoder) that their kernel-layout copies are stale."""
 
     def __init__(self, model, decay=0.9999, use_num_upates=True):
         super().__init__()
-        if decay < 0.0 or decay > 1.0:
+        if not 0.0 <= decay <= 1.0:
             raise ValueError("Decay must be between 0 and 1")
-        self.m_name2s_name = {}
         self.register_buffer("decay", torch.tensor(decay, dtype=torch.float32))
         self.register_buffer("num_updates", torch.tensor(0 if use_num_upates else -1, dtype=torch.int))
+        self.m_name2s_name = {name: name.replace(".", "") for name, _ in model.named_parameters()}
         for name, p in model.named_parameters():
-            s_name = name.replace(".", "")
-            self.m_name2s_name[name] = s_name
-            self.register_buffer(s_name, p.clone().detach().data)
+            self.register_buffer(self.m_name2s_name[name], p.detach().clone())
         self.collected_params = []
+
+    def shadow_of(self, name):
+        return getattr(self, self.m_name2s_name[name])
 
     @torch.no_grad()
     def copy_to(self, model):
-        shadow = dict(self.named_buffers())
-        for key, p in model.named_parameters():
-            p.data.copy_(shadow[self.m_name2s_name[key]].data)
+        """ema.py:46-55: shadow -> parameters."""
+        for name, p in model.named_parameters():
+            p.copy_(self.shadow_of(name))
 
+    @torch.no_grad()
     def store(self, parameters):
-        self.collected_params = [p.clone() for p in parameters]
+        """ema.py:57-64."""
+        self.collected_params = [p.detach().clone() for p in parameters]
 
     @torch.no_grad()
     def restore(self, parameters):
-        for c, p in zip(self.collected_params, parameters):
-            p.data.copy_(c.data)
+        """ema.py:66-76."""
+        for saved, p in zip(self.collected_params, parameters):
+            p.copy_(saved)
+        self.collected_params = []
 
 
 class DiffusionWrapper(_Base):
@@ -134,6 +144,11 @@ class LatentDiffusion(_Base):
         self.instantiate_first_stage(first_stage_config)
         self.instantiate_cond_stage(cond_stage_config)
         self.cond_stage_forward = cond_stage_forward
+        self.learn_logvar = learn_logvar
+        if learn_logvar:
+            raise NotImplementedError("learn_logvar=True is unused by the shipped configs")
+        self.use_scheduler = scheduler_config is not None
+        self.scheduler_config = scheduler_config
         self.restarted_from_ckpt = False
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys)
@@ -164,22 +179,26 @@ class LatentDiffusion(_Base):
         if not self.cond_stage_trainable:
             self.cond_stage_model.eval()
 
-    def init_from_ckpt(self, path, ignore_keys=list(), only_model=False):
-        sd = torch.load(path, map_location="cpu")
-        sd = sd.get("state_dict", sd)
-        for k in list(sd.keys()):
-            if any(k.startswith(ik) for ik in ignore_keys):
-                print("Deleting key {} from state_dict.".format(k))
-                del sd[k]
-        missing, unexpected = (self.load_state_dict(sd, strict=False) if not only_model
-                               else self.model.load_state_dict(sd, strict=False))
-        print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
+    def init_from_ckpt(self, path, ignore_keys=(), only_model=False):
+        """ddpm.py:186-201: load a Lightning checkpoint (or a bare state dict), dropping keys by prefix."""
+        state = torch.load(path, map_location="cpu")
+        state = state["state_dict"] if "state_dict" in state else state
+        dropped = [k for k in state if any(k.startswith(prefix) for prefix in ignore_keys)]
+        for k in dropped:
+            state.pop(k)
+        target = self.model if only_model else self
+        result = target.load_state_dict(state, strict=False)
+        print(f"init_from_ckpt: {path}: dropped {len(dropped)} keys, {len(result.missing_keys)} missing, "
+              f"{len(result.unexpected_keys)} unexpected")
+        return result
 
     @contextmanager
     def ema_scope(self, context=None):
-        """ddpm.py:171-184: swap the EMA shadow weights in for sampling (the packed kernel weights are re-derived
-        automatically because the parameter versions change)."""
-        if self.use_ema:
+        """ddpm.py:171-184: sample with the EMA weights, then put the training weights back.  Every reference sampling
+        script runs inside this scope.  The swap writes through the parameters (LitEma.copy_to / restore), so the
+        kernel-layout weight copies are rebuilt on the next forward, inside the scope and again after it."""
+        swapped = bool(self.use_ema)
+        if swapped:
             self.model_ema.store(self.model.parameters())
             self.model_ema.copy_to(self.model)
             if context is not None:
@@ -187,7 +206,7 @@ class LatentDiffusion(_Base):
         try:
             yield None
         finally:
-            if self.use_ema:
+            if swapped:
                 self.model_ema.restore(self.model.parameters())
                 if context is not None:
                     print(f"{context}: Restored training weights")
@@ -384,9 +403,39 @@ class LatentDiffusion(_Base):
         if getattr(self, "_trainer", None) is None:
             from .train import UNetTrainer
             self._trainer = UNetTrainer(self.model.diffusion_model)
-            self._ema_flat = self._trainer.P.flat.clone() if self.use_ema else None
+            self._ema_flat = None
+            if self.use_ema:
+                # the shadow starts from the `model_ema` buffers (what a checkpoint restored), not from the live
+                # weights: resuming keeps the stored average like the reference's LitEma does (ema.py:25-44)
+                pre = "diffusion_model."
+                ema_sd = {k[len(pre):]: self.model_ema.shadow_of(k) for k in self.model_ema.m_name2s_name
+                          if k.startswith(pre)}
+                self._ema_flat = self._trainer.pack_reference_state(ema_sd)
             self._cond_opt = None
         return self._trainer
+
+    def training_state(self):
+        """Everything a faithful resume needs beyond the module's own state dict: packed weights + AdamW moments + step
+        (UNetTrainer.optimizer_state), the packed EMA shadow, and the conditioner optimisers."""
+        tr = self.trainer()
+        st = dict(unet=tr.optimizer_state(), ema_flat=None if self._ema_flat is None else self._ema_flat.clone())
+        for key in ("_cond_opt", "_audio_opt"):
+            opt = getattr(self, key, None)
+            st[key] = None if opt is None else opt.state_dict()
+        return st
+
+    def load_training_state(self, st, lr=1e-4, weight_decay=1e-2):
+        tr = self.trainer()
+        tr.load_optimizer_state(st["unet"])
+        if st.get("ema_flat") is not None and self.use_ema:
+            self._ema_flat.copy_(st["ema_flat"])
+        owners = {"_cond_opt": getattr(self, "cond_stage_model_1", None) or self.cond_stage_model,
+                  "_audio_opt": getattr(self, "cond_stage_model_2", None)}
+        for key, owner in owners.items():
+            if st.get(key) is not None and owner is not None:
+                opt = torch.optim.AdamW(owner.parameters(), lr=lr, weight_decay=weight_decay)
+                opt.load_state_dict(st[key])
+                setattr(self, key, opt)
 
     def _context_tensor(self, cond):
         if isinstance(cond, dict):
@@ -462,7 +511,10 @@ class LatentDiffusion(_Base):
     def training_step(self, batch, batch_idx=0):
         """ddpm.py:341-358 with manual optimisation: batch -> (latents, condition) -> one full step."""
         z, c = self.get_input(batch, self.first_stage_key)
-        loss, loss_dict = self.training_step_latents(z, c, float(getattr(self, "learning_rate", 1e-4)))
+        lr = float(getattr(self, "learning_rate", 1e-4))
+        if getattr(self, "lr_schedule", None) is not None:
+            lr *= float(self.lr_schedule(self.trainer().P.step))
+        loss, loss_dict = self.training_step_latents(z, c, lr)
         self.log_dict(loss_dict, prog_bar=True, logger=True, on_step=True, on_epoch=True)
         return loss
 
@@ -477,6 +529,48 @@ class LatentDiffusion(_Base):
         x = x.permute(0, 3, 1, 2).contiguous().float().to(self.device)
         z = self.get_first_stage_encoding(self.encode_first_stage(x)).detach()
         return z, batch
+
+    def configure_optimizers(self):
+        """ddpm.py:1363-1385.  The UNet's AdamW runs inside the HIP training engine (`ldmk_adamw` over the flat packed
+        buffer, driven by `training_step`), so what Lightning receives here is the optimiser of the parameters that
+        stay under torch autograd: the trainable conditioner.  `learning_rate` is read per step by `training_step`; a
+        `scheduler_config` is instantiated and exposed as `lr_schedule` (step -> multiplier), which `training_step`
+        applies to both optimisers."""
+        lr = float(getattr(self, "learning_rate", 1e-4))
+        self.lr_schedule = None
+        if self.use_scheduler:
+            assert "target" in self.scheduler_config
+            self.lr_schedule = instantiate_from_config(self.scheduler_config).schedule
+        if not self.cond_stage_trainable or self.cond_stage_model is None:
+            return None
+        print(f"{self.__class__.__name__}: Also optimizing conditioner params!")
+        self._cond_opt = torch.optim.AdamW(self.cond_stage_model.parameters(), lr=lr)
+        return self._cond_opt
+
+    @torch.no_grad()
+    def log_images(self, batch, N=8, n_row=4, sample=True, ddim_steps=200, ddim_eta=1., return_keys=None,
+                   quantize_denoised=False, inpaint=False, plot_denoise_rows=False, plot_progressive_rows=False,
+                   plot_diffusion_rows=False, **kwargs):
+        """ddpm.py:1253-1361, the hook ImageLogger calls during training: inputs, first-stage reconstruction, and
+        samples drawn under `ema_scope` (DDIM when `ddim_steps` is set), decoded.  The diagnostic rows the shipped
+        logger settings leave off (denoise / progressive / diffusion rows, inpainting, quantised x0) raise."""
+        if quantize_denoised or inpaint or plot_denoise_rows or plot_progressive_rows or plot_diffusion_rows:
+            raise NotImplementedError("log_images: only inputs / reconstruction / samples are produced")
+        x = batch[self.first_stage_key]
+        x = (x[..., None] if x.dim() == 3 else x)[:N].permute(0, 3, 1, 2).contiguous().float().to(self.device)
+        z = self.get_first_stage_encoding(self.encode_first_stage(x))
+        log = {"inputs": x, "reconstruction": self.decode_first_stage(z)}
+        if sample:
+            cond = batch[self.cond_stage_key]
+            cond = {self.cond_stage_key: cond[:N]} if not isinstance(cond, dict) else cond
+            c = self.get_learned_conditioning(cond) if self.cond_stage_model is not None else None
+            with self.ema_scope("Plotting"):
+                samples, _ = self.sample_log(cond=c, batch_size=x.shape[0], ddim=ddim_steps is not None,
+                                             ddim_steps=ddim_steps, eta=ddim_eta)
+            log["samples"] = self.decode_first_stage(samples)
+        if return_keys and any(k in log for k in return_keys):
+            return {k: log[k] for k in return_keys if k in log}
+        return log
 
     def sync_trained_weights(self):
         """Copy the trained (and EMA) weights from the training engine back into the nn.Module tree, so that

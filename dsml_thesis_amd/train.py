@@ -617,6 +617,15 @@ class UNetTrainer:
     def ema_update(self, shadow_flat, decay):
         T.ema_(shadow_flat, self.P.flat, 1.0 - decay)
 
+    def pack_reference_state(self, sd):
+        """Reference-layout tensors (state-dict key -> tensor, e.g. the `model_ema` shadow of a checkpoint) -> one flat
+        buffer in this trainer's packed layout: the inverse of state_dict_reference()."""
+        flat = torch.zeros_like(self.P.flat)
+        sd = {k: v.to(self.dev, torch.float32) for k, v in sd.items()}
+        for name, shape, off, n in self.P.specs:
+            flat[off:off + n].view(shape).copy_(reference_grad_layout(self.unet, name, sd).reshape(shape))
+        return flat
+
     # ---- back to the reference's state-dict layout -------------------------------------------------------------
     def state_dict_reference(self, flat=None):
         """Unpack the flat (packed-layout) parameters into the reference's state-dict keys and shapes

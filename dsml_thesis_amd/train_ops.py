@@ -49,13 +49,21 @@ def wgrad(w):
 
 
 _WS = {}
+_WS_RETIRED = []     # outgrown scratches stay alive: a captured hipGraph may still replay partial sums into them
 
 
 def _workspace(dev, elems):
-    """One grow-only scratch per device for the wgrad partial slabs (stream-ordered reuse)."""
+    """One scratch per device for the wgrad partial slabs (stream-ordered reuse).  It only grows outside a stream
+    capture, geometrically (so the retired ones add up to less than the live one), and an outgrown scratch is never
+    freed: hipGraphs captured earlier keep its address."""
     ws = _WS.get(dev)
     if ws is None or ws.numel() < elems:
-        ws = _f32(max(int(elems), 1 << 22), device=dev)
+        if torch.cuda.is_current_stream_capturing():
+            raise L.LdmkError(f"wgrad scratch of {elems} floats requested during a stream capture, but only "
+                              f"{0 if ws is None else ws.numel()} are allocated: run the step once eagerly first")
+        if ws is not None:
+            _WS_RETIRED.append(ws)
+        ws = _f32(max(int(elems), 1 << 22, 0 if ws is None else 2 * ws.numel()), device=dev)
         _WS[dev] = ws
     return ws
 

@@ -162,6 +162,27 @@ def test_g6_vqgan():
     close(O.encode_first_stage(sd, W.VQ_F4, img), g["encoded"], 1e-4, 2e-4)
 
 
+def test_g11_northstar_shapes():
+    """The oracle against the real reference at BASELINE.json's metric shape: dim-4 / 16384-code quantiser (indices
+    bit-exact), decode 4x64x64 -> 3x256x256, DDIMSampler.sample S=4 at 64x64x4."""
+    g = golden("g11_northstar.npz")
+    vsd = recipe(W.vqmodel_param_shapes(W.VQ_F4_256))
+    z = rnd(112, 1, 4, 64, 64)
+    zq, idx = O.vq_quantize(z, vsd["quantize.embedding.weight"])
+    assert np.array_equal(idx.reshape(-1).numpy(), g["vq4_idx"].reshape(-1))
+    close(zq, g["vq4_zq"], 0, 0)
+    img, _ = O.decode_first_stage(vsd, W.VQ_F4_256, z)
+    close(img, g["decoded256"], 1e-4, 2e-4)
+    vsd128 = recipe(W.vqmodel_param_shapes(W.VQ_F4))
+    img128, _ = O.decode_first_stage(vsd128, W.VQ_F4, rnd(61, 1, 3, 32, 32))
+    close(img128, g["decoded128"], 1e-4, 2e-4)
+    usd = recipe(W.unet_param_shapes(W.NS_UNET), gain=0.25)
+    emb = T(W.synth_tensor("embedding.weight", (8, 512)))
+    out = O.ddim_sample(usd, W.NS_UNET, O.register_schedule(**W.SCHEDULE), 4, rnd(111, 2, 4, 64, 64),
+                        cond=emb[[3, 4]][:, None])
+    close(out, g["sample_S4"], 1e-4, 1e-4)
+
+
 def test_g7_talking_face():
     g = golden("g7_talking_face.npz")
     usd = recipe(W.unet_param_shapes(W.TF_UNET))

@@ -111,18 +111,16 @@ def test_first_stage_decode_encode_golden():
     m = make_fr_model()
     z = rnd(61, 1, 3, 32, 32).cuda()
     img, idx = m.first_stage_model.decode(z, return_indices=True)
-    ref_idx = g["vq_idx"].reshape(-1)
-    nm = int((idx.cpu().numpy() != ref_idx).sum())
-    assert nm <= 2, f"{nm} codebook index mismatches"
-    if nm == 0:
-        close(m.decode_first_stage(z), g["decoded"].astype(np.float32), 2e-3, 2e-3)      # fixture is fp16
-        st = g["decoded_stats"]
-        assert abs(img.abs().max().item() - st[0]) < 2e-3 and abs(img.std().item() - st[2]) < 1e-4
+    assert np.array_equal(idx.cpu().numpy(), g["vq_idx"].reshape(-1))          # index work: bit-exact
+    close(m.decode_first_stage(z), g["decoded"].astype(np.float32), 2e-3, 2e-3)      # g6 stores fp16
+    close(img, golden("g11_northstar.npz")["decoded128"], 3e-4, 3e-4)                 # the same frame in fp32
+    st = g["decoded_stats"]
+    assert abs(img.abs().max().item() - st[0]) < 2e-3 and abs(img.std().item() - st[2]) < 1e-4
     # tight check against the oracle recomputed here in fp32
     sd = W.synth_state_dict(W.vqmodel_param_shapes(W.VQ_F4))
     ref, ridx = O.decode_first_stage(sd, W.VQ_F4, z.cpu())
-    if (idx.cpu().long() == ridx).all():
-        close(img, ref, 3e-4, 3e-4)
+    assert torch.equal(idx.cpu().long(), ridx.reshape(-1))
+    close(img, ref, 3e-4, 3e-4)
     x = torch.tanh(rnd(64, 1, 3, 128, 128)).cuda()
     close(m.encode_first_stage(x), g["encoded"], 3e-4, 3e-4)
     # batch > 1 and no-quantise path
@@ -163,21 +161,49 @@ def test_talking_face_progressive_golden():
 
 
 def test_ema_scope_swaps_weights_and_repacks(fr):
+    """Inside ema_scope EVERY weight the kernels read is the EMA one (packed conv / linear matrices included, not only
+    the aliased biases): the in-scope output equals the oracle evaluated on the shadow weights."""
     c, _ = _cond(fr)
     x, t = rnd(90, 1, 3, 32, 32).cuda(), torch.tensor([400], device="cuda")
     base = fr.apply_model(x, t, c[:1])
     with torch.no_grad():
-        for b_ in fr.model_ema.buffers():
+        for name, b_ in fr.model_ema.named_buffers():
             if b_.dtype.is_floating_point and b_.dim() > 0:
-                b_.mul_(0.5)
+                b_.mul_(0.5 if b_.dim() > 1 else 0.9)
+    ema_sd = {k[len("diffusion_model."):]: fr.model_ema.shadow_of(k).detach().cpu().clone()
+              for k in fr.model_ema.m_name2s_name if k.startswith("diffusion_model.")}
+    ref = O.unet_forward(ema_sd, W.FR_UNET, x.cpu(), t.cpu(), c[:1].cpu())
     with fr.ema_scope():
         ema = fr.apply_model(x, t, c[:1])
     again = fr.apply_model(x, t, c[:1])
+    close(ema, ref, 5e-4, 5e-4)
     assert not torch.allclose(base, ema) and torch.equal(base, again)
     keys = fr.state_dict().keys()
     assert "model.diffusion_model.input_blocks.1.0.in_layers.2.weight" in keys
     assert "model_ema.diffusion_modelinput_blocks10in_layers2weight" in keys
     assert "first_stage_model.decoder.up.2.attn.1.q.weight" in keys and "cond_stage_model.embedding.weight" in keys
+
+
+def test_northstar_trajectory_and_decode_golden():
+    """BASELINE.json's metric shape, against outputs of the real reference (tests/golden/g11_northstar.npz):
+    DDIMSampler.sample S=4 at 64x64x4 (B=2), then decode_first_stage 4x64x64 -> 3x256x256 with bit-exact indices."""
+    from dsml_thesis_amd import synth
+    from dsml_thesis_amd.ddim import DDIMSampler
+    g = golden("g11_northstar.npz")
+    m = make_fr_model(gain=0.25, unet=synth.NS_UNET, vq=synth.VQ_F4_256)
+    labels = torch.tensor([3, 4], device="cuda")
+    c = m.cond_stage_model.embedding(labels[:, None])
+    xT = rnd(111, 2, 4, 64, 64).cuda()
+    for use_graph in (False, True):
+        out, inter = DDIMSampler(m).sample(S=4, batch_size=2, shape=[4, 64, 64], conditioning=c, eta=0.0, x_T=xT,
+                                           verbose=False, log_every_t=1, use_graph=use_graph)
+        close(inter["x_inter"][1], g["x_inter_1"], 2e-4, 2e-4)
+        close(out, g["sample_S4"], 5e-4, 5e-4)
+    z = rnd(112, 1, 4, 64, 64).cuda()
+    img, idx = m.first_stage_model.decode(z, return_indices=True)
+    assert np.array_equal(idx.cpu().numpy(), g["vq4_idx"].reshape(-1))
+    close(img, g["decoded256"], 3e-4, 3e-4)
+    close(m.decode_first_stage(z, force_not_quantize=True), g["decoded256_noquant"], 3e-4, 3e-4)
 
 
 def test_sharded_sampling_bitwise_equals_single_gpu(fr):

@@ -156,6 +156,41 @@ def test_latent_diffusion_training_step_updates_unet_conditioner_and_ema():
     assert not torch.equal(eps_ema, eps1)
 
 
+def test_ema_shadow_resumes_from_the_checkpointed_model_ema_and_training_state_round_trips():
+    """Resume semantics of LitEma (ema.py:25-44): the packed shadow starts from the `model_ema` buffers a checkpoint
+    restored -- not from the live weights -- so one step gives decay*old_ema + (1-decay)*new_weights; and
+    training_state()/load_training_state() carry the shadow and the conditioner optimiser."""
+    from helpers import make_fr_model
+    model = make_fr_model(gain=0.5).train()
+    with torch.no_grad():                                 # a checkpoint whose EMA differs from the model
+        for b_ in model.model_ema.buffers():
+            if b_.dtype.is_floating_point and b_.dim() > 0:
+                b_.mul_(0.75)
+        model.model_ema.num_updates.fill_(1000)
+    tr = model.trainer()
+    pre = "diffusion_model."
+    ema_sd = {k[len(pre):]: model.model_ema.shadow_of(k) for k in model.model_ema.m_name2s_name if k.startswith(pre)}
+    back = tr.state_dict_reference(model._ema_flat)
+    for k, v in ema_sd.items():
+        assert torch.equal(back[k], v), k                 # pack_reference_state is the exact inverse
+    old = model._ema_flat.clone()
+    z = rnd(90, 2, 3, 32, 32).cuda()
+    batch = {"class_label": torch.tensor([1, 5]).cuda()}
+    model.cond_stage_model.p_uncond = 0.0
+    model.training_step_latents(z, batch, lr=1e-5, t=torch.tensor([300, 800]).cuda(), noise=rnd(93, 2, 3, 32, 32).cuda())
+    n_up = int(model.model_ema.num_updates)
+    assert n_up == 1001
+    decay = min(float(model.model_ema.decay), (1 + n_up) / (10 + n_up))
+    want = old - (1.0 - decay) * (old - tr.P.flat)
+    torch.testing.assert_close(model._ema_flat, want, rtol=1e-6, atol=1e-7)
+    st = model.training_state()
+    assert st["ema_flat"] is not None and st["_cond_opt"] is not None and st["unet"]["step"] == 1
+    other = make_fr_model(gain=0.5).train()
+    other.load_training_state(st)
+    assert torch.equal(other._ema_flat, model._ema_flat) and torch.equal(other.trainer().P.flat, tr.P.flat)
+    assert other._cond_opt is not None and other.trainer().P.step == 1
+
+
 def test_p_losses_against_reference_fixture():
     """tests/golden/g9_p_losses.npz holds loss and gradients of the reference's own LatentDiffusion.p_losses +
     autograd (tools/make_golden.py --tree train).  The HIP step must reproduce them."""

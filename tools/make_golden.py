@@ -577,9 +577,97 @@ def gen_tf():
     save("g7_talking_face.npz", **g)
 
 
+# --------------------------------------------------------------------------- north-star shapes (BASELINE.json metric)
+def gen_northstar():
+    """G11: the shapes BASELINE.json quotes its metric on (64x64x4 latent -> 256x256 face), from the real reference:
+    a full DDIMSampler.sample trajectory (S=4, B=2), the dim-4 / 16384-code quantiser on 4096 latent vectors (indices
+    must match bit for bit), and decode_first_stage 4x64x64 -> 3x256x256 stored in fp32."""
+    from tools import ref_shims
+    ref_shims.install("face_reenactment")
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    torch.set_grad_enabled(False)
+    unet_cfg = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(W.NS_UNET))
+    fs_cfg = dict(target="ldm.models.autoencoder.VQModelInterface",
+                  params=dict(embed_dim=4, n_embed=16384, ddconfig=dict(W.VQ_F4_256["ddconfig"]),
+                              lossconfig=dict(target="torch.nn.Identity")))
+    cond_cfg = dict(target="ldm.modules.encoders.modules.ClassEmbedder3",
+                    params=dict(embed_dim=512, n_classes=8, key="class_label", p_uncond=0.2))
+    ld = LatentDiffusion(first_stage_config=fs_cfg, cond_stage_config=cond_cfg, num_timesteps_cond=1,
+                         cond_stage_key="class_label", cond_stage_trainable=True,
+                         conditioning_key="crossattn", unet_config=unet_cfg, image_size=64, channels=4,
+                         first_stage_key="image", log_every_t=200, monitor="val_loss_ema", **W.SCHEDULE)
+    sched = O.register_schedule(**W.SCHEDULE)
+
+    class CPUDDIM(DDIMSampler):
+        def register_buffer(self, n, a):
+            setattr(self, n, a)
+
+    g = {}
+    print("[G11] 64x64x4 DDIM trajectory")
+    usd = load_recipe(ld.model.diffusion_model, seed=0, gain=0.25, prefix_check=W.unet_param_shapes(W.NS_UNET))
+    csd = load_recipe(ld.cond_stage_model, seed=0)
+    labels = torch.tensor([3, 4])
+    c = ld.cond_stage_model.embedding(labels[:, None])
+    xT = rnd(111, 2, 4, 64, 64)
+    ref, inter = CPUDDIM(ld).sample(S=4, batch_size=2, shape=[4, 64, 64], conditioning=c, eta=0.0, x_T=xT, verbose=False,
+                                    log_every_t=1)
+    mine = O.ddim_sample(usd, W.NS_UNET, sched, 4, xT, cond=csd["embedding.weight"][labels][:, None])
+    check("DDIMSampler.sample S=4 @64x64x4", ref, mine, 1e-4, 1e-4)
+    g["sample_S4"] = ref
+    g["x_inter_1"] = inter["x_inter"][1]          # after the first step: localises a failure
+
+    print("[G11] dim-4 / 16384-code quantiser")
+    fsm = ld.first_stage_model
+    vsd = load_recipe(fsm, seed=0, prefix_check=W.vqmodel_param_shapes(W.VQ_F4_256))
+    z = rnd(112, 1, 4, 64, 64)
+    zq, _, (_, _, idx) = fsm.quantize(z)
+    mzq, midx = O.vq_quantize(z, vsd["quantize.embedding.weight"])
+    assert (idx == midx).all()
+    check("vq4 z_q", zq, mzq, 0, 0)
+    g["vq4_idx"], g["vq4_zq"] = idx.to(torch.int32), zq
+    # the rounding sequence of the distance (what the HIP kernel restates): squares rounded then added left to right,
+    # k-ordered fma dot product, fl(fl(zz + ee) - 2 ze); checked here on all 4096 x 16384 distances
+    zf = z.permute(0, 2, 3, 1).reshape(-1, 4)
+    e = vsd["quantize.embedding.weight"]
+    d_ref = torch.sum(zf ** 2, dim=1, keepdim=True) + torch.sum(e ** 2, dim=1) - 2 * torch.einsum("bd,dn->bn", zf, e.t())
+
+    def sq(x):
+        acc = x[:, 0] * x[:, 0]
+        for k in range(1, x.shape[1]):
+            acc = acc + x[:, k] * x[:, k]
+        return acc
+
+    ze = (zf[:, :1].double() * e[None, :, 0].double()).float()
+    for k in range(1, 4):
+        ze = (zf[:, k:k + 1].double() * e[None, :, k].double() + ze.double()).float()
+    d_mine = (sq(zf)[:, None] + sq(e)[None, :]) - 2 * ze
+    assert torch.equal(d_ref, d_mine), "distance rounding sequence differs from the documented one"
+    print("  distance rounding sequence reproduced bit for bit on", d_ref.numel(), "distances")
+
+    print("[G11] decode 4x64x64 -> 3x256x256")
+    ref = ld.decode_first_stage(z)
+    mine, _ = O.decode_first_stage(vsd, W.VQ_F4_256, z)
+    check("decode_first_stage 256^2", ref, mine, 1e-4, 2e-4)
+    g["decoded256"] = ref
+    g["decoded256_noquant"] = ld.decode_first_stage(z, force_not_quantize=True)
+
+    print("[G11] decode 3x32x32 -> 3x128x128 in fp32 (g6 holds this frame in fp16 only)")
+    from ldm.models.autoencoder import VQModelInterface
+    fs128 = VQModelInterface(embed_dim=3, n_embed=16384, ddconfig=dict(W.VQ_F4["ddconfig"]),
+                             lossconfig=dict(target="torch.nn.Identity"))
+    vsd128 = load_recipe(fs128, seed=0, prefix_check=W.vqmodel_param_shapes(W.VQ_F4))
+    z128 = rnd(61, 1, 3, 32, 32)
+    ref = fs128.decode(z128)
+    mine, _ = O.decode_first_stage(vsd128, W.VQ_F4, z128)
+    check("decode_first_stage 128^2", ref, mine, 1e-4, 2e-4)
+    g["decoded128"] = ref
+    save("g11_northstar.npz", **g)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip"])
+    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar"])
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -591,6 +679,8 @@ if __name__ == "__main__":
         gen_fr()
     elif a.tree == "talking_face":
         gen_tf()
+    elif a.tree == "northstar":
+        gen_northstar()
     else:
-        for tree in ("face_reenactment", "talking_face", "train", "diffclip"):
+        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", tree], cwd=ROOT)
