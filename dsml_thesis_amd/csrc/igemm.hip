@@ -575,6 +575,11 @@ static int dispatch(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hi
   }
 }
 
+// the wave-autonomous row GEMM (rgemm.hip): tile_cfg kNumCfg+1 .. kNumCfg+6
+const char* rgemm_unsupported(const ldmk_igemm_args& a, int rcfg);
+int rgemm_dispatch(const ldmk_igemm_args& a, int rcfg, hipStream_t st);
+constexpr int kNumRCfg = 6;
+
 }  // namespace ldmk
 
 // test hook: force a tile configuration (0 = heuristic)
@@ -617,13 +622,19 @@ extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) {
   if (a.stats_out)
     LDMK_REQUIRE(a.M % 32 == 0 && a.rows_per_sample % 32 == 0 && a.epi == LDMK_EPI_NONE && a.batch <= 1,
                  "ldmk_igemm: stats_out needs M%%32==0, rows_per_sample%%32==0, no GEGLU, no batching");
-  LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]", a.tile_cfg, kNumCfg);
+  LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg + kNumRCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]", a.tile_cfg,
+               kNumCfg + kNumRCfg);
   LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 16, "ldmk_igemm: splitk=%d outside [0,16]", a.splitk);
   if (a.alpha == 0.f) a.alpha = 1.f;
   int cfg = 0, sk = 1;
   plan(a, &cfg, &sk, a.splitk_ws ? a.splitk_ws_elems : 0);
   if (a.tile_cfg > 0) cfg = a.tile_cfg;
-  if (g_force_cfg > 0) cfg = g_force_cfg;
+  if (g_force_cfg > 0 && (g_force_cfg <= kNumCfg || !rgemm_unsupported(a, g_force_cfg - kNumCfg - 1))) cfg = g_force_cfg;
+  if (cfg > kNumCfg) {      // row GEMM: one wave per output tile, K never split
+    const char* why = rgemm_unsupported(a, cfg - kNumCfg - 1);
+    LDMK_REQUIRE(why == nullptr, "ldmk_igemm: tile_cfg=%d (row GEMM) cannot run this problem: %s", cfg, why ? why : "");
+    return rgemm_dispatch(a, cfg - kNumCfg - 1, (hipStream_t)stream);
+  }
   if (a.splitk > 0) sk = a.splitk;
   if (a.epi == LDMK_EPI_GEGLU) sk = 1;
   if (sk > 1) {

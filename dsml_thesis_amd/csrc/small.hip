@@ -299,7 +299,11 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict
     const int oh = __shfl_xor(has, o, 64);
     if (oh && (!has || vq_before(ob, oi, best, besti))) { best = ob; besti = oi; has = 1; }
   }
-  if (lane < DIM) zq[((long long)b * DIM + lane) * hw + p] = cb[(long long)besti * DIM + lane];
+  if (lane < DIM) {
+    // the reference returns the straight-through value z + (e - z) (quantize.py:299), which is not e bit for bit
+    const float zl = z[((long long)b * DIM + lane) * hw + p];
+    zq[((long long)b * DIM + lane) * hw + p] = __fadd_rn(zl, __fsub_rn(cb[(long long)besti * DIM + lane], zl));
+  }
   if (lane == 0 && idx_out) idx_out[pix] = besti;
 }
 

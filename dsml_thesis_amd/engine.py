@@ -121,6 +121,8 @@ class Program:
                 args.M = max(1, m * scale_m[0] // scale_m[1])
         cfg, sk = C.c_int(0), C.c_int(0)
         tuned = tuned_plan(args, args.M) if nbatch <= 1 and args.M > 0 else None
+        if tuned is not None and tuned[0] > 6 and not args.w_frag:
+            tuned = None                                  # a row-GEMM plan without the fragment-order weight copy
         if tuned is not None:
             cfg.value, sk.value = int(tuned[0]), int(tuned[1])
         else:
@@ -242,8 +244,9 @@ class NetBuilder:
             a.stats_out = part.data_ptr()
             self.attach_stats(out2d, part)
 
-    def lin(self, x0, wp, bias, rows_per_sample, x1=None, out=None, geglu=False, stats=False, **kw):
-        """Linear / 1x1 conv on token rows, with the igemm prologue/epilogue options passed through."""
+    def lin(self, x0, wp, bias, rows_per_sample, x1=None, out=None, geglu=False, stats=False, wf=None, **kw):
+        """Linear / 1x1 conv on token rows, with the igemm prologue/epilogue options passed through.  `wf`: the
+        fragment-order copy of wp (ops.pack_wfrag); with it the plan may pick the wave-autonomous row GEMM."""
         pg, ops = self.pg, self.ops
         M, c0 = x0.shape[0], x0.shape[-1]
         c1 = 0 if x1 is None else x1.shape[-1]
@@ -252,7 +255,7 @@ class NetBuilder:
         if out is None:
             out = pg.alloc(M, ncol)
         a = ops.make_igemm_args(M, N, c0 + c1, x0, c0, wp, out, ncol, rows_per_sample, a1=x1, c1=c1, bias=bias,
-                                epi=L.EPI_GEGLU if geglu else L.EPI_NONE, **kw)
+                                epi=L.EPI_GEGLU if geglu else L.EPI_NONE, w_frag=wf, **kw)
         self._maybe_stats(a, out, rows_per_sample, stats)
         pg.igemm(a, self.pin)
         return out

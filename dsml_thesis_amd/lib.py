@@ -27,7 +27,7 @@ class IgemmArgs(C.Structure):
         ("out", _fp), ("ldc", C.c_int), ("batch", C.c_int),
         ("a_bstride", C.c_longlong), ("w_bstride", C.c_longlong), ("out_bstride", C.c_longlong),
         ("alpha", C.c_float), ("tile_cfg", C.c_int), ("splitk", C.c_int),
-        ("splitk_ws", _fp), ("splitk_ws_elems", C.c_longlong), ("stats_out", _fp),
+        ("splitk_ws", _fp), ("splitk_ws_elems", C.c_longlong), ("stats_out", _fp), ("w_frag", _fp),
     ]
 
 
@@ -48,6 +48,8 @@ _SIGS = {
     "ldmk_igemm": (C.c_int, [C.POINTER(IgemmArgs), _fp]),
     "ldmk_igemm_plan": (C.c_int, [C.POINTER(IgemmArgs), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ldmk_igemm_force_config": (None, [C.c_int]),
+    "ldmk_wfrag_elems": (C.c_longlong, [C.c_int, C.c_int]),
+    "ldmk_pack_wfrag": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ldmk_attn_force_qt": (None, [C.c_int]),
     "ldmk_gn_chunks": (C.c_int, [C.c_int]),
     "ldmk_gn_partial": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),

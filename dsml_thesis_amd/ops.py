@@ -55,6 +55,18 @@ def pack_linear(w):
     return out
 
 
+def pack_wfrag(wp):
+    """[K][N] packed weight -> its MFMA-fragment-order copy for the row GEMM (ldmk_pack_wfrag); None when the shape
+    cannot be packed (K % 8 or N % 32)."""
+    _chk(wp, "pack_wfrag")
+    k, n = wp.shape
+    if L.load().ldmk_wfrag_elems(k, n) < 0:
+        return None
+    out = torch.empty(k * n, device=wp.device, dtype=torch.float32)
+    L.call("ldmk_pack_wfrag", _ptr(wp), n, k, n, _ptr(out), stream())
+    return out
+
+
 def pack_geglu(w, b):
     """GEGLU proj weight [2*inner][K] / bias [2*inner] -> packed [K][2*inner] / [2*inner] where every
     64-column block is (32 value columns | their 32 gate columns), so that one wave holds both halves."""
@@ -105,7 +117,7 @@ def ln_stats(x2d, eps=1e-5, out=None):
 def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0, conv=None, tf=L.TF_NONE,
                     tf_coef=None, row_stats=None, ln_gamma=None, ln_beta=None, b_trans=False, ldb=None, bias=None,
                     batch_vec=None, batch_vec_ld=0, residual=None, epi=L.EPI_NONE, batch=1, a_bstride=0, w_bstride=0,
-                    out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None):
+                    out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None, w_frag=None, tile_cfg=0):
     a = L.IgemmArgs()
     a.M, a.N, a.K = M, N, K
     a.a0, a.a1, a.c0, a.c1 = _ptr(a0), _ptr(a1), c0, c1
@@ -125,6 +137,7 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
     a.a_bstride, a.w_bstride, a.out_bstride = a_bstride, w_bstride, out_bstride
     a.alpha = alpha
     a.splitk = splitk
+    a.w_frag, a.tile_cfg = _ptr(w_frag), tile_cfg
     if splitk_ws is not None:
         a.splitk_ws, a.splitk_ws_elems = splitk_ws.data_ptr(), splitk_ws.numel()
     return a
@@ -160,7 +173,8 @@ def conv3x3(x, wp, bias=None, x1=None, stride=1, pad_lo=1, upsample=False, coef=
 
 
 def linear(x2d, wp, bias=None, x1=None, rows_per_sample=None, coef=None, silu=False, row_stats=None, ln_gamma=None,
-           ln_beta=None, batch_vec=None, residual=None, geglu=False, out=None, b_trans=False):
+           ln_beta=None, batch_vec=None, residual=None, geglu=False, out=None, b_trans=False, w_frag=None, tile_cfg=0,
+           stats_out=None):
     """x2d: [M][c0] (+ x1 [M][c1]); wp: [K][N] (or torch [N][K] with b_trans) -> [M][N] (N/2 for geglu)."""
     M, c0 = x2d.shape
     c1 = 0 if x1 is None else x1.shape[-1]
@@ -177,7 +191,9 @@ def linear(x2d, wp, bias=None, x1=None, rows_per_sample=None, coef=None, silu=Fa
     a = make_igemm_args(M, N, K, x2d, c0, wp, out, ncol, rows_per_sample or M, a1=x1, c1=c1, tf=tf, tf_coef=coef,
                         row_stats=row_stats, ln_gamma=ln_gamma, ln_beta=ln_beta, b_trans=b_trans, bias=bias,
                         batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0),
-                        residual=residual, epi=L.EPI_GEGLU if geglu else L.EPI_NONE)
+                        residual=residual, epi=L.EPI_GEGLU if geglu else L.EPI_NONE, w_frag=w_frag, tile_cfg=tile_cfg)
+    if stats_out is not None:
+        a.stats_out = _ptr(stats_out)
     igemm(a)
     return out
 

@@ -275,6 +275,11 @@ class UNetModel(nn.Module):
         P["te2"] = ops.pack_linear(sd["time_embed.2.weight"])
         P["out"] = ops.pack_conv3x3_narrow(sd["out.2.weight"])
         P["freqs"] = ops.timestep_freqs(self.model_channels, device=dev)
+        # fragment-order copies of the token-row Linear weights: the row GEMM (csrc/rgemm.hip) reads these
+        for k in [k for k in P if k.rsplit(".", 1)[-1] in ("pin", "pout", "qkv", "o1", "q2", "o2", "ff1", "ff2", "skip")]:
+            wf = ops.pack_wfrag(P[k])
+            if wf is not None:
+                P[k + "#f"] = wf
         self._sd = sd
         self._packed = P
         self._pack_sig = self._signature()
@@ -338,7 +343,7 @@ class UNetModel(nn.Module):
             if m.cin != m.cout:
                 x0r = x0.reshape(n * hw, -1)
                 x1r = None if x1 is None else x1.reshape(n * hw, -1)
-                skip = lin(x0r, P[prefix + "skip"], sd[prefix + "skip_connection.bias"], hw, x1=x1r)
+                skip = lin(x0r, P[prefix + "skip"], sd[prefix + "skip_connection.bias"], hw, x1=x1r, wf=P.get(prefix + "skip#f"))
                 out = conv(y2, None, P[prefix + "c2"], sd[prefix + "out_layers.3.bias"], h, w, residual=skip,
                            out=skip.view(n, h, w, m.cout), stats=True)
             else:
@@ -353,7 +358,7 @@ class UNetModel(nn.Module):
             rows = n * hw
             xr = x.reshape(rows, m.ch)
             coef = gn(x, None, hw, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-6)
-            hcur = lin(xr, P[prefix + "pin"], sd[prefix + "proj_in.bias"], hw, tf=L.TF_AFFINE, tf_coef=coef)
+            hcur = lin(xr, P[prefix + "pin"], sd[prefix + "proj_in.bias"], hw, tf=L.TF_AFFINE, tf_coef=coef, wf=P.get(prefix + "pin#f"))
             nb_.release(coef)
             stats = pg.alloc(rows, 2)
             for d in range(m.depth):
@@ -361,7 +366,7 @@ class UNetModel(nn.Module):
                 # --- attn1 (self): LN1 folded into the fused QKV GEMM, flash attention, to_out + residual
                 pg.add("ldmk_ln_stats", p_(hcur), rows, C_, 1e-5, p_(stats))
                 qkv = lin(hcur, P[q + "qkv"], None, hw, tf=L.TF_LAYERNORM, row_stats=stats,
-                          ln_gamma=sd[q + "norm1.weight"], ln_beta=sd[q + "norm1.bias"])
+                          ln_gamma=sd[q + "norm1.weight"], ln_beta=sd[q + "norm1.bias"], wf=P.get(q + "qkv#f"))
                 att = pg.alloc(rows, C_)
                 pg.add("ldmk_attn_self", p_(qkv), p_(att), n, hw, m.heads, m.d_head ** -0.5)
                 nb_.release(qkv)
@@ -375,11 +380,11 @@ class UNetModel(nn.Module):
                     ctx_pg.add("ldmk_dense_small", p_(v), C_, p_(P[q + "o2"]), p_(sd[q + "attn2.to_out.0.bias"]), p_(cvec),
                                C_, n, C_, C_, 0)
                     h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur,
-                             batch_vec=cvec, batch_vec_ld=C_)      # + the per-sample cross-attention vector
+                             batch_vec=cvec, batch_vec_ld=C_, wf=P.get(q + "o1#f"))   # + the per-sample cross-attention vector
                     nb_.release(att)
                     h2 = h1
                 else:
-                    h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur)
+                    h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur, wf=P.get(q + "o1#f"))
                     kk = ctx_pg.alloc(n * L_ctx, C_)
                     vv = ctx_pg.alloc(n * L_ctx, C_)
                     ctx_pg.add("ldmk_dense_small", p_(ctx_in), self.context_dim, p_(P[q + "k2"]), 0, p_(kk), C_,
@@ -388,19 +393,19 @@ class UNetModel(nn.Module):
                                n * L_ctx, self.context_dim, C_, 0)
                     pg.add("ldmk_ln_stats", p_(h1), rows, C_, 1e-5, p_(stats))
                     q2 = lin(h1, P[q + "q2"], None, hw, tf=L.TF_LAYERNORM, row_stats=stats,
-                             ln_gamma=sd[q + "norm2.weight"], ln_beta=sd[q + "norm2.bias"], out=att)
+                             ln_gamma=sd[q + "norm2.weight"], ln_beta=sd[q + "norm2.bias"], out=att, wf=P.get(q + "q2#f"))
                     a2 = pg.alloc(rows, C_)
                     pg.add("ldmk_attn_cross", p_(q2), C_, p_(kk), p_(vv), C_, p_(a2), C_, n, hw, L_ctx, m.heads,
                            m.d_head ** -0.5)
-                    h2 = lin(a2, P[q + "o2"], sd[q + "attn2.to_out.0.bias"], hw, residual=h1, out=h1)
+                    h2 = lin(a2, P[q + "o2"], sd[q + "attn2.to_out.0.bias"], hw, residual=h1, out=h1, wf=P.get(q + "o2#f"))
                     nb_.release(att, a2)
                 # --- GEGLU feed-forward: LN3 folded into the first GEMM, gate in its epilogue
                 pg.add("ldmk_ln_stats", p_(h2), rows, C_, 1e-5, p_(stats))
                 f = lin(h2, P[q + "ff1"], P[q + "ff1b"], hw, geglu=True, tf=L.TF_LAYERNORM, row_stats=stats,
-                        ln_gamma=sd[q + "norm3.weight"], ln_beta=sd[q + "norm3.bias"])
-                hcur = lin(f, P[q + "ff2"], sd[q + "ff.net.2.bias"], hw, residual=h2, out=h2)
+                        ln_gamma=sd[q + "norm3.weight"], ln_beta=sd[q + "norm3.bias"], wf=P.get(q + "ff1#f"))
+                hcur = lin(f, P[q + "ff2"], sd[q + "ff.net.2.bias"], hw, residual=h2, out=h2, wf=P.get(q + "ff2#f"))
                 nb_.release(f)
-            out = lin(hcur, P[prefix + "pout"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True)
+            out = lin(hcur, P[prefix + "pout"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True, wf=P.get(prefix + "pout#f"))
             nb_.release(hcur, stats)
             return out.view(n, h, w, m.ch)
 

@@ -73,7 +73,8 @@ typedef struct ldmk_igemm_args {
   int batch;                 /* >1: batched GEMM over blockIdx.z with the strides below           */
   long long a_bstride, w_bstride, out_bstride;
   float alpha;               /* scale applied to the product before the epilogue (1.0 default)    */
-  int tile_cfg;              /* 0 = choose from the problem size; 1..6 = pin a tile shape.  The K-summation
+  int tile_cfg;              /* 0 = choose from the problem size; 1..6 = pin an LDS-tiled workgroup shape, 7..12 = pin
+                                a row-GEMM wave tile (32 TM x 32 TN: 1x5, 2x5, 1x4, 2x4, 1x2, 1x1).  The K-summation
                                 order depends on (tile_cfg, splitk), so a caller that needs results that are
                                 bitwise independent of the batch size pins both (ldmk_igemm_plan)          */
   int splitk;                /* 0 = choose; 1 = none; 2..16 = split K over that many workgroups            */
@@ -81,9 +82,17 @@ typedef struct ldmk_igemm_args {
   long long splitk_ws_elems; /* capacity of splitk_ws in floats                                           */
   float* stats_out;          /* optional [M/32][N][3] GroupNorm partial records of the *output* (after the
                                 epilogue), one per 32-row tile and column; needs M%32==0, rows_per_sample%32==0 */
+  const float* w_frag;       /* optional second copy of w in MFMA-fragment order (ldmk_pack_wfrag).  With it, rows-mode
+                                problems may run on the wave-autonomous row GEMM (tile_cfg 7..12: no LDS, no barrier;
+                                csrc/rgemm.hip), which is what the short-K Linear layers of the transformer blocks want */
 } ldmk_igemm_args;
 
 int ldmk_igemm(const ldmk_igemm_args* args, void* stream);
+/* W[K][ldb] (row-major, as ldmk_igemm reads it with b_trans = 0) -> the fragment-order copy `w_frag` of K*N floats:
+ * Wf[k/8][n/32][h][n%32][s] = W[8(k/8) + 4h + s][n], one contiguous 1-KiB wave load per four MFMAs.  K%8 == 0, N%32 == 0.
+ * ldmk_wfrag_elems returns the size of that copy in floats (-1 when the shape cannot be packed). */
+long long ldmk_wfrag_elems(int K, int N);
+int ldmk_pack_wfrag(const float* w, int ldb, int K, int N, float* wfrag, void* stream);
 /* the (tile_cfg, splitk) ldmk_igemm would choose for these sizes; reads M, N, K, epi, batch, splitk_ws* */
 int ldmk_igemm_plan(const ldmk_igemm_args* args, int* tile_cfg, int* splitk);
 

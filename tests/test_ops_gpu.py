@@ -210,6 +210,92 @@ def test_linear_layernorm_prologue(ops, M, K, N, b_trans):
     close(y, ref, 1e-4, 1e-4)
 
 
+ROW_TILES = {7: (1, 5), 8: (2, 5), 9: (1, 4), 10: (2, 4), 11: (1, 2), 12: (1, 1)}
+
+
+@pytest.mark.parametrize("cfg", sorted(ROW_TILES))
+@pytest.mark.parametrize("case", [
+    # M, c0, c1, N, rows_per_sample, prologue, epilogue options
+    (256, 160, 0, 160, 64, "none", "bias+vec+res+stats"),
+    (300, 320, 0, 640, 300, "ln", "bias+res"),              # ragged M: clamped loads, masked stores
+    (512, 160, 0, 1280, 128, "ln", "geglu"),
+    (256, 320, 160, 320, 64, "none", "bias"),               # two-source channel concat (skip 1x1 conv)
+    (512, 160, 0, 160, 128, "affine", "bias"),              # GroupNorm-affine prologue (proj_in)
+    (64, 640, 0, 1920, 64, "ln", "none"),
+])
+def test_row_gemm_wave_tiles(ops, cfg, case):
+    """The wave-autonomous row GEMM (csrc/rgemm.hip, tile_cfg 7..12) against torch fp32 and, bitwise, against itself."""
+    M, c0, c1, N, rps, pro, epi = case
+    tm, tn = ROW_TILES[cfg]
+    if N % (32 * tn) or (epi == "geglu" and tn % 2) or (("vec" in epi or pro == "affine") and rps % (32 * tm)):
+        pytest.skip("tile does not fit this problem (the dispatcher rejects it; covered by test_row_gemm_rejects)")
+    K = c0 + c1
+    x = rnd(70, M, K) * 1.2 + 0.1
+    w, b = rnd(71, N, K) / np.sqrt(K), 0.1 * rnd(72, N)
+    g, be = 1 + 0.1 * rnd(73, K), 0.1 * rnd(74, K)
+    nsmp = (M + rps - 1) // rps
+    vec, res = rnd(75, nsmp, N), rnd(76, M, N)
+    sc, sh = 1 + 0.2 * rnd(77, nsmp, K), 0.3 * rnd(78, nsmp, K)
+    a_ref = x
+    if pro == "ln":
+        a_ref = F.layer_norm(x, (K,), g, be, 1e-5)
+    elif pro == "affine":
+        a_ref = x * sc.repeat_interleave(rps, 0)[:M] + sh.repeat_interleave(rps, 0)[:M]
+    y_ref = a_ref @ w.t()
+    xc = x.cuda()
+    x0 = xc[:, :c0].contiguous()
+    x1 = xc[:, c0:].contiguous() if c1 else None
+    kw = {}
+    if pro == "ln":
+        kw.update(row_stats=ops.ln_stats(xc), ln_gamma=g.cuda(), ln_beta=be.cuda())
+    elif pro == "affine":
+        kw.update(coef=torch.stack([sc, sh], 1).contiguous().cuda())
+    part = None
+    if epi == "geglu":
+        wp, bp = ops.pack_geglu(w.cuda(), b.cuda())
+        kw.update(geglu=True, bias=bp)
+        v_, g_ = (y_ref + b).chunk(2, dim=1)
+        y_ref = v_ * F.gelu(g_)
+    else:
+        wp = ops.pack_linear(w.cuda())
+        if "bias" in epi:
+            kw.update(bias=b.cuda())
+            y_ref = y_ref + b
+        if "vec" in epi:
+            kw.update(batch_vec=vec.cuda())
+            y_ref = y_ref + vec.repeat_interleave(rps, 0)[:M]
+        if "res" in epi:
+            kw.update(residual=res.cuda())
+            y_ref = y_ref + res
+        if "stats" in epi:
+            part = torch.zeros(M // 32, N, 3, device="cuda")
+            kw.update(stats_out=part)
+    wf = ops.pack_wfrag(wp)
+    y = ops.linear(x0, wp, x1=x1, rows_per_sample=rps, w_frag=wf, tile_cfg=cfg, **kw)
+    close(y, y_ref, 1e-4, 1e-4)
+    y2 = ops.linear(x0, wp, x1=x1, rows_per_sample=rps, w_frag=wf, tile_cfg=cfg, **kw)
+    assert torch.equal(y, y2)
+    if part is not None:      # the GroupNorm partial records of the output equal the stand-alone statistics pass
+        ref_part = torch.empty_like(part)
+        from dsml_thesis_amd import lib as L
+        L.call("ldmk_gn_partial", y.data_ptr(), N, nsmp, rps, ref_part.data_ptr(), ops.stream())
+        full = lambda p_: (p_[..., 1] + 32 * p_[..., 0], p_[..., 2] + 2 * p_[..., 0] * p_[..., 1] + 32 * p_[..., 0] ** 2)
+        for u, v in zip(full(part), full(ref_part)):
+            close(u, v, 1e-4, 1e-4)
+
+
+def test_row_gemm_rejects_what_it_cannot_run(ops):
+    from dsml_thesis_amd import lib as L
+    x, w = rnd(80, 64, 160).cuda(), rnd(81, 96, 160).cuda()
+    wp = ops.pack_linear(w)
+    with pytest.raises(L.LdmkError, match="w_frag"):
+        ops.linear(x, wp, tile_cfg=7)                                   # no fragment copy given
+    with pytest.raises(L.LdmkError, match="multiple of the tile"):
+        ops.linear(x, wp, w_frag=ops.pack_wfrag(wp), tile_cfg=7)        # N = 96 is not a multiple of 160
+    y = ops.linear(x, wp, w_frag=ops.pack_wfrag(wp), tile_cfg=12)       # 32-column tiles fit
+    close(y, x.cpu() @ w.cpu().t(), 1e-4, 1e-4)
+
+
 def test_geglu_ff_golden(ops):
     g = golden("g3_ops.npz")
     ff = {"net.0.proj.weight": (1280, 160), "net.0.proj.bias": (1280,), "net.2.weight": (160, 640), "net.2.bias": (160,)}

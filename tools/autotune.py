@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+ROWS_RETUNE = False
 CFG_WK = {1: 1, 2: 2, 3: 4, 4: 2, 5: 1, 6: 2}          # K slices of 32 staged per iteration
 EVEN_TN = {1, 2, 3}
 SKS = [1, 2, 3, 4, 6, 8, 12, 16]
@@ -28,7 +29,8 @@ SKS = [1, 2, 3, 4, 6, 8, 12, 16]
 def time_call(lib, a, st, reps=5):
     ts = []
     for _ in range(2):
-        lib.ldmk_igemm(C.byref(a), st)
+        if lib.ldmk_igemm(C.byref(a), st) != 0:
+            return None
     torch.cuda.synchronize()
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -102,7 +104,8 @@ def tune_program(pg, table):
         if name != "ldmk_igemm":
             continue
         key = plan_key(a, a.M)
-        if key in seen or key in table or a.batch > 1:
+        rows_retune = ROWS_RETUNE and a.w_frag and a.a_mode == 0 and not a.b_trans
+        if key in seen or a.batch > 1 or (key in table and not rows_retune):
             continue
         saved = (a.tile_cfg, a.splitk, a.splitk_ws, a.splitk_ws_elems, a.out, a.stats_out, a.residual)
         # time into scratch so that in-place residual / stats outputs of the real program are not disturbed
@@ -113,7 +116,20 @@ def tune_program(pg, table):
         a.stats_out = 0
         nkc = a.K // 32
         best = None
+        if key in table:          # rows re-tune: the LDS-tiled plan on record is the one to beat
+            a.tile_cfg, a.splitk = table[key]
+            a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
+            t = time_call(lib, a, st)
+            best = (t, a.tile_cfg, a.splitk)
+        if rows_retune:
+            for cfg in range(7, 13):          # wave-autonomous row GEMM tiles (illegal ones return an error code)
+                a.tile_cfg, a.splitk = cfg, 1
+                t = time_call(lib, a, st)
+                if t is not None and (best is None or t < best[0]):
+                    best = (t, cfg, 1)
         for cfg in range(1, 7):
+            if key in table:
+                break
             if a.epi == 1 and cfg not in EVEN_TN:
                 continue
             iters = -(-nkc // CFG_WK[cfg])
@@ -138,7 +154,10 @@ if __name__ == "__main__":
     ap.add_argument("--case", action="append", default=[], help="[unet|dec|enc:]latent:batch, e.g. 64:16 or dec:64:16")
     ap.add_argument("--out", default=os.path.join(ROOT, "dsml_thesis_amd", "igemm_plans.json"))
     ap.add_argument("--fresh", action="store_true")
+    ap.add_argument("--rows", action="store_true", help="re-tune rows-mode shapes already in the table against the "
+                    "row-GEMM wave tiles (tile_cfg 7..12)")
     a = ap.parse_args()
+    ROWS_RETUNE = a.rows
     table = {}
     if os.path.exists(a.out) and not a.fresh:
         table = json.load(open(a.out))

@@ -39,34 +39,47 @@ def dump(latent, batch, path):
     torch.cuda.synchronize()
 
 
+KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "rgemm_kernel"), "ldmk_gn_finalize": ("gn_finalize",), "ldmk_gn_apply": ("gn_apply",),
+             "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_attn_self": ("attn_self",),
+             "ldmk_attn_cross": ("attn_cross",), "ldmk_dense_small": ("dense_small",),
+             "ldmk_timestep_embedding": ("timestep_embedding",), "ldmk_conv3x3_in": ("conv3x3_in",),
+             "ldmk_conv3x3_out": ("conv3x3_out",)}
+PEAK_F32_MFMA = 157.3
+
+
 def join(d):
+    """Walk the trace and the launch program side by side, matching kernel NAMES (a split-K GEMM is its main kernel
+    plus the reduce kernel that follows it); any mismatch is an error, and so is a GEMM row above the matrix peak."""
     prog = json.load(open(os.path.join(d, "prog.json")))
     calls = prog["calls"]
     tr = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = [r for r in csv.DictReader(open(tr)) if "ldmk::" in r["Kernel_Name"]]
-    # expected ldmk dispatches per step
-    per = 0
-    for c in calls:
-        per += 2 if (c["name"] == "ldmk_gn_coef" or c.get("sk", 1) > 1) else 1
-    per += 2  # ddim step + advance
-    last = rows[-per:]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    per = sum(2 if (c["name"] == "ldmk_igemm" and c.get("sk", 1) > 1 and c.get("cfg", 0) <= 6) else 1 for c in calls) + 1
+    # the last step of the trace: find it by walking back from the end to the step's first kernel (timestep_embedding)
+    starts = [i for i, r in enumerate(rows) if "timestep_embedding" in r["Kernel_Name"]]
+    last = rows[starts[-1]:]
+    dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     i = 0
     out = []
     for c in calls:
-        k = 2 if (c["name"] == "ldmk_gn_coef" or c.get("sk", 1) > 1) else 1
-        dur = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last[i:i + k]) / 1e3
-        i += k
-        out.append((c, dur))
+        want = KERNEL_OF.get(c["name"])
+        r = last[i]
+        assert want is None or any(w in r["Kernel_Name"] for w in want), (c, r["Kernel_Name"])
+        d_ = dur(r)
+        i += 1
+        if c["name"] == "ldmk_igemm" and "igemm_kernel" in r["Kernel_Name"] and c.get("sk", 1) > 1:
+            assert "igemm_reduce" in last[i]["Kernel_Name"], (c, last[i]["Kernel_Name"])
+            d_ += dur(last[i])
+            i += 1
+        out.append((c, d_))
+    assert per >= i, (per, i)
     tot = sum(d_ for _, d_ in out)
     print(f"step total (sum of kernel durations) {tot / 1e3:.3f} ms over {len(out)} calls")
     agg = {}
-    lines = []
     for c, d_ in out:
         if c["name"] == "ldmk_igemm":
-            fl = 2.0 * c["M"] * c["N"] * c["K"]
-            tf = fl / (d_ * 1e-6) / 1e12
             key = f"igemm M={c['M']:6d} N={c['N']:5d} K={c['K']:6d} conv={c['conv']} tf={c['tf']} epi={c['epi']} cfg={c['cfg']} sk={c.get('sk', 1)}"
-            lines.append((key, d_, tf))
         else:
             key = c["name"]
         a = agg.setdefault(key, [0, 0.0, 0.0])
@@ -75,9 +88,15 @@ def join(d):
         if c["name"] == "ldmk_igemm":
             a[2] += 2.0 * c["M"] * c["N"] * c["K"]
     print(f"{'call':75s} {'n':>3s} {'us_total':>10s} {'pct':>6s} {'TFLOP/s':>8s}")
+    fam_t = fam_f = 0.0
     for key, (n, d_, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        tfs = f"{fl / (d_ * 1e-6) / 1e12:8.1f}" if fl else "        "
-        print(f"{key:75s} {n:3d} {d_:10.1f} {100 * d_ / tot:6.2f} {tfs}")
+        tfs = fl / (d_ * 1e-6) / 1e12 if fl else 0.0
+        assert tfs <= PEAK_F32_MFMA, f"{key}: {tfs:.1f} TFLOP/s exceeds the f32 matrix peak -- the join is wrong"
+        fam_t += d_ if fl else 0.0
+        fam_f += fl
+        print(f"{key:75s} {n:3d} {d_:10.1f} {100 * d_ / tot:6.2f} {tfs:8.1f}" if fl else f"{key:75s} {n:3d} {d_:10.1f} {100 * d_ / tot:6.2f}")
+    print(f"GEMM family (LDS-tiled igemm + row GEMM): {fam_f * 1e-9:.1f} GFLOP executed in {fam_t / 1e3:.3f} ms = "
+          f"{fam_f / (fam_t * 1e-6) / 1e12:.1f} TFLOP/s = {fam_f / (fam_t * 1e-6) / 1e12 / PEAK_F32_MFMA:.3f} of the f32 matrix peak")
 
 
 if __name__ == "__main__":
