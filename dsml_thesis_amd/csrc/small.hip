@@ -99,71 +99,127 @@ __global__ void timestep_embedding_kernel(const long long* __restrict__ t, const
 
 // ---------------------------------------------------------------------------------------------
 // 3x3 pad-1 convolution from a narrow NCHW input (<= 16 channels, optionally the concat of two
-// tensors) to a wide NHWC output.  Workgroup = 256 threads = 4 output pixels x 64 couts per pass.
+// tensors) to a wide NHWC output (openaimodel.py:515-517, model.py:394-398,503-507).
+// Workgroup = one segment of up to 64 pixels of one image row.  The 3 input rows of the segment (+halo) are staged in
+// LDS once; thread <-> output channel, with that channel's 9*cin weights held in registers for the whole segment
+// (the first version re-read them from L2 for every pixel: 23 KB per pixel, 1.5 GB per launch at 64x64, 123 us).
+// Per pixel a thread reads the 9*cin patch values as LDS broadcasts and writes one float: a wave's store is a
+// contiguous 256-B run of the NHWC row.
+constexpr int CIN_MAX = 16, CIN_SEG = 64;
+template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_in_kernel(const float* __restrict__ x0, int c0,
                                                          const float* __restrict__ x1, int c1,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ out, int n, int h, int wd, int cout) {
-  __shared__ float patch[4][16 * 9];
-  const int cin = c0 + c1;
+  __shared__ float patch[3][CIN][CIN_SEG + 2];
+  const int segs = (wd + CIN_SEG - 1) / CIN_SEG;
+  const int seg = blockIdx.x % segs, y = (blockIdx.x / segs) % h, b = blockIdx.x / (segs * h);
+  const int xs = seg * CIN_SEG, np = min(CIN_SEG, wd - xs);
   const int hw = h * wd;
-  const long long pix0 = (long long)blockIdx.x * 4;
-  const long long total = (long long)n * hw;
-  // stage the 4 pixels' 3x3xcin neighbourhoods
-  for (int i = threadIdx.x; i < 4 * cin * 9; i += 256) {
-    int pl = i / (cin * 9), rem = i - pl * (cin * 9);
-    int c = rem / 9, tap = rem - c * 9;
-    long long pix = pix0 + pl;
+  for (int i = threadIdx.x; i < 3 * CIN * (CIN_SEG + 2); i += 256) {
+    const int px = i % (CIN_SEG + 2), c = (i / (CIN_SEG + 2)) % CIN, dy = i / ((CIN_SEG + 2) * CIN);
+    const int yy = y + dy - 1, xx = xs + px - 1;
     float v = 0.f;
-    if (pix < total) {
-      int b = (int)(pix / hw), p = (int)(pix - (long long)b * hw);
-      int y = p / wd + tap / 3 - 1, xx = p % wd + tap % 3 - 1;
-      if (y >= 0 && y < h && xx >= 0 && xx < wd) {
-        v = c < c0 ? x0[((long long)b * c0 + c) * hw + y * wd + xx] : x1[((long long)b * c1 + (c - c0)) * hw + y * wd + xx];
-      }
-    }
-    patch[pl][c * 9 + tap] = v;
+    if (yy >= 0 && yy < h && xx >= 0 && xx < wd)
+      v = c < c0 ? x0[((long long)b * c0 + c) * hw + yy * wd + xx] : x1[((long long)b * c1 + (c - c0)) * hw + yy * wd + xx];
+    patch[dy][c][px] = v;
   }
   __syncthreads();
-  const int pl = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long pix = pix0 + pl;
-  if (pix >= total) return;
-  for (int co = lane; co < cout; co += 64) {
-    float acc = bias ? bias[co] : 0.f;
-    for (int tap = 0; tap < 9; ++tap)
-      for (int c = 0; c < cin; ++c) acc = fmaf(patch[pl][c * 9 + tap], w[((long long)tap * cin + c) * cout + co], acc);
-    out[pix * cout + co] = acc;
+  float* orow = out + ((long long)b * hw + (long long)y * wd + xs) * cout;
+  for (int co = threadIdx.x; co < cout; co += 256) {
+    float wr[9][CIN];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) wr[t][c] = w[((long long)t * CIN + c) * cout + co];
+    const float bv = bias ? bias[co] : 0.f;
+    for (int p0 = 0; p0 < np; p0 += 4) {         // 4 pixels per pass: every LDS value feeds up to 3 of them
+      float acc[4] = {bv, bv, bv, bv};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          float v[6];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) v[q] = patch[dy][c][min(p0 + q, CIN_SEG + 1)];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) acc[q] = fmaf(v[q + dx], wr[dy * 3 + dx][c], acc[q]);
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (p0 + q < np) orow[(long long)(p0 + q) * cout + co] = acc[q];
+    }
   }
 }
 
-// GroupNorm+SiLU (coef planes) -> 3x3 pad-1 conv to <= 4 channels, NHWC in -> NCHW out.
-// One wave per output pixel: lanes stride over input channels (coalesced), wave-shuffle reduce.
+// GroupNorm+SiLU (coef planes) -> 3x3 pad-1 conv to <= 4 channels, NHWC in -> NCHW out (openaimodel.py:682-686,
+// model.py:457-459,566-568).  Workgroup = 16x16 output pixels; the 18x18 input tile is staged through LDS in 32-channel
+// chunks with the normalisation and SiLU applied ONCE per element (the first version, one wave per output pixel,
+// re-normalised every element for each of its 9 uses: 353 us at 16x64x64x160); thread <-> pixel, its <= 4 accumulators
+// walk 9 taps x 32 channels per chunk with ds_read_b128 (pixel stride 36 floats: conflict-free for the 16 pixels a
+// b128 read serves together) and wave-uniform weights.
+constexpr int CO_T = 16, CO_CK = 32, CO_STR = 36;
+template <int COUT>
 __global__ __launch_bounds__(256) void conv3x3_out_kernel(const float* __restrict__ x, const float* __restrict__ coef,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
-                                                          float* __restrict__ out, int n, int h, int wd, int cin,
-                                                          int cout) {
-  const int lane = threadIdx.x & 63;
-  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int hw = h * wd;
-  if (pix >= (long long)n * hw) return;
-  const int b = (int)(pix / hw), p = (int)(pix - (long long)b * hw);
-  const int oy = p / wd, ox = p - oy * wd;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                                                          float* __restrict__ out, int n, int h, int wd, int cin) {
+  __shared__ __attribute__((aligned(16))) float tile[(CO_T + 2) * (CO_T + 2) * CO_STR];
+  __shared__ __attribute__((aligned(16))) float wch[9 * CO_CK * 4];      // this chunk's weights, [tap][c][4] (cout padded)
+  const int tx_n = (wd + CO_T - 1) / CO_T, ty_n = (h + CO_T - 1) / CO_T;
+  const int b = blockIdx.x / (tx_n * ty_n), t = blockIdx.x % (tx_n * ty_n);
+  const int y0 = (t / tx_n) * CO_T, x0 = (t % tx_n) * CO_T;
+  const int ty = threadIdx.x / CO_T, tx = threadIdx.x % CO_T;
   const float* sc = coef ? coef + ((long long)b * 2) * cin : nullptr;
-  for (int c = lane; c < cin; c += 64) {
-    const float s = sc ? sc[c] : 1.f, t = sc ? sc[cin + c] : 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < cin; c0 += CO_CK) {
+    __syncthreads();                                   // the previous chunk's reads are done
+    for (int i = threadIdx.x; i < (CO_T + 2) * (CO_T + 2) * (CO_CK / 4); i += 256) {
+      const int c4 = i % (CO_CK / 4), pix = i / (CO_CK / 4);
+      const int yy = y0 + pix / (CO_T + 2) - 1, xx = x0 + pix % (CO_T + 2) - 1;
+      const int c = c0 + 4 * c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding applies to the ACTIVATED tensor
+      if (yy >= 0 && yy < h && xx >= 0 && xx < wd && c < cin) {
+        v = *reinterpret_cast<const float4*>(x + (((long long)b * h + yy) * wd + xx) * cin + c);
+        if (sc) {
+          const float4 s4 = *reinterpret_cast<const float4*>(sc + c), t4 = *reinterpret_cast<const float4*>(sc + cin + c);
+          v.x = silu_f(fmaf(v.x, s4.x, t4.x)); v.y = silu_f(fmaf(v.y, s4.y, t4.y));
+          v.z = silu_f(fmaf(v.z, s4.z, t4.z)); v.w = silu_f(fmaf(v.w, s4.w, t4.w));
+        }
+      }
+      *reinterpret_cast<float4*>(tile + pix * CO_STR + 4 * c4) = v;
+    }
+    for (int i = threadIdx.x; i < 9 * CO_CK * 4; i += 256) {
+      const int co = i & 3, c = (i >> 2) % CO_CK, tap = i / (4 * CO_CK);
+      wch[i] = (co < COUT && c0 + c < cin) ? w[((long long)tap * cin + c0 + c) * COUT + co] : 0.f;
+    }
+    __syncthreads();
+    // every lane reads the same weight address (LDS broadcast); channels beyond cin hold zero data and zero weights
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      int y = oy + tap / 3 - 1, xx = ox + tap % 3 - 1;
-      if (y < 0 || y >= h || xx < 0 || xx >= wd) continue;
-      float v = x[(((long long)b * h + y) * wd + xx) * cin + c];
-      if (sc) v = silu_f(fmaf(v, s, t));
-      const float* wp = w + ((long long)tap * cin + c) * cout;
-      for (int co = 0; co < cout; ++co) acc[co] = fmaf(v, wp[co], acc[co]);
+      const float* tp = tile + ((ty + tap / 3) * (CO_T + 2) + tx + tap % 3) * CO_STR;
+      const float4* wp = reinterpret_cast<const float4*>(wch + tap * CO_CK * 4);
+#pragma unroll
+      for (int c = 0; c < CO_CK; c += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(tp + c);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 w4 = wp[c + q];
+          acc[0] = fmaf(vv[q], w4.x, acc[0]);
+          if (COUT > 1) acc[1] = fmaf(vv[q], w4.y, acc[1]);
+          if (COUT > 2) acc[2] = fmaf(vv[q], w4.z, acc[2]);
+          if (COUT > 3) acc[3] = fmaf(vv[q], w4.w, acc[3]);
+        }
+      }
     }
   }
-  for (int co = 0; co < cout; ++co) {
-    float v = wave_sum(acc[co]);
-    if (lane == 0) out[((long long)b * cout + co) * hw + p] = v + (bias ? bias[co] : 0.f);
+  const int oy = y0 + ty, ox = x0 + tx;
+  if (oy < h && ox < wd) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+      out[((long long)b * COUT + co) * h * wd + (long long)oy * wd + ox] = acc[co] + (bias ? bias[co] : 0.f);
   }
 }
 
@@ -491,22 +547,40 @@ extern "C" int ldmk_timestep_embedding(const long long* t, const float* freqs, f
 extern "C" int ldmk_conv3x3_in(const float* x0, int c0, const float* x1, int c1, const float* w, const float* bias,
                                float* out, int n, int h, int w_, int cout, void* stream) {
   LDMK_ENTER();
+  using namespace ldmk;
   LDMK_REQUIRE(x0 && w && out && n > 0 && h > 0 && w_ > 0 && cout > 0, "ldmk_conv3x3_in: bad args");
-  LDMK_REQUIRE(c0 > 0 && c0 + c1 <= 16 && (c1 == 0) == (x1 == nullptr), "ldmk_conv3x3_in: c0+c1 must be <= 16");
-  long long total = (long long)n * h * w_;
-  hipLaunchKernelGGL(conv3x3_in_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x0, c0, x1,
-                     c1, w, bias, out, n, h, w_, cout);
+  LDMK_REQUIRE(c0 > 0 && c0 + c1 <= CIN_MAX && (c1 == 0) == (x1 == nullptr), "ldmk_conv3x3_in: c0+c1 must be <= 16");
+  const int segs = (w_ + CIN_SEG - 1) / CIN_SEG;
+  const long long blocks = (long long)n * h * segs;
+  LDMK_REQUIRE(blocks < (1LL << 31), "ldmk_conv3x3_in: too many row segments");
+  const dim3 grid((unsigned)blocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define LDMK_CIN_CASE(C) case C: hipLaunchKernelGGL(conv3x3_in_kernel<C>, grid, block, 0, st, x0, c0, x1, c1, w, bias, out, n, h, w_, cout); break;
+  switch (c0 + c1) {
+    LDMK_CIN_CASE(1) LDMK_CIN_CASE(2) LDMK_CIN_CASE(3) LDMK_CIN_CASE(4) LDMK_CIN_CASE(5) LDMK_CIN_CASE(6) LDMK_CIN_CASE(7) LDMK_CIN_CASE(8)
+    LDMK_CIN_CASE(9) LDMK_CIN_CASE(10) LDMK_CIN_CASE(11) LDMK_CIN_CASE(12) LDMK_CIN_CASE(13) LDMK_CIN_CASE(14) LDMK_CIN_CASE(15) LDMK_CIN_CASE(16)
+  }
+#undef LDMK_CIN_CASE
   return check_launch("ldmk_conv3x3_in");
 }
 
 extern "C" int ldmk_conv3x3_out(const float* x, const float* coef, const float* w, const float* bias, float* out, int n,
                                 int h, int w_, int cin, int cout, void* stream) {
   LDMK_ENTER();
+  using namespace ldmk;
   LDMK_REQUIRE(x && w && out && n > 0 && h > 0 && w_ > 0 && cin > 0, "ldmk_conv3x3_out: bad args");
   LDMK_REQUIRE(cout >= 1 && cout <= 4, "ldmk_conv3x3_out: cout=%d must be in [1,4]", cout);
-  long long total = (long long)n * h * w_;
-  hipLaunchKernelGGL(conv3x3_out_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, coef, w,
-                     bias, out, n, h, w_, cin, cout);
+  LDMK_REQUIRE(cin % 4 == 0, "ldmk_conv3x3_out: cin=%d must be a multiple of 4", cin);
+  const long long blocks = (long long)n * ((h + CO_T - 1) / CO_T) * ((w_ + CO_T - 1) / CO_T);
+  LDMK_REQUIRE(blocks < (1LL << 31), "ldmk_conv3x3_out: too many tiles");
+  const dim3 grid((unsigned)blocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (cout) {
+    case 1: hipLaunchKernelGGL(conv3x3_out_kernel<1>, grid, block, 0, st, x, coef, w, bias, out, n, h, w_, cin); break;
+    case 2: hipLaunchKernelGGL(conv3x3_out_kernel<2>, grid, block, 0, st, x, coef, w, bias, out, n, h, w_, cin); break;
+    case 3: hipLaunchKernelGGL(conv3x3_out_kernel<3>, grid, block, 0, st, x, coef, w, bias, out, n, h, w_, cin); break;
+    default: hipLaunchKernelGGL(conv3x3_out_kernel<4>, grid, block, 0, st, x, coef, w, bias, out, n, h, w_, cin); break;
+  }
   return check_launch("ldmk_conv3x3_out");
 }
 

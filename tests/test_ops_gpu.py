@@ -389,6 +389,31 @@ def test_boundary_convs(ops):
     close(ops.conv1x1_nchw(x.cuda(), w.cuda(), b.cuda()), F.conv2d(x, w, b), 1e-6, 1e-6)
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 4, 160, 64, 64), (1, 3, 512, 32, 32), (3, 9, 160, 5, 70), (1, 16, 96, 3, 130),
+                                            (1, 1, 300, 7, 1)])
+def test_conv3x3_in_row_segments(ops, n, cin, cout, h, w):
+    """Row-segment kernel: widths below / at / above one 64-pixel segment, cout beyond one pass of 256 threads."""
+    x, wt, b = rnd(160, n, cin, h, w), rnd(161, cout, cin, 3, 3) / 3.0, rnd(162, cout)
+    y = ops.conv3x3_in(x.cuda(), ops.pack_conv3x3_narrow(wt.cuda()), b.cuda(), cout)
+    close(nchw(y), F.conv2d(x, wt, b, padding=1), 1e-5, 2e-5)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,norm", [(2, 160, 4, 64, 64, True), (1, 128, 3, 48, 80, True), (2, 512, 4, 5, 19, True),
+                                                 (1, 36, 1, 17, 16, False), (1, 160, 2, 1, 1, True)])
+def test_conv3x3_out_tiles(ops, n, cin, cout, h, w, norm):
+    """16x16-pixel tiles with a halo, 32-channel chunks (cin not a multiple of 32 too), ragged tiles, no-norm path."""
+    x = rnd(170, n, cin, h, w) * 1.4
+    wt, b = rnd(171, cout, cin, 3, 3) / np.sqrt(9 * cin), rnd(172, cout)
+    xs = nhwc(x)
+    coef, ref_in = None, x
+    if norm:
+        gamma, beta = 1 + 0.1 * rnd(173, cin), 0.1 * rnd(174, cin)
+        coef = ops.gn_coef(xs, None, n, h * w, gamma.cuda(), beta.cuda(), 1e-5)
+        ref_in = F.silu(F.group_norm(x, 32, gamma, beta, 1e-5))
+    y = ops.conv3x3_out(xs, coef, ops.pack_conv3x3_narrow(wt.cuda()), b.cuda(), cout)
+    close(y, F.conv2d(ref_in, wt, b, padding=1), 1e-4, 1e-4)
+
+
 def test_sampler_updates_golden(ops):
     from dsml_thesis_amd import lib as L
     g = golden("g3_ops.npz")
