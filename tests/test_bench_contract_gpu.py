@@ -10,9 +10,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags):
+def _run(*flags, env=None):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT, capture_output=True, text=True,
-                         timeout=600)
+                         timeout=900, env=None if env is None else dict(os.environ, **env))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -20,7 +20,7 @@ def _run(*flags):
 
 
 def test_bench_line_has_the_contract_fields():
-    d = _run("--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline")
+    d = _run("--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-clip")
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "sample-steps/s"
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -31,6 +31,9 @@ def test_bench_line_has_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 0.2 < r["frac"] < 1.0 and d["value"] > 50
+    # the numerator is what the launches execute (sum of 2 M N K), printed next to the reference algorithm's count
+    assert r["flops_basis"].startswith("executed") and 150 < r["executed_gflop_per_sample_step"] < r["reference_gflop_per_sample_step"]
+    assert abs(r["achieved"] - r["executed_gflop_per_sample_step"] * 16 / r["sum_launch_ms_per_step"]) / r["achieved"] < 1e-3
     # value is consistent with the timed region: batch * steps / time
     assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
 
@@ -39,3 +42,15 @@ def test_bench_train_mode_line():
     d = _run("--train", "--steps", "2", "--warmup", "1", "--batch", "4")
     assert d["unit"] == "samples/s" and d["n_gpus"] == 1 and d["dtype"] == "f32" and d["value"] > 1
     assert d["roofline"]["bound"] == "mfma" and 0.0 < d["roofline"]["frac"] < 1.0
+
+
+def test_bench_self_launches_two_ranks_and_the_clip_checksum_does_not_depend_on_the_rank_count():
+    """`python bench.py --gpus 2` starts its own ranks (here both on the one GPU, gloo collectives): n_gpus = 2, the clip
+    leg runs sharded with its all-gather inside the timed region, and its checksum equals the 1-rank run's bit for bit."""
+    flags = ("--steps", "2", "--warmup", "1", "--batch", "2", "--latent", "32", "--no-secondary", "--no-cpu-baseline",
+             "--clip-frames", "6", "--clip-steps", "4")
+    one = _run(*flags)
+    two = _run("--gpus", "2", *flags, env={"LDMK_BENCH_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["global_batch"] == 4
+    assert two["clip"]["scaling"] == "strong" and "all_gather" in two["clip"]["collective"]
+    assert one["clip"]["checksum"] == two["clip"]["checksum"] and one["clip"]["frames"] == 6
