@@ -503,20 +503,38 @@ static const TileCfg kCfg[] = {
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT>
-static int launch_cfg(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
+static size_t cfg_lds_bytes() {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KC = 32 * WK * KS;
   constexpr int ASTR = BM + 1, BSTR = BN + (BT ? 1 : 0);
   size_t stage = (size_t)KC * (ASTR + BSTR) * sizeof(float) * (DB ? 2 : 1);
   size_t red = WK > 1 ? (size_t)(WK - 1) * WM * WN * TM * TN * 16 * 64 * sizeof(float) : 0;
-  size_t lds = stage > red ? stage : red;
+  return stage > red ? stage : red;
+}
+
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT>
+static bool& cfg_attr_done() {
+  static bool done = false;
+  return done;
+}
+
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT>
+static void cfg_set_attr() {
+  bool& done = cfg_attr_done<TM, TN, WM, WN, WK, KS, DB, BT>();
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg_lds_bytes<TM, TN, WM, WN, WK, KS, DB, BT>());
+    done = true;
+  }
+}
+
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT>
+static int launch_cfg(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  size_t lds = cfg_lds_bytes<TM, TN, WM, WN, WK, KS, DB, BT>();
   int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles, splitk, a.batch > 1 ? a.batch : 1);
   auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT>;
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  cfg_set_attr<TM, TN, WM, WN, WK, KS, DB, BT>();
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, splitk, ws);
   if (splitk > 1 && a.stats_out) {
     hipLaunchKernelGGL(igemm_reduce_stats_kernel, dim3(a.M / 32, (a.N + 63) / 64), dim3(256), 0, st, a, splitk, ws);
@@ -575,6 +593,20 @@ static int dispatch(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hi
   }
 }
 
+template <bool BT>
+static void set_all_attrs() {
+  cfg_set_attr<2, 2, 2, 2, 1, 1, false, BT>();
+  cfg_set_attr<1, 2, 2, 2, 1, 2, false, BT>();
+  cfg_set_attr<2, 2, 1, 1, 4, 1, false, BT>();
+  cfg_set_attr<1, 1, 2, 2, 1, 2, false, BT>();
+  cfg_set_attr<1, 5, 4, 1, 1, 1, false, BT>();
+  cfg_set_attr<1, 5, 2, 1, 2, 1, false, BT>();
+}
+void igemm_init_attributes() {
+  set_all_attrs<false>();
+  set_all_attrs<true>();
+}
+
 // the wave-autonomous row GEMM (rgemm.hip): tile_cfg kNumCfg+1 .. kNumCfg+6
 const char* rgemm_unsupported(const ldmk_igemm_args& a, int rcfg);
 int rgemm_dispatch(const ldmk_igemm_args& a, int rcfg, hipStream_t st);
@@ -590,6 +622,22 @@ extern "C" int ldmk_igemm_plan(const ldmk_igemm_args* args, int* tile_cfg, int* 
   if (!args || !tile_cfg || !splitk) return LDMK_EINVAL;
   ldmk::plan(*args, tile_cfg, splitk, args->splitk_ws ? args->splitk_ws_elems : 0);
   return LDMK_OK;
+}
+
+extern "C" long long ldmk_igemm_workspace_elems(const ldmk_igemm_args* args) {
+  using namespace ldmk;
+  LDMK_REQUIRE(args != nullptr, "ldmk_igemm_workspace_elems: null args");
+  const ldmk_igemm_args& a = *args;
+  LDMK_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "ldmk_igemm_workspace_elems: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+  LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 16, "ldmk_igemm_workspace_elems: splitk=%d outside [0,16]", a.splitk);
+  int cfg = a.tile_cfg, sk = a.splitk;
+  if (sk == 0) {
+    int c2 = 0;
+    plan(a, &c2, &sk, 1LL << 50);          // what the planner would use with unlimited scratch
+    if (cfg == 0) cfg = c2;
+  }
+  if (cfg > kNumCfg || a.epi == LDMK_EPI_GEGLU || sk <= 1) return 0;      // row GEMM / GEGLU never split K
+  return (long long)(a.batch > 1 ? a.batch : 1) * sk * (long long)a.M * a.N;
 }
 
 extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) {
@@ -639,8 +687,9 @@ extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) {
   if (a.epi == LDMK_EPI_GEGLU) sk = 1;
   if (sk > 1) {
     const long long b = a.batch > 1 ? a.batch : 1;
-    LDMK_REQUIRE(a.splitk_ws && b * sk * (long long)a.M * a.N <= a.splitk_ws_elems,
-                 "ldmk_igemm: splitk=%d needs a workspace of %lld floats", sk, b * sk * (long long)a.M * a.N);
+    LDMK_REQUIRE_MEM(a.splitk_ws && b * sk * (long long)a.M * a.N <= a.splitk_ws_elems,
+                     "ldmk_igemm: splitk=%d needs a workspace of %lld floats (ldmk_igemm_workspace_elems), %lld given", sk,
+                     b * sk * (long long)a.M * a.N, a.splitk_ws ? a.splitk_ws_elems : 0LL);
   }
   hipStream_t st = (hipStream_t)stream;
   return a.b_trans ? dispatch<true>(a, cfg, sk, a.splitk_ws, st) : dispatch<false>(a, cfg, sk, a.splitk_ws, st);

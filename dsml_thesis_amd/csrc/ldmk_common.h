@@ -30,6 +30,14 @@ inline int check_launch(const char* what) {
     }                                  \
   } while (0)
 
+#define LDMK_REQUIRE_MEM(cond, ...)    \
+  do {                                 \
+    if (!(cond)) {                     \
+      ldmk::set_error(__VA_ARGS__);    \
+      return LDMK_ENOMEM;              \
+    }                                  \
+  } while (0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -521,7 +521,32 @@ static inline unsigned grid_for(long long total, int block = 256, int cap = 4096
 
 using namespace ldmk;
 
-extern "C" int ldmk_version(void) { return 100; }
+extern "C" int ldmk_version(void) { return 200; }
+
+namespace ldmk { void igemm_init_attributes(); }
+
+extern "C" int ldmk_init(int device) {
+  using namespace ldmk;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    set_error("ldmk_init: no HIP device (%s)", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    return LDMK_EHIP;
+  }
+  LDMK_REQUIRE(device >= 0 && device < count, "ldmk_init: device %d outside [0,%d)", device, count);
+  hipDeviceProp_t prop;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+    set_error("ldmk_init: device %d: %s", device, hipGetErrorString(e));
+    return LDMK_EHIP;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("ldmk_init: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    return LDMK_EHIP;
+  }
+  igemm_init_attributes();
+  return check_launch("ldmk_init");
+}
 extern "C" const char* ldmk_last_error(void) { return g_err; }
 
 extern "C" int ldmk_dense_small(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,

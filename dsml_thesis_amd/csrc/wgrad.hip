@@ -245,6 +245,20 @@ static int wgrad_plan_splitr(const ldmk_wgrad_args& a, int cfg) {
 
 }  // namespace ldmk
 
+extern "C" long long ldmk_wgrad_workspace_elems(const ldmk_wgrad_args* args) {
+  LDMK_REQUIRE(args != nullptr, "ldmk_wgrad_workspace_elems: null args");
+  ldmk_wgrad_args a = *args;
+  LDMK_REQUIRE(a.R > 0 && a.Kw > 0 && a.N > 0 && a.splitr >= 0 && a.splitr <= 256, "ldmk_wgrad_workspace_elems: bad shape / splitr");
+  int sr = a.splitr;
+  if (sr == 0) {
+    a.ws = reinterpret_cast<float*>(1);
+    a.ws_elems = 1LL << 40;
+    sr = ldmk::wgrad_plan_splitr(a, ldmk::wgrad_cfg(a));
+  }
+  if (sr <= 1) return 0;
+  return (long long)(a.batch > 1 ? a.batch : 1) * sr * (a.Kw + (a.dbias ? 1 : 0)) * (long long)a.N;
+}
+
 extern "C" int ldmk_wgrad_plan(const ldmk_wgrad_args* args, int* splitr) {
   if (!args || !splitr) return LDMK_EINVAL;
   ldmk_wgrad_args a = *args;
@@ -274,7 +288,8 @@ extern "C" int ldmk_wgrad(const ldmk_wgrad_args* args, void* stream) {
   int sr = a.splitr > 0 ? a.splitr : wgrad_plan_splitr(a, cfg);
   if (sr > 1) {
     const long long need = (long long)(a.batch > 1 ? a.batch : 1) * sr * (a.Kw + (a.dbias ? 1 : 0)) * a.N;
-    LDMK_REQUIRE(a.ws && need <= a.ws_elems, "ldmk_wgrad: splitr=%d needs a workspace of %lld floats", sr, need);
+    LDMK_REQUIRE_MEM(a.ws && need <= a.ws_elems, "ldmk_wgrad: splitr=%d needs a workspace of %lld floats (ldmk_wgrad_workspace_elems), "
+                     "%lld given", sr, need, a.ws ? a.ws_elems : 0LL);
   }
   hipStream_t st = (hipStream_t)stream;
   switch (cfg) {

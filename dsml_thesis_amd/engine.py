@@ -67,6 +67,7 @@ class Program:
     def __init__(self, device):
         self.device = torch.device(device)
         self.lib = L.load()
+        L.init(self.device.index if self.device.index is not None else torch.cuda.current_device())
         self.calls = []          # (fn, args, keepalive)
         self._free = {}          # numel -> [tensor]
         self._all = []

@@ -45,7 +45,9 @@ class WgradArgs(C.Structure):
 _SIGS = {
     "ldmk_version": (C.c_int, []),
     "ldmk_last_error": (C.c_char_p, []),
+    "ldmk_init": (C.c_int, [C.c_int]),
     "ldmk_igemm": (C.c_int, [C.POINTER(IgemmArgs), _fp]),
+    "ldmk_igemm_workspace_elems": (C.c_longlong, [C.POINTER(IgemmArgs)]),
     "ldmk_igemm_plan": (C.c_int, [C.POINTER(IgemmArgs), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ldmk_igemm_force_config": (None, [C.c_int]),
     "ldmk_wfrag_elems": (C.c_longlong, [C.c_int, C.c_int]),
@@ -79,6 +81,7 @@ _SIGS = {
     "ldmk_add_rowvec": (C.c_int, [_fp, _fp, C.c_int, C.c_longlong, C.c_int, C.c_int, _fp]),
     # ---- training step (N1)
     "ldmk_wgrad": (C.c_int, [C.POINTER(WgradArgs), _fp]),
+    "ldmk_wgrad_workspace_elems": (C.c_longlong, [C.POINTER(WgradArgs)]),
     "ldmk_wgrad_plan": (C.c_int, [C.POINTER(WgradArgs), C.POINTER(C.c_int)]),
     "ldmk_pack_dgrad3x3": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
     "ldmk_gn_group_stats": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp]),
@@ -140,6 +143,18 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+_inited = set()
+
+
+def init(device_index):
+    """ldmk_init once per device: arch check (gfx950) + kernel attributes set up front, so that no later call -- possibly
+    inside a hipGraph capture -- changes a function attribute."""
+    device_index = int(device_index)
+    if device_index not in _inited:
+        check(load().ldmk_init(device_index), "ldmk_init")
+        _inited.add(device_index)
 
 
 def check(rc, what=""):

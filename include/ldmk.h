@@ -24,9 +24,17 @@ extern "C" {
 #define LDMK_OK 0
 #define LDMK_EINVAL (-1) /* bad shape / alignment / unsupported combination */
 #define LDMK_EHIP (-2)   /* HIP launch error, see ldmk_last_error() */
+#define LDMK_ENOMEM (-3) /* the caller's workspace is too small for the pinned plan; size it with ldmk_*_workspace_elems() */
 
 int ldmk_version(void);
 const char* ldmk_last_error(void);
+/* Once per process and device, before the first launch: selects `device` (hipSetDevice), checks that it is a gfx950 part
+ * and raises the dynamic-LDS limits of the GEMM kernels, so that no later call changes a function attribute (every later
+ * call only enqueues work: capture-safe).  The library owns no device memory: every buffer, INCLUDING scratch, is the
+ * caller's -- a non-PyTorch host sizes scratch with the *_workspace_elems queries below.  Calling a kernel entry point
+ * without ldmk_init works too (attributes are then set lazily at the first launch of each tile shape).
+ * Returns LDMK_EHIP when there is no such device / it is not gfx950. */
+int ldmk_init(int device);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit GEMM on the f32 matrix cores (v_mfma_f32_32x32x2_f32):
@@ -88,6 +96,14 @@ typedef struct ldmk_igemm_args {
 } ldmk_igemm_args;
 
 int ldmk_igemm(const ldmk_igemm_args* args, void* stream);
+/* Scratch (in floats) ldmk_igemm(args) needs in args->splitk_ws: batch * splitk * M * N for a split-K plan, 0 otherwise.
+ * With args->splitk pinned (> 0) that is what the call will require (too little -> LDMK_ENOMEM); with splitk == 0 it is
+ * what the plan chosen with unlimited scratch would use (ldmk_igemm itself never fails for lack of scratch in that case:
+ * it plans within the scratch it is given).  Host flow without PyTorch:
+ *     ldmk_igemm_plan(&a, &a.tile_cfg, &a.splitk);  n = ldmk_igemm_workspace_elems(&a);  a.splitk_ws = my_alloc(4 * n);
+ *     a.splitk_ws_elems = n;  ldmk_igemm(&a, stream);
+ * Returns a negative LDMK_E* code for invalid arguments. */
+long long ldmk_igemm_workspace_elems(const ldmk_igemm_args* args);
 /* W[K][ldb] (row-major, as ldmk_igemm reads it with b_trans = 0) -> the fragment-order copy `w_frag` of K*N floats:
  * Wf[k/8][n/32][h][n%32][s] = W[8(k/8) + 4h + s][n], one contiguous 1-KiB wave load per four MFMAs.  K%8 == 0, N%32 == 0.
  * ldmk_wfrag_elems returns the size of that copy in floats (-1 when the shape cannot be packed). */
@@ -253,6 +269,9 @@ typedef struct ldmk_wgrad_args {
 } ldmk_wgrad_args;
 int ldmk_wgrad(const ldmk_wgrad_args* args, void* stream);
 int ldmk_wgrad_plan(const ldmk_wgrad_args* args, int* splitr);
+/* scratch floats ldmk_wgrad(args) needs in args->ws for args->splitr (0: the split ldmk_wgrad_plan would choose):
+ * batch * splitr * (Kw + (dbias ? 1 : 0)) * N when splitr > 1, else 0; too little with a pinned splitr -> LDMK_ENOMEM */
+long long ldmk_wgrad_workspace_elems(const ldmk_wgrad_args* args);
 /* packed forward 3x3 weights [cin/32][9][32][cout] -> data-gradient weights [cout/32][9][32][cin], taps mirrored */
 int ldmk_pack_dgrad3x3(const float* w_fwd, float* w_dgrad, int cin, int cout, void* stream);
 

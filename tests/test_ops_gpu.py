@@ -133,6 +133,30 @@ def test_conv3x3_split_k_reduce(ops, splitk):
     assert torch.equal(out, out2), "split-K partials are summed in a fixed order"
 
 
+def test_split_k_scratch_sized_from_the_abi_query_alone(ops):
+    """A host that is not PyTorch: plan -> ldmk_igemm_workspace_elems -> allocate exactly that -> run."""
+    import ctypes as C
+    from dsml_thesis_amd import lib as L
+    lib = L.load()
+    assert lib.ldmk_init(torch.cuda.current_device()) == 0
+    n, cin, cout, h, w = 2, 640, 640, 8, 8
+    x, wt, b = rnd(10, n, cin, h, w), rnd(11, cout, cin, 3, 3) / np.sqrt(9 * cin), 0.1 * rnd(12, cout)
+    xd, wd, bd = nhwc(x), ops.pack_conv3x3(wt.cuda()), b.cuda()
+    out = torch.empty(n, h, w, cout, device="cuda")
+    a = ops.make_igemm_args(n * h * w, cout, 9 * cin, xd, cin, wd, out, cout, h * w, conv=(h, w, h, w, 1, 1, 0), bias=bd)
+    a.splitk_ws, a.splitk_ws_elems = 1, 1 << 40                 # "plan as if scratch were free"
+    cfg, sk = C.c_int(0), C.c_int(0)
+    assert lib.ldmk_igemm_plan(C.byref(a), C.byref(cfg), C.byref(sk)) == 0 and sk.value > 1
+    a.tile_cfg, a.splitk, a.splitk_ws, a.splitk_ws_elems = cfg.value, sk.value, 0, 0
+    need = lib.ldmk_igemm_workspace_elems(C.byref(a))
+    assert need == sk.value * n * h * w * cout
+    assert lib.ldmk_igemm(C.byref(a), ops.stream()) == -3       # LDMK_ENOMEM: no scratch given for the pinned plan
+    ws = torch.empty(need, device="cuda")
+    a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), need
+    L.call("ldmk_igemm", C.byref(a), ops.stream())
+    close(nchw(out), F.conv2d(x, wt, b, padding=1), 1e-4, 1e-4)
+
+
 @pytest.mark.parametrize("splitk", [1, 4])
 def test_igemm_emits_groupnorm_partials(ops, splitk):
     """The conv epilogue (and the split-K reduce) emit the same per-32-pixel-chunk records as ldmk_gn_partial, so the
