@@ -640,7 +640,11 @@ extern "C" long long ldmk_igemm_workspace_elems(const ldmk_igemm_args* args) {
   return (long long)(a.batch > 1 ? a.batch : 1) * sk * (long long)a.M * a.N;
 }
 
-extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) {
+static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch);
+extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) { return igemm_entry(args, stream, true); }
+extern "C" int ldmk_igemm_check(const ldmk_igemm_args* args) { return igemm_entry(args, nullptr, false); }
+
+static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(args != nullptr, "ldmk_igemm: null args");
@@ -681,6 +685,7 @@ extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) {
   if (cfg > kNumCfg) {      // row GEMM: one wave per output tile, K never split
     const char* why = rgemm_unsupported(a, cfg - kNumCfg - 1);
     LDMK_REQUIRE(why == nullptr, "ldmk_igemm: tile_cfg=%d (row GEMM) cannot run this problem: %s", cfg, why ? why : "");
+    if (!launch) return LDMK_OK;
     return rgemm_dispatch(a, cfg - kNumCfg - 1, (hipStream_t)stream);
   }
   if (a.splitk > 0) sk = a.splitk;
@@ -691,6 +696,7 @@ extern "C" int ldmk_igemm(const ldmk_igemm_args* args, void* stream) {
                      "ldmk_igemm: splitk=%d needs a workspace of %lld floats (ldmk_igemm_workspace_elems), %lld given", sk,
                      b * sk * (long long)a.M * a.N, a.splitk_ws ? a.splitk_ws_elems : 0LL);
   }
+  if (!launch) return LDMK_OK;
   hipStream_t st = (hipStream_t)stream;
   return a.b_trans ? dispatch<true>(a, cfg, sk, a.splitk_ws, st) : dispatch<false>(a, cfg, sk, a.splitk_ws, st);
 }

@@ -122,8 +122,14 @@ class Program:
                 args.M = max(1, m * scale_m[0] // scale_m[1])
         cfg, sk = C.c_int(0), C.c_int(0)
         tuned = tuned_plan(args, args.M) if nbatch <= 1 and args.M > 0 else None
-        if tuned is not None and tuned[0] > 6 and not args.w_frag:
-            tuned = None                                  # a row-GEMM plan without the fragment-order weight copy
+        if tuned is not None and tuned[0] > 6:
+            # a row-GEMM wave tile: legal only with the fragment-order weight copy and when the tile divides this
+            # problem (per-sample operands need rows_per_sample % tile rows == 0); else the heuristic decides
+            saved = (args.M, args.batch, args.tile_cfg, args.splitk)
+            args.M, args.batch, args.tile_cfg, args.splitk = m, nbatch, int(tuned[0]), 1
+            if not args.w_frag or self.lib.ldmk_igemm_check(C.byref(args)) != 0:
+                tuned = None
+            args.M, args.batch, args.tile_cfg, args.splitk = saved
         if tuned is not None:
             cfg.value, sk.value = int(tuned[0]), int(tuned[1])
         else:

@@ -48,6 +48,7 @@ _SIGS = {
     "ldmk_init": (C.c_int, [C.c_int]),
     "ldmk_igemm": (C.c_int, [C.POINTER(IgemmArgs), _fp]),
     "ldmk_igemm_workspace_elems": (C.c_longlong, [C.POINTER(IgemmArgs)]),
+    "ldmk_igemm_check": (C.c_int, [C.POINTER(IgemmArgs)]),
     "ldmk_igemm_plan": (C.c_int, [C.POINTER(IgemmArgs), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ldmk_igemm_force_config": (None, [C.c_int]),
     "ldmk_wfrag_elems": (C.c_longlong, [C.c_int, C.c_int]),

@@ -104,6 +104,10 @@ int ldmk_igemm(const ldmk_igemm_args* args, void* stream);
  *     a.splitk_ws_elems = n;  ldmk_igemm(&a, stream);
  * Returns a negative LDMK_E* code for invalid arguments. */
 long long ldmk_igemm_workspace_elems(const ldmk_igemm_args* args);
+/* every check ldmk_igemm(args) makes (shapes, alignment, the pinned tile_cfg / splitk against this problem, scratch
+ * size), without launching: LDMK_OK or the code ldmk_igemm would return.  Lets a host validate a whole launch program
+ * up front, and a planner ask "can this wave tile run this problem" before pinning it. */
+int ldmk_igemm_check(const ldmk_igemm_args* args);
 /* W[K][ldb] (row-major, as ldmk_igemm reads it with b_trans = 0) -> the fragment-order copy `w_frag` of K*N floats:
  * Wf[k/8][n/32][h][n%32][s] = W[8(k/8) + 4h + s][n], one contiguous 1-KiB wave load per four MFMAs.  K%8 == 0, N%32 == 0.
  * ldmk_wfrag_elems returns the size of that copy in floats (-1 when the shape cannot be packed). */
