@@ -251,8 +251,7 @@ def test_row_gemm_wave_tiles(ops, cfg, case):
     """The wave-autonomous row GEMM (csrc/rgemm.hip, tile_cfg 7..12) against torch fp32 and, bitwise, against itself."""
     M, c0, c1, N, rps, pro, epi = case
     tm, tn = ROW_TILES[cfg]
-    if N % (32 * tn) or (epi == "geglu" and tn % 2) or (("vec" in epi or pro == "affine") and rps % (32 * tm)):
-        pytest.skip("tile does not fit this problem (the dispatcher rejects it; covered by test_row_gemm_rejects)")
+    fits = not (N % (32 * tn) or (epi == "geglu" and tn % 2) or (("vec" in epi or pro == "affine") and rps % (32 * tm)))
     K = c0 + c1
     x = rnd(70, M, K) * 1.2 + 0.1
     w, b = rnd(71, N, K) / np.sqrt(K), 0.1 * rnd(72, N)
@@ -295,6 +294,11 @@ def test_row_gemm_wave_tiles(ops, cfg, case):
             part = torch.zeros(M // 32, N, 3, device="cuda")
             kw.update(stats_out=part)
     wf = ops.pack_wfrag(wp)
+    if not fits:          # a wave tile that does not divide the problem is refused loudly, never run on a fallback
+        from dsml_thesis_amd import lib as L
+        with pytest.raises(L.LdmkError, match="row GEMM"):
+            ops.linear(x0, wp, x1=x1, rows_per_sample=rps, w_frag=wf, tile_cfg=cfg, **kw)
+        return
     y = ops.linear(x0, wp, x1=x1, rows_per_sample=rps, w_frag=wf, tile_cfg=cfg, **kw)
     close(y, y_ref, 1e-4, 1e-4)
     y2 = ops.linear(x0, wp, x1=x1, rows_per_sample=rps, w_frag=wf, tile_cfg=cfg, **kw)
