@@ -11,7 +11,7 @@ import glob
 import os
 import sys
 
-FAM = (("igemm_kernel", "igemm (all tiles)"), ("attn_self", "attention forward"), ("wgrad_kernel", "wgrad"),
+FAM = (("igemm_kernel", "igemm (LDS-tiled, all tiles)"), ("rgemm_kernel", "row GEMM (all wave tiles)"), ("attn_self", "attention forward"), ("wgrad_kernel", "wgrad"),
        ("attn_bwd", "attention backward"))
 
 
