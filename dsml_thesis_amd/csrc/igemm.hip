@@ -24,7 +24,19 @@
 
 namespace ldmk {
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT>
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {          // round-to-nearest-even (v_cvt_pk_bf16_f32)
+  return bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+}
+
+// BF = true: bf16 matrix-core compute for the training step (BASELINE configs[4]).  Operands stay fp32 in HBM; they are
+// rounded to bf16 (RNE) while being staged, after the fp32 prologue (LayerNorm / GroupNorm-affine), into K-contiguous LDS
+// rows [tile row][KC + 8] (the +8 bf16 = 16 B pad makes the 16 rows one ds_read_b128 group touches bank-disjoint), and
+// multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 epilogue).  Per 32-deep K slice a wave issues 2 TM TN
+// bf16 MFMAs of 32 cycles instead of 16 TM TN fp32 MFMAs of 64: the matrix work shrinks 16x and the kernel becomes
+// staging-bound, which is the expected regime as long as activations are stored in fp32.
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws) {
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
@@ -34,12 +46,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   constexpr int BSTR = BN + (BT ? 1 : 0);
   constexpr int AROWS = BM / 32;        // float4 per thread per 32-wide K sub-chunk (A)
   constexpr int BROWS = BN / 32;        // same for B
+  constexpr int RS = KC + 8;            // BF: bf16 elements per LDS row
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
+  static_assert(!BF || (WK == 1 && !DB), "the bf16 form is built for WK = 1, single-buffered");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int STAGE = KC * (ASTR + BSTR);   // floats per staging buffer (DB: two of them)
   float* As = smem;                     // [KC][ASTR]
   float* Bs = smem + KC * ASTR;         // [KC][BSTR]
+  __bf16* As16 = reinterpret_cast<__bf16*>(smem);               // BF: [BM][RS]
+  __bf16* Bs16 = reinterpret_cast<__bf16*>(smem) + BM * RS;     // BF: [BN][RS]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -146,6 +162,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         if (BT) {       // W given as [N][ldb]: rows n, contiguous k
           const int n = n0 + arow + 32 * i;
           if (kvalid && n < p.N) v = *reinterpret_cast<const float4*>(wp + (long long)n * p.ldb + kc * 32 + acol);
+        } else if (BF) { // W given as [K][ldb]; the bf16 LDS image is K-contiguous per column: a thread takes 4 consecutive
+                         // k of ONE column (4 dword loads, each a contiguous 256-B run across the wave) -> one 8-B LDS store
+          const int idx = tid + 256 * i;
+          const int kq = idx / BN, n = n0 + idx - kq * BN;
+          if (kvalid && n < p.N) {
+            const float* src = wp + (long long)(kc * 32 + 4 * kq) * p.ldb + n;
+            v.x = src[0]; v.y = src[p.ldb]; v.z = src[2 * (long long)p.ldb]; v.w = src[3 * (long long)p.ldb];
+          }
         } else {        // W given as [K][ldb]: rows k, contiguous n
           const int idx = tid + 256 * i;
           const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
@@ -195,6 +219,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
           }
         }
       }
+      if (BF) {
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i)
+          *reinterpret_cast<bf16x4*>(As16 + (arow + 32 * i) * RS + j * 32 + acol) = to_bf16x4(areg[j][i]);
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+          if (BT) {
+            *reinterpret_cast<bf16x4*>(Bs16 + (arow + 32 * i) * RS + j * 32 + acol) = to_bf16x4(breg[j][i]);
+          } else {
+            const int idx = tid + 256 * i;
+            const int kq = idx / BN, n = idx - kq * BN;
+            *reinterpret_cast<bf16x4*>(Bs16 + n * RS + j * 32 + 4 * kq) = to_bf16x4(breg[j][i]);
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         float* d = As + boff + (j * 32 + acol) * ASTR + arow + 32 * i;
@@ -226,6 +266,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   const float* Bw = Bs + (wk * KS * 32 + half) * BSTR + wn * (32 * TN) + l31;
 
   auto compute = [&](int boff) {
+    if constexpr (BF) {
+      const __bf16* Aw16 = As16 + (wm * (32 * TM) + l31) * RS + 8 * half;
+      const __bf16* Bw16 = Bs16 + (wn * (32 * TN) + l31) * RS + 8 * half;
+#pragma unroll
+      for (int s = 0; s < KC / 16; ++s) {
+        bf16x8 a8[TM], b8[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a8[i] = *reinterpret_cast<const bf16x8*>(Aw16 + i * 32 * RS + 16 * s);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b8[j] = *reinterpret_cast<const bf16x8*>(Bw16 + j * 32 * RS + 16 * s);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
     // operands of k-step s+1 are read from LDS before the MFMAs of step s are issued (two register sets)
     float a[2][TM], b[2][TN];
     auto fetch = [&](int s, int q) {
@@ -502,39 +559,40 @@ static const TileCfg kCfg[] = {
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false>
 static size_t cfg_lds_bytes() {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KC = 32 * WK * KS;
   constexpr int ASTR = BM + 1, BSTR = BN + (BT ? 1 : 0);
+  if (BF) return (size_t)(BM + BN) * (KC + 8) * 2;
   size_t stage = (size_t)KC * (ASTR + BSTR) * sizeof(float) * (DB ? 2 : 1);
   size_t red = WK > 1 ? (size_t)(WK - 1) * WM * WN * TM * TN * 16 * 64 * sizeof(float) : 0;
   return stage > red ? stage : red;
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false>
 static bool& cfg_attr_done() {
   static bool done = false;
   return done;
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false>
 static void cfg_set_attr() {
-  bool& done = cfg_attr_done<TM, TN, WM, WN, WK, KS, DB, BT>();
+  bool& done = cfg_attr_done<TM, TN, WM, WN, WK, KS, DB, BT, BF>();
   if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg_lds_bytes<TM, TN, WM, WN, WK, KS, DB, BT>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg_lds_bytes<TM, TN, WM, WN, WK, KS, DB, BT, BF>());
     done = true;
   }
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false>
 static int launch_cfg(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  size_t lds = cfg_lds_bytes<TM, TN, WM, WN, WK, KS, DB, BT>();
+  size_t lds = cfg_lds_bytes<TM, TN, WM, WN, WK, KS, DB, BT, BF>();
   int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles, splitk, a.batch > 1 ? a.batch : 1);
-  auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT>;
-  cfg_set_attr<TM, TN, WM, WN, WK, KS, DB, BT>();
+  auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF>;
+  cfg_set_attr<TM, TN, WM, WN, WK, KS, DB, BT, BF>();
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, splitk, ws);
   if (splitk > 1 && a.stats_out) {
     hipLaunchKernelGGL(igemm_reduce_stats_kernel, dim3(a.M / 32, (a.N + 63) / 64), dim3(256), 0, st, a, splitk, ws);
@@ -580,8 +638,24 @@ static void plan(const ldmk_igemm_args& a, int* cfg_out, int* splitk_out, long l
   *splitk_out = best_sk;
 }
 
+// bf16 matrix-core compute (args.compute = LDMK_COMPUTE_BF16): the WK = 1 tile shapes
+template <bool BT>
+static int dispatch_bf16(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hipStream_t st) {
+  const bool geglu = a.epi == LDMK_EPI_GEGLU;
+  if (cfg == 3) cfg = 4;                       // 64x64 with K split over the waves -> 64x64, 64 k per stage
+  if (cfg == 6) cfg = geglu ? 2 : 5;           // 64x160 with K split over wave pairs -> 128x160
+  if (geglu && !kCfg[cfg - 1].even_tn) cfg = 1;
+  switch (cfg) {
+    case 1: return launch_cfg<2, 2, 2, 2, 1, 1, false, BT, true>(a, splitk, ws, st);
+    case 2: return launch_cfg<1, 2, 2, 2, 1, 2, false, BT, true>(a, splitk, ws, st);
+    case 4: return launch_cfg<1, 1, 2, 2, 1, 2, false, BT, true>(a, splitk, ws, st);
+    default: return launch_cfg<1, 5, 4, 1, 1, 1, false, BT, true>(a, splitk, ws, st);
+  }
+}
+
 template <bool BT>
 static int dispatch(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hipStream_t st) {
+  if (a.compute == LDMK_COMPUTE_BF16) return dispatch_bf16<BT>(a, cfg, splitk, ws, st);
   if (a.epi == LDMK_EPI_GEGLU && !kCfg[cfg - 1].even_tn) cfg = 3;   // GEGLU needs (value, gate) tile pairs
   switch (cfg) {
     case 1: return launch_cfg<2, 2, 2, 2, 1, 1, false, BT>(a, splitk, ws, st);   // 128x128
@@ -677,6 +751,8 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg + kNumRCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]", a.tile_cfg,
                kNumCfg + kNumRCfg);
   LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 16, "ldmk_igemm: splitk=%d outside [0,16]", a.splitk);
+  LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.compute == LDMK_COMPUTE_BF16, "ldmk_igemm: compute=%d", a.compute);
+  LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.tile_cfg <= kNumCfg, "ldmk_igemm: the row GEMM tiles are fp32 only");
   if (a.alpha == 0.f) a.alpha = 1.f;
   int cfg = 0, sk = 1;
   plan(a, &cfg, &sk, a.splitk_ws ? a.splitk_ws_elems : 0);

@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libldmk.so")
 A_ROWS, A_CONV3X3 = 0, 1
 TF_NONE, TF_AFFINE, TF_AFFINE_SILU, TF_LAYERNORM = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU = 0, 1
+COMPUTE_F32, COMPUTE_BF16 = 0, 1
 
 _fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -27,7 +28,7 @@ class IgemmArgs(C.Structure):
         ("out", _fp), ("ldc", C.c_int), ("batch", C.c_int),
         ("a_bstride", C.c_longlong), ("w_bstride", C.c_longlong), ("out_bstride", C.c_longlong),
         ("alpha", C.c_float), ("tile_cfg", C.c_int), ("splitk", C.c_int),
-        ("splitk_ws", _fp), ("splitk_ws_elems", C.c_longlong), ("stats_out", _fp), ("w_frag", _fp),
+        ("splitk_ws", _fp), ("splitk_ws_elems", C.c_longlong), ("stats_out", _fp), ("compute", C.c_int), ("w_frag", _fp),
     ]
 
 
@@ -38,7 +39,7 @@ class WgradArgs(C.Structure):
         ("stride", C.c_int), ("pad_lo", C.c_int), ("upsample", C.c_int),
         ("dy", _fp), ("ldy", C.c_int), ("dw", _fp), ("ldw", C.c_int), ("accumulate", C.c_int), ("alpha", C.c_float),
         ("batch", C.c_int), ("a_bstride", C.c_longlong), ("dy_bstride", C.c_longlong), ("dw_bstride", C.c_longlong),
-        ("splitr", C.c_int), ("ws", _fp), ("ws_elems", C.c_longlong), ("dbias", _fp),
+        ("splitr", C.c_int), ("ws", _fp), ("ws_elems", C.c_longlong), ("dbias", _fp), ("compute", C.c_int),
     ]
 
 

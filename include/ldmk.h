@@ -51,6 +51,10 @@ int ldmk_init(int device);
 enum { LDMK_A_ROWS = 0, LDMK_A_CONV3X3 = 1 };
 enum { LDMK_TF_NONE = 0, LDMK_TF_AFFINE = 1, LDMK_TF_AFFINE_SILU = 2, LDMK_TF_LAYERNORM = 3 };
 enum { LDMK_EPI_NONE = 0, LDMK_EPI_GEGLU = 1 };
+/* arithmetic of the product.  F32: v_mfma_f32_32x32x2_f32, bit-identical to an fp32 fmaf chain -- the sampling path and
+ * every parity test.  BF16: operands rounded to bf16 (RNE) while staged, v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+ * and fp32 prologue / epilogue -- the mixed-precision training step (BASELINE configs[4]); HBM tensors stay fp32. */
+enum { LDMK_COMPUTE_F32 = 0, LDMK_COMPUTE_BF16 = 1 };
 
 typedef struct ldmk_igemm_args {
   int M, N, K;               /* K = 9*(c0+c1) for LDMK_A_CONV3X3 (weights packed by ldmk_pack_conv3x3), else c0+c1 */
@@ -90,6 +94,7 @@ typedef struct ldmk_igemm_args {
   long long splitk_ws_elems; /* capacity of splitk_ws in floats                                           */
   float* stats_out;          /* optional [M/32][N][3] GroupNorm partial records of the *output* (after the
                                 epilogue), one per 32-row tile and column; needs M%32==0, rows_per_sample%32==0 */
+  int compute;               /* LDMK_COMPUTE_*: F32 (default) or BF16 matrix-core arithmetic (tile_cfg 1..6 only)       */
   const float* w_frag;       /* optional second copy of w in MFMA-fragment order (ldmk_pack_wfrag).  With it, rows-mode
                                 problems may run on the wave-autonomous row GEMM (tile_cfg 7..12: no LDS, no barrier;
                                 csrc/rgemm.hip), which is what the short-K Linear layers of the transformer blocks want */
@@ -270,6 +275,8 @@ typedef struct ldmk_wgrad_args {
   float* ws;                 /* scratch for the partial slabs: batch*splitr*(Kw + (dbias?1:0))*N floats      */
   long long ws_elems;
   float* dbias;              /* optional [N]: column sums of dy (the bias gradient) from the same pass       */
+  int compute;               /* LDMK_COMPUTE_*: BF16 rounds both operands to bf16 while staging (fp32 accumulate; the
+                                bias column sums stay fp32)                                                    */
 } ldmk_wgrad_args;
 int ldmk_wgrad(const ldmk_wgrad_args* args, void* stream);
 int ldmk_wgrad_plan(const ldmk_wgrad_args* args, int* splitr);
