@@ -236,7 +236,7 @@ def train_mode(a, rank, world, dev, dist, backend, barrier, graph):
     from dsml_thesis_amd.train import UNetTrainer
     latent = 32 if a.latent == 64 and "--latent" not in " ".join(sys.argv) else a.latent
     model, ucfg = build_model(latent, dev)
-    tr = UNetTrainer(model.model.diffusion_model)
+    tr = UNetTrainer(model.model.diffusion_model, compute="bf16" if a.bf16 else "f32")
     sa, sb = model.sqrt_alphas_cumprod, model.sqrt_one_minus_alphas_cumprod
     n, c = a.batch, ucfg["in_channels"]
     g = torch.Generator(device="cpu").manual_seed(100 + rank)
@@ -291,10 +291,12 @@ def train_mode(a, rank, world, dev, dist, backend, barrier, graph):
     out = {"metric": "UNet training samples/sec (p_losses forward+backward+AdamW+EMA), BASELINE configs[4]",
            "value": round(world * n * a.steps / el, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "vs_baseline": None, "dtype": "bf16" if a.bf16 else "f32", "data": "synthetic",
            "config": {"workload": f"face_reenactment UNet fine-tune step (latent_manipulation_tuned.py / main.py -t), "
-                                  f"{n} samples/GPU, {latent}x{latent}x{c} latent, fp32 (BASELINE asks bf16: fp32 is the "
-                                  f"higher precision), AdamW + EMA, random-init weights", "batch_per_gpu": n,
+                                  f"{n} samples/GPU, {latent}x{latent}x{c} latent, "
+                                  + ("bf16 matrix-core GEMMs (fp32 accumulate, master weights, norms, attention)" if a.bf16
+                                     else "fp32 (the parity path; --bf16 selects BASELINE's bf16 compute)")
+                                  + ", AdamW + EMA, random-init weights", "batch_per_gpu": n,
                       "global_batch": n * world, "hipgraph": graph,
                       "parallelism": f"dp{world} (flat gradient buffer all-reduced in 128 MB buckets, overlapped with the backward)"},
            "step_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
@@ -322,6 +324,8 @@ def main():
     ap.add_argument("--no-clip", action="store_true", help="skip the talking-face clip leg (BASELINE configs[2]/[3])")
     ap.add_argument("--clip-steps", type=int, default=20, help="DDIM steps of the clip leg (the shipped run uses 200)")
     ap.add_argument("--clip-frames", type=int, default=128)
+    ap.add_argument("--bf16", action="store_true", help="with --train: bf16 matrix-core compute for every GEMM of the step "
+                    "(BASELINE configs[4]); fp32 master weights, accumulation, normalisations and attention")
     ap.add_argument("--train", action="store_true",
                     help="measure BASELINE configs[4] instead (UNet p_losses forward+backward+AdamW+EMA, fp32, data-"
                          "parallel with one all-reduce of the flat gradient buffer); not the default metric")

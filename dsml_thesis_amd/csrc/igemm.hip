@@ -54,8 +54,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   constexpr int STAGE = KC * (ASTR + BSTR);   // floats per staging buffer (DB: two of them)
   float* As = smem;                     // [KC][ASTR]
   float* Bs = smem + KC * ASTR;         // [KC][BSTR]
-  __bf16* As16 = reinterpret_cast<__bf16*>(smem);               // BF: [BM][RS]
-  __bf16* Bs16 = reinterpret_cast<__bf16*>(smem) + BM * RS;     // BF: [BN][RS]
+  __bf16* As16 = reinterpret_cast<__bf16*>(smem);               // BF: [BM][RS] bf16, K-contiguous rows
+  __bf16* Bs16 = reinterpret_cast<__bf16*>(smem) + BM * RS;     // BF, BT: [BN][RS] bf16 (W^T rows are K-contiguous in HBM)
+  float* Bs32 = smem + BM * RS / 2;                             // BF, !BT: [KC][BN] fp32 as it lies in HBM (n-contiguous);
+                                                                // fragments are gathered from it, see compute()
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -162,14 +164,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         if (BT) {       // W given as [N][ldb]: rows n, contiguous k
           const int n = n0 + arow + 32 * i;
           if (kvalid && n < p.N) v = *reinterpret_cast<const float4*>(wp + (long long)n * p.ldb + kc * 32 + acol);
-        } else if (BF) { // W given as [K][ldb]; the bf16 LDS image is K-contiguous per column: a thread takes 4 consecutive
-                         // k of ONE column (4 dword loads, each a contiguous 256-B run across the wave) -> one 8-B LDS store
-          const int idx = tid + 256 * i;
-          const int kq = idx / BN, n = n0 + idx - kq * BN;
-          if (kvalid && n < p.N) {
-            const float* src = wp + (long long)(kc * 32 + 4 * kq) * p.ldb + n;
-            v.x = src[0]; v.y = src[p.ldb]; v.z = src[2 * (long long)p.ldb]; v.w = src[3 * (long long)p.ldb];
-          }
         } else {        // W given as [K][ldb]: rows k, contiguous n
           const int idx = tid + 256 * i;
           const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
@@ -229,8 +223,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
             *reinterpret_cast<bf16x4*>(Bs16 + (arow + 32 * i) * RS + j * 32 + acol) = to_bf16x4(breg[j][i]);
           } else {
             const int idx = tid + 256 * i;
-            const int kq = idx / BN, n = idx - kq * BN;
-            *reinterpret_cast<bf16x4*>(Bs16 + n * RS + j * 32 + 4 * kq) = to_bf16x4(breg[j][i]);
+            const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
+            *reinterpret_cast<float4*>(Bs32 + (j * 32 + kk) * BN + n4 * 4) = breg[j][i];
           }
         }
         continue;
@@ -274,8 +268,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         bf16x8 a8[TM], b8[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a8[i] = *reinterpret_cast<const bf16x8*>(Aw16 + i * 32 * RS + 16 * s);
+        if (BT) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b8[j] = *reinterpret_cast<const bf16x8*>(Bw16 + j * 32 * RS + 16 * s);
+          for (int j = 0; j < TN; ++j) b8[j] = *reinterpret_cast<const bf16x8*>(Bw16 + j * 32 * RS + 16 * s);
+        } else {
+          // W is [K][N] in HBM: a K-contiguous bf16 image would need 2-byte scatter stores or 4 dword loads per thread
+          // (tried: the staging instructions cost more than the matrix work they feed).  Instead the fp32 slice is staged
+          // as it lies and the 8 k of a fragment are gathered with strided ds_read_b32 (consecutive lanes = consecutive
+          // columns: conflict-free) and rounded in registers.
+          const float* Bg = Bs32 + (16 * s + 8 * half) * BN + wn * (32 * TN) + l31;
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b8[j][e] = (__bf16)Bg[e * BN + j * 32];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -563,7 +569,7 @@ template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool
 static size_t cfg_lds_bytes() {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KC = 32 * WK * KS;
   constexpr int ASTR = BM + 1, BSTR = BN + (BT ? 1 : 0);
-  if (BF) return (size_t)(BM + BN) * (KC + 8) * 2;
+  if (BF) return BT ? (size_t)(BM + BN) * (KC + 8) * 2 : (size_t)BM * (KC + 8) * 2 + (size_t)KC * BN * 4;
   size_t stage = (size_t)KC * (ASTR + BSTR) * sizeof(float) * (DB ? 2 : 1);
   size_t red = WK > 1 ? (size_t)(WK - 1) * WM * WN * TM * TN * 16 * 64 * sizeof(float) : 0;
   return stage > red ? stage : red;

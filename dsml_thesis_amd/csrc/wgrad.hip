@@ -12,7 +12,17 @@
 
 namespace ldmk {
 
-template <int TM, int TN, int WM, int WN>
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+
+// BF = true: bf16 matrix-core compute (BASELINE configs[4]).  Staging is the fp32 kernel's, unchanged (float4 loads, one
+// index computation per 16 bytes, r-major fp32 LDS slices).  The MFMA's K dimension is the ROW index r here, so a bf16
+// fragment (8 consecutive r of one column) is gathered from the slice with 8 strided ds_read_b32 -- consecutive lanes read
+// consecutive columns: conflict-free -- and rounded to bf16 (RNE) in registers.  2 TM TN MFMAs (v_mfma_f32_32x32x16_bf16)
+// per 32-row slice instead of 16 TM TN fp32 ones; accumulation, slabs and the bias column sums stay fp32.  (First
+// version: a transposed bf16 LDS image filled by 4 dword loads per thread and element-wise conv index arithmetic --
+// 40 % SLOWER than the fp32 kernel, the staging instructions cost more than the matrix work saved.)
+template <int TM, int TN, int WM, int WN, bool BF = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(const ldmk_wgrad_args p, const int splitr, float* __restrict__ ws) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int ASTR = BM + 4, BSTR = BN + 4;       // 16-B aligned rows for the float4 staging stores
@@ -66,25 +76,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ldmk_wgrad_args p, con
   }
 
   float4 areg[NA], breg[NB];
+  // one element of the (virtual) A matrix: row r of the reduction, column described by (ch, dy, dx)
+  auto a_elem_ptr = [&](int r, int ch, int ddy, int ddx) -> const float* {
+    if (!conv) return ap + (long long)r * p.lda + ch;
+    int n, pix, oy, ox;
+    if (rps_shift >= 0) { n = r >> rps_shift; pix = r & (rps - 1); } else { n = r / rps; pix = r - n * rps; }
+    if (ow_shift >= 0) { oy = pix >> ow_shift; ox = pix & (p.out_w - 1); } else { oy = pix / p.out_w; ox = pix - oy * p.out_w; }
+    int iy = oy * p.stride - p.pad_lo + ddy, ix = ox * p.stride - p.pad_lo + ddx;
+    const int lim_h = p.upsample ? 2 * p.in_h : p.in_h, lim_w = p.upsample ? 2 * p.in_w : p.in_w;
+    if (iy < 0 || ix < 0 || iy >= lim_h || ix >= lim_w) return nullptr;
+    if (p.upsample) { iy >>= 1; ix >>= 1; }
+    return ap + ((long long)(n * p.in_h + iy) * p.in_w + ix) * p.c + ch;
+  };
   auto load_slice = [&](int it) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int r = it * 32 + a_rl[i];
       if (a_ok[i] && r < p.R) {
-        if (conv) {
-          int n, pix, oy, ox;
-          if (rps_shift >= 0) { n = r >> rps_shift; pix = r & (rps - 1); } else { n = r / rps; pix = r - n * rps; }
-          if (ow_shift >= 0) { oy = pix >> ow_shift; ox = pix & (p.out_w - 1); } else { oy = pix / p.out_w; ox = pix - oy * p.out_w; }
-          int iy = oy * p.stride - p.pad_lo + a_dy[i], ix = ox * p.stride - p.pad_lo + a_dx[i];
-          const int lim_h = p.upsample ? 2 * p.in_h : p.in_h, lim_w = p.upsample ? 2 * p.in_w : p.in_w;
-          if (iy >= 0 && ix >= 0 && iy < lim_h && ix < lim_w) {
-            if (p.upsample) { iy >>= 1; ix >>= 1; }
-            v = *reinterpret_cast<const float4*>(ap + ((long long)(n * p.in_h + iy) * p.in_w + ix) * p.c + a_ch[i]);
-          }
-        } else {
-          v = *reinterpret_cast<const float4*>(ap + (long long)r * p.lda + a_ch[i]);
-        }
+        const float* src = a_elem_ptr(r, a_ch[i], a_dy[i], a_dx[i]);
+        if (src) v = *reinterpret_cast<const float4*>(src);
       }
       areg[i] = v;
     }
@@ -125,6 +136,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ldmk_wgrad_args p, con
     if (do_bias) {
 #pragma unroll
       for (int r = 0; r < 32; ++r) bsum += Bs[r * BSTR + tid];
+    }
+    if constexpr (BF) {
+      // fragment of k-step s: rows 16 s + 8 half + e (e = 0..7) of this lane's column, rounded to bf16
+      const float* Ag = As + (8 * half) * ASTR + wm * (32 * TM) + l31;
+      const float* Bg = Bs + (8 * half) * BSTR + wn * (32 * TN) + l31;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        wbf16x8 a8[TM], b8[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a8[i][e] = (__bf16)Ag[(16 * s + e) * ASTR + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) b8[j][e] = (__bf16)Bg[(16 * s + e) * BSTR + j * 32];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+      }
+      continue;
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -196,12 +229,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ldmk_wgrad_args
   }
 }
 
+template <int TM, int TN, int WM, int WN, bool BF>
+static int launch_wgrad_t(const ldmk_wgrad_args& a, int splitr, hipStream_t st);
+
 template <int TM, int TN, int WM, int WN>
 static int launch_wgrad(const ldmk_wgrad_args& a, int splitr, hipStream_t st) {
+  return a.compute == LDMK_COMPUTE_BF16 ? launch_wgrad_t<TM, TN, WM, WN, true>(a, splitr, st)
+                                        : launch_wgrad_t<TM, TN, WM, WN, false>(a, splitr, st);
+}
+
+template <int TM, int TN, int WM, int WN, bool BF>
+static int launch_wgrad_t(const ldmk_wgrad_args& a, int splitr, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   const int tiles = ((a.Kw + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const int nb = a.batch > 1 ? a.batch : 1;
-  hipLaunchKernelGGL((wgrad_kernel<TM, TN, WM, WN>), dim3(tiles, splitr, nb), dim3(256), 0, st, a, splitr, a.ws);
+  hipLaunchKernelGGL((wgrad_kernel<TM, TN, WM, WN, BF>), dim3(tiles, splitr, nb), dim3(256), 0, st, a, splitr, a.ws);
   if (splitr > 1) {
     long long total = (long long)(a.Kw + (a.dbias ? 1 : 0)) * (a.N / 4);
     int g = (int)((total + 255) / 256);
@@ -283,6 +325,7 @@ extern "C" int ldmk_wgrad(const ldmk_wgrad_args* args, void* stream) {
   }
   LDMK_REQUIRE(!a.dbias || a.batch <= 1, "ldmk_wgrad: dbias is not available for batched problems");
   LDMK_REQUIRE(a.splitr >= 0 && a.splitr <= 256, "ldmk_wgrad: splitr=%d outside [0,256]", a.splitr);
+  LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.compute == LDMK_COMPUTE_BF16, "ldmk_wgrad: compute=%d", a.compute);
   if (a.alpha == 0.f) a.alpha = 1.f;
   const int cfg = wgrad_cfg(a);
   int sr = a.splitr > 0 ? a.splitr : wgrad_plan_splitr(a, cfg);

@@ -397,12 +397,16 @@ class LatentDiffusion(_Base):
 
     # ---- training surface -------------------------------------------------------------
     automatic_optimization = False      # Lightning: the step below runs its own backward + optimizer (no autograd)
+    # arithmetic of the training step's GEMMs: "f32" (parity path) or "bf16" (BASELINE configs[4]: bf16 matrix-core
+    # products, fp32 accumulation / master weights / AdamW / EMA).  Set it before the first training call, e.g.
+    # `model.train_compute = "bf16"` -- the role `precision=bf16` plays for the reference's Lightning Trainer (main.py)
+    train_compute = "f32"
 
     def trainer(self):
         """The HIP training engine for the UNet (forward + hand-written backward, flat packed parameters)."""
         if getattr(self, "_trainer", None) is None:
             from .train import UNetTrainer
-            self._trainer = UNetTrainer(self.model.diffusion_model)
+            self._trainer = UNetTrainer(self.model.diffusion_model, compute=self.train_compute)
             self._ema_flat = None
             if self.use_ema:
                 # the shadow starts from the `model_ema` buffers (what a checkpoint restored), not from the live

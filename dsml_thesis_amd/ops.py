@@ -117,7 +117,7 @@ def ln_stats(x2d, eps=1e-5, out=None):
 def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0, conv=None, tf=L.TF_NONE,
                     tf_coef=None, row_stats=None, ln_gamma=None, ln_beta=None, b_trans=False, ldb=None, bias=None,
                     batch_vec=None, batch_vec_ld=0, residual=None, epi=L.EPI_NONE, batch=1, a_bstride=0, w_bstride=0,
-                    out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None, w_frag=None, tile_cfg=0):
+                    out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None, w_frag=None, tile_cfg=0, compute=0):
     a = L.IgemmArgs()
     a.M, a.N, a.K = M, N, K
     a.a0, a.a1, a.c0, a.c1 = _ptr(a0), _ptr(a1), c0, c1
@@ -137,7 +137,7 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
     a.a_bstride, a.w_bstride, a.out_bstride = a_bstride, w_bstride, out_bstride
     a.alpha = alpha
     a.splitk = splitk
-    a.w_frag, a.tile_cfg = _ptr(w_frag), tile_cfg
+    a.w_frag, a.tile_cfg, a.compute = _ptr(w_frag), tile_cfg, compute
     if splitk_ws is not None:
         a.splitk_ws, a.splitk_ws_elems = splitk_ws.data_ptr(), splitk_ws.numel()
     return a
@@ -148,7 +148,7 @@ def igemm(args):
 
 
 def conv3x3(x, wp, bias=None, x1=None, stride=1, pad_lo=1, upsample=False, coef=None, silu=True, batch_vec=None,
-            residual=None, out=None, out_hw=None):
+            residual=None, out=None, out_hw=None, compute=0):
     """x: (n,h,w,c0) [+ x1 (n,h,w,c1) channel-concat]; wp: [9*(c0+c1)][cout] -> (n,oh,ow,cout)."""
     n, h, w_, c0 = x.shape
     c1 = 0 if x1 is None else x1.shape[-1]
@@ -167,14 +167,14 @@ def conv3x3(x, wp, bias=None, x1=None, stride=1, pad_lo=1, upsample=False, coef=
     a = make_igemm_args(n * oh * ow, cout, 9 * (c0 + c1), x, c0, wp, out, cout, oh * ow, a1=x1, c1=c1,
                         conv=(h, w_, oh, ow, stride, pad_lo, 1 if upsample else 0), tf=tf, tf_coef=coef, bias=bias,
                         batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0),
-                        residual=residual)
+                        residual=residual, compute=compute)
     igemm(a)
     return out
 
 
 def linear(x2d, wp, bias=None, x1=None, rows_per_sample=None, coef=None, silu=False, row_stats=None, ln_gamma=None,
            ln_beta=None, batch_vec=None, residual=None, geglu=False, out=None, b_trans=False, w_frag=None, tile_cfg=0,
-           stats_out=None):
+           stats_out=None, compute=0):
     """x2d: [M][c0] (+ x1 [M][c1]); wp: [K][N] (or torch [N][K] with b_trans) -> [M][N] (N/2 for geglu)."""
     M, c0 = x2d.shape
     c1 = 0 if x1 is None else x1.shape[-1]
@@ -191,7 +191,8 @@ def linear(x2d, wp, bias=None, x1=None, rows_per_sample=None, coef=None, silu=Fa
     a = make_igemm_args(M, N, K, x2d, c0, wp, out, ncol, rows_per_sample or M, a1=x1, c1=c1, tf=tf, tf_coef=coef,
                         row_stats=row_stats, ln_gamma=ln_gamma, ln_beta=ln_beta, b_trans=b_trans, bias=bias,
                         batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0),
-                        residual=residual, epi=L.EPI_GEGLU if geglu else L.EPI_NONE, w_frag=w_frag, tile_cfg=tile_cfg)
+                        residual=residual, epi=L.EPI_GEGLU if geglu else L.EPI_NONE, w_frag=w_frag, tile_cfg=tile_cfg,
+                        compute=compute)
     if stats_out is not None:
         a.stats_out = _ptr(stats_out)
     igemm(a)

@@ -39,7 +39,10 @@ def gemm(a, dev):
     ws = _splitk_ws(dev)
     if RECORD is not None:
         RECORD.append(a)
+    a.compute = T.COMPUTE
     plan = tuned_plan(a, a.M) if a.batch <= 1 else None
+    if plan is not None and plan[0] > 6:
+        plan = None                 # row-GEMM tiles need the fragment-order weight copy, which the trainer does not keep
     if plan is not None and max(1, a.batch) * plan[1] * a.M * a.N <= ws.numel():
         a.tile_cfg, a.splitk = plan
     a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
@@ -90,7 +93,12 @@ class FlatParams:
 
 
 class UNetTrainer:
-    def __init__(self, unet):
+    def __init__(self, unet, compute="f32"):
+        """compute: "f32" (the parity path: fp32 matrix cores, bit-exact fmaf-chain products) or "bf16" (BASELINE configs[4]:
+        every Conv2d / Linear forward, data-gradient and weight-gradient GEMM rounds its operands to bf16 and runs on
+        v_mfma_f32_32x32x16_bf16 with fp32 accumulation; master weights, gradients, AdamW, EMA, normalisations and the
+        attention kernels stay fp32)."""
+        self.compute = T.set_compute(compute)
         if unet._packed is None:
             unet.pack_weights()
         if unet.context_dim is None:
@@ -455,6 +463,7 @@ class UNetTrainer:
         (L = 1: the shipped configs' fast path; 1 < L <= 128: general cross-attention).
         Returns eps (n,C_out,H,W); records the tape for backward()."""
         u, p, dev = self.unet, self.P.p, self.dev
+        T.set_compute(self.compute)
         if not x.is_cuda:
             raise L.LdmkError("UNetTrainer.forward: CUDA tensors only (no CPU fallback)")
         if context is None:
@@ -545,6 +554,7 @@ class UNetTrainer:
         gradient buffer past some offset is final, that bucket (>= bucket_elems floats, 128 MB by default: few, large
         collectives suit the xGMI rings) is handed to an asynchronous all-reduce while earlier layers still compute."""
         ps = self.last_pass if pass_ is None else pass_
+        T.set_compute(self.compute)
         self.tape, self.G, self.ginit, self.eps_pad, self.dctx = ps["tape"], ps["G"], ps["ginit"], ps["eps_pad"], ps["dctx"]
         self._dctx_init = False
         self._alias_grad(self.eps_pad, deps_pad)

@@ -13,6 +13,18 @@ def _f32(*shape, device="cuda"):
     return torch.empty(*shape, device=device, dtype=torch.float32)
 
 
+# Arithmetic of the matrix-core GEMMs the training helpers below launch: L.COMPUTE_F32 (parity path) or L.COMPUTE_BF16
+# (BASELINE configs[4]: bf16 operands, fp32 accumulation / master weights).  UNetTrainer sets it from its `compute` argument
+# at the start of every forward / backward; the step is single-threaded host code.
+COMPUTE = L.COMPUTE_F32
+
+
+def set_compute(mode):
+    global COMPUTE
+    COMPUTE = {None: L.COMPUTE_F32, "f32": L.COMPUTE_F32, "fp32": L.COMPUTE_F32, "bf16": L.COMPUTE_BF16}.get(mode, mode)
+    return COMPUTE
+
+
 def wgrad_args(R, Kw, N, a, dy, dw, c=0, lda=None, conv=None, ldy=None, ldw=None, accumulate=False, alpha=1.0, batch=1,
                a_bstride=0, dy_bstride=0, dw_bstride=0, splitr=0, ws=None, dbias=None):
     w = L.WgradArgs()
@@ -33,6 +45,7 @@ def wgrad_args(R, Kw, N, a, dy, dw, c=0, lda=None, conv=None, ldy=None, ldw=None
     w.batch, w.a_bstride, w.dy_bstride, w.dw_bstride = batch, a_bstride, dy_bstride, dw_bstride
     w.splitr = splitr
     w.dbias = _ptr(dbias)
+    w.compute = COMPUTE
     if ws is not None:
         w.ws, w.ws_elems = ws.data_ptr(), ws.numel()
     return w
@@ -113,7 +126,7 @@ def conv3x3_dgrad(dy, wd, in_hw, stride=1, out=None, residual=None):
     cin = wd.shape[1]
     if out is None:
         out = _f32(n, h, w_, cin, device=dy.device)
-    a = ops.make_igemm_args(n * h * w_, cin, 9 * cout, dy, cout, wd, out, cin, h * w_,
+    a = ops.make_igemm_args(n * h * w_, cin, 9 * cout, dy, cout, wd, out, cin, h * w_, compute=COMPUTE,
                             conv=(oh, ow, h, w_, 1, 1, 2 if stride == 2 else 0), residual=residual)
     ops.igemm(a)
     return out

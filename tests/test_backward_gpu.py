@@ -299,3 +299,4 @@ def test_audio_attention_backward():
         audio_attention_backward(mod, x.cuda(), dout.cuda())
         for (k, p), (_, pr) in zip(mod.named_parameters(), ref.named_parameters()):
             _close(p.grad, pr.grad, 5e-5, f"audio attention grad {k}")
+

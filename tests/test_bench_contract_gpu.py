@@ -42,6 +42,8 @@ def test_bench_train_mode_line():
     d = _run("--train", "--steps", "2", "--warmup", "1", "--batch", "4")
     assert d["unit"] == "samples/s" and d["n_gpus"] == 1 and d["dtype"] == "f32" and d["value"] > 1
     assert d["roofline"]["bound"] == "mfma" and 0.0 < d["roofline"]["frac"] < 1.0
+    b = _run("--train", "--bf16", "--steps", "2", "--warmup", "1", "--batch", "4")
+    assert b["dtype"] == "bf16" and b["value"] > 1 and "bf16 matrix-core" in b["config"]["workload"]
 
 
 def test_bench_self_launches_two_ranks_and_the_clip_checksum_does_not_depend_on_the_rank_count():
