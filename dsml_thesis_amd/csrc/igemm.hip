@@ -370,25 +370,68 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       }
     }
   }
-  if (wk != 0) return;
-
   // ---- epilogue.  C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int rowbase = m0 + wm * (32 * TM);
   const int colbase = n0 + wn * (32 * TN);
-  if (splitk > 1) {   // raw partial slab [ks][M][N]; bias/residual/... happen in igemm_reduce_kernel
+  if (splitk > 1) {   // raw partial slab [ks][M][N]
     float* slab = ws + ((long long)bz * splitk + ks) * p.M * p.N;
+    const bool inl = p.splitk_counters != nullptr;       // in-launch combine (below) or the two-launch form
+    if (wk == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = colbase + j * 32 + l31;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < p.M) {
+              float* d = slab + (long long)row * p.N + col;
+              if (inl) __hip_atomic_store(d, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store ... sc1
+              else *d = acc[i][j][r];
+            }
+          }
+      }
+    }
+    if (!inl) return;    // two-launch form: igemm_reduce_kernel sums the slabs and runs the epilogue
+    // In-launch combine: the LAST of the tile's `splitk` workgroups to arrive sums all slabs (fixed order k = 0..splitk-1,
+    // so the result does not depend on which one that is) and runs the ordinary epilogue below -- no reduce launch, no
+    // second pass over the output.  Hand-off per MI355X_MICROARCH.md (per-XCD L2s are not coherent, a CU's L1 is never
+    // refreshed): the slabs are stored write-through (sc1) and read back with sc1 loads -- EVERY store and EVERY load of the
+    // handed-off bytes -- every storing wave drains its stores (vmcnt(0)), then a workgroup barrier, then ONE lane takes an
+    // agent-scope ticket; the wave that drew the last ticket loads behind a workgroup barrier.  No agent-scope fence:
+    // a release fence (buffer_wbl2) writes back EVERYTHING dirty in the XCD's L2 -- with ~100 MB of activations in flight
+    // that made the fused form 1.5-2x slower than the reduce launch it replaces (measured; kept out).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);             // the staging buffer is free now (all MFMA reads are done)
+    if (tid == 0) {
+      int* cnt = p.splitk_counters + (long long)bz * tiles_m * tiles_n + bid;
+      const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == splitk - 1;
+      if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zeroed for the next launch
+      *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0 || wk != 0) return;
+    const float* slab0 = ws + (long long)bz * splitk * p.M * p.N;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = colbase + j * 32 + l31;
-      if (col >= p.N) continue;
+      const int col = min(colbase + j * 32 + l31, p.N - 1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < p.M) slab[(long long)row * p.N + col] = acc[i][j][r];
+          const int row = min(rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.M - 1);
+          const float* src = slab0 + (long long)row * p.N + col;
+          float sum = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               // global_load ... sc1
+          for (int k = 1; k < splitk; ++k)
+            sum += __hip_atomic_load(src + (long long)k * p.M * p.N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc[i][j][r] = sum;
         }
     }
+  } else if (wk != 0) {
     return;
   }
   float* __restrict__ outp = p.out + (long long)bz * p.out_bstride;
@@ -600,7 +643,9 @@ static int launch_cfg(const ldmk_igemm_args& a, int splitk, float* ws, hipStream
   auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF>;
   cfg_set_attr<TM, TN, WM, WN, WK, KS, DB, BT, BF>();
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, splitk, ws);
-  if (splitk > 1 && a.stats_out) {
+  if (splitk > 1 && a.splitk_counters) {
+    // the last-arriving workgroup of each tile combined the slabs and ran the epilogue inside the launch
+  } else if (splitk > 1 && a.stats_out) {
     hipLaunchKernelGGL(igemm_reduce_stats_kernel, dim3(a.M / 32, (a.N + 63) / 64), dim3(256), 0, st, a, splitk, ws);
   } else if (splitk > 1) {
     long long total = (long long)a.M * (a.N / 4);
@@ -772,6 +817,11 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   }
   if (a.splitk > 0) sk = a.splitk;
   if (a.epi == LDMK_EPI_GEGLU) sk = 1;
+  if (sk > 1 && a.splitk_counters) {
+    const long long tiles = (long long)(a.batch > 1 ? a.batch : 1) * ((a.M + 63) / 64) * ((a.N + 63) / 64);   // smallest tile: 64x64
+    LDMK_REQUIRE_MEM(tiles <= a.splitk_counters_len, "ldmk_igemm: in-launch split-K combine needs %lld zeroed counters, %d given",
+                     tiles, a.splitk_counters_len);
+  }
   if (sk > 1) {
     const long long b = a.batch > 1 ? a.batch : 1;
     LDMK_REQUIRE_MEM(a.splitk_ws && b * sk * (long long)a.M * a.N <= a.splitk_ws_elems,

@@ -8,6 +8,7 @@ consumer kernels instead of streaming ~1 GB of fresh HBM lines per step.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -110,6 +111,14 @@ class Program:
                     a.splitk_ws, a.splitk_ws_elems = self._skws.data_ptr(), self._skws.numel()
         return self._skws
 
+    def splitk_counters(self, n=16384):
+        """Arrival counters of the in-launch split-K combine: zeroed once; every GEMM launch leaves them zeroed, and the
+        GEMMs of a program are stream-ordered, so they all share this one array."""
+        if getattr(self, "_skcnt", None) is None:
+            self._skcnt = torch.zeros(n, device=self.device, dtype=torch.int32)
+            self._all.append(self._skcnt)
+        return self._skcnt
+
     def igemm(self, args, scale_m=None, allow_splitk=True):
         """Record a GEMM.  The (tile shape, K split) pair is planned here, once: for the real M, or -- with
         scale_m = (num, den) -- for M*num/den rows, which pins the K-summation order so that results are
@@ -144,6 +153,14 @@ class Program:
             need = max(1, args.batch) * args.splitk * args.M * args.N
             ws = self.splitk_workspace(need)
             args.splitk_ws, args.splitk_ws_elems = ws.data_ptr(), ws.numel()
+            # In-launch combine (each tile's last-arriving workgroup sums the slabs) is built and tested, but OFF: split-K is
+            # chosen exactly when a GEMM has few output tiles, so the combine runs on those few workgroups (10 of 256 CUs
+            # for the 8x8-level convolutions at batch 1) reading `splitk` slabs with write-through traffic, while the reduce
+            # launch spreads the same bytes over the whole chip.  Measured (A/B in one process): 476 -> 446 sample-steps/s at
+            # 64x64x4 B=16, 1657 -> 1231 at 32x32x3, 249 -> 141 at B=1.  LDMK_SPLITK_IN_LAUNCH=1 turns it on.
+            if os.environ.get("LDMK_SPLITK_IN_LAUNCH"):
+                cnt = self.splitk_counters()
+                args.splitk_counters, args.splitk_counters_len = cnt.data_ptr(), cnt.numel()
         self.calls.append((self.lib.ldmk_igemm, (C.byref(args),), args, "ldmk_igemm"))
 
     def run(self, stream=None):

@@ -28,7 +28,8 @@ class IgemmArgs(C.Structure):
         ("out", _fp), ("ldc", C.c_int), ("batch", C.c_int),
         ("a_bstride", C.c_longlong), ("w_bstride", C.c_longlong), ("out_bstride", C.c_longlong),
         ("alpha", C.c_float), ("tile_cfg", C.c_int), ("splitk", C.c_int),
-        ("splitk_ws", _fp), ("splitk_ws_elems", C.c_longlong), ("stats_out", _fp), ("compute", C.c_int), ("w_frag", _fp),
+        ("splitk_ws", _fp), ("splitk_ws_elems", C.c_longlong), ("stats_out", _fp), ("compute", C.c_int), ("splitk_counters", _fp), ("splitk_counters_len", C.c_int),
+        ("w_frag", _fp),
     ]
 
 

@@ -14,6 +14,8 @@ libldmk.so on the current stream, so a whole step can be captured in a hipGraph.
 Scope: cross-attention context of 1 token (both shipped configs: (B,1,512) FR, (B,1,1024) TF; the block collapses to a
 per-sample vector) or up to 128 tokens (general cross-attention forward/backward kernels), dropout 0.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -23,6 +25,7 @@ from . import train_ops as T
 from .engine import tuned_plan
 
 _SK_WS = {}
+_SK_CNT = {}
 RECORD = None      # tools/autotune.py --train: list collecting one (args, keepalive tensors) entry per distinct GEMM shape
 
 
@@ -46,6 +49,11 @@ def gemm(a, dev):
     if plan is not None and max(1, a.batch) * plan[1] * a.M * a.N <= ws.numel():
         a.tile_cfg, a.splitk = plan
     a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
+    if os.environ.get("LDMK_SPLITK_IN_LAUNCH"):       # off by default: slower than the reduce launch (engine.Program.igemm)
+        cnt = _SK_CNT.get(dev)
+        if cnt is None:
+            cnt = _SK_CNT[dev] = torch.zeros(16384, device=dev, dtype=torch.int32)
+        a.splitk_counters, a.splitk_counters_len = cnt.data_ptr(), cnt.numel()
     ops.igemm(a)
 
 

@@ -95,6 +95,13 @@ typedef struct ldmk_igemm_args {
   float* stats_out;          /* optional [M/32][N][3] GroupNorm partial records of the *output* (after the
                                 epilogue), one per 32-row tile and column; needs M%32==0, rows_per_sample%32==0 */
   int compute;               /* LDMK_COMPUTE_*: F32 (default) or BF16 matrix-core arithmetic (tile_cfg 1..6 only)       */
+  int* splitk_counters;      /* optional: >= ceil(M/64)*ceil(N/64)*batch ints, ZEROED once by the caller.  With it a split-K
+                                GEMM is ONE launch: each tile's last-arriving workgroup sums the slabs (fixed order: bitwise
+                                reproducible) and runs the epilogue; every launch leaves the counters zeroed again, so one
+                                array serves all GEMMs of a stream.  NULL: the slabs are summed by a second (reduce) launch,
+                                which is the FASTER form whenever the output has fewer tiles than the chip has CUs -- the
+                                usual reason to split K -- because the combine then runs on those few workgroups only */
+  int splitk_counters_len;
   const float* w_frag;       /* optional second copy of w in MFMA-fragment order (ldmk_pack_wfrag).  With it, rows-mode
                                 problems may run on the wave-autonomous row GEMM (tile_cfg 7..12: no LDS, no barrier;
                                 csrc/rgemm.hip), which is what the short-K Linear layers of the transformer blocks want */

@@ -133,6 +133,41 @@ def test_conv3x3_split_k_reduce(ops, splitk):
     assert torch.equal(out, out2), "split-K partials are summed in a fixed order"
 
 
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("splitk", [2, 5, 16])
+def test_split_k_in_launch_combine_equals_the_two_launch_form(ops, cfg, splitk):
+    """One launch: each tile's last-arriving workgroup sums the slabs in the fixed order and runs the epilogue (bias,
+    per-sample vector, residual, GroupNorm partial records).  Bitwise equal to main + reduce launches, launch after launch
+    (the counters are left zeroed), for every workgroup tile shape incl. the ones that split K over their own waves."""
+    n, cin, cout, h, w = 4, 320, 320, 16, 16
+    x, wt, b = rnd(10, n, cin, h, w), rnd(11, cout, cin, 3, 3) / np.sqrt(9 * cin), 0.1 * rnd(12, cout)
+    vec, res = rnd(13, n, cout), rnd(14, n, cout, h, w)
+    xd, wd, bd, vd, rd = nhwc(x), ops.pack_conv3x3(wt.cuda()), b.cuda(), vec.cuda(), nhwc(res)
+    ws = torch.empty(splitk * n * h * w * cout, device="cuda")
+    cnt = torch.zeros(1024, device="cuda", dtype=torch.int32)
+    outs, parts = [], []
+    for counters in (None, cnt, cnt, cnt):
+        out = torch.empty(n, h, w, cout, device="cuda")
+        part = torch.zeros(n * h * w // 32, cout, 3, device="cuda")
+        a = ops.make_igemm_args(n * h * w, cout, 9 * cin, xd, cin, wd, out, cout, h * w, conv=(h, w, h, w, 1, 1, 0), bias=bd,
+                                batch_vec=vd, batch_vec_ld=cout, residual=rd, splitk=splitk, splitk_ws=ws, tile_cfg=cfg,
+                                splitk_counters=counters)
+        a.stats_out = part.data_ptr()
+        ops.igemm(a)
+        outs.append(out)
+        parts.append(part)
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0, "every launch must leave the arrival counters zeroed"
+    ref = F.conv2d(x, wt, b, padding=1) + vec[:, :, None, None] + res
+    close(nchw(outs[0]), ref, 1e-4, 1e-4)
+    for o, p_ in zip(outs[1:], parts[1:]):
+        assert torch.equal(o, outs[0]) and torch.equal(p_, parts[1])
+    # the GroupNorm records of the two forms sum the same 32 values in a different order: same sums to fp32 accuracy
+    full = lambda q: (q[..., 1] + 32 * q[..., 0], q[..., 2] + 2 * q[..., 0] * q[..., 1] + 32 * q[..., 0] ** 2)
+    for u, v in zip(full(parts[1]), full(parts[0])):
+        close(u, v, 1e-4, 1e-4)
+
+
 def test_split_k_scratch_sized_from_the_abi_query_alone(ops):
     """A host that is not PyTorch: plan -> ldmk_igemm_workspace_elems -> allocate exactly that -> run."""
     import ctypes as C
