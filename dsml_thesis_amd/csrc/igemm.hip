@@ -22,6 +22,14 @@
 //     (M = 64 rows per sample at 8x8, K up to 9*1280).
 #include "ldmk_common.h"
 
+// Diagnostic build only (tools/igemm_probe.hip defines LDMK_IG_STAMPS): per-wave cycle totals of the main loop's phases
+// (barrier 1, LDS store, barrier 2, global-load issue, MFMA block) go to args.splitk_ws (split-K off in the probe) as [wave][8] 64-bit ticks.
+#ifdef LDMK_IG_STAMPS
+#define IG_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ig_acc[i] += t_ - ig_last; ig_last = t_; } while (0)
+#else
+#define IG_T(i) do { } while (0)
+#endif
+
 namespace ldmk {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -36,7 +44,7 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {          // round
 // multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 epilogue).  Per 32-deep K slice a wave issues 2 TM TN
 // bf16 MFMAs of 32 cycles instead of 16 TM TN fp32 MFMAs of 64: the matrix work shrinks 16x and the kernel becomes
 // staging-bound, which is the expected regime as long as activations are stored in fp32.
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false, bool FG = true>
 __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws) {
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
@@ -128,8 +136,80 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   float4 areg[NS][AROWS];
   float4 breg[NS][BROWS];
 
-  // raw global loads of one iteration's slices (no arithmetic on the data: nothing here waits for memory)
-  auto load_slices = [&](int it) {
+  // ---- fast gather (every launch except the upsampling convolutions).  Measured with s_memtime stamps
+  // (tools/igemm_probe.hip) on the ResBlock convolutions: of 7400 cycles per 32-deep slice the generic gather below spent
+  // 1225 issuing its 9 loads (~300 VALU instructions of index arithmetic, 64-bit addresses and one divergent branch per
+  // masked load) -- 3000 when the co-resident wave was in its MFMA block, because non-MFMA instructions compete for the
+  // SIMD's issue slots.  Here everything that does not change along K is computed once: per row a 32-bit byte offset
+  // of (tap 0, channel acol) in each source, per B item its offset in the first slice; per slice only scalars change
+  // (tap, channel chunk -> one SGPR byte offset), so a load costs one add and the tap-mask select.  Loads are raw buffer
+  // loads: a masked tap / ragged column gets offset 0xFFFFFFFF, which is out of range and returns zeros -- no branch.
+  const long long samples_ = ((long long)p.M + p.rows_per_sample - 1) / p.rows_per_sample;
+  const long long a_rows_ = conv ? samples_ * p.in_h * p.in_w : (long long)p.M;
+  const long long w_bytes_ = (BT ? (long long)p.N : (long long)p.K) * p.ldb * 4;
+  constexpr bool fastg = FG;       // the host picks the instantiation (igemm_fast_gather_ok): upsample == 0, sources < 4 GB
+  unsigned aoff0[AROWS], aoff1[AROWS], boff[BROWS];
+  __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a0), 0, (int)(unsigned)(a_rows_ * p.c0 * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a1 ? a1 : a0), 0, (int)(unsigned)(a_rows_ * p.c1 * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, (int)(unsigned)w_bytes_, 0x00020000);
+  if constexpr (FG) {
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      // conv: pixel of tap (0,0) (may lie outside the image for border rows: only masked taps use it); rows: the row
+      const long long pix = conv ? ((long long)r_n[i] * p.in_h + r_y[i]) * p.in_w + r_x[i] : (long long)r_y[i];
+      aoff0[i] = (unsigned)((pix * p.c0 + acol) * 4);       // mod 2^32: offset + per-slice scalar is exact for valid taps
+      aoff1[i] = (unsigned)((pix * p.c1 + acol) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+      if (BT) {
+        const int n = n0 + arow + 32 * i;
+        boff[i] = n < p.N ? (unsigned)(((long long)n * p.ldb + acol) * 4) : 0xFFFFFFFFu;
+      } else {
+        const int idx = tid + 256 * i;
+        const int kk = idx / (BN / 4), n = n0 + (idx - kk * (BN / 4)) * 4;
+        boff[i] = n < p.N ? (unsigned)(((long long)kk * p.ldb + n) * 4) : 0xFFFFFFFFu;
+      }
+    }
+  }
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  auto bload = [&](__amdgpu_buffer_rsrc_t rs, unsigned off) -> float4 {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  };
+  auto load_slices_fast = [&](int it) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int kc = it * NS + j;
+      const bool kvalid = kc < nkc;
+      int tap = 0, cc = kc;
+      if (conv) { cc = kc / 9; tap = kc - cc * 9; }
+      const bool second = cc * 32 >= p.c0;                   // c0 % 32 == 0: a 32-channel chunk lies in one source
+      const int cs = second ? p.c1 : p.c0;
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const unsigned sa = (unsigned)(((conv ? (dy * p.in_w + dx) * cs : 0) + cc * 32 - (second ? p.c0 : 0)) * 4);
+      const unsigned sb = (unsigned)((BT ? (long long)kc * 32 : (long long)kc * 32 * p.ldb) * 4);
+      const unsigned tbit = 1u << tap;
+      // all offsets first, then the loads back to back: when the compiler interleaves them it re-uses the destination
+      // registers of the previous slice's loads as temporaries and puts a conservative s_waitcnt vmcnt(1) -- a full
+      // memory round trip -- in the middle of the issue sequence
+      unsigned oa[AROWS], ob[BROWS];
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i)
+        oa[i] = (kvalid && (r_mask[i] & tbit)) ? (second ? aoff1[i] : aoff0[i]) + sa : 0xFFFFFFFFu;
+#pragma unroll
+      for (int i = 0; i < BROWS; ++i) ob[i] = (kvalid && boff[i] != 0xFFFFFFFFu) ? boff[i] + sb : 0xFFFFFFFFu;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) areg[j][i] = second ? bload(rs_a1, oa[i]) : bload(rs_a0, oa[i]);
+#pragma unroll
+      for (int i = 0; i < BROWS; ++i) breg[j][i] = bload(rs_w, ob[i]);
+    }
+  };
+
+  // generic gather: nearest-x2 upsampling folded into the index math (Upsample convolutions), zero-inserted x2 (data
+  // gradient of a stride-2 convolution), tensors beyond 4 GB
+  auto load_slices_generic = [&](int it) {
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
       const int kc = it * NS + j;
@@ -310,9 +390,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       // covered by TM*TN matrix instructions instead of being waited for in front of every pair of them
       __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+      // ... and ONE of the next slice's global loads behind each of the first k-steps: issued together in front of the
+      // MFMA block, the 4 waves of a workgroup queue 36 KiB on the CU's 64 B/clk vector-memory path at the same moment
+      // (~800 cycles per slice per wave in which no MFMA issues, measured with tools/igemm_probe.hip)
+      if (s < NS * (AROWS + BROWS)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
   };
 
+  auto load_slices = [&](int it) {
+    if constexpr (FG) load_slices_fast(it);
+    else load_slices_generic(it);
+  };
   if (it_begin < it_end) load_slices(it_begin);
   if (DB) {
     // two LDS buffers: slice i+1 is written while nobody reads its buffer -> one barrier per slice.
@@ -333,13 +421,34 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       cur ^= 1;
     }
   } else {
-    for (int it = it_begin; it < it_end; ++it) {
-      __syncthreads();                 // previous iteration's MFMA reads are done
-      store_slices(it, 0);
-      __syncthreads();
-      if (it + 1 < it_end) load_slices(it + 1);   // in flight while the matrix cores work
-      compute(0);
-    }
+    // one copy of the loop per gather form, so that the loads and the MFMA block are ONE basic block (scheduling region)
+    auto run_loop = [&](auto&& loader) {
+#ifdef LDMK_IG_STAMPS
+      unsigned long long ig_acc[6] = {0, 0, 0, 0, 0, 0}, ig_last = __builtin_amdgcn_s_memtime();
+      const unsigned long long ig_t0 = ig_last;
+#endif
+      for (int it = it_begin; it < it_end; ++it) {
+        __syncthreads();                 // previous iteration's MFMA reads are done
+        IG_T(0);
+        store_slices(it, 0);
+        IG_T(1);
+        __syncthreads();
+        IG_T(2);
+        loader(min(it + 1, it_end - 1));   // in flight while the matrix cores work; unconditional (the last slice re-loads
+        IG_T(3);                           // itself) so that the loads share the MFMA block's scheduling region
+        compute(0);
+        IG_T(4);
+      }
+#ifdef LDMK_IG_STAMPS
+      if (lane == 0) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(ws) + ((long long)blockIdx.x * 4 + wave) * 8;
+        for (int q = 0; q < 5; ++q) d[q] = ig_acc[q];
+        d[5] = ig_t0; d[6] = __builtin_amdgcn_s_memtime(); d[7] = it_end - it_begin;
+      }
+#endif
+    };
+    if constexpr (FG) run_loop(load_slices_fast);
+    else run_loop(load_slices_generic);
   }
 
   // ---- in-workgroup split-K reduction (fixed order -> bitwise reproducible)
@@ -462,6 +571,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
     }
     return;
   }
+  // element offsets are 32-bit (the host checks M * ldc < 2^31): one add per address; the per-sample vector is looked up
+  // once per 32-row tile when a tile cannot straddle two samples (rows_per_sample % 32 == 0: every UNet / VQGAN level)
+  // instead of one integer division per output element
+  const bool tile_in_sample = p.rows_per_sample % 32 == 0;
+  int smp[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) smp[i] = p.batch_vec ? min(rowbase + i * 32, p.M - 1) / p.rows_per_sample : 0;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = colbase + j * 32 + l31;
@@ -470,14 +586,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float vals[16];
+      const int r0 = rowbase + i * 32 + 4 * half;
+      const unsigned obase = (unsigned)r0 * (unsigned)p.ldc + (unsigned)col;
+      const float vec = (p.batch_vec && tile_in_sample) ? p.batch_vec[(long long)smp[i] * p.batch_vec_ld + col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int dr = (r & 3) + 8 * (r >> 2);
         float v = 0.f;
-        if (row < p.M) {
+        if (r0 + dr < p.M) {
           v = acc[i][j][r] * alpha + bv;
-          if (p.batch_vec) v += p.batch_vec[(long long)(row / p.rows_per_sample) * p.batch_vec_ld + col];
-          const long long o = (long long)row * p.ldc + col;
+          if (p.batch_vec) v += tile_in_sample ? vec : p.batch_vec[(long long)((r0 + dr) / p.rows_per_sample) * p.batch_vec_ld + col];
+          const unsigned o = obase + (unsigned)(dr * p.ldc);
           if (resp) v += resp[o];
           outp[o] = v;
         }
@@ -618,30 +737,48 @@ static size_t cfg_lds_bytes() {
   return stage > red ? stage : red;
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false, bool FG = true>
 static bool& cfg_attr_done() {
   static bool done = false;
   return done;
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false, bool FG = true>
 static void cfg_set_attr() {
-  bool& done = cfg_attr_done<TM, TN, WM, WN, WK, KS, DB, BT, BF>();
+  bool& done = cfg_attr_done<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG>();
   if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg_lds_bytes<TM, TN, WM, WN, WK, KS, DB, BT, BF>());
     done = true;
   }
 }
 
+// the fast gather's preconditions (32-bit byte offsets into each source, no upsampling index math)
+static bool igemm_fast_gather_ok(const ldmk_igemm_args& a) {
+  const long long samples = ((long long)a.M + a.rows_per_sample - 1) / a.rows_per_sample;
+  const long long rows = a.a_mode == LDMK_A_CONV3X3 ? samples * a.in_h * a.in_w : (long long)a.M;
+  const long long wb = (a.b_trans ? (long long)a.N : (long long)a.K) * a.ldb * 4;
+  return a.upsample == 0 && rows * a.c0 * 4 < (1LL << 32) && rows * a.c1 * 4 < (1LL << 32) && wb < (1LL << 32) &&
+         a.batch <= 1;
+}
+
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF, bool FG>
+static int launch_cfg_g(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st);
+
 template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false>
 static int launch_cfg(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
+  return igemm_fast_gather_ok(a) ? launch_cfg_g<TM, TN, WM, WN, WK, KS, DB, BT, BF, true>(a, splitk, ws, st)
+                                 : launch_cfg_g<TM, TN, WM, WN, WK, KS, DB, BT, BF, false>(a, splitk, ws, st);
+}
+
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF, bool FG>
+static int launch_cfg_g(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   size_t lds = cfg_lds_bytes<TM, TN, WM, WN, WK, KS, DB, BT, BF>();
   int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles, splitk, a.batch > 1 ? a.batch : 1);
-  auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF>;
-  cfg_set_attr<TM, TN, WM, WN, WK, KS, DB, BT, BF>();
+  auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG>;
+  cfg_set_attr<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG>();
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, splitk, ws);
   if (splitk > 1 && a.splitk_counters) {
     // the last-arriving workgroup of each tile combined the slabs and ran the epilogue inside the launch
@@ -718,18 +855,20 @@ static int dispatch(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hi
   }
 }
 
-template <bool BT>
+template <bool BT, bool FG>
 static void set_all_attrs() {
-  cfg_set_attr<2, 2, 2, 2, 1, 1, false, BT>();
-  cfg_set_attr<1, 2, 2, 2, 1, 2, false, BT>();
-  cfg_set_attr<2, 2, 1, 1, 4, 1, false, BT>();
-  cfg_set_attr<1, 1, 2, 2, 1, 2, false, BT>();
-  cfg_set_attr<1, 5, 4, 1, 1, 1, false, BT>();
-  cfg_set_attr<1, 5, 2, 1, 2, 1, false, BT>();
+  cfg_set_attr<2, 2, 2, 2, 1, 1, false, BT, false, FG>();
+  cfg_set_attr<1, 2, 2, 2, 1, 2, false, BT, false, FG>();
+  cfg_set_attr<2, 2, 1, 1, 4, 1, false, BT, false, FG>();
+  cfg_set_attr<1, 1, 2, 2, 1, 2, false, BT, false, FG>();
+  cfg_set_attr<1, 5, 4, 1, 1, 1, false, BT, false, FG>();
+  cfg_set_attr<1, 5, 2, 1, 2, 1, false, BT, false, FG>();
 }
 void igemm_init_attributes() {
-  set_all_attrs<false>();
-  set_all_attrs<true>();
+  set_all_attrs<false, true>();
+  set_all_attrs<true, true>();
+  set_all_attrs<false, false>();
+  set_all_attrs<true, false>();
 }
 
 // the wave-autonomous row GEMM (rgemm.hip): tile_cfg kNumCfg+1 .. kNumCfg+6
@@ -781,6 +920,7 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   LDMK_REQUIRE(a.K == taps * (a.c0 + a.c1), "ldmk_igemm: K=%d != taps*(c0+c1)=%d", a.K, taps * (a.c0 + a.c1));
   LDMK_REQUIRE(a.N % 4 == 0 && a.ldb % 4 == 0, "ldmk_igemm: N and ldb must be multiples of 4");
   LDMK_REQUIRE(a.rows_per_sample > 0, "ldmk_igemm: rows_per_sample");
+  LDMK_REQUIRE((long long)a.M * a.ldc < (1LL << 31) && a.ldc > 0, "ldmk_igemm: output exceeds 2^31 elements per batch item (32-bit epilogue offsets)");
   const long long samples = ((long long)a.M + a.rows_per_sample - 1) / a.rows_per_sample;
   if (a.a_mode == LDMK_A_CONV3X3) {
     LDMK_REQUIRE(a.in_h > 0 && a.in_w > 0 && a.out_h > 0 && a.out_w > 0 && a.stride >= 1, "ldmk_igemm: conv geometry");
