@@ -24,8 +24,10 @@
 
 // Diagnostic build only (tools/igemm_probe.hip defines LDMK_IG_STAMPS): per-wave cycle totals of the main loop's phases
 // (barrier 1, LDS store, barrier 2, global-load issue, MFMA block) go to args.splitk_ws (split-K off in the probe) as [wave][8] 64-bit ticks.
-#ifdef LDMK_IG_STAMPS
+#if defined(LDMK_IG_STAMPS) && LDMK_IG_STAMPS == 1
 #define IG_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ig_acc[i] += t_ - ig_last; ig_last = t_; } while (0)
+#elif defined(LDMK_IG_STAMPS)      /* 2: only the loop's begin / end stamps (the schedule stays the shipped one) */
+#define IG_T(i) do { (void)ig_acc; (void)ig_last; } while (0)
 #else
 #define IG_T(i) do { } while (0)
 #endif

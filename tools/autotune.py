@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ROWS_RETUNE = False
+FORCE = False
 CFG_WK = {1: 1, 2: 2, 3: 4, 4: 2, 5: 1, 6: 2}          # K slices of 32 staged per iteration
 EVEN_TN = {1, 2, 3}
 SKS = [1, 2, 3, 4, 6, 8, 12, 16]
@@ -105,6 +106,8 @@ def tune_program(pg, table):
             continue
         key = plan_key(a, a.M)
         rows_retune = ROWS_RETUNE and a.w_frag and a.a_mode == 0 and not a.b_trans
+        if FORCE and key in table and key not in seen:
+            del table[key]                      # --force: forget the recorded plan, sweep everything again
         if key in seen or a.batch > 1 or (key in table and not rows_retune):
             continue
         saved = (a.tile_cfg, a.splitk, a.splitk_ws, a.splitk_ws_elems, a.out, a.stats_out, a.residual)
@@ -156,8 +159,10 @@ if __name__ == "__main__":
     ap.add_argument("--fresh", action="store_true")
     ap.add_argument("--rows", action="store_true", help="re-tune rows-mode shapes already in the table against the "
                     "row-GEMM wave tiles (tile_cfg 7..12)")
+    ap.add_argument("--force", action="store_true", help="re-sweep shapes that are already in the table (after a kernel change)")
     a = ap.parse_args()
-    ROWS_RETUNE = a.rows
+    ROWS_RETUNE = a.rows or a.force
+    FORCE = a.force
     table = {}
     if os.path.exists(a.out) and not a.fresh:
         table = json.load(open(a.out))

@@ -1,6 +1,8 @@
 // Diagnostic: where a workgroup of the LDS-tiled conv kernel spends its cycles (s_memtime stamps, IG_T in csrc/igemm.hip).
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/igemm_probe.hip -o tools/bin/igemm_probe ; igemm_probe n cin cout hw
+#ifndef LDMK_IG_STAMPS
 #define LDMK_IG_STAMPS 1
+#endif
 #include "../dsml_thesis_amd/csrc/igemm.hip"
 #include <algorithm>
 #include <vector>
