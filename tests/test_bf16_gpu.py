@@ -10,6 +10,13 @@ from test_ops_gpu import close, nchw, nhwc, ops  # noqa: F401  (the `ops` fixtur
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _autograd_on():
+    """Reference sides use autograd; other test modules switch it off process-wide."""
+    with torch.enable_grad():
+        yield
+
 # bf16 matrix-core compute (BASELINE configs[4]).  Tolerance, stated: both operands of every product are rounded to bf16
 # (8 significand bits, relative rounding error <= 2^-9 each), products and sums are fp32, so an output element differs
 # from the fp32 result by at most ~2^-8 * sum|a_k b_k|; against the typical |sum a_k b_k| ~ sqrt(K) * |a||b| of these
