@@ -4,6 +4,14 @@
 //   ldmk_softmax_rows: row softmax for the VQGAN single-head AttnBlock (d = 512).
 #include "ldmk_common.h"
 
+// Diagnostic build only (tools/attn_probe.hip defines LDMK_AT_STAMPS): per-wave cycle totals of the key-tile loop's phases
+// go to `lse` (unused by the probe) as [wave][8] 64-bit ticks.
+#ifdef LDMK_AT_STAMPS
+#define AT_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); at_acc[i] += t_ - at_last; at_last = t_; } while (0)
+#else
+#define AT_T(i) do { } while (0)
+#endif
+
 namespace ldmk {
 
 // ---------------------------------------------------------------------------------------------
@@ -57,6 +65,9 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
   // staging map: 64 keys x 32 d = 512 float4 for K and for V; thread t -> key t/8 (+32), d4 = (t%8)*4
   const int skey = tid >> 3, sd = (tid & 7) * 4;
   const int ntiles = (tokens + AT_KT - 1) / AT_KT;
+#ifdef LDMK_AT_STAMPS
+  unsigned long long at_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, at_last = __builtin_amdgcn_s_memtime();
+#endif
   for (int kt = 0; kt < ntiles; ++kt) {
     float4 kr[2], vr[2];
 #pragma unroll
@@ -71,14 +82,18 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
         vr[i] = kr[i];
       }
     }
+    AT_T(0);
     __syncthreads();
+    AT_T(1);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float* kd = Ks + (skey + 32 * i) * AT_KSTR + sd;
       kd[0] = kr[i].x; kd[1] = kr[i].y; kd[2] = kr[i].z; kd[3] = kr[i].w;
       *reinterpret_cast<float4*>(Vs + (skey + 32 * i) * AT_D + sd) = vr[i];
     }
+    AT_T(2);
     __syncthreads();
+    AT_T(3);
     if (!wave_active) continue;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -107,6 +122,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
         __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
+      AT_T(4);
       // s_acc[t][r] = S[query 32t + l31][key = key0 + (r&3) + 8*(r>>2) + 4*half]
       const bool ragged = key0 + 32 > tokens;            // last sub-tile: keys past the end get -inf (V rows are zero)
 #pragma unroll
@@ -137,14 +153,24 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] *= corr;
       }
+      AT_T(5);
       // O^T[d][query] += sum_key V[key][d] * P[query][key]
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r], s_acc[t][r], o[t], 0, 0, 0);
       }
+      AT_T(6);
     }
   }
+#ifdef LDMK_AT_STAMPS
+  if (lane == 0) {
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(lse) + ((((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    for (int q = 0; q < 7; ++q) d[q] = at_acc[q];
+    d[7] = ntiles;
+  }
+  lse = nullptr;
+#endif
   if (!wave_active) return;
   if (lse != nullptr && half == 0) {     // training: log-sum-exp of the scaled scores per query row, [n][heads][tokens]
 #pragma unroll
