@@ -24,17 +24,27 @@ namespace ldmk {
 //         k-pair layout of the 32x32x2 B operand) -> no data movement between the two products.
 // The score matrix never exists in memory (the reference materialises 120 MB/sample at 32x32).
 constexpr int AT_D = 32;
-constexpr int AT_KT = 64;            // keys per staged tile
+constexpr int AT_KT = 128;           // keys per staged tile (round 1: 64 -- two workgroup barriers per 64 keys)
 constexpr int AT_KSTR = AT_D + 1;    // K rows padded: lanes read 32 different keys at fixed d
+constexpr int AT_SUB = AT_KT / 32;   // 32-key sub-tiles per staged tile
+constexpr int AT_LD4 = AT_KT * AT_D / 4 / 256;   // float4 per thread per operand per staged tile
 
 // QT = query tiles (of 32) per wave.  QT = 2 lets one K / V operand read from LDS feed two MFMAs and halves the
 // barriers per MFMA (used when there are enough 256-query workgroups to fill the chip).
+//
+// Round 2 (measured with s_memtime stamps, tools/attn_probe.hip, 4 waves per SIMD): of ~19.9k cycles a wave spent per 64 keys,
+// 4.1k were its MFMAs, 1.5k the issue of FOUR global loads (64-bit address arithmetic and bounds branches, starved of
+// issue slots by the other waves' MFMA streams), 1.5k the two barriers, 2.2k the softmax.  Changes: 128-key tiles (half
+// the barriers per key), K/V fetched by raw buffer loads from one per-thread byte offset that advances by a scalar per
+// tile (keys past the end are out of range and read as zeros: no branch), exponentials as bare v_exp_f32 (the scale
+// carries log2 e), the running-output rescale skipped for tiles in which no lane's maximum moved, and the output transpose
+// buffer aliased onto the K/V staging (33 KB of LDS per workgroup as before: 4 workgroups per CU).
 template <int QT>
 __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                         int tokens, int heads, float scale, float* __restrict__ lse) {
-  __shared__ float Ks[AT_KT * AT_KSTR];
-  __shared__ float Vs[AT_KT * AT_D];
-  __shared__ float Os[4][32 * 33];
+  __shared__ __attribute__((aligned(16))) float smem_at[AT_KT * AT_KSTR + AT_KT * AT_D];
+  float* Ks = smem_at;                          // [AT_KT][33]
+  float* Vs = smem_at + AT_KT * AT_KSTR;        // [AT_KT][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -44,8 +54,10 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
   const int q0 = blockIdx.x * (128 * QT) + wave * (32 * QT);
   const float* base = qkv + (long long)b * tokens * ld;
   const bool wave_active = q0 < tokens;
+  constexpr float LOG2E = 1.4426950408889634f;
 
-  // Q fragments: B operand of S^T = K Q^T: lane holds Q[query = l31][d = 2s + half], pre-scaled
+  // Q fragments: B operand of S^T = K Q^T: lane holds Q[query = l31][d = 2s + half], pre-scaled by scale * log2(e):
+  // the scores live in the log2 domain, so every exponential below is a bare v_exp_f32 (2^x)
   float qf[QT][16];
   f32x16 o[QT];
   float m_run[QT], l_run[QT];
@@ -53,7 +65,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
   for (int t = 0; t < QT; ++t) {
     const bool q_valid = q0 + 32 * t + l31 < tokens;   // ragged tail: lanes past the last query never store
     const float* qp = base + (long long)(q_valid ? q0 + 32 * t + l31 : 0) * ld + h * AT_D;
-    const float qs = q_valid ? scale : 0.f;      // the row pointer is clamped: load unconditionally (16 independent loads)
+    const float qs = q_valid ? scale * LOG2E : 0.f;  // the row pointer is clamped: load unconditionally (16 independent loads)
 #pragma unroll
     for (int s = 0; s < 16; ++s) qf[t][s] = qp[2 * s + half] * qs;
 #pragma unroll
@@ -62,31 +74,53 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
     l_run[t] = 0.f;
   }
 
-  // staging map: 64 keys x 32 d = 512 float4 for K and for V; thread t -> key t/8 (+32), d4 = (t%8)*4
+  // staging map: AT_KT keys x 32 d = AT_KT * 8 float4 for K and for V; thread t -> key t/8 (+32 i), d4 = (t%8)*4.
+  // One descriptor over this sample's qkv rows; byte offset of (key skey, this head's K slice); V sits C floats further.
   const int skey = tid >> 3, sd = (tid & 7) * 4;
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  const unsigned kv_bytes = (unsigned)min((long long)tokens * ld * 4, 0xFFFFFFFFLL);
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)kv_bytes, 0x00020000);
+  const unsigned row_bytes = (unsigned)ld * 4u;
+  unsigned koff = (unsigned)skey * row_bytes + (unsigned)(C + h * AT_D + sd) * 4u;      // advances by AT_KT rows per tile
+  const bool small = (long long)tokens * ld * 4 < (1LL << 32);                            // else: plain loads below
+  auto ldg = [&](unsigned off) -> float4 {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  };
   const int ntiles = (tokens + AT_KT - 1) / AT_KT;
 #ifdef LDMK_AT_STAMPS
   unsigned long long at_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, at_last = __builtin_amdgcn_s_memtime();
 #endif
   for (int kt = 0; kt < ntiles; ++kt) {
-    float4 kr[2], vr[2];
+    float4 kr[AT_LD4], vr[AT_LD4];
+    if (small) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int key = kt * AT_KT + skey + 32 * i;
-      if (key < tokens) {
-        const float* kp = base + (long long)key * ld + C + h * AT_D + sd;
-        kr[i] = *reinterpret_cast<const float4*>(kp);
-        vr[i] = *reinterpret_cast<const float4*>(kp + C);
-      } else {
+      for (int i = 0; i < AT_LD4; ++i) {
+        // rows past the last key are past the descriptor's range only for the LAST sample; for the others they are the
+        // next sample's rows: mask by key index (one compare per load, no branch: out-of-range offset reads zeros)
+        const unsigned off = (kt * AT_KT + skey + 32 * i < tokens) ? koff + (unsigned)(32 * i) * row_bytes : 0xFFFFFFFFu;
+        kr[i] = ldg(off);
+        vr[i] = ldg(off == 0xFFFFFFFFu ? off : off + (unsigned)C * 4u);
+      }
+      koff += (unsigned)AT_KT * row_bytes;
+    } else {
+#pragma unroll
+      for (int i = 0; i < AT_LD4; ++i) {
+        const int key = kt * AT_KT + skey + 32 * i;
         kr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         vr[i] = kr[i];
+        if (key < tokens) {
+          const float* kp = base + (long long)key * ld + C + h * AT_D + sd;
+          kr[i] = *reinterpret_cast<const float4*>(kp);
+          vr[i] = *reinterpret_cast<const float4*>(kp + C);
+        }
       }
     }
     AT_T(0);
     __syncthreads();
     AT_T(1);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < AT_LD4; ++i) {
       float* kd = Ks + (skey + 32 * i) * AT_KSTR + sd;
       kd[0] = kr[i].x; kd[1] = kr[i].y; kd[2] = kr[i].z; kd[3] = kr[i].w;
       *reinterpret_cast<float4*>(Vs + (skey + 32 * i) * AT_D + sd) = vr[i];
@@ -96,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
     AT_T(3);
     if (!wave_active) continue;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < AT_SUB; ++sub) {
       const int key0 = kt * AT_KT + sub * 32;
       if (key0 >= tokens) break;
       f32x16 s_acc[QT];
@@ -123,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
       AT_T(4);
-      // s_acc[t][r] = S[query 32t + l31][key = key0 + (r&3) + 8*(r>>2) + 4*half]
+      // s_acc[t][r] = log2(e) * scale * S[query 32t + l31][key = key0 + (r&3) + 8*(r>>2) + 4*half]
       const bool ragged = key0 + 32 > tokens;            // last sub-tile: keys past the end get -inf (V rows are zero)
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
@@ -135,23 +169,28 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
           for (int r = 0; r < 16; ++r)
             if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s_acc[t][r] = -INFINITY;
         }
-        float mx = s_acc[t][0];
+        float mx = fmaxf(s_acc[t][0], s_acc[t][1]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_acc[t][r]);
+        for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s_acc[t][r], s_acc[t][r + 1]));     // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run[t], mx);
-        const float corr = __expf(m_run[t] - m_new);     // 0 on the first tile (m_run = -inf)
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          s_acc[t][r] = __expf(s_acc[t][r] - m_new);
+          s_acc[t][r] = __builtin_amdgcn_exp2f(s_acc[t][r] - m_new);
           psum += s_acc[t][r];
         }
         psum += __shfl_xor(psum, 32, 64);
-        l_run[t] = l_run[t] * corr + psum;
-        m_run[t] = m_new;
+        // rescale the running sum / output only when some lane's maximum moved (wave-uniform branch; in steady state the
+        // maximum is stable for most tiles and 17 multiplies + one exponential per sub-tile go away)
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run[t]) != 0) {
+          const float corr = __builtin_amdgcn_exp2f(m_run[t] - m_new);     // 0 on the first tile (m_run = -inf)
+          l_run[t] *= corr;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] *= corr;
+          for (int r = 0; r < 16; ++r) o[t][r] *= corr;
+          m_run[t] = m_new;
+        }
+        l_run[t] += psum;
       }
       AT_T(5);
       // O^T[d][query] += sum_key V[key][d] * P[query][key]
@@ -171,15 +210,16 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
   }
   lse = nullptr;
 #endif
+  __syncthreads();                       // every wave is done with the K/V staging: its memory becomes the transpose buffers
   if (!wave_active) return;
-  if (lse != nullptr && half == 0) {     // training: log-sum-exp of the scaled scores per query row, [n][heads][tokens]
+  if (lse != nullptr && half == 0) {     // training: natural log-sum-exp of the scaled scores per query row, [n][heads][tokens]
 #pragma unroll
     for (int t = 0; t < QT; ++t)
       if (q0 + 32 * t + l31 < tokens)
-        lse[((long long)b * heads + h) * tokens + q0 + 32 * t + l31] = m_run[t] + logf(l_run[t]);
+        lse[((long long)b * heads + h) * tokens + q0 + 32 * t + l31] = (m_run[t] + log2f(l_run[t])) * 0.6931471805599453f;
   }
   // o[t][r] = O[query][d = (r&3) + 8*(r>>2) + 4*half]; transpose through LDS for 128-B row stores
-  float* ow = Os[wave];
+  float* ow = smem_at + wave * (32 * 33);
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const float inv = 1.0f / l_run[t];
