@@ -430,6 +430,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       const unsigned long long ig_t0 = ig_last;
 #endif
       for (int it = it_begin; it < it_end; ++it) {
+        // (s_setprio(2) around the staging phase, so that its instructions win issue slots over the co-resident wave's
+        // MFMA stream: measured neutral to -2 %, not kept)
         __syncthreads();                 // previous iteration's MFMA reads are done
         IG_T(0);
         store_slices(it, 0);
