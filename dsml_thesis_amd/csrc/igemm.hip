@@ -149,16 +149,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   const long long samples_ = ((long long)p.M + p.rows_per_sample - 1) / p.rows_per_sample;
   const long long a_rows_ = conv ? samples_ * p.in_h * p.in_w : (long long)p.M;
   const long long w_bytes_ = (BT ? (long long)p.N : (long long)p.K) * p.ldb * 4;
-  constexpr bool fastg = FG;       // the host picks the instantiation (igemm_fast_gather_ok): upsample == 0, sources < 4 GB
+  constexpr bool fastg = FG;       // the host picks the instantiation (igemm_fast_gather_ok): no zero-insertion, sources < 4 GB
   unsigned aoff0[AROWS], aoff1[AROWS], boff[BROWS];
   __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a0), 0, (int)(unsigned)(a_rows_ * p.c0 * 4), 0x00020000);
   __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a1 ? a1 : a0), 0, (int)(unsigned)(a_rows_ * p.c1 * 4), 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, (int)(unsigned)w_bytes_, 0x00020000);
+  // nearest-x2 upsampling folded into the gather (upsample == 1, single source): tap (dy, dx) of output pixel (oy, ox)
+  // reads input pixel ((oy - 1 + dy) >> 1, (ox - 1 + dx) >> 1).  Relative to the pixel of tap (0, 0) that is a row step of
+  // {0, e, 1} for dy = {0, 1, 2} with e = 1 for even oy and 0 for odd oy (same in x): the parity-dependent middle steps
+  // are two more per-row byte offsets (aoff1 doubles as the x one: the second source does not exist in this mode).
+  unsigned upy[AROWS];
   if constexpr (FG) {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       // conv: pixel of tap (0,0) (may lie outside the image for border rows: only masked taps use it); rows: the row
-      const long long pix = conv ? ((long long)r_n[i] * p.in_h + r_y[i]) * p.in_w + r_x[i] : (long long)r_y[i];
+      long long pix = conv ? ((long long)r_n[i] * p.in_h + r_y[i]) * p.in_w + r_x[i] : (long long)r_y[i];
+      if (p.upsample == 1) {      // r_y / r_x are coordinates in the upsampled grid (oy - 1, ox - 1): floor-halve them
+        const int by = r_y[i] >> 1, bx = r_x[i] >> 1;       // arithmetic shift: -1 -> -1 (masked taps only)
+        pix = ((long long)r_n[i] * p.in_h + by) * p.in_w + bx;
+        upy[i] = (r_y[i] & 1) ? (unsigned)(p.in_w * p.c0 * 4) : 0u;     // oy even <=> r_y odd: the middle tap steps one row
+        aoff1[i] = (r_x[i] & 1) ? (unsigned)(p.c0 * 4) : 0u;
+        aoff0[i] = (unsigned)((pix * p.c0 + acol) * 4);
+        continue;
+      }
+      upy[i] = 0u;
       aoff0[i] = (unsigned)((pix * p.c0 + acol) * 4);       // mod 2^32: offset + per-slice scalar is exact for valid taps
       aoff1[i] = (unsigned)((pix * p.c1 + acol) * 4);
     }
@@ -189,7 +203,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       const bool second = cc * 32 >= p.c0;                   // c0 % 32 == 0: a 32-channel chunk lies in one source
       const int cs = second ? p.c1 : p.c0;
       const int dy = tap / 3, dx = tap - dy * 3;
-      const unsigned sa = (unsigned)(((conv ? (dy * p.in_w + dx) * cs : 0) + cc * 32 - (second ? p.c0 : 0)) * 4);
+      const bool ups = p.upsample == 1;
+      // upsampling: taps 0 / 2 step 0 / 1 input pixels, tap 1 steps by the row's parity (upy / aoff1, added below)
+      const int sy = ups ? (dy == 2) : dy, sx = ups ? (dx == 2) : dx;
+      const unsigned sa = (unsigned)(((conv ? (sy * p.in_w + sx) * cs : 0) + cc * 32 - (second ? p.c0 : 0)) * 4);
       const unsigned sb = (unsigned)((BT ? (long long)kc * 32 : (long long)kc * 32 * p.ldb) * 4);
       const unsigned tbit = 1u << tap;
       // all offsets first, then the loads back to back: when the compiler interleaves them it re-uses the destination
@@ -197,8 +214,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       // memory round trip -- in the middle of the issue sequence
       unsigned oa[AROWS], ob[BROWS];
 #pragma unroll
-      for (int i = 0; i < AROWS; ++i)
-        oa[i] = (kvalid && (r_mask[i] & tbit)) ? (second ? aoff1[i] : aoff0[i]) + sa : 0xFFFFFFFFu;
+      for (int i = 0; i < AROWS; ++i) {
+        unsigned o_ = (second ? aoff1[i] : aoff0[i]) + sa;
+        if (ups) o_ = aoff0[i] + sa + (dy == 1 ? upy[i] : 0u) + (dx == 1 ? aoff1[i] : 0u);
+        oa[i] = (kvalid && (r_mask[i] & tbit)) ? o_ : 0xFFFFFFFFu;
+      }
 #pragma unroll
       for (int i = 0; i < BROWS; ++i) ob[i] = (kvalid && boff[i] != 0xFFFFFFFFu) ? boff[i] + sb : 0xFFFFFFFFu;
       __builtin_amdgcn_sched_barrier(0);
@@ -762,8 +782,8 @@ static bool igemm_fast_gather_ok(const ldmk_igemm_args& a) {
   const long long samples = ((long long)a.M + a.rows_per_sample - 1) / a.rows_per_sample;
   const long long rows = a.a_mode == LDMK_A_CONV3X3 ? samples * a.in_h * a.in_w : (long long)a.M;
   const long long wb = (a.b_trans ? (long long)a.N : (long long)a.K) * a.ldb * 4;
-  return a.upsample == 0 && rows * a.c0 * 4 < (1LL << 32) && rows * a.c1 * 4 < (1LL << 32) && wb < (1LL << 32) &&
-         a.batch <= 1;
+  const bool ups_ok = a.upsample == 0 || (a.upsample == 1 && a.c1 == 0 && a.a_mode == LDMK_A_CONV3X3);
+  return ups_ok && rows * a.c0 * 4 < (1LL << 32) && rows * a.c1 * 4 < (1LL << 32) && wb < (1LL << 32) && a.batch <= 1;
 }
 
 template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF, bool FG>
