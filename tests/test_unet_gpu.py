@@ -24,6 +24,37 @@ def close(a, b, rtol, atol):
     torch.testing.assert_close(a.float().cpu(), torch.as_tensor(np.asarray(b)).float(), rtol=rtol, atol=atol)
 
 
+def test_resblock_golden_through_the_launch_program():
+    """SURVEY row A7 on its own: ResBlock 160 -> 320 at 8x8 with the timestep embedding (openaimodel.py:255-275) against the
+    reference's output (g3 `resblock`), built from the same NetBuilder calls UNetModel._build emits for a ResBlock:
+    GroupNorm+SiLU pass, conv + per-sample emb vector + GroupNorm records from the epilogue, second GroupNorm+SiLU,
+    1x1 skip projection, conv + residual."""
+    from dsml_thesis_amd import ops
+    from dsml_thesis_amd.engine import NetBuilder, Program
+    g = golden("g3_ops.npz")
+    keys = {}
+    W._resblock(keys, "", 160, 320, 640)
+    sd = {k: v.cuda() for k, v in W.synth_state_dict(keys, seed=3).items()}
+    x, emb = rnd(14, 2, 160, 8, 8), rnd(15, 2, 640)
+    n, h, w, hw = 2, 8, 8, 64
+    pg = Program("cuda")
+    nb = NetBuilder(pg, n)
+    x0 = x.permute(0, 2, 3, 1).contiguous().cuda()
+    emb_out = ops.dense_small(emb.cuda(), ops.pack_linear(sd["emb_layers.1.weight"]), sd["emb_layers.1.bias"], silu_in=True)
+    c1, c2 = ops.pack_conv3x3(sd["in_layers.2.weight"]), ops.pack_conv3x3(sd["out_layers.3.weight"])
+    skip_w = ops.pack_linear(sd["skip_connection.weight"])
+    y1 = nb.gn_act(x0, None, hw, sd["in_layers.0.weight"], sd["in_layers.0.bias"], 1e-5)
+    h1 = nb.conv(y1.view(n, h, w, 160), None, c1, sd["in_layers.2.bias"], h, w, batch_vec=emb_out.data_ptr(), bv_ld=320, stats=True)
+    y2 = nb.gn_act(h1, None, hw, sd["out_layers.0.weight"], sd["out_layers.0.bias"], 1e-5).view(n, h, w, 320)
+    skip = nb.lin(x0.view(n * hw, 160), skip_w, sd["skip_connection.bias"], hw)
+    out = nb.conv(y2, None, c2, sd["out_layers.3.bias"], h, w, residual=skip, out=skip.view(n, h, w, 320), stats=True)
+    pg.run()
+    close(out.permute(0, 3, 1, 2), g["resblock"], 1e-4, 1e-4)
+    first = out.clone()
+    pg.run()                                   # the program is replayable: same buffers, same result
+    assert torch.equal(out, first)
+
+
 def test_unet_fr_golden():
     g = golden("g4_unet_fr.npz")
     m, _ = make_unet(W.FR_UNET)

@@ -1,5 +1,6 @@
+"""Boundary convolutions (ldmk_conv3x3_in / ldmk_conv3x3_out) at the UNet and VQGAN shapes: python tools/boundary_conv_bench.py"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dsml_thesis_amd import ops
 from tools.rgemm_bench import timeit
 for (n, cin, cout, h) in [(16, 160, 4, 64), (16, 160, 3, 32), (1, 128, 3, 256), (16, 128, 3, 128)]:

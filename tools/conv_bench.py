@@ -1,5 +1,6 @@
+"""3x3 convolution on the LDS-tiled igemm (128x160 tile) at 1 / 2 / 4 workgroups per CU: python tools/conv_bench.py"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dsml_thesis_amd import ops, lib
 from tools.rgemm_bench import timeit
 for cin, cout, hw in [(160, 160, 64), (320, 160, 64), (320, 320, 32), (640, 640, 16)]:
