@@ -230,7 +230,7 @@ def clip_leg(rank, world, dev, dist, barrier, frames=128, ddim_steps=20, window=
             "checksum": float(out.double().sum())}
 
 
-def train_mode(a, rank, world, dev, dist, backend, barrier, graph):
+def train_mode(a, rank, world, dev, dist, backend, barrier, graph, emit):
     """BASELINE configs[4]: one optimisation step = q_sample + UNet forward + hand-written backward
     (hipGraph-captured) + gradient all-reduce over the ranks + AdamW + EMA, fixed batch per GPU (weak scaling)."""
     from dsml_thesis_amd.train import UNetTrainer
@@ -305,7 +305,7 @@ def train_mode(a, rank, world, dev, dist, backend, barrier, graph):
                         "traffic": None, "kernel": "whole step (igemm + wgrad + attention fwd/bwd), 3x forward GEMM FLOPs"},
            "cpu_baseline": None, "loss": float(loss_buf.item())}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -343,6 +343,15 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         raise SystemExit(subprocess.call(cmd, env=env))
+    # stdout carries exactly ONE line (the JSON): everything else this process or its libraries print there -- RCCL's
+    # version banner at communicator creation, for one -- goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -394,7 +403,7 @@ def main():
 
     graph = not a.no_graph
     if a.train:
-        train_mode(a, rank, world, dev, dist, backend, barrier, graph)
+        train_mode(a, rank, world, dev, dist, backend, barrier, graph, emit)
         return
     run, el = measure(a.latent, a.steps, a.warmup, graph)
     value = world * a.batch * a.steps / el
@@ -461,7 +470,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
