@@ -548,21 +548,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
     }
     __syncthreads();
     if (*flag == 0 || wk != 0) return;
+    // Non-atomic sc1 buffer loads (aux bit 4), so the compiler keeps a whole batch in flight: up to 4 slabs x 16 rows
+    // per 32x32 tile before the first add.  (One relaxed atomic load per element serialised on its own s_waitcnt:
+    // 16 slabs x ~2 us each, which is what made the first version of this path 1.5-2x slower than the reduce launch.)
     const float* slab0 = ws + (long long)bz * splitk * p.M * p.N;
+    const unsigned slab_bytes = (unsigned)((long long)p.M * p.N * 4);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(slab0), 0,
+                                                                         (int)(slab_bytes * (unsigned)splitk), 0x00020000);
+    constexpr int SC1 = 1 << 4;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = min(colbase + j * 32 + l31, p.N - 1);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) {
+        int off[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = min(rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.M - 1);
-          const float* src = slab0 + (long long)row * p.N + col;
-          float sum = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               // global_load ... sc1
-          for (int k = 1; k < splitk; ++k)
-            sum += __hip_atomic_load(src + (long long)k * p.M * p.N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          acc[i][j][r] = sum;
+          off[r] = (row * p.N + col) * 4;
+          acc[i][j][r] = 0.f;
         }
+        for (int k0 = 0; k0 < splitk; k0 += 4) {
+          float t[4][16];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            // slabs past the last one: an offset beyond num_records reads as 0
+            const unsigned so = (k0 + kk < splitk) ? (unsigned)(k0 + kk) * slab_bytes : 0xFFFFFFF0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              t[kk][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off[r], (int)so, SC1));
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)      // fixed order k = 0 .. splitk-1
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += t[kk][r];
+        }
+      }
     }
   } else if (wk != 0) {
     return;
@@ -917,7 +938,7 @@ extern "C" long long ldmk_igemm_workspace_elems(const ldmk_igemm_args* args) {
   LDMK_REQUIRE(args != nullptr, "ldmk_igemm_workspace_elems: null args");
   const ldmk_igemm_args& a = *args;
   LDMK_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "ldmk_igemm_workspace_elems: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
-  LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 16, "ldmk_igemm_workspace_elems: splitk=%d outside [0,16]", a.splitk);
+  LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 64, "ldmk_igemm_workspace_elems: splitk=%d outside [0,64]", a.splitk);
   int cfg = a.tile_cfg, sk = a.splitk;
   if (sk == 0) {
     int c2 = 0;
@@ -965,7 +986,7 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
                  "ldmk_igemm: stats_out needs M%%32==0, rows_per_sample%%32==0, no GEGLU, no batching");
   LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg + kNumRCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]", a.tile_cfg,
                kNumCfg + kNumRCfg);
-  LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 16, "ldmk_igemm: splitk=%d outside [0,16]", a.splitk);
+  LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 64, "ldmk_igemm: splitk=%d outside [0,64]", a.splitk);
   LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.compute == LDMK_COMPUTE_BF16, "ldmk_igemm: compute=%d", a.compute);
   LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.tile_cfg <= kNumCfg, "ldmk_igemm: the row GEMM tiles are fp32 only");
   if (a.alpha == 0.f) a.alpha = 1.f;
@@ -985,6 +1006,8 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
     const long long tiles = (long long)(a.batch > 1 ? a.batch : 1) * ((a.M + 63) / 64) * ((a.N + 63) / 64);   // smallest tile: 64x64
     LDMK_REQUIRE_MEM(tiles <= a.splitk_counters_len, "ldmk_igemm: in-launch split-K combine needs %lld zeroed counters, %d given",
                      tiles, a.splitk_counters_len);
+    LDMK_REQUIRE((long long)sk * a.M * a.N * 4 < (1LL << 31), "ldmk_igemm: in-launch split-K combine addresses the %d slabs of one "
+                 "batch entry with 32-bit offsets (%lld bytes)", sk, (long long)sk * a.M * a.N * 4);
   }
   if (sk > 1) {
     const long long b = a.batch > 1 ? a.batch : 1;

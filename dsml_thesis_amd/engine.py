@@ -155,9 +155,12 @@ class Program:
             args.splitk_ws, args.splitk_ws_elems = ws.data_ptr(), ws.numel()
             # In-launch combine (each tile's last-arriving workgroup sums the slabs) is built and tested, but OFF: split-K is
             # chosen exactly when a GEMM has few output tiles, so the combine runs on those few workgroups (10 of 256 CUs
-            # for the 8x8-level convolutions at batch 1) reading `splitk` slabs with write-through traffic, while the reduce
-            # launch spreads the same bytes over the whole chip.  Measured (A/B in one process): 476 -> 446 sample-steps/s at
-            # 64x64x4 B=16, 1657 -> 1231 at 32x32x3, 249 -> 141 at B=1.  LDMK_SPLITK_IN_LAUNCH=1 turns it on.
+            # for the 8x8-level convolutions at batch 1) reading `splitk` slabs with sc1 traffic, while the reduce launch
+            # spreads the same bytes over the whole chip.  Measured A/B (sample-steps/s, reduce launch -> in-launch):
+            # first version (one atomic load per element) 476 -> 446 at 64x64x4 B=16, 1657 -> 1231 at 32x32x3, 249 -> 141
+            # at B=1; with the loads batched (64 in flight per wave) 1720 -> 1614 at 32x32x3 and 252 -> 249 at B=1.  The
+            # batch-1 step loses ~130 launches this way and is not faster: its time is the chain of dependent memory round
+            # trips inside the launches, not the launch count.  LDMK_SPLITK_IN_LAUNCH=1 turns it on.
             if os.environ.get("LDMK_SPLITK_IN_LAUNCH"):
                 cnt = self.splitk_counters()
                 args.splitk_counters, args.splitk_counters_len = cnt.data_ptr(), cnt.numel()

@@ -89,7 +89,7 @@ typedef struct ldmk_igemm_args {
                                 a row-GEMM wave tile (32 TM x 32 TN: 1x5, 2x5, 1x4, 2x4, 1x2, 1x1).  The K-summation
                                 order depends on (tile_cfg, splitk), so a caller that needs results that are
                                 bitwise independent of the batch size pins both (ldmk_igemm_plan)          */
-  int splitk;                /* 0 = choose; 1 = none; 2..16 = split K over that many workgroups            */
+  int splitk;                /* 0 = choose; 1 = none; 2..64 = split K over that many workgroups            */
   float* splitk_ws;          /* scratch for split-K partial slabs (batch*splitk*M*N floats) or NULL        */
   long long splitk_ws_elems; /* capacity of splitk_ws in floats                                           */
   float* stats_out;          /* optional [M/32][N][3] GroupNorm partial records of the *output* (after the

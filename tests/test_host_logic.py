@@ -112,7 +112,7 @@ def test_tuned_plan_table_is_legal_and_nearest():
         assert [r[0] for r in rows] == sorted(r[0] for r in rows)
         row_tiles = {7: (1, 5), 8: (2, 5), 9: (1, 4), 10: (2, 4), 11: (1, 2), 12: (1, 1)}
         for m, cfg, sk in rows:
-            assert 1 <= cfg <= 12 and sk in (1, 2, 3, 4, 6, 8, 12, 16)
+            assert 1 <= cfg <= 12 and sk in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64)
             if cfg > 6:            # wave-autonomous row GEMM: rows mode only, K never split, whole column tiles
                 tm, tn = row_tiles[cfg]
                 assert mode == 0 and sk == 1 and n % (32 * tn) == 0 and (epi != 1 or tn % 2 == 0) and "bt" not in key

@@ -24,7 +24,7 @@ ROWS_RETUNE = False
 FORCE = False
 CFG_WK = {1: 1, 2: 2, 3: 4, 4: 2, 5: 1, 6: 2}          # K slices of 32 staged per iteration
 EVEN_TN = {1, 2, 3}
-SKS = [1, 2, 3, 4, 6, 8, 12, 16]
+SKS = [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64]
 
 
 def time_call(lib, a, st, reps=5):
@@ -137,7 +137,7 @@ def tune_program(pg, table):
                 continue
             iters = -(-nkc // CFG_WK[cfg])
             for sk in SKS:
-                if sk > 1 and (a.epi == 1 or iters // sk < 2 or sk * a.M * a.N > ws.numel()):
+                if sk > 1 and (a.epi == 1 or iters // sk < 1 or sk * a.M * a.N > ws.numel()):
                     continue
                 a.tile_cfg, a.splitk = cfg, sk
                 a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
