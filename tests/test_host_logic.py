@@ -120,7 +120,7 @@ def test_tuned_plan_table_is_legal_and_nearest():
             if epi == 1:
                 assert cfg in (1, 2, 3) and sk == 1
             if sk > 1:
-                assert (-(-(k // 32) // wk[cfg])) // sk >= 2
+                assert (-(-(k // 32) // wk[cfg])) // sk >= 1      # every slab owns at least one K slice
     a = L.IgemmArgs()
     a.N, a.K, a.a_mode, a.a_tf, a.epi, a.batch = 320, 2880, 1, 0, 0, 1
     assert engine.tuned_plan(a, 65536) == engine.tuned_plan(a, 65536)
