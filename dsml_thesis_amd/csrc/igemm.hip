@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   const int it_begin = ks * it_per;
   const int it_end = min(iters_all, it_begin + it_per);
   const bool conv = p.a_mode == LDMK_A_CONV3X3;
-  const int tf = p.a_tf;
+  const int tf = p.a_tf == LDMK_TF_LAYERNORM_FOLDED ? LDMK_TF_NONE : p.a_tf;   // folded LayerNorm: raw rows here, the
+                                                                               // two per-row scalars in the epilogue
 
   // ---- per-thread A row bookkeeping (rows are fixed for the whole K loop); 32-bit element indices
   const int arow = tid >> 3;            // 0..31
@@ -591,6 +592,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   float* __restrict__ outp = p.out + (long long)bz * p.out_bstride;
   const float* resp = p.residual ? p.residual + (long long)bz * p.out_bstride : nullptr;
   const float alpha = p.alpha;
+  const bool lnf = p.a_tf == LDMK_TF_LAYERNORM_FOLDED;
+  const float2* __restrict__ stats2 = reinterpret_cast<const float2*>(p.row_stats);
   if (p.epi == LDMK_EPI_GEGLU) {
     if constexpr (TN % 2 == 0) {
 #pragma unroll
@@ -600,18 +603,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         if (cv >= p.N) continue;
         const int oc = ((colbase + j * 32) >> 1) + l31;
         const float bv = p.bias ? p.bias[cv] : 0.f, bg = p.bias ? p.bias[cg] : 0.f;
+        const float csv = lnf ? p.ln_colsum[cv] : 0.f, csg = lnf ? p.ln_colsum[cg] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+          float2 st[16];
+          if (lnf) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              st[r] = stats2[min(rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.M - 1)];
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (row < p.M) {
-              const float v = acc[i][j][r] * alpha + bv;
-              const float g = acc[i][j + 1][r] * alpha + bg;
+              float v = acc[i][j][r] * alpha, g = acc[i][j + 1][r] * alpha;
+              if (lnf) {      // same arithmetic as rgemm.hip and igemm_reduce_kernel
+                v = fmaf(-st[r].x, csv, v) * st[r].y;
+                g = fmaf(-st[r].x, csg, g) * st[r].y;
+              }
+              v += bv;
+              g += bg;
               const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));   // exact (erf) GELU
               outp[(long long)row * p.ldc + oc] = v * ge;
             }
           }
+        }
       }
     }
     return;
@@ -628,10 +644,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
     const int col = colbase + j * 32 + l31;
     if (col >= p.N) continue;
     const float bv = p.bias ? p.bias[col] : 0.f;
+    const float cs = lnf ? p.ln_colsum[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float vals[16];
       const int r0 = rowbase + i * 32 + 4 * half;
+      if (lnf) {
+        float2 st[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = stats2[min(r0 + (r & 3) + 8 * (r >> 2), p.M - 1)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(-st[r].x, cs, acc[i][j][r] * alpha) * st[r].y;
+      }
       const unsigned obase = (unsigned)r0 * (unsigned)p.ldc + (unsigned)col;
       const float vec = (p.batch_vec && tile_in_sample) ? p.batch_vec[(long long)smp[i] * p.batch_vec_ld + col] : 0.f;
 #pragma unroll
@@ -639,7 +663,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         const int dr = (r & 3) + 8 * (r >> 2);
         float v = 0.f;
         if (r0 + dr < p.M) {
-          v = acc[i][j][r] * alpha + bv;
+          v = (lnf ? acc[i][j][r] : acc[i][j][r] * alpha) + bv;
           if (p.batch_vec) v += tile_in_sample ? vec : p.batch_vec[(long long)((r0 + dr) / p.rows_per_sample) * p.batch_vec_ld + col];
           const unsigned o = obase + (unsigned)(dr * p.ldc);
           if (resp) v += resp[o];
@@ -687,6 +711,12 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const ldmk_igemm_args
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
     s.x *= p.alpha; s.y *= p.alpha; s.z *= p.alpha; s.w *= p.alpha;
+    if (p.a_tf == LDMK_TF_LAYERNORM_FOLDED) {
+      const float2 st = reinterpret_cast<const float2*>(p.row_stats)[row];
+      const float4 c = *reinterpret_cast<const float4*>(p.ln_colsum + col);
+      s.x = fmaf(-st.x, c.x, s.x) * st.y; s.y = fmaf(-st.x, c.y, s.y) * st.y;
+      s.z = fmaf(-st.x, c.z, s.z) * st.y; s.w = fmaf(-st.x, c.w, s.w) * st.y;
+    }
     if (p.bias) {
       const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
       s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
@@ -980,6 +1010,10 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   if (a.a_tf == LDMK_TF_LAYERNORM) {
     LDMK_REQUIRE(a.row_stats && a.ln_gamma && a.ln_beta && a.a_mode == LDMK_A_ROWS, "ldmk_igemm: layernorm prologue args");
   }
+  if (a.a_tf == LDMK_TF_LAYERNORM_FOLDED)
+    LDMK_REQUIRE(a.row_stats && a.ln_colsum && a.a_mode == LDMK_A_ROWS && !a.stats_out && a.batch <= 1,
+                 "ldmk_igemm: folded layernorm needs row_stats, ln_colsum (ldmk_fold_layernorm), rows mode, no stats_out, no batching");
+  LDMK_REQUIRE(a.a_tf >= LDMK_TF_NONE && a.a_tf <= LDMK_TF_LAYERNORM_FOLDED, "ldmk_igemm: a_tf=%d", a.a_tf);
   if (a.epi == LDMK_EPI_GEGLU) LDMK_REQUIRE(a.N % 64 == 0 && !a.residual && !a.batch_vec, "ldmk_igemm: GEGLU needs N%%64==0 and no residual");
   if (a.stats_out)
     LDMK_REQUIRE(a.M % 32 == 0 && a.rows_per_sample % 32 == 0 && a.epi == LDMK_EPI_NONE && a.batch <= 1,

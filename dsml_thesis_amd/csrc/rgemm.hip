@@ -199,7 +199,12 @@ __global__ __launch_bounds__(256) void rgemm_kernel(const ldmk_igemm_args p, con
     if ((k1 - k0) % 2 == 0) wait_all(a[0], b[0], t[0]);          // the tail re-load of the last block (never consumed)
   }
   // the last MFMAs are still in the pipe (16 passes): pad before the compiler's epilogue code reads the accumulators
+  // (the accumulators are operands of the statement: nothing that reads them may be scheduled above it)
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
 
   RG_STAMP(2);
   // ---- epilogue.  C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half.  Element offsets are 32-bit
@@ -207,6 +212,9 @@ __global__ __launch_bounds__(256) void rgemm_kernel(const ldmk_igemm_args p, con
   const float alpha = p.alpha;
   const int col0 = nb0 * 32;
   const int rlane = row0 + 4 * half;
+  // LayerNorm folded through the product (ldmk.h): the loop above ran on raw rows
+  const bool lnf = p.a_tf == LDMK_TF_LAYERNORM_FOLDED;
+  const float2* __restrict__ stats2 = reinterpret_cast<const float2*>(p.row_stats);
   float* __restrict__ outp = p.out;
   if (p.epi == LDMK_EPI_GEGLU) {
     if constexpr (TN % 2 == 0) {
@@ -215,18 +223,31 @@ __global__ __launch_bounds__(256) void rgemm_kernel(const ldmk_igemm_args p, con
         const int cv = col0 + j * 32 + l31, cg = cv + 32;       // packed (value | gate) 32-column pair
         const unsigned obase = (unsigned)rlane * p.ldc + ((col0 + j * 32) >> 1) + l31;
         const float bv = p.bias ? p.bias[cv] : 0.f, bg = p.bias ? p.bias[cg] : 0.f;
+        const float csv = lnf ? p.ln_colsum[cv] : 0.f, csg = lnf ? p.ln_colsum[cg] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+          float2 st[16];
+          if (lnf) {                                            // (mean, rstd) of the 16 rows this lane holds
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              st[r] = stats2[min(rlane + i * 32 + (r & 3) + 8 * (r >> 2), p.M - 1)];
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
             if (rlane + dr < p.M) {
-              const float v = acc[i][j][r] * alpha + bv;
-              const float g = acc[i][j + 1][r] * alpha + bg;
+              float v = acc[i][j][r] * alpha, g = acc[i][j + 1][r] * alpha;
+              if (lnf) {
+                v = fmaf(-st[r].x, csv, v) * st[r].y;
+                g = fmaf(-st[r].x, csg, g) * st[r].y;
+              }
+              v += bv;
+              g += bg;
               const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));   // exact (erf) GELU
               outp[obase + (unsigned)(dr * p.ldc)] = v * ge;
             }
           }
+        }
       }
     }
     return;
@@ -239,9 +260,17 @@ __global__ __launch_bounds__(256) void rgemm_kernel(const ldmk_igemm_args p, con
     const unsigned obase = (unsigned)rlane * p.ldc + col;
     const float bias = p.bias ? p.bias[col] : 0.f;
     const float vec = bvec ? bvec[col] : 0.f;
+    const float cs = lnf ? p.ln_colsum[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float vals[16];
+      if (lnf) {
+        float2 st[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = stats2[min(rlane + i * 32 + (r & 3) + 8 * (r >> 2), p.M - 1)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(-st[r].x, cs, acc[i][j][r] * alpha) * st[r].y;
+      }
       if (resp) {                                               // all 16 loads in flight before the first add
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -252,7 +281,7 @@ __global__ __launch_bounds__(256) void rgemm_kernel(const ldmk_igemm_args p, con
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-        float v = acc[i][j][r] * alpha + bias;                  // same association as igemm.hip
+        float v = (lnf ? acc[i][j][r] : acc[i][j][r] * alpha) + bias;      // same association as igemm.hip
         if (bvec) v += vec;
         if (resp) v += vals[r];
         vals[r] = v;
@@ -296,6 +325,25 @@ __global__ __launch_bounds__(256) void pack_wfrag_kernel(const float* __restrict
   }
 }
 
+// operands of LDMK_TF_LAYERNORM_FOLDED (ldmk.h): thread <-> column, rows walked in order (coalesced across the wave)
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ w, int ldb, int K, int N,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ bias, float* __restrict__ w_out,
+                                                             float* __restrict__ colsum, float* __restrict__ bias_out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double cs = 0.0, bb = bias ? (double)bias[n] : 0.0;
+  for (int k = 0; k < K; ++k) {
+    const float x = w[(long long)k * ldb + n];
+    const float y = gamma[k] * x;
+    w_out[(long long)k * N + n] = y;
+    cs += (double)y;                 // the sum of what the matrix cores will multiply, not of the unrounded products
+    bb += (double)beta[k] * (double)x;
+  }
+  colsum[n] = (float)cs;
+  bias_out[n] = (float)bb;
+}
+
 struct RTile { int tm, tn; };
 static const RTile kRTiles[] = {{1, 5}, {2, 5}, {1, 4}, {2, 4}, {1, 2}, {1, 1}};
 constexpr int kNumRTiles = sizeof(kRTiles) / sizeof(kRTiles[0]);
@@ -306,7 +354,10 @@ static int launch_r(const ldmk_igemm_args& a, hipStream_t st) {
   const dim3 grid((tiles + 3) / 4), block(256);
   const float4* wf = reinterpret_cast<const float4*>(a.w_frag);
   switch (a.a_tf) {
-    case LDMK_TF_NONE: hipLaunchKernelGGL((rgemm_kernel<TM, TN, LDMK_TF_NONE>), grid, block, 0, st, a, wf); break;
+    case LDMK_TF_NONE:
+    case LDMK_TF_LAYERNORM_FOLDED:        // raw rows in the loop, the two per-row scalars in the epilogue
+      hipLaunchKernelGGL((rgemm_kernel<TM, TN, LDMK_TF_NONE>), grid, block, 0, st, a, wf);
+      break;
     case LDMK_TF_AFFINE: hipLaunchKernelGGL((rgemm_kernel<TM, TN, LDMK_TF_AFFINE>), grid, block, 0, st, a, wf); break;
     default: hipLaunchKernelGGL((rgemm_kernel<TM, TN, LDMK_TF_LAYERNORM>), grid, block, 0, st, a, wf); break;
   }
@@ -341,6 +392,16 @@ int rgemm_dispatch(const ldmk_igemm_args& a, int rcfg, hipStream_t st) {
 }
 
 }  // namespace ldmk
+
+extern "C" int ldmk_fold_layernorm(const float* w, int ldb, int K, int N, const float* gamma, const float* beta,
+                                   const float* bias, float* w_out, float* colsum, float* bias_out, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(w && gamma && beta && w_out && colsum && bias_out && K > 0 && N > 0 && ldb >= N, "ldmk_fold_layernorm: bad args");
+  hipLaunchKernelGGL(fold_layernorm_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, ldb, K, N, gamma, beta,
+                     bias, w_out, colsum, bias_out);
+  return check_launch("ldmk_fold_layernorm");
+}
 
 extern "C" long long ldmk_wfrag_elems(int K, int N) { return (K % 8 == 0 && N % 32 == 0) ? (long long)K * N : -1; }
 

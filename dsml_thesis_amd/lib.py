@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldmk.so")
 
 A_ROWS, A_CONV3X3 = 0, 1
-TF_NONE, TF_AFFINE, TF_AFFINE_SILU, TF_LAYERNORM = 0, 1, 2, 3
+TF_NONE, TF_AFFINE, TF_AFFINE_SILU, TF_LAYERNORM, TF_LAYERNORM_FOLDED = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GEGLU = 0, 1
 COMPUTE_F32, COMPUTE_BF16 = 0, 1
 
@@ -30,6 +30,7 @@ class IgemmArgs(C.Structure):
         ("alpha", C.c_float), ("tile_cfg", C.c_int), ("splitk", C.c_int),
         ("splitk_ws", _fp), ("splitk_ws_elems", C.c_longlong), ("stats_out", _fp), ("compute", C.c_int), ("splitk_counters", _fp), ("splitk_counters_len", C.c_int),
         ("w_frag", _fp),
+        ("ln_colsum", _fp),
     ]
 
 
@@ -55,6 +56,7 @@ _SIGS = {
     "ldmk_igemm_force_config": (None, [C.c_int]),
     "ldmk_wfrag_elems": (C.c_longlong, [C.c_int, C.c_int]),
     "ldmk_pack_wfrag": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ldmk_fold_layernorm": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "ldmk_attn_force_qt": (None, [C.c_int]),
     "ldmk_gn_chunks": (C.c_int, [C.c_int]),
     "ldmk_gn_partial": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),

@@ -117,7 +117,7 @@ def ln_stats(x2d, eps=1e-5, out=None):
 def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0, conv=None, tf=L.TF_NONE,
                     tf_coef=None, row_stats=None, ln_gamma=None, ln_beta=None, b_trans=False, ldb=None, bias=None,
                     batch_vec=None, batch_vec_ld=0, residual=None, epi=L.EPI_NONE, batch=1, a_bstride=0, w_bstride=0,
-                    out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None, w_frag=None, tile_cfg=0, compute=0,
+                    out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None, w_frag=None, tile_cfg=0, compute=0, ln_colsum=None,
                     splitk_counters=None):
     a = L.IgemmArgs()
     a.M, a.N, a.K = M, N, K
@@ -139,6 +139,7 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
     a.alpha = alpha
     a.splitk = splitk
     a.w_frag, a.tile_cfg, a.compute = _ptr(w_frag), tile_cfg, compute
+    a.ln_colsum = _ptr(ln_colsum)
     if splitk_counters is not None:
         a.splitk_counters, a.splitk_counters_len = splitk_counters.data_ptr(), splitk_counters.numel()
     if splitk_ws is not None:
@@ -177,7 +178,7 @@ def conv3x3(x, wp, bias=None, x1=None, stride=1, pad_lo=1, upsample=False, coef=
 
 def linear(x2d, wp, bias=None, x1=None, rows_per_sample=None, coef=None, silu=False, row_stats=None, ln_gamma=None,
            ln_beta=None, batch_vec=None, residual=None, geglu=False, out=None, b_trans=False, w_frag=None, tile_cfg=0,
-           stats_out=None, compute=0):
+           stats_out=None, compute=0, ln_colsum=None):
     """x2d: [M][c0] (+ x1 [M][c1]); wp: [K][N] (or torch [N][K] with b_trans) -> [M][N] (N/2 for geglu)."""
     M, c0 = x2d.shape
     c1 = 0 if x1 is None else x1.shape[-1]
@@ -189,17 +190,29 @@ def linear(x2d, wp, bias=None, x1=None, rows_per_sample=None, coef=None, silu=Fa
     tf = L.TF_NONE
     if coef is not None:
         tf = L.TF_AFFINE_SILU if silu else L.TF_AFFINE
-    elif row_stats is not None:
-        tf = L.TF_LAYERNORM
+    elif row_stats is not None:      # ln_colsum: LayerNorm folded through the product (wp, bias, ln_colsum from fold_layernorm)
+        tf = L.TF_LAYERNORM if ln_colsum is None else L.TF_LAYERNORM_FOLDED
     a = make_igemm_args(M, N, K, x2d, c0, wp, out, ncol, rows_per_sample or M, a1=x1, c1=c1, tf=tf, tf_coef=coef,
                         row_stats=row_stats, ln_gamma=ln_gamma, ln_beta=ln_beta, b_trans=b_trans, bias=bias,
                         batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0),
                         residual=residual, epi=L.EPI_GEGLU if geglu else L.EPI_NONE, w_frag=w_frag, tile_cfg=tile_cfg,
-                        compute=compute)
+                        compute=compute, ln_colsum=ln_colsum)
     if stats_out is not None:
         a.stats_out = _ptr(stats_out)
     igemm(a)
     return out
+
+
+def fold_layernorm(wp, gamma, beta, bias=None):
+    """Packed Linear weight wp [K][N] + the LayerNorm in front of it -> (diag(gamma) wp, colsum [N], beta^T wp + bias [N]):
+    the operands of LDMK_TF_LAYERNORM_FOLDED (ldmk.h)."""
+    K, N = wp.shape
+    w2 = torch.empty(K, N, device=wp.device, dtype=torch.float32)
+    cs = torch.empty(N, device=wp.device, dtype=torch.float32)
+    b2 = torch.empty(N, device=wp.device, dtype=torch.float32)
+    L.call("ldmk_fold_layernorm", _ptr(wp), wp.stride(0), K, N, _ptr(gamma), _ptr(beta), _ptr(bias), _ptr(w2), _ptr(cs), _ptr(b2),
+           stream())
+    return w2, cs, b2
 
 
 def bmm(a, b, b_trans, alpha=1.0, out=None):

@@ -9,6 +9,7 @@ pointers, nearest-upsample folded into the conv gather, the time-embedding and 1
 cross-attention adds folded into GEMM epilogues.  There is no PyTorch fallback path.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -16,6 +17,9 @@ import torch.nn as nn
 from . import lib as L
 from . import ops
 from .engine import NetBuilder, Program
+
+# diagnostic A/B switch: LayerNorm applied while the A operand is staged (round-1 form) instead of folded through the product
+_UNFOLDED = bool(os.environ.get("LDMK_LN_UNFOLDED"))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -248,6 +252,11 @@ class UNetModel(nn.Module):
                 P[q + "o2"] = ops.pack_linear(sd[q + "attn2.to_out.0.weight"])
                 P[q + "ff1"], P[q + "ff1b"] = ops.pack_geglu(sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"])
                 P[q + "ff2"] = ops.pack_linear(sd[q + "ff.net.2.weight"])
+                # LayerNorm folded through the Linear that follows it (LDMK_TF_LAYERNORM_FOLDED): gamma-scaled weights,
+                # their column sums and beta^T W + bias; the unfolded copies above stay for the training step
+                for k, nrm, b in (("qkv", "norm1", None), ("q2", "norm2", None), ("ff1", "norm3", P[q + "ff1b"])):
+                    P[q + k + "_ln"], P[q + k + "_ln#cs"], P[q + k + "_ln#b"] = ops.fold_layernorm(
+                        P[q + k], sd[q + nrm + ".weight"], sd[q + nrm + ".bias"], b)
 
         emb_w, emb_b = [], []
         self._emb_off = {}
@@ -276,7 +285,8 @@ class UNetModel(nn.Module):
         P["out"] = ops.pack_conv3x3_narrow(sd["out.2.weight"])
         P["freqs"] = ops.timestep_freqs(self.model_channels, device=dev)
         # fragment-order copies of the token-row Linear weights: the row GEMM (csrc/rgemm.hip) reads these
-        for k in [k for k in P if k.rsplit(".", 1)[-1] in ("pin", "pout", "qkv", "o1", "q2", "o2", "ff1", "ff2", "skip")]:
+        for k in [k for k in P if k.rsplit(".", 1)[-1] in ("pin", "pout", "qkv_ln", "o1", "q2_ln", "o2", "ff1_ln", "ff2", "skip")
+                  or (_UNFOLDED and k.rsplit(".", 1)[-1] in ("qkv", "ff1"))]:
             wf = ops.pack_wfrag(P[k])
             if wf is not None:
                 P[k + "#f"] = wf
@@ -365,8 +375,12 @@ class UNetModel(nn.Module):
                 q = f"{prefix}transformer_blocks.{d}."
                 # --- attn1 (self): LN1 folded into the fused QKV GEMM, flash attention, to_out + residual
                 pg.add("ldmk_ln_stats", p_(hcur), rows, C_, 1e-5, p_(stats))
-                qkv = lin(hcur, P[q + "qkv"], None, hw, tf=L.TF_LAYERNORM, row_stats=stats,
-                          ln_gamma=sd[q + "norm1.weight"], ln_beta=sd[q + "norm1.bias"], wf=P.get(q + "qkv#f"))
+                if _UNFOLDED:
+                    qkv = lin(hcur, P[q + "qkv"], None, hw, tf=L.TF_LAYERNORM, row_stats=stats,
+                              ln_gamma=sd[q + "norm1.weight"], ln_beta=sd[q + "norm1.bias"], wf=P.get(q + "qkv#f"))
+                else:
+                    qkv = lin(hcur, P[q + "qkv_ln"], P[q + "qkv_ln#b"], hw, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
+                              ln_colsum=P[q + "qkv_ln#cs"], wf=P.get(q + "qkv_ln#f"))
                 att = pg.alloc(rows, C_)
                 pg.add("ldmk_attn_self", p_(qkv), p_(att), n, hw, m.heads, m.d_head ** -0.5)
                 nb_.release(qkv)
@@ -392,8 +406,8 @@ class UNetModel(nn.Module):
                     ctx_pg.add("ldmk_dense_small", p_(ctx_in), self.context_dim, p_(P[q + "v2"]), 0, p_(vv), C_,
                                n * L_ctx, self.context_dim, C_, 0)
                     pg.add("ldmk_ln_stats", p_(h1), rows, C_, 1e-5, p_(stats))
-                    q2 = lin(h1, P[q + "q2"], None, hw, tf=L.TF_LAYERNORM, row_stats=stats,
-                             ln_gamma=sd[q + "norm2.weight"], ln_beta=sd[q + "norm2.bias"], out=att, wf=P.get(q + "q2#f"))
+                    q2 = lin(h1, P[q + "q2_ln"], P[q + "q2_ln#b"], hw, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
+                             ln_colsum=P[q + "q2_ln#cs"], out=att, wf=P.get(q + "q2_ln#f"))
                     a2 = pg.alloc(rows, C_)
                     pg.add("ldmk_attn_cross", p_(q2), C_, p_(kk), p_(vv), C_, p_(a2), C_, n, hw, L_ctx, m.heads,
                            m.d_head ** -0.5)
@@ -401,8 +415,12 @@ class UNetModel(nn.Module):
                     nb_.release(att, a2)
                 # --- GEGLU feed-forward: LN3 folded into the first GEMM, gate in its epilogue
                 pg.add("ldmk_ln_stats", p_(h2), rows, C_, 1e-5, p_(stats))
-                f = lin(h2, P[q + "ff1"], P[q + "ff1b"], hw, geglu=True, tf=L.TF_LAYERNORM, row_stats=stats,
-                        ln_gamma=sd[q + "norm3.weight"], ln_beta=sd[q + "norm3.bias"], wf=P.get(q + "ff1#f"))
+                if _UNFOLDED:
+                    f = lin(h2, P[q + "ff1"], P[q + "ff1b"], hw, geglu=True, tf=L.TF_LAYERNORM, row_stats=stats,
+                            ln_gamma=sd[q + "norm3.weight"], ln_beta=sd[q + "norm3.bias"], wf=P.get(q + "ff1#f"))
+                else:
+                    f = lin(h2, P[q + "ff1_ln"], P[q + "ff1_ln#b"], hw, geglu=True, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
+                            ln_colsum=P[q + "ff1_ln#cs"], wf=P.get(q + "ff1_ln#f"))
                 hcur = lin(f, P[q + "ff2"], sd[q + "ff.net.2.bias"], hw, residual=h2, out=h2, wf=P.get(q + "ff2#f"))
                 nb_.release(f)
             out = lin(hcur, P[prefix + "pout"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True, wf=P.get(prefix + "pout#f"))

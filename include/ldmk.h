@@ -49,7 +49,13 @@ int ldmk_init(int device);
  * add (openaimodel.py:264-273), residual adds (:275, attention.py:211-215,261) and GEGLU.
  */
 enum { LDMK_A_ROWS = 0, LDMK_A_CONV3X3 = 1 };
-enum { LDMK_TF_NONE = 0, LDMK_TF_AFFINE = 1, LDMK_TF_AFFINE_SILU = 2, LDMK_TF_LAYERNORM = 3 };
+enum { LDMK_TF_NONE = 0, LDMK_TF_AFFINE = 1, LDMK_TF_AFFINE_SILU = 2, LDMK_TF_LAYERNORM = 3,
+       /* LayerNorm folded through the product (rows mode): with W' = diag(gamma) W,
+        *     LN(x) W + b  ==  rstd * (x W' - mean * colsum(W')) + (beta^T W + b)
+        * so A is staged raw (no per-element arithmetic next to the matrix cores) and the epilogue applies the two
+        * per-row scalars.  The caller passes w = W' (and w_frag of W'), ln_colsum, bias = beta^T W + b -- all three from
+        * ldmk_fold_layernorm -- and row_stats as for LDMK_TF_LAYERNORM; ln_gamma / ln_beta are not read. */
+       LDMK_TF_LAYERNORM_FOLDED = 4 };
 enum { LDMK_EPI_NONE = 0, LDMK_EPI_GEGLU = 1 };
 /* arithmetic of the product.  F32: v_mfma_f32_32x32x2_f32, bit-identical to an fp32 fmaf chain -- the sampling path and
  * every parity test.  BF16: operands rounded to bf16 (RNE) while staged, v_mfma_f32_32x32x16_bf16 with fp32 accumulation
@@ -105,6 +111,7 @@ typedef struct ldmk_igemm_args {
   const float* w_frag;       /* optional second copy of w in MFMA-fragment order (ldmk_pack_wfrag).  With it, rows-mode
                                 problems may run on the wave-autonomous row GEMM (tile_cfg 7..12: no LDS, no barrier;
                                 csrc/rgemm.hip), which is what the short-K Linear layers of the transformer blocks want */
+  const float* ln_colsum;    /* LDMK_TF_LAYERNORM_FOLDED: [N] column sums of w (= diag(gamma) W), see ldmk_fold_layernorm */
 } ldmk_igemm_args;
 
 int ldmk_igemm(const ldmk_igemm_args* args, void* stream);
@@ -125,6 +132,11 @@ int ldmk_igemm_check(const ldmk_igemm_args* args);
  * ldmk_wfrag_elems returns the size of that copy in floats (-1 when the shape cannot be packed). */
 long long ldmk_wfrag_elems(int K, int N);
 int ldmk_pack_wfrag(const float* w, int ldb, int K, int N, float* wfrag, void* stream);
+/* Operands of LDMK_TF_LAYERNORM_FOLDED from a Linear's packed weight w[K][ldb] (N used columns), the LayerNorm's
+ * gamma[K] / beta[K] and the Linear's bias[N] (or NULL):  w_out[k][n] = gamma[k] w[k][n] (row stride N),
+ * colsum[n] = sum_k w_out[k][n], bias_out[n] = bias[n] + sum_k beta[k] w[k][n]  (sums in double). */
+int ldmk_fold_layernorm(const float* w, int ldb, int K, int N, const float* gamma, const float* beta, const float* bias,
+                        float* w_out, float* colsum, float* bias_out, void* stream);
 /* the (tile_cfg, splitk) ldmk_igemm would choose for these sizes; reads M, N, K, epi, batch, splitk_ws* */
 int ldmk_igemm_plan(const ldmk_igemm_args* args, int* tile_cfg, int* splitk);
 

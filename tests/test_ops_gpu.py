@@ -347,6 +347,69 @@ def test_row_gemm_wave_tiles(ops, cfg, case):
             close(u, v, 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("cfg,splitk", [(1, 1), (2, 1), (3, 1), (4, 1), (4, 3), (5, 1), (6, 2), (7, 1), (8, 1), (9, 1), (10, 1),
+                                        (11, 1), (12, 1)])
+@pytest.mark.parametrize("case", [(300, 320, 640, "res"), (512, 160, 1280, "geglu"), (64, 640, 1920, "none")])
+def test_linear_layernorm_folded_through_the_product(ops, cfg, splitk, case):
+    """LDMK_TF_LAYERNORM_FOLDED: LN(x) W + b computed as rstd (x W' - mean colsum(W')) + (beta^T W + b) with W' = diag(gamma) W
+    (attention.py:203-205 followed by :161-168 / :37-64).  Rows carry a mean of the order of their spread, as the token
+    rows of a transformer block do; the reference is float64, the tolerance the one of the unfolded prologue's test."""
+    from dsml_thesis_amd import lib as L
+    M, K, N, epi = case
+    x = rnd(90, M, K) * 1.2 + 0.8 * rnd(91, M, 1) + 0.3
+    w, b = rnd(92, N, K) / np.sqrt(K), 0.1 * rnd(93, N)
+    g, be = 1 + 0.2 * rnd(94, K), 0.2 * rnd(95, K)
+    res = rnd(96, M, N)
+    ref = F.linear(F.layer_norm(x.double(), (K,), g.double(), be.double(), 1e-5), w.double(), b.double())
+    xc = x.cuda()
+    kw = dict(row_stats=ops.ln_stats(xc))
+    if epi == "geglu":
+        wp, bp = ops.pack_geglu(w.cuda(), b.cuda())
+        v_, g_ = ref.chunk(2, dim=1)
+        ref = v_ * F.gelu(g_)
+        kw.update(geglu=True)
+    else:
+        wp, bp = ops.pack_linear(w.cuda()), b.cuda()
+        if epi == "res":
+            ref = ref + res.double()
+            kw.update(residual=res.cuda())
+    w2, cs, b2 = ops.fold_layernorm(wp, g.cuda(), be.cuda(), bp)
+    close(w2, wp.cpu() * g[:, None], 0, 1e-7)
+    close(cs, (wp.cpu().double() * g.double()[:, None]).sum(0).float(), 1e-5, 1e-5)
+    wf = ops.pack_wfrag(w2) if cfg > 6 else None
+    tn = ROW_TILES[cfg][1] if cfg > 6 else 1
+    a = dict(ln_colsum=cs, w_frag=wf, tile_cfg=cfg, **kw)
+    if cfg > 6 and (N % (32 * tn) or (epi == "geglu" and tn % 2)):
+        with pytest.raises(L.LdmkError, match="row GEMM"):
+            ops.linear(xc, w2, b2, **a)
+        return
+    if epi == "geglu" and (splitk > 1 or cfg in (5, 6)):
+        return                      # GEGLU never splits K and runs on the even-column tiles (dispatch remaps the others)
+    y = _linear_pinned(ops, xc, w2, b2, splitk, **a)
+    close(y, ref.float(), 1e-4, 1e-4)
+    # and it agrees with the unfolded prologue (same statistics, same weights) far inside that tolerance
+    y3 = ops.linear(xc, wp, bp, ln_gamma=g.cuda(), ln_beta=be.cuda(), **kw)
+    assert (y - y3).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    with pytest.raises(L.LdmkError, match="folded layernorm"):
+        ops.linear(xc, w2, b2, ln_colsum=cs, row_stats=kw["row_stats"], stats_out=torch.zeros(M // 32 + 1, N, 3, device="cuda"))
+
+
+def _linear_pinned(ops, x, wp, bias, splitk, **kw):
+    """ops.linear with the split-K factor pinned (ops.linear itself leaves it to the plan)."""
+    if splitk == 1:
+        return ops.linear(x, wp, bias, **kw)
+    from dsml_thesis_amd import lib as L
+    M, K = x.shape
+    N = wp.shape[1]
+    out = torch.empty(M, N, device="cuda")
+    a = ops.make_igemm_args(M, N, K, x, K, wp, out, N, M, tf=L.TF_LAYERNORM_FOLDED, row_stats=kw["row_stats"], bias=bias,
+                            residual=kw.get("residual"), ln_colsum=kw["ln_colsum"], tile_cfg=kw["tile_cfg"], splitk=splitk)
+    ws = torch.empty(splitk * M * N, device="cuda")
+    a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
+    ops.igemm(a)
+    return out
+
+
 def test_row_gemm_rejects_what_it_cannot_run(ops):
     from dsml_thesis_amd import lib as L
     x, w = rnd(80, 64, 160).cuda(), rnd(81, 96, 160).cuda()
