@@ -25,7 +25,8 @@ namespace ldmk {
 // The score matrix never exists in memory (the reference materialises 120 MB/sample at 32x32).
 constexpr int AT_D = 32;
 constexpr int AT_KT = 128;           // keys per staged tile (round 1: 64 -- two workgroup barriers per 64 keys)
-constexpr int AT_KSTR = AT_D + 1;    // K rows padded: lanes read 32 different keys at fixed d
+constexpr int AT_KSTR = AT_D + 4;    // K rows [key][d], padded to 36: each lane reads 16 contiguous d of its key as 4 x b128
+constexpr int AT_VSTR = AT_KT + 4;   // V stored transposed [d][key], padded: each lane reads 4 contiguous keys of its d as b128
 constexpr int AT_SUB = AT_KT / 32;   // 32-key sub-tiles per staged tile
 constexpr int AT_LD4 = AT_KT * AT_D / 4 / 256;   // float4 per thread per operand per staged tile
 
@@ -38,13 +39,13 @@ constexpr int AT_LD4 = AT_KT * AT_D / 4 / 256;   // float4 per thread per operan
 // the barriers per key), K/V fetched by raw buffer loads from one per-thread byte offset that advances by a scalar per
 // tile (keys past the end are out of range and read as zeros: no branch), exponentials as bare v_exp_f32 (the scale
 // carries log2 e), the running-output rescale skipped for tiles in which no lane's maximum moved, and the output transpose
-// buffer aliased onto the K/V staging (33 KB of LDS per workgroup as before: 4 workgroups per CU).
+// buffer aliased onto the K/V staging (34.5 KB of LDS per workgroup: 4 workgroups per CU).
 template <int QT>
 __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                         int tokens, int heads, float scale, float* __restrict__ lse) {
-  __shared__ __attribute__((aligned(16))) float smem_at[AT_KT * AT_KSTR + AT_KT * AT_D];
-  float* Ks = smem_at;                          // [AT_KT][33]
-  float* Vs = smem_at + AT_KT * AT_KSTR;        // [AT_KT][32]
+  __shared__ __attribute__((aligned(16))) float smem_at[AT_KT * AT_KSTR + AT_D * AT_VSTR];
+  float* Ks = smem_at;                          // [AT_KT][36]
+  float* Vs = smem_at + AT_KT * AT_KSTR;        // [AT_D][AT_KT + 4]  (transposed)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -56,8 +57,13 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
   const bool wave_active = q0 < tokens;
   constexpr float LOG2E = 1.4426950408889634f;
 
-  // Q fragments: B operand of S^T = K Q^T: lane holds Q[query = l31][d = 2s + half], pre-scaled by scale * log2(e):
-  // the scores live in the log2 domain, so every exponential below is a bare v_exp_f32 (2^x)
+  // Q fragments: B operand of S^T = K Q^T.  The k index of an MFMA step may be any bijection as long as A and B agree:
+  // step s pairs d = s (lanes 0-31) with d = 16 + s (lanes 32-63), so a lane's 16 operands are 16 CONTIGUOUS floats of its
+  // row -- four 16-byte loads here, four ds_read_b128 for the K operand below (round 2b; before: d = 2s + half, sixteen
+  // 4-byte reads per operand and 128 LDS instructions per wave per 128 keys; now 32.  Measured A/B on one box: 1457-1472
+  // vs 1453-1493 us at 4096 tokens -- inside the noise: the LDS instruction count was not what holds the matrix pipe
+  // at ~76 % busy).  Pre-scaled by scale * log2(e): the
+  // scores live in the log2 domain, so every exponential below is a bare v_exp_f32 (2^x)
   float qf[QT][16];
   f32x16 o[QT];
   float m_run[QT], l_run[QT];
@@ -67,7 +73,10 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
     const float* qp = base + (long long)(q_valid ? q0 + 32 * t + l31 : 0) * ld + h * AT_D;
     const float qs = q_valid ? scale * LOG2E : 0.f;  // the row pointer is clamped: load unconditionally (16 independent loads)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) qf[t][s] = qp[2 * s + half] * qs;
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float4 q4 = *reinterpret_cast<const float4*>(qp + 16 * half + 4 * s4);
+      qf[t][4 * s4] = q4.x * qs; qf[t][4 * s4 + 1] = q4.y * qs; qf[t][4 * s4 + 2] = q4.z * qs; qf[t][4 * s4 + 3] = q4.w * qs;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     m_run[t] = -INFINITY;
@@ -121,9 +130,9 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
     AT_T(1);
 #pragma unroll
     for (int i = 0; i < AT_LD4; ++i) {
-      float* kd = Ks + (skey + 32 * i) * AT_KSTR + sd;
-      kd[0] = kr[i].x; kd[1] = kr[i].y; kd[2] = kr[i].z; kd[3] = kr[i].w;
-      *reinterpret_cast<float4*>(Vs + (skey + 32 * i) * AT_D + sd) = vr[i];
+      *reinterpret_cast<float4*>(Ks + (skey + 32 * i) * AT_KSTR + sd) = kr[i];
+      float* vd = Vs + sd * AT_VSTR + skey + 32 * i;
+      vd[0] = vr[i].x; vd[AT_VSTR] = vr[i].y; vd[2 * AT_VSTR] = vr[i].z; vd[3 * AT_VSTR] = vr[i].w;
     }
     AT_T(2);
     __syncthreads();
@@ -138,23 +147,30 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
       for (int t = 0; t < QT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_acc[t][r] = 0.f;
-      const float* kbase = Ks + (sub * 32 + l31) * AT_KSTR + half;
-      const float* vbase = Vs + (sub * 32 + 4 * half) * AT_D + l31;
+      const float4* kbase = reinterpret_cast<const float4*>(Ks + (sub * 32 + l31) * AT_KSTR + 16 * half);
+      // V^T operand of step r: keys (r&3) + 8 (r>>2) + 4 half -- four runs of 4 contiguous keys in the transposed tile
+      const float4* vbase = reinterpret_cast<const float4*>(Vs + l31 * AT_VSTR + sub * 32 + 4 * half);
       // all 16 K operands are read ahead of the 16 S matrix instructions, and the 16 V operands of the P.V product
       // are read while those run (pinned with sched_group_barrier: the scheduler otherwise parks one read + full
       // lgkmcnt(0) wait in front of every pair of MFMAs)
       float kreg[16], vreg[16];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) kreg[s] = kbase[2 * s];
-      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+      for (int j = 0; j < 4; ++j) {
+        const float4 k4 = kbase[j];
+        kreg[4 * j] = k4.x; kreg[4 * j + 1] = k4.y; kreg[4 * j + 2] = k4.z; kreg[4 * j + 3] = k4.w;
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) vreg[r] = vbase[((r & 3) + 8 * (r >> 2)) * AT_D];
+      for (int j = 0; j < 4; ++j) {
+        const float4 v4 = vbase[2 * j];          // + 8 keys per run
+        vreg[4 * j] = v4.x; vreg[4 * j + 1] = v4.y; vreg[4 * j + 2] = v4.z; vreg[4 * j + 3] = v4.w;
+      }
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) s_acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[s], qf[t][s], s_acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (s % 4 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
       AT_T(4);
       // s_acc[t][r] = log2(e) * scale * S[query 32t + l31][key = key0 + (r&3) + 8*(r>>2) + 4*half]

@@ -1,0 +1,38 @@
+"""Self-attention kernel alone on the UNet's three levels (HIP events, median of 20).
+
+    python tools/attn_bench.py [--latent 64] [--batch 16]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from dsml_thesis_amd import ops  # noqa: E402
+from rgemm_bench import timeit  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--lib", help="another build of libldmk.so to time instead (A/B on one box)")
+    a = ap.parse_args()
+    if a.lib:
+        from dsml_thesis_amd import lib as L
+        L.LIB_PATH = os.path.abspath(a.lib)
+    tot = 0.0
+    for lvl, (heads, calls) in enumerate(((5, 5), (10, 5), (20, 6))):
+        tokens = (a.latent >> lvl) ** 2
+        qkv = torch.randn(a.batch * tokens, 3 * heads * 32, device="cuda")
+        out = torch.empty(a.batch * tokens, heads * 32, device="cuda")
+        t = timeit(lambda: ops.attn_self(qkv, a.batch, tokens, heads, out=out))
+        gf = 4.0 * tokens * tokens * 32 * heads * a.batch * 1e-9
+        tot += t * calls
+        print(f"tokens {tokens:5d} heads {heads:2d}: {t:8.1f} us  {gf / t * 1e3:6.1f} TFLOP/s  (x{calls} per step)", flush=True)
+    print(f"per step: {tot / 1e3:.3f} ms")
+
+
+if __name__ == "__main__":
+    main()
