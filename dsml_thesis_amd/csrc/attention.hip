@@ -97,6 +97,23 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   };
   const int ntiles = (tokens + AT_KT - 1) / AT_KT;
+#ifdef LDMK_AT_STAGGER
+  // Experiment: the 4 workgroups of a CU start together and run the same code, so their staging phases (loads, two
+  // barriers, LDS stores: no MFMA) coincide and the matrix pipe idles through them.  Offset each workgroup by a quarter
+  // of a tile period according to the hardware wave slot of its first wave.
+  {
+    int* slot_sh = reinterpret_cast<int*>(smem_at);
+    if (tid == 0) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      *slot_sh = (int)(hw & 0xF);
+    }
+    __syncthreads();
+    const int slot = *slot_sh & 3;
+    __syncthreads();
+    for (int i = 0; i < slot * LDMK_AT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
 #ifdef LDMK_AT_STAMPS
   unsigned long long at_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, at_last = __builtin_amdgcn_s_memtime();
 #endif

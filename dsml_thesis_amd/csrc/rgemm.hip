@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void rgemm_kernel(const ldmk_igemm_args p, con
   // the next block: an L2 hit's worth.  Loads are unconditional (the last block re-loads itself).
   // hipcc neither counts these loads nor pads hazards around the asm MFMAs: the waits are explicit, operands_ready()
   // fences the VALU prologue, and the accumulators are read only after the drain behind the loop.
-  constexpr int NT = TF == LDMK_TF_NONE ? 0 : 2;
+  constexpr int NT = (TF == LDMK_TF_NONE || TF == LDMK_TF_LAYERNORM_FOLDED) ? 0 : 2;
   constexpr int NLD = TM + NT + TN;                              // loads per block
   static_assert(4 * TM * TN >= NLD, "one load per MFMA");
   f32x4 a[2][TM], b[2][TN], t[2][2];
@@ -213,98 +213,119 @@ __global__ __launch_bounds__(256) void rgemm_kernel(const ldmk_igemm_args p, con
   const int col0 = nb0 * 32;
   const int rlane = row0 + 4 * half;
   // LayerNorm folded through the product (ldmk.h): the loop above ran on raw rows
-  const bool lnf = p.a_tf == LDMK_TF_LAYERNORM_FOLDED;
+  constexpr bool lnf = TF == LDMK_TF_LAYERNORM_FOLDED;
   const float2* __restrict__ stats2 = reinterpret_cast<const float2*>(p.row_stats);
   float* __restrict__ outp = p.out;
+  // Vector-memory operations complete in order on this ISA (one vmcnt for loads and stores): a tile that loads its
+  // residual, waits, and stores also waits for the PREVIOUS tile's stores -- a load round trip plus a store round trip per
+  // tile, 4-10 tiles per wave (tools/rgemm_probe.hip: epilogue 19-43k cycles against a 33-43k cycle main loop at K = 160).
+  // So: per-column constants and the folded-LayerNorm row statistics are loaded once up front, and the residual of tile
+  // t+1 is requested before tile t is stored (two register sets), which leaves only younger stores behind each wait.
+  float2 st[lnf ? TM : 1][16];
+  if constexpr (lnf) {                                        // (mean, rstd) of the 16 rows per row tile this lane holds
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[i][r] = stats2[min(rlane + i * 32 + (r & 3) + 8 * (r >> 2), p.M - 1)];
+  }
   if (p.epi == LDMK_EPI_GEGLU) {
     if constexpr (TN % 2 == 0) {
+      float bv[TN / 2], bg[TN / 2], csv[TN / 2], csg[TN / 2];
 #pragma unroll
       for (int j = 0; j < TN; j += 2) {
         const int cv = col0 + j * 32 + l31, cg = cv + 32;       // packed (value | gate) 32-column pair
-        const unsigned obase = (unsigned)rlane * p.ldc + ((col0 + j * 32) >> 1) + l31;
-        const float bv = p.bias ? p.bias[cv] : 0.f, bg = p.bias ? p.bias[cg] : 0.f;
-        const float csv = lnf ? p.ln_colsum[cv] : 0.f, csg = lnf ? p.ln_colsum[cg] : 0.f;
+        bv[j / 2] = p.bias ? p.bias[cv] : 0.f;
+        bg[j / 2] = p.bias ? p.bias[cg] : 0.f;
+        csv[j / 2] = lnf ? p.ln_colsum[cv] : 0.f;
+        csg[j / 2] = lnf ? p.ln_colsum[cg] : 0.f;
+      }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          float2 st[16];
-          if (lnf) {                                            // (mean, rstd) of the 16 rows this lane holds
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              st[r] = stats2[min(rlane + i * 32 + (r & 3) + 8 * (r >> 2), p.M - 1)];
-          }
+        for (int j = 0; j < TN; j += 2) {
+          const unsigned obase = (unsigned)rlane * p.ldc + ((col0 + j * 32) >> 1) + l31;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
             if (rlane + dr < p.M) {
               float v = acc[i][j][r] * alpha, g = acc[i][j + 1][r] * alpha;
-              if (lnf) {
-                v = fmaf(-st[r].x, csv, v) * st[r].y;
-                g = fmaf(-st[r].x, csg, g) * st[r].y;
+              if constexpr (lnf) {
+                v = fmaf(-st[i][r].x, csv[j / 2], v) * st[i][r].y;
+                g = fmaf(-st[i][r].x, csg[j / 2], g) * st[i][r].y;
               }
-              v += bv;
-              g += bg;
+              v += bv[j / 2];
+              g += bg[j / 2];
               const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));   // exact (erf) GELU
               outp[obase + (unsigned)(dr * p.ldc)] = v * ge;
             }
           }
         }
-      }
     }
+    RG_STAMP(3);
     return;
   }
   const float* bvec = p.batch_vec ? p.batch_vec + (long long)sample * p.batch_vec_ld : nullptr;
   const float* __restrict__ resp = p.residual;
+  float bias[TN], vec[TN], cs[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = col0 + j * 32 + l31;
+    bias[j] = p.bias ? p.bias[col] : 0.f;
+    vec[j] = bvec ? bvec[col] : 0.f;
+    cs[j] = lnf ? p.ln_colsum[col] : 0.f;
+  }
+  // (the folded-LayerNorm instantiation keeps one set: its registers hold the row statistics, and none of the layers that
+  // use it has a residual)
+  constexpr int RSETS = lnf ? 1 : 2;
+  float rv[RSETS][16];                                          // residual of the tile in work / of the next one
+  auto load_residual = [&](auto T) {
+    constexpr int t = decltype(T)::value, i = t / TN, j = t % TN;
+    const unsigned obase = (unsigned)rlane * p.ldc + col0 + j * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = min(i * 32 + (r & 3) + 8 * (r >> 2), p.M - 1 - rlane);
+      rv[t % RSETS][r] = resp[obase + (unsigned)(dr * p.ldc)];
+    }
+  };
+  if (RSETS == 2 && resp) load_residual(std::integral_constant<int, 0>{});
+  static_for<0, TM * TN>([&](auto T) {
+    constexpr int t = decltype(T)::value, i = t / TN, j = t % TN;
+    const int col = col0 + j * 32 + l31;
     const unsigned obase = (unsigned)rlane * p.ldc + col;
-    const float bias = p.bias ? p.bias[col] : 0.f;
-    const float vec = bvec ? bvec[col] : 0.f;
-    const float cs = lnf ? p.ln_colsum[col] : 0.f;
+    if constexpr (RSETS == 1) {
+      if (resp) load_residual(T);
+    } else if constexpr (t + 1 < TM * TN) {
+      if (resp) load_residual(std::integral_constant<int, t + 1>{});
+    }
+    float vals[16];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      float vals[16];
-      if (lnf) {
-        float2 st[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = stats2[min(rlane + i * 32 + (r & 3) + 8 * (r >> 2), p.M - 1)];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(-st[r].x, cs, acc[i][j][r] * alpha) * st[r].y;
-      }
-      if (resp) {                                               // all 16 loads in flight before the first add
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dr = min(i * 32 + (r & 3) + 8 * (r >> 2), p.M - 1 - rlane);
-          vals[r] = resp[obase + (unsigned)(dr * p.ldc)];
-        }
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+      float v = acc[i][j][r] * alpha;
+      if constexpr (lnf) v = fmaf(-st[i][r].x, cs[j], v) * st[i][r].y;
+      v += bias[j];                                             // same association as igemm.hip
+      if (bvec) v += vec[j];
+      if (resp) v += rv[t % RSETS][r];
+      vals[r] = v;
+      if (rlane + dr < p.M) outp[obase + (unsigned)(dr * p.ldc)] = v;
+    }
+    if (p.stats_out && row0 + i * 32 < p.M) {
+      const float shift = __shfl(vals[0], l31, 64);           // row 0 of the 32-row tile
+      float sm = 0.f, sq = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-        float v = (lnf ? acc[i][j][r] : acc[i][j][r] * alpha) + bias;      // same association as igemm.hip
-        if (bvec) v += vec;
-        if (resp) v += vals[r];
-        vals[r] = v;
-        if (rlane + dr < p.M) outp[obase + (unsigned)(dr * p.ldc)] = v;
+        const float d = vals[r] - shift;
+        sm += d;
+        sq = fmaf(d, d, sq);
       }
-      if (p.stats_out && row0 + i * 32 < p.M) {
-        const float shift = __shfl(vals[0], l31, 64);           // row 0 of the 32-row tile
-        float sm = 0.f, sq = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float d = vals[r] - shift;
-          sm += d;
-          sq = fmaf(d, d, sq);
-        }
-        sm += __shfl_xor(sm, 32, 64);
-        sq += __shfl_xor(sq, 32, 64);
-        if (half == 0) {
-          float* d = p.stats_out + ((long long)((row0 + i * 32) >> 5) * p.N + col) * 3;
-          d[0] = shift; d[1] = sm; d[2] = sq;
-        }
+      sm += __shfl_xor(sm, 32, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      if (half == 0) {
+        float* d = p.stats_out + ((long long)((row0 + i * 32) >> 5) * p.N + col) * 3;
+        d[0] = shift; d[1] = sm; d[2] = sq;
       }
     }
-  }
+  });
   RG_STAMP(3);
 }
 
@@ -354,9 +375,9 @@ static int launch_r(const ldmk_igemm_args& a, hipStream_t st) {
   const dim3 grid((tiles + 3) / 4), block(256);
   const float4* wf = reinterpret_cast<const float4*>(a.w_frag);
   switch (a.a_tf) {
-    case LDMK_TF_NONE:
+    case LDMK_TF_NONE: hipLaunchKernelGGL((rgemm_kernel<TM, TN, LDMK_TF_NONE>), grid, block, 0, st, a, wf); break;
     case LDMK_TF_LAYERNORM_FOLDED:        // raw rows in the loop, the two per-row scalars in the epilogue
-      hipLaunchKernelGGL((rgemm_kernel<TM, TN, LDMK_TF_NONE>), grid, block, 0, st, a, wf);
+      hipLaunchKernelGGL((rgemm_kernel<TM, TN, LDMK_TF_LAYERNORM_FOLDED>), grid, block, 0, st, a, wf);
       break;
     case LDMK_TF_AFFINE: hipLaunchKernelGGL((rgemm_kernel<TM, TN, LDMK_TF_AFFINE>), grid, block, 0, st, a, wf); break;
     default: hipLaunchKernelGGL((rgemm_kernel<TM, TN, LDMK_TF_LAYERNORM>), grid, block, 0, st, a, wf); break;

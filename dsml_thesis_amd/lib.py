@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libldmk.so")
+# LDMK_LIBRARY: another build of the same library (A/B timing of a kernel change on one box); still no fallback
+LIB_PATH = os.environ.get("LDMK_LIBRARY") or os.path.join(_HERE, "libldmk.so")
 
 A_ROWS, A_CONV3X3 = 0, 1
 TF_NONE, TF_AFFINE, TF_AFFINE_SILU, TF_LAYERNORM, TF_LAYERNORM_FOLDED = 0, 1, 2, 3, 4

@@ -1,6 +1,7 @@
 // Diagnostic: where a row-GEMM wave spends its cycles (s_memtime stamps; see RG_STAMP in csrc/rgemm.hip).
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form tools/rgemm_probe.hip -o /tmp/rgemm_probe
-//   /tmp/rgemm_probe M K N cfg        (cfg 0..5 = wave tiles 1x5 2x5 1x4 2x4 1x2 1x1)
+//   /tmp/rgemm_probe M K N cfg [flags]   (cfg 0..5 = wave tiles 1x5 2x5 1x4 2x4 1x2 1x1; flags: 1 residual (default), 2 GEGLU,
+//                                         4 folded LayerNorm, 0 plain bias)
 #define LDMK_RG_STAMPS 1
 #include "../dsml_thesis_amd/csrc/rgemm.hip"
 #include <algorithm>
@@ -8,6 +9,7 @@
 namespace ldmk { void set_error(const char*, ...) {} }
 int main(int argc, char** argv) {
   int M = atoi(argv[1]), K = atoi(argv[2]), N = atoi(argv[3]), cfg = atoi(argv[4]);
+  const int flags = argc > 5 ? atoi(argv[5]) : 1;
   float *x, *w, *wf, *out, *bias, *res;
   unsigned long long* st;
   hipMalloc(&x, (size_t)M * K * 4); hipMalloc(&w, (size_t)K * N * 4); hipMalloc(&wf, (size_t)K * N * 4);
@@ -26,6 +28,12 @@ int main(int argc, char** argv) {
   ldmk_igemm_args a = {};
   a.M = M; a.N = N; a.K = K; a.a0 = x; a.c0 = K; a.rows_per_sample = M; a.w = w; a.ldb = N; a.bias = bias; a.residual = res;
   a.out = out; a.ldc = N; a.alpha = 1.f; a.w_frag = wf; a.splitk_ws = (float*)st;
+  if (!(flags & 1)) a.residual = nullptr;
+  if (flags & 2) { a.epi = LDMK_EPI_GEGLU; a.ldc = N / 2; a.residual = nullptr; }
+  if (flags & 4) {
+    float* rs; hipMalloc(&rs, (size_t)M * 8); hipMemset(rs, 0, (size_t)M * 8);
+    a.a_tf = LDMK_TF_LAYERNORM_FOLDED; a.row_stats = rs; a.ln_colsum = bias;
+  }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e9f;
   for (int it = 0; it < 10; ++it) {
