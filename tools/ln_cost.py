@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--cfgs", action="store_true", help="print every tile, not only the best")
     a = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -42,12 +43,20 @@ def main():
             out = torch.empty(M, ncol, device=dev)
             gflop = 2.0 * M * N * K * 1e-9
             row = f"M={M:6d} K={K:4d} N={N:5d} {epi:6s}"
-            for name, extra in (("ln", ln), ("raw", {})):
+            w2, cs, b2 = ops.fold_layernorm(wp, ln["ln_gamma"], ln["ln_beta"], kw.get("bias"))
+            wf2 = ops.pack_wfrag(w2)
+            folded = dict(row_stats=ln["row_stats"], ln_colsum=cs)
+            for name, extra in (("ln", ln), ("folded", folded), ("raw", {})):
                 best = None
                 for cfg in list(range(1, 7)) + list(range(7, 13)):
                     try:
-                        t = timeit(lambda: ops.linear(x, wp, rows_per_sample=hw, out=out, w_frag=wf if cfg > 6 else None,
-                                                      tile_cfg=cfg, **kw, **extra))
+                        if name == "folded":
+                            k2 = dict(kw, bias=b2)
+                            t = timeit(lambda: ops.linear(x, w2, rows_per_sample=hw, out=out, w_frag=wf2 if cfg > 6 else None,
+                                                          tile_cfg=cfg, **k2, **extra))
+                        else:
+                            t = timeit(lambda: ops.linear(x, wp, rows_per_sample=hw, out=out, w_frag=wf if cfg > 6 else None,
+                                                          tile_cfg=cfg, **kw, **extra))
                     except L.LdmkError:
                         continue
                     if best is None or t < best[0]:
