@@ -36,7 +36,8 @@ def plan_table():
     if _PLAN_TABLE is None:
         import json
         import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans.json")
+        # LDMK_PLAN_TABLE: another table to A/B against the committed one (tools/autotune.py --out)
+        path = os.environ.get("LDMK_PLAN_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans.json")
         _PLAN_TABLE = {}
         if os.path.exists(path) and not os.environ.get("LDMK_NO_PLAN_TABLE"):
             try:
