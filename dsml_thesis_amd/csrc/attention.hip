@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
 #endif
 #ifdef LDMK_AT_STAMPS
   unsigned long long at_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, at_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long at_rt0 = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz: gives the shader clock in the loop
 #endif
   for (int kt = 0; kt < ntiles; ++kt) {
     float4 kr[AT_LD4], vr[AT_LD4];
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
   if (lane == 0) {
     unsigned long long* d = reinterpret_cast<unsigned long long*>(lse) + ((((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
     for (int q = 0; q < 7; ++q) d[q] = at_acc[q];
-    d[7] = ntiles;
+    d[7] = (unsigned long long)ntiles | ((__builtin_amdgcn_s_memrealtime() - at_rt0) << 32);
   }
   lse = nullptr;
 #endif

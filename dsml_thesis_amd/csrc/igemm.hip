@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
     auto run_loop = [&](auto&& loader) {
 #ifdef LDMK_IG_STAMPS
       unsigned long long ig_acc[6] = {0, 0, 0, 0, 0, 0}, ig_last = __builtin_amdgcn_s_memtime();
-      const unsigned long long ig_t0 = ig_last;
+      const unsigned long long ig_t0 = ig_last, ig_rt0 = __builtin_amdgcn_s_memrealtime();    // 100 MHz reference
 #endif
       for (int it = it_begin; it < it_end; ++it) {
         // (s_setprio(2) around the staging phase, so that its instructions win issue slots over the co-resident wave's
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       if (lane == 0) {
         unsigned long long* d = reinterpret_cast<unsigned long long*>(ws) + ((long long)blockIdx.x * 4 + wave) * 8;
         for (int q = 0; q < 5; ++q) d[q] = ig_acc[q];
-        d[5] = ig_t0; d[6] = __builtin_amdgcn_s_memtime(); d[7] = it_end - it_begin;
+        d[5] = ig_t0; d[6] = __builtin_amdgcn_s_memtime(); d[7] = (unsigned long long)(it_end - it_begin) | ((__builtin_amdgcn_s_memrealtime() - ig_rt0) << 32);
       }
 #endif
     };

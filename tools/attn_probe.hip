@@ -30,12 +30,19 @@ int main(int argc, char** argv) {
   const char* names[7] = {"load-issue", "barrier-1", "lds-store", "barrier-2", "K-read + S mfma", "softmax", "PV mfma"};
   std::vector<double> ph[7];
   for (long long i = 0; i < waves; ++i)
-    for (int q = 0; q < 7; ++q) ph[q].push_back((double)s[i * 8 + q] / (double)s[i * 8 + 7]);
+    for (int q = 0; q < 7; ++q) ph[q].push_back((double)s[i * 8 + q] / (double)(s[i * 8 + 7] & 0xFFFFFFFFull));
+  std::vector<double> mhz;
+  for (long long i = 0; i < waves; ++i) {
+    double ticks = 0;
+    for (int q = 0; q < 7; ++q) ticks += (double)s[i * 8 + q];
+    mhz.push_back(100.0 * ticks / (double)(s[i * 8 + 7] >> 32));
+  }
   auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
   double tot = 0;
-  printf("attention n=%d tokens=%d heads=%d: %.1f us (stamped build) = %.1f TFLOP/s; median cycles per 64-key tile per wave:\n", n, tokens,
+  printf("attention n=%d tokens=%d heads=%d: %.1f us (stamped build) = %.1f TFLOP/s; median cycles per 128-key tile per wave:\n", n, tokens,
          heads, best * 1e3, 4.0 * tokens * tokens * 32 * heads * n / best * 1e-9);
   for (int q = 0; q < 7; ++q) { const double m = med(ph[q]); tot += m; printf("   %-16s %7.0f\n", names[q], m); }
-  printf("   total            %7.0f   (64 MFMAs of 64 cycles = 4096 when the pipe is all this wave's)\n", tot);
+  printf("   shader clock in the loop (s_memtime / s_memrealtime): median %.0f MHz\n", med(mhz));
+  printf("   total            %7.0f   (128 MFMAs of 64 cycles = 8192 when the pipe is all this wave's)\n", tot);
   return 0;
 }

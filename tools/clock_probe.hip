@@ -1,0 +1,54 @@
+// Diagnostic: the shader clock the chip sustains while every SIMD runs back-to-back fp32 MFMAs.
+//   hipcc -O3 --offload-arch=gfx950 tools/clock_probe.hip -o tools/bin/clock_probe ; clock_probe [waves_per_simd] [iters]
+// s_memtime counts shader clocks, s_memrealtime a constant 100 MHz reference: their ratio over the loop is the clock.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void spin(unsigned long long* out, float* sink, int iters) {
+  f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+  const float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c3, 0, 0, 0);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
+  if (s == 12345.f) sink[0] = s;
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* d = out + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    d[0] = t1 - t0; d[1] = r1 - r0;
+  }
+}
+int main(int argc, char** argv) {
+  const int wps = argc > 1 ? atoi(argv[1]) : 1, iters = argc > 2 ? atoi(argv[2]) : 20000;
+  const int blocks = 256 * wps;           // 4 waves per block: one per SIMD; `wps` blocks per CU
+  unsigned long long* out; float* sink;
+  (void)hipMalloc(&out, (size_t)blocks * 4 * 16); (void)hipMalloc(&sink, 4);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(spin, dim3(blocks), dim3(256), 0, 0, out, sink, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h((size_t)blocks * 8);
+    (void)hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> mhz, cpm;
+    for (size_t i = 0; i < h.size() / 2; ++i) {
+      mhz.push_back(100.0 * (double)h[2 * i] / (double)h[2 * i + 1]);
+      cpm.push_back((double)h[2 * i] / (4.0 * iters));
+    }
+    std::sort(mhz.begin(), mhz.end()); std::sort(cpm.begin(), cpm.end());
+    const double flops = 4096.0 * 4.0 * iters * blocks * 4;
+    printf("%d wave(s)/SIMD, %d x 4 MFMAs per wave: %.3f ms = %.1f TFLOP/s; shader clock median %.0f MHz (min %.0f, max %.0f); "
+           "clocks per MFMA per wave %.1f\n", wps, iters, ms, flops / ms * 1e-9, mhz[mhz.size() / 2], mhz.front(), mhz.back(),
+           cpm[cpm.size() / 2]);
+  }
+  return 0;
+}

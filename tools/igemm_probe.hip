@@ -41,9 +41,10 @@ int main(int argc, char** argv) {
   std::vector<unsigned long long> s((size_t)tiles * 4 * 8);
   hipMemcpy(s.data(), st, s.size() * 8, hipMemcpyDeviceToHost);
   const char* names[5] = {"barrier-1", "lds-store", "barrier-2", "load-issue", "mfma-block"};
-  std::vector<double> ph[5], tot;
+  std::vector<double> ph[5], tot, mhz;
   for (int i = 0; i < tiles * 4; ++i) {
-    const double iters = (double)s[i * 8 + 7];
+    const double iters = (double)(s[i * 8 + 7] & 0xFFFFFFFFull);
+    mhz.push_back(100.0 * (double)(s[i * 8 + 6] - s[i * 8 + 5]) / (double)(s[i * 8 + 7] >> 32));
     for (int q = 0; q < 5; ++q) ph[q].push_back((double)s[i * 8 + q] / iters);
     tot.push_back((double)(s[i * 8 + 6] - s[i * 8 + 5]) / iters);
   }
@@ -52,5 +53,6 @@ int main(int argc, char** argv) {
          hw, n, tiles, best * 1e3, med(tot));
   for (int q = 0; q < 5; ++q) printf("   %-11s %7.0f\n", names[q], med(ph[q]));
   printf("   (80 MFMAs of 64 cycles = 5120 when the pipe is all this wave's)\n");
+  printf("   shader clock in the loop (s_memtime / s_memrealtime): median %.0f MHz\n", med(mhz));
   return 0;
 }
