@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
               }
               v += bv;
               g += bg;
-              const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));   // exact (erf) GELU
+              const float ge = gelu_erf_f(g);                                            // exact (erf) GELU
               outp[(long long)row * p.ldc + oc] = v * ge;
             }
           }

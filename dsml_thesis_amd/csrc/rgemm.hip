@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void rgemm_kernel(const ldmk_igemm_args p, con
               }
               v += bv[j / 2];
               g += bg[j / 2];
-              const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));   // exact (erf) GELU
+              const float ge = gelu_erf_f(g);                                            // exact (erf) GELU
               outp[obase + (unsigned)(dr * p.ldc)] = v * ge;
             }
           }
