@@ -22,6 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ROWS_RETUNE = False
 FORCE = False
+CANDS = {}
 CFG_WK = {1: 1, 2: 2, 3: 4, 4: 2, 5: 1, 6: 2}          # K slices of 32 staged per iteration
 EVEN_TN = {1, 2, 3}
 SKS = [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64]
@@ -137,15 +138,19 @@ def tune_program(pg, table):
         a.stats_out = 0
         nkc = a.K // 32
         best = None
+        tried = []
         if key in table:          # rows re-tune: the LDS-tiled plan on record is the one to beat
             a.tile_cfg, a.splitk = table[key]
             a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
             t = time_call(lib, a, st, touch=touch)
             best = (t, a.tile_cfg, a.splitk)
+            tried.append(best)
         if rows_retune:
             for cfg in range(7, 13):          # wave-autonomous row GEMM tiles (illegal ones return an error code)
                 a.tile_cfg, a.splitk = cfg, 1
                 t = time_call(lib, a, st, touch=touch)
+                if t is not None:
+                    tried.append((t, cfg, 1))
                 if t is not None and (best is None or t < best[0]):
                     best = (t, cfg, 1)
         for cfg in range(1, 7):
@@ -160,6 +165,8 @@ def tune_program(pg, table):
                 a.tile_cfg, a.splitk = cfg, sk
                 a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
                 t = time_call(lib, a, st, touch=touch)
+                if t is not None:
+                    tried.append((t, cfg, sk))
                 if t is not None and (best is None or t < best[0]):
                     best = (t, cfg, sk)
         (a.tile_cfg, a.splitk, a.splitk_ws, a.splitk_ws_elems, a.out, a.stats_out, a.residual) = saved
@@ -167,6 +174,8 @@ def tune_program(pg, table):
         a.a0, a.a1 = saved_a
         seen[key] = best
         table[key] = [best[1], best[2]]
+        # runners-up (isolated timing, ms) for the in-step comparison: tools/instep_tune.py
+        CANDS[key] = [[c, k, round(t, 5)] for t, c, k in sorted(set(tried))[:4]]
         print(f"{key:40s} heuristic cfg={saved[0]} sk={saved[1]} {1e3 * base:8.1f} us -> tuned cfg={best[1]} sk={best[2]} "
               f"{1e3 * best[0]:8.1f} us", flush=True)
 
@@ -195,4 +204,5 @@ if __name__ == "__main__":
         json.dump(table, open(a.out, "w"), indent=0, sort_keys=True)
         torch.cuda.empty_cache()
     json.dump(table, open(a.out, "w"), indent=0, sort_keys=True)
+    json.dump(CANDS, open(a.out + ".cands.json", "w"), indent=0, sort_keys=True)
     print(f"wrote {a.out} ({len(table)} shapes)")

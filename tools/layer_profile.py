@@ -28,8 +28,9 @@ def dump(latent, batch, path):
     for fn, args, keep, name in run.pg.calls:
         if name == "ldmk_igemm":
             a = keep
+            from dsml_thesis_amd.engine import plan_key
             calls.append(dict(name=name, M=a.M, N=a.N, K=a.K, conv=a.a_mode, tf=a.a_tf, epi=a.epi, cfg=a.tile_cfg,
-                              sk=a.splitk))
+                              sk=a.splitk, key=plan_key(a, a.M)))
         else:
             calls.append(dict(name=name))
     json.dump(dict(calls=calls, marker_steps=3), open(path, "w"))
@@ -76,6 +77,14 @@ def join(d):
     assert per >= i, (per, i)
     tot = sum(d_ for _, d_ in out)
     print(f"step total (sum of kernel durations) {tot / 1e3:.3f} ms over {len(out)} calls")
+    # machine-readable twin for tools/instep_tune.py: per plan key the plan that ran and its total time in the step
+    per_key = {}
+    for c, d_ in out:
+        if c["name"] == "ldmk_igemm" and "key" in c:
+            e = per_key.setdefault(c["key"], dict(cfg=c["cfg"], sk=c.get("sk", 1), us=0.0, n=0))
+            e["us"] += d_
+            e["n"] += 1
+    json.dump(per_key, open(os.path.join(d, "per_key.json"), "w"), indent=0, sort_keys=True)
     agg = {}
     for c, d_ in out:
         if c["name"] == "ldmk_igemm":
