@@ -175,7 +175,7 @@ def tune_program(pg, table):
         seen[key] = best
         table[key] = [best[1], best[2]]
         # runners-up (isolated timing, ms) for the in-step comparison: tools/instep_tune.py
-        CANDS[key] = [[c, k, round(t, 5)] for t, c, k in sorted(set(tried))[:4]]
+        CANDS[key] = [[c, k, round(t, 5)] for t, c, k in sorted(set(tried))[:8]]
         print(f"{key:40s} heuristic cfg={saved[0]} sk={saved[1]} {1e3 * base:8.1f} us -> tuned cfg={best[1]} sk={best[2]} "
               f"{1e3 * best[0]:8.1f} us", flush=True)
 

@@ -1,8 +1,8 @@
 """In-step plan selection.  Isolated launch timings mispredict what a plan costs inside the hipGraph step (the chip is
 power-limited there and the operands arrive from another XCD): this tool lets the step decide.
 
-    python tools/instep_tune.py variants TABLE.json CANDS.json OUTDIR     # OUTDIR/v2.json, v3.json: every shape on its
-                                                                          # 2nd / 3rd isolated candidate
+    python tools/instep_tune.py variants TABLE.json CANDS.json OUTDIR [R]  # OUTDIR/v2.json .. vR.json: every shape on its
+                                                                          # 2nd .. R-th isolated candidate (default 3)
     (on the GPU box: tools/layer_multi.sh OUTDIR/v2.json OUTDIR/v3.json -> per_key.json per table)
     python tools/instep_tune.py pick TABLE.json RUNDIR [--min-gain 0.02]  # RUNDIR/{t0,t1,...}/per_key.json -> TABLE.json updated
 """
@@ -11,11 +11,11 @@ import os
 import sys
 
 
-def variants(table_path, cands_path, outdir):
+def variants(table_path, cands_path, outdir, max_rank=3):
     table = json.load(open(table_path))
     cands = json.load(open(cands_path))
     os.makedirs(outdir, exist_ok=True)
-    for rank in (2, 3):
+    for rank in range(2, int(max_rank) + 1):
         t = dict(table)
         n = 0
         for key, cs in cands.items():
@@ -49,7 +49,7 @@ def pick(table_path, rundir, min_gain):
 
 if __name__ == "__main__":
     if sys.argv[1] == "variants":
-        variants(*sys.argv[2:5])
+        variants(*sys.argv[2:6])
     else:
         mg = float(sys.argv[sys.argv.index("--min-gain") + 1]) if "--min-gain" in sys.argv else 0.02
         pick(sys.argv[2], sys.argv[3], mg)
