@@ -27,6 +27,27 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+# LDMK_REPORT_MARGINS=<file>: every torch.testing.assert_close of the run also logs how much of its tolerance it used
+# (worst element: |a - b| / (atol + rtol |b|)) -- the evidence behind the tolerances quoted in DESIGN.md section 4.
+if os.environ.get("LDMK_REPORT_MARGINS"):
+    _orig_close = torch.testing.assert_close
+
+    def _logging_close(actual, expected, *a, rtol=None, atol=None, **kw):
+        try:
+            x, y = torch.as_tensor(actual).detach().double().cpu(), torch.as_tensor(expected).detach().double().cpu()
+            if rtol is not None and atol is not None and x.shape == y.shape and x.numel() and x.is_floating_point():
+                d = (x - y).abs()
+                used = (d / (atol + rtol * y.abs())).max().item()
+                with open(os.environ["LDMK_REPORT_MARGINS"], "a") as f:
+                    f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}\t{d.max().item():.3e}\t"
+                            f"{y.abs().max().item():.3e}\t{rtol:g}\t{atol:g}\t{used:.4f}\n")
+        except Exception:
+            pass
+        return _orig_close(actual, expected, *a, rtol=rtol, atol=atol, **kw)
+
+    torch.testing.assert_close = _logging_close
+
+
 def rnd(seed, *shape):
     """Seeded standard-normal float32 tensor -- the same generator tools/make_golden.py uses."""
     return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32))

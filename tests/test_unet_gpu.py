@@ -60,8 +60,9 @@ def test_unet_fr_golden():
     m, _ = make_unet(W.FR_UNET)
     x, t, ctx = rnd(41, 2, 3, 32, 32), torch.tensor([3, 981]), rnd(42, 2, 1, 512)
     eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
-    # fp32 end to end; different summation order than PyTorch-CPU over ~60 layers
-    close(eps, g["fr_eps"], 2e-4, 2e-4)
+    # fp32 end to end; different summation order than PyTorch-CPU over ~60 layers.  Measured (tools/parity_margin.py):
+    # max |diff| 5.7e-6 on values up to 2.0 -- the bound below leaves a factor ~10 for other summation orders (plan changes)
+    close(eps, g["fr_eps"], 3e-5, 3e-5)
     # replay of the same program is bitwise reproducible
     eps2 = m(x.cuda(), t.cuda(), context=ctx.cuda())
     assert torch.equal(eps, eps2)
@@ -73,7 +74,7 @@ def test_unet_tf_concat_golden():
     x, t = rnd(71, 2, 3, 32, 32), torch.tensor([11, 756])
     c12, c34 = rnd(72, 2, 1, 1024), rnd(73, 2, 6, 32, 32)
     eps = m(x.cuda(), t.cuda(), context=c12.cuda(), c_concat=c34.cuda())
-    close(eps, g["tf_eps"], 2e-4, 2e-4)
+    close(eps, g["tf_eps"], 3e-5, 3e-5)
     eps_cat = m(torch.cat([x, c34], 1).cuda(), t.cuda(), context=c12.cuda())
     assert torch.equal(eps, eps_cat)
 
@@ -82,7 +83,7 @@ def test_unet_northstar_64_golden():
     g = golden("g4_unet_fr.npz")
     m, _ = make_unet(W.NS_UNET)
     eps = m(rnd(43, 1, 4, 64, 64).cuda(), torch.tensor([501]).cuda(), context=rnd(44, 1, 1, 512).cuda())
-    close(eps, g["ns_eps"], 2e-4, 2e-4)
+    close(eps, g["ns_eps"], 3e-5, 3e-5)
 
 
 def test_unet_multi_token_context_vs_oracle():
@@ -90,7 +91,7 @@ def test_unet_multi_token_context_vs_oracle():
     m, sd = make_unet(W.FR_UNET)
     x, t, ctx = rnd(45, 1, 3, 16, 16), torch.tensor([250]), rnd(46, 1, 3, 512)
     ref = O.unet_forward(sd, W.FR_UNET, x, t, ctx)
-    close(m(x.cuda(), t.cuda(), context=ctx.cuda()), ref, 2e-4, 2e-4)
+    close(m(x.cuda(), t.cuda(), context=ctx.cuda()), ref, 3e-5, 3e-5)
 
 
 def test_unet_batch_invariance_and_ragged_batch():
@@ -124,7 +125,7 @@ def test_unet_ragged_shapes_vs_oracle(n, h, w):
     m, sd = make_unet(W.FR_UNET)
     x, t, ctx = rnd(50, n, 3, h, w), torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(1)), rnd(51, n, 1, 512)
     ref = O.unet_forward(sd, W.FR_UNET, x, t, ctx)
-    close(m(x.cuda(), t.cuda(), context=ctx.cuda()), ref, 3e-4, 3e-4)
+    close(m(x.cuda(), t.cuda(), context=ctx.cuda()), ref, 1e-4, 1e-4)
 
 
 def test_unet_empty_batch_fails_loudly():
@@ -142,4 +143,4 @@ def test_unet_non_square_ragged_token_counts_vs_oracle():
     x, t, ctx = rnd(47, 2, 3, 24, 40), torch.tensor([10, 990]), rnd(48, 2, 1, 512)
     eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
     ref = O.unet_forward(sd, W.FR_UNET, x, t, ctx)
-    close(eps, ref, 3e-4, 3e-4)
+    close(eps, ref, 1e-4, 1e-4)
