@@ -834,7 +834,7 @@ static bool igemm_fast_gather_ok(const ldmk_igemm_args& a) {
   const long long rows = a.a_mode == LDMK_A_CONV3X3 ? samples * a.in_h * a.in_w : (long long)a.M;
   const long long wb = (a.b_trans ? (long long)a.N : (long long)a.K) * a.ldb * 4;
   const bool ups_ok = a.upsample == 0 || (a.upsample == 1 && a.c1 == 0 && a.a_mode == LDMK_A_CONV3X3);
-  return ups_ok && rows * a.c0 * 4 < (1LL << 32) && rows * a.c1 * 4 < (1LL << 32) && wb < (1LL << 32) && a.batch <= 1;
+  return ups_ok && rows * a.c0 * 4 < (1LL << 32) && rows * a.c1 * 4 < (1LL << 32) && wb < (1LL << 32) && (a.batch <= 1 || a.a1 == nullptr);   // (a batch offsets a0 and w only)
 }
 
 template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF, bool FG>

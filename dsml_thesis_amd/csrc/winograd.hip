@@ -1,0 +1,193 @@
+// Winograd F(2x2, 3x3) transforms around a batched igemm: a stride-1, pad-1 3x3 convolution as
+//     V_p = (B^T d B)_p  ->  M_p = V_p U_p  (16 GEMMs of K = C_in on the matrix cores, ldmk_igemm batch = 16)  ->  Y = A^T M A
+// with 4 multiplications per output and input channel instead of 9 (Lavin & Gray 2016, the correlation form nn.Conv2d
+// computes: openaimodel.py:204,230; model.py:95-129).  Used where the transforms' traffic (4x the activation, in and out)
+// is small next to the matrix time saved: the 640-channel ResBlock convolutions.
+//
+//   B^T = | 1  0 -1  0 |   G = | 1    0    0  |   A^T = | 1  1  1  0 |
+//         | 0  1  1  0 |       | 1/2  1/2  1/2|         | 0  1 -1 -1 |
+//         | 0 -1  1  0 |       | 1/2 -1/2  1/2|
+//         | 0  1  0 -1 |       | 0    0    1  |
+//
+// The input transform also applies the GroupNorm(+SiLU) that precedes the convolution (it replaces the gn_apply pass: the
+// zero padding is a padding of the ACTIVATED tensor, so out-of-image taps stay 0), and reads the channel concat of two
+// tensors; the output transform takes over the convolution's epilogue: bias, per-sample (timestep-embedding) vector,
+// residual, and the GroupNorm partial records of the result for the next layer.
+#include "ldmk_common.h"
+
+namespace ldmk {
+
+// thread <-> (tile, 4 channels); tiles are the 2x2 output blocks in (sample, ty, tx) order; V is [16][tiles][C]
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x0, int c0, const float* __restrict__ x1,
+                                                         int c1, const float* __restrict__ coef, int silu, int H, int W,
+                                                         long long tiles, float* __restrict__ V) {
+  const int C = c0 + c1, c4n = C >> 2;
+  const int tw = W >> 1, th = H >> 1;
+  const long long total = tiles * c4n;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long t = idx / c4n;
+    const int c = (int)(idx - t * c4n) * 4;
+    const int tx = (int)(t % tw);
+    const long long t2 = t / tw;
+    const int ty = (int)(t2 % th), n = (int)(t2 / th);
+    const float* src = c < c0 ? x0 + (long long)n * H * W * c0 + c : x1 + (long long)n * H * W * c1 + (c - c0);
+    const int cs = c < c0 ? c0 : c1;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (coef) {
+      const float* cf = coef + ((long long)n * 2) * C + c;
+      sc = *reinterpret_cast<const float4*>(cf);
+      sh = *reinterpret_cast<const float4*>(cf + C);
+    }
+    float4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = 2 * ty - 1 + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = 2 * tx - 1 + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+          v = *reinterpret_cast<const float4*>(src + ((long long)y * W + x) * cs);
+          if (coef) { v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w); }
+          if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        }
+        d[i][j] = v;
+      }
+    }
+    auto sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
+    auto add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+    float4 r[4][4];                     // B^T d
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r[0][j] = sub(d[0][j], d[2][j]);
+      r[1][j] = add(d[1][j], d[2][j]);
+      r[2][j] = sub(d[2][j], d[1][j]);
+      r[3][j] = sub(d[1][j], d[3][j]);
+    }
+    float* dst = V + t * C + c;
+    const long long ps = tiles * C;     // stride between transform positions
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // (B^T d) B
+      *reinterpret_cast<float4*>(dst + (4 * i + 0) * ps) = sub(r[i][0], r[i][2]);
+      *reinterpret_cast<float4*>(dst + (4 * i + 1) * ps) = add(r[i][1], r[i][2]);
+      *reinterpret_cast<float4*>(dst + (4 * i + 2) * ps) = sub(r[i][2], r[i][1]);
+      *reinterpret_cast<float4*>(dst + (4 * i + 3) * ps) = sub(r[i][1], r[i][3]);
+    }
+  }
+}
+
+// One workgroup = (sample, band of 2R image rows); thread <-> channel (coalesced over N), walking the band's tiles left to
+// right.  The band is a whole number of 32-pixel GroupNorm chunks (W = 8: R = 2; W >= 16: R = 1), so the partial records of
+// the result (same records as gn_partial_kernel: shift, sum, sum of squares of the chunk) are complete per workgroup.
+constexpr int WINO_MAX_CHUNKS = 4;      // W <= 64
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
+                                                          const float* __restrict__ bvec, int bvec_ld,
+                                                          const float* __restrict__ res, float* __restrict__ out,
+                                                          float* __restrict__ stats, int H, int W, int N, int R,
+                                                          long long tiles) {
+  const int tw = W >> 1, th = H >> 1;
+  const int bands = th / R;
+  const int n = blockIdx.x / bands, band = blockIdx.x - n * bands;
+  const long long ps = tiles * N;
+  const int nchunks = (2 * R * W) >> 5;
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;      // grid.y covers the channels
+  if (c < N) {
+    const float add0 = (bias ? bias[c] : 0.f) + (bvec ? bvec[(long long)n * bvec_ld + c] : 0.f);
+    float shift[WINO_MAX_CHUNKS], sm[WINO_MAX_CHUNKS], sq[WINO_MAX_CHUNKS];
+    bool have[WINO_MAX_CHUNKS];
+#pragma unroll
+    for (int k = 0; k < WINO_MAX_CHUNKS; ++k) { shift[k] = 0.f; sm[k] = 0.f; sq[k] = 0.f; have[k] = false; }
+    for (int r = 0; r < R; ++r) {
+      const int ty = band * R + r;
+      for (int tx = 0; tx < tw; ++tx) {
+        const long long t = ((long long)n * th + ty) * tw + tx;
+        const float* mp = Mb + t * N + c;
+        float m[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) m[p] = mp[p * ps];
+        float s0[4], s1[4];                 // A^T m
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s0[j] = (m[j] + m[4 + j]) + m[8 + j];
+          s1[j] = (m[4 + j] - m[8 + j]) - m[12 + j];
+        }
+        float y[2][2];
+        y[0][0] = (s0[0] + s0[1]) + s0[2];
+        y[0][1] = (s0[1] - s0[2]) - s0[3];
+        y[1][0] = (s1[0] + s1[1]) + s1[2];
+        y[1][1] = (s1[1] - s1[2]) - s1[3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int yy = 2 * ty + i, xx = 2 * tx + j;
+            const long long o = (((long long)n * H + yy) * W + xx) * N + c;
+            float v = y[i][j] + add0;
+            if (res) v += res[o];
+            out[o] = v;
+            if (stats) {
+              const int k = (((2 * r + i) * W) + xx) >> 5;     // chunk of this pixel inside the band
+#pragma unroll
+              for (int q = 0; q < WINO_MAX_CHUNKS; ++q)
+                if (q == k) {
+                  if (!have[q]) { shift[q] = v; have[q] = true; }
+                  const float dv = v - shift[q];
+                  sm[q] += dv;
+                  sq[q] = fmaf(dv, dv, sq[q]);
+                }
+            }
+          }
+      }
+    }
+    if (stats) {
+      const long long chunk0 = ((long long)n * H * W + (long long)band * 2 * R * W) >> 5;
+#pragma unroll
+      for (int q = 0; q < WINO_MAX_CHUNKS; ++q)
+        if (q < nchunks) {
+          float* d = stats + ((chunk0 + q) * N + c) * 3;
+          d[0] = shift[q]; d[1] = sm[q]; d[2] = sq[q];
+        }
+    }
+  }
+}
+
+}  // namespace ldmk
+
+extern "C" long long ldmk_winograd_tiles(int n, int h, int w) { return (long long)n * (h / 2) * (w / 2); }
+
+extern "C" int ldmk_winograd_input(const float* x0, int c0, const float* x1, int c1, const float* coef, int silu, int n, int h,
+                                   int w, float* v, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(x0 && v && n > 0 && c0 > 0, "ldmk_winograd_input: bad args");
+  LDMK_REQUIRE((c1 == 0) == (x1 == nullptr), "ldmk_winograd_input: x1/c1 mismatch");
+  LDMK_REQUIRE(h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "ldmk_winograd_input: H=%d W=%d must be even", h, w);
+  LDMK_REQUIRE(c0 % 4 == 0 && c1 % 4 == 0, "ldmk_winograd_input: channel counts must be multiples of 4");
+  const long long tiles = ldmk_winograd_tiles(n, h, w);
+  const long long total = tiles * ((c0 + c1) / 4);
+  long long g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x0, c0, x1, c1, coef, silu, h, w,
+                     tiles, v);
+  return check_launch("ldmk_winograd_input");
+}
+
+extern "C" int ldmk_winograd_output(const float* m, const float* bias, const float* batch_vec, int batch_vec_ld,
+                                    const float* residual, float* out, float* stats_out, int n, int h, int w, int cout,
+                                    void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(m && out && n > 0 && cout > 0, "ldmk_winograd_output: bad args");
+  LDMK_REQUIRE(h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "ldmk_winograd_output: H=%d W=%d must be even", h, w);
+  int R = 1;
+  if (stats_out) {
+    // a band of 2R image rows must be a whole number of 32-pixel chunks and at most WINO_MAX_CHUNKS of them
+    while ((2 * R * w) % 32 != 0 && R < h / 2) R *= 2;
+    LDMK_REQUIRE((2 * R * w) % 32 == 0 && (h / 2) % R == 0 && (2 * R * w) / 32 <= WINO_MAX_CHUNKS && (h * w) % 32 == 0,
+                 "ldmk_winograd_output: stats_out needs bands of whole 32-pixel chunks (H=%d W=%d)", h, w);
+  }
+  const long long tiles = ldmk_winograd_tiles(n, h, w);
+  hipLaunchKernelGGL(wino_output_kernel, dim3(n * ((h / 2) / R), (cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, m, bias, batch_vec,
+                     batch_vec_ld, residual, out, stats_out, h, w, cout, R, tiles);
+  return check_launch("ldmk_winograd_output");
+}

@@ -120,18 +120,19 @@ class Program:
             self._all.append(self._skcnt)
         return self._skcnt
 
-    def igemm(self, args, scale_m=None, allow_splitk=True):
+    def igemm(self, args, scale_m=None, allow_splitk=True, batch_is_samples=True):
         """Record a GEMM.  The (tile shape, K split) pair is planned here, once: for the real M, or -- with
         scale_m = (num, den) -- for M*num/den rows, which pins the K-summation order so that results are
         bitwise independent of how a batch is split across calls / ranks."""
         m, nbatch = args.M, args.batch
         if scale_m is not None and scale_m[0] != scale_m[1]:
-            if nbatch > 1:        # batched GEMM (one problem per sample): the job-wide view has more problems
+            if nbatch > 1 and batch_is_samples:   # batched GEMM (one problem per sample): the job-wide view has more problems
                 args.batch = max(1, nbatch * scale_m[0] // scale_m[1])
             else:
                 args.M = max(1, m * scale_m[0] // scale_m[1])
         cfg, sk = C.c_int(0), C.c_int(0)
-        tuned = tuned_plan(args, args.M) if nbatch <= 1 and args.M > 0 else None
+        # (a batch that is not per sample -- the 16 transform positions of a Winograd convolution -- is part of the plan key)
+        tuned = tuned_plan(args, args.M) if (nbatch <= 1 or not batch_is_samples) and args.M > 0 else None
         if tuned is not None and tuned[0] > 6:
             # a row-GEMM wave tile: legal only with the fragment-order weight copy and when the tile divides this
             # problem (per-sample operands need rows_per_sample % tile rows == 0); else the heuristic decides
@@ -263,6 +264,59 @@ class NetBuilder:
             a.batch_vec, a.batch_vec_ld = self.ptr(batch_vec), bv_ld
         self._maybe_stats(a, out.view(-1, cout), oh * ow, stats)
         pg.igemm(a, self.pin)
+        return out
+
+    # ---- GroupNorm -> SiLU -> Conv2d 3x3 (stride 1), the ResBlock pattern.  Large enough problems go through Winograd
+    # F(2x2,3x3) (csrc/winograd.hip): 4 instead of 9 multiplications per output and input channel on a path whose matrix
+    # work is power-limited; the transforms replace the gn_apply pass and the convolution's epilogue.  The decision is made on
+    # the plan-policy batch (pin[0]), like the tile plans, so a sample's result does not depend on how a batch is sharded.
+    # Measured on MI355X (tools/winograd_bench.py, in-step times of the direct form): wins from 320 input channels and
+    # ~1024 tiles up (16x: 640->640 at 16x16 243+8 -> 165 us); loses at 160 channels (transform traffic) and at batch 1.
+    WINO_MIN_TILES, WINO_MIN_CIN = 1024, 320
+
+    def winograd_ok(self, cin, h, w):
+        import os
+        if os.environ.get("LDMK_NO_WINOGRAD"):
+            return False
+        pol_n = self.pin[0] if self.pin else self.n
+        return (cin >= self.WINO_MIN_CIN and pol_n * (h // 2) * (w // 2) >= self.WINO_MIN_TILES and h % 2 == 0
+                and w in (8, 16, 32, 64) and (h * w) % 32 == 0 and (w >= 16 or (h // 2) % 2 == 0))
+
+    def gn_conv(self, x0, x1, h, w, gamma, beta, eps, wp, u, bias, batch_vec=None, bv_ld=0, residual=None, out=None,
+                stats=False):
+        """GroupNorm(32)+SiLU of (the concat of) x0 | x1, then the 3x3 convolution with packed weights `wp` (implicit GEMM)
+        or, when `u` (ops.pack_winograd) is given and the problem is large enough, through Winograd."""
+        pg, n, ops, p_ = self.pg, self.n, self.ops, self.ptr
+        c0 = x0.shape[-1]
+        c1 = 0 if x1 is None else x1.shape[-1]
+        cin = c0 + c1
+        if u is None or not self.winograd_ok(cin, h, w):
+            y = self.gn_act(x0, x1, h * w, gamma, beta, eps)
+            res = self.conv(y.view(n, h, w, cin), None, wp, bias, h, w, batch_vec=batch_vec, bv_ld=bv_ld, residual=residual,
+                            out=out, stats=stats)
+            self.release(y)
+            return res
+        cout = u.shape[2]
+        tiles = n * (h // 2) * (w // 2)
+        coef = self.gn(x0, x1, h * w, gamma, beta, eps)
+        V, Mb = pg.alloc(16, tiles, cin), pg.alloc(16, tiles, cout)
+        if out is None:
+            out = pg.alloc(n, h, w, cout)
+        pg.add("ldmk_winograd_input", p_(x0), c0, p_(x1), c1, p_(coef), 1, n, h, w, p_(V))
+        a = ops.make_igemm_args(tiles, cout, cin, V, cin, u, Mb, cout, tiles, batch=16, a_bstride=tiles * cin,
+                                w_bstride=cin * cout, out_bstride=tiles * cout)
+        a._winograd = True            # (tools/autotune.py sweeps these batched problems; per-sample batches are not planned by table)
+        pg.igemm(a, self.pin, batch_is_samples=False)
+        part = None
+        out2d = out.view(-1, cout)
+        if stats:
+            self.drop_stats(out2d)
+            part = self.stats_buffer(n * h * w, cout)
+        pg.add("ldmk_winograd_output", p_(Mb), p_(bias), p_(batch_vec), bv_ld, p_(residual), p_(out), p_(part), n, h, w, cout)
+        if stats:
+            self.attach_stats(out2d, part)
+        self.release(coef)
+        pg.release(V, Mb)
         return out
 
     def _maybe_stats(self, a, out2d, rows_per_sample, stats):

@@ -57,6 +57,9 @@ _SIGS = {
     "ldmk_igemm_force_config": (None, [C.c_int]),
     "ldmk_wfrag_elems": (C.c_longlong, [C.c_int, C.c_int]),
     "ldmk_pack_wfrag": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ldmk_winograd_tiles": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "ldmk_winograd_input": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ldmk_winograd_output": (C.c_int, [_fp, _fp, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_fold_layernorm": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "ldmk_attn_force_qt": (None, [C.c_int]),
     "ldmk_gn_chunks": (C.c_int, [C.c_int]),

@@ -215,6 +215,43 @@ def fold_layernorm(wp, gamma, beta, bias=None):
     return w2, cs, b2
 
 
+# ------------------------------------------------------------------------------------------ Winograd F(2x2, 3x3)
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def pack_winograd(w):
+    """torch conv weight [cout][cin][3][3] -> U[16][cin][cout] with U[4i+j] = (G g G^T)[i][j] (computed in float64): the
+    16 [K][N] weight matrices of the batched GEMM between the Winograd transforms."""
+    _chk(w, "pack_winograd")
+    g = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    u = torch.einsum("ia,ocab,jb->ijco", g, w.double(), g)
+    return u.reshape(16, w.shape[1], w.shape[0]).float().contiguous()
+
+
+def conv3x3_winograd(x, u, bias=None, x1=None, coef=None, silu=True, batch_vec=None, residual=None, out=None, stats_out=None,
+                     scratch=None):
+    """Stride-1 pad-1 3x3 convolution through Winograd F(2x2,3x3): x (n,h,w,c0) [+ x1 channel concat], u = pack_winograd(w).
+    `coef`: GroupNorm scale/shift planes applied (with SiLU if `silu`) to the input first."""
+    n, h, w_, c0 = x.shape
+    c1 = 0 if x1 is None else x1.shape[-1]
+    K, N = u.shape[1], u.shape[2]
+    assert K == c0 + c1
+    tiles = n * (h // 2) * (w_ // 2)
+    if scratch is None:
+        scratch = (torch.empty(16, tiles, K, device=x.device), torch.empty(16, tiles, N, device=x.device))
+    V, Mb = scratch
+    if out is None:
+        out = torch.empty(n, h, w_, N, device=x.device, dtype=torch.float32)
+    L.call("ldmk_winograd_input", _ptr(x), c0, _ptr(x1), c1, _ptr(coef), 1 if (silu and coef is not None) else 0, n, h, w_,
+           _ptr(V), stream())
+    a = make_igemm_args(tiles, N, K, V, K, u, Mb, N, tiles, batch=16, a_bstride=tiles * K, w_bstride=K * N,
+                        out_bstride=tiles * N)
+    igemm(a)
+    L.call("ldmk_winograd_output", _ptr(Mb), _ptr(bias), _ptr(batch_vec), 0 if batch_vec is None else batch_vec.stride(0),
+           _ptr(residual), _ptr(out), _ptr(stats_out), n, h, w_, N, stream())
+    return out
+
+
 def bmm(a, b, b_trans, alpha=1.0, out=None):
     """Batched a[B][M][K] x (b[B][K][N] | b[B][N][K]^T) -> [B][M][N] on the matrix cores."""
     B, M, K = a.shape

@@ -235,6 +235,11 @@ class UNetModel(nn.Module):
         def res(prefix, m):
             P[prefix + "c1"] = ops.pack_conv3x3(sd[prefix + "in_layers.2.weight"])
             P[prefix + "c2"] = ops.pack_conv3x3(sd[prefix + "out_layers.3.weight"])
+            # Winograd-domain weights for the convolutions wide enough to take that route (NetBuilder.gn_conv decides per size)
+            if m.cin >= NetBuilder.WINO_MIN_CIN:
+                P[prefix + "c1#wg"] = ops.pack_winograd(sd[prefix + "in_layers.2.weight"])
+            if m.cout >= NetBuilder.WINO_MIN_CIN:
+                P[prefix + "c2#wg"] = ops.pack_winograd(sd[prefix + "out_layers.3.weight"])
             if m.cin != m.cout:
                 P[prefix + "skip"] = ops.pack_linear(sd[prefix + "skip_connection.weight"])
 
@@ -342,24 +347,23 @@ class UNetModel(nn.Module):
             hw = h * w
             # GroupNorm+SiLU materialised once (stats pass + one elementwise pass over the concat); the conv
             # then reads it raw -- cheaper than re-normalising every element 9 x (N/tile) times in the gather
-            y1 = nb_.gn_act(x0, x1, hw, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5)
+            # (gn_conv: one elementwise GroupNorm+SiLU pass + implicit-GEMM conv, or the Winograd route for the wide levels)
             bv = emb_all.data_ptr() + 4 * self._emb_off[prefix]
-            h1 = conv(y1.view(n, h, w, m.cin), None, P[prefix + "c1"], sd[prefix + "in_layers.2.bias"], h, w,
-                      batch_vec=bv, bv_ld=self._emb_total, stats=True)
-            nb_.release(y1)
-            y2 = nb_.gn_act(h1, None, hw, sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"], 1e-5)
-            nb_.release(h1)
-            y2 = y2.view(n, h, w, m.cout)
+            h1 = nb_.gn_conv(x0, x1, h, w, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5,
+                             P[prefix + "c1"], P.get(prefix + "c1#wg"), sd[prefix + "in_layers.2.bias"], batch_vec=bv,
+                             bv_ld=self._emb_total, stats=True)
+            g2, b2 = sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"]
             if m.cin != m.cout:
                 x0r = x0.reshape(n * hw, -1)
                 x1r = None if x1 is None else x1.reshape(n * hw, -1)
                 skip = lin(x0r, P[prefix + "skip"], sd[prefix + "skip_connection.bias"], hw, x1=x1r, wf=P.get(prefix + "skip#f"))
-                out = conv(y2, None, P[prefix + "c2"], sd[prefix + "out_layers.3.bias"], h, w, residual=skip,
-                           out=skip.view(n, h, w, m.cout), stats=True)
+                out = nb_.gn_conv(h1, None, h, w, g2, b2, 1e-5, P[prefix + "c2"], P.get(prefix + "c2#wg"),
+                                  sd[prefix + "out_layers.3.bias"], residual=skip, out=skip.view(n, h, w, m.cout), stats=True)
             else:
                 assert x1 is None
-                out = conv(y2, None, P[prefix + "c2"], sd[prefix + "out_layers.3.bias"], h, w, residual=x0, stats=True)
-            nb_.release(y2)
+                out = nb_.gn_conv(h1, None, h, w, g2, b2, 1e-5, P[prefix + "c2"], P.get(prefix + "c2#wg"),
+                                  sd[prefix + "out_layers.3.bias"], residual=x0, stats=True)
+            nb_.release(h1)
             return out
 
         def spatial_tf(prefix, m, x, h, w):

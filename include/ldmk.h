@@ -141,6 +141,23 @@ int ldmk_fold_layernorm(const float* w, int ldb, int K, int N, const float* gamm
 int ldmk_igemm_plan(const ldmk_igemm_args* args, int* tile_cfg, int* splitk);
 
 /* ------------------------------------------------------------------------------------------
+ * Winograd F(2x2, 3x3) around a batched ldmk_igemm: a stride-1, pad-1 nn.Conv2d 3x3 (openaimodel.py:204,230) with 4
+ * instead of 9 multiplications per output and input channel.  H and W even; tiles = n (H/2) (W/2).
+ *   ldmk_winograd_input : V[16][tiles][c0+c1] = B^T d B of the 4x4 patches of (the channel concat of) x0 | x1 (NHWC), after
+ *                         the optional GroupNorm scale/shift planes `coef` ([n][2][C], ldmk_gn_coef) and SiLU; padding
+ *                         taps are zeros of the activated tensor.
+ *   ldmk_igemm          : batch = 16, M = tiles, K = c0+c1, N = cout, a0 = V (a_bstride = tiles K), w = U (w_bstride = K N,
+ *                         U[p] = (G g G^T)[p] as [K][N]: dsml_thesis_amd.ops.pack_winograd), out = M (out_bstride = tiles N)
+ *   ldmk_winograd_output: out (NHWC) = A^T M A + bias + batch_vec[sample] + residual; optional stats_out = the GroupNorm
+ *                         partial records of the result ([n H W / 32][cout][3], as ldmk_igemm's stats_out).
+ */
+long long ldmk_winograd_tiles(int n, int h, int w);
+int ldmk_winograd_input(const float* x0, int c0, const float* x1, int c1, const float* coef, int silu, int n, int h, int w,
+                        float* v, void* stream);
+int ldmk_winograd_output(const float* m, const float* bias, const float* batch_vec, int batch_vec_ld, const float* residual,
+                         float* out, float* stats_out, int n, int h, int w, int cout, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Normalisation statistics (HBM-bound, wave-shuffle reductions).
  * ldmk_gn_coef: GroupNorm(groups, C) statistics over an NHWC tensor that may be the channel
  *   concat of two tensors (groups may straddle the seam) -> per-(sample, channel)

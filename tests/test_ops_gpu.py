@@ -410,6 +410,50 @@ def _linear_pinned(ops, x, wp, bias, splitk, **kw):
     return out
 
 
+@pytest.mark.parametrize("case", [
+    # n, h, w, c0, c1, cout, GroupNorm+SiLU prologue, epilogue options
+    (2, 16, 16, 64, 0, 96, True, "bias+vec+res+stats"),
+    (1, 8, 8, 32, 32, 64, True, "bias+stats"),                 # channel concat; W = 8: two tile rows per GroupNorm chunk
+    (3, 4, 32, 32, 0, 32, False, "bias+res"),                   # non-square, no prologue
+    (1, 64, 64, 32, 0, 32, True, "bias+stats"),                 # W = 64: two chunks per image row
+])
+def test_conv3x3_winograd_matches_conv2d(ops, case):
+    """Winograd F(2x2,3x3) (csrc/winograd.hip + batched igemm) against F.conv2d in float64: openaimodel.py:201-204 / :226-230
+    (GroupNorm -> SiLU -> Conv2d 3x3, + timestep vector, + skip).  Same tolerance as the direct implicit-GEMM convolution."""
+    n, h, w, c0, c1, cout, pro, epi = case
+    C_ = c0 + c1
+    x = rnd(110, n, C_, h, w) * 1.3 + 0.2
+    wt, b = rnd(111, cout, C_, 3, 3) / np.sqrt(9 * C_), 0.1 * rnd(112, cout)
+    gamma, beta = 1 + 0.1 * rnd(113, C_), 0.1 * rnd(114, C_)
+    vec, res = rnd(115, n, cout), rnd(116, n, cout, h, w)
+    a = x.double()
+    if pro:
+        a = F.silu(F.group_norm(a, 32 if C_ % 32 == 0 else 8, gamma.double(), beta.double(), 1e-5))
+    ref = F.conv2d(a, wt.double(), b.double(), padding=1)
+    kw = dict(bias=b.cuda())
+    if "vec" in epi:
+        ref = ref + vec.double()[:, :, None, None]
+        kw.update(batch_vec=vec.cuda())
+    if "res" in epi:
+        ref = ref + res.double()
+        kw.update(residual=nhwc(res))
+    xc = nhwc(x)
+    x0 = xc[..., :c0].contiguous()
+    x1 = xc[..., c0:].contiguous() if c1 else None
+    if pro:
+        kw.update(coef=ops.gn_coef(x0, x1, n, h * w, gamma.cuda(), beta.cuda(), 1e-5, groups=32 if C_ % 32 == 0 else 8))
+    part = torch.zeros(n * h * w // 32, cout, 3, device="cuda") if "stats" in epi else None
+    y = ops.conv3x3_winograd(x0, ops.pack_winograd(wt.cuda()), x1=x1, stats_out=part, **kw)
+    close(nchw(y), ref.float(), 1e-4, 1e-4)
+    if part is not None:      # the GroupNorm partial records of the result equal the stand-alone statistics pass
+        from dsml_thesis_amd import lib as L
+        ref_part = torch.empty_like(part)
+        L.call("ldmk_gn_partial", y.data_ptr(), cout, n, h * w, ref_part.data_ptr(), ops.stream())
+        full = lambda p_: (p_[..., 1] + 32 * p_[..., 0], p_[..., 2] + 2 * p_[..., 0] * p_[..., 1] + 32 * p_[..., 0] ** 2)
+        for got, want in zip(full(part.double()), full(ref_part.double())):
+            close(got, want, 1e-4, 1e-3)
+
+
 def test_row_gemm_rejects_what_it_cannot_run(ops):
     from dsml_thesis_amd import lib as L
     x, w = rnd(80, 64, 160).cuda(), rnd(81, 96, 160).cuda()

@@ -86,6 +86,25 @@ def test_unet_northstar_64_golden():
     close(eps, g["ns_eps"], 3e-5, 3e-5)
 
 
+def test_unet_winograd_route_against_the_reference_fixtures(monkeypatch):
+    """The wide ResBlock convolutions take the Winograd F(2x2,3x3) route only from ~1024 tiles up (batch 16 at the
+    benchmark sizes); the fixtures are batch 1-2.  Lower the threshold so that every eligible convolution of these small
+    batches goes through it, and hold the result to the same reference fixtures and the same bound as the direct route."""
+    from dsml_thesis_amd.engine import NetBuilder
+    monkeypatch.setattr(NetBuilder, "WINO_MIN_TILES", 1)
+    g = golden("g4_unet_fr.npz")
+    m, _ = make_unet(W.FR_UNET)
+    x, t, ctx = rnd(41, 2, 3, 32, 32), torch.tensor([3, 981]), rnd(42, 2, 1, 512)
+    eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
+    launches = [c[3] for c in m.program(2, 32, 32, 1, 0).calls]
+    assert launches.count("ldmk_winograd_input") >= 10 and "ldmk_gn_apply" in launches      # 160-channel convs stay direct
+    close(eps, g["fr_eps"], 3e-5, 3e-5)
+    assert torch.equal(eps, m(x.cuda(), t.cuda(), context=ctx.cuda()))
+    m2, _ = make_unet(W.NS_UNET)
+    eps = m2(rnd(43, 1, 4, 64, 64).cuda(), torch.tensor([501]).cuda(), context=rnd(44, 1, 1, 512).cuda())
+    close(eps, g["ns_eps"], 3e-5, 3e-5)
+
+
 def test_unet_multi_token_context_vs_oracle():
     # L_ctx = 3 exercises the general cross-attention kernel (the shipped configs use L_ctx = 1)
     m, sd = make_unet(W.FR_UNET)

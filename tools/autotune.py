@@ -115,7 +115,7 @@ def tune_program(pg, table):
         rows_retune = ROWS_RETUNE and a.w_frag and a.a_mode == 0 and not a.b_trans
         if FORCE and key in table and key not in seen:
             del table[key]                      # --force: forget the recorded plan, sweep everything again
-        if key in seen or a.batch > 1 or (key in table and not rows_retune):
+        if key in seen or (a.batch > 1 and not getattr(a, "_winograd", False)) or (key in table and not rows_retune):
             continue
         saved = (a.tile_cfg, a.splitk, a.splitk_ws, a.splitk_ws_elems, a.out, a.stats_out, a.residual)
         saved_a = (a.a0, a.a1)
@@ -131,7 +131,7 @@ def tune_program(pg, table):
             a.a1 = sa1.data_ptr()
         touch = (sa0,) if sa1 is None else (sa0, sa1)
         # time into scratch so that in-place residual / stats outputs of the real program are not disturbed
-        scratch = torch.empty(a.M * max(a.ldc, 1) + 16, device="cuda")
+        scratch = torch.empty(a.M * max(a.ldc, 1) + 16 + (max(1, a.batch) - 1) * a.out_bstride, device="cuda")
         a.out = scratch.data_ptr()
         if a.residual == saved[4]:
             a.residual = scratch.data_ptr()
@@ -160,7 +160,7 @@ def tune_program(pg, table):
                 continue
             iters = -(-nkc // CFG_WK[cfg])
             for sk in SKS:
-                if sk > 1 and (a.epi == 1 or iters // sk < 1 or sk * a.M * a.N > ws.numel()):
+                if sk > 1 and (a.epi == 1 or iters // sk < 1 or max(1, a.batch) * sk * a.M * a.N > ws.numel()):
                     continue
                 a.tile_cfg, a.splitk = cfg, sk
                 a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
