@@ -30,7 +30,7 @@ def dump(latent, batch, path):
             a = keep
             from dsml_thesis_amd.engine import plan_key
             calls.append(dict(name=name, M=a.M, N=a.N, K=a.K, conv=a.a_mode, tf=a.a_tf, epi=a.epi, cfg=a.tile_cfg,
-                              sk=a.splitk, key=plan_key(a, a.M)))
+                              sk=a.splitk, key=plan_key(a, a.M), batch=max(1, a.batch)))
         else:
             calls.append(dict(name=name))
     json.dump(dict(calls=calls, marker_steps=3), open(path, "w"))
@@ -44,7 +44,8 @@ KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "rgemm_kernel"), "ldmk_gn_finalize":
              "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_attn_self": ("attn_self",),
              "ldmk_attn_cross": ("attn_cross",), "ldmk_dense_small": ("dense_small",),
              "ldmk_timestep_embedding": ("timestep_embedding",), "ldmk_conv3x3_in": ("conv3x3_in",),
-             "ldmk_conv3x3_out": ("conv3x3_out",)}
+             "ldmk_conv3x3_out": ("conv3x3_out",), "ldmk_winograd_input": ("wino_input",),
+             "ldmk_winograd_output": ("wino_output",)}
 PEAK_F32_MFMA = 157.3
 
 
@@ -89,13 +90,15 @@ def join(d):
     for c, d_ in out:
         if c["name"] == "ldmk_igemm":
             key = f"igemm M={c['M']:6d} N={c['N']:5d} K={c['K']:6d} conv={c['conv']} tf={c['tf']} epi={c['epi']} cfg={c['cfg']} sk={c.get('sk', 1)}"
+            if c.get("batch", 1) > 1:
+                key += f" x{c['batch']} (Winograd)"
         else:
             key = c["name"]
         a = agg.setdefault(key, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += d_
         if c["name"] == "ldmk_igemm":
-            a[2] += 2.0 * c["M"] * c["N"] * c["K"]
+            a[2] += 2.0 * c["M"] * c["N"] * c["K"] * c.get("batch", 1)
     print(f"{'call':75s} {'n':>3s} {'us_total':>10s} {'pct':>6s} {'TFLOP/s':>8s}")
     fam_t = fam_f = 0.0
     for key, (n, d_, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
