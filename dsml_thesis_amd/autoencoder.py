@@ -213,6 +213,8 @@ class VQModelInterface(nn.Module):
                 if v.shape[2] == 3:
                     narrow = v.shape[1] % 32 != 0 or v.shape[0] <= 4      # conv_in / conv_out at the latent / image boundary
                     P[k] = ops.pack_conv3x3_narrow(v) if narrow else ops.pack_conv3x3(v)
+                    if not narrow and v.shape[1] >= NetBuilder.WINO_MIN_CIN and k.endswith(("conv1.weight", "conv2.weight")):
+                        P[k + "#wg"] = ops.pack_winograd(v)     # ResnetBlock convs wide enough for the Winograd route
                 elif k.startswith(("quant_conv", "post_quant_conv")):
                     P[k] = v.reshape(v.shape[0], v.shape[1]).contiguous()      # narrow NCHW 1x1: [cout][cin]
                 else:
@@ -226,21 +228,19 @@ class VQModelInterface(nn.Module):
     # ---- shared block emitters -----------------------------------------------------------------------
     def _resnet_block(self, nb, prefix, m, x, h, w):
         pg, P, sd, n = nb.pg, self._packed, self._sd, nb.n
-        y1 = nb.gn_act(x, None, h * w, sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"], 1e-6)
-        h1 = nb.conv(y1.view(n, h, w, m.cin), None, P[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], h, w,
-                     stats=True)
-        nb.release(y1)
-        y2 = nb.gn_act(h1, None, h * w, sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"], 1e-6)
-        nb.release(h1)
-        y2 = y2.view(n, h, w, m.cout)
+        # GroupNorm+SiLU then conv: one elementwise pass + implicit GEMM, or (wide blocks, large batches) the Winograd route
+        h1 = nb.gn_conv(x, None, h, w, sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"], 1e-6, P[prefix + "conv1.weight"],
+                        P.get(prefix + "conv1.weight#wg"), sd[prefix + "conv1.bias"], stats=True)
+        g2, b2 = sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"]
         if m.cin != m.cout:
             sk = nb.lin(x.reshape(n * h * w, m.cin), P[prefix + "nin_shortcut.weight"], sd[prefix + "nin_shortcut.bias"],
                         h * w)
-            out = nb.conv(y2, None, P[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], h, w, residual=sk,
-                          out=sk.view(n, h, w, m.cout), stats=True)
+            out = nb.gn_conv(h1, None, h, w, g2, b2, 1e-6, P[prefix + "conv2.weight"], P.get(prefix + "conv2.weight#wg"),
+                             sd[prefix + "conv2.bias"], residual=sk, out=sk.view(n, h, w, m.cout), stats=True)
         else:
-            out = nb.conv(y2, None, P[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], h, w, residual=x, stats=True)
-        nb.release(y2)
+            out = nb.gn_conv(h1, None, h, w, g2, b2, 1e-6, P[prefix + "conv2.weight"], P.get(prefix + "conv2.weight#wg"),
+                             sd[prefix + "conv2.bias"], residual=x, stats=True)
+        nb.release(h1)
         return out
 
     def _attn(self, nb, prefix, m, x, h, w):

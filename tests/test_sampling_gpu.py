@@ -106,6 +106,23 @@ def test_p_sample_loop_T3(fr):
     close(out, g["p_sample_loop_T3"], 1e-4, 1e-4)
 
 
+def test_first_stage_winograd_route_golden(monkeypatch):
+    """The VQGAN's 512-channel ResnetBlocks (model.py:95-129) take the Winograd route only for large batches; force it for
+    one frame and hold decoder and encoder to the same reference fixtures and bounds as the direct route."""
+    from dsml_thesis_amd.engine import NetBuilder
+    monkeypatch.setattr(NetBuilder, "WINO_MIN_TILES", 1)
+    m = make_fr_model()
+    z = rnd(61, 1, 3, 32, 32).cuda()
+    img, idx = m.first_stage_model.decode(z, return_indices=True)
+    fs = m.first_stage_model
+    launches = [c[3] for pg in fs._programs.values() for c in pg.calls]
+    assert launches.count("ldmk_winograd_input") >= 10
+    assert np.array_equal(idx.cpu().numpy(), golden("g6_vqgan.npz")["vq_idx"].reshape(-1))
+    close(img, golden("g11_northstar.npz")["decoded128"], 1e-4, 1e-4)
+    x = torch.tanh(rnd(64, 1, 3, 128, 128)).cuda()
+    close(m.encode_first_stage(x), golden("g6_vqgan.npz")["encoded"], 1e-4, 1e-4)
+
+
 def test_first_stage_decode_encode_golden():
     g = golden("g6_vqgan.npz")
     m = make_fr_model()
