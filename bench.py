@@ -110,7 +110,7 @@ class StepRunner:
         for _ in range(reps):
             evs, tevs = [], []
             for fn, args, _, name in pg.calls:
-                if name in ("ldmk_igemm", "ldmk_winograd_input", "ldmk_winograd_output"):
+                if name in ("ldmk_igemm", "ldmk_winograd_input", "ldmk_winograd_output", "ldmk_upconv_gather", "ldmk_upconv_scatter"):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     rc = fn(*args, st)
@@ -138,14 +138,12 @@ def executed_gemm_flops(pg):
 
 def algorithmic_gemm_flops(pg):
     """FLOPs of the Conv2d / Linear layers those launches compute, in the reference's arithmetic: 2 M N K, and for a
-    convolution that runs through Winograd F(2x2,3x3) (16 batched GEMMs over M/4 tiles) the direct form's 2 (4 tiles) N (9 C)."""
+    convolution that runs through Winograd F(2x2,3x3) (16 batched GEMMs over M/4 tiles) or as four 2x2-tap phase convolutions
+    (nearest-x2 upsampling + conv) the direct form's 2 M N (9 C)."""
     fl = 0.0
     for _, _, a, name in pg.calls:
         if name == "ldmk_igemm":
-            if getattr(a, "_winograd", False):
-                fl += 2.0 * (4 * a.M) * a.N * (9 * a.K)
-            else:
-                fl += 2.0 * a.M * a.N * a.K * max(1, a.batch)
+            fl += getattr(a, "_algo_flops", 2.0 * a.M * a.N * a.K * max(1, a.batch))
     return fl
 
 

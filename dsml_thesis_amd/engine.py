@@ -306,6 +306,7 @@ class NetBuilder:
         a = ops.make_igemm_args(tiles, cout, cin, V, cin, u, Mb, cout, tiles, batch=16, a_bstride=tiles * cin,
                                 w_bstride=cin * cout, out_bstride=tiles * cout)
         a._winograd = True            # (tools/autotune.py sweeps these batched problems; per-sample batches are not planned by table)
+        a._algo_flops = 2.0 * (4 * tiles) * cout * (9 * cin)      # the direct convolution's arithmetic (bench.py)
         pg.igemm(a, self.pin, batch_is_samples=False)
         part = None
         out2d = out.view(-1, cout)
@@ -317,6 +318,39 @@ class NetBuilder:
             self.attach_stats(out2d, part)
         self.release(coef)
         pg.release(V, Mb)
+        return out
+
+    def up_conv(self, x, h, w, wp, w4, bias, stats=False):
+        """Upsample (nearest x2) + Conv2d 3x3: the implicit GEMM with the upsampling folded into its gather, or -- `w4`
+        (ops.pack_upconv) given, >= 320 channels, >= 1024 low-resolution pixels at the plan-policy batch -- four 2x2-tap phase
+        convolutions on the low-resolution input: 4/9 of the multiplications, exact (measured: 898 -> 522 us for 640->640 at
+        16x16 -> 32x32, B = 16)."""
+        import os
+        pg, n, ops, p_ = self.pg, self.n, self.ops, self.ptr
+        c = x.shape[-1]
+        pol_n = self.pin[0] if self.pin else n
+        if (w4 is None or os.environ.get("LDMK_NO_WINOGRAD") or c < self.WINO_MIN_CIN or pol_n * h * w < self.WINO_MIN_TILES
+                or w not in (8, 16, 32)):
+            return self.conv(x, None, wp, bias, h, w, upsample=True, stats=stats)
+        cout = w4.shape[2]
+        pix = n * h * w
+        A, Pm = pg.alloc(4, pix, 4 * c), pg.alloc(4, pix, cout)
+        out = pg.alloc(n, 2 * h, 2 * w, cout)
+        pg.add("ldmk_upconv_gather", p_(x), c, n, h, w, p_(A))
+        a = ops.make_igemm_args(pix, cout, 4 * c, A, 4 * c, w4, Pm, cout, pix, batch=4, a_bstride=pix * 4 * c,
+                                w_bstride=4 * c * cout, out_bstride=pix * cout)
+        a._winograd = True            # a batch of transform planes, not of samples: planned by table like the Winograd GEMMs
+        a._algo_flops = 2.0 * (4 * pix) * cout * (9 * c)
+        pg.igemm(a, self.pin, batch_is_samples=False)
+        part = None
+        out2d = out.view(-1, cout)
+        if stats:
+            self.drop_stats(out2d)
+            part = self.stats_buffer(4 * pix, cout)
+        pg.add("ldmk_upconv_scatter", p_(Pm), p_(bias), p_(out), p_(part), n, h, w, cout)
+        if stats:
+            self.attach_stats(out2d, part)
+        pg.release(A, Pm)
         return out
 
     def _maybe_stats(self, a, out2d, rows_per_sample, stats):

@@ -60,6 +60,8 @@ _SIGS = {
     "ldmk_winograd_tiles": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "ldmk_winograd_input": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ldmk_winograd_output": (C.c_int, [_fp, _fp, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_upconv_gather": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ldmk_upconv_scatter": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_fold_layernorm": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "ldmk_attn_force_qt": (None, [C.c_int]),
     "ldmk_gn_chunks": (C.c_int, [C.c_int]),

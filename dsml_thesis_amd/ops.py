@@ -252,6 +252,43 @@ def conv3x3_winograd(x, u, bias=None, x1=None, coef=None, silu=True, batch_vec=N
     return out
 
 
+_UP_TAPS = (((0,), (1, 2)), ((0, 1), (2,)))      # [parity][collapsed tap] -> the 3x3 taps it sums
+
+
+def pack_upconv(w):
+    """torch conv weight [cout][cin][3][3] of an Upsample layer -> Wp[4 phases][4 taps * cin][cout]: for output parity (a, b)
+    the 2x2-tap kernel whose tap (i, j) sums the 3x3 taps that read the same low-resolution pixel (float64 sums)."""
+    _chk(w, "pack_upconv")
+    cout, cin = w.shape[0], w.shape[1]
+    wd = w.double()
+    out = torch.empty(4, 4 * cin, cout, dtype=torch.float64, device=w.device)
+    for a in range(2):
+        for b in range(2):
+            for i in range(2):
+                for j in range(2):
+                    acc = sum(wd[:, :, dy, dx] for dy in _UP_TAPS[a][i] for dx in _UP_TAPS[b][j])        # [cout][cin]
+                    out[2 * a + b, (2 * i + j) * cin:(2 * i + j + 1) * cin] = acc.t()
+    return out.float().contiguous()
+
+
+def upsample_conv3x3_phases(x, wp4, bias=None, out=None, stats_out=None, scratch=None):
+    """Nearest-x2 upsample + 3x3 conv through the four 2x2-tap phase convolutions: x (n,h,w,c) -> (n,2h,2w,cout)."""
+    n, h, w_, c = x.shape
+    N = wp4.shape[2]
+    pix = n * h * w_
+    if scratch is None:
+        scratch = (torch.empty(4, pix, 4 * c, device=x.device), torch.empty(4, pix, N, device=x.device))
+    A, Pm = scratch
+    if out is None:
+        out = torch.empty(n, 2 * h, 2 * w_, N, device=x.device, dtype=torch.float32)
+    L.call("ldmk_upconv_gather", _ptr(x), c, n, h, w_, _ptr(A), stream())
+    a = make_igemm_args(pix, N, 4 * c, A, 4 * c, wp4, Pm, N, pix, batch=4, a_bstride=pix * 4 * c, w_bstride=4 * c * N,
+                        out_bstride=pix * N)
+    igemm(a)
+    L.call("ldmk_upconv_scatter", _ptr(Pm), _ptr(bias), _ptr(out), _ptr(stats_out), n, h, w_, N, stream())
+    return out
+
+
 def bmm(a, b, b_trans, alpha=1.0, out=None):
     """Batched a[B][M][K] x (b[B][K][N] | b[B][N][K]^T) -> [B][M][N] on the matrix cores."""
     B, M, K = a.shape

@@ -281,6 +281,8 @@ class UNetModel(nn.Module):
                 P[prefix + "w"] = ops.pack_conv3x3(sd[prefix + "op.weight"])
             elif m.kind == "up":
                 P[prefix + "w"] = ops.pack_conv3x3(sd[prefix + "conv.weight"])
+                if sd[prefix + "conv.weight"].shape[1] >= NetBuilder.WINO_MIN_CIN:      # four 2x2-tap phase convolutions
+                    P[prefix + "w#up"] = ops.pack_upconv(sd[prefix + "conv.weight"])
         # every ResBlock's emb_layers Linear batched into one [4mc][sum cout] matrix
         P["emb_all"] = ops.pack_linear(torch.cat(emb_w, 0).contiguous())
         P["emb_all_b"] = torch.cat(emb_b, 0).contiguous()
@@ -445,7 +447,7 @@ class UNetModel(nn.Module):
                     out = conv(cur0, None, P[p + "w"], sd[p + "op.bias"], h, w, stride=2, stats=True)
                     h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
                 elif m.kind == "up":
-                    out = conv(cur0, None, P[p + "w"], sd[p + "conv.bias"], h, w, upsample=True, stats=True)
+                    out = nb_.up_conv(cur0, h, w, P[p + "w"], P.get(p + "w#up"), sd[p + "conv.bias"], stats=True)
                     h, w = 2 * h, 2 * w
                 else:
                     raise AssertionError(m.kind)

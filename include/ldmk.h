@@ -157,6 +157,15 @@ int ldmk_winograd_input(const float* x0, int c0, const float* x1, int c1, const 
 int ldmk_winograd_output(const float* m, const float* bias, const float* batch_vec, int batch_vec_ld, const float* residual,
                          float* out, float* stats_out, int n, int h, int w, int cout, void* stream);
 
+/* Nearest-x2 upsampling + Conv2d 3x3 (openaimodel.py:107-118) as four 2x2-tap convolutions on the low-resolution input
+ * (one per output parity; exact: the collapsed taps carry the summed weights) -- 4/9 of the multiplications:
+ *   ldmk_upconv_gather : A[4][n h w][4 c] (tap-major K), zeros outside the image
+ *   ldmk_igemm         : batch = 4, M = n h w, K = 4 c, N = cout, w from dsml_thesis_amd.ops.pack_upconv (w_bstride = K N)
+ *   ldmk_upconv_scatter: out (n, 2h, 2w, cout) NHWC = the 4 planes interleaved + bias; optional GroupNorm partial records */
+int ldmk_upconv_gather(const float* x, int c, int n, int h, int w, float* a, void* stream);
+int ldmk_upconv_scatter(const float* planes, const float* bias, float* out, float* stats_out, int n, int h, int w, int cout,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Normalisation statistics (HBM-bound, wave-shuffle reductions).
  * ldmk_gn_coef: GroupNorm(groups, C) statistics over an NHWC tensor that may be the channel

@@ -454,6 +454,26 @@ def test_conv3x3_winograd_matches_conv2d(ops, case):
             close(got, want, 1e-4, 1e-3)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 8, 64, 96), (1, 16, 32, 32, 32), (3, 4, 8, 32, 64)])
+def test_upsample_conv_phases_match_interpolate_conv2d(ops, n, h, w, cin, cout):
+    """Upsample (nearest x2) + Conv2d 3x3 (openaimodel.py:107-118) as four 2x2-tap phase convolutions on the low-resolution
+    input, against F.interpolate + F.conv2d in float64, and against the folded-gather implicit GEMM it replaces."""
+    x = rnd(120, n, cin, h, w)
+    wt, b = rnd(121, cout, cin, 3, 3) / np.sqrt(9 * cin), 0.1 * rnd(122, cout)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), wt.double(), b.double(), padding=1)
+    part = torch.zeros(n * 4 * h * w // 32, cout, 3, device="cuda")
+    y = ops.upsample_conv3x3_phases(nhwc(x), ops.pack_upconv(wt.cuda()), b.cuda(), stats_out=part)
+    close(nchw(y), ref.float(), 1e-4, 1e-4)
+    y_direct = ops.conv3x3(nhwc(x), ops.pack_conv3x3(wt.cuda()), b.cuda(), upsample=True)
+    close(y, y_direct, 1e-4, 1e-4)
+    from dsml_thesis_amd import lib as L
+    ref_part = torch.empty_like(part)
+    L.call("ldmk_gn_partial", y.data_ptr(), cout, n, 4 * h * w, ref_part.data_ptr(), ops.stream())
+    full = lambda p_: (p_[..., 1] + 32 * p_[..., 0], p_[..., 2] + 2 * p_[..., 0] * p_[..., 1] + 32 * p_[..., 0] ** 2)
+    for got, want in zip(full(part.double()), full(ref_part.double())):
+        close(got, want, 1e-4, 1e-3)
+
+
 def test_row_gemm_rejects_what_it_cannot_run(ops):
     from dsml_thesis_amd import lib as L
     x, w = rnd(80, 64, 160).cuda(), rnd(81, 96, 160).cuda()

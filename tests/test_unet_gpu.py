@@ -98,6 +98,7 @@ def test_unet_winograd_route_against_the_reference_fixtures(monkeypatch):
     eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
     launches = [c[3] for c in m.program(2, 32, 32, 1, 0).calls]
     assert launches.count("ldmk_winograd_input") >= 10 and "ldmk_gn_apply" in launches      # 160-channel convs stay direct
+    assert launches.count("ldmk_upconv_gather") == 2                  # both Upsample convolutions as four 2x2-tap phases
     close(eps, g["fr_eps"], 3e-5, 3e-5)
     assert torch.equal(eps, m(x.cuda(), t.cuda(), context=ctx.cuda()))
     m2, _ = make_unet(W.NS_UNET)

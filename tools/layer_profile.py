@@ -45,7 +45,8 @@ KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "rgemm_kernel"), "ldmk_gn_finalize":
              "ldmk_attn_cross": ("attn_cross",), "ldmk_dense_small": ("dense_small",),
              "ldmk_timestep_embedding": ("timestep_embedding",), "ldmk_conv3x3_in": ("conv3x3_in",),
              "ldmk_conv3x3_out": ("conv3x3_out",), "ldmk_winograd_input": ("wino_input",),
-             "ldmk_winograd_output": ("wino_output",)}
+             "ldmk_winograd_output": ("wino_output",), "ldmk_upconv_gather": ("upconv_gather",),
+             "ldmk_upconv_scatter": ("upconv_scatter",)}
 PEAK_F32_MFMA = 157.3
 
 
@@ -91,7 +92,7 @@ def join(d):
         if c["name"] == "ldmk_igemm":
             key = f"igemm M={c['M']:6d} N={c['N']:5d} K={c['K']:6d} conv={c['conv']} tf={c['tf']} epi={c['epi']} cfg={c['cfg']} sk={c.get('sk', 1)}"
             if c.get("batch", 1) > 1:
-                key += f" x{c['batch']} (Winograd)"
+                key += f" x{c['batch']} ({'Winograd' if c['batch'] == 16 else 'upsample phases'})"
         else:
             key = c["name"]
         a = agg.setdefault(key, [0, 0.0, 0.0])

@@ -18,7 +18,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--upsample", action="store_true")
     a = ap.parse_args()
+    if a.upsample:
+        return upsample_main(a)
     n = a.batch
     for lvl, cin, cout in ((2, 640, 640), (2, 1280, 640), (2, 960, 640), (1, 320, 320), (1, 640, 320), (0, 160, 160)):
         h = a.latent >> lvl
@@ -45,6 +48,25 @@ def main():
         gf = 2.0 * n * h * h * cout * 9 * cin * 1e-9
         print(f"{cin:5d}->{cout:4d} @{h:2d}x{h:<2d} n={n}: gn_apply + direct {td:7.1f} us ({gf / td * 1e3:6.1f} TF)   winograd {tw:7.1f} us "
               f"({gf / tw * 1e3:6.1f} TF direct-equivalent)  x{td / tw:.2f}", flush=True)
+
+
+def upsample_main(a):
+    n = a.batch
+    for lvl, c in ((2, 640), (1, 320)):
+        h = a.latent >> lvl
+        x = torch.randn(n, h, h, c, device="cuda")
+        w = torch.randn(c, c, 3, 3, device="cuda") / (9 * c) ** 0.5
+        b = torch.randn(c, device="cuda")
+        wp, w4 = ops.pack_conv3x3(w), ops.pack_upconv(w)
+        out = torch.empty(n, 2 * h, 2 * h, c, device="cuda")
+        part = torch.zeros(n * 4 * h * h // 32, c, 3, device="cuda")
+        pix = n * h * h
+        scratch = (torch.empty(4, pix, 4 * c, device="cuda"), torch.empty(4, pix, c, device="cuda"))
+        td = timeit(lambda: ops.conv3x3(x, wp, b, upsample=True, out=out))
+        tp = timeit(lambda: ops.upsample_conv3x3_phases(x, w4, b, out=out, stats_out=part, scratch=scratch))
+        gf = 2.0 * n * 4 * h * h * c * 9 * c * 1e-9
+        print(f"upsample {c}->{c} {h}x{h}->{2 * h}x{2 * h} n={n}: folded-gather conv {td:7.1f} us ({gf / td * 1e3:6.1f} TF)   four 2x2-tap phases "
+              f"{tp:7.1f} us ({gf / tp * 1e3:6.1f} TF direct-equivalent)  x{td / tp:.2f}", flush=True)
 
 
 if __name__ == "__main__":
