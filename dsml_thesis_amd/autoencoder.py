@@ -215,6 +215,8 @@ class VQModelInterface(nn.Module):
                     P[k] = ops.pack_conv3x3_narrow(v) if narrow else ops.pack_conv3x3(v)
                     if not narrow and v.shape[1] >= NetBuilder.WINO_MIN_CIN and k.endswith(("conv1.weight", "conv2.weight")):
                         P[k + "#wg"] = ops.pack_winograd(v)     # ResnetBlock convs wide enough for the Winograd route
+                    if not narrow and v.shape[1] >= NetBuilder.WINO_MIN_CIN and k.endswith("upsample.conv.weight"):
+                        P[k + "#up"] = ops.pack_upconv(v)       # Upsample conv as four 2x2-tap phase convolutions
                 elif k.startswith(("quant_conv", "post_quant_conv")):
                     P[k] = v.reshape(v.shape[0], v.shape[1]).contiguous()      # narrow NCHW 1x1: [cout][cin]
                 else:
@@ -312,8 +314,8 @@ class VQModelInterface(nn.Module):
                 if len(up.attn) > 0:
                     step(self._attn, f"decoder.up.{lvl}.attn.{ib}.", up.attn[ib], ch_, cw_)
             if lvl != 0:
-                y = nb.conv(x, None, P[f"decoder.up.{lvl}.upsample.conv.weight"],
-                            sd[f"decoder.up.{lvl}.upsample.conv.bias"], ch_, cw_, upsample=True, stats=True)
+                kw_ = f"decoder.up.{lvl}.upsample.conv.weight"
+                y = nb.up_conv(x, ch_, cw_, P[kw_], P.get(kw_ + "#up"), sd[f"decoder.up.{lvl}.upsample.conv.bias"], stats=True)
                 nb.release(x)
                 x = y
                 ch_, cw_ = 2 * ch_, 2 * cw_
