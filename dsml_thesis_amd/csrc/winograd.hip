@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 // One workgroup = (sample, band of 2R image rows); thread <-> channel (coalesced over N), walking the band's tiles left to
 // right.  The band is a whole number of 32-pixel GroupNorm chunks (W = 8: R = 2; W >= 16: R = 1), so the partial records of
 // the result (same records as gn_partial_kernel: shift, sum, sum of squares of the chunk) are complete per workgroup.
-constexpr int WINO_MAX_CHUNKS = 4;      // W <= 64
+constexpr int WINO_MAX_CHUNKS = 8;      // Winograd output: W <= 128; upsample scatter: low-resolution W <= 64
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
                                                           const float* __restrict__ bvec, int bvec_ld,
                                                           const float* __restrict__ res, float* __restrict__ out,

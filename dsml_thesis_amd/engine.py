@@ -280,7 +280,7 @@ class NetBuilder:
             return False
         pol_n = self.pin[0] if self.pin else self.n
         return (cin >= self.WINO_MIN_CIN and pol_n * (h // 2) * (w // 2) >= self.WINO_MIN_TILES and h % 2 == 0
-                and w in (8, 16, 32, 64) and (h * w) % 32 == 0 and (w >= 16 or (h // 2) % 2 == 0))
+                and w in (8, 16, 32, 64, 128) and (h * w) % 32 == 0 and (w >= 16 or (h // 2) % 2 == 0))
 
     def gn_conv(self, x0, x1, h, w, gamma, beta, eps, wp, u, bias, batch_vec=None, bv_ld=0, residual=None, out=None,
                 stats=False):
@@ -330,7 +330,7 @@ class NetBuilder:
         c = x.shape[-1]
         pol_n = self.pin[0] if self.pin else n
         if (w4 is None or os.environ.get("LDMK_NO_WINOGRAD") or c < self.WINO_MIN_CIN or pol_n * h * w < self.WINO_MIN_TILES
-                or w not in (8, 16, 32)):
+                or w not in (8, 16, 32, 64)):
             return self.conv(x, None, wp, bias, h, w, upsample=True, stats=stats)
         cout = w4.shape[2]
         pix = n * h * w

@@ -416,6 +416,7 @@ def _linear_pinned(ops, x, wp, bias, splitk, **kw):
     (1, 8, 8, 32, 32, 64, True, "bias+stats"),                 # channel concat; W = 8: two tile rows per GroupNorm chunk
     (3, 4, 32, 32, 0, 32, False, "bias+res"),                   # non-square, no prologue
     (1, 64, 64, 32, 0, 32, True, "bias+stats"),                 # W = 64: two chunks per image row
+    (1, 4, 128, 32, 0, 32, True, "bias+stats"),                 # W = 128: eight chunks per band
 ])
 def test_conv3x3_winograd_matches_conv2d(ops, case):
     """Winograd F(2x2,3x3) (csrc/winograd.hip + batched igemm) against F.conv2d in float64: openaimodel.py:201-204 / :226-230
@@ -454,7 +455,7 @@ def test_conv3x3_winograd_matches_conv2d(ops, case):
             close(got, want, 1e-4, 1e-3)
 
 
-@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 8, 64, 96), (1, 16, 32, 32, 32), (3, 4, 8, 32, 64)])
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 8, 64, 96), (1, 16, 32, 32, 32), (3, 4, 8, 32, 64), (1, 2, 64, 32, 32)])
 def test_upsample_conv_phases_match_interpolate_conv2d(ops, n, h, w, cin, cout):
     """Upsample (nearest x2) + Conv2d 3x3 (openaimodel.py:107-118) as four 2x2-tap phase convolutions on the low-resolution
     input, against F.interpolate + F.conv2d in float64, and against the folded-gather implicit GEMM it replaces."""
