@@ -271,8 +271,12 @@ class NetBuilder:
     # work is power-limited; the transforms replace the gn_apply pass and the convolution's epilogue.  The decision is made on
     # the plan-policy batch (pin[0]), like the tile plans, so a sample's result does not depend on how a batch is sharded.
     # Measured on MI355X (tools/winograd_bench.py, in-step times of the direct form): wins from 320 input channels and
-    # ~1024 tiles up (16x: 640->640 at 16x16 243+8 -> 165 us); loses at 160 channels (transform traffic) and at batch 1.
-    WINO_MIN_TILES, WINO_MIN_CIN = 1024, 320
+    # 256 tiles up (640->640 at 16x16, B = 16: 243+8 -> 165 us); loses at 160 channels (transform traffic) and at batch 1.
+    # (the two environment overrides exist for A/B experiments only).  Tiles: 1024 -> 256 is +2.3 % at 32x32x3 B = 16 (the
+    # 640-channel level has 256 tiles there); 64 tiles (batch 1) loses 7 %.
+    WINO_MIN_TILES = int(os.environ.get("LDMK_WINO_MIN_TILES", "256"))
+    UP_MIN_PIXELS = 1024
+    WINO_MIN_CIN = int(os.environ.get("LDMK_WINO_MIN_CIN", "320"))
 
     def winograd_ok(self, cin, h, w):
         import os
@@ -322,14 +326,14 @@ class NetBuilder:
 
     def up_conv(self, x, h, w, wp, w4, bias, stats=False):
         """Upsample (nearest x2) + Conv2d 3x3: the implicit GEMM with the upsampling folded into its gather, or -- `w4`
-        (ops.pack_upconv) given, >= 320 channels, >= 1024 low-resolution pixels at the plan-policy batch -- four 2x2-tap phase
+        (ops.pack_upconv) given, >= 320 channels, >= UP_MIN_PIXELS low-resolution pixels at the plan-policy batch -- four 2x2-tap phase
         convolutions on the low-resolution input: 4/9 of the multiplications, exact (measured: 898 -> 522 us for 640->640 at
         16x16 -> 32x32, B = 16)."""
         import os
         pg, n, ops, p_ = self.pg, self.n, self.ops, self.ptr
         c = x.shape[-1]
         pol_n = self.pin[0] if self.pin else n
-        if (w4 is None or os.environ.get("LDMK_NO_WINOGRAD") or c < self.WINO_MIN_CIN or pol_n * h * w < self.WINO_MIN_TILES
+        if (w4 is None or os.environ.get("LDMK_NO_WINOGRAD") or c < self.WINO_MIN_CIN or pol_n * h * w < self.UP_MIN_PIXELS
                 or w not in (8, 16, 32, 64)):
             return self.conv(x, None, wp, bias, h, w, upsample=True, stats=stats)
         cout = w4.shape[2]

@@ -111,6 +111,7 @@ def test_first_stage_winograd_route_golden(monkeypatch):
     one frame and hold decoder and encoder to the same reference fixtures and bounds as the direct route."""
     from dsml_thesis_amd.engine import NetBuilder
     monkeypatch.setattr(NetBuilder, "WINO_MIN_TILES", 1)
+    monkeypatch.setattr(NetBuilder, "UP_MIN_PIXELS", 1)
     m = make_fr_model()
     z = rnd(61, 1, 3, 32, 32).cuda()
     img, idx = m.first_stage_model.decode(z, return_indices=True)

@@ -87,11 +87,12 @@ def test_unet_northstar_64_golden():
 
 
 def test_unet_winograd_route_against_the_reference_fixtures(monkeypatch):
-    """The wide ResBlock convolutions take the Winograd F(2x2,3x3) route only from ~1024 tiles up (batch 16 at the
+    """The wide ResBlock convolutions take the Winograd F(2x2,3x3) route only from 256 tiles up (batch 16 at the
     benchmark sizes); the fixtures are batch 1-2.  Lower the threshold so that every eligible convolution of these small
     batches goes through it, and hold the result to the same reference fixtures and the same bound as the direct route."""
     from dsml_thesis_amd.engine import NetBuilder
     monkeypatch.setattr(NetBuilder, "WINO_MIN_TILES", 1)
+    monkeypatch.setattr(NetBuilder, "UP_MIN_PIXELS", 1)
     g = golden("g4_unet_fr.npz")
     m, _ = make_unet(W.FR_UNET)
     x, t, ctx = rnd(41, 2, 3, 32, 32), torch.tensor([3, 981]), rnd(42, 2, 1, 512)
