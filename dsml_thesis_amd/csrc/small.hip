@@ -521,7 +521,8 @@ static inline unsigned grid_for(long long total, int block = 256, int cap = 4096
 
 using namespace ldmk;
 
-extern "C" int ldmk_version(void) { return 200; }
+// 2.1: folded LayerNorm, Winograd / upsample-phase transforms, split-K up to 64
+extern "C" int ldmk_version(void) { return 210; }
 
 namespace ldmk { void igemm_init_attributes(); }
 
