@@ -265,12 +265,13 @@ def test_talking_face_unet_gradients_with_channel_concat():
     _check_all_grads(m, tr, {k: v.grad for k, v in sdg.items()}, 1e-4)
 
 
-def _ddp_worker(rank, world, port, q, overlap=False):
+def _ddp_worker(rank, world, rdzv, q, overlap=False):
     import os
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo: both ranks share the one GPU of the box
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # gloo: both ranks share the one GPU of the box.  File rendezvous: a TCP port picked by the parent and released before
+    # the children bind it can be taken in between (seen once in ~10 full-suite runs)
+    dist.init_process_group("gloo", init_method=f"file://{rdzv}", rank=rank, world_size=world)
     m, tr, sd, _, _, _, _ = _setup(SMALL, 2, 16)
     x0, noise, ctx = rnd(201, 4, 3, 16, 16), rnd(202, 4, 3, 16, 16), rnd(203, 4, 1, 512)
     t = torch.tensor([17, 803, 400, 999])
@@ -301,15 +302,13 @@ def test_data_parallel_gradients_equal_full_batch_gradients(overlap):
     """N1 multi-GPU contract: shard the batch over ranks, one all-reduce (mean) of the flat gradient buffer ==
     the gradient of the full batch on one rank (the loss is a mean over samples).  overlap=True: the bucketed
     reduction that runs inside backward() (tail buckets of the flat buffer are reduced while earlier layers compute)."""
-    import socket
+    import os
+    import tempfile
     import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    rdzv = os.path.join(tempfile.mkdtemp(prefix="ldmk_rdzv_"), "store")
     ctx_mp = mp.get_context("spawn")
     q = ctx_mp.Queue()
-    procs = [ctx_mp.Process(target=_ddp_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
+    procs = [ctx_mp.Process(target=_ddp_worker, args=(r, 2, rdzv, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     g2 = q.get(timeout=300)
