@@ -2,7 +2,7 @@
 bench's max-over-ranks timing reduction.  The sampler itself needs a GPU, so a deterministic stand-in with the
 same (per-item independent) contract produces the per-rank blocks."""
 import os
-import socket
+import tempfile
 
 import pytest
 import torch
@@ -11,11 +11,8 @@ import torch.multiprocessing as mp
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A file rendezvous, not a port: a port picked here and released before the children bind it can be taken in between."""
+    return os.path.join(tempfile.mkdtemp(prefix="ldmk_rdzv_"), "store")
 
 
 def _fake_frames(x_T):
@@ -24,8 +21,8 @@ def _fake_frames(x_T):
 
 
 def _worker(rank, world, port, n_items, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from dsml_thesis_amd.parallel import all_gather_items, batch_noise, shard_range
     lo, hi = shard_range(n_items, world, rank)
     local = _fake_frames(batch_noise(5, lo, hi, (3, 8, 8))) if hi > lo else torch.zeros(0, 8, 8, 3)
@@ -57,8 +54,8 @@ def test_sharded_equals_unsharded_world2(n_items):
 
 
 def _grad_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     from dsml_thesis_amd.train import FlatParams, UNetTrainer
     tr = UNetTrainer.__new__(UNetTrainer)          # the data-parallel reduction only touches the flat gradient buffer
     tr.P = FlatParams()
