@@ -86,22 +86,34 @@ class DDIMSampler(object):
         ctx, _ = self._split_cond(conditioning)
         if ctx.shape[0] != batch_size:
             print(f"Warning: Got {ctx.shape[0]} conditionings but batch-size is {batch_size}")
-        if mask is not None or quantize_x0 or score_corrector is not None or noise_dropout > 0. or temperature != 1.:
-            raise NotImplementedError("DDIMSampler.sample: mask/x0, quantize_x0, score_corrector, noise_dropout and "
-                                      "temperature are not used by any shipped script and are not built")
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
         C_, H, W_ = shape
         size = (batch_size, C_, H, W_)
         return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback, x_T=x_T,
                                   log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
                                   unconditional_conditioning=unconditional_conditioning, noise=noise,
-                                  use_graph=use_graph, policy_batch=policy_batch)
+                                  use_graph=use_graph, policy_batch=policy_batch, mask=mask, x0=x0,
+                                  quantize_denoised=quantize_x0, temperature=temperature, noise_dropout=noise_dropout,
+                                  score_corrector=score_corrector, corrector_kwargs=corrector_kwargs,
+                                  mask_noise=kwargs.get("mask_noise"))
 
     @torch.no_grad()
     def ddim_sampling(self, cond, shape, x_T=None, callback=None, img_callback=None, log_every_t=100,
                       unconditional_guidance_scale=1., unconditional_conditioning=None, noise=None,
-                      use_graph=False, policy_batch=None, return_x_inter_only=False, invert=False, **kwargs):
-        """invert=True runs the forward DDIM (inversion) direction: index 0 -> S-1 with q_sample_ddim's update."""
+                      use_graph=False, policy_batch=None, return_x_inter_only=False, invert=False, mask=None, x0=None,
+                      quantize_denoised=False, temperature=1., noise_dropout=0., score_corrector=None,
+                      corrector_kwargs=None, mask_noise=None, **kwargs):
+        """invert=True runs the forward DDIM (inversion) direction: index 0 -> S-1 with q_sample_ddim's update.
+
+        The reference's rarely used options (ddim.py:112-203; no shipped script sets them) run as device-side elementwise
+        work around the same captured step, never on the host:
+          mask / x0          inpainting blend before every step, `img = q_sample(x0, t) * mask + (1 - mask) * img` (:143-146);
+                             `mask_noise` = optional per-step noise list for q_sample (parity with a seeded reference run)
+          temperature        scales the step noise (:199)
+          noise_dropout      F.dropout on the step noise (:200-201)
+          quantize_denoised  pred_x0 snapped to the first stage's codebook before x_prev is formed (:195-196)
+          score_corrector    `modify_score(model, e_t, x, t, c, **corrector_kwargs)` between the UNet and the update (:179-181);
+                             a host callback, so it runs with eager launches."""
         dev = self.model.device
         unet = self.model.model.diffusion_model
         b = shape[0]
@@ -130,13 +142,22 @@ class DDIMSampler(object):
         if cfg:
             x_buf[b:].copy_(img0)
         need_noise = self._eta != 0. or noise is not None
+        if mask is not None:
+            assert x0 is not None, "mask needs x0 (ddim.py:144)"
+            mask = mask.to(dev, torch.float32).expand(shape).contiguous()
+            x0 = x0.to(dev, torch.float32)
+        if score_corrector is not None:
+            assert self.model.parameterization == "eps"
+            use_graph = False                              # a host callback sits inside the step
+        extras = mask is not None or quantize_denoised or score_corrector is not None or noise_dropout > 0. or temperature != 1.
         lkey = (id(pg), cfg, float(unconditional_guidance_scale), self._sched_key, need_noise, bool(use_graph),
                 noise is None, bool(invert))
-        st = self._loops.get(lkey)
+        st = None if extras else self._loops.get(lkey)     # (option runs capture their own tensors: never cached)
         if st is None:
             st = dict(pred_x0=torch.empty_like(img0), step_idx=torch.zeros(1, dtype=torch.int32, device=dev),
                       nz=torch.empty_like(img0) if need_noise else None, graph=None)
-            self._loops[lkey] = st
+            if not extras:
+                self._loops[lkey] = st
         pred_x0, step_idx, nz_buf = st["pred_x0"], st["step_idx"], st["nz"]
         eps = pg.outputs["eps"]
         per = img0[0].numel()
@@ -152,13 +173,39 @@ class DDIMSampler(object):
             step_idx.fill_(first)
             pg.inputs["t"].fill_(int(self.ddim_timesteps[first]))
 
+        mnz = torch.empty_like(img0) if mask is not None else None
+        sqrt_ac, sqrt_1mac = self.model.sqrt_alphas_cumprod, self.model.sqrt_one_minus_alphas_cumprod
+        eps_c = torch.empty_like(img0) if score_corrector is not None else None
+
         def one_step():
+            if mask is not None:                           # ddim.py:143-146, timestep read from the device-side vector
+                tcur = pg.inputs["t"][:b]
+                img_orig = (sqrt_ac.gather(-1, tcur).view(b, 1, 1, 1) * x0 + sqrt_1mac.gather(-1, tcur).view(b, 1, 1, 1) * mnz)
+                img.copy_(img_orig * mask + (1. - mask) * img)
+                if cfg:
+                    x_buf[b:].copy_(img)
+            if nz_buf is not None and (temperature != 1. or noise_dropout > 0.):
+                if temperature != 1.:
+                    nz_buf.mul_(temperature)
+                if noise_dropout > 0.:
+                    nz_buf.copy_(torch.nn.functional.dropout(nz_buf, p=noise_dropout))
+            a_prev = table[step_idx.long(), 1] if quantize_denoised else None      # read before the kernel advances the counter
             pg.run()
-            rc = lib.ldmk_ddim_step(img.data_ptr(), eps.data_ptr(), 0 if nz_buf is None else nz_buf.data_ptr(),
-                                    table.data_ptr(), step_idx.data_ptr(), scale, 1 if cfg else 0, img.data_ptr(),
+            e_ptr, k_cfg = eps.data_ptr(), (1 if cfg else 0)
+            if score_corrector is not None:                # ddim.py:179-181 acts on the guidance-combined score
+                e_t = eps[:b] if not cfg else eps[:b] + scale * (eps[b:] - eps[:b])
+                tcur = pg.inputs["t"][:b].clone()
+                eps_c.copy_(score_corrector.modify_score(self.model, e_t, img.clone(), tcur, cond, **(corrector_kwargs or {})))
+                e_ptr, k_cfg = eps_c.data_ptr(), 0
+            rc = lib.ldmk_ddim_step(img.data_ptr(), e_ptr, 0 if nz_buf is None else nz_buf.data_ptr(),
+                                    table.data_ptr(), step_idx.data_ptr(), scale, k_cfg, img.data_ptr(),
                                     pred_x0.data_ptr(), per, b, ts_table.data_ptr(), pg.inputs["t"].data_ptr(), nb, adv, S,
                                     torch.cuda.current_stream().cuda_stream)
             L.check(rc, "ldmk_ddim_step")
+            if quantize_denoised:                          # x_prev = sqrt(a_prev) Q(pred_x0) + dir_xt + noise (ddim.py:194-202)
+                q = self.model.first_stage_model.quantize(pred_x0)[0]
+                img.add_(torch.sqrt(a_prev) * (q - pred_x0))
+                pred_x0.copy_(q)
             if cfg:
                 x_buf[b:].copy_(img)                       # both CFG halves see the same latent (ddim.py:173)
 
@@ -166,9 +213,12 @@ class DDIMSampler(object):
         step = one_step
         if use_graph:
             if st["graph"] is None:
-                if nz_buf is not None and noise is None:
+                if (nz_buf is not None and noise is None) or (mask is not None and mask_noise is None):
                     def step_with_noise():
-                        nz_buf.normal_()
+                        if nz_buf is not None and noise is None:
+                            nz_buf.normal_()
+                        if mask is not None and mask_noise is None:
+                            mnz.normal_()
                         one_step()
                     st["graph"] = GraphedProgram(step_with_noise)
                 else:
@@ -184,6 +234,11 @@ class DDIMSampler(object):
                     nz_buf.copy_(noise[i])
                 elif not use_graph:
                     nz_buf.normal_()
+            if mask is not None:
+                if mask_noise is not None:
+                    mnz.copy_(mask_noise[i])
+                elif not use_graph:
+                    mnz.normal_()
             step()
             if callback:
                 callback(i)
@@ -202,8 +257,9 @@ class DDIMSampler(object):
                       temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
                       unconditional_guidance_scale=1., unconditional_conditioning=None, noise=None):
         """Single step with the reference's signature (ddim.py:164-203); returns (x_prev, pred_x0)."""
-        if use_original_steps or quantize_denoised or score_corrector is not None or noise_dropout > 0.:
-            raise NotImplementedError("p_sample_ddim: only the DDIM-subsequence path is built")
+        if use_original_steps:
+            raise NotImplementedError("p_sample_ddim: only the DDIM-subsequence path is built (no shipped script sets "
+                                      "ddim_use_original_steps)")
         dev = x.device
         b = x.shape[0]
         ctx, cat = self._split_cond(c)
@@ -214,14 +270,27 @@ class DDIMSampler(object):
                                        None if cat is None else torch.cat([cat] * 2))
         else:
             e = self.model.apply_model(x, t, ctx, cat)
-        if noise is None and self._eta != 0.:
-            noise = torch.randn_like(x) * temperature
+        if score_corrector is not None:                      # ddim.py:179-181, on the guidance-combined score
+            assert self.model.parameterization == "eps"
+            if cfg:
+                e_u, e_c = e.chunk(2)
+                e = e_u + unconditional_guidance_scale * (e_c - e_u)
+                cfg = False
+            e = score_corrector.modify_score(self.model, e, x, t, c, **(corrector_kwargs or {})).contiguous()
+        if self._eta != 0.:
+            noise = (torch.randn_like(x) if noise is None else noise.to(dev)) * temperature
+            if noise_dropout > 0.:
+                noise = torch.nn.functional.dropout(noise, p=noise_dropout)
         step_idx = torch.full((1,), int(index), dtype=torch.int32, device=dev)
         x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)
         L.call("ldmk_ddim_step", x.contiguous().data_ptr(), e.data_ptr(), 0 if noise is None else noise.contiguous().data_ptr(),
                self._table.data_ptr(), step_idx.data_ptr(), float(unconditional_guidance_scale), 1 if cfg else 0,
                x_prev.data_ptr(), pred_x0.data_ptr(), x[0].numel(), b, 0, 0, 0, 0, 0,
                torch.cuda.current_stream().cuda_stream)
+        if quantize_denoised:                                # ddim.py:195-196
+            q = self.model.first_stage_model.quantize(pred_x0)[0]
+            x_prev = x_prev + torch.sqrt(self._table[int(index), 1]) * (q - pred_x0)
+            pred_x0 = q
         return x_prev, pred_x0
 
     # ------------------------------------------------------------------------------------------ latent manipulation

@@ -274,29 +274,47 @@ class LatentDiffusion(_Base):
     def p_sample(self, x, c, t, clip_denoised=False, repeat_noise=False, return_codebook_ids=False,
                  quantize_denoised=False, return_x0=False, temperature=1., noise_dropout=0., score_corrector=None,
                  corrector_kwargs=None, noise=None):
-        """ddpm.py:1080-1109 (with p_mean_variance :1049-1078, q_posterior :221-228) as one fused update kernel."""
-        if clip_denoised or quantize_denoised or return_codebook_ids or score_corrector is not None or noise_dropout > 0.:
-            raise NotImplementedError("p_sample: clip/quantize/score-corrector options are unused on the shipped path")
+        """ddpm.py:1080-1109 (with p_mean_variance :1049-1078, q_posterior :221-228) as one fused update kernel.  The
+        options no shipped script sets (clip / quantise the x0 estimate, a score corrector, return_x0) take the same
+        arithmetic as a few elementwise device ops around the UNet evaluation instead."""
+        if return_codebook_ids:
+            raise DeprecationWarning("Support dropped.")                    # ddpm.py:1092
         eps = self.apply_model(x, t, c)
         if noise is None:
-            noise = torch.randn_like(x) * temperature
-        tab, logvar = self._ddpm_device_tables()
-        out = torch.empty_like(x)
-        L.call("ldmk_ddpm_step", x.contiguous().data_ptr(), eps.data_ptr(), noise.contiguous().data_ptr(), tab.data_ptr(),
-               logvar.data_ptr(), t.to(torch.int64).contiguous().data_ptr(), out.data_ptr(), x[0].numel(), x.shape[0],
-               torch.cuda.current_stream().cuda_stream)
-        return out
+            noise = torch.randn_like(x)
+        noise = noise * temperature
+        if noise_dropout > 0.:
+            noise = torch.nn.functional.dropout(noise, p=noise_dropout)
+        t = t.to(torch.int64)
+        if not (clip_denoised or quantize_denoised or score_corrector is not None or return_x0):
+            tab, logvar = self._ddpm_device_tables()
+            out = torch.empty_like(x)
+            L.call("ldmk_ddpm_step", x.contiguous().data_ptr(), eps.data_ptr(), noise.contiguous().data_ptr(), tab.data_ptr(),
+                   logvar.data_ptr(), t.contiguous().data_ptr(), out.data_ptr(), x[0].numel(), x.shape[0],
+                   torch.cuda.current_stream().cuda_stream)
+            return out
+        if score_corrector is not None:
+            assert self.parameterization == "eps"
+            eps = score_corrector.modify_score(self, eps, x, t, c, **(corrector_kwargs or {}))
+        ex = lambda a: a.gather(-1, t).view(-1, 1, 1, 1)                    # extract_into_tensor, util.py:96-99
+        x_recon = ex(self.sqrt_recip_alphas_cumprod) * x - ex(self.sqrt_recipm1_alphas_cumprod) * eps      # :215-219
+        if clip_denoised:
+            x_recon = x_recon.clamp(-1., 1.)
+        if quantize_denoised:
+            x_recon = self.first_stage_model.quantize(x_recon)[0]
+        mean = ex(self.posterior_mean_coef1) * x_recon + ex(self.posterior_mean_coef2) * x                # q_posterior :221-228
+        nonzero = (1 - (t == 0).float()).view(-1, 1, 1, 1)
+        out = mean + nonzero * (0.5 * ex(self.posterior_log_variance_clipped)).exp() * noise
+        return (out, x_recon) if return_x0 else out
 
     @torch.no_grad()
     def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None,
                       timesteps=None, quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None,
-                      log_every_t=None, noise=None, use_graph=False):
+                      log_every_t=None, noise=None, use_graph=False, mask_noise=None):
         """ddpm.py:1167-1216.  Device-resident loop: the latent lives in the UNet program's input buffer, the
         per-sample timestep vector is rewritten by a kernel, one step = UNet program + fused posterior update, and
         (use_graph=True) the step is captured once in a hipGraph and replayed T times.
         `noise`: optional per-step noise list (parity with a seeded reference run)."""
-        if mask is not None or quantize_denoised:
-            raise NotImplementedError("p_sample_loop: mask/x0 and quantize_denoised are unused on the shipped path")
         from .engine import GraphedProgram
         log_every_t = log_every_t or self.log_every_t
         dev = self.betas.device
@@ -305,6 +323,27 @@ class LatentDiffusion(_Base):
         timesteps = self.num_timesteps if timesteps is None else timesteps
         if start_T is not None:
             timesteps = min(timesteps, start_T)
+        if mask is not None or quantize_denoised or self.clip_denoised:
+            # the options no shipped script sets (ddpm.py:1199-1208): step by step through p_sample, eager launches;
+            # `mask_noise` (a per-step list, like `noise`) pins q_sample's draw for parity with a seeded reference run
+            if mask is not None:
+                assert x0 is not None and x0.shape[2:3] == mask.shape[2:3]
+                mask, x0 = mask.to(dev, torch.float32), x0.to(dev, torch.float32)
+            img, intermediates = img0, [img0]
+            for k, i in enumerate(reversed(range(0, timesteps))):
+                ts = torch.full((b,), i, device=dev, dtype=torch.long)
+                img = self.p_sample(img, cond, ts, clip_denoised=self.clip_denoised, quantize_denoised=quantize_denoised,
+                                    noise=None if noise is None else noise[k].to(dev))
+                if mask is not None:
+                    img_orig = self.q_sample(x0, ts, noise=None if mask_noise is None else mask_noise[k].to(dev))
+                    img = img_orig * mask + (1. - mask) * img
+                if i % log_every_t == 0 or i == timesteps - 1:
+                    intermediates.append(img)
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(img, i)
+            return (img, intermediates) if return_intermediates else img
         if isinstance(cond, dict):
             ctx = cond.get("c_crossattn")
             cat = cond.get("c_concat")
@@ -415,7 +454,11 @@ class LatentDiffusion(_Base):
                 ema_sd = {k[len(pre):]: self.model_ema.shadow_of(k) for k in self.model_ema.m_name2s_name
                           if k.startswith(pre)}
                 self._ema_flat = self._trainer.pack_reference_state(ema_sd)
-            self._cond_opt = None
+            if not hasattr(self, "_cond_opt"):       # (configure_optimizers may already have created the one Lightning owns)
+                self._cond_opt = None
+            pending = self.__dict__.pop("_pending_training_state", None)
+            if pending is not None:                  # a Lightning checkpoint written by on_save_checkpoint
+                self.load_training_state(pending)
         return self._trainer
 
     def training_state(self):
@@ -545,10 +588,13 @@ class LatentDiffusion(_Base):
         if self.use_scheduler:
             assert "target" in self.scheduler_config
             self.lr_schedule = instantiate_from_config(self.scheduler_config).schedule
-        if not self.cond_stage_trainable or self.cond_stage_model is None:
+        owner = self.cond_stage_model if self.cond_stage_model is not None else getattr(self, "cond_stage_model_1", None)
+        if not self.cond_stage_trainable or owner is None:
             return None
         print(f"{self.__class__.__name__}: Also optimizing conditioner params!")
-        self._cond_opt = torch.optim.AdamW(self.cond_stage_model.parameters(), lr=lr)
+        # the very object training_step_latents steps (it only creates one when none exists), so that what Lightning
+        # checkpoints are the moments that were actually updated
+        self._cond_opt = torch.optim.AdamW(owner.parameters(), lr=lr)
         return self._cond_opt
 
     @torch.no_grad()
@@ -560,14 +606,15 @@ class LatentDiffusion(_Base):
         logger settings leave off (denoise / progressive / diffusion rows, inpainting, quantised x0) raise."""
         if quantize_denoised or inpaint or plot_denoise_rows or plot_progressive_rows or plot_diffusion_rows:
             raise NotImplementedError("log_images: only inputs / reconstruction / samples are produced")
+        # during training the live weights and the EMA live in the training engine's flat buffers: bring the module tree
+        # (what ema_scope / the samplers read) up to date first, or the logged samples would show the step-0 weights
+        self._sync_if_training()
         x = batch[self.first_stage_key]
         x = (x[..., None] if x.dim() == 3 else x)[:N].permute(0, 3, 1, 2).contiguous().float().to(self.device)
         z = self.get_first_stage_encoding(self.encode_first_stage(x))
         log = {"inputs": x, "reconstruction": self.decode_first_stage(z)}
         if sample:
-            cond = batch[self.cond_stage_key]
-            cond = {self.cond_stage_key: cond[:N]} if not isinstance(cond, dict) else cond
-            c = self.get_learned_conditioning(cond) if self.cond_stage_model is not None else None
+            c = self._log_conditioning(batch, x.shape[0])
             with self.ema_scope("Plotting"):
                 samples, _ = self.sample_log(cond=c, batch_size=x.shape[0], ddim=ddim_steps is not None,
                                              ddim_steps=ddim_steps, eta=ddim_eta)
@@ -575,6 +622,37 @@ class LatentDiffusion(_Base):
         if return_keys and any(k in log for k in return_keys):
             return {k: log[k] for k in return_keys if k in log}
         return log
+
+    def _log_conditioning(self, batch, n):
+        """The condition `log_images` samples with (ddpm.py:1262-1266: get_input(..., return_first_stage_outputs=True))."""
+        cond = batch[self.cond_stage_key]
+        cond = {self.cond_stage_key: cond[:n]} if not isinstance(cond, dict) else cond
+        cond = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in cond.items()}
+        return self.get_learned_conditioning(cond)
+
+    def _sync_if_training(self):
+        if getattr(self, "_trainer", None) is not None:
+            self.sync_trained_weights()
+
+    def on_save_checkpoint(self, checkpoint):
+        """Lightning hook: a checkpoint taken mid-training must hold the trained weights and EMA (they live in the training
+        engine's flat buffers between steps), plus the engine's optimiser state for a faithful resume."""
+        if getattr(self, "_trainer", None) is not None:
+            self.sync_trained_weights()
+            if isinstance(checkpoint, dict):
+                if "state_dict" in checkpoint:
+                    checkpoint["state_dict"] = {k: v.detach().clone() for k, v in super().state_dict().items()}
+                checkpoint["ldmk_training_state"] = self.training_state()
+
+    def on_load_checkpoint(self, checkpoint):
+        st = checkpoint.get("ldmk_training_state") if isinstance(checkpoint, dict) else None
+        if st is not None:
+            self._pending_training_state = st
+
+    def state_dict(self, *args, **kwargs):
+        """nn.Module.state_dict, after copying the trained weights / EMA out of the training engine when one exists."""
+        self._sync_if_training()
+        return super().state_dict(*args, **kwargs)
 
     def sync_trained_weights(self):
         """Copy the trained (and EMA) weights from the training engine back into the nn.Module tree, so that
@@ -601,6 +679,19 @@ class LatentDiffusion2Cond(LatentDiffusion):
         self.cond_stage_model_1 = self.cond_stage_model
         self.cond_stage_model = None
         self.cond_stage_model_2 = instantiate_from_config(cond_stage_config_2)
+
+    def _log_conditioning(self, batch, n):
+        """ddpm2cond.py log_images: c12 = cat([class embedding, audio-window feature], 2) as the cross-attention token,
+        c34 = cat([encode(masked frame), encode(identity)], 1) on the channel axis (get_input, ddpm2cond.py:676-741)."""
+        def img(k):
+            v = batch[k][:n]
+            return (v[..., None] if v.dim() == 3 else v).permute(0, 3, 1, 2).contiguous().float().to(self.device)
+        c1 = self.cond_stage_model_1({self.cond_stage_key_1: batch[self.cond_stage_key_1][:n].to(self.device)})
+        c2 = self.cond_stage_model_2(batch[self.cond_stage_key_2][:n].float().to(self.device))
+        z_mask = self.get_first_stage_encoding(self.encode_first_stage(img("masked_image")))
+        z_id = self.get_first_stage_encoding(self.encode_first_stage(img("identity")))
+        from .ddim import C12, C34
+        return {C12: torch.cat([c1, c2], 2), C34: torch.cat([z_mask, z_id], 1)}
 
     def p_losses(self, x_start, cond12, cond34=None, t=None, noise=None):
         """ddpm2cond.py p_losses(x_start, cond12, cond34, t): cross-attention tokens + channel-concat latents."""

@@ -48,6 +48,18 @@ def all_gather_items(local, n_items, group=None):
     return out[:n_items]
 
 
+def gathered_item_shape(model, shape, decode=True, postprocess=True):
+    """Per-item shape of what `sample_sharded` gathers, from the latent shape and the first stage alone: the latent
+    itself, the decoded frame (out_ch, H*f, W*f) with f = 2^(levels-1) of the VQGAN decoder, or its channels-last
+    [0,1] post-processed form (sample_affectnet.py:127,132)."""
+    c, h, w = (int(v) for v in shape)
+    if not decode:
+        return (c, h, w)
+    dec = model.first_stage_model.decoder
+    f = 2 ** (dec.num_resolutions - 1)
+    return (h * f, w * f, dec.out_ch) if postprocess else (dec.out_ch, h * f, w * f)
+
+
 @torch.no_grad()
 def sample_sharded(sampler, S, n_items, shape, conditioning_fn, seed=0, eta=0.0, decode=True, use_graph=True,
                    rank=0, world_size=1, group=None, postprocess=True, _noise_offset=0, _policy_items=None,
@@ -74,14 +86,8 @@ def sample_sharded(sampler, S, n_items, shape, conditioning_fn, seed=0, eta=0.0,
             out = z
     else:
         out = None
-    if world_size > 1:
-        import torch.distributed as dist
-        # every rank must contribute a block of the common shape, also an idle one
-        probe = torch.zeros(8, dtype=torch.int64, device=dev)
-        if out is not None:
-            probe[:out.dim()] = torch.tensor(out.shape, device=dev)
-        dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
-        tail = tuple(int(v) for v in probe[1:] if v > 0)
-        if out is None:
-            out = torch.zeros((0,) + tail, device=dev)
+    if out is None:
+        # an idle rank (more ranks than items) still contributes a block of the common shape to the ONE collective of
+        # the job; that shape follows from (shape, first-stage factor) alone, so no probe collective is needed
+        out = torch.zeros((0,) + gathered_item_shape(model, shape, decode, postprocess), device=dev)
     return all_gather_items(out, n_items, group=group)

@@ -241,12 +241,17 @@ def apply_model(sd, cfg, x, t, c_crossattn=None, c_concat=None):
 
 # ============================================================================ samplers
 def ddim_sample(sd, cfg, sched, S, x_T, cond=None, c_concat=None, eta=0.0, scale=1.0, uncond=None,
-                noise=None, return_all=False):
+                noise=None, return_all=False, mask=None, x0=None, mask_noise=None, temperature=1.0,
+                quantize_codebook=None, score_fn=None):
     """DDIMSampler.sample/ddim_sampling/p_sample_ddim: ddim.py:56-203 (FR, CFG by batch doubling)
     and TF ddim2cond.py:56-195 (scale==1 path; c_concat = 'motion_&_id').
 
     `noise`: optional (S, *x.shape) pre-generated standard-normal noise used when eta>0
     (the reference draws torch.randn on the device, which no other backend can reproduce).
+    Options of ddim.py:112-203 no shipped script sets: `mask`/`x0` (+ `mask_noise`, q_sample's per-step draw) blend
+    `q_sample(x0, t) * mask + (1 - mask) * img` before each step (:143-146); `temperature` scales the step noise (:199);
+    `quantize_codebook` snaps pred_x0 to the codebook before x_prev is formed (:195-196); `score_fn(e_t, x, t)` stands for
+    score_corrector.modify_score (:179-181).
     """
     ts = make_ddim_timesteps(S, sched["betas"].shape[0])
     tab = make_ddim_tables(sched["alphas_cumprod"], ts, eta)
@@ -257,6 +262,11 @@ def ddim_sample(sd, cfg, sched, S, x_T, cond=None, c_concat=None, eta=0.0, scale
         index = S - i - 1
         t = torch.full((b,), int(step), dtype=torch.long)
         cc = None if c_concat is None else [c_concat]
+        if mask is not None:
+            sh = (b, 1, 1, 1)
+            img_orig = (sched["sqrt_alphas_cumprod"].gather(-1, t).reshape(sh) * x0 +
+                        sched["sqrt_one_minus_alphas_cumprod"].gather(-1, t).reshape(sh) * mask_noise[i])
+            img = img_orig * mask + (1. - mask) * img
         if uncond is None or scale == 1.0:
             e_t = apply_model(sd, cfg, img, t, None if cond is None else [cond], cc)
         else:
@@ -266,9 +276,16 @@ def ddim_sample(sd, cfg, sched, S, x_T, cond=None, c_concat=None, eta=0.0, scale
             cc2 = None if c_concat is None else [torch.cat([c_concat] * 2)]
             e_u, e_c = apply_model(sd, cfg, x_in, t_in, [c_in], cc2).chunk(2)
             e_t = cfg_combine(e_u, e_c, scale)
-        nz = None if noise is None else noise[i]
+        if score_fn is not None:
+            e_t = score_fn(e_t, img, t)
+        nz = None if noise is None else noise[i] * temperature
+        x_in_step = img
         img, pred_x0 = ddim_update(img, e_t, tab["a_t"][index], tab["a_prev"][index],
                                    tab["sigma_t"][index], tab["sqrt_one_minus_at"][index], nz)
+        if quantize_codebook is not None:                   # x_prev re-formed from the quantised x0 estimate
+            pred_q, _ = vq_quantize(pred_x0, quantize_codebook)
+            a_prev, sig = torch.as_tensor(tab["a_prev"][index]).float(), torch.as_tensor(tab["sigma_t"][index]).float()
+            img = a_prev.sqrt() * pred_q + (1. - a_prev - sig ** 2).sqrt() * e_t + (0. if nz is None else sig * nz)
         if return_all:
             traj.append(img)
     return (img, traj) if return_all else img
@@ -315,16 +332,32 @@ def ddim_invert_and_regenerate(sd, cfg, sched, S, x0, cond, strength=0.5, scale=
     return img, x_lat
 
 
-def p_sample_loop(sd, cfg, sched, x_T, cond=None, timesteps=None, noise=None):
-    """LatentDiffusion.p_sample_loop, ddpm.py:1167-1216 (clip_denoised False, ddpm.py:463)."""
+def p_sample_loop(sd, cfg, sched, x_T, cond=None, timesteps=None, noise=None, clip_denoised=False,
+                  quantize_codebook=None, mask=None, x0=None, mask_noise=None):
+    """LatentDiffusion.p_sample_loop, ddpm.py:1167-1216 (clip_denoised False by default, ddpm.py:463).  Options:
+    clamp / quantise the x0 estimate inside p_mean_variance (:1069-1072), inpainting blend after each step (:1205-1208)."""
     T = sched["betas"].shape[0] if timesteps is None else timesteps
     img = x_T
     b = x_T.shape[0]
+    sh = (b, 1, 1, 1)
+    g = lambda name, t: sched[name].gather(-1, t).reshape(sh)
     for k, i in enumerate(reversed(range(0, T))):
         t = torch.full((b,), i, dtype=torch.long)
         eps = apply_model(sd, cfg, img, t, None if cond is None else [cond])
         nz = torch.zeros_like(img) if noise is None else noise[k]
-        img = ddpm_update(sched, img, eps, t, nz)
+        if clip_denoised or quantize_codebook is not None:
+            xr = g("sqrt_recip_alphas_cumprod", t) * img - g("sqrt_recipm1_alphas_cumprod", t) * eps
+            if clip_denoised:
+                xr = xr.clamp(-1., 1.)
+            if quantize_codebook is not None:
+                xr, _ = vq_quantize(xr, quantize_codebook)
+            mean = g("posterior_mean_coef1", t) * xr + g("posterior_mean_coef2", t) * img
+            img = mean + (1 - (t == 0).float()).reshape(sh) * (0.5 * g("posterior_log_variance_clipped", t)).exp() * nz
+        else:
+            img = ddpm_update(sched, img, eps, t, nz)
+        if mask is not None:
+            img_orig = g("sqrt_alphas_cumprod", t) * x0 + g("sqrt_one_minus_alphas_cumprod", t) * mask_noise[k]
+            img = img_orig * mask + (1. - mask) * img
     return img
 
 

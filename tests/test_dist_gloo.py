@@ -46,11 +46,78 @@ def test_sharded_equals_unsharded_world2(n_items):
         p.start()
     full, tmax = q.get(timeout=120)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=180)
         assert p.exitcode == 0
     ref = _fake_frames(batch_noise(5, 0, n_items, (3, 8, 8)))
     assert full.shape == ref.shape and torch.equal(full, ref)
     assert abs(tmax - 0.020) < 1e-12
+
+
+class _FakeDecoder:
+    num_resolutions, out_ch = 3, 3            # f = 4 like the shipped VQGAN (model.py:462-568)
+
+
+class _FakeFirstStage:
+    decoder = _FakeDecoder()
+    policy_batch = None
+
+
+class _FakeModel:
+    """Stand-in with the contract sample_sharded uses (the real sampler needs a GPU): per-item independent sampler +
+    decoder, `device`, `first_stage_model.decoder.{num_resolutions,out_ch}`."""
+    device = torch.device("cpu")
+    first_stage_model = _FakeFirstStage()
+
+    def decode_first_stage(self, z):
+        return torch.tanh(z).repeat_interleave(4, 2).repeat_interleave(4, 3)
+
+
+class _FakeSampler:
+    model = _FakeModel()
+
+    def sample(self, S, batch_size, shape, conditioning, eta=0.0, x_T=None, **kw):
+        assert x_T.shape[0] == batch_size == conditioning.shape[0]
+        return x_T * 0.5 + conditioning.view(-1, 1, 1, 1), None
+
+
+def _sharded_worker(rank, world, port, n_items, decode, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
+    from dsml_thesis_amd import parallel
+    calls = []
+    for name in ("all_reduce", "all_gather_into_tensor", "all_gather", "broadcast", "reduce_scatter_tensor"):
+        real = getattr(dist, name)
+        setattr(dist, name, (lambda real, name: lambda *a, **k: (calls.append(name), real(*a, **k))[1])(real, name))
+    cond = lambda lo, hi: torch.arange(lo, hi, dtype=torch.float32)
+    full = parallel.sample_sharded(_FakeSampler(), 4, n_items, (3, 8, 8), cond, seed=5, decode=decode, postprocess=False,
+                                   rank=rank, world_size=world)
+    q.put((rank, full, calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items,decode", [(1, True), (1, False), (5, True)])
+def test_sample_sharded_one_collective_also_with_an_idle_rank(n_items, decode):
+    """`sample_sharded` itself on two gloo ranks: n_items = 1 leaves rank 1 idle; it must still join the job's ONE
+    collective with a block of the right shape (derived from the latent shape and the first-stage factor, no probe)."""
+    from dsml_thesis_amd import parallel
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, n_items, decode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    x_T = parallel.batch_noise(5, 0, n_items, (3, 8, 8))
+    ref, _ = _FakeSampler().sample(4, n_items, (3, 8, 8), torch.arange(n_items, dtype=torch.float32), x_T=x_T)
+    if decode:
+        ref = _FakeModel().decode_first_stage(ref)
+    for rank, full, calls in got:
+        assert calls == ["all_gather_into_tensor"], (rank, calls)       # exactly one collective, no shape probe
+        assert full.shape == ref.shape and torch.equal(full, ref)
 
 
 def _grad_worker(rank, world, port, q):
@@ -80,6 +147,6 @@ def test_gradient_all_reduce_world2():
         p.start()
     g = q.get(timeout=120)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=180)
         assert p.exitcode == 0
     assert torch.equal(g, torch.arange(g.numel(), dtype=torch.float32) * 1.5)

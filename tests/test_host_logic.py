@@ -156,3 +156,57 @@ def test_gradient_bucket_plan():
     assert plan_buckets([0], 64, 16) == {0: (0, 64)}
     with pytest.raises(ValueError):
         plan_buckets([500, 800, 0], 1000, 100)
+
+
+# ---- the shipped YAMLs (container only: /root/reference does not travel to the GPU box) -----------------------------
+_REF = "/root/reference"
+_YAMLS = {
+    "fr": "face_reenactment/configs/latent-diffusion/affectnet-128-ldm-vq-f4.yaml",
+    "fr_clip": "face_reenactment/configs/latent-diffusion/affectnet-128-clip-ldm-vq-f4.yaml",
+    "tf": "talking_face/configs/latent-diffusion/mead-128-ldm-f4.yaml",
+}
+
+
+def _strip_ckpt(node):
+    """Drop every `ckpt_path` (checkpoints are not in the repository) -- the only edit made to a shipped config."""
+    if isinstance(node, dict):
+        return {k: _strip_ckpt(v) for k, v in node.items() if k != "ckpt_path"}
+    if isinstance(node, list):
+        return [_strip_ckpt(v) for v in node]
+    return node
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(_REF), reason="the reference tree exists only in the build container")
+@pytest.mark.parametrize("which", sorted(_YAMLS))
+def test_shipped_yaml_instantiates_and_matches_the_enumerated_layout(which):
+    """the YAML `target:` factory is the drop-in boundary.  The three shipped model configs are read with
+    yaml.safe_load, instantiated UNCHANGED (minus ckpt_path) through util.instantiate_from_config, and every UNet / VQGAN
+    state-dict key and shape must equal the enumeration the oracle and the synthetic-weight recipe are built on; the
+    hyper-parameter copies in oracle/weights.py and dsml_thesis_amd/synth.py must equal the YAML's."""
+    import os
+    from dsml_thesis_amd import synth
+    from dsml_thesis_amd.util import instantiate_from_config, load_yaml_config
+    cfg = _strip_ckpt(load_yaml_config(os.path.join(_REF, _YAMLS[which])))["model"]
+    params = cfg["params"]
+    ucfg, fcfg = params["unet_config"]["params"], params["first_stage_config"]["params"]
+    want_unet = W.TF_UNET if which == "tf" else W.FR_UNET
+    for table, name in ((want_unet, "oracle.weights"), (synth.TF_UNET if which == "tf" else synth.FR_UNET, "synth")):
+        for k, v in table.items():
+            assert ucfg[k] == v, (name, k, ucfg[k], v)
+        assert set(ucfg) - set(table) <= {"use_checkpoint"}, (name, set(ucfg) - set(table))
+    for table in (W.VQ_F4, synth.VQ_F4):
+        assert fcfg["embed_dim"] == table["embed_dim"] and fcfg["n_embed"] == table["n_embed"]
+        for k, v in table["ddconfig"].items():
+            assert fcfg["ddconfig"][k] == v, (k, fcfg["ddconfig"][k], v)
+    for table in (W.SCHEDULE, synth.SCHEDULE):
+        assert {k: params[k] for k in table} == table
+    model = instantiate_from_config(cfg)
+    sd = model.state_dict()
+    unet_keys = {"model.diffusion_model." + k: tuple(s) for k, s in W.unet_param_shapes(want_unet).items()}
+    vq_keys = {"first_stage_model." + k: tuple(s) for k, s in W.vqmodel_param_shapes(W.VQ_F4).items()}
+    for k, shp in {**unet_keys, **vq_keys}.items():
+        assert tuple(sd[k].shape) == shp, k
+    assert {k for k in sd if k.startswith("model.diffusion_model.")} == set(unet_keys)
+    assert {k for k in sd if k.startswith("first_stage_model.")} == set(vq_keys)
+    assert type(model).__name__ == {"fr": "LatentDiffusion", "fr_clip": "LatentDiffusionCLIP", "tf": "LatentDiffusion2Cond"}[which]
+    assert model.num_timesteps == 1000 and model.channels == 3 and model.image_size == 32

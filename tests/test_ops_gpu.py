@@ -394,6 +394,28 @@ def test_linear_layernorm_folded_through_the_product(ops, cfg, splitk, case):
         ops.linear(xc, w2, b2, ln_colsum=cs, row_stats=kw["row_stats"], stats_out=torch.zeros(M // 32 + 1, N, 3, device="cuda"))
 
 
+@pytest.mark.parametrize("ratio", [1.0, 30.0, 100.0])
+def test_layernorm_folded_error_growth_with_mean_dominated_rows(ops, ratio):
+    """The folded form subtracts mean * colsum(W') from x W' in fp32: when a row's |mean| is `ratio` times its spread the two
+    terms cancel and the error grows ~ ratio * sqrt(K) * eps relative to the output scale.  This pins the growth (what a
+    checkpoint with mean-dominated token rows would see) next to the unfolded prologue, which does not have it --
+    LDMK_LN_UNFOLDED=1 is the supported switch for such checkpoints."""
+    M, K, N = 256, 640, 640
+    x = rnd(90, M, K) + ratio * (1.0 + 0.1 * rnd(91, M, 1))
+    w, b = rnd(92, N, K) / np.sqrt(K), 0.1 * rnd(93, N)
+    g, be = 1 + 0.2 * rnd(94, K), 0.2 * rnd(95, K)
+    ref = F.linear(F.layer_norm(x.double(), (K,), g.double(), be.double(), 1e-5), w.double(), b.double()).float()
+    xc = x.cuda()
+    st = ops.ln_stats(xc)
+    wp, bp = ops.pack_linear(w.cuda()), b.cuda()
+    w2, cs, b2 = ops.fold_layernorm(wp, g.cuda(), be.cuda(), bp)
+    err_f = (ops.linear(xc, w2, b2, ln_colsum=cs, row_stats=st).cpu() - ref).abs().max().item()
+    err_u = (ops.linear(xc, wp, bp, ln_gamma=g.cuda(), ln_beta=be.cuda(), row_stats=st).cpu() - ref).abs().max().item()
+    print(f"|mean|/std = {ratio:5.0f}: folded max error {err_f:.2e}, unfolded {err_u:.2e} (outputs up to {ref.abs().max().item():.1f})")
+    assert err_u < 1e-4                                        # the unfolded prologue normalises before it multiplies
+    assert err_f < 1e-4 * max(1.0, ratio / 5.0)                # measured: see DESIGN section 5
+
+
 def _linear_pinned(ops, x, wp, bias, splitk, **kw):
     """ops.linear with the split-K factor pinned (ops.linear itself leaves it to the plan)."""
     if splitk == 1:

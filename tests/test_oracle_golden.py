@@ -308,3 +308,34 @@ def test_g10_differentiable_ddim_pins_the_oracle():
             assert n_ref == 0.0, k
         else:
             assert abs(grads[k].double().norm().item() - n_ref) <= 1e-3 * n_ref + 1e-12, k
+
+
+def _options_inputs():
+    usd = recipe(W.unet_param_shapes(W.FR_UNET), gain=0.25)
+    emb = T(W.synth_tensor("embedding.weight", (8, 512)))
+    c = emb[torch.tensor([1, 6])][:, None]
+    uc = T(W.synth_tensor("uncond_embedding.weight", (1, 512)))[None].expand(2, 1, 512)
+    code = T(W.synth_tensor("quantize.embedding.weight", (16384, 3)))
+    xT, x0 = rnd(51, 2, 3, 32, 32), 0.5 * rnd(52, 2, 3, 32, 32)
+    mask = (rnd(53, 2, 1, 32, 32) > 0).float()
+    return usd, c, uc, code, xT, x0, mask
+
+
+def test_g12_sampler_options():
+    """The sampler options no shipped script sets (ddim.py:143-146,179-181,195-201; ddpm.py:1069-1072,1205-1208), against
+    runs of the reference's own DDIMSampler.sample / p_sample_loop with those options (tools/make_golden.py --tree options)."""
+    from tools.make_golden import ShiftCorrector
+    g = golden("g12_sampler_options.npz")
+    sched = O.register_schedule(**W.SCHEDULE)
+    usd, c, uc, code, xT, x0, mask = _options_inputs()
+    mine = O.ddim_sample(usd, W.FR_UNET, sched, 4, xT, cond=c, eta=1.0, scale=3.0, uncond=uc, noise=T(g["step_noise"]),
+                         mask=mask, x0=x0, mask_noise=T(g["mask_noise"]), temperature=0.7)
+    close(mine, g["ddim_mask_temp_cfg"], 1e-4, 1e-4)
+    close(O.ddim_sample(usd, W.FR_UNET, sched, 4, xT, cond=c, quantize_codebook=code), g["ddim_quantize"], 1e-4, 1e-4)
+    corr = ShiftCorrector()
+    mine = O.ddim_sample(usd, W.FR_UNET, sched, 4, xT, cond=c, scale=3.0, uncond=uc,
+                         score_fn=lambda e, x, t: corr.modify_score(None, e, x, t, None, strength=0.2))
+    close(mine, g["ddim_corrector_cfg"], 1e-4, 1e-4)
+    mine = O.p_sample_loop(usd, W.FR_UNET, sched, xT, cond=c, timesteps=3, noise=T(g["ddpm_noise"]), clip_denoised=True,
+                           quantize_codebook=code, mask=mask, x0=x0, mask_noise=T(g["ddpm_mask_noise"]))
+    close(mine, g["ddpm_clip_quant_mask"], 1e-4, 1e-4)

@@ -52,6 +52,37 @@ def test_ddim_sample_S4_and_graph_replay(fr):
     assert torch.equal(out, out_g2), "a cached graph replays from a clean state"
 
 
+@pytest.mark.parametrize("latent", [32, 64])
+def test_config0_ddim50_batch1_end_to_end(fr, latent):
+    """BASELINE configs[0]: DDIM 50 steps, batch 1, the 'unconditional' plumbing case.  A spatial-transformer UNet fed
+    context=None raises in the reference itself (DESIGN F8), so the unconditional run is the FR UNet on its null-class
+    token (`uncond_embedding`, what sample_affectnet.py:93-94 feeds as the unconditional branch).  End to end at S = 50,
+    B = 1: finite, hipGraph replay == eager launches bit for bit, and (32x32x3) equal to the oracle's 50-step chain."""
+    from dsml_thesis_amd import synth
+    from dsml_thesis_amd.ddim import DDIMSampler
+    m = fr if latent == 32 else make_fr_model(gain=0.25, unet=synth.NS_UNET, vq=synth.VQ_F4_256)
+    ch = 3 if latent == 32 else 4
+    lab = torch.zeros(1, 1, dtype=torch.long, device="cuda")
+    uc = m.cond_stage_model.uncond_embedding(lab)                                   # (1,1,512)
+    xT = rnd(0, 1, ch, latent, latent).cuda()
+    s = DDIMSampler(m)
+    out, inter = s.sample(S=50, batch_size=1, shape=[ch, latent, latent], conditioning=uc, eta=0.0, x_T=xT, verbose=False)
+    assert s.ddim_timesteps.shape == (50,) and int(s.ddim_timesteps[0]) == 1 and int(s.ddim_timesteps[-1]) == 981
+    assert torch.isfinite(out).all() and out.shape == (1, ch, latent, latent)
+    out_g, _ = s.sample(S=50, batch_size=1, shape=[ch, latent, latent], conditioning=uc, eta=0.0, x_T=xT, verbose=False,
+                        use_graph=True)
+    assert torch.equal(out, out_g), "hipGraph replay must be bitwise identical to eager launches"
+    if latent == 32:
+        usd = W.synth_state_dict(W.unet_param_shapes(W.FR_UNET), gain=0.25)
+        ucw = torch.from_numpy(W.synth_tensor("uncond_embedding.weight", (1, 512)))
+        ref = O.ddim_sample(usd, W.FR_UNET, O.register_schedule(**W.SCHEDULE), 50, xT.cpu(), cond=ucw[None])
+        d = (out.cpu() - ref).abs().max().item()
+        print(f"config0 32x32x3: max |diff| vs the oracle after 50 steps {d:.3e} (|x| up to {ref.abs().max().item():.2f})")
+        close(out, ref, 1e-3, 1e-3)
+        img = m.decode_first_stage(out)
+        assert img.shape == (1, 3, 128, 128) and torch.isfinite(img).all()
+
+
 def _run3(fr, eta, scale, noise=None):
     from dsml_thesis_amd.ddim import DDIMSampler
     c, uc = _cond(fr)
@@ -96,6 +127,59 @@ def test_ddim_sample_cfg_loop_matches_stepwise(fr):
         s3.sample(S=200, batch_size=2, shape=[3, 32, 32], conditioning=c, eta=0.0, x_T=xT, verbose=False,
                   unconditional_guidance_scale=3.0, unconditional_conditioning=uc, callback=cb)
     assert torch.equal(seen["x"], ref3)
+
+
+class _ShiftCorrector:
+    """the deterministic stand-in tools/make_golden.py used for the (unshipped) score-corrector plugin"""
+
+    def modify_score(self, model, e_t, x, t, c, strength=0.1):
+        return e_t - strength * x * (t.float().view(-1, 1, 1, 1) / 1000.0)
+
+
+def _close_but_for_codebook_ties(a, b, tol, max_frac=0.01):
+    """After a nearest-codebook snap a latent within ~1e-5 of a cell boundary may legitimately land on the neighbouring
+    code: all elements must agree within `tol` except at most `max_frac` of them."""
+    a, b = a.float().cpu(), torch.as_tensor(np.asarray(b)).float()
+    bad = ((a - b).abs() > tol + tol * b.abs()).float().mean().item()
+    assert bad <= max_frac, f"{100 * bad:.2f} % of the elements differ by more than {tol}"
+
+
+def test_sampler_options_against_reference_fixtures(fr):
+    """ddim.py:112-203 / ddpm.py:1049-1216 options that no shipped script sets -- mask + x0 blend, temperature, quantize_x0,
+    score_corrector (DDIM); clip_denoised, quantize_denoised, mask (ancestral loop) -- against runs of the reference's own
+    samplers with those options (tests/golden/g12_sampler_options.npz; the reference's noise draws are injected)."""
+    from dsml_thesis_amd.ddim import DDIMSampler
+    g = golden("g12_sampler_options.npz")
+    c, uc = _cond(fr)
+    xT, x0 = rnd(51, 2, 3, 32, 32).cuda(), (0.5 * rnd(52, 2, 3, 32, 32)).cuda()
+    mask = (rnd(53, 2, 1, 32, 32) > 0).float().cuda()
+    s = DDIMSampler(fr)
+    kw = dict(S=4, batch_size=2, shape=[3, 32, 32], conditioning=c, x_T=xT, verbose=False)
+    out, _ = s.sample(eta=1.0, mask=mask, x0=x0, temperature=0.7, unconditional_guidance_scale=3.0,
+                      unconditional_conditioning=uc, noise=T(g["step_noise"]).cuda(), mask_noise=T(g["mask_noise"]).cuda(), **kw)
+    close(out, g["ddim_mask_temp_cfg"], 2e-4, 2e-4)
+    out_g, _ = s.sample(eta=1.0, mask=mask, x0=x0, temperature=0.7, unconditional_guidance_scale=3.0, use_graph=True,
+                        unconditional_conditioning=uc, noise=T(g["step_noise"]).cuda(), mask_noise=T(g["mask_noise"]).cuda(), **kw)
+    assert torch.equal(out, out_g), "the option steps are device-side work: hipGraph replay == eager"
+    out, inter = s.sample(eta=0.0, quantize_x0=True, log_every_t=1, **kw)
+    _close_but_for_codebook_ties(out, g["ddim_quantize"], 2e-4)
+    _close_but_for_codebook_ties(inter["pred_x0"][-1], g["ddim_quantize_pred_x0"], 2e-4)
+    out, _ = s.sample(eta=0.0, score_corrector=_ShiftCorrector(), corrector_kwargs=dict(strength=0.2),
+                      unconditional_guidance_scale=3.0, unconditional_conditioning=uc, **kw)
+    close(out, g["ddim_corrector_cfg"], 2e-4, 2e-4)
+    fr.clip_denoised = True
+    try:
+        out = fr.p_sample_loop(c, (2, 3, 32, 32), x_T=xT, timesteps=3, verbose=False, quantize_denoised=True, mask=mask, x0=x0,
+                               noise=list(T(g["ddpm_noise"]).cuda()), mask_noise=list(T(g["ddpm_mask_noise"]).cuda()))
+    finally:
+        fr.clip_denoised = False
+    _close_but_for_codebook_ties(out, g["ddpm_clip_quant_mask"], 2e-4)
+    # noise_dropout has no cross-device fixture (its Bernoulli draw is the device's): a fraction p of the step noise is
+    # zeroed and the rest scaled by 1/(1-p) (F.dropout), so the run stays finite and differs from the p = 0 run
+    a, _ = s.sample(eta=1.0, noise=T(g["step_noise"]).cuda(), **kw)
+    torch.manual_seed(3)
+    b_, _ = s.sample(eta=1.0, noise=T(g["step_noise"]).cuda(), noise_dropout=0.5, **kw)
+    assert torch.isfinite(b_).all() and not torch.equal(a, b_)
 
 
 def test_p_sample_loop_T3(fr):

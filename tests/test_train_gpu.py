@@ -156,6 +156,56 @@ def test_latent_diffusion_training_step_updates_unet_conditioner_and_ema():
     assert not torch.equal(eps_ema, eps1)
 
 
+def test_log_images_state_dict_and_lightning_optimizer_follow_the_training_engine():
+    """ImageLogger's hook and checkpoints during training (main.py:298-401, ddpm.py:1253-1361): after a step with a large
+    learning rate, `log_images` must sample with the TRAINED EMA weights (they live in the engine's flat buffers), and
+    `state_dict()` / `on_save_checkpoint` must hold the trained weights; the optimiser `configure_optimizers` hands to
+    Lightning is the object `training_step` steps."""
+    from helpers import make_fr_model
+    model = make_fr_model(gain=0.25).train()
+    model.cond_stage_trainable = True
+    model.cond_stage_model.p_uncond = 0.0
+    opt = model.configure_optimizers()
+    assert opt is not None
+    imgs = torch.tanh(rnd(70, 2, 128, 128, 3))
+    batch = {"image": imgs, "class_label": torch.tensor([1, 5])}
+
+    decoded = []
+    real_decode = model.decode_first_stage
+    model.decode_first_stage = lambda z, **kw: (decoded.append(z.detach().clone()), real_decode(z, **kw))[1]
+
+    def logged():
+        torch.manual_seed(1234)
+        return model.log_images(batch, N=2, ddim_steps=4, ddim_eta=0.0)
+
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    log0 = logged()
+    assert set(log0) == {"inputs", "reconstruction", "samples"} and log0["samples"].shape == (2, 3, 128, 128)
+    torch.testing.assert_close(logged()["samples"], log0["samples"], rtol=0, atol=0)       # same seed, same weights
+    z = rnd(90, 2, 3, 32, 32).cuda()
+    model.training_step_latents(z, {"class_label": batch["class_label"].cuda()}, lr=1e-3, t=torch.tensor([300, 800]).cuda(),
+                                noise=rnd(93, 2, 3, 32, 32).cuda())
+    assert model._cond_opt is opt and len(opt.state) > 0, "Lightning's optimiser must be the one that was stepped"
+    log1 = logged()                                            # no explicit sync_trained_weights() call
+    assert (log1["samples"] - log0["samples"]).abs().max().item() > 1e-3, "samples must reflect the training step"
+    sd1 = model.state_dict()
+    k_w, k_e = "model.diffusion_model.out.2.weight", "model_ema.diffusion_modelout2weight"
+    assert not torch.equal(sd1[k_w], sd0[k_w]) and not torch.equal(sd1[k_e], sd0[k_e])
+    tr = model.trainer()
+    ema_sd = {k: v.cpu() for k, v in tr.state_dict_reference(model._ema_flat).items()}
+    assert torch.equal(sd1[k_e].cpu(), ema_sd["out.2.weight"]) and torch.equal(sd1[k_w].cpu(), tr.state_dict_reference()["out.2.weight"].cpu())
+    ckpt = {"state_dict": dict(sd0)}
+    model.on_save_checkpoint(ckpt)
+    assert torch.equal(ckpt["state_dict"][k_w], sd1[k_w]) and ckpt["ldmk_training_state"]["unet"]["step"] == 1
+    # checker: the oracle's DDIM + decode on the synced EMA weights and the trained class embedding
+    torch.manual_seed(1234)
+    x_T = torch.randn((2, 3, 32, 32), device="cuda").cpu()
+    c = model.cond_stage_model.embedding.weight.detach().cpu()[batch["class_label"]][:, None]
+    lat = O.ddim_sample(ema_sd, W.FR_UNET, O.register_schedule(**W.SCHEDULE), 4, x_T, cond=c)
+    # (compared before the quantiser: a latent within 1e-5 of a codebook cell boundary may legitimately decode to another code)
+    torch.testing.assert_close(decoded[-1].cpu(), lat, rtol=5e-4, atol=5e-4)
+
+
 def test_ema_shadow_resumes_from_the_checkpointed_model_ema_and_training_state_round_trips():
     """Resume semantics of LitEma (ema.py:25-44): the packed shadow starts from the `model_ema` buffers a checkpoint
     restored -- not from the live weights -- so one step gives decay*old_ema + (1-decay)*new_weights; and

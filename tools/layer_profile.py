@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def dump(latent, batch, path):
+def dump(latent, batch, path, graph=False):
     import torch
     from bench import StepRunner, build_model
     model, ucfg = build_model(latent, torch.device("cuda", 0))
@@ -34,7 +34,12 @@ def dump(latent, batch, path):
         else:
             calls.append(dict(name=name))
     json.dump(dict(calls=calls, marker_steps=3), open(path, "w"))
-    # marker: three more steps whose dispatches we will read from the END of the trace
+    # marker: three more steps whose dispatches we will read from the END of the trace (--graph: hipGraph replays, so the
+    # durations and the step span are those of the captured step the samplers actually run)
+    if graph:
+        from dsml_thesis_amd.engine import GraphedProgram
+        g = GraphedProgram(run.eager_step)
+        run.step = g.replay
     for _ in range(3):
         run.step()
     torch.cuda.synchronize()
@@ -78,7 +83,9 @@ def join(d):
         out.append((c, d_))
     assert per >= i, (per, i)
     tot = sum(d_ for _, d_ in out)
-    print(f"step total (sum of kernel durations) {tot / 1e3:.3f} ms over {len(out)} calls")
+    span = (int(last[i - 1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])) / 1e6
+    print(f"step total (sum of kernel durations) {tot / 1e3:.3f} ms over {len(out)} calls, {i} kernel launches; "
+          f"first start to last end {span:.3f} ms")
     # machine-readable twin for tools/instep_tune.py: per plan key the plan that ran and its total time in the step
     per_key = {}
     for c, d_ in out:
@@ -118,8 +125,9 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dump")
     ap.add_argument("--join")
+    ap.add_argument("--graph", action="store_true", help="profile hipGraph replays of the step instead of eager launches")
     a = ap.parse_args()
     if a.dump:
-        dump(a.latent, a.batch, a.dump)
+        dump(a.latent, a.batch, a.dump, a.graph)
     else:
         join(a.join)

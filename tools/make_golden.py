@@ -665,9 +665,110 @@ def gen_northstar():
     save("g11_northstar.npz", **g)
 
 
+# --------------------------------------------------------------------------- sampler options (ddim.py:112-203, ddpm.py:1049-1216)
+class ShiftCorrector:
+    """A deterministic stand-in for the (unshipped) score-corrector plugin: modify_score(model, e_t, x, t, c)."""
+
+    def modify_score(self, model, e_t, x, t, c, strength=0.1):
+        return e_t - strength * x * (t.float().view(-1, 1, 1, 1) / 1000.0)
+
+
+def gen_options():
+    """G12: the reference's own DDIMSampler.sample / LatentDiffusion.p_sample_loop with the options no shipped script sets
+    (mask + x0 inpainting blend, temperature, quantize_x0 / quantize_denoised, score_corrector, clip_denoised), on seeded
+    CPU noise.  The reference draws, per DDIM step, q_sample's randn_like (only with a mask) and then noise_like's randn
+    (always): the same draws are replayed here in the same order and stored, so the GPU path can inject them."""
+    from tools import ref_shims
+    ref_shims.install("face_reenactment")
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    torch.set_grad_enabled(False)
+    unet_cfg = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(W.FR_UNET))
+    fs_cfg = dict(target="ldm.models.autoencoder.VQModelInterface",
+                  params=dict(embed_dim=3, n_embed=16384, ddconfig=dict(W.VQ_F4["ddconfig"]),
+                              lossconfig=dict(target="torch.nn.Identity")))
+    cond_cfg = dict(target="ldm.modules.encoders.modules.ClassEmbedder3",
+                    params=dict(embed_dim=512, n_classes=8, key="class_label", p_uncond=0.2))
+    ld = LatentDiffusion(first_stage_config=fs_cfg, cond_stage_config=cond_cfg, num_timesteps_cond=1,
+                         cond_stage_key="class_label", cond_stage_trainable=True, conditioning_key="crossattn",
+                         unet_config=unet_cfg, image_size=32, channels=3, first_stage_key="image", log_every_t=200,
+                         monitor="val_loss_ema", **W.SCHEDULE)
+    sched = O.register_schedule(**W.SCHEDULE)
+    usd = load_recipe(ld.model.diffusion_model, seed=0, gain=0.25)
+    load_recipe(ld.cond_stage_model, seed=0)
+    vsd = load_recipe(ld.first_stage_model, seed=0)
+    code = vsd["quantize.embedding.weight"]
+
+    class CPUDDIM(DDIMSampler):
+        def register_buffer(self, n, a):
+            setattr(self, n, a)
+
+    sampler = CPUDDIM(ld)
+    labels = torch.tensor([1, 6])
+    c = ld.cond_stage_model.embedding(labels[:, None])
+    uc = ld.cond_stage_model.uncond_embedding(torch.zeros(2, 1, dtype=torch.long))
+    xT, x0 = rnd(51, 2, 3, 32, 32), 0.5 * rnd(52, 2, 3, 32, 32)
+    mask = (rnd(53, 2, 1, 32, 32) > 0).float()
+    S = 4
+    g = {}
+
+    def draws(seed, with_mask):
+        torch.manual_seed(seed)
+        mz, nz = [], []
+        for _ in range(S):
+            if with_mask:
+                mz.append(torch.randn(xT.shape))
+            nz.append(torch.randn(xT.shape))
+        return (torch.stack(mz) if with_mask else None), torch.stack(nz)
+
+    # (a) mask + x0, eta 1, temperature 0.7, guidance 3
+    mz, nz = draws(7, True)
+    torch.manual_seed(7)
+    ref, _ = sampler.sample(S=S, batch_size=2, shape=[3, 32, 32], conditioning=c, eta=1.0, x_T=xT, verbose=False, mask=mask,
+                            x0=x0, temperature=0.7, unconditional_guidance_scale=3.0, unconditional_conditioning=uc)
+    mine = O.ddim_sample(usd, W.FR_UNET, sched, S, xT, cond=c, eta=1.0, scale=3.0, uncond=uc, noise=nz, mask=mask, x0=x0,
+                         mask_noise=mz, temperature=0.7)
+    check("ddim mask/x0 + temperature + cfg", ref, mine, 1e-4, 1e-4)
+    g["ddim_mask_temp_cfg"], g["mask_noise"], g["step_noise"] = ref, mz, nz
+    # (b) quantize_x0, eta 0
+    torch.manual_seed(8)
+    ref, inter = sampler.sample(S=S, batch_size=2, shape=[3, 32, 32], conditioning=c, eta=0.0, x_T=xT, verbose=False,
+                                quantize_x0=True, log_every_t=1)
+    mine = O.ddim_sample(usd, W.FR_UNET, sched, S, xT, cond=c, quantize_codebook=code)
+    check("ddim quantize_x0", ref, mine, 1e-4, 1e-4)
+    g["ddim_quantize"], g["ddim_quantize_pred_x0"] = ref, inter["pred_x0"][-1]
+    # (c) score corrector, eta 0, guidance 3
+    corr = ShiftCorrector()
+    torch.manual_seed(9)
+    ref, _ = sampler.sample(S=S, batch_size=2, shape=[3, 32, 32], conditioning=c, eta=0.0, x_T=xT, verbose=False,
+                            score_corrector=corr, corrector_kwargs=dict(strength=0.2), unconditional_guidance_scale=3.0,
+                            unconditional_conditioning=uc)
+    mine = O.ddim_sample(usd, W.FR_UNET, sched, S, xT, cond=c, scale=3.0, uncond=uc,
+                         score_fn=lambda e, x, t: corr.modify_score(None, e, x, t, None, strength=0.2))
+    check("ddim score_corrector + cfg", ref, mine, 1e-4, 1e-4)
+    g["ddim_corrector_cfg"] = ref
+    # (d) ancestral loop: clip_denoised + quantize_denoised + mask, 3 steps.  p_sample draws noise_like first, the mask
+    # blend's q_sample second (ddpm.py:1199-1208)
+    T_ = 3
+    torch.manual_seed(11)
+    pn, pm = [], []
+    for _ in range(T_):
+        pn.append(torch.randn(xT.shape))
+        pm.append(torch.randn(xT.shape))
+    ld.clip_denoised = True
+    torch.manual_seed(11)
+    ref = ld.p_sample_loop(c, (2, 3, 32, 32), x_T=xT, timesteps=T_, verbose=False, quantize_denoised=True, mask=mask, x0=x0)
+    ld.clip_denoised = False
+    mine = O.p_sample_loop(usd, W.FR_UNET, sched, xT, cond=c, timesteps=T_, noise=pn, clip_denoised=True,
+                           quantize_codebook=code, mask=mask, x0=x0, mask_noise=pm)
+    check("p_sample_loop clip + quantize + mask", ref, mine, 1e-4, 1e-4)
+    g["ddpm_clip_quant_mask"], g["ddpm_noise"], g["ddpm_mask_noise"] = ref, torch.stack(pn), torch.stack(pm)
+    save("g12_sampler_options.npz", **g)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar"])
+    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar", "options"])
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -681,6 +782,8 @@ if __name__ == "__main__":
         gen_tf()
     elif a.tree == "northstar":
         gen_northstar()
+    elif a.tree == "options":
+        gen_options()
     else:
-        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar"):
+        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar", "options"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", tree], cwd=ROOT)
