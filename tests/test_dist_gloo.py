@@ -30,7 +30,7 @@ def _worker(rank, world, port, n_items, q):
     t = torch.tensor([0.010 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        q.put((full, t.item()))
+        q.put((full.numpy(), t.item()))         # by value (see above)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -45,6 +45,7 @@ def test_sharded_equals_unsharded_world2(n_items):
     for p in procs:
         p.start()
     full, tmax = q.get(timeout=120)
+    full = torch.from_numpy(full)
     for p in procs:
         p.join(timeout=180)
         assert p.exitcode == 0
@@ -91,7 +92,7 @@ def _sharded_worker(rank, world, port, n_items, decode, q):
     cond = lambda lo, hi: torch.arange(lo, hi, dtype=torch.float32)
     full = parallel.sample_sharded(_FakeSampler(), 4, n_items, (3, 8, 8), cond, seed=5, decode=decode, postprocess=False,
                                    rank=rank, world_size=world)
-    q.put((rank, full, calls))
+    q.put((rank, full.numpy(), calls))      # by value: a shared-memory tensor handle can die with the worker
     dist.barrier()
     dist.destroy_process_group()
 
@@ -116,6 +117,7 @@ def test_sample_sharded_one_collective_also_with_an_idle_rank(n_items, decode):
     if decode:
         ref = _FakeModel().decode_first_stage(ref)
     for rank, full, calls in got:
+        full = torch.from_numpy(full)
         assert calls == ["all_gather_into_tensor"], (rank, calls)       # exactly one collective, no shape probe
         assert full.shape == ref.shape and torch.equal(full, ref)
 
@@ -132,7 +134,7 @@ def _grad_worker(rank, world, port, q):
     tr.P.grad.copy_(torch.arange(tr.P.grad.numel(), dtype=torch.float32) * (rank + 1))
     tr.all_reduce_grads(world)
     if rank == 0:
-        q.put(tr.P.grad.clone())
+        q.put(tr.P.grad.clone().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -145,7 +147,7 @@ def test_gradient_all_reduce_world2():
     procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    g = q.get(timeout=120)
+    g = torch.from_numpy(q.get(timeout=120))
     for p in procs:
         p.join(timeout=180)
         assert p.exitcode == 0
