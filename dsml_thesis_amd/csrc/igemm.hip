@@ -837,6 +837,19 @@ static bool igemm_fast_gather_ok(const ldmk_igemm_args& a) {
   return ups_ok && rows * a.c0 * 4 < (1LL << 32) && rows * a.c1 * 4 < (1LL << 32) && wb < (1LL << 32) && (a.batch <= 1 || a.a1 == nullptr);   // (a batch offsets a0 and w only)
 }
 
+// the second launch of a split-K GEMM: slabs summed in slab order + the epilogue (also used by the slab GEMM, sgemm.hip)
+int launch_splitk_reduce(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
+  if (a.stats_out) {
+    hipLaunchKernelGGL(igemm_reduce_stats_kernel, dim3(a.M / 32, (a.N + 63) / 64), dim3(256), 0, st, a, splitk, ws);
+  } else {
+    long long total = (long long)a.M * (a.N / 4);
+    int g = (int)((total + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(igemm_reduce_kernel, dim3(g, 1, a.batch > 1 ? a.batch : 1), dim3(256), 0, st, a, splitk, ws);
+  }
+  return check_launch("ldmk_igemm(reduce)");
+}
+
 template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF, bool FG>
 static int launch_cfg_g(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st);
 
@@ -855,16 +868,9 @@ static int launch_cfg_g(const ldmk_igemm_args& a, int splitk, float* ws, hipStre
   auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG>;
   cfg_set_attr<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG>();
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, splitk, ws);
-  if (splitk > 1 && a.splitk_counters) {
-    // the last-arriving workgroup of each tile combined the slabs and ran the epilogue inside the launch
-  } else if (splitk > 1 && a.stats_out) {
-    hipLaunchKernelGGL(igemm_reduce_stats_kernel, dim3(a.M / 32, (a.N + 63) / 64), dim3(256), 0, st, a, splitk, ws);
-  } else if (splitk > 1) {
-    long long total = (long long)a.M * (a.N / 4);
-    int g = (int)((total + 255) / 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(igemm_reduce_kernel, dim3(g, 1, a.batch > 1 ? a.batch : 1), dim3(256), 0, st, a, splitk, ws);
-  }
+  if (splitk > 1 && !a.splitk_counters && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
+  // (splitk_counters: the last-arriving workgroup of each tile combined the slabs and ran the epilogue inside the launch;
+  //  raw_slabs: the consumer sums the slabs)
   return check_launch("ldmk_igemm");
 }
 
@@ -950,6 +956,10 @@ void igemm_init_attributes() {
 const char* rgemm_unsupported(const ldmk_igemm_args& a, int rcfg);
 int rgemm_dispatch(const ldmk_igemm_args& a, int rcfg, hipStream_t st);
 constexpr int kNumRCfg = 6;
+// the slab GEMM for small row counts (sgemm.hip): tile_cfg kNumCfg+kNumRCfg+1 .. +8
+const char* sgemm_unsupported(const ldmk_igemm_args& a, int scfg, int splitk);
+int sgemm_dispatch(const ldmk_igemm_args& a, int scfg, int splitk, float* ws, hipStream_t st);
+constexpr int kNumSCfg = 8;
 
 }  // namespace ldmk
 
@@ -974,6 +984,10 @@ extern "C" long long ldmk_igemm_workspace_elems(const ldmk_igemm_args* args) {
     int c2 = 0;
     plan(a, &c2, &sk, 1LL << 50);          // what the planner would use with unlimited scratch
     if (cfg == 0) cfg = c2;
+  }
+  if (cfg > kNumCfg + kNumRCfg) {                                           // slab GEMM: GEGLU may split when the consumer reduces
+    if (sk <= 1 || (a.epi == LDMK_EPI_GEGLU && !a.raw_slabs)) return 0;
+    return (long long)sk * (long long)a.M * a.N;
   }
   if (cfg > kNumCfg || a.epi == LDMK_EPI_GEGLU || sk <= 1) return 0;      // row GEMM / GEGLU never split K
   return (long long)(a.batch > 1 ? a.batch : 1) * sk * (long long)a.M * a.N;
@@ -1018,16 +1032,28 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   if (a.stats_out)
     LDMK_REQUIRE(a.M % 32 == 0 && a.rows_per_sample % 32 == 0 && a.epi == LDMK_EPI_NONE && a.batch <= 1,
                  "ldmk_igemm: stats_out needs M%%32==0, rows_per_sample%%32==0, no GEGLU, no batching");
-  LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg + kNumRCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]", a.tile_cfg,
-               kNumCfg + kNumRCfg);
+  LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg + kNumRCfg + kNumSCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]", a.tile_cfg,
+               kNumCfg + kNumRCfg + kNumSCfg);
   LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 64, "ldmk_igemm: splitk=%d outside [0,64]", a.splitk);
   LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.compute == LDMK_COMPUTE_BF16, "ldmk_igemm: compute=%d", a.compute);
-  LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.tile_cfg <= kNumCfg, "ldmk_igemm: the row GEMM tiles are fp32 only");
+  LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.tile_cfg <= kNumCfg, "ldmk_igemm: the row / slab GEMM tiles are fp32 only");
   if (a.alpha == 0.f) a.alpha = 1.f;
   int cfg = 0, sk = 1;
   plan(a, &cfg, &sk, a.splitk_ws ? a.splitk_ws_elems : 0);
   if (a.tile_cfg > 0) cfg = a.tile_cfg;
   if (g_force_cfg > 0 && (g_force_cfg <= kNumCfg || !rgemm_unsupported(a, g_force_cfg - kNumCfg - 1))) cfg = g_force_cfg;
+  if (cfg > kNumCfg + kNumRCfg) {      // slab GEMM: wave-autonomous, K split over the waves of a workgroup and over workgroups
+    const int scfg = cfg - kNumCfg - kNumRCfg - 1;
+    int ssk = a.splitk > 0 ? a.splitk : 1;
+    const char* why = sgemm_unsupported(a, scfg, ssk);
+    LDMK_REQUIRE(why == nullptr, "ldmk_igemm: tile_cfg=%d splitk=%d (slab GEMM) cannot run this problem: %s", cfg, ssk, why ? why : "");
+    if (ssk > 1)
+      LDMK_REQUIRE_MEM(a.splitk_ws && ssk * (long long)a.M * a.N <= a.splitk_ws_elems,
+                       "ldmk_igemm: splitk=%d needs a workspace of %lld floats (ldmk_igemm_workspace_elems), %lld given", ssk,
+                       ssk * (long long)a.M * a.N, a.splitk_ws ? a.splitk_ws_elems : 0LL);
+    if (!launch) return LDMK_OK;
+    return sgemm_dispatch(a, scfg, ssk, a.splitk_ws, (hipStream_t)stream);
+  }
   if (cfg > kNumCfg) {      // row GEMM: one wave per output tile, K never split
     const char* why = rgemm_unsupported(a, cfg - kNumCfg - 1);
     LDMK_REQUIRE(why == nullptr, "ldmk_igemm: tile_cfg=%d (row GEMM) cannot run this problem: %s", cfg, why ? why : "");
@@ -1035,7 +1061,9 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
     return rgemm_dispatch(a, cfg - kNumCfg - 1, (hipStream_t)stream);
   }
   if (a.splitk > 0) sk = a.splitk;
-  if (a.epi == LDMK_EPI_GEGLU) sk = 1;
+  if (a.epi == LDMK_EPI_GEGLU && !a.raw_slabs) sk = 1;
+  LDMK_REQUIRE(!a.raw_slabs || (sk >= 2 && a.batch <= 1 && !a.splitk_counters && !a.stats_out),
+               "ldmk_igemm: raw_slabs needs a split-K plan (splitk >= 2), no batching / in-launch combine / stats_out");
   if (sk > 1 && a.splitk_counters) {
     const long long tiles = (long long)(a.batch > 1 ? a.batch : 1) * ((a.M + 63) / 64) * ((a.N + 63) / 64);   // smallest tile: 64x64
     LDMK_REQUIRE_MEM(tiles <= a.splitk_counters_len, "ldmk_igemm: in-launch split-K combine needs %lld zeroed counters, %d given",

@@ -223,6 +223,59 @@ __global__ __launch_bounds__(256) void conv3x3_out_kernel(const float* __restric
   }
 }
 
+// The same layer for SMALL images (batch 1-2 of the small-batch route): the 16x16-pixel workgroups above give a 32x32 image
+// 4 workgroups on 256 CUs (57 us for 8.8 MFLOP, profiles/r02_layers32_b1.txt).  Here a workgroup owns 4x4 output pixels
+// (64 workgroups per 32x32 image) and 16 lanes share a pixel, each taking every 16th float4 of the channel axis: inputs
+// come straight from global memory (the 6x6 halo of a tile is 23 KB, L2-resident), the 9 cin COUT weights are staged in
+// LDS once, GroupNorm+SiLU (optional coef planes) is applied per use, and the 16 partial sums of a pixel are folded
+// with four xor-shuffles in a fixed order.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_out_small_kernel(const float* __restrict__ x, const float* __restrict__ coef,
+                                                                const float* __restrict__ w, const float* __restrict__ bias,
+                                                                float* __restrict__ out, int n, int h, int wd, int cin) {
+  extern __shared__ float wl[];                                        // [9][cin][COUT]
+  for (int i = threadIdx.x; i < 9 * cin * COUT; i += 256) wl[i] = w[i];
+  const int tx_n = (wd + 3) / 4, ty_n = (h + 3) / 4;
+  const int b = blockIdx.x / (tx_n * ty_n), t = blockIdx.x % (tx_n * ty_n);
+  const int pix = threadIdx.x >> 4, g = threadIdx.x & 15;
+  const int oy = (t / tx_n) * 4 + (pix >> 2), ox = (t % tx_n) * 4 + (pix & 3);
+  const float* sc = coef ? coef + ((long long)b * 2) * cin : nullptr;
+  __syncthreads();
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+  const int c4n = cin >> 2;
+  for (int c4 = g; c4 < c4n; c4 += 16) {
+    const int c = 4 * c4;
+    float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sc) { s4 = *reinterpret_cast<const float4*>(sc + c); t4 = *reinterpret_cast<const float4*>(sc + cin + c); }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int yy = oy + tap / 3 - 1, xx = ox + tap % 3 - 1;
+      if (yy < 0 || yy >= h || xx < 0 || xx >= wd || oy >= h || ox >= wd) continue;    // zero padding of the ACTIVATED tensor
+      float4 v = *reinterpret_cast<const float4*>(x + (((long long)b * h + yy) * wd + xx) * cin + c);
+      if (sc) {
+        v.x = silu_f(fmaf(v.x, s4.x, t4.x)); v.y = silu_f(fmaf(v.y, s4.y, t4.y));
+        v.z = silu_f(fmaf(v.z, s4.z, t4.z)); v.w = silu_f(fmaf(v.w, s4.w, t4.w));
+      }
+      const float* wp = wl + ((long long)tap * cin + c) * COUT;
+#pragma unroll
+      for (int co = 0; co < COUT; ++co)
+        acc[co] = fmaf(v.w, wp[3 * COUT + co], fmaf(v.z, wp[2 * COUT + co], fmaf(v.y, wp[COUT + co], fmaf(v.x, wp[co], acc[co]))));
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc[co] += __shfl_xor(acc[co], o, 64);
+  }
+  if (g == 0 && oy < h && ox < wd) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+      out[((long long)b * COUT + co) * h * wd + (long long)oy * wd + ox] = acc[co] + (bias ? bias[co] : 0.f);
+  }
+}
+
 __global__ void conv1x1_nchw_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                     const float* __restrict__ bias, float* __restrict__ out, int n, int hw, int cin,
                                     int cout) {
@@ -522,7 +575,7 @@ static inline unsigned grid_for(long long total, int block = 256, int cap = 4096
 using namespace ldmk;
 
 // 2.1: folded LayerNorm, Winograd / upsample-phase transforms, split-K up to 64
-extern "C" int ldmk_version(void) { return 210; }
+extern "C" int ldmk_version(void) { return 220; }
 
 namespace ldmk { void igemm_init_attributes(); }
 
@@ -608,6 +661,28 @@ extern "C" int ldmk_conv3x3_out(const float* x, const float* coef, const float* 
     default: hipLaunchKernelGGL(conv3x3_out_kernel<4>, grid, block, 0, st, x, coef, w, bias, out, n, h, w_, cin); break;
   }
   return check_launch("ldmk_conv3x3_out");
+}
+
+extern "C" int ldmk_conv3x3_out_small(const float* x, const float* coef, const float* w, const float* bias, float* out, int n,
+                                      int h, int w_, int cin, int cout, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(x && w && out && n > 0 && h > 0 && w_ > 0 && cin > 0, "ldmk_conv3x3_out_small: bad args");
+  LDMK_REQUIRE(cout >= 1 && cout <= 4, "ldmk_conv3x3_out_small: cout=%d must be in [1,4]", cout);
+  LDMK_REQUIRE(cin % 4 == 0 && 9 * cin * cout * 4 <= 60 * 1024, "ldmk_conv3x3_out_small: cin=%d must be a multiple of 4 and the "
+               "weights must fit 60 KB of LDS", cin);
+  const long long blocks = (long long)n * ((h + 3) / 4) * ((w_ + 3) / 4);
+  LDMK_REQUIRE(blocks < (1LL << 31), "ldmk_conv3x3_out_small: too many tiles");
+  const dim3 grid((unsigned)blocks), block(256);
+  const size_t lds = (size_t)9 * cin * cout * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  switch (cout) {
+    case 1: hipLaunchKernelGGL(conv3x3_out_small_kernel<1>, grid, block, lds, st, x, coef, w, bias, out, n, h, w_, cin); break;
+    case 2: hipLaunchKernelGGL(conv3x3_out_small_kernel<2>, grid, block, lds, st, x, coef, w, bias, out, n, h, w_, cin); break;
+    case 3: hipLaunchKernelGGL(conv3x3_out_small_kernel<3>, grid, block, lds, st, x, coef, w, bias, out, n, h, w_, cin); break;
+    default: hipLaunchKernelGGL(conv3x3_out_small_kernel<4>, grid, block, lds, st, x, coef, w, bias, out, n, h, w_, cin); break;
+  }
+  return check_launch("ldmk_conv3x3_out_small");
 }
 
 extern "C" int ldmk_conv1x1_nchw(const float* x, const float* w, const float* bias, float* out, int n, int hw, int cin,

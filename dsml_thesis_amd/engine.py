@@ -108,7 +108,7 @@ class Program:
             self._skws = torch.empty(int(elems), device=self.device, dtype=torch.float32)
             self._all.append(self._skws)
             for _, _, a, name in self.calls:          # re-point GEMMs recorded against an older scratch
-                if name == "ldmk_igemm":
+                if name == "ldmk_igemm" and a.splitk_ws and not hasattr(a, "_own_slabs"):
                     a.splitk_ws, a.splitk_ws_elems = self._skws.data_ptr(), self._skws.numel()
         return self._skws
 
@@ -120,10 +120,10 @@ class Program:
             self._all.append(self._skcnt)
         return self._skcnt
 
-    def igemm(self, args, scale_m=None, allow_splitk=True, batch_is_samples=True):
-        """Record a GEMM.  The (tile shape, K split) pair is planned here, once: for the real M, or -- with
-        scale_m = (num, den) -- for M*num/den rows, which pins the K-summation order so that results are
-        bitwise independent of how a batch is split across calls / ranks."""
+    def plan(self, args, scale_m=None, allow_splitk=True, batch_is_samples=True):
+        """Choose (tile shape, K split) for a GEMM and pin them in `args`: for the real M, or -- with scale_m = (num, den) --
+        for M*num/den rows, which pins the K-summation order so that results are bitwise independent of how a batch is
+        split across calls / ranks.  Returns (tile_cfg, splitk)."""
         m, nbatch = args.M, args.batch
         if scale_m is not None and scale_m[0] != scale_m[1]:
             if nbatch > 1 and batch_is_samples:   # batched GEMM (one problem per sample): the job-wide view has more problems
@@ -134,13 +134,16 @@ class Program:
         # (a batch that is not per sample -- the 16 transform positions of a Winograd convolution -- is part of the plan key)
         tuned = tuned_plan(args, args.M) if (nbatch <= 1 or not batch_is_samples) and args.M > 0 else None
         if tuned is not None and tuned[0] > 6:
-            # a row-GEMM wave tile: legal only with the fragment-order weight copy and when the tile divides this
-            # problem (per-sample operands need rows_per_sample % tile rows == 0); else the heuristic decides
-            saved = (args.M, args.batch, args.tile_cfg, args.splitk)
-            args.M, args.batch, args.tile_cfg, args.splitk = m, nbatch, int(tuned[0]), 1
+            # a row-GEMM wave tile (7..12, never splits K) or a slab-GEMM shape (13..20, small row counts): legal only with
+            # the fragment-order weight copy and when the tile divides this problem (per-sample operands need
+            # rows_per_sample % tile rows == 0); else the heuristic decides
+            saved = (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems)
+            args.M, args.batch, args.tile_cfg = m, nbatch, int(tuned[0])
+            args.splitk = 1 if tuned[0] <= 12 else int(tuned[1])
+            args.splitk_ws, args.splitk_ws_elems = 1, 1 << 40          # (validated against the real scratch below)
             if not args.w_frag or self.lib.ldmk_igemm_check(C.byref(args)) != 0:
                 tuned = None
-            args.M, args.batch, args.tile_cfg, args.splitk = saved
+            (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems) = saved
         if tuned is not None:
             cfg.value, sk.value = int(tuned[0]), int(tuned[1])
         else:
@@ -151,6 +154,12 @@ class Program:
         args.M, args.batch = m, nbatch
         args.tile_cfg, args.splitk = cfg.value, max(1, sk.value)
         args.splitk_ws, args.splitk_ws_elems = 0, 0
+        return args.tile_cfg, args.splitk
+
+    def igemm(self, args, scale_m=None, allow_splitk=True, batch_is_samples=True):
+        """Record a GEMM (planned here, once: see plan()); a split-K plan gets the program's shared scratch and is
+        followed by its reduce launch."""
+        self.plan(args, scale_m, allow_splitk, batch_is_samples)
         if args.splitk > 1:
             need = max(1, args.batch) * args.splitk * args.M * args.N
             ws = self.splitk_workspace(need)
@@ -160,13 +169,28 @@ class Program:
             # for the 8x8-level convolutions at batch 1) reading `splitk` slabs with sc1 traffic, while the reduce launch
             # spreads the same bytes over the whole chip.  Measured A/B (sample-steps/s, reduce launch -> in-launch):
             # first version (one atomic load per element) 476 -> 446 at 64x64x4 B=16, 1657 -> 1231 at 32x32x3, 249 -> 141
-            # at B=1; with the loads batched (64 in flight per wave) 1720 -> 1614 at 32x32x3 and 252 -> 249 at B=1.  The
-            # batch-1 step loses ~130 launches this way and is not faster: its time is the chain of dependent memory round
-            # trips inside the launches, not the launch count.  LDMK_SPLITK_IN_LAUNCH=1 turns it on.
+            # at B=1; with the loads batched (64 in flight per wave) 1720 -> 1614 at 32x32x3 and 252 -> 249 at B=1.
+            # LDMK_SPLITK_IN_LAUNCH=1 turns it on.
             if os.environ.get("LDMK_SPLITK_IN_LAUNCH"):
                 cnt = self.splitk_counters()
                 args.splitk_counters, args.splitk_counters_len = cnt.data_ptr(), cnt.numel()
         self.calls.append((self.lib.ldmk_igemm, (C.byref(args),), args, "ldmk_igemm"))
+
+    def igemm_raw(self, args, slabs):
+        """Record an already planned GEMM that leaves its raw K slabs [splitk][M][N] in `slabs` for the consumer
+        (ldmk_post / ldmk_attn_self_small) -- no reduce launch; with splitk == 1 the one 'slab' is simply the GEMM's output
+        (the caller passes no bias / residual, so that output is the raw product)."""
+        if args.splitk > 1:
+            args.raw_slabs = 1
+            args.splitk_ws, args.splitk_ws_elems = slabs.data_ptr(), args.splitk * args.M * args.N
+        else:
+            args.raw_slabs = 0
+            args.out = slabs.data_ptr()
+        args._own_slabs = slabs                       # (keeps the buffer alive; marks the call for splitk_workspace below)
+        self.calls.append((self.lib.ldmk_igemm, (C.byref(args),), args, "ldmk_igemm"))
+
+    def post(self, pargs, keep=None):
+        self.calls.append((self.lib.ldmk_post, (C.byref(pargs),), (pargs, keep), "ldmk_post"))
 
     def run(self, stream=None):
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
@@ -242,7 +266,7 @@ class NetBuilder:
         return y
 
     def conv(self, x0, x1, wp, bias, h, w, coef=None, stride=1, pad_lo=1, upsample=False, batch_vec=None, bv_ld=0,
-             residual=None, out=None, stats=False):
+             residual=None, out=None, stats=False, wf=None):
         """3x3 conv (implicit GEMM) with optional GN+SiLU prologue / per-sample vector / residual epilogue."""
         pg, n, ops = self.pg, self.n, self.ops
         c0 = x0.shape[-1]
@@ -259,7 +283,7 @@ class NetBuilder:
         a = ops.make_igemm_args(n * oh * ow, cout, 9 * (c0 + c1), x0, c0, wp, out, cout, oh * ow, a1=x1, c1=c1,
                                 conv=(h, w, oh, ow, stride, pad_lo, 1 if upsample else 0),
                                 tf=L.TF_NONE if coef is None else L.TF_AFFINE_SILU, tf_coef=coef, bias=bias,
-                                residual=residual)
+                                residual=residual, w_frag=wf)
         if batch_vec is not None:
             a.batch_vec, a.batch_vec_ld = self.ptr(batch_vec), bv_ld
         self._maybe_stats(a, out.view(-1, cout), oh * ow, stats)
@@ -287,7 +311,7 @@ class NetBuilder:
                 and w in (8, 16, 32, 64, 128) and (h * w) % 32 == 0 and (w >= 16 or (h // 2) % 2 == 0))
 
     def gn_conv(self, x0, x1, h, w, gamma, beta, eps, wp, u, bias, batch_vec=None, bv_ld=0, residual=None, out=None,
-                stats=False):
+                stats=False, wf=None):
         """GroupNorm(32)+SiLU of (the concat of) x0 | x1, then the 3x3 convolution with packed weights `wp` (implicit GEMM)
         or, when `u` (ops.pack_winograd) is given and the problem is large enough, through Winograd."""
         pg, n, ops, p_ = self.pg, self.n, self.ops, self.ptr
@@ -297,7 +321,7 @@ class NetBuilder:
         if u is None or not self.winograd_ok(cin, h, w):
             y = self.gn_act(x0, x1, h * w, gamma, beta, eps)
             res = self.conv(y.view(n, h, w, cin), None, wp, bias, h, w, batch_vec=batch_vec, bv_ld=bv_ld, residual=residual,
-                            out=out, stats=stats)
+                            out=out, stats=stats, wf=wf)
             self.release(y)
             return res
         cout = u.shape[2]

@@ -11,6 +11,7 @@ A_ROWS, A_CONV3X3 = 0, 1
 TF_NONE, TF_AFFINE, TF_AFFINE_SILU, TF_LAYERNORM, TF_LAYERNORM_FOLDED = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GEGLU = 0, 1
 COMPUTE_F32, COMPUTE_BF16 = 0, 1
+POST_NONE, POST_GROUPNORM, POST_LAYERNORM = 0, 1, 2
 
 _fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -32,6 +33,17 @@ class IgemmArgs(C.Structure):
         ("splitk_ws", _fp), ("splitk_ws_elems", C.c_longlong), ("stats_out", _fp), ("compute", C.c_int), ("splitk_counters", _fp), ("splitk_counters_len", C.c_int),
         ("w_frag", _fp),
         ("ln_colsum", _fp),
+        ("raw_slabs", C.c_int),
+    ]
+
+
+class PostArgs(C.Structure):
+    _fields_ = [
+        ("src", _fp), ("nslab", C.c_int), ("slab_stride", C.c_longlong), ("M", C.c_int), ("N", C.c_int),
+        ("rows_per_sample", C.c_int), ("alpha", C.c_float), ("bias", _fp), ("batch_vec", _fp), ("batch_vec_ld", C.c_int),
+        ("residual", _fp), ("ldr", C.c_int), ("geglu", C.c_int), ("raw_out", _fp), ("ld_raw", C.c_int), ("norm", C.c_int),
+        ("x1", _fp), ("c1", C.c_int), ("groups", C.c_int), ("eps", C.c_float), ("gamma", _fp), ("beta", _fp),
+        ("silu", C.c_int), ("norm_out", _fp), ("ld_norm", C.c_int), ("gn_cache_floats", C.c_int),
     ]
 
 
@@ -70,7 +82,9 @@ _SIGS = {
     "ldmk_gn_coef": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _fp]),
     "ldmk_ln_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp]),
     "ldmk_gn_apply": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_post": (C.c_int, [C.POINTER(PostArgs), _fp]),
     "ldmk_attn_self": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    "ldmk_attn_self_small": (C.c_int, [_fp, C.c_int, C.c_longlong, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_cross": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_float, _fp]),
     "ldmk_softmax_rows": (C.c_int, [_fp, C.c_longlong, C.c_int, C.c_float, _fp]),
@@ -78,6 +92,7 @@ _SIGS = {
     "ldmk_timestep_embedding": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp]),
     "ldmk_conv3x3_in": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_conv3x3_out": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_conv3x3_out_small": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_conv1x1_nchw": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_ddim_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_float, C.c_int, _fp, _fp, C.c_longlong, C.c_int, _fp, _fp,
                                  C.c_int, C.c_int, C.c_int, _fp]),

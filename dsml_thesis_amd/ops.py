@@ -10,7 +10,8 @@ from . import lib as L
 
 
 def _ptr(t):
-    return 0 if t is None else t.data_ptr()
+    """device pointer of a tensor; None -> 0; an int is taken as a raw device pointer (e.g. an offset into a tensor)"""
+    return 0 if t is None else (t if isinstance(t, int) else t.data_ptr())
 
 
 def stream():
@@ -113,12 +114,33 @@ def ln_stats(x2d, eps=1e-5, out=None):
     return out
 
 
+def make_post_args(src, M, N, rows_per_sample, nslab=1, slab_stride=None, bias=None, batch_vec=None, batch_vec_ld=0,
+                   residual=None, ldr=None, geglu=False, raw_out=None, ld_raw=None, norm=L.POST_NONE, x1=None, c1=0,
+                   gamma=None, beta=None, eps=1e-5, silu=False, norm_out=None, ld_norm=None, groups=32, alpha=1.0):
+    """ldmk_post_args (include/ldmk.h): the split-K reduce + GEMM epilogue + GroupNorm / LayerNorm launch."""
+    a = L.PostArgs()
+    a.src, a.nslab, a.slab_stride = _ptr(src), nslab, (M * N if slab_stride is None else slab_stride)
+    a.M, a.N, a.rows_per_sample, a.alpha = M, N, rows_per_sample, alpha
+    a.bias, a.batch_vec, a.batch_vec_ld = _ptr(bias), _ptr(batch_vec), batch_vec_ld
+    a.residual, a.ldr = _ptr(residual), (N if ldr is None else ldr)
+    a.geglu = 1 if geglu else 0
+    a.raw_out, a.ld_raw = _ptr(raw_out), ((N // 2 if geglu else N) if ld_raw is None else ld_raw)
+    a.norm, a.x1, a.c1, a.groups, a.eps = norm, _ptr(x1), c1, groups, float(eps)
+    a.gamma, a.beta, a.silu = _ptr(gamma), _ptr(beta), 1 if silu else 0
+    a.norm_out, a.ld_norm = _ptr(norm_out), ((N + c1) if ld_norm is None else ld_norm)
+    return a
+
+
+def post(args):
+    L.call("ldmk_post", C.byref(args), stream())
+
+
 # ------------------------------------------------------------------------------------------ igemm
 def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0, conv=None, tf=L.TF_NONE,
                     tf_coef=None, row_stats=None, ln_gamma=None, ln_beta=None, b_trans=False, ldb=None, bias=None,
                     batch_vec=None, batch_vec_ld=0, residual=None, epi=L.EPI_NONE, batch=1, a_bstride=0, w_bstride=0,
                     out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None, w_frag=None, tile_cfg=0, compute=0, ln_colsum=None,
-                    splitk_counters=None):
+                    splitk_counters=None, raw_slabs=False):
     a = L.IgemmArgs()
     a.M, a.N, a.K = M, N, K
     a.a0, a.a1, a.c0, a.c1 = _ptr(a0), _ptr(a1), c0, c1
@@ -140,6 +162,7 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
     a.splitk = splitk
     a.w_frag, a.tile_cfg, a.compute = _ptr(w_frag), tile_cfg, compute
     a.ln_colsum = _ptr(ln_colsum)
+    a.raw_slabs = 1 if raw_slabs else 0
     if splitk_counters is not None:
         a.splitk_counters, a.splitk_counters_len = splitk_counters.data_ptr(), splitk_counters.numel()
     if splitk_ws is not None:
@@ -366,12 +389,14 @@ def conv3x3_in(x0, wp, bias, cout, x1=None, out=None):
     return out
 
 
-def conv3x3_out(x, coef, wp, bias, cout, out=None):
-    """NHWC (n,h,w,cin) -> GN+SiLU -> conv -> NCHW (n,cout,h,w).  wp: [9*cin][cout]."""
+def conv3x3_out(x, coef, wp, bias, cout, out=None, small=False):
+    """NHWC (n,h,w,cin) -> GN+SiLU -> conv -> NCHW (n,cout,h,w).  wp: [9*cin][cout].  small: the 4x4-pixel tiling for
+    small images (ldmk_conv3x3_out_small)."""
     n, h, w_, cin = x.shape
     if out is None:
         out = torch.empty(n, cout, h, w_, device=x.device, dtype=torch.float32)
-    L.call("ldmk_conv3x3_out", _ptr(x), _ptr(coef), _ptr(wp), _ptr(bias), _ptr(out), n, h, w_, cin, cout, stream())
+    L.call("ldmk_conv3x3_out_small" if small else "ldmk_conv3x3_out", _ptr(x), _ptr(coef), _ptr(wp), _ptr(bias), _ptr(out),
+           n, h, w_, cin, cout, stream())
     return out
 
 

@@ -292,7 +292,9 @@ class UNetModel(nn.Module):
         P["out"] = ops.pack_conv3x3_narrow(sd["out.2.weight"])
         P["freqs"] = ops.timestep_freqs(self.model_channels, device=dev)
         # fragment-order copies of the token-row Linear weights: the row GEMM (csrc/rgemm.hip) reads these
-        for k in [k for k in P if k.rsplit(".", 1)[-1] in ("pin", "pout", "qkv_ln", "o1", "q2_ln", "o2", "ff1_ln", "ff2", "skip")
+        # (and the slab GEMM of the small-batch route, csrc/sgemm.hip, which also takes the ResBlock convolutions: c1 / c2)
+        for k in [k for k in P if k.rsplit(".", 1)[-1] in ("pin", "pout", "qkv_ln", "o1", "q2_ln", "o2", "ff1_ln", "ff2", "skip",
+                                                            "c1", "c2")
                   or (_UNFOLDED and k.rsplit(".", 1)[-1] in ("qkv", "ff1"))]:
             wf = ops.pack_wfrag(P[k])
             if wf is not None:
@@ -353,18 +355,19 @@ class UNetModel(nn.Module):
             bv = emb_all.data_ptr() + 4 * self._emb_off[prefix]
             h1 = nb_.gn_conv(x0, x1, h, w, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5,
                              P[prefix + "c1"], P.get(prefix + "c1#wg"), sd[prefix + "in_layers.2.bias"], batch_vec=bv,
-                             bv_ld=self._emb_total, stats=True)
+                             bv_ld=self._emb_total, stats=True, wf=P.get(prefix + "c1#f"))
             g2, b2 = sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"]
             if m.cin != m.cout:
                 x0r = x0.reshape(n * hw, -1)
                 x1r = None if x1 is None else x1.reshape(n * hw, -1)
                 skip = lin(x0r, P[prefix + "skip"], sd[prefix + "skip_connection.bias"], hw, x1=x1r, wf=P.get(prefix + "skip#f"))
                 out = nb_.gn_conv(h1, None, h, w, g2, b2, 1e-5, P[prefix + "c2"], P.get(prefix + "c2#wg"),
-                                  sd[prefix + "out_layers.3.bias"], residual=skip, out=skip.view(n, h, w, m.cout), stats=True)
+                                  sd[prefix + "out_layers.3.bias"], residual=skip, out=skip.view(n, h, w, m.cout), stats=True,
+                                  wf=P.get(prefix + "c2#f"))
             else:
                 assert x1 is None
                 out = nb_.gn_conv(h1, None, h, w, g2, b2, 1e-5, P[prefix + "c2"], P.get(prefix + "c2#wg"),
-                                  sd[prefix + "out_layers.3.bias"], residual=x0, stats=True)
+                                  sd[prefix + "out_layers.3.bias"], residual=x0, stats=True, wf=P.get(prefix + "c2#f"))
             nb_.release(h1)
             return out
 
@@ -489,7 +492,12 @@ class UNetModel(nn.Module):
         key = (n, H, W_, L_ctx, c_concat, policy_n)
         pg = self._programs.get(key)
         if pg is None:
-            pg = self._build(n, H, W_, L_ctx, c_concat, policy_n)
+            from . import unet_small
+            if unet_small.wants_small_route(policy_n, H, W_, L_ctx):
+                # batch 1-2 (the reference's shipped talking-face mode): the program cut for few dependent launches
+                pg = unet_small.build_small(self, n, H, W_, L_ctx, c_concat, policy_n)
+            else:
+                pg = self._build(n, H, W_, L_ctx, c_concat, policy_n)
             self._programs[key] = pg
         return pg
 

@@ -92,7 +92,10 @@ typedef struct ldmk_igemm_args {
   long long a_bstride, w_bstride, out_bstride;
   float alpha;               /* scale applied to the product before the epilogue (1.0 default)    */
   int tile_cfg;              /* 0 = choose from the problem size; 1..6 = pin an LDS-tiled workgroup shape, 7..12 = pin
-                                a row-GEMM wave tile (32 TM x 32 TN: 1x5, 2x5, 1x4, 2x4, 1x2, 1x1).  The K-summation
+                                a row-GEMM wave tile (32 TM x 32 TN: 1x5, 2x5, 1x4, 2x4, 1x2, 1x1), 13..20 = pin a
+                                slab-GEMM shape for small row counts (csrc/sgemm.hip; wave tile x waves that split K
+                                inside the workgroup: 2x1x4, 2x2x4, 1x1x4, 1x2x4, 1x1x8, 1x1x16, 2x1x8, 1x2x8; needs
+                                w_frag; stride-1 3x3 convolutions and rows mode).  The K-summation
                                 order depends on (tile_cfg, splitk), so a caller that needs results that are
                                 bitwise independent of the batch size pins both (ldmk_igemm_plan)          */
   int splitk;                /* 0 = choose; 1 = none; 2..64 = split K over that many workgroups            */
@@ -112,6 +115,10 @@ typedef struct ldmk_igemm_args {
                                 problems may run on the wave-autonomous row GEMM (tile_cfg 7..12: no LDS, no barrier;
                                 csrc/rgemm.hip), which is what the short-K Linear layers of the transformer blocks want */
   const float* ln_colsum;    /* LDMK_TF_LAYERNORM_FOLDED: [N] column sums of w (= diag(gamma) W), see ldmk_fold_layernorm */
+  int raw_slabs;             /* != 0 (split-K plans only, splitk >= 2, batch <= 1): leave the raw partial slabs
+                                [splitk][M][N] in splitk_ws and launch NO reduce kernel -- the consumer (ldmk_post,
+                                ldmk_attn_self with qkv_slabs) sums them in slab order and applies bias / per-sample vector /
+                                residual / GEGLU itself; `out`, `bias`, `batch_vec`, `residual` and `epi` are then not used */
 } ldmk_igemm_args;
 
 int ldmk_igemm(const ldmk_igemm_args* args, void* stream);
@@ -193,6 +200,50 @@ int ldmk_gn_apply(const float* x0, int c0, const float* x1, int c1, const float*
                   int silu, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ldmk_post: everything that sits BETWEEN two GEMMs of a ResBlock / transformer block, as one launch -- the small-batch
+ * (latency-bound) route of the UNet: batch 1 is the reference's shipped talking-face mode
+ * (talking_face/progressive_sampling_difftalk.py:282-317, batch size 1 at :350), where a step is a chain of dependent
+ * launches and every separate reduce / statistics / apply pass costs a launch ramp plus a memory round trip.
+ *     v      = alpha * (slab_0 + slab_1 + ... in this order) + bias + batch_vec[sample] + residual
+ *              -- the split-K reduce and the GEMM epilogue: openaimodel.py:264-275 (timestep vector, residual),
+ *                 attention.py:211-215,261 (residual adds);  nslab = 1 with the other operands NULL reads a plain tensor
+ *     raw    = v, or with geglu != 0 value * gelu(gate) of the packed (value | gate) 32-column pairs (attention.py:37-50)
+ *     normed = LDMK_POST_GROUPNORM: GroupNorm(groups, eps)[+SiLU] over the channel concat (raw | x1), statistics per
+ *              (sample, group) in two passes (openaimodel.py:201-203,225-227,683-684; attention.py:254; the concat of a
+ *              skip connection is two base pointers, :736, and groups may straddle the seam);
+ *              LDMK_POST_LAYERNORM: LayerNorm(raw) * gamma + beta per row (attention.py:203-205, eps 1e-5)
+ * raw_out and norm_out are both optional (at least one).  Fixed summation orders: bitwise reproducible. */
+enum { LDMK_POST_NONE = 0, LDMK_POST_GROUPNORM = 1, LDMK_POST_LAYERNORM = 2 };
+typedef struct ldmk_post_args {
+  const float* src;          /* [nslab][M][N] raw GEMM accumulators (ldmk_igemm with raw_slabs), or a plain [M][N] tensor */
+  int nslab;                 /* >= 1 */
+  long long slab_stride;     /* floats between slabs (>= M*N) */
+  int M, N;                  /* rows (n * H * W) and columns of src; N % 4 == 0 */
+  int rows_per_sample;       /* H * W */
+  float alpha;               /* scale of the slab sum (1.0) */
+  const float* bias;         /* [N] or NULL */
+  const float* batch_vec;    /* [n][batch_vec_ld] per-sample vector or NULL */
+  int batch_vec_ld;
+  const float* residual;     /* [M][ldr] or NULL */
+  int ldr;
+  int geglu;                 /* != 0: src holds packed (value | gate) pairs, raw_out is [M][N/2]; no norm / residual / batch_vec */
+  float* raw_out;            /* [M][ld_raw] or NULL */
+  int ld_raw;
+  int norm;                  /* LDMK_POST_* */
+  const float* x1;           /* GroupNorm: second tensor of the channel concat, [M][c1] contiguous, or NULL */
+  int c1;
+  int groups;                /* GroupNorm: 32 in every reference layer */
+  float eps;
+  const float* gamma;        /* [N + c1] */
+  const float* beta;         /* [N + c1] */
+  int silu;                  /* GroupNorm: apply SiLU after the affine */
+  float* norm_out;           /* [M][ld_norm], ld_norm >= N + c1 */
+  int ld_norm;
+  int gn_cache_floats;       /* (set by the library) */
+} ldmk_post_args;
+int ldmk_post(const ldmk_post_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Attention.
  * ldmk_attn_self: flash-style softmax(Q K^T * scale) V for d_head = 32 on the f32 matrix cores;
  *   qkv is the fused projection [n*tokens][3*C] (q | k | v), out [n*tokens][C].
@@ -202,6 +253,13 @@ int ldmk_gn_apply(const float* x0, int c0, const float* x1, int c1, const float*
  * ldmk_softmax_rows: in-place row softmax of x*scale; model.py:191-192 (VQGAN AttnBlock).
  */
 int ldmk_attn_self(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream);
+/* ldmk_attn_self_small: the same product for SMALL problems (batch 1-2: the reference's talking-face mode runs batch 1,
+ *   talking_face/progressive_sampling_difftalk.py:350).  One workgroup per 32-query tile of a (sample, head), the keys split
+ *   over its 4 / 8 waves and streamed from global memory without LDS staging, partial (max, sum, O) merged in wave order
+ *   (bitwise reproducible).  `qkv` may be the nslab raw split-K slabs [nslab][n*tokens][3*C] of the fused QKV projection
+ *   (ldmk_igemm with raw_slabs): operand loads sum them in slab order.  nslab = 1: a plain qkv tensor. */
+int ldmk_attn_self_small(const float* qkv, int nslab, long long slab_stride, float* out, int n, int tokens, int heads,
+                         float scale, void* stream);
 int ldmk_attn_cross(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo,
                     int n, int tokens, int ctx_len, int heads, float scale, void* stream);
 int ldmk_softmax_rows(float* x, long long rows, int cols, float scale, void* stream);
@@ -232,6 +290,12 @@ int ldmk_conv3x3_in(const float* x0, int c0, const float* x1, int c1, const floa
                     float* out, int n, int h, int w_, int cout, void* stream);
 int ldmk_conv3x3_out(const float* x, const float* coef, const float* w, const float* bias, float* out,
                      int n, int h, int w_, int cin, int cout, void* stream);
+/* ldmk_conv3x3_out_small: the same layer tiled for SMALL images (batch 1-2): 4x4-pixel workgroups, 16 lanes per pixel
+ *   splitting the channel axis -- 64 workgroups for one 32x32 image where the 16x16-pixel tiles above give 4.  Same
+ *   arguments; a different (fixed) summation order, so a caller that needs results independent of the batch split picks
+ *   one of the two from the JOB's batch (engine.NetBuilder does). */
+int ldmk_conv3x3_out_small(const float* x, const float* coef, const float* w, const float* bias, float* out,
+                           int n, int h, int w_, int cin, int cout, void* stream);
 /* 1x1 conv between narrow NCHW tensors (quant_conv / post_quant_conv, autoencoder.py:44-45) */
 int ldmk_conv1x1_nchw(const float* x, const float* w, const float* bias, float* out, int n, int hw, int cin,
                       int cout, void* stream);

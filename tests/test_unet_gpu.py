@@ -55,9 +55,28 @@ def test_resblock_golden_through_the_launch_program():
     assert torch.equal(out, first)
 
 
-def test_unet_fr_golden():
+ROUTES = ["small", "batched"]
+
+
+def _route(m, route, n, h, w, c_concat=0):
+    """Pin the launch program the fixtures are held against: batch 1-2 takes the small-batch route (unet_small.py: slab
+    GEMMs + ldmk_post, the reference's talking-face mode), a job batch of 16 the batched program (unet.py)."""
+    m.policy_batch = None if route == "small" else 16
+    pg = m.program(n, h, w, 1, c_concat)
+    names = [c[3] for c in pg.calls]
+    if route == "small":
+        assert getattr(pg, "small_route", False) and "ldmk_post" in names and "ldmk_attn_self_small" in names
+        assert not {"ldmk_gn_finalize", "ldmk_gn_apply", "ldmk_ln_stats", "ldmk_gn_partial"} & set(names)
+    else:
+        assert not getattr(pg, "small_route", False) and "ldmk_gn_finalize" in names and "ldmk_post" not in names
+    return pg
+
+
+@pytest.mark.parametrize("route", ROUTES)
+def test_unet_fr_golden(route):
     g = golden("g4_unet_fr.npz")
     m, _ = make_unet(W.FR_UNET)
+    _route(m, route, 2, 32, 32)
     x, t, ctx = rnd(41, 2, 3, 32, 32), torch.tensor([3, 981]), rnd(42, 2, 1, 512)
     eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
     # fp32 end to end; different summation order than PyTorch-CPU over ~60 layers.  Measured (tools/parity_margin.py):
@@ -68,9 +87,11 @@ def test_unet_fr_golden():
     assert torch.equal(eps, eps2)
 
 
-def test_unet_tf_concat_golden():
+@pytest.mark.parametrize("route", ROUTES)
+def test_unet_tf_concat_golden(route):
     g = golden("g7_talking_face.npz")
     m, _ = make_unet(W.TF_UNET)
+    _route(m, route, 2, 32, 32, 6)
     x, t = rnd(71, 2, 3, 32, 32), torch.tensor([11, 756])
     c12, c34 = rnd(72, 2, 1, 1024), rnd(73, 2, 6, 32, 32)
     eps = m(x.cuda(), t.cuda(), context=c12.cuda(), c_concat=c34.cuda())
@@ -79,9 +100,11 @@ def test_unet_tf_concat_golden():
     assert torch.equal(eps, eps_cat)
 
 
-def test_unet_northstar_64_golden():
+@pytest.mark.parametrize("route", ROUTES)
+def test_unet_northstar_64_golden(route):
     g = golden("g4_unet_fr.npz")
     m, _ = make_unet(W.NS_UNET)
+    _route(m, route, 1, 64, 64)
     eps = m(rnd(43, 1, 4, 64, 64).cuda(), torch.tensor([501]).cuda(), context=rnd(44, 1, 1, 512).cuda())
     close(eps, g["ns_eps"], 3e-5, 3e-5)
 
@@ -95,6 +118,7 @@ def test_unet_winograd_route_against_the_reference_fixtures(monkeypatch):
     monkeypatch.setattr(NetBuilder, "UP_MIN_PIXELS", 1)
     g = golden("g4_unet_fr.npz")
     m, _ = make_unet(W.FR_UNET)
+    m.policy_batch = 16                      # the batched program (batch 1-2 jobs take the small-batch route)
     x, t, ctx = rnd(41, 2, 3, 32, 32), torch.tensor([3, 981]), rnd(42, 2, 1, 512)
     eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
     launches = [c[3] for c in m.program(2, 32, 32, 1, 0).calls]
@@ -103,6 +127,7 @@ def test_unet_winograd_route_against_the_reference_fixtures(monkeypatch):
     close(eps, g["fr_eps"], 3e-5, 3e-5)
     assert torch.equal(eps, m(x.cuda(), t.cuda(), context=ctx.cuda()))
     m2, _ = make_unet(W.NS_UNET)
+    m2.policy_batch = 16
     eps = m2(rnd(43, 1, 4, 64, 64).cuda(), torch.tensor([501]).cuda(), context=rnd(44, 1, 1, 512).cuda())
     close(eps, g["ns_eps"], 3e-5, 3e-5)
 
@@ -138,12 +163,24 @@ def test_unet_rejects_unsupported():
         m(torch.zeros(1, 3, 32, 32), torch.zeros(1, dtype=torch.long), context=torch.zeros(1, 1, 512))
 
 
+def test_small_route_launch_count():
+    """The batch-1 step is a chain of dependent launches: the small-batch program must stay at <= 260 of them (the batched
+    program issues ~415 kernels for the same evaluation) -- and <= 2 ldmk_post per GEMM-free stretch by construction."""
+    m, _ = make_unet(W.FR_UNET)
+    pg = _route(m, "small", 1, 32, 32)
+    names = [c[3] for c in pg.calls]
+    assert len(names) <= 260, len(names)
+    assert names.count("ldmk_attn_self_small") == 16 and names.count("ldmk_post") <= 110
+
+
+@pytest.mark.parametrize("policy", [None, 16])
 @pytest.mark.parametrize("n,h,w", [(1, 24, 40), (3, 8, 8), (5, 16, 24)])
-def test_unet_ragged_shapes_vs_oracle(n, h, w):
+def test_unet_ragged_shapes_vs_oracle(n, h, w, policy):
     """Non-square / small latents and odd batch sizes: exercises partial tiles, the ragged attention tail (60 and
     4 tokens at the lowest level), the stand-alone GroupNorm statistics fallback (H*W not a multiple of 32) and
     split-K plans that differ from the benchmark shapes."""
     m, sd = make_unet(W.FR_UNET)
+    m.policy_batch = policy                   # None: the small-batch route (all three jobs are below its row limit); 16: batched
     x, t, ctx = rnd(50, n, 3, h, w), torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(1)), rnd(51, n, 1, 512)
     ref = O.unet_forward(sd, W.FR_UNET, x, t, ctx)
     close(m(x.cuda(), t.cuda(), context=ctx.cuda()), ref, 1e-4, 1e-4)

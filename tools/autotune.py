@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ROWS_RETUNE = False
+SLAB_RETUNE = False
 FORCE = False
 CANDS = {}
 CFG_WK = {1: 1, 2: 2, 3: 4, 4: 2, 5: 1, 6: 2}          # K slices of 32 staged per iteration
@@ -113,9 +114,10 @@ def tune_program(pg, table):
             continue
         key = plan_key(a, a.M)
         rows_retune = ROWS_RETUNE and a.w_frag and a.a_mode == 0 and not a.b_trans
+        slab_retune = SLAB_RETUNE and a.w_frag and not a.b_trans and max(1, a.batch) == 1
         if FORCE and key in table and key not in seen:
             del table[key]                      # --force: forget the recorded plan, sweep everything again
-        if key in seen or (a.batch > 1 and not getattr(a, "_winograd", False)) or (key in table and not rows_retune):
+        if key in seen or (a.batch > 1 and not getattr(a, "_winograd", False)) or (key in table and not (rows_retune or slab_retune)):
             continue
         saved = (a.tile_cfg, a.splitk, a.splitk_ws, a.splitk_ws_elems, a.out, a.stats_out, a.residual)
         saved_a = (a.a0, a.a1)
@@ -153,6 +155,18 @@ def tune_program(pg, table):
                     tried.append((t, cfg, 1))
                 if t is not None and (best is None or t < best[0]):
                     best = (t, cfg, 1)
+        if slab_retune:
+            for cfg in range(13, 21):         # slab GEMM tiles (small row counts; illegal combinations return an error code)
+                for sk in SKS:
+                    if (a.epi == 1 and sk > 1) or sk * a.M * a.N > ws.numel():
+                        continue
+                    a.tile_cfg, a.splitk = cfg, sk
+                    a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
+                    t = time_call(lib, a, st, touch=touch)
+                    if t is not None:
+                        tried.append((t, cfg, sk))
+                    if t is not None and (best is None or t < best[0]):
+                        best = (t, cfg, sk)
         for cfg in range(1, 7):
             if key in table:
                 break
@@ -187,9 +201,12 @@ if __name__ == "__main__":
     ap.add_argument("--fresh", action="store_true")
     ap.add_argument("--rows", action="store_true", help="re-tune rows-mode shapes already in the table against the "
                     "row-GEMM wave tiles (tile_cfg 7..12)")
+    ap.add_argument("--slab", action="store_true", help="re-tune shapes already in the table against the slab-GEMM tiles "
+                    "(tile_cfg 13..16, csrc/sgemm.hip): the small-batch cases")
     ap.add_argument("--force", action="store_true", help="re-sweep shapes that are already in the table (after a kernel change)")
     a = ap.parse_args()
     ROWS_RETUNE = a.rows or a.force
+    SLAB_RETUNE = a.slab
     FORCE = a.force
     table = {}
     if os.path.exists(a.out) and not a.fresh:

@@ -30,7 +30,7 @@ def dump(latent, batch, path, graph=False):
             a = keep
             from dsml_thesis_amd.engine import plan_key
             calls.append(dict(name=name, M=a.M, N=a.N, K=a.K, conv=a.a_mode, tf=a.a_tf, epi=a.epi, cfg=a.tile_cfg,
-                              sk=a.splitk, key=plan_key(a, a.M), batch=max(1, a.batch)))
+                              sk=a.splitk, key=plan_key(a, a.M), batch=max(1, a.batch), raw=int(a.raw_slabs)))
         else:
             calls.append(dict(name=name))
     json.dump(dict(calls=calls, marker_steps=3), open(path, "w"))
@@ -45,7 +45,8 @@ def dump(latent, batch, path, graph=False):
     torch.cuda.synchronize()
 
 
-KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "rgemm_kernel"), "ldmk_gn_finalize": ("gn_finalize",), "ldmk_gn_apply": ("gn_apply",),
+KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "rgemm_kernel", "sgemm_kernel"), "ldmk_post": ("post_",),
+             "ldmk_attn_self_small": ("attn_small",), "ldmk_conv3x3_out_small": ("conv3x3_out_small",), "ldmk_gn_finalize": ("gn_finalize",), "ldmk_gn_apply": ("gn_apply",),
              "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_attn_self": ("attn_self",),
              "ldmk_attn_cross": ("attn_cross",), "ldmk_dense_small": ("dense_small",),
              "ldmk_timestep_embedding": ("timestep_embedding",), "ldmk_conv3x3_in": ("conv3x3_in",),
@@ -63,7 +64,7 @@ def join(d):
     tr = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = [r for r in csv.DictReader(open(tr)) if "ldmk::" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    per = sum(2 if (c["name"] == "ldmk_igemm" and c.get("sk", 1) > 1 and c.get("cfg", 0) <= 6) else 1 for c in calls) + 1
+    per = sum(2 if (c["name"] == "ldmk_igemm" and c.get("sk", 1) > 1 and not 7 <= c.get("cfg", 0) <= 12) else 1 for c in calls) + 1
     # the last step of the trace: find it by walking back from the end to the step's first kernel (timestep_embedding)
     starts = [i for i, r in enumerate(rows) if "timestep_embedding" in r["Kernel_Name"]]
     last = rows[starts[-1]:]
@@ -76,8 +77,10 @@ def join(d):
         assert want is None or any(w in r["Kernel_Name"] for w in want), (c, r["Kernel_Name"])
         d_ = dur(r)
         i += 1
-        if c["name"] == "ldmk_igemm" and "igemm_kernel" in r["Kernel_Name"] and c.get("sk", 1) > 1:
+        if (c["name"] == "ldmk_igemm" and ("igemm_kernel" in r["Kernel_Name"] or "sgemm_kernel" in r["Kernel_Name"])
+                and c.get("sk", 1) > 1 and not c.get("raw")):
             assert "igemm_reduce" in last[i]["Kernel_Name"], (c, last[i]["Kernel_Name"])
+            c["main_us"] = d_
             d_ += dur(last[i])
             i += 1
         out.append((c, d_))
@@ -102,19 +105,20 @@ def join(d):
                 key += f" x{c['batch']} ({'Winograd' if c['batch'] == 16 else 'upsample phases'})"
         else:
             key = c["name"]
-        a = agg.setdefault(key, [0, 0.0, 0.0])
+        a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += d_
+        a[3] += c.get("main_us", d_)
         if c["name"] == "ldmk_igemm":
             a[2] += 2.0 * c["M"] * c["N"] * c["K"] * c.get("batch", 1)
     print(f"{'call':75s} {'n':>3s} {'us_total':>10s} {'pct':>6s} {'TFLOP/s':>8s}")
     fam_t = fam_f = 0.0
-    for key, (n, d_, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    for key, (n, d_, fl, mn) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         tfs = fl / (d_ * 1e-6) / 1e12 if fl else 0.0
         assert tfs <= PEAK_F32_MFMA, f"{key}: {tfs:.1f} TFLOP/s exceeds the f32 matrix peak -- the join is wrong"
         fam_t += d_ if fl else 0.0
         fam_f += fl
-        print(f"{key:75s} {n:3d} {d_:10.1f} {100 * d_ / tot:6.2f} {tfs:8.1f}" if fl else f"{key:75s} {n:3d} {d_:10.1f} {100 * d_ / tot:6.2f}")
+        print(f"{key:75s} {n:3d} {d_:10.1f} {100 * d_ / tot:6.2f} {tfs:8.1f}  main {mn / n:6.1f} us/call" if fl else f"{key:75s} {n:3d} {d_:10.1f} {100 * d_ / tot:6.2f}")
     print(f"GEMM family (LDS-tiled igemm + row GEMM): {fam_f * 1e-9:.1f} GFLOP executed in {fam_t / 1e3:.3f} ms = "
           f"{fam_f / (fam_t * 1e-6) / 1e12:.1f} TFLOP/s = {fam_f / (fam_t * 1e-6) / 1e12 / PEAK_F32_MFMA:.3f} of the f32 matrix peak")
 
