@@ -111,8 +111,14 @@ def test_tuned_plan_table_is_legal_and_nearest():
         n, k, mode, tf, epi, nb = (int(v) for v in key.split(",")[:6])      # optional suffixes: ",bt", ",s<stride>u<ups>"
         assert [r[0] for r in rows] == sorted(r[0] for r in rows)
         row_tiles = {7: (1, 5), 8: (2, 5), 9: (1, 4), 10: (2, 4), 11: (1, 2), 12: (1, 1)}
+        slab_tiles = {13: (2, 1, 4), 14: (2, 2, 4), 15: (1, 1, 4), 16: (1, 2, 4), 17: (1, 1, 8), 18: (1, 1, 16), 19: (2, 1, 8), 20: (1, 2, 8)}
         for m, cfg, sk in rows:
-            assert 1 <= cfg <= 12 and sk in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64)
+            assert 1 <= cfg <= 20 and sk in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64)
+            if cfg > 12:           # slab GEMM (small row counts): whole column tiles, every wave owns >= 1 eight-deep K block;
+                tm, tn, nw = slab_tiles[cfg]          # GEGLU splits K only when the consumer reduces (raw slabs)
+                assert m <= 4096 and n % (32 * tn) == 0 and nw * sk <= k // 8 and (epi != 1 or tn % 2 == 0) and "bt" not in key
+                assert mode == 0 or ",s" not in key   # stride-1 3x3 convolutions only
+                continue
             if cfg > 6:            # wave-autonomous row GEMM: rows mode only, K never split, whole column tiles
                 tm, tn = row_tiles[cfg]
                 assert mode == 0 and sk == 1 and n % (32 * tn) == 0 and (epi != 1 or tn % 2 == 0) and "bt" not in key
