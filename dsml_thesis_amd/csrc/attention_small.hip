@@ -20,7 +20,7 @@ namespace ldmk {
 
 constexpr int AS_D = 32;
 
-template <int NW>
+template <int NW, bool SLABS>
 __global__ __launch_bounds__(64 * NW) void attn_small_kernel(const float* __restrict__ qkv, const int nslab,
                                                              const long long slab_stride, float* __restrict__ out,
                                                              const int tokens, const int heads, const float scale) {
@@ -44,9 +44,11 @@ __global__ __launch_bounds__(64 * NW) void attn_small_kernel(const float* __rest
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       float4 q4 = *reinterpret_cast<const float4*>(qp + 4 * s4);
-      for (int sl = 1; sl < nslab; ++sl) {
-        const float4 t = *reinterpret_cast<const float4*>(qp + sl * slab_stride + 4 * s4);
-        q4.x += t.x; q4.y += t.y; q4.z += t.z; q4.w += t.w;
+      if constexpr (SLABS) {
+        for (int sl = 1; sl < nslab; ++sl) {
+          const float4 t = *reinterpret_cast<const float4*>(qp + sl * slab_stride + 4 * s4);
+          q4.x += t.x; q4.y += t.y; q4.z += t.z; q4.w += t.w;
+        }
       }
       qf[4 * s4] = q4.x * qs; qf[4 * s4 + 1] = q4.y * qs; qf[4 * s4 + 2] = q4.z * qs; qf[4 * s4 + 3] = q4.w * qs;
     }
@@ -62,24 +64,35 @@ __global__ __launch_bounds__(64 * NW) void attn_small_kernel(const float* __rest
 
   float kreg[16], vreg[16];
   auto load_kv = [&](int key0) {
-    // K: key key0 + l31, d = 16 half .. + 15;  V^T operand of step s: key key0 + (s&3) + 8 (s>>2) + 4 half, d = l31
+    // K: key key0 + l31, d = 16 half .. + 15;  V^T operand of step s: key key0 + (s&3) + 8 (s>>2) + 4 half, d = l31.
+    // All 20 loads of a slab are issued before anything is added: one memory round trip per slab, not per load.
     const float* kp = base + (long long)min(key0 + l31, tokens - 1) * ld + C + h * AS_D + 16 * half;
+    const float* vp[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      vp[s] = base + (long long)min(key0 + (s & 3) + 8 * (s >> 2) + 4 * half, tokens - 1) * ld + 2 * C + h * AS_D + l31;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float4 k4 = *reinterpret_cast<const float4*>(kp + 4 * j);
-      for (int sl = 1; sl < nslab; ++sl) {
-        const float4 t = *reinterpret_cast<const float4*>(kp + sl * slab_stride + 4 * j);
-        k4.x += t.x; k4.y += t.y; k4.z += t.z; k4.w += t.w;
-      }
+      const float4 k4 = *reinterpret_cast<const float4*>(kp + 4 * j);
       kreg[4 * j] = k4.x; kreg[4 * j + 1] = k4.y; kreg[4 * j + 2] = k4.z; kreg[4 * j + 3] = k4.w;
     }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int key = min(key0 + (s & 3) + 8 * (s >> 2) + 4 * half, tokens - 1);
-      const float* vp = base + (long long)key * ld + 2 * C + h * AS_D + l31;
-      float v = *vp;
-      for (int sl = 1; sl < nslab; ++sl) v += vp[sl * slab_stride];
-      vreg[s] = v;
+    for (int s = 0; s < 16; ++s) vreg[s] = *vp[s];
+    if constexpr (SLABS) {
+      for (int sl = 1; sl < nslab; ++sl) {
+        float4 kt[4];
+        float vt[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kt[j] = *reinterpret_cast<const float4*>(kp + sl * slab_stride + 4 * j);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) vt[s] = vp[s][sl * slab_stride];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          kreg[4 * j] += kt[j].x; kreg[4 * j + 1] += kt[j].y; kreg[4 * j + 2] += kt[j].z; kreg[4 * j + 3] += kt[j].w;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) vreg[s] += vt[s];
+      }
     }
   };
   if (kbeg < kend) load_kv(kbeg);
@@ -163,9 +176,13 @@ extern "C" int ldmk_attn_self_small(const float* qkv, int nslab, long long slab_
   LDMK_REQUIRE(nslab == 1 || slab_stride >= (long long)n * tokens * 3 * heads * AS_D, "ldmk_attn_self_small: slab_stride smaller than one slab");
   LDMK_REQUIRE(heads <= 65535 && n <= 65535, "ldmk_attn_self_small: grid limits");
   const dim3 grid((tokens + 31) / 32, heads, n);
-  if (tokens >= 512)
-    hipLaunchKernelGGL((attn_small_kernel<8>), grid, dim3(512), 0, (hipStream_t)stream, qkv, nslab, slab_stride, out, tokens, heads, scale);
-  else
-    hipLaunchKernelGGL((attn_small_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, qkv, nslab, slab_stride, out, tokens, heads, scale);
+  hipStream_t st = (hipStream_t)stream;
+  if (tokens >= 512) {
+    if (nslab > 1) hipLaunchKernelGGL((attn_small_kernel<8, true>), grid, dim3(512), 0, st, qkv, nslab, slab_stride, out, tokens, heads, scale);
+    else hipLaunchKernelGGL((attn_small_kernel<8, false>), grid, dim3(512), 0, st, qkv, nslab, slab_stride, out, tokens, heads, scale);
+  } else {
+    if (nslab > 1) hipLaunchKernelGGL((attn_small_kernel<4, true>), grid, dim3(256), 0, st, qkv, nslab, slab_stride, out, tokens, heads, scale);
+    else hipLaunchKernelGGL((attn_small_kernel<4, false>), grid, dim3(256), 0, st, qkv, nslab, slab_stride, out, tokens, heads, scale);
+  }
   return check_launch("ldmk_attn_self_small");
 }

@@ -65,7 +65,24 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(const ldmk_igemm_args p,
   const int KB = p.K >> 3;
   // this wave's K range: part q of NW * splitk equal parts (in eight-deep blocks)
   const int q = blockIdx.y * NW + wave, parts = NW * splitk;
-  const int kb0 = (int)((long long)KB * q / parts), kb1 = (int)((long long)KB * (q + 1) / parts);
+  // (32-bit: KB * parts < 2^31 is checked by the host)
+  const int kb0 = (int)((unsigned)(KB * q) / (unsigned)parts), kb1 = (int)((unsigned)(KB * (q + 1)) / (unsigned)parts);
+  const f32x4* bp = reinterpret_cast<const f32x4*>(wf) + (long long)nb0 * 64 + lane;
+  // The weights are what comes from HBM (each byte is read once per step): their loads of the first register set are issued
+  // before anything else is computed, so that the A addressing below (pixel decode, tap masks) runs under their latency
+  // (tools/sgemm_probe.py: 1.3 us of set-up in front of the first load, 2-2.5 us until the first operands arrive).
+  SgFrag<TM, TN, SG_U> f0, f1;
+  auto load_b = [&](SgFrag<TM, TN, SG_U>& f, int kb) {
+#pragma unroll
+    for (int u = 0; u < SG_U; ++u) {
+      const int k = min(kb + u, kb1 - 1);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) f.b[u][j] = bp[((long long)k * NB + j) * 64];
+    }
+  };
+  if (kb0 < kb1) load_b(f0, kb0);
+  __builtin_amdgcn_sched_barrier(0);
+
 
   // ---- per-lane A addressing
   const float* abase0[TM];
@@ -96,7 +113,6 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(const ldmk_igemm_args p,
   const int kb_split = p.c0 >> 3;                                // rows mode: first block of the second source
   const int sample = row0 / p.rows_per_sample;                   // a tile never straddles samples when it matters (host check)
   const float* coef = TF == LDMK_TF_AFFINE ? p.tf_coef + (long long)sample * 2 * p.K + 4 * half : nullptr;
-  const f32x4* bp = reinterpret_cast<const f32x4*>(wf) + (long long)nb0 * 64 + lane;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -106,8 +122,8 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(const ldmk_igemm_args p,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // loads of the U blocks starting at kb (blocks past kb1 re-load the last one: never consumed)
-  auto load = [&](SgFrag<TM, TN, SG_U>& f, int kb) {
+  // A loads of the U blocks starting at kb (blocks past kb1 re-load the last one: never consumed)
+  auto load_a = [&](SgFrag<TM, TN, SG_U>& f, int kb) {
 #pragma unroll
     for (int u = 0; u < SG_U; ++u) {
       const int k = min(kb + u, kb1 - 1);
@@ -138,10 +154,9 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(const ldmk_igemm_args p,
         f.t[u][0] = *reinterpret_cast<const f32x4*>(coef + 8 * k);
         f.t[u][1] = *reinterpret_cast<const f32x4*>(coef + p.K + 8 * k);
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) f.b[u][j] = bp[((long long)k * NB + j) * 64];
     }
   };
+  auto load = [&](SgFrag<TM, TN, SG_U>& f, int kb) { load_b(f, kb); load_a(f, kb); };
   auto compute = [&](SgFrag<TM, TN, SG_U>& f, int kb) {
 #pragma unroll
     for (int u = 0; u < SG_U; ++u) {
@@ -169,8 +184,7 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(const ldmk_igemm_args p,
   };
   SG_STAMP(1);
   if (kb0 < kb1) {
-    SgFrag<TM, TN, SG_U> f0, f1;
-    load(f0, kb0);
+    load_a(f0, kb0);
     SG_STAMP(2);
     // (sched_barrier: nothing of a compute() -- its tap selects wait for the set's loads -- may be scheduled above the
     //  issue of the other set's loads, or the wave would sit out a memory round trip with no load in flight)
@@ -350,6 +364,7 @@ const char* sgemm_unsupported(const ldmk_igemm_args& a, int scfg, int splitk) {
   if ((a.a_tf == LDMK_TF_AFFINE || a.batch_vec) && a.rows_per_sample % (32 * t.tm) != 0)
     return "per-sample operands need rows_per_sample to be a multiple of the tile's rows";
   if (splitk < 1 || (long long)t.nw * splitk > (a.K >> 3)) return "every wave needs at least one eight-deep K block (K / 8 >= waves x splitk)";
+  if ((long long)(a.K >> 3) * t.nw * splitk >= (1LL << 31)) return "K x splits exceeds the 32-bit range arithmetic";
   if (splitk > 1 && a.splitk_counters) return "the in-launch combine is not built for the slab GEMM";
   if (a.raw_slabs && splitk < 2) return "raw_slabs needs splitk >= 2";
   return nullptr;

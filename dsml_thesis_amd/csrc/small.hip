@@ -15,17 +15,21 @@ void set_error(const char* fmt, ...) {
 
 // ---------------------------------------------------------------------------------------------
 // out[b][n] = sum_k act(x[b][k]) * W[k][n] + bias[n]   (weight-bandwidth bound: W is read once).
-// Workgroup = 64 output columns x 4 K-quarters (one wave each, coalesced 256-B rows of W); up to
-// DS_ROWS batch rows accumulate in registers against x rows broadcast from LDS; the four K-quarter
-// partials are summed through LDS in a fixed order.
+// Workgroup = 64 output columns x DS_NW K-parts (one wave each, coalesced 256-B rows of W); up to
+// DS_ROWS batch rows accumulate in registers against x rows broadcast from LDS; the K-part
+// partials are summed through LDS in a fixed order.  A wave keeps 16 weight rows in flight: the kernel is a chain of
+// memory round trips (round 2: 4 parts x 8 loads = 20 round trips for the 640 x 7040 emb_layers matrix, 21 us per call
+// at batch 1; now 8 parts x 16 loads = 5).
 constexpr int DS_ROWS = 16;
 constexpr int DS_KT = 512;
-__global__ __launch_bounds__(256) void dense_small_kernel(const float* __restrict__ x, int ldx,
+constexpr int DS_NW = 8;
+constexpr int DS_LD = 16;
+__global__ __launch_bounds__(64 * DS_NW) void dense_small_kernel(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ out, int ldo, int rows, int K, int N,
                                                           int silu_in) {
   __shared__ __attribute__((aligned(16))) float xs[DS_KT][DS_ROWS];   // [k][row]: one k = 4 broadcast b128 reads
-  __shared__ float red[3][DS_ROWS][64];
+  __shared__ float red[DS_NW - 1][DS_ROWS][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + lane;
   const int r0 = blockIdx.y * DS_ROWS;
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
   for (int k0 = 0; k0 < K; k0 += DS_KT) {
     const int kn = min(DS_KT, K - k0);
     __syncthreads();
-    for (int i = threadIdx.x; i < DS_ROWS * DS_KT; i += 256) {
+    for (int i = threadIdx.x; i < DS_ROWS * DS_KT; i += 64 * DS_NW) {
       const int r = i / DS_KT, kk = i - r * DS_KT;          // consecutive threads read consecutive k of one row
       float v = 0.f;
       if (r < nr && kk < kn) {
@@ -47,16 +51,16 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
     }
     __syncthreads();
     if (n < N) {
-      const int q = (kn + 3) / 4;
+      const int q = (kn + DS_NW - 1) / DS_NW;
       const int kb = wave * q, ke = min(kn, kb + q);
       const float* wp = w + (long long)(k0 + kb) * N + n;
-      for (int kk = kb; kk < ke; kk += 8) {
-        float wv[8];                       // 8 independent weight loads in flight per lane before any use
+      for (int kk = kb; kk < ke; kk += DS_LD) {
+        float wv[DS_LD];                   // DS_LD independent weight loads in flight per lane before any use
 #pragma unroll
-        for (int u = 0; u < 8; ++u) wv[u] = (kk + u < ke) ? wp[(long long)u * N] : 0.f;
-        wp += 8LL * N;
+        for (int u = 0; u < DS_LD; ++u) wv[u] = (kk + u < ke) ? wp[(long long)u * N] : 0.f;
+        wp += (long long)DS_LD * N;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < DS_LD; ++u) {
           if (kk + u >= ke) break;
           const float4* xr = reinterpret_cast<const float4*>(&xs[kk + u][0]);
 #pragma unroll
@@ -78,8 +82,12 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
   __syncthreads();
   if (wave == 0 && n < N) {
     const float bv = bias ? bias[n] : 0.f;
-    for (int r = 0; r < nr; ++r)
-      out[(long long)(r0 + r) * ldo + n] = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane] + bv;
+    for (int r = 0; r < nr; ++r) {
+      float v = acc[r];
+#pragma unroll
+      for (int q = 0; q < DS_NW - 1; ++q) v += red[q][r][lane];
+      out[(long long)(r0 + r) * ldo + n] = v + bv;
+    }
   }
 }
 
@@ -609,7 +617,7 @@ extern "C" int ldmk_dense_small(const float* x, int ldx, const float* w, const f
   LDMK_REQUIRE(x && w && out && rows > 0 && K > 0 && N > 0, "ldmk_dense_small: bad args");
   LDMK_REQUIRE(ldx >= K && ldo >= N, "ldmk_dense_small: leading dims");
   dim3 grid((N + 63) / 64, (rows + DS_ROWS - 1) / DS_ROWS);
-  hipLaunchKernelGGL(dense_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, out, ldo, rows, K, N,
+  hipLaunchKernelGGL(dense_small_kernel, grid, dim3(64 * ldmk::DS_NW), 0, (hipStream_t)stream, x, ldx, w, bias, out, ldo, rows, K, N,
                      silu_in);
   return check_launch("ldmk_dense_small");
 }
