@@ -190,6 +190,15 @@ class Program:
         self.calls.append((self.lib.ldmk_igemm, (C.byref(args),), args, "ldmk_igemm"))
 
     def post(self, pargs, keep=None):
+        need = self.lib.ldmk_post_scratch_elems(C.byref(pargs))
+        if need > 0:                                   # row-tiled GroupNorm (large images): one shared, stream-ordered scratch
+            if getattr(self, "_gnws", None) is None or self._gnws.numel() < need:
+                self._gnws = torch.empty(int(need), device=self.device, dtype=torch.float32)
+                self._all.append(self._gnws)
+                for _, _, k, name in self.calls:
+                    if name == "ldmk_post" and k[0].gn_scratch:
+                        k[0].gn_scratch, k[0].gn_scratch_elems = self._gnws.data_ptr(), self._gnws.numel()
+            pargs.gn_scratch, pargs.gn_scratch_elems = self._gnws.data_ptr(), self._gnws.numel()
         self.calls.append((self.lib.ldmk_post, (C.byref(pargs),), (pargs, keep), "ldmk_post"))
 
     def run(self, stream=None):

@@ -44,6 +44,7 @@ class PostArgs(C.Structure):
         ("residual", _fp), ("ldr", C.c_int), ("geglu", C.c_int), ("raw_out", _fp), ("ld_raw", C.c_int), ("norm", C.c_int),
         ("x1", _fp), ("c1", C.c_int), ("groups", C.c_int), ("eps", C.c_float), ("gamma", _fp), ("beta", _fp),
         ("silu", C.c_int), ("norm_out", _fp), ("ld_norm", C.c_int), ("gn_cache_floats", C.c_int),
+        ("gn_scratch", _fp), ("gn_scratch_elems", C.c_longlong),
     ]
 
 
@@ -83,6 +84,7 @@ _SIGS = {
     "ldmk_ln_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp]),
     "ldmk_gn_apply": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_post": (C.c_int, [C.POINTER(PostArgs), _fp]),
+    "ldmk_post_scratch_elems": (C.c_longlong, [C.POINTER(PostArgs)]),
     "ldmk_attn_self": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_self_small": (C.c_int, [_fp, C.c_int, C.c_longlong, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_cross": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -132,6 +132,12 @@ def make_post_args(src, M, N, rows_per_sample, nslab=1, slab_stride=None, bias=N
 
 
 def post(args):
+    """ldmk_post; the row-tiled GroupNorm form (large images) gets its scratch here (programs allocate it from their pool)."""
+    need = L.load().ldmk_post_scratch_elems(C.byref(args))
+    if need > 0 and not args.gn_scratch:
+        scratch = torch.empty(need, device="cuda", dtype=torch.float32)
+        args.gn_scratch, args.gn_scratch_elems = scratch.data_ptr(), need
+        args._scratch = scratch
     L.call("ldmk_post", C.byref(args), stream())
 
 

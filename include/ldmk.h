@@ -240,8 +240,13 @@ typedef struct ldmk_post_args {
   float* norm_out;           /* [M][ld_norm], ld_norm >= N + c1 */
   int ld_norm;
   int gn_cache_floats;       /* (set by the library) */
+  float* gn_scratch;         /* GroupNorm with rows_per_sample >= LDMK_POST_GN_TILED_ROWS: (mean, M2) pairs per (row tile, group), */
+  long long gn_scratch_elems;/*   ldmk_post_scratch_elems(args) floats; the call is then two launches (row-tiled statistics, apply) */
 } ldmk_post_args;
+#define LDMK_POST_GN_TILED_ROWS 256
 int ldmk_post(const ldmk_post_args* args, void* stream);
+/* floats of gn_scratch ldmk_post(args) needs (0 for the single-launch forms); negative for invalid arguments */
+long long ldmk_post_scratch_elems(const ldmk_post_args* args);
 
 /* ------------------------------------------------------------------------------------------
  * Attention.

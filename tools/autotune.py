@@ -145,8 +145,9 @@ def tune_program(pg, table):
             a.tile_cfg, a.splitk = table[key]
             a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
             t = time_call(lib, a, st, touch=touch)
-            best = (t, a.tile_cfg, a.splitk)
-            tried.append(best)
+            if t is not None:             # (None: the plan on record cannot run this problem, e.g. a raw-slab GEMM of the small route)
+                best = (t, a.tile_cfg, a.splitk)
+                tried.append(best)
         if rows_retune:
             for cfg in range(7, 13):          # wave-autonomous row GEMM tiles (illegal ones return an error code)
                 a.tile_cfg, a.splitk = cfg, 1
@@ -156,19 +157,29 @@ def tune_program(pg, table):
                 if t is not None and (best is None or t < best[0]):
                     best = (t, cfg, 1)
         if slab_retune:
+            small = bool(getattr(pg, "small_route", False))
             for cfg in range(13, 21):         # slab GEMM tiles (small row counts; illegal combinations return an error code)
                 for sk in SKS:
-                    if (a.epi == 1 and sk > 1) or sk * a.M * a.N > ws.numel():
+                    if (a.epi == 1 and sk > 1 and not small) or sk * a.M * a.N > ws.numel():
                         continue
                     a.tile_cfg, a.splitk = cfg, sk
                     a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
+                    geglu_split = a.epi == 1 and sk > 1   # small route: raw slabs + a GEGLU post launch (charged 4 us)
+                    saved_gs = (a.raw_slabs, a.bias)
+                    if geglu_split:
+                        a.raw_slabs, a.bias = 1, 0
+                    elif sk == 1 and a.raw_slabs:
+                        a.raw_slabs = 0
                     t = time_call(lib, a, st, touch=touch)
+                    a.raw_slabs, a.bias = saved_gs
+                    if t is not None and geglu_split:
+                        t += 0.004
                     if t is not None:
                         tried.append((t, cfg, sk))
                     if t is not None and (best is None or t < best[0]):
                         best = (t, cfg, sk)
         for cfg in range(1, 7):
-            if key in table:
+            if key in table and best is not None:
                 break
             if a.epi == 1 and cfg not in EVEN_TN:
                 continue

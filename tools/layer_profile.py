@@ -64,7 +64,8 @@ def join(d):
     tr = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = [r for r in csv.DictReader(open(tr)) if "ldmk::" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    per = sum(2 if (c["name"] == "ldmk_igemm" and c.get("sk", 1) > 1 and not 7 <= c.get("cfg", 0) <= 12) else 1 for c in calls) + 1
+    per = sum(2 if (c["name"] == "ldmk_post" or (c["name"] == "ldmk_igemm" and c.get("sk", 1) > 1 and not 7 <= c.get("cfg", 0) <= 12)) else 1
+              for c in calls) + 1
     # the last step of the trace: find it by walking back from the end to the step's first kernel (timestep_embedding)
     starts = [i for i, r in enumerate(rows) if "timestep_embedding" in r["Kernel_Name"]]
     last = rows[starts[-1]:]
@@ -77,6 +78,10 @@ def join(d):
         assert want is None or any(w in r["Kernel_Name"] for w in want), (c, r["Kernel_Name"])
         d_ = dur(r)
         i += 1
+        if c["name"] == "ldmk_post" and "post_gnstat" in r["Kernel_Name"]:       # row-tiled GroupNorm: statistics + apply launches
+            assert "post_gnapply" in last[i]["Kernel_Name"], last[i]["Kernel_Name"]
+            d_ += dur(last[i])
+            i += 1
         if (c["name"] == "ldmk_igemm" and ("igemm_kernel" in r["Kernel_Name"] or "sgemm_kernel" in r["Kernel_Name"])
                 and c.get("sk", 1) > 1 and not c.get("raw")):
             assert "igemm_reduce" in last[i]["Kernel_Name"], (c, last[i]["Kernel_Name"])
