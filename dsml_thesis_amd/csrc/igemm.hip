@@ -1006,7 +1006,11 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   LDMK_REQUIRE(a.c0 > 0 && a.c0 % 32 == 0 && a.c1 % 32 == 0, "ldmk_igemm: channel counts must be multiples of 32 (c0=%d c1=%d)", a.c0, a.c1);
   LDMK_REQUIRE((a.c1 == 0) == (a.a1 == nullptr), "ldmk_igemm: a1/c1 mismatch");
   const int taps = a.a_mode == LDMK_A_CONV3X3 ? 9 : 1;
-  LDMK_REQUIRE(a.K == taps * (a.c0 + a.c1), "ldmk_igemm: K=%d != taps*(c0+c1)=%d", a.K, taps * (a.c0 + a.c1));
+  const int skip_k = a.skip_a0 ? a.skip_c0 + a.skip_c1 : 0;       // fused 1x1 skip connection (slab GEMM only, checked there)
+  LDMK_REQUIRE(a.K == taps * (a.c0 + a.c1) + skip_k, "ldmk_igemm: K=%d != taps*(c0+c1)+skip=%d", a.K, taps * (a.c0 + a.c1) + skip_k);
+  LDMK_REQUIRE(!a.skip_a0 || (a.a_mode == LDMK_A_CONV3X3 && a.skip_c0 > 0 && a.skip_c0 % 8 == 0 && a.skip_c1 % 8 == 0 &&
+                              (a.skip_c1 == 0) == (a.skip_a1 == nullptr) && (a.tile_cfg > kNumCfg + kNumRCfg || a.tile_cfg == 0)),
+               "ldmk_igemm: the fused skip connection needs a 3x3 convolution on a slab-GEMM tile, skip channels in multiples of 8");
   LDMK_REQUIRE(a.N % 4 == 0 && a.ldb % 4 == 0, "ldmk_igemm: N and ldb must be multiples of 4");
   LDMK_REQUIRE(a.rows_per_sample > 0, "ldmk_igemm: rows_per_sample");
   LDMK_REQUIRE((long long)a.M * a.ldc < (1LL << 31) && a.ldc > 0, "ldmk_igemm: output exceeds 2^31 elements per batch item (32-bit epilogue offsets)");
@@ -1042,6 +1046,7 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   plan(a, &cfg, &sk, a.splitk_ws ? a.splitk_ws_elems : 0);
   if (a.tile_cfg > 0) cfg = a.tile_cfg;
   if (g_force_cfg > 0 && (g_force_cfg <= kNumCfg || !rgemm_unsupported(a, g_force_cfg - kNumCfg - 1))) cfg = g_force_cfg;
+  LDMK_REQUIRE(!a.skip_a0 || cfg > kNumCfg + kNumRCfg, "ldmk_igemm: the fused skip connection runs on the slab GEMM only (tile_cfg 13..20)");
   if (cfg > kNumCfg + kNumRCfg) {      // slab GEMM: wave-autonomous, K split over the waves of a workgroup and over workgroups
     const int scfg = cfg - kNumCfg - kNumRCfg - 1;
     int ssk = a.splitk > 0 ? a.splitk : 1;

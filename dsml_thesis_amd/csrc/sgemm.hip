@@ -28,7 +28,7 @@
 // Diagnostic build only (tools/sgemm_probe.py builds a second library with -DLDMK_SG_STAMPS): per-wave s_memrealtime stamps
 // (constant 100 MHz) at the phase boundaries go to args.stats_out as [workgroup][wave][8] 64-bit ticks.
 #ifdef LDMK_SG_STAMPS
-#define SG_STAMP(i) do { if (lane == 0) reinterpret_cast<unsigned long long*>(p.stats_out)[(((long long)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SG_STAMP(i) do { if (lane == 0) reinterpret_cast<unsigned long long*>(p.stats_out)[((long long)blockIdx.x * NW + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define SG_STAMP(i) do { } while (0)
 #endif
@@ -59,12 +59,17 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(const ldmk_igemm_args p,
   SG_STAMP(0);
   const int tiles_m = (p.M + 32 * TM - 1) / (32 * TM);
   const int NB = p.N >> 5;
-  const int tile = blockIdx.x;
+  // XCD-aware order (workgroups are dealt round-robin over the 8 XCDs, each with its own L2): consecutive remapped ids
+  // share an XCD, and they walk  K slab (slowest) > column tile > row tile, so the row tiles that read the SAME weight
+  // block sit in one L2 (the block comes from HBM once, not once per row tile) and an XCD touches only its slabs' A columns
+  const int tiles_all = tiles_m * ((p.N >> 5) / TN);
+  const int rid = xcd_remap(blockIdx.x, gridDim.x);
+  const int kslab = rid / tiles_all, tile = rid - kslab * tiles_all;
   const int tn = tile / tiles_m, tm = tile - tn * tiles_m;      // m fastest: neighbours share the B column block
   const int row0 = tm * 32 * TM, nb0 = tn * TN;
   const int KB = p.K >> 3;
   // this wave's K range: part q of NW * splitk equal parts (in eight-deep blocks)
-  const int q = blockIdx.y * NW + wave, parts = NW * splitk;
+  const int q = kslab * NW + wave, parts = NW * splitk;
   // (32-bit: KB * parts < 2^31 is checked by the host)
   const int kb0 = (int)((unsigned)(KB * q) / (unsigned)parts), kb1 = (int)((unsigned)(KB * (q + 1)) / (unsigned)parts);
   const f32x4* bp = reinterpret_cast<const f32x4*>(wf) + (long long)nb0 * 64 + lane;
@@ -111,6 +116,17 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(const ldmk_igemm_args p,
     }
   }
   const int kb_split = p.c0 >> 3;                                // rows mode: first block of the second source
+  // convolution with the ResBlock's 1x1 skip connection fused as extra K: blocks [kb_conv, KB) read rows of skip_a0 | skip_a1
+  const int kb_conv = CONV ? (9 * p.c0) >> 3 : 0;
+  const int kb_skip1 = kb_conv + (p.skip_c0 >> 3);
+  const float* sbase0[TM];
+  const float* sbase1[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = min(row0 + 32 * i + l31, p.M - 1);
+    sbase0[i] = (CONV && p.skip_a0) ? p.skip_a0 + (long long)r * p.skip_c0 + 4 * half : nullptr;
+    sbase1[i] = (CONV && p.skip_a1) ? p.skip_a1 + (long long)r * p.skip_c1 + 4 * half : nullptr;
+  }
   const int sample = row0 / p.rows_per_sample;                   // a tile never straddles samples when it matters (host check)
   const float* coef = TF == LDMK_TF_AFFINE ? p.tf_coef + (long long)sample * 2 * p.K + 4 * half : nullptr;
 
@@ -127,7 +143,12 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(const ldmk_igemm_args p,
 #pragma unroll
     for (int u = 0; u < SG_U; ++u) {
       const int k = min(kb + u, kb1 - 1);
-      if constexpr (CONV) {
+      if (CONV && k >= kb_conv) {                                  // (wave-uniform) fused skip connection: plain rows
+        f.ok[u] = ~0u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          f.a[u][i] = *reinterpret_cast<const f32x4*>(k < kb_skip1 ? sbase0[i] + 8 * (k - kb_conv) : sbase1[i] + 8 * (k - kb_skip1));
+      } else if constexpr (CONV) {
         // K order of ldmk_pack_conv3x3: [chunk of 32 channels][tap][32]  ->  k = (chunk * 9 + tap) * 4 + quarter
         const int ct = k >> 2, qq = k & 3;
         const int chunk = ct / 9, tap = ct - chunk * 9;
@@ -232,7 +253,7 @@ __global__ __launch_bounds__(64 * NW) void sgemm_kernel(const ldmk_igemm_args p,
   const int col0 = nb0 * 32;
   const int rlane = row0 + 4 * half;
   if (splitk > 1) {
-    float* slab = ws + (long long)blockIdx.y * p.M * p.N;
+    float* slab = ws + (long long)kslab * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -331,7 +352,7 @@ int launch_splitk_reduce(const ldmk_igemm_args& a, int splitk, float* ws, hipStr
 template <int TM, int TN, int NW>
 static int launch_s(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
   const int tiles = ((a.M + 32 * TM - 1) / (32 * TM)) * ((a.N / 32) / TN);
-  const dim3 grid(tiles, splitk), block(64 * NW);
+  const dim3 grid(tiles * splitk), block(64 * NW);
   const float4* wf = reinterpret_cast<const float4*>(a.w_frag);
   const bool conv = a.a_mode == LDMK_A_CONV3X3;
   const bool aff = a.a_tf == LDMK_TF_AFFINE;
@@ -357,6 +378,7 @@ const char* sgemm_unsupported(const ldmk_igemm_args& a, int scfg, int splitk) {
   if (a.a_mode == LDMK_A_CONV3X3) {
     if (a.stride != 1 || a.upsample || a.pad_lo != 1 || a.a1 || a.in_h != a.out_h || a.in_w != a.out_w || a.a_tf != LDMK_TF_NONE)
       return "3x3 convolutions: stride 1, pad 1, one source, no prologue";
+    if (a.skip_a0 && (a.skip_c0 % 8 != 0 || a.skip_c1 % 8 != 0)) return "skip channels must be multiples of 8";
   } else if (a.c0 % 8 != 0 || a.c1 % 8 != 0) {
     return "channel counts must be multiples of 8";
   }

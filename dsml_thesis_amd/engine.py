@@ -137,13 +137,15 @@ class Program:
             # a row-GEMM wave tile (7..12, never splits K) or a slab-GEMM shape (13..20, small row counts): legal only with
             # the fragment-order weight copy and when the tile divides this problem (per-sample operands need
             # rows_per_sample % tile rows == 0); else the heuristic decides
-            saved = (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems)
+            saved = (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems, args.raw_slabs)
             args.M, args.batch, args.tile_cfg = m, nbatch, int(tuned[0])
             args.splitk = 1 if tuned[0] <= 12 else int(tuned[1])
             args.splitk_ws, args.splitk_ws_elems = 1, 1 << 40          # (validated against the real scratch below)
+            if args.splitk == 1:
+                args.raw_slabs = 0                                      # an unsplit plan writes its output itself
             if not args.w_frag or self.lib.ldmk_igemm_check(C.byref(args)) != 0:
                 tuned = None
-            (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems) = saved
+            (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems, args.raw_slabs) = saved
         if tuned is not None:
             cfg.value, sk.value = int(tuned[0]), int(tuned[1])
         else:

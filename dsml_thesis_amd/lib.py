@@ -34,6 +34,7 @@ class IgemmArgs(C.Structure):
         ("w_frag", _fp),
         ("ln_colsum", _fp),
         ("raw_slabs", C.c_int),
+        ("skip_a0", _fp), ("skip_a1", _fp), ("skip_c0", C.c_int), ("skip_c1", C.c_int),
     ]
 
 

@@ -119,6 +119,10 @@ typedef struct ldmk_igemm_args {
                                 [splitk][M][N] in splitk_ws and launch NO reduce kernel -- the consumer (ldmk_post,
                                 ldmk_attn_self with qkv_slabs) sums them in slab order and applies bias / per-sample vector /
                                 residual / GEGLU itself; `out`, `bias`, `batch_vec`, `residual` and `epi` are then not used */
+  const float* skip_a0;      /* slab GEMM, LDMK_A_CONV3X3 only: K = 9*c0 + skip_c0 + skip_c1, the trailing K columns multiply the ROWS */
+  const float* skip_a1;      /*   of the (two-source) tensor skip_a0 | skip_a1 at the output pixel -- the ResBlock's 1x1      */
+  int skip_c0, skip_c1;      /*   skip_connection as extra K of its second 3x3 convolution (openaimodel.py:241,275): one GEMM  */
+                             /*   instead of two.  Weights: the packed conv weight with the [skip_c0+skip_c1][N] matrix appended. */
 } ldmk_igemm_args;
 
 int ldmk_igemm(const ldmk_igemm_args* args, void* stream);
@@ -243,7 +247,7 @@ typedef struct ldmk_post_args {
   float* gn_scratch;         /* GroupNorm with rows_per_sample >= LDMK_POST_GN_TILED_ROWS: (mean, M2) pairs per (row tile, group), */
   long long gn_scratch_elems;/*   ldmk_post_scratch_elems(args) floats; the call is then two launches (row-tiled statistics, apply) */
 } ldmk_post_args;
-#define LDMK_POST_GN_TILED_ROWS 256
+#define LDMK_POST_GN_TILED_ROWS 512
 int ldmk_post(const ldmk_post_args* args, void* stream);
 /* floats of gn_scratch ldmk_post(args) needs (0 for the single-launch forms); negative for invalid arguments */
 long long ldmk_post_scratch_elems(const ldmk_post_args* args);
