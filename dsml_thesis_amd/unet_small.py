@@ -61,6 +61,9 @@ def pack_small(unet):
             P[last + "ff2o#b"] = (sd[prefix + "proj_out.bias"].double() + sd[last + "ff.net.2.bias"].double() @ wo).float().contiguous()
         elif m.kind == "res" and m.cin != m.cout:
             P[prefix + "c2skip#b"] = (sd[prefix + "out_layers.3.bias"] + sd[prefix + "skip_connection.bias"]).contiguous()
+            # the 1x1 skip connection as extra K rows of the second 3x3 convolution: [9 cout + cin][cout]
+            P[prefix + "c2s"] = torch.cat([P[prefix + "c2"], P[prefix + "skip"]], 0).contiguous()
+            P[prefix + "c2s#f"] = ops.pack_wfrag(P[prefix + "c2s"])
         elif m.kind in ("down", "up"):
             pass
     P["#small"] = True
@@ -84,7 +87,7 @@ class SmallBuilder:
     def raw(self, gemms, M, N, hw, bias=None, bvec=0, bvec_ld=0, residual=None):
         """Plan and record GEMMs whose raw products add up to one [M][N] tensor; returns its Lazy."""
         pg = self.pg
-        sks = [pg.plan(a, self.pin)[1] for a in gemms]
+        sks = [a.splitk if getattr(a, "_planned", False) else pg.plan(a, self.pin)[1] for a in gemms]
         slabs = pg.alloc(sum(sks), M, N)
         off = 0
         for a, sk in zip(gemms, sks):
@@ -154,7 +157,9 @@ def build_small(unet, n, H, W_, L_ctx, c_concat, policy_n):
     pin = (policy_n, n)
     sb = SmallBuilder(pg, n, pin)
 
-    # -- time embedding MLP + all emb_layers (one launch each), as in the batched program
+    # -- time embedding MLP + all emb_layers (one launch each), as in the batched program; they only read `t`, so they are
+    # recorded as SIDE launches (a parallel branch of the captured step, joined in front of the first ResBlock's post)
+    n_main0 = len(pg.calls)
     temb = pg.alloc(n, mc)
     pg.add("ldmk_timestep_embedding", p_(t_in), p_(P["freqs"]), p_(temb), n, mc)
     e1 = pg.alloc(n, emb_ch)
@@ -164,6 +169,10 @@ def build_small(unet, n, H, W_, L_ctx, c_concat, policy_n):
     emb_all = pg.alloc(n, unet._emb_total)
     pg.add("ldmk_dense_small", p_(emb), emb_ch, p_(P["emb_all"]), p_(P["emb_all_b"]), p_(emb_all), unet._emb_total, n,
            emb_ch, unet._emb_total, 1)
+
+    pg.side_calls = pg.calls[n_main0:]
+    del pg.calls[n_main0:]
+    pg.side_join = None                      # set when the first consumer of emb_all is recorded
 
     def conv_args(a_in, cin, wp, wf, cout, h, w, stride=1, upsample=False):
         oh, ow = (2 * h, 2 * w) if upsample else ((h - 1) // stride + 1, (w - 1) // stride + 1)
@@ -177,14 +186,34 @@ def build_small(unet, n, H, W_, L_ctx, c_concat, policy_n):
         hmid = sb.raw([g1], rows, m.cout, hw, bias=sd[prefix + "in_layers.2.bias"],
                       bvec=emb_all.data_ptr() + 4 * unet._emb_off[prefix], bvec_ld=unet._emb_total)
         pg.release(a1)
+        if pg.side_join is None:
+            pg.side_join = len(pg.calls)     # the post below is the first launch that reads emb_all
         a2 = sb.post_gn(hmid, None, sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"], 1e-5, True)
         pg.release(hmid.raw)
         g2, _, _ = conv_args(a2, m.cout, P[prefix + "c2"], P.get(prefix + "c2#f"), m.cout, h, w)
         if m.cin != m.cout:
             c1 = 0 if x1 is None else x1.N
-            gs = ops.make_igemm_args(rows, m.cout, m.cin, x0.raw, x0.N, P[prefix + "skip"], None, m.cout, hw,
-                                     a1=None if x1 is None else x1.raw, c1=c1, w_frag=P.get(prefix + "skip#f"))
-            out = sb.raw([g2, gs], rows, m.cout, hw, bias=P[prefix + "c2skip#b"])
+            # the 1x1 skip connection (openaimodel.py:241) rides along as extra K of the second convolution when the plan is a
+            # slab-GEMM tile; otherwise it is a GEMM of its own whose slabs land next to the convolution's
+            gm, _, _ = conv_args(a2, m.cout, P[prefix + "c2s"], P.get(prefix + "c2s#f"), m.cout, h, w)
+            gm.K = 9 * m.cout + m.cin
+            gm.skip_a0, gm.skip_c0 = x0.raw.data_ptr(), x0.N
+            gm.skip_a1, gm.skip_c1 = (0 if x1 is None else x1.raw.data_ptr()), c1
+            cfg, sk = pg.plan(gm, pin)
+            if cfg <= 12:                      # no tuned slab plan for the fused shape yet: the plain convolution's plan
+                cfg, sk = pg.plan(g2, pin)
+                gm.tile_cfg, gm.splitk = cfg, sk
+            gm.raw_slabs = 1 if sk > 1 else 0
+            gm.splitk_ws, gm.splitk_ws_elems = 1, 1 << 40
+            fused = cfg > 12 and pg.lib.ldmk_igemm_check(L.C.byref(gm)) == 0
+            gm.splitk_ws, gm.splitk_ws_elems, gm.raw_slabs = 0, 0, 0
+            gm._planned = True
+            if fused:
+                out = sb.raw([gm], rows, m.cout, hw, bias=P[prefix + "c2skip#b"])
+            else:
+                gs = ops.make_igemm_args(rows, m.cout, m.cin, x0.raw, x0.N, P[prefix + "skip"], None, m.cout, hw,
+                                         a1=None if x1 is None else x1.raw, c1=c1, w_frag=P.get(prefix + "skip#f"))
+                out = sb.raw([g2, gs], rows, m.cout, hw, bias=P[prefix + "c2skip#b"])
         else:
             assert x1 is None
             out = sb.raw([g2], rows, m.cout, hw, bias=sd[prefix + "out_layers.3.bias"], residual=x0.raw)

@@ -305,3 +305,36 @@ def test_conv3x3_out_small(ops, n, cin, cout, h, w, norm):
     y = ops.conv3x3_out(xs, coef, wp, bd, cout, small=True)
     close(y, F.conv2d(ref_in.double(), wt.double(), b.double(), padding=1).float(), 1e-4, 1e-4)
     close(y, ops.conv3x3_out(xs, coef, wp, bd, cout), 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize("cfg,splitk", [(13, 1), (15, 4), (18, 2), (14, 3), (19, 1)])
+@pytest.mark.parametrize("case", [(1, 320, 160, 640, 8, 8), (2, 160, 160, 320, 16, 16), (1, 640, 0, 320, 5, 7)])
+def test_slab_gemm_conv_with_fused_skip_connection(ops, cfg, splitk, case):
+    """ResBlock tail (openaimodel.py:241,275): conv3x3(h) + skip_connection(cat(x, skip)) as ONE GEMM -- the 1x1 projection
+    of the (two-source) block input rides along as extra K columns of the 3x3 convolution."""
+    from dsml_thesis_amd import lib as L
+    n, c0, c1, cout, h, w = case
+    cin = c0 + c1
+    hmid, x = rnd(10, n, cout, h, w), rnd(11, n, cin, h, w)
+    wc, ws_ = rnd(12, cout, cout, 3, 3) / np.sqrt(9 * cout), rnd(13, cout, cin, 1, 1) / np.sqrt(cin)
+    b = 0.1 * rnd(14, cout)
+    ref = F.conv2d(hmid.double(), wc.double(), None, padding=1) + F.conv2d(x.double(), ws_.double(), b.double())
+    wp = torch.cat([ops.pack_conv3x3(wc.cuda()), ops.pack_linear(ws_.cuda())], 0).contiguous()
+    wf = ops.pack_wfrag(wp)
+    xs = nhwc(x)
+    x0, x1 = (xs[..., :c0].contiguous(), xs[..., c0:].contiguous()) if c1 else (xs, None)
+    hd, bd = nhwc(hmid), b.cuda()
+    M, K = n * h * w, 9 * cout + cin
+    out = torch.empty(n, h, w, cout, device="cuda")
+    a = ops.make_igemm_args(M, cout, 9 * cout, hd, cout, wp, out, cout, h * w, conv=(h, w, h, w, 1, 1, 0), bias=bd, w_frag=wf)
+    a.K = K
+    a.skip_a0, a.skip_c0 = x0.data_ptr(), c0
+    a.skip_a1, a.skip_c1 = (0 if x1 is None else x1.data_ptr()), c1
+    tm, tn, nw = SLAB_TILES[cfg]
+    if cout % (32 * tn) or nw * splitk > K // 8:
+        pytest.skip("tile does not fit this shape")
+    _run(ops, a, cfg, splitk, M, cout)
+    close(nchw(out), ref.float())
+    a.tile_cfg = 4
+    with pytest.raises(L.LdmkError, match="fused skip"):
+        ops.igemm(a)

@@ -33,7 +33,8 @@ def dump(latent, batch, path, graph=False):
                               sk=a.splitk, key=plan_key(a, a.M), batch=max(1, a.batch), raw=int(a.raw_slabs)))
         else:
             calls.append(dict(name=name))
-    json.dump(dict(calls=calls, marker_steps=3), open(path, "w"))
+    side = [c[3] for c in getattr(run.pg, "side_calls", None) or []]       # launches on the forked stream (parallel branch)
+    json.dump(dict(calls=calls, marker_steps=3, side=side), open(path, "w"))
     # marker: three more steps whose dispatches we will read from the END of the trace (--graph: hipGraph replays, so the
     # durations and the step span are those of the captured step the samplers actually run)
     if graph:
@@ -70,6 +71,12 @@ def join(d):
     starts = [i for i, r in enumerate(rows) if "timestep_embedding" in r["Kernel_Name"]]
     last = rows[starts[-1]:]
     dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    # launches of the parallel branch (timestep embedding + emb_layers on the forked stream) interleave with the main chain
+    # in the trace: take them out of the walk and list them on their own
+    side_kernels = tuple(k for name in prog.get("side", []) for k in KERNEL_OF.get(name, ()))
+    side_rows = [r for r in last if side_kernels and any(k in r["Kernel_Name"] for k in side_kernels)]
+    if side_rows:
+        last = [r for r in last if r not in side_rows]
     i = 0
     out = []
     for c in calls:
@@ -116,6 +123,9 @@ def join(d):
         a[3] += c.get("main_us", d_)
         if c["name"] == "ldmk_igemm":
             a[2] += 2.0 * c["M"] * c["N"] * c["K"] * c.get("batch", 1)
+    if side_rows:
+        print(f"parallel branch (forked stream, not on the critical path): {len(side_rows)} launches, "
+              f"{sum(dur(r) for r in side_rows):.1f} us")
     print(f"{'call':75s} {'n':>3s} {'us_total':>10s} {'pct':>6s} {'TFLOP/s':>8s}")
     fam_t = fam_f = 0.0
     for key, (n, d_, fl, mn) in sorted(agg.items(), key=lambda kv: -kv[1][1]):

@@ -42,7 +42,7 @@ def main():
     model, ucfg = build_model(a.latent, torch.device("cuda", 0))
     run = StepRunner(model, ucfg, a.batch, graph=False)
     pg = run.pg
-    calls = list(pg.calls)
+    calls = list(getattr(pg, "side_calls", None) or []) + list(pg.calls)      # (here the side launches run in line)
     names = sorted({c[3] for c in calls})
 
     def runner(skip):
@@ -56,6 +56,8 @@ def main():
 
     full = replay_us(runner(()))
     print(f"full step: {full:8.1f} us, {len(calls)} calls")
+    print(f"program as it runs (side launches on their forked branch), UNet only: {replay_us(pg.run):8.1f} us; "
+          f"whole DDIM step: {replay_us(run.eager_step):8.1f} us")
     for name in names:
         n = sum(1 for c in calls if c[3] == name)
         if name == "ldmk_igemm":
