@@ -248,6 +248,50 @@ def clip_leg(rank, world, dev, dist, barrier, frames=128, ddim_steps=20, window=
             "checksum": float(out.double().sum())}
 
 
+def batch1_leg(dev, frames=4, ddim_steps=50, window=8):
+    """The mode the reference SHIPS for talking faces (talking_face/progressive_sampling_difftalk.py:282-317, batch size 1 at
+    :350): frames are a serial chain -- the identity latent of frame k+1 is the latent generated for frame k -- so every DDIM
+    step is one UNet evaluation at batch 1: a chain of dependent launches, not a throughput problem.  Timed: `frames` frames x
+    `ddim_steps` hipGraph-replayed steps through DDIMSampler.progressive_sampling(fixed_identity=False), conditioning
+    (audio window encoder, first-stage encode) included, after one untimed clip that builds the program and the graph."""
+    from dsml_thesis_amd.synth import make_tf_model
+    from dsml_thesis_amd.ddim import DDIMSampler
+    T, W_ = frames, window
+    m = make_tf_model(gain=0.25, seq_len=2 * W_ + 1, device=dev)
+    rs = np.random.RandomState(3)
+    audio = torch.from_numpy(rs.standard_normal((T, 768)).astype(np.float32)).to(dev)
+    masked = torch.tanh(torch.from_numpy(rs.standard_normal((T, 3, 128, 128)).astype(np.float32))).to(dev)
+    masked[:, :, 70:, :] = -1.0
+    ident = torch.tanh(torch.from_numpy(rs.standard_normal((1, 3, 128, 128)).astype(np.float32))).to(dev)
+    x_T = torch.from_numpy(rs.standard_normal((T, 1, 3, 32, 32)).astype(np.float32)).to(dev)
+    c1 = m.cond_stage_model_1.embedding(torch.tensor([[4]], device=dev))
+    s = DDIMSampler(m)
+
+    def clip():
+        xid = m.encode_first_stage(ident)
+        fr, _ = s.progressive_sampling(c1, xid, masked, audio, ddim_steps, 1, T, (3, 32, 32), W_, eta=0.0, x_T=x_T,
+                                       fixed_identity=False, use_graph=True)
+        return fr
+    clip()
+    torch.cuda.synchronize()
+    els = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fr = clip()
+        torch.cuda.synchronize()
+        els.append(time.perf_counter() - t0)
+    el = sorted(els)[1]
+    assert len(fr) == T and all(torch.isfinite(f).all() for f in fr)
+    pg = m.model.diffusion_model.program(1, 32, 32, 1, 6)
+    return {"workload": f"talking_face autoregressive clip (the reference's shipped mode), batch 1, {T} frames x DDIM-{ddim_steps}, "
+                        f"32x32x3 latent, hipGraph step; conditioning encoders included, decode not",
+            "frames": T, "ddim_steps": ddim_steps, "seconds": round(el, 4), "ms_per_step": round(1e3 * el / (T * ddim_steps), 4),
+            "sample_steps_per_s": round(T * ddim_steps / el, 1),
+            "frames_per_s_at_ddim200": round(1.0 / (200 * el / (T * ddim_steps)), 3),
+            "launches_per_unet_eval": len(pg.calls) + len(getattr(pg, "side_calls", None) or []),
+            "route": "small-batch program (unet_small.py)" if getattr(pg, "small_route", False) else "batched program"}
+
+
 def train_mode(a, rank, world, dev, dist, backend, barrier, graph, emit):
     """BASELINE configs[4]: one optimisation step = q_sample + UNet forward + hand-written backward
     (hipGraph-captured) + gradient all-reduce over the ranks + AdamW + EMA, fixed batch per GPU (weak scaling)."""
@@ -496,6 +540,9 @@ def main():
     if not a.no_clip:
         torch.cuda.empty_cache()
         out["clip"] = clip_leg(rank, world, dev, dist, barrier, frames=a.clip_frames, ddim_steps=a.clip_steps)
+        if rank == 0 and world == 1:
+            torch.cuda.empty_cache()
+            out["batch1"] = batch1_leg(dev)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.latent)
     elif rank == 0:

@@ -157,9 +157,9 @@ def build_small(unet, n, H, W_, L_ctx, c_concat, policy_n):
     pin = (policy_n, n)
     sb = SmallBuilder(pg, n, pin)
 
-    # -- time embedding MLP + all emb_layers (one launch each), as in the batched program; they only read `t`, so they are
-    # recorded as SIDE launches (a parallel branch of the captured step, joined in front of the first ResBlock's post)
-    n_main0 = len(pg.calls)
+    # -- time embedding MLP + all emb_layers (one launch each), as in the batched program.  (They only read `t`; running
+    # them as a parallel branch of the captured step -- a forked stream, engine.Program.side_calls -- was measured: the
+    # fork / join inside the hipGraph costs more than the 45 us it hides, 2265 -> 2423 us per step.  Kept in line.)
     temb = pg.alloc(n, mc)
     pg.add("ldmk_timestep_embedding", p_(t_in), p_(P["freqs"]), p_(temb), n, mc)
     e1 = pg.alloc(n, emb_ch)
@@ -169,10 +169,6 @@ def build_small(unet, n, H, W_, L_ctx, c_concat, policy_n):
     emb_all = pg.alloc(n, unet._emb_total)
     pg.add("ldmk_dense_small", p_(emb), emb_ch, p_(P["emb_all"]), p_(P["emb_all_b"]), p_(emb_all), unet._emb_total, n,
            emb_ch, unet._emb_total, 1)
-
-    pg.side_calls = pg.calls[n_main0:]
-    del pg.calls[n_main0:]
-    pg.side_join = None                      # set when the first consumer of emb_all is recorded
 
     def conv_args(a_in, cin, wp, wf, cout, h, w, stride=1, upsample=False):
         oh, ow = (2 * h, 2 * w) if upsample else ((h - 1) // stride + 1, (w - 1) // stride + 1)
@@ -186,8 +182,6 @@ def build_small(unet, n, H, W_, L_ctx, c_concat, policy_n):
         hmid = sb.raw([g1], rows, m.cout, hw, bias=sd[prefix + "in_layers.2.bias"],
                       bvec=emb_all.data_ptr() + 4 * unet._emb_off[prefix], bvec_ld=unet._emb_total)
         pg.release(a1)
-        if pg.side_join is None:
-            pg.side_join = len(pg.calls)     # the post below is the first launch that reads emb_all
         a2 = sb.post_gn(hmid, None, sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"], 1e-5, True)
         pg.release(hmid.raw)
         g2, _, _ = conv_args(a2, m.cout, P[prefix + "c2"], P.get(prefix + "c2#f"), m.cout, h, w)
