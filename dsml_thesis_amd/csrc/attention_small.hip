@@ -45,9 +45,12 @@ __global__ __launch_bounds__(64 * NW) void attn_small_kernel(const float* __rest
     for (int s4 = 0; s4 < 4; ++s4) {
       float4 q4 = *reinterpret_cast<const float4*>(qp + 4 * s4);
       if constexpr (SLABS) {
-        for (int sl = 1; sl < nslab; ++sl) {
-          const float4 t = *reinterpret_cast<const float4*>(qp + sl * slab_stride + 4 * s4);
+        for (int sl = 1; sl < nslab; sl += 2) {
+          const float4 t = *reinterpret_cast<const float4*>(qp + (long long)sl * slab_stride + 4 * s4);
+          const float4 u = *reinterpret_cast<const float4*>(qp + (long long)min(sl + 1, nslab - 1) * slab_stride + 4 * s4);
+          const bool two = sl + 1 < nslab;
           q4.x += t.x; q4.y += t.y; q4.z += t.z; q4.w += t.w;
+          q4.x += two ? u.x : 0.f; q4.y += two ? u.y : 0.f; q4.z += two ? u.z : 0.f; q4.w += two ? u.w : 0.f;
         }
       }
       qf[4 * s4] = q4.x * qs; qf[4 * s4 + 1] = q4.y * qs; qf[4 * s4 + 2] = q4.z * qs; qf[4 * s4 + 3] = q4.w * qs;
@@ -79,19 +82,27 @@ __global__ __launch_bounds__(64 * NW) void attn_small_kernel(const float* __rest
 #pragma unroll
     for (int s = 0; s < 16; ++s) vreg[s] = *vp[s];
     if constexpr (SLABS) {
-      for (int sl = 1; sl < nslab; ++sl) {
-        float4 kt[4];
-        float vt[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) kt[j] = *reinterpret_cast<const float4*>(kp + sl * slab_stride + 4 * j);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) vt[s] = vp[s][sl * slab_stride];
+      // two more slabs per round trip (clamped addresses, a slab past the end contributes +0)
+      for (int sl = 1; sl < nslab; sl += 2) {
+        const long long o0 = (long long)sl * slab_stride, o1 = (long long)min(sl + 1, nslab - 1) * slab_stride;
+        const bool two = sl + 1 < nslab;
+        float4 kt[2][4];
+        float vt[2][16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          kreg[4 * j] += kt[j].x; kreg[4 * j + 1] += kt[j].y; kreg[4 * j + 2] += kt[j].z; kreg[4 * j + 3] += kt[j].w;
+          kt[0][j] = *reinterpret_cast<const float4*>(kp + o0 + 4 * j);
+          kt[1][j] = *reinterpret_cast<const float4*>(kp + o1 + 4 * j);
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) vreg[s] += vt[s];
+        for (int s = 0; s < 16; ++s) { vt[0][s] = vp[s][o0]; vt[1][s] = vp[s][o1]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          kreg[4 * j] += kt[0][j].x; kreg[4 * j + 1] += kt[0][j].y; kreg[4 * j + 2] += kt[0][j].z; kreg[4 * j + 3] += kt[0][j].w;
+          kreg[4 * j] += two ? kt[1][j].x : 0.f; kreg[4 * j + 1] += two ? kt[1][j].y : 0.f;
+          kreg[4 * j + 2] += two ? kt[1][j].z : 0.f; kreg[4 * j + 3] += two ? kt[1][j].w : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { vreg[s] += vt[0][s]; vreg[s] += two ? vt[1][s] : 0.f; }
       }
     }
   };

@@ -170,6 +170,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("LDMK_ATTN_QT"):          # A/B hook: query tiles per wave of the staged attention kernel (1 / 2)
+        lib.ldmk_attn_force_qt(int(os.environ["LDMK_ATTN_QT"]))
     _lib = lib
     return lib
 
