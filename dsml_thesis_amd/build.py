@@ -11,13 +11,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libldmk.so")
-SOURCES = ["igemm.hip", "rgemm.hip", "norms.hip", "attention.hip", "small.hip", "wgrad.hip", "backward.hip", "attention_bwd.hip", "winograd.hip", "post.hip", "sgemm.hip", "attention_small.hip"]
+SOURCES = ["igemm.hip", "rgemm.hip", "norms.hip", "attention.hip", "small.hip", "wgrad.hip", "backward.hip", "attention_bwd.hip", "winograd.hip", "post.hip", "sgemm.hip", "attention_small.hip", "attention_bf16.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
 # The attention kernels run their softmax on the MFMA results: keep the accumulators in VGPRs (MFMA VGPR form) instead of
 # AGPRs, otherwise every score / output tile costs a v_accvgpr_read + v_accvgpr_write round trip per register
 # (208 such moves per key tile in the forward kernel).  The GEMM kernels only touch their accumulators in the epilogue.
 EXTRA_FLAGS = {"rgemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attention_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "attention_small.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+               "attention_small.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "attention_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _digest():

@@ -1,0 +1,313 @@
+// Self attention (d_head = 32) forward + backward with bf16 matrix-core products, for the bf16 TRAINING step
+// (BASELINE configs[4]; the reference trains under Lightning's mixed precision, main.py:532 / ddpm.py:1014-1047).
+//
+// Round 2 ran the training step's GEMMs on v_mfma_f32_32x32x16_bf16 but kept attention on the fp32 pipe: at 64x64x4,
+// batch 16, the three attention kernels were then 35 of the step's 88 ms (profiles/r03_train_bf16_kernel_stats.txt:
+// forward 8.3, dQ 11.7, dK/dV 15.1 ms).  Same split as torch.autocast(bfloat16) makes for scaled-dot-product attention:
+// Q K^T, P V and the five backward products take bf16 operands (rounded to nearest even) and accumulate in fp32; the
+// softmax, its statistics (log-sum-exp, D = rowsum(dO o O)) and everything stored stay fp32.
+//
+// Algorithm = attention.hip / attention_bwd.hip (flash style, scores recomputed from the forward's log-sum-exp, two
+// deterministic backward kernels), re-cut for the 32x32x16 instruction:
+//   * a 32-deep contraction is TWO instructions (k = 16 each) instead of sixteen; operands are 8 bf16 per lane
+//     (lanes 0-31: k 0..7, lanes 32-63: k 8..15);
+//   * tiles of 64 rows are staged once as TWO bf16 LDS images: row-major [row][d] (16-byte operand reads for products
+//     that contract over d) and transposed [d][row] (two 8-byte reads for products that contract over rows);
+//   * the accumulator trick carries over: a 32x32 score tile holds, in registers 8t .. 8t+7 of lane (column, half h), rows
+//     16t + 4h + (j&3) + 8(j>>2) -- taken as they are (packed to bf16) they are the B operand of step t of the next
+//     product, provided the A operand enumerates the contraction index in the same order; the transposed image serves that
+//     order as two runs of four.
+#include "ldmk_common.h"
+
+namespace ldmk {
+
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int BA_D = 32;
+constexpr int BA_T = 64;            // rows per staged tile
+constexpr int BA_RS = 40;           // row-major image: bf16 per row (80 B: 16-byte aligned operand reads, odd multiple of 16 B)
+constexpr int BA_TS = 72;           // transposed image: bf16 per d row (144 B)
+constexpr int BA_FS = 33;           // fp32 transpose buffer stride (output rows)
+
+__device__ __forceinline__ bf16x8_t pack8(const float* v) {
+  return bf16x8_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3], (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+}
+__device__ __forceinline__ bf16x8_t pack8(const f32x16& a, int t) {
+  return bf16x8_t{(__bf16)a[8 * t], (__bf16)a[8 * t + 1], (__bf16)a[8 * t + 2], (__bf16)a[8 * t + 3],
+                  (__bf16)a[8 * t + 4], (__bf16)a[8 * t + 5], (__bf16)a[8 * t + 6], (__bf16)a[8 * t + 7]};
+}
+
+// stage 64 rows x 32 floats of a [rows][ld] fp32 matrix as bf16: R[row][d] (if R) and T[d][row] (if T); rows past the end are 0
+__device__ __forceinline__ void stage_bf16(__bf16* R, __bf16* T, const float* __restrict__ src, long long ld, int r0, int rows, int tid) {
+  const int rr = tid >> 3, d4 = (tid & 7) * 4;
+  float4 v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = r0 + rr + 32 * i;
+    v[i] = r < rows ? *reinterpret_cast<const float4*>(src + (long long)r * ld + d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = rr + 32 * i;
+    const bf16x4_t b = {(__bf16)v[i].x, (__bf16)v[i].y, (__bf16)v[i].z, (__bf16)v[i].w};
+    if (R) *reinterpret_cast<bf16x4_t*>(R + row * BA_RS + d4) = b;
+    if (T) { T[(d4 + 0) * BA_TS + row] = b[0]; T[(d4 + 1) * BA_TS + row] = b[1]; T[(d4 + 2) * BA_TS + row] = b[2]; T[(d4 + 3) * BA_TS + row] = b[3]; }
+  }
+}
+
+// A operand from the row-major image: rows sub*32 + l31, contraction index d = 16 t + 8 half .. + 7
+__device__ __forceinline__ bf16x8_t op_rows(const __bf16* R, int sub, int l31, int half, int t) {
+  return *reinterpret_cast<const bf16x8_t*>(R + (sub * 32 + l31) * BA_RS + 16 * t + 8 * half);
+}
+// A operand from the transposed image: row d = l31, contraction index = tile rows sub*32 + 16 t + 4 half + (j&3) + 8 (j>>2)
+__device__ __forceinline__ bf16x8_t op_cols(const __bf16* T, int sub, int l31, int half, int t) {
+  const __bf16* p = T + l31 * BA_TS + sub * 32 + 16 * t + 4 * half;
+  const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(p), hi = *reinterpret_cast<const bf16x4_t*>(p + 8);
+  return bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// register fragment (B operand): row `rowp` of a [rows][ld] fp32 matrix, d = 16 t + 8 half .. + 7, scaled
+__device__ __forceinline__ void frag_rows(bf16x8_t (&f)[2], const float* __restrict__ rowp, int half, float mul) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float4 a = *reinterpret_cast<const float4*>(rowp + 16 * t + 8 * half), b = *reinterpret_cast<const float4*>(rowp + 16 * t + 8 * half + 4);
+    const float v[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, b.x * mul, b.y * mul, b.z * mul, b.w * mul};
+    f[t] = pack8(v);
+  }
+}
+__device__ __forceinline__ f32x16 mm(const bf16x8_t a, const bf16x8_t b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// write a wave's accumulator acc[r] = X^T[d = (r&3)+8(r>>2)+4 half][row = l31] as fp32 rows of 128 B
+__device__ __forceinline__ void store_rows_bf(float* ts, const f32x16& acc, float mul, float* __restrict__ dst, long long ld,
+                                              int row0, int rows, int l31, int half) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ts[l31 * BA_FS + (r & 3) + 8 * (r >> 2) + 4 * half] = acc[r] * mul;
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < 32; q += 2)
+    if (row0 + q + half < rows) dst[(long long)(row0 + q + half) * ld + l31] = ts[(q + half) * BA_FS + l31];
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- forward: out = softmax(scale Q K^T) V, lse = log-sum-exp of the scaled scores (natural log), both fp32
+__global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                            float* __restrict__ lse, int tokens, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) __bf16 Kr[BA_T * BA_RS];
+  __shared__ __attribute__((aligned(16))) __bf16 Vt[BA_D * BA_TS];
+  __shared__ float Ts[4][32 * BA_FS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int C = heads * BA_D, ld = 3 * C;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float* base = qkv + (long long)b * tokens * ld;
+  const bool wave_active = q0 < tokens;
+  const bool q_valid = q0 + l31 < tokens;
+  bf16x8_t qf[2];
+  frag_rows(qf, base + (long long)(q_valid ? q0 + l31 : 0) * ld + h * BA_D, half, q_valid ? scale : 0.f);
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int ntiles = (tokens + BA_T - 1) / BA_T;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();
+    stage_bf16(Kr, nullptr, base + C + h * BA_D, ld, kt * BA_T, tokens, tid);
+    stage_bf16(nullptr, Vt, base + 2 * C + h * BA_D, ld, kt * BA_T, tokens, tid);
+    __syncthreads();
+    if (!wave_active) continue;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int key0 = kt * BA_T + sub * 32;
+      if (key0 >= tokens) break;
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) s = mm(op_rows(Kr, sub, l31, half, t), qf[t], s);        // S^T[key][q]
+      if (key0 + 32 > tokens) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s[r] = -INFINITY;
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_new); psum += s[r]; }
+      psum += __shfl_xor(psum, 32, 64);
+      const float corr = __expf(m_run - m_new);
+      l_run = l_run * corr + psum;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] *= corr;
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) o = mm(op_cols(Vt, sub, l31, half, t), pack8(s, t), o);   // O^T[d][q] += V^T P^T
+    }
+  }
+  if (!wave_active) return;
+  if (lse != nullptr && half == 0 && q_valid) lse[((long long)b * heads + h) * tokens + q0 + l31] = m_run + __logf(l_run);
+  store_rows_bf(Ts[wave], o, 1.0f / l_run, out + (long long)b * tokens * C + h * BA_D, C, q0, tokens, l31, half);
+}
+
+// ---- backward, dQ: a wave owns 32 queries and walks the keys
+__global__ __launch_bounds__(256) void attn_bf16_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                           float* __restrict__ dqkv, int tokens, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) __bf16 Kr[BA_T * BA_RS];
+  __shared__ __attribute__((aligned(16))) __bf16 Kt[BA_D * BA_TS];
+  __shared__ __attribute__((aligned(16))) __bf16 Vr[BA_T * BA_RS];
+  __shared__ float Ts[4][32 * BA_FS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int C = heads * BA_D, ld = 3 * C;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float* base = qkv + (long long)b * tokens * ld;
+  const bool wave_active = q0 < tokens;
+  const bool q_valid = q0 + l31 < tokens;
+  const int qq = q_valid ? q0 + l31 : 0;
+  bf16x8_t qf[2], dof[2];
+  frag_rows(qf, base + (long long)qq * ld + h * BA_D, half, q_valid ? scale : 0.f);
+  frag_rows(dof, dout + ((long long)b * tokens + qq) * C + h * BA_D, half, q_valid ? 1.f : 0.f);
+  const float Lq = q_valid ? lse[((long long)b * heads + h) * tokens + qq] : INFINITY;
+  const float Dq = q_valid ? dsum[((long long)b * heads + h) * tokens + qq] : 0.f;
+  f32x16 dq;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+  const int ntiles = (tokens + BA_T - 1) / BA_T;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();
+    stage_bf16(Kr, Kt, base + C + h * BA_D, ld, kt * BA_T, tokens, tid);
+    stage_bf16(Vr, nullptr, base + 2 * C + h * BA_D, ld, kt * BA_T, tokens, tid);
+    __syncthreads();
+    if (!wave_active) continue;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int key0 = kt * BA_T + sub * 32;
+      if (key0 >= tokens) break;
+      f32x16 sa, da;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        sa = mm(op_rows(Kr, sub, l31, half, t), qf[t], sa);      // S^T[key][q]
+        da = mm(op_rows(Vr, sub, l31, half, t), dof[t], da);     // dP^T[key][q]
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = __expf(sa[r] - Lq);
+        if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) p = 0.f;
+        sa[r] = p * (da[r] - Dq);                                 // dS^T[key][q]
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) dq = mm(op_cols(Kt, sub, l31, half, t), pack8(sa, t), dq);   // dQ^T[d][q] += K^T dS^T
+    }
+  }
+  if (!wave_active) return;
+  store_rows_bf(Ts[wave], dq, scale, dqkv + (long long)b * tokens * ld + h * BA_D, ld, q0, tokens, l31, half);
+}
+
+// ---- backward, dK / dV: a wave owns 32 keys and walks the queries
+__global__ __launch_bounds__(256) void attn_bf16_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                            float* __restrict__ dqkv, int tokens, int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) __bf16 Qr[BA_T * BA_RS];
+  __shared__ __attribute__((aligned(16))) __bf16 Qt[BA_D * BA_TS];
+  __shared__ __attribute__((aligned(16))) __bf16 Or[BA_T * BA_RS];      // dO tile
+  __shared__ __attribute__((aligned(16))) __bf16 Ot[BA_D * BA_TS];
+  __shared__ float Ls[BA_T], Ds[BA_T];
+  __shared__ float Ts[4][32 * BA_FS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int C = heads * BA_D, ld = 3 * C;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const float* base = qkv + (long long)b * tokens * ld;
+  const float* dbase = dout + (long long)b * tokens * C;
+  const bool wave_active = k0 < tokens;
+  const bool k_valid = k0 + l31 < tokens;
+  const int kk = k_valid ? k0 + l31 : 0;
+  bf16x8_t kf[2], vf[2];
+  frag_rows(kf, base + (long long)kk * ld + C + h * BA_D, half, k_valid ? scale : 0.f);
+  frag_rows(vf, base + (long long)kk * ld + 2 * C + h * BA_D, half, k_valid ? 1.f : 0.f);
+  f32x16 dk, dv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+  const float* lrow = lse + ((long long)b * heads + h) * tokens;
+  const float* drow = dsum + ((long long)b * heads + h) * tokens;
+  const int ntiles = (tokens + BA_T - 1) / BA_T;
+  for (int qt = 0; qt < ntiles; ++qt) {
+    __syncthreads();
+    stage_bf16(Qr, Qt, base + h * BA_D, ld, qt * BA_T, tokens, tid);
+    stage_bf16(Or, Ot, dbase + h * BA_D, C, qt * BA_T, tokens, tid);
+    if (tid < BA_T) {
+      const int q = qt * BA_T + tid;
+      Ls[tid] = q < tokens ? lrow[q] : INFINITY;       // exp(s - inf) = 0: rows past the end contribute nothing
+      Ds[tid] = q < tokens ? drow[q] : 0.f;
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int qbase = qt * BA_T + sub * 32;
+      if (qbase >= tokens) break;
+      f32x16 sa, da;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        sa = mm(op_rows(Qr, sub, l31, half, t), kf[t], sa);      // S[q][key]
+        da = mm(op_rows(Or, sub, l31, half, t), vf[t], da);      // dP[q][key]
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float p = __expf(sa[r] - Ls[ql]);
+        da[r] = p * (da[r] - Ds[ql]);      // dS[q][key]
+        sa[r] = p;                         // P[q][key]
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        dv = mm(op_cols(Ot, sub, l31, half, t), pack8(sa, t), dv);          // dV^T[d][key] += dO^T P
+        dk = mm(op_cols(Qt, sub, l31, half, t), pack8(da, t), dk);          // dK^T[d][key] += Q^T dS
+      }
+    }
+  }
+  if (!wave_active) return;
+  float* obase = dqkv + (long long)b * tokens * ld + h * BA_D;
+  store_rows_bf(Ts[wave], dk, scale, obase + C, ld, k0, tokens, l31, half);
+  store_rows_bf(Ts[wave], dv, 1.0f, obase + 2 * C, ld, k0, tokens, l31, half);
+}
+
+void attn_rowdot_launch(const float* dout, const float* out, float* dsum, int tokens, int heads, long long total, hipStream_t st);   // attention_bwd.hip
+
+}  // namespace ldmk
+
+extern "C" int ldmk_attn_self_lse_bf16(const float* qkv, float* out, float* lse, int n, int tokens, int heads, float scale,
+                                       void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(qkv && out && n > 0 && tokens > 0 && heads > 0 && heads <= 65535 && n <= 65535, "ldmk_attn_self_lse_bf16: bad args");
+  dim3 grid((tokens + 127) / 128, heads, n);
+  hipLaunchKernelGGL(attn_bf16_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, lse, tokens, heads, scale);
+  return check_launch("ldmk_attn_self_lse_bf16");
+}
+
+extern "C" int ldmk_attn_self_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                                       float* dsum, int n, int tokens, int heads, float scale, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(qkv && out && dout && lse && dqkv && dsum, "ldmk_attn_self_bwd_bf16: null buffer");
+  LDMK_REQUIRE(n > 0 && tokens > 0 && heads > 0 && heads <= 65535 && n <= 65535, "ldmk_attn_self_bwd_bf16: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  attn_rowdot_launch(dout, out, dsum, tokens, heads, (long long)n * tokens * heads, st);
+  dim3 grid((tokens + 127) / 128, heads, n);
+  hipLaunchKernelGGL(attn_bf16_dq_kernel, grid, dim3(256), 0, st, qkv, dout, lse, dsum, dqkv, tokens, heads, scale);
+  hipLaunchKernelGGL(attn_bf16_dkv_kernel, grid, dim3(256), 0, st, qkv, dout, lse, dsum, dqkv, tokens, heads, scale);
+  return check_launch("ldmk_attn_self_bwd_bf16");
+}

@@ -36,6 +36,10 @@ __global__ void attn_rowdot_kernel(const float* __restrict__ dout, const float* 
   dsum[(b * heads + h) * tokens + q] = s;
 }
 
+void attn_rowdot_launch(const float* dout, const float* out, float* dsum, int tokens, int heads, long long total, hipStream_t st) {
+  hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dout, out, dsum, tokens, heads, total);
+}
+
 // stage 64 rows x 32 floats of a [rows][ld] matrix (row r0.., column offset coff) into a stride-33 LDS image
 __device__ __forceinline__ void stage_tile(float* dst, const float* __restrict__ src, long long ld, int r0, int rows, int tid) {
   const int rr = tid >> 3, d4 = (tid & 7) * 4;

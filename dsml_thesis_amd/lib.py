@@ -134,6 +134,8 @@ _SIGS = {
     "ldmk_mse_grad": (C.c_int, [_fp, _fp, _fp, C.c_longlong, C.c_longlong, _fp, _fp, _fp]),
     "ldmk_attn_self_lse": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_self_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    "ldmk_attn_self_lse_bf16": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    "ldmk_attn_self_bwd_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_cross_bwd": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_float, _fp]),
     "ldmk_audio_attention_grad_elems": (C.c_longlong, [C.c_int, C.c_int]),

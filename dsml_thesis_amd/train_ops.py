@@ -291,7 +291,9 @@ def attn_self_lse(qkv, n, tokens, heads):
     """Forward attention that also returns the per-row log-sum-exp [n][heads][tokens] (saved for the backward)."""
     out = _f32(n * tokens, heads * 32, device=qkv.device)
     lse = _f32(n, heads, tokens, device=qkv.device)
-    L.call("ldmk_attn_self_lse", _ptr(qkv), _ptr(out), _ptr(lse), n, tokens, heads, 32 ** -0.5, stream())
+    # bf16 compute mode: Q K^T and P V on the bf16 matrix cores (fp32 softmax / statistics / storage), like the GEMMs
+    name = "ldmk_attn_self_lse_bf16" if COMPUTE == L.COMPUTE_BF16 else "ldmk_attn_self_lse"
+    L.call(name, _ptr(qkv), _ptr(out), _ptr(lse), n, tokens, heads, 32 ** -0.5, stream())
     return out, lse
 
 
@@ -299,8 +301,8 @@ def attn_self_bwd(qkv, out, dout, lse, n, tokens, heads):
     """d(qkv) of ldmk_attn_self, flash style (probabilities recomputed from lse; any token count)."""
     dqkv = torch.empty_like(qkv)
     dsum = _f32(n * heads * tokens, device=qkv.device)
-    L.call("ldmk_attn_self_bwd", _ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _ptr(dsum), n, tokens, heads,
-           32 ** -0.5, stream())
+    name = "ldmk_attn_self_bwd_bf16" if COMPUTE == L.COMPUTE_BF16 else "ldmk_attn_self_bwd"
+    L.call(name, _ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _ptr(dsum), n, tokens, heads, 32 ** -0.5, stream())
     return dqkv
 
 

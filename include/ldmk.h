@@ -447,6 +447,12 @@ int ldmk_mse_grad(const float* pred, const float* target, float* dpred, long lon
 int ldmk_attn_self_lse(const float* qkv, float* out, float* lse, int n, int tokens, int heads, float scale, void* stream);
 int ldmk_attn_self_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* dsum,
                        int n, int tokens, int heads, float scale, void* stream);
+/* The same forward / backward pair with bf16 matrix-core products (v_mfma_f32_32x32x16_bf16, operands rounded to nearest even,
+ * fp32 accumulation; softmax, log-sum-exp, D and every stored tensor fp32): the attention of the bf16 training step
+ * (BASELINE configs[4]) -- the split torch.autocast(bfloat16) makes for attention.py:178-192.  Same arguments. */
+int ldmk_attn_self_lse_bf16(const float* qkv, float* out, float* lse, int n, int tokens, int heads, float scale, void* stream);
+int ldmk_attn_self_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, float* dsum,
+                            int n, int tokens, int heads, float scale, void* stream);
 /* Backward of ldmk_attn_cross (context of ctx_len <= 128 tokens): dq [n*tokens][ldq], dk / dv [n*ctx_len][ldkv];
  * scratch = 2 * n*tokens*heads*ctx_len floats (probabilities and score gradients kept between the two passes). */
 int ldmk_attn_cross_bwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* dout, int ldo,

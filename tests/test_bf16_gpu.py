@@ -82,6 +82,39 @@ def test_bf16_wgrad(ops, conv):
         T.set_compute("f32")
 
 
+@pytest.mark.parametrize("n,tokens,heads", [(2, 256, 5), (1, 1024, 5), (3, 100, 3), (1, 64, 20)])
+def test_bf16_attention_forward_and_backward(n, tokens, heads):
+    """Self attention of the bf16 training step (csrc/attention_bf16.hip): Q K^T, P V and the five backward products on the
+    bf16 matrix cores, fp32 softmax / statistics / storage.  Tolerance, stated: output and gradients within 1.5 % relative
+    L2 of float64 autograd on the fp32 inputs (bf16 operand rounding 2^-9 on Q, K, V, dO and on the probabilities; measured
+    ~0.3-0.6 %); and within 2e-3 of the fp32 kernels' log-sum-exp."""
+    from dsml_thesis_amd import train_ops as T
+    C = heads * 32
+    qkv = (rnd(430, n * tokens, 3 * C) * 0.8).double().requires_grad_(True)
+    dout = rnd(431, n * tokens, C).double()
+    q, k, v = (t_.reshape(n, tokens, heads, 32).permute(0, 2, 1, 3) for t_ in qkv.chunk(3, dim=1))
+    sc = q @ k.transpose(-1, -2) * 32 ** -0.5
+    att = (torch.softmax(sc, dim=-1) @ v).permute(0, 2, 1, 3).reshape(n * tokens, C)
+    (att * dout).sum().backward()
+    lse_ref = torch.logsumexp(sc, dim=-1)                                   # [n][heads][tokens]
+    qd, dd = qkv.detach().float().cuda(), dout.float().cuda()
+    T.set_compute("bf16")
+    try:
+        out, lse = T.attn_self_lse(qd, n, tokens, heads)
+        dqkv = T.attn_self_bwd(qd, out, dd, lse, n, tokens, heads)
+    finally:
+        T.set_compute("f32")
+    rel = lambda a, b: ((a.double().cpu() - b).norm() / b.norm()).item()
+    e_out, e_lse, e_grad = rel(out, att.detach()), (lse.double().cpu() - lse_ref.detach()).abs().max().item(), rel(dqkv, qkv.grad)
+    print(f"bf16 attention n={n} tokens={tokens} heads={heads}: out {e_out:.2e}, lse {e_lse:.2e}, dqkv {e_grad:.2e}")
+    assert e_out < 1.5e-2 and e_lse < 2e-2 and e_grad < 1.5e-2
+    for part, name in zip(dqkv.double().cpu().chunk(3, dim=1), "qkv"):
+        ref = qkv.grad.chunk(3, dim=1)["qkv".index(name)]
+        assert ((part - ref).norm() / ref.norm()).item() < 2e-2, name
+    out32, lse32 = T.attn_self_lse(qd, n, tokens, heads)                     # the fp32 kernels are untouched by the mode switch
+    assert rel(out32, att.detach()) < 1e-5
+
+
 def test_bf16_training_step_gradients_against_float64_autograd():
     """BASELINE configs[4]: p_losses forward + backward with every GEMM on the bf16 matrix cores.  Tolerance, stated: per
     parameter tensor, the relative L2 error of the gradient vs float64 autograd on the oracle is below 3 % (bf16 operand
