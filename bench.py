@@ -36,6 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 GFLOP_STEP = {32: 46.011, 64: 230.051}
 GFLOP_IGEMM = {32: 24.318 + 15.122 + 2.726, 64: 97.297 + 60.421 + 10.905}   # conv3x3 + linear + conv1x1
 PEAK_F32_MFMA = 157.3  # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32, dense)
+PEAK_BF16_MFMA = 2516.6  # TFLOP/s dense = 16 x the f32 matrix rate (same guide: "1/16 of BF16 MFMA", ~2.5 PF)
 
 
 def build_model(latent, device):
@@ -356,14 +357,17 @@ def train_mode(a, rank, world, dev, dist, backend, barrier, graph, emit):
            "vs_baseline": None, "dtype": "bf16" if a.bf16 else "f32", "data": "synthetic",
            "config": {"workload": f"face_reenactment UNet fine-tune step (latent_manipulation_tuned.py / main.py -t), "
                                   f"{n} samples/GPU, {latent}x{latent}x{c} latent, "
-                                  + ("bf16 matrix-core GEMMs (fp32 accumulate, master weights, norms, attention)" if a.bf16
+                                  + ("bf16 matrix-core GEMMs and attention products (fp32 accumulate, master weights, norms, softmax)" if a.bf16
                                      else "fp32 (the parity path; --bf16 selects BASELINE's bf16 compute)")
                                   + ", AdamW + EMA, random-init weights", "batch_per_gpu": n,
                       "global_batch": n * world, "hipgraph": graph,
                       "parallelism": f"dp{world} (flat gradient buffer all-reduced in 128 MB buckets, overlapped with the backward)"},
            "step_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
-           "roofline": {"bound": "mfma", "achieved": round(flops / world / (ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA,
-                        "unit": "TFLOP/s", "frac": round(flops / world / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA, 4),
+           # priced against the peak of the arithmetic the products run in: bf16 matrix cores for --bf16 (the step is then far
+           # from that roofline -- its GEMMs stage fp32 activations: DESIGN section 9), the f32 matrix rate otherwise
+           "roofline": {"bound": "mfma", "achieved": round(flops / world / (ms * 1e-3) / 1e12, 2),
+                        "peak": PEAK_BF16_MFMA if a.bf16 else PEAK_F32_MFMA, "unit": "TFLOP/s",
+                        "frac": round(flops / world / (ms * 1e-3) / 1e12 / (PEAK_BF16_MFMA if a.bf16 else PEAK_F32_MFMA), 4),
                         "traffic": None, "kernel": "whole step (igemm + wgrad + attention fwd/bwd), 3x forward GEMM FLOPs"},
            "cpu_baseline": None, "loss": float(loss_buf.item())}
     if rank == 0:

@@ -50,6 +50,7 @@ def test_bench_train_mode_line():
     assert d["roofline"]["bound"] == "mfma" and 0.0 < d["roofline"]["frac"] < 1.0
     b = _run("--train", "--bf16", "--steps", "2", "--warmup", "1", "--batch", "4")
     assert b["dtype"] == "bf16" and b["value"] > 1 and "bf16 matrix-core" in b["config"]["workload"]
+    assert b["roofline"]["peak"] > 2000 and d["roofline"]["peak"] < 200      # each priced against its own arithmetic's peak
 
 
 def test_bench_self_launches_two_ranks_and_the_clip_checksum_does_not_depend_on_the_rank_count():
