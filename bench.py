@@ -503,7 +503,7 @@ def main():
         fl_alg = algorithmic_gemm_flops(run.pg) * 1e-12           # the same layers in the reference's arithmetic
         t_tr = getattr(run, "winograd_transform_ms", 0.0)
         traffic, tnote = None, None
-        for tname in ("traffic_r02.json", "traffic_r01.json"):
+        for tname in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 try:

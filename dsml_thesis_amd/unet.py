@@ -478,8 +478,11 @@ class UNetModel(nn.Module):
             hcur = new
         coef = gn(hcur, None, ch_ * cw_, sd["out.0.weight"], sd["out.0.bias"], 1e-5)
         eps = pg.alloc(n, self.out_channels, H, W_)
-        pg.add("ldmk_conv3x3_out", p_(hcur), p_(coef), p_(P["out"]), p_(sd["out.2.bias"]), p_(eps), n, H, W_,
-               self._final_ch, self.out_channels)
+        # latent-sized images: 4x4-pixel workgroups with the weights in LDS (16x the workgroups of the 16x16-pixel form: 60 -> ~15 us at
+        # 32x32, B = 16); the choice depends on the image and channel counts only, never on the batch
+        co_small = H * W_ <= 64 * 64 and self._final_ch % 4 == 0 and 9 * self._final_ch * self.out_channels * 4 <= 60 * 1024
+        pg.add("ldmk_conv3x3_out_small" if co_small else "ldmk_conv3x3_out", p_(hcur), p_(coef), p_(P["out"]), p_(sd["out.2.bias"]),
+               p_(eps), n, H, W_, self._final_ch, self.out_channels)
         pg.outputs = dict(eps=eps)
         pg.ctx_program = ctx_pg
         return pg
