@@ -286,7 +286,174 @@ __global__ __launch_bounds__(256) void attn_bf16_dkv_kernel(const float* __restr
 
 void attn_rowdot_launch(const float* dout, const float* out, float* dsum, int tokens, int heads, long long total, hipStream_t st);   // attention_bwd.hip
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32-ACCURATE self attention on the bf16 matrix cores (the sampling path; LDMK_COMPUTE_BF16X3 of include/ldmk.h applied
+// to the two attention products).  Every fp32 operand -- Q (pre-scaled), K, V and the probabilities P -- is the exact sum
+// of three bf16 values; each product accumulates the six partial products that are not below fp32 resolution.  A 32-key
+// step is 24 bf16 MFMAs of 32 cycles (768) where the fp32 form issues 32 of 64 (2048); softmax, running statistics and the
+// output stay fp32.  Same tile walk and operand orders as attn_bf16_fwd_kernel above; K / V tiles hold three images each.
+__device__ __forceinline__ float bfu(__bf16 b) { return (float)b; }
+__device__ __forceinline__ void split4(const float4& v, bf16x4_t& h, bf16x4_t& m, bf16x4_t& l) {
+  h = bf16x4_t{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  const float r0 = v.x - bfu(h[0]), r1 = v.y - bfu(h[1]), r2 = v.z - bfu(h[2]), r3 = v.w - bfu(h[3]);
+  m = bf16x4_t{(__bf16)r0, (__bf16)r1, (__bf16)r2, (__bf16)r3};
+  l = bf16x4_t{(__bf16)(r0 - bfu(m[0])), (__bf16)(r1 - bfu(m[1])), (__bf16)(r2 - bfu(m[2])), (__bf16)(r3 - bfu(m[3]))};
+}
+__device__ __forceinline__ void split8(const float* v, bf16x8_t (&o)[3]) {
+  float r[8];
+  o[0] = pack8(v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = v[i] - bfu(o[0][i]);
+  o[1] = pack8(r);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] -= bfu(o[1][i]);
+  o[2] = pack8(r);
+}
+// the six partial products, smallest first (images: 0 = hi, 1 = mid, 2 = lo)
+__device__ __forceinline__ f32x16 mm6(const bf16x8_t (&a)[3], const bf16x8_t (&b)[3], f32x16 c) {
+  c = mm(a[2], b[0], c);
+  c = mm(a[0], b[2], c);
+  c = mm(a[1], b[1], c);
+  c = mm(a[1], b[0], c);
+  c = mm(a[0], b[1], c);
+  return mm(a[0], b[0], c);
+}
+
+constexpr int X3_KIMG = BA_T * BA_RS, X3_VIMG = BA_D * BA_TS;       // bf16 elements per K / V image
+
+__global__ __launch_bounds__(256) void attn_x3_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens,
+                                                          int heads, float scale) {
+  // one array: three K images, three V^T images; after the key loop the same memory is the four output transpose buffers
+  __shared__ __attribute__((aligned(16))) __bf16 smem_x3[3 * X3_KIMG + 3 * X3_VIMG];
+  static_assert((3 * X3_KIMG + 3 * X3_VIMG) * 2 >= 4 * 32 * BA_FS * 4, "transpose buffers alias the staging images");
+  __bf16* Kr = smem_x3;
+  __bf16* Vt = smem_x3 + 3 * X3_KIMG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int C = heads * BA_D, ld = 3 * C;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float* base = qkv + (long long)b * tokens * ld;
+  const bool wave_active = q0 < tokens;
+  const bool q_valid = q0 + l31 < tokens;
+  constexpr float LOG2E = 1.4426950408889634f;
+  // Q fragments (B operand of S^T = K Q^T), pre-scaled by scale * log2(e) in fp32 (scores live in the log2 domain), then split
+  bf16x8_t qf[2][3];
+  {
+    const float* rowp = base + (long long)(q_valid ? q0 + l31 : 0) * ld + h * BA_D;
+    const float mul = q_valid ? scale * LOG2E : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 a = *reinterpret_cast<const float4*>(rowp + 16 * t + 8 * half), c = *reinterpret_cast<const float4*>(rowp + 16 * t + 8 * half + 4);
+      const float v[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, c.x * mul, c.y * mul, c.z * mul, c.w * mul};
+      split8(v, qf[t]);
+    }
+  }
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int ntiles = (tokens + BA_T - 1) / BA_T;
+  // staging map: thread -> rows rr, rr + 32 of the tile, 4 consecutive d
+  const int rr = tid >> 3, d4 = (tid & 7) * 4;
+  const float* kp = base + C + h * BA_D + d4;
+  float4 kreg[2], vreg[2];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = kt * BA_T + rr + 32 * i;
+      const bool ok = r < tokens;
+      const float* src = kp + (long long)(ok ? r : 0) * ld;
+      kreg[i] = *reinterpret_cast<const float4*>(src);
+      vreg[i] = *reinterpret_cast<const float4*>(src + C);
+      if (!ok) { kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f); vreg[i] = kreg[i]; }
+    }
+  };
+  fetch(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = rr + 32 * i;
+      bf16x4_t g[3];
+      split4(kreg[i], g[0], g[1], g[2]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4_t*>(Kr + q * X3_KIMG + row * BA_RS + d4) = g[q];
+      split4(vreg[i], g[0], g[1], g[2]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        __bf16* T = Vt + q * X3_VIMG + d4 * BA_TS + row;
+        T[0] = g[q][0]; T[BA_TS] = g[q][1]; T[2 * BA_TS] = g[q][2]; T[3 * BA_TS] = g[q][3];
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < ntiles) fetch(kt + 1);               // in flight under this tile's products
+    if (!wave_active) continue;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int key0 = kt * BA_T + sub * 32;
+      if (key0 >= tokens) break;
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8_t ka[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ka[q] = op_rows(Kr + q * X3_KIMG, sub, l31, half, t);
+        s = mm6(ka, qf[t], s);                                                          // S^T[key][q], log2 domain
+      }
+      if (key0 + 32 > tokens) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s[r] = -INFINITY;
+      }
+      float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+      for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); psum += s[r]; }
+      psum += __shfl_xor(psum, 32, 64);
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {      // rescale only when some lane's maximum moved
+        const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= corr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= corr;
+        m_run = m_new;
+      }
+      l_run += psum;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv[j] = s[8 * t + j];
+        bf16x8_t pb[3], va[3];
+        split8(pv, pb);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) va[q] = op_cols(Vt + q * X3_VIMG, sub, l31, half, t);
+        o = mm6(va, pb, o);                                                             // O^T[d][q] += V^T P^T
+      }
+    }
+  }
+  __syncthreads();                     // every wave is done with the staging images: their memory becomes the transpose buffers
+  if (!wave_active) return;
+  float* ts = reinterpret_cast<float*>(smem_x3) + wave * (32 * BA_FS);
+  store_rows_bf(ts, o, 1.0f / l_run, out + (long long)b * tokens * C + h * BA_D, C, q0, tokens, l31, half);
+}
+
 }  // namespace ldmk
+
+extern "C" int ldmk_attn_self_x3(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(qkv && out && n > 0 && tokens > 0 && heads > 0 && heads <= 65535 && n <= 65535, "ldmk_attn_self_x3: bad args");
+  dim3 grid((tokens + 127) / 128, heads, n);
+  hipLaunchKernelGGL(attn_x3_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, tokens, heads, scale);
+  return check_launch("ldmk_attn_self_x3");
+}
 
 extern "C" int ldmk_attn_self_lse_bf16(const float* qkv, float* out, float* lse, int n, int tokens, int heads, float scale,
                                        void* stream) {

@@ -40,16 +40,32 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {          // round
   return bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
 }
 
+// exact three-way split x = hi + mid + lo (each difference below is exact in fp32: the subtrahend is the leading part of x)
+__device__ __forceinline__ float bf_up(__bf16 b) { return (float)b; }
+__device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf16x4& l) {
+  h = to_bf16x4(v);
+  const float4 r = make_float4(v.x - bf_up(h[0]), v.y - bf_up(h[1]), v.z - bf_up(h[2]), v.w - bf_up(h[3]));
+  m = to_bf16x4(r);
+  l = to_bf16x4(make_float4(r.x - bf_up(m[0]), r.y - bf_up(m[1]), r.z - bf_up(m[2]), r.w - bf_up(m[3])));
+}
+
 // BF = true: bf16 matrix-core compute for the training step (BASELINE configs[4]).  Operands stay fp32 in HBM; they are
 // rounded to bf16 (RNE) while being staged, after the fp32 prologue (LayerNorm / GroupNorm-affine), into K-contiguous LDS
 // rows [tile row][KC + 8] (the +8 bf16 = 16 B pad makes the 16 rows one ds_read_b128 group touches bank-disjoint), and
 // multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 epilogue).  Per 32-deep K slice a wave issues 2 TM TN
 // bf16 MFMAs of 32 cycles instead of 16 TM TN fp32 MFMAs of 64: the matrix work shrinks 16x and the kernel becomes
 // staging-bound, which is the expected regime as long as activations are stored in fp32.
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false, bool FG = true>
+//
+// BF = 3: LDMK_COMPUTE_BF16X3, fp32-accurate products from six bf16 MFMAs (include/ldmk.h).  A is split three ways while it is
+// staged (three bf16 images [img][tile row][KC + 8]); the weights arrive pre-split and K-contiguous (args.w_split,
+// [3][N][ld] bf16), so their staging is a 16-byte copy; per 16 k a wave issues 6 TM TN MFMAs of 32 cycles where the fp32 form
+// issues 8 TM TN of 64.
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0, bool FG = true>
 __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws) {
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
+  constexpr bool X3 = BF == 3;
+  constexpr int BSI = X3 ? (3 * BN * 4 + 255) / 256 : 1;     // X3: 16-byte items of the three B images per thread and 32-k slice
   constexpr int NS = WK * KS;           // 32-wide K slices staged per iteration (KS per wave-group)
   constexpr int KC = 32 * NS;           // K elements staged per iteration
   constexpr int ASTR = BM + 1;          // odd stride: conflict-free transposed writes + reads
@@ -58,7 +74,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   constexpr int BROWS = BN / 32;        // same for B
   constexpr int RS = KC + 8;            // BF: bf16 elements per LDS row
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
-  static_assert(!BF || (WK == 1 && !DB), "the bf16 form is built for WK = 1, single-buffered");
+  static_assert(!BF || (WK == 1 && !DB), "the bf16 forms are built for WK = 1, single-buffered");
+  static_assert(!X3 || (!BT && FG), "the split form reads pre-split W (b_trans = 0) through the fast gather");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int STAGE = KC * (ASTR + BSTR);   // floats per staging buffer (DB: two of them)
@@ -68,6 +85,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   __bf16* Bs16 = reinterpret_cast<__bf16*>(smem) + BM * RS;     // BF, BT: [BN][RS] bf16 (W^T rows are K-contiguous in HBM)
   float* Bs32 = smem + BM * RS / 2;                             // BF, !BT: [KC][BN] fp32 as it lies in HBM (n-contiguous);
                                                                 // fragments are gathered from it, see compute()
+  constexpr int AIMG = BM * RS, BIMG = BN * RS;                 // X3: elements per image; A images first, then the B images
+  __bf16* Bx16 = reinterpret_cast<__bf16*>(smem) + 3 * AIMG;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -136,8 +155,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
     }
   }
 
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   float4 areg[NS][AROWS];
-  float4 breg[NS][BROWS];
+  float4 breg[X3 ? 1 : NS][X3 ? 1 : BROWS];
+  u32x4_t bxreg[NS][BSI];               // X3: the next slice's pre-split weight items
 
   // ---- fast gather (every launch except the upsampling convolutions).  Measured with s_memtime stamps
   // (tools/igemm_probe.hip) on the ResBlock convolutions: of 7400 cycles per 32-deep slice the generic gather below spent
@@ -160,6 +181,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   // {0, e, 1} for dy = {0, 1, 2} with e = 1 for even oy and 0 for odd oy (same in x): the parity-dependent middle steps
   // are two more per-row byte offsets (aoff1 doubles as the x one: the second source does not exist in this mode).
   unsigned upy[AROWS];
+  unsigned bxoff[BSI], bxlds[BSI];
+  __amdgpu_buffer_rsrc_t rs_wx = rs_w;
+  if constexpr (X3) {
+    const __bf16* wx = reinterpret_cast<const __bf16*>(p.w_split) + (long long)bz * p.w_split_bstride;
+    rs_wx = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wx), 0, (int)(unsigned)(3LL * p.N * p.w_split_ld * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < BSI; ++i) {
+      const int idx = tid + 256 * i;
+      const int img = idx / (BN * 4), rem = idx - img * (BN * 4);
+      const int nn = rem >> 2, q = rem & 3;
+      const bool ok = idx < 3 * BN * 4 && n0 + nn < p.N;
+      bxoff[i] = ok ? (unsigned)((((long long)img * p.N + n0 + nn) * p.w_split_ld + q * 8) * 2) : 0xFFFFFFFFu;
+      bxlds[i] = (unsigned)((img * BIMG + nn * RS + q * 8) * 2);                  // byte offset inside the B images
+    }
+  }
   if constexpr (FG) {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
@@ -189,7 +225,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       }
     }
   }
-  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   auto bload = [&](__amdgpu_buffer_rsrc_t rs, unsigned off) -> float4 {
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
@@ -220,13 +255,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         if (ups) o_ = aoff0[i] + sa + (dy == 1 ? upy[i] : 0u) + (dx == 1 ? aoff1[i] : 0u);
         oa[i] = (kvalid && (r_mask[i] & tbit)) ? o_ : 0xFFFFFFFFu;
       }
+      if constexpr (X3) {
+        unsigned ox[BSI];
 #pragma unroll
-      for (int i = 0; i < BROWS; ++i) ob[i] = (kvalid && boff[i] != 0xFFFFFFFFu) ? boff[i] + sb : 0xFFFFFFFFu;
-      __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < BSI; ++i) ox[i] = (kvalid && bxoff[i] != 0xFFFFFFFFu) ? bxoff[i] + (unsigned)(kc * 64) : 0xFFFFFFFFu;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < AROWS; ++i) areg[j][i] = second ? bload(rs_a1, oa[i]) : bload(rs_a0, oa[i]);
+        for (int i = 0; i < AROWS; ++i) areg[j][i] = second ? bload(rs_a1, oa[i]) : bload(rs_a0, oa[i]);
 #pragma unroll
-      for (int i = 0; i < BROWS; ++i) breg[j][i] = bload(rs_w, ob[i]);
+        for (int i = 0; i < BSI; ++i) bxreg[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wx, (int)ox[i], 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) ob[i] = (kvalid && boff[i] != 0xFFFFFFFFu) ? boff[i] + sb : 0xFFFFFFFFu;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) areg[j][i] = second ? bload(rs_a1, oa[i]) : bload(rs_a0, oa[i]);
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) breg[j][i] = bload(rs_w, ob[i]);
+      }
     }
   };
 
@@ -262,7 +308,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         areg[j][i] = v;
       }
 #pragma unroll
-      for (int i = 0; i < BROWS; ++i) {
+      for (int i = 0; i < (X3 ? 0 : BROWS); ++i) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (BT) {       // W given as [N][ldb]: rows n, contiguous k
           const int n = n0 + arow + 32 * i;
@@ -316,6 +362,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
           }
         }
       }
+      if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+          bf16x4 h, m, l;
+          split3(areg[j][i], h, m, l);
+          __bf16* d = As16 + (arow + 32 * i) * RS + j * 32 + acol;
+          *reinterpret_cast<bf16x4*>(d) = h;
+          *reinterpret_cast<bf16x4*>(d + AIMG) = m;
+          *reinterpret_cast<bf16x4*>(d + 2 * AIMG) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < BSI; ++i) {
+          if (tid + 256 * i < 3 * BN * 4)
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(Bx16) + bxlds[i] + j * 64) = bxreg[j][i];
+        }
+        continue;
+      }
       if (BF) {
 #pragma unroll
         for (int i = 0; i < AROWS; ++i)
@@ -363,6 +426,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   const float* Bw = Bs + (wk * KS * 32 + half) * BSTR + wn * (32 * TN) + l31;
 
   auto compute = [&](int boff) {
+    if constexpr (X3) {
+      const __bf16* Aw16 = As16 + (wm * (32 * TM) + l31) * RS + 8 * half;
+      const __bf16* Bw16 = Bx16 + (wn * (32 * TN) + l31) * RS + 8 * half;
+#pragma unroll
+      for (int s = 0; s < KC / 16; ++s) {
+        bf16x8 a8[3][TM];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a8[g][i] = *reinterpret_cast<const bf16x8*>(Aw16 + g * AIMG + i * 32 * RS + 16 * s);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bf16x8 b8[3];
+#pragma unroll
+          for (int g = 0; g < 3; ++g) b8[g] = *reinterpret_cast<const bf16x8*>(Bw16 + g * BIMG + j * 32 * RS + 16 * s);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            // smallest partial products first (images: 0 = hi, 1 = mid, 2 = lo)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][i], b8[0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[0], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      return;
+    }
     if constexpr (BF) {
       const __bf16* Aw16 = As16 + (wm * (32 * TM) + l31) * RS + 8 * half;
       const __bf16* Bw16 = Bs16 + (wn * (32 * TN) + l31) * RS + 8 * half;
@@ -788,6 +880,31 @@ __global__ __launch_bounds__(256) void igemm_reduce_stats_kernel(const ldmk_igem
   }
 }
 
+// W[K][ldb] fp32 -> the three bf16 images [3][N][ld_out] of its exact split, K-contiguous (LDMK_COMPUTE_BF16X3)
+__global__ __launch_bounds__(256) void pack_wsplit_kernel(const float* __restrict__ w, int K, int N, int ldb, long long w_bstride,
+                                                          __bf16* __restrict__ out, int ld_out) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const float* wb = w + (long long)blockIdx.z * w_bstride;
+  __bf16* ob = out + (long long)blockIdx.z * 3 * N * ld_out;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = (threadIdx.x >> 5) + 8 * r, n = threadIdx.x & 31;
+    tile[k][n] = (k0 + k < K && n0 + n < N) ? wb[(long long)(k0 + k) * ldb + n0 + n] : 0.f;
+  }
+  __syncthreads();
+  const int n = threadIdx.x >> 3, kq = (threadIdx.x & 7) * 4;
+  if (n0 + n < N && k0 + kq < ld_out) {
+    const float4 v = make_float4(tile[kq][n], tile[kq + 1][n], tile[kq + 2][n], tile[kq + 3][n]);
+    bf16x4 h, m, l;
+    split3(v, h, m, l);
+    __bf16* d = ob + (long long)(n0 + n) * ld_out + k0 + kq;
+    *reinterpret_cast<bf16x4*>(d) = h;
+    *reinterpret_cast<bf16x4*>(d + (long long)N * ld_out) = m;
+    *reinterpret_cast<bf16x4*>(d + 2LL * N * ld_out) = l;
+  }
+}
+
 struct TileCfg { int bm, bn, ns; bool even_tn; float eff; };
 // eff: measured sustained fraction of the f32 MFMA peak on long-K problems (profiles/r01_layers*_v2.txt, refined with
 // the tools/autotune.py sweeps: the 128x128 tile reaches 0.76 on the VQGAN decoder convolutions).  Shapes the
@@ -802,23 +919,24 @@ static const TileCfg kCfg[] = {
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0>
 static size_t cfg_lds_bytes() {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KC = 32 * WK * KS;
   constexpr int ASTR = BM + 1, BSTR = BN + (BT ? 1 : 0);
+  if (BF == 3) return (size_t)3 * (BM + BN) * (KC + 8) * 2;
   if (BF) return BT ? (size_t)(BM + BN) * (KC + 8) * 2 : (size_t)BM * (KC + 8) * 2 + (size_t)KC * BN * 4;
   size_t stage = (size_t)KC * (ASTR + BSTR) * sizeof(float) * (DB ? 2 : 1);
   size_t red = WK > 1 ? (size_t)(WK - 1) * WM * WN * TM * TN * 16 * 64 * sizeof(float) : 0;
   return stage > red ? stage : red;
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false, bool FG = true>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0, bool FG = true>
 static bool& cfg_attr_done() {
   static bool done = false;
   return done;
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false, bool FG = true>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0, bool FG = true>
 static void cfg_set_attr() {
   bool& done = cfg_attr_done<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG>();
   if (!done) {
@@ -850,16 +968,16 @@ int launch_splitk_reduce(const ldmk_igemm_args& a, int splitk, float* ws, hipStr
   return check_launch("ldmk_igemm(reduce)");
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF, bool FG>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF, bool FG>
 static int launch_cfg_g(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st);
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF = false>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0>
 static int launch_cfg(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
   return igemm_fast_gather_ok(a) ? launch_cfg_g<TM, TN, WM, WN, WK, KS, DB, BT, BF, true>(a, splitk, ws, st)
                                  : launch_cfg_g<TM, TN, WM, WN, WK, KS, DB, BT, BF, false>(a, splitk, ws, st);
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, bool BF, bool FG>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF, bool FG>
 static int launch_cfg_g(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   size_t lds = cfg_lds_bytes<TM, TN, WM, WN, WK, KS, DB, BT, BF>();
@@ -915,16 +1033,31 @@ static int dispatch_bf16(const ldmk_igemm_args& a, int cfg, int splitk, float* w
   if (cfg == 6) cfg = geglu ? 2 : 5;           // 64x160 with K split over wave pairs -> 128x160
   if (geglu && !kCfg[cfg - 1].even_tn) cfg = 1;
   switch (cfg) {
-    case 1: return launch_cfg<2, 2, 2, 2, 1, 1, false, BT, true>(a, splitk, ws, st);
-    case 2: return launch_cfg<1, 2, 2, 2, 1, 2, false, BT, true>(a, splitk, ws, st);
-    case 4: return launch_cfg<1, 1, 2, 2, 1, 2, false, BT, true>(a, splitk, ws, st);
-    default: return launch_cfg<1, 5, 4, 1, 1, 1, false, BT, true>(a, splitk, ws, st);
+    case 1: return launch_cfg<2, 2, 2, 2, 1, 1, false, BT, 1>(a, splitk, ws, st);
+    case 2: return launch_cfg<1, 2, 2, 2, 1, 2, false, BT, 1>(a, splitk, ws, st);
+    case 4: return launch_cfg<1, 1, 2, 2, 1, 2, false, BT, 1>(a, splitk, ws, st);
+    default: return launch_cfg<1, 5, 4, 1, 1, 1, false, BT, 1>(a, splitk, ws, st);
+  }
+}
+
+// fp32-accurate three-way bf16 split (args.compute = LDMK_COMPUTE_BF16X3): the WK = 1 tile shapes, pre-split weights
+static int dispatch_x3(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hipStream_t st) {
+  const bool geglu = a.epi == LDMK_EPI_GEGLU;
+  if (cfg == 3) cfg = 4;
+  if (cfg == 6) cfg = geglu ? 2 : 5;
+  if (geglu && !kCfg[cfg - 1].even_tn) cfg = 1;
+  switch (cfg) {
+    case 1: return launch_cfg_g<2, 2, 2, 2, 1, 1, false, false, 3, true>(a, splitk, ws, st);
+    case 2: return launch_cfg_g<1, 2, 2, 2, 1, 2, false, false, 3, true>(a, splitk, ws, st);
+    case 4: return launch_cfg_g<1, 1, 2, 2, 1, 2, false, false, 3, true>(a, splitk, ws, st);
+    default: return launch_cfg_g<1, 5, 4, 1, 1, 1, false, false, 3, true>(a, splitk, ws, st);
   }
 }
 
 template <bool BT>
 static int dispatch(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hipStream_t st) {
   if (a.compute == LDMK_COMPUTE_BF16) return dispatch_bf16<BT>(a, cfg, splitk, ws, st);
+  if (a.compute == LDMK_COMPUTE_BF16X3) return dispatch_x3(a, cfg, splitk, ws, st);
   if (a.epi == LDMK_EPI_GEGLU && !kCfg[cfg - 1].even_tn) cfg = 3;   // GEGLU needs (value, gate) tile pairs
   switch (cfg) {
     case 1: return launch_cfg<2, 2, 2, 2, 1, 1, false, BT>(a, splitk, ws, st);   // 128x128
@@ -962,6 +1095,16 @@ int sgemm_dispatch(const ldmk_igemm_args& a, int scfg, int splitk, float* ws, hi
 constexpr int kNumSCfg = 8;
 
 }  // namespace ldmk
+
+extern "C" int ldmk_pack_wsplit(const float* w, int K, int N, int ldb, int batch, long long w_bstride, void* out, int ld_out,
+                                void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(w && out && K > 0 && N > 0 && ldb >= N && batch >= 1, "ldmk_pack_wsplit: bad args");
+  LDMK_REQUIRE(ld_out >= K && ld_out % 8 == 0, "ldmk_pack_wsplit: ld_out=%d must be >= K=%d and a multiple of 8", ld_out, K);
+  hipLaunchKernelGGL(ldmk::pack_wsplit_kernel, dim3((ld_out + 31) / 32, (N + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, w, K,
+                     N, ldb, w_bstride, reinterpret_cast<__bf16*>(out), ld_out);
+  return ldmk::check_launch("ldmk_pack_wsplit");
+}
 
 // test hook: force a tile configuration (0 = heuristic)
 static int g_force_cfg = 0;
@@ -1039,7 +1182,14 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg + kNumRCfg + kNumSCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]", a.tile_cfg,
                kNumCfg + kNumRCfg + kNumSCfg);
   LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 64, "ldmk_igemm: splitk=%d outside [0,64]", a.splitk);
-  LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.compute == LDMK_COMPUTE_BF16, "ldmk_igemm: compute=%d", a.compute);
+  LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.compute == LDMK_COMPUTE_BF16 || a.compute == LDMK_COMPUTE_BF16X3, "ldmk_igemm: compute=%d", a.compute);
+  if (a.compute == LDMK_COMPUTE_BF16X3) {
+    LDMK_REQUIRE(a.w_split && !a.b_trans && a.w_split_ld >= a.K && a.w_split_ld % 8 == 0,
+                 "ldmk_igemm: LDMK_COMPUTE_BF16X3 needs w_split (ldmk_pack_wsplit), b_trans = 0, w_split_ld >= K and a multiple of 8");
+    LDMK_REQUIRE(3LL * a.N * a.w_split_ld * 2 < (1LL << 32), "ldmk_igemm: w_split exceeds 4 GB per batch entry");
+    LDMK_REQUIRE(igemm_fast_gather_ok(a), "ldmk_igemm: LDMK_COMPUTE_BF16X3 needs the fast gather (no zero-insertion, two-source "
+                 "upsampling or operands beyond 4 GB)");
+  }
   LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.tile_cfg <= kNumCfg, "ldmk_igemm: the row / slab GEMM tiles are fp32 only");
   if (a.alpha == 0.f) a.alpha = 1.f;
   int cfg = 0, sk = 1;

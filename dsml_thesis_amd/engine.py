@@ -52,6 +52,48 @@ def plan_table():
     return _PLAN_TABLE
 
 
+_X3_TABLE = None
+
+
+def split_enabled():
+    """LDMK_COMPUTE_BF16X3 (fp32-accurate GEMMs from six bf16 MFMAs, include/ldmk.h) for the shapes the x3 plan table lists;
+    LDMK_SPLIT_BF16=0 keeps every GEMM on the f32 matrix-core form."""
+    return os.environ.get("LDMK_SPLIT_BF16", "1") != "0"
+
+
+def x3_table():
+    """{shape key: [(M, cfg, splitk)]}: shapes that tools/autotune.py --x3 measured FASTER in the bf16x3 arithmetic than their
+    best f32 plan (dsml_thesis_amd/igemm_plans_x3.json; LDMK_X3_TABLE overrides the path)."""
+    global _X3_TABLE
+    if _X3_TABLE is None:
+        import json
+        path = os.environ.get("LDMK_X3_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans_x3.json")
+        _X3_TABLE = {}
+        if os.path.exists(path) and split_enabled():
+            try:
+                raw = json.load(open(path))
+            except Exception:
+                raw = {}
+            for k, (cfg, sk) in raw.items():
+                m, rest = k.split(",", 1)
+                _X3_TABLE.setdefault(rest, []).append((int(m), int(cfg), int(sk)))
+            for v in _X3_TABLE.values():
+                v.sort()
+    return _X3_TABLE
+
+
+def x3_plan(a, m):
+    """(cfg, splitk) of the bf16x3 plan for this shape, or None: same bucket rule as tuned_plan, but only an exact or
+    within-2x row count of a shape that was measured faster in this arithmetic."""
+    rows = x3_table().get(plan_key(a, m).split(",", 1)[1])
+    if not rows:
+        return None
+    best = min(rows, key=lambda r: (abs(math.log(r[0] / m)), r[0]))
+    if max(best[0], m) > 2 * min(best[0], m):
+        return None
+    return best[1], best[2]
+
+
 def tuned_plan(a, m):
     """Plan of the tuned shape with the same (N, K, prologue, epilogue) and the closest row count (log scale, at
     most a factor 2 away; ties go to the smaller M), or None.  Every plan in a bucket is legal for every M: the
@@ -131,6 +173,27 @@ class Program:
             else:
                 args.M = max(1, m * scale_m[0] // scale_m[1])
         cfg, sk = C.c_int(0), C.c_int(0)
+        # bf16x3 arithmetic for the shapes measured faster in it (needs the weight's split images; decided on the policy row
+        # count like every plan, so a sample's result does not depend on how the batch is sharded)
+        if (args.compute == L.COMPUTE_F32 and not args.b_trans and not args.raw_slabs and (nbatch <= 1 or not batch_is_samples)
+                and args.M > 0 and x3_table()):
+            xp = x3_plan(args, args.M)
+            if xp is not None:
+                from . import ops as _ops
+                saved = (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems)
+                args.M, args.batch = m, nbatch
+                ok = _ops.set_split(args)
+                if ok:
+                    args.tile_cfg, args.splitk = int(xp[0]), int(xp[1])
+                    args.splitk_ws, args.splitk_ws_elems = 1, 1 << 40
+                    ok = self.lib.ldmk_igemm_check(C.byref(args)) == 0
+                (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems) = saved
+                if ok:
+                    args.M, args.batch = m, nbatch
+                    args.tile_cfg, args.splitk = int(xp[0]), max(1, int(xp[1]))
+                    args.splitk_ws, args.splitk_ws_elems = 0, 0
+                    return args.tile_cfg, args.splitk
+                args.compute, args.w_split, args.w_split_ld, args.w_split_bstride = L.COMPUTE_F32, 0, 0, 0
         # (a batch that is not per sample -- the 16 transform positions of a Winograd convolution -- is part of the plan key)
         tuned = tuned_plan(args, args.M) if (nbatch <= 1 or not batch_is_samples) and args.M > 0 else None
         if tuned is not None and tuned[0] > 6:

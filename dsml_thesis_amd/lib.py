@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("LDMK_LIBRARY") or os.path.join(_HERE, "libldmk.so")
 A_ROWS, A_CONV3X3 = 0, 1
 TF_NONE, TF_AFFINE, TF_AFFINE_SILU, TF_LAYERNORM, TF_LAYERNORM_FOLDED = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GEGLU = 0, 1
-COMPUTE_F32, COMPUTE_BF16 = 0, 1
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
 POST_NONE, POST_GROUPNORM, POST_LAYERNORM = 0, 1, 2
 
 _fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
@@ -35,6 +35,7 @@ class IgemmArgs(C.Structure):
         ("ln_colsum", _fp),
         ("raw_slabs", C.c_int),
         ("skip_a0", _fp), ("skip_a1", _fp), ("skip_c0", C.c_int), ("skip_c1", C.c_int),
+        ("w_split", _fp), ("w_split_ld", C.c_int), ("w_split_bstride", C.c_longlong),
     ]
 
 
@@ -71,6 +72,7 @@ _SIGS = {
     "ldmk_igemm_force_config": (None, [C.c_int]),
     "ldmk_wfrag_elems": (C.c_longlong, [C.c_int, C.c_int]),
     "ldmk_pack_wfrag": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ldmk_pack_wsplit": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, _fp, C.c_int, _fp]),
     "ldmk_winograd_tiles": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "ldmk_winograd_input": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ldmk_winograd_output": (C.c_int, [_fp, _fp, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
@@ -87,6 +89,7 @@ _SIGS = {
     "ldmk_post": (C.c_int, [C.POINTER(PostArgs), _fp]),
     "ldmk_post_scratch_elems": (C.c_longlong, [C.POINTER(PostArgs)]),
     "ldmk_attn_self": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    "ldmk_attn_self_x3": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_self_small": (C.c_int, [_fp, C.c_int, C.c_longlong, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_cross": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_float, _fp]),

@@ -4,6 +4,8 @@ stream and never synchronises.  Activations are NHWC float32 CUDA tensors."""
 import ctypes as C
 import math
 
+import weakref
+
 import torch
 
 from . import lib as L
@@ -173,11 +175,56 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
         a.splitk_counters, a.splitk_counters_len = splitk_counters.data_ptr(), splitk_counters.numel()
     if splitk_ws is not None:
         a.splitk_ws, a.splitk_ws_elems = splitk_ws.data_ptr(), splitk_ws.numel()
+    if compute == L.COMPUTE_BF16X3 and not set_split(a):
+        raise ValueError("COMPUTE_BF16X3: no split images registered for this weight (ops.pack_wsplit) or b_trans set")
     return a
 
 
 def igemm(args):
     L.call("ldmk_igemm", C.byref(args), stream())
+
+
+# ---- LDMK_COMPUTE_BF16X3: the weights as three bf16 images of their exact split (include/ldmk.h) -------------------
+_SPLIT = {}          # data_ptr of a packed fp32 weight [K][N] (or a batch of them) -> (bf16 tensor, ld, batch stride in elements)
+
+
+def pack_wsplit(w, batch=1):
+    """w: [K][N] fp32 (or [batch][K][N]) on the GPU -> bf16 [batch][3][N][ld] (ldmk_pack_wsplit), registered under w's address
+    so that make_igemm_args(..., compute=COMPUTE_BF16X3) finds it."""
+    if batch > 1:
+        assert w.dim() == 3 and w.shape[0] == batch and w.is_contiguous()
+        K, N = w.shape[1], w.shape[2]
+    else:
+        assert w.dim() == 2 and w.is_contiguous()
+        K, N = w.shape
+    ld = (K + 7) // 8 * 8
+    out = torch.empty(batch, 3, N, ld, device=w.device, dtype=torch.bfloat16)
+    L.call("ldmk_pack_wsplit", _ptr(w), K, N, N, batch, K * N, _ptr(out), ld, stream())
+    _SPLIT[w.data_ptr()] = (out, ld, 3 * N * ld, weakref.ref(w), w._version)
+    return out
+
+
+def split_of(w_ptr):
+    """The registered split images of the weight at this address, or None (also when the weight tensor has since been freed
+    or written in place: its address / contents may no longer be what was split)."""
+    hit = _SPLIT.get(w_ptr)
+    if hit is None:
+        return None
+    src = hit[3]()
+    if src is None or src.data_ptr() != w_ptr or src._version != hit[4]:
+        del _SPLIT[w_ptr]
+        return None
+    return hit
+
+
+def set_split(a, w_ptr=None):
+    """Switch igemm args to the fp32-accurate bf16x3 arithmetic when the weight's split images exist; returns True if it did."""
+    hit = split_of(a.w if w_ptr is None else w_ptr)
+    if hit is None or a.b_trans:
+        return False
+    a.w_split, a.w_split_ld, a.w_split_bstride = hit[0].data_ptr(), hit[1], hit[2]
+    a.compute = L.COMPUTE_BF16X3
+    return True
 
 
 def conv3x3(x, wp, bias=None, x1=None, stride=1, pad_lo=1, upsample=False, coef=None, silu=True, batch_vec=None,
@@ -331,11 +378,12 @@ def bmm(a, b, b_trans, alpha=1.0, out=None):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def attn_self(qkv, n, tokens, heads, out=None):
+def attn_self(qkv, n, tokens, heads, out=None, x3=False):
+    """x3: both products in the fp32-accurate three-way bf16 split arithmetic (ldmk_attn_self_x3)."""
     C_ = heads * 32
     if out is None:
         out = torch.empty(n * tokens, C_, device=qkv.device, dtype=torch.float32)
-    L.call("ldmk_attn_self", _ptr(qkv), _ptr(out), n, tokens, heads, 32 ** -0.5, stream())
+    L.call("ldmk_attn_self_x3" if x3 else "ldmk_attn_self", _ptr(qkv), _ptr(out), n, tokens, heads, 32 ** -0.5, stream())
     return out
 
 

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
-from .engine import NetBuilder, Program
+from .engine import NetBuilder, Program, split_enabled as engine_split_enabled
 
 # diagnostic A/B switch: LayerNorm applied while the A operand is staged (round-1 form) instead of folded through the product
 _UNFOLDED = bool(os.environ.get("LDMK_LN_UNFOLDED"))
@@ -299,6 +299,16 @@ class UNetModel(nn.Module):
             wf = ops.pack_wfrag(P[k])
             if wf is not None:
                 P[k + "#f"] = wf
+        # bf16x3 images of the GEMM weights (LDMK_COMPUTE_BF16X3, include/ldmk.h): fp32-accurate products at the bf16 matrix
+        # rate; engine.Program.plan() uses them for the shapes dsml_thesis_amd/igemm_plans_x3.json lists
+        if engine_split_enabled():
+            for k in list(P):
+                tail = k.rsplit(".", 1)[-1]
+                if tail in ("pin", "pout", "qkv_ln", "o1", "ff1_ln", "ff2", "skip", "c1", "c2", "w"):
+                    if P[k].dim() == 2:
+                        P[k + "#s"] = ops.pack_wsplit(P[k])
+                elif tail in ("c1#wg", "c2#wg", "w#up"):
+                    P[k + "#s"] = ops.pack_wsplit(P[k], batch=P[k].shape[0])
         self._sd = sd
         self._packed = P
         self._pack_sig = self._signature()
@@ -391,7 +401,10 @@ class UNetModel(nn.Module):
                     qkv = lin(hcur, P[q + "qkv_ln"], P[q + "qkv_ln#b"], hw, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
                               ln_colsum=P[q + "qkv_ln#cs"], wf=P.get(q + "qkv_ln#f"))
                 att = pg.alloc(rows, C_)
-                pg.add("ldmk_attn_self", p_(qkv), p_(att), n, hw, m.heads, m.d_head ** -0.5)
+                # both attention products in the fp32-accurate bf16x3 arithmetic (24 bf16 MFMAs of 32 cycles per 32 keys
+                # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel
+                pg.add("ldmk_attn_self_x3" if engine_split_enabled() else "ldmk_attn_self", p_(qkv), p_(att), n, hw, m.heads,
+                       m.d_head ** -0.5)
                 nb_.release(qkv)
                 if L_ctx == 1:
                     # --- attn2 with a single context token: softmax over one key == 1, so the block adds

@@ -60,7 +60,15 @@ enum { LDMK_EPI_NONE = 0, LDMK_EPI_GEGLU = 1 };
 /* arithmetic of the product.  F32: v_mfma_f32_32x32x2_f32, bit-identical to an fp32 fmaf chain -- the sampling path and
  * every parity test.  BF16: operands rounded to bf16 (RNE) while staged, v_mfma_f32_32x32x16_bf16 with fp32 accumulation
  * and fp32 prologue / epilogue -- the mixed-precision training step (BASELINE configs[4]); HBM tensors stay fp32. */
-enum { LDMK_COMPUTE_F32 = 0, LDMK_COMPUTE_BF16 = 1 };
+enum { LDMK_COMPUTE_F32 = 0, LDMK_COMPUTE_BF16 = 1, LDMK_COMPUTE_BF16X3 = 2 };
+/* BF16X3 -- fp32-accurate products on the bf16 matrix cores (the f32 MFMA of gfx950 peaks at 157 TFLOP/s, the bf16 one at
+ * 2.5 PFLOP/s).  Every fp32 operand is written as the EXACT sum of three bf16 values
+ *     x = hi + mid + lo,   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)      (3 x 8 significand bits = 24)
+ * and the product is accumulated in fp32 from the six partial products that are not below fp32 resolution
+ *     a*b ~= hi*hi + hi*mid + mid*hi + hi*lo + mid*mid + lo*hi        (dropped: mid*lo, lo*mid, lo*lo <= 2^-25 |a*b|)
+ * with v_mfma_f32_32x32x16_bf16 (each bf16 x bf16 product is exact in fp32).  Six 32-cycle instructions per 16 k instead of
+ * eight 64-cycle ones: 2.67x the matrix rate of the F32 form at the same accuracy class (tests/test_split_gpu.py bounds both
+ * against float64).  Activations are split while they are staged; the weights come pre-split (args.w_split, ldmk_pack_wsplit). */
 
 typedef struct ldmk_igemm_args {
   int M, N, K;               /* K = 9*(c0+c1) for LDMK_A_CONV3X3 (weights packed by ldmk_pack_conv3x3), else c0+c1 */
@@ -103,7 +111,7 @@ typedef struct ldmk_igemm_args {
   long long splitk_ws_elems; /* capacity of splitk_ws in floats                                           */
   float* stats_out;          /* optional [M/32][N][3] GroupNorm partial records of the *output* (after the
                                 epilogue), one per 32-row tile and column; needs M%32==0, rows_per_sample%32==0 */
-  int compute;               /* LDMK_COMPUTE_*: F32 (default) or BF16 matrix-core arithmetic (tile_cfg 1..6 only)       */
+  int compute;               /* LDMK_COMPUTE_*: F32 (default), BF16 or BF16X3 matrix-core arithmetic (tile_cfg 1..6 only) */
   int* splitk_counters;      /* optional: >= ceil(M/64)*ceil(N/64)*batch ints, ZEROED once by the caller.  With it a split-K
                                 GEMM is ONE launch: each tile's last-arriving workgroup sums the slabs (fixed order: bitwise
                                 reproducible) and runs the epilogue; every launch leaves the counters zeroed again, so one
@@ -123,7 +131,15 @@ typedef struct ldmk_igemm_args {
   const float* skip_a1;      /*   of the (two-source) tensor skip_a0 | skip_a1 at the output pixel -- the ResBlock's 1x1      */
   int skip_c0, skip_c1;      /*   skip_connection as extra K of its second 3x3 convolution (openaimodel.py:241,275): one GEMM  */
                              /*   instead of two.  Weights: the packed conv weight with the [skip_c0+skip_c1][N] matrix appended. */
+  const void* w_split;       /* LDMK_COMPUTE_BF16X3 (b_trans = 0, tile_cfg 0..6): the weights as three bf16 images (hi, mid, lo)   */
+  int w_split_ld;            /*   [3][N][w_split_ld], K-contiguous rows (w_split_ld >= K, a multiple of 8), made by               */
+  long long w_split_bstride; /*   ldmk_pack_wsplit from `w`; batched GEMMs step w_split_bstride bf16 ELEMENTS per batch entry      */
 } ldmk_igemm_args;
+
+/* w[K][ldb] fp32 (row-major, as ldmk_igemm reads it with b_trans = 0; `batch` matrices w_bstride floats apart) -> the three
+ * bf16 images [batch][3][N][ld_out] of its exact three-way split, transposed so that every output column's K run is
+ * contiguous.  ld_out >= K, a multiple of 8; columns K..ld_out-1 are zero-filled. */
+int ldmk_pack_wsplit(const float* w, int K, int N, int ldb, int batch, long long w_bstride, void* out, int ld_out, void* stream);
 
 int ldmk_igemm(const ldmk_igemm_args* args, void* stream);
 /* Scratch (in floats) ldmk_igemm(args) needs in args->splitk_ws: batch * splitk * M * N for a split-K plan, 0 otherwise.
@@ -262,6 +278,10 @@ long long ldmk_post_scratch_elems(const ldmk_post_args* args);
  * ldmk_softmax_rows: in-place row softmax of x*scale; model.py:191-192 (VQGAN AttnBlock).
  */
 int ldmk_attn_self(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream);
+/* ldmk_attn_self_x3: the same product with both matrix products in the fp32-accurate three-way bf16 split arithmetic
+ *   (LDMK_COMPUTE_BF16X3 above: Q, K, V and the probabilities are exact sums of three bf16 values, six partial products each,
+ *   fp32 accumulation, fp32 softmax): the accuracy class of ldmk_attn_self at the bf16 matrix rate. */
+int ldmk_attn_self_x3(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream);
 /* ldmk_attn_self_small: the same product for SMALL problems (batch 1-2: the reference's talking-face mode runs batch 1,
  *   talking_face/progressive_sampling_difftalk.py:350).  One workgroup per 32-query tile of a (sample, head), the keys split
  *   over its 4 / 8 waves and streamed from global memory without LDS staging, partial (max, sum, O) merged in wave order

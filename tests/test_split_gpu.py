@@ -1,0 +1,144 @@
+"""GPU: LDMK_COMPUTE_BF16X3 -- fp32-accurate GEMMs on the bf16 matrix cores (include/ldmk.h).  Every fp32 operand is the exact
+sum of three bf16 values; six of the nine partial products are accumulated in fp32.  The bar, stated: the result is as close
+to the float64 product as the fp32 matrix-core form (LDMK_COMPUTE_F32) is -- the same accuracy class, not a reduced one."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rnd
+from test_ops_gpu import close, nchw, nhwc, ops  # noqa: F401  (the `ops` fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(y, ref):
+    """(max, rms) error against the float64 reference"""
+    d = y.detach().cpu().double() - ref
+    return d.abs().max().item(), d.pow(2).mean().sqrt().item()
+
+
+def _same_class(e32, e3, floor):
+    """The split arithmetic is in the accuracy class of the fp32 matrix-core form: its RMS error is within 1.5x (measured:
+    0.6-1.1x, tools/x3_probe.py) and its worst element -- a tail statistic of ~1e5 samples -- within 3x."""
+    assert e3[1] <= max(1.5 * e32[1], 0.3 * floor), (e32, e3)
+    assert e3[0] <= max(3.0 * e32[0], floor), (e32, e3)
+
+
+def test_pack_wsplit_is_an_exact_split(ops):
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(100, 72, generator=g) * torch.exp2(torch.randint(-20, 20, (100, 72), generator=g).float())
+    w[0, :8] = torch.tensor([0.0, 1.0, -1.0, 1.0 + 2.0 ** -23, 3.0e38, 1.17549435e-38 * 4096, 255.99998, -0.1])
+    wc = w.cuda().contiguous()
+    s = ops.pack_wsplit(wc)                                  # [1][3][N][ld]
+    assert s.shape == (1, 3, 72, 104) and s.dtype == torch.bfloat16
+    parts = s[0].double().cpu()                              # hi, mid, lo
+    back = (parts[0] + parts[1] + parts[2])[:, :100].t()
+    assert torch.equal(back, w.double()), "hi + mid + lo must reproduce every fp32 weight exactly"
+    assert torch.count_nonzero(s[0][:, :, 100:]).item() == 0
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 4, 5])
+@pytest.mark.parametrize("M,K,N,sk", [(300, 320, 160, 1), (256, 640, 1920, 1), (4096, 160, 480, 1), (1024, 2560, 640, 3),
+                                      (64, 1280, 1280, 4)])
+def test_split_linear_matches_float64_like_the_fp32_form(ops, M, K, N, sk, cfg):
+    from dsml_thesis_amd import lib as L
+    x, w, b = rnd(500, M, K), rnd(501, N, K) / np.sqrt(K), 0.1 * rnd(502, N)
+    res = rnd(503, M, N)
+    wp = ops.pack_linear(w.cuda())
+    ops.pack_wsplit(wp)
+    ws = torch.empty(8 * M * N, device="cuda")
+    ref = x.double() @ w.double().t() + b.double() + res.double()
+    ys = []
+    for compute in (L.COMPUTE_F32, L.COMPUTE_BF16X3):
+        out = torch.empty(M, N, device="cuda")
+        a = ops.make_igemm_args(M, N, K, x.cuda(), K, wp, out, N, M, bias=b.cuda(), residual=res.cuda(), tile_cfg=cfg, splitk=sk,
+                                splitk_ws=ws, compute=compute)
+        ops.igemm(a)
+        ys.append(out)
+    e32, e3 = _err(ys[0], ref), _err(ys[1], ref)
+    _same_class(e32, e3, 2e-6)
+    close(ys[1], ref.float(), 3e-6, 3e-6)
+
+
+@pytest.mark.parametrize("case", [(2, 160, 320, 16, 16, 1), (2, 64, 96, 9, 7, 1), (1, 160, 160, 16, 16, 2), (3, 640, 640, 8, 8, 1),
+                                  (2, 320, 160, 32, 32, 1)])
+def test_split_conv3x3_with_groupnorm_silu_prologue(ops, case):
+    from dsml_thesis_amd import lib as L
+    n, cin, cout, h, w, stride = case
+    x, wt, b = rnd(510, n, cin, h, w), rnd(511, cout, cin, 3, 3) / np.sqrt(9 * cin), 0.1 * rnd(512, cout)
+    scale, shift = 1.0 + 0.2 * rnd(513, n, cin), 0.3 * rnd(514, n, cin)
+    coef = torch.stack([scale, shift], 1).contiguous().cuda()
+    wp = ops.pack_conv3x3(wt.cuda())
+    ops.pack_wsplit(wp)
+    xa = F.silu(x.double() * scale.double()[:, :, None, None] + shift.double()[:, :, None, None])
+    ref = F.conv2d(xa, wt.double(), b.double(), stride=stride, padding=1)
+    y32 = ops.conv3x3(nhwc(x), wp, b.cuda(), stride=stride, coef=coef)
+    y3 = ops.conv3x3(nhwc(x), wp, b.cuda(), stride=stride, coef=coef, compute=L.COMPUTE_BF16X3)
+    e32, e3 = _err(nchw(y32), ref), _err(nchw(y3), ref)
+    _same_class(e32, e3, 3e-6)
+
+
+def test_split_geglu_with_folded_layernorm(ops):
+    from dsml_thesis_amd import lib as L
+    M, K, inner = 512, 320, 1280
+    x = rnd(520, M, K) + 0.5
+    w, b = rnd(521, 2 * inner, K) / np.sqrt(K), 0.1 * rnd(522, 2 * inner)
+    gamma, beta = 1.0 + 0.1 * rnd(523, K), 0.1 * rnd(524, K)
+    wp, bp = ops.pack_geglu(w.cuda(), b.cuda())
+    w2, cs, b2 = ops.fold_layernorm(wp, gamma.cuda(), beta.cuda(), bp)
+    ops.pack_wsplit(w2)
+    st = ops.ln_stats(x.cuda())
+    xn = F.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5)
+    hcat = xn @ w.double().t() + b.double()
+    ref = hcat[:, :inner] * F.gelu(hcat[:, inner:])
+    y32 = ops.linear(x.cuda(), w2, b2, row_stats=st, ln_colsum=cs, geglu=True)
+    y3 = ops.linear(x.cuda(), w2, b2, row_stats=st, ln_colsum=cs, geglu=True, compute=L.COMPUTE_BF16X3)
+    e32, e3 = _err(y32, ref), _err(y3, ref)
+    _same_class(e32, e3, 3e-6)
+
+
+def test_split_batched_gemm(ops):
+    """the Winograd form: 16 independent [M][K] x [K][N] products in one launch."""
+    from dsml_thesis_amd import lib as L
+    B, M, K, N = 16, 256, 320, 640
+    a = rnd(530, B, M, K)
+    w = rnd(531, B, K, N) / np.sqrt(K)
+    ac, wc = a.cuda().contiguous(), w.cuda().contiguous()
+    ops.pack_wsplit(wc, batch=B)
+    ref = torch.bmm(a.double(), w.double())
+    ws = torch.empty(4 * B * M * N, device="cuda")
+    outs = []
+    for compute in (L.COMPUTE_F32, L.COMPUTE_BF16X3):
+        out = torch.empty(B, M, N, device="cuda")
+        ar = ops.make_igemm_args(M, N, K, ac, K, wc, out, N, M, batch=B, a_bstride=M * K, w_bstride=K * N, out_bstride=M * N,
+                                 tile_cfg=5, splitk=2, splitk_ws=ws, compute=compute)
+        ops.igemm(ar)
+        outs.append(out)
+    e32, e3 = _err(outs[0], ref), _err(outs[1], ref)
+    _same_class(e32, e3, 2e-6)
+
+
+def test_split_rejects_what_it_cannot_run(ops):
+    from dsml_thesis_amd import lib as L
+    x, w = rnd(540, 64, 64).cuda(), rnd(541, 64, 64).cuda().contiguous()
+    out = torch.empty(64, 64, device="cuda")
+    with pytest.raises(ValueError):
+        ops.make_igemm_args(64, 64, 64, x, 64, w, out, 64, 64, compute=L.COMPUTE_BF16X3)        # no split images registered
+    ops.pack_wsplit(w)
+    a = ops.make_igemm_args(64, 64, 64, x, 64, w, out, 64, 64, compute=L.COMPUTE_BF16X3, tile_cfg=9)
+    assert L.load().ldmk_igemm_check(__import__("ctypes").byref(a)) != 0                         # row-GEMM tiles are fp32 only
+
+
+@pytest.mark.parametrize("n,tokens,heads", [(2, 1024, 5), (1, 4096, 5), (3, 256, 10), (2, 64, 20), (2, 100, 2), (1, 130, 1)])
+def test_split_attention_matches_float64_like_the_fp32_kernel(ops, n, tokens, heads):
+    C_ = heads * 32
+    qkv = (1.5 * rnd(550, n * tokens, 3 * C_)).cuda()
+    q, k, v = [t.reshape(n, tokens, heads, 32).permute(0, 2, 1, 3).double() for t in qkv.cpu().split(C_, dim=1)]
+    att = torch.softmax(q @ k.transpose(-1, -2) * 32 ** -0.5, -1) @ v
+    ref = att.permute(0, 2, 1, 3).reshape(n * tokens, C_)
+    y32 = ops.attn_self(qkv, n, tokens, heads)
+    y3 = ops.attn_self(qkv, n, tokens, heads, x3=True)
+    e32, e3 = _err(y32, ref), _err(y3, ref)
+    _same_class(e32, e3, 2e-6)
+    close(y3, ref.float(), 3e-6, 3e-6)

@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 ROWS_RETUNE = False
 SLAB_RETUNE = False
 FORCE = False
+X3_TABLE = None
 CANDS = {}
 CFG_WK = {1: 1, 2: 2, 3: 4, 4: 2, 5: 1, 6: 2}          # K slices of 32 staged per iteration
 EVEN_TN = {1, 2, 3}
@@ -103,7 +104,76 @@ def tune(kind, latent, batch, table):
     tune_program(pg, table)
 
 
+def tune_x3(pg, xtable):
+    """--x3: for every GEMM of the program whose weight has bf16x3 split images, the best LDMK_COMPUTE_BF16X3 plan against the
+    plan the program runs today (f32: LDS-tiled, row GEMM or slab GEMM, as recorded); shapes where the split arithmetic wins
+    by > 3 % go to the x3 table (dsml_thesis_amd/igemm_plans_x3.json), which engine.Program.plan() consults first."""
+    from dsml_thesis_amd import lib as L, ops
+    from dsml_thesis_amd.engine import plan_key
+    lib = pg.lib
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(16 * 1024 * 1024 * 16, device="cuda")
+    seen = set()
+    for fn, args, a, name in pg.calls:
+        if name != "ldmk_igemm":
+            continue
+        key = plan_key(a, a.M)
+        if key in seen or a.b_trans or a.raw_slabs or a.compute != L.COMPUTE_F32 or ops.split_of(a.w) is None:
+            continue
+        seen.add(key)
+        saved = (a.tile_cfg, a.splitk, a.splitk_ws, a.splitk_ws_elems, a.out, a.stats_out, a.residual, a.compute, a.w_split,
+                 a.w_split_ld, a.w_split_bstride)
+        saved_a = (a.a0, a.a1)
+        nb = max(1, a.batch)
+        samples = -(-a.M // a.rows_per_sample)
+        rows = samples * a.in_h * a.in_w if a.a_mode == 1 else a.M
+        span = (nb - 1) * a.a_bstride if nb > 1 else 0
+        sa0 = torch.randn(rows * a.c0 + span, device="cuda")
+        sa1 = torch.randn(rows * a.c1 + span, device="cuda") if a.c1 else None
+        a.a0 = sa0.data_ptr()
+        if sa1 is not None:
+            a.a1 = sa1.data_ptr()
+        touch = (sa0,) if sa1 is None else (sa0, sa1)
+        scratch = torch.empty(a.M * max(a.ldc, 1) + 16 + (nb - 1) * a.out_bstride, device="cuda")
+        a.out = scratch.data_ptr()
+        if a.residual == saved[4]:
+            a.residual = scratch.data_ptr()
+        a.stats_out = 0
+        if a.splitk > 1:
+            a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
+        base = time_call(lib, a, st, touch=touch)
+        best = None
+        ops.set_split(a)
+        nkc = a.K // 32
+        for cfg in (1, 2, 4, 5):
+            if a.epi == 1 and cfg not in EVEN_TN:
+                continue
+            iters = -(-nkc // CFG_WK[cfg])
+            for sk in SKS:
+                if sk > 1 and (a.epi == 1 or iters // sk < 1 or nb * sk * a.M * a.N > ws.numel()):
+                    continue
+                a.tile_cfg, a.splitk = cfg, sk
+                a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
+                t = time_call(lib, a, st, touch=touch)
+                if t is not None and (best is None or t < best[0]):
+                    best = (t, cfg, sk)
+        (a.tile_cfg, a.splitk, a.splitk_ws, a.splitk_ws_elems, a.out, a.stats_out, a.residual, a.compute, a.w_split, a.w_split_ld,
+         a.w_split_bstride) = saved
+        a.a0, a.a1 = saved_a
+        if base is None or best is None:
+            continue
+        win = best[0] < 0.97 * base
+        if win:
+            xtable[key] = [best[1], best[2]]
+        elif key in xtable:
+            del xtable[key]
+        print(f"{key:40s} f32 cfg={saved[0]} sk={saved[1]} {1e3 * base:8.1f} us | x3 cfg={best[1]} sk={best[2]} {1e3 * best[0]:8.1f} us"
+              f"  x{base / best[0]:.2f} {'-> x3' if win else ''}", flush=True)
+
+
 def tune_program(pg, table):
+    if X3_TABLE is not None:
+        return tune_x3(pg, X3_TABLE)
     from dsml_thesis_amd.engine import plan_key
     lib = pg.lib
     st = torch.cuda.current_stream().cuda_stream
@@ -215,7 +285,24 @@ if __name__ == "__main__":
     ap.add_argument("--slab", action="store_true", help="re-tune shapes already in the table against the slab-GEMM tiles "
                     "(tile_cfg 13..16, csrc/sgemm.hip): the small-batch cases")
     ap.add_argument("--force", action="store_true", help="re-sweep shapes that are already in the table (after a kernel change)")
+    ap.add_argument("--x3", action="store_true", help="sweep the bf16x3 arithmetic (LDMK_COMPUTE_BF16X3) against the plans on record; "
+                    "writes dsml_thesis_amd/igemm_plans_x3.json (or --x3-out)")
+    ap.add_argument("--x3-out", default=os.path.join(ROOT, "dsml_thesis_amd", "igemm_plans_x3.json"))
     a = ap.parse_args()
+    if a.x3:
+        # the programs must be built with their f32 plans (table on, x3 table off) but with the split images packed
+        os.environ["LDMK_X3_TABLE"] = "/nonexistent"
+        X3_TABLE = json.load(open(a.x3_out)) if os.path.exists(a.x3_out) and not a.fresh else {}
+        for c in a.case or ["64:16", "32:16"]:
+            parts = c.split(":")
+            kind = parts[0] if len(parts) == 3 else "unet"
+            lat, b = parts[-2:]
+            print(f"== x3 {kind} latent {lat} batch {b}", flush=True)
+            tune(kind, int(lat), int(b), None)
+            json.dump(X3_TABLE, open(a.x3_out, "w"), indent=0, sort_keys=True)
+            torch.cuda.empty_cache()
+        print(f"wrote {a.x3_out} ({len(X3_TABLE)} shapes)")
+        sys.exit(0)
     ROWS_RETUNE = a.rows or a.force
     SLAB_RETUNE = a.slab
     FORCE = a.force

@@ -30,7 +30,7 @@ def dump(latent, batch, path, graph=False):
             a = keep
             from dsml_thesis_amd.engine import plan_key
             calls.append(dict(name=name, M=a.M, N=a.N, K=a.K, conv=a.a_mode, tf=a.a_tf, epi=a.epi, cfg=a.tile_cfg,
-                              sk=a.splitk, key=plan_key(a, a.M), batch=max(1, a.batch), raw=int(a.raw_slabs)))
+                              sk=a.splitk, key=plan_key(a, a.M), batch=max(1, a.batch), raw=int(a.raw_slabs), compute=int(a.compute)))
         else:
             calls.append(dict(name=name))
     side = [c[3] for c in getattr(run.pg, "side_calls", None) or []]       # launches on the forked stream (parallel branch)
@@ -48,13 +48,14 @@ def dump(latent, batch, path, graph=False):
 
 KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "rgemm_kernel", "sgemm_kernel"), "ldmk_post": ("post_",),
              "ldmk_attn_self_small": ("attn_small",), "ldmk_conv3x3_out_small": ("conv3x3_out_small",), "ldmk_gn_finalize": ("gn_finalize",), "ldmk_gn_apply": ("gn_apply",),
-             "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_attn_self": ("attn_self",),
+             "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_attn_self": ("attn_self",), "ldmk_attn_self_x3": ("attn_x3",),
              "ldmk_attn_cross": ("attn_cross",), "ldmk_dense_small": ("dense_small",),
              "ldmk_timestep_embedding": ("timestep_embedding",), "ldmk_conv3x3_in": ("conv3x3_in",),
              "ldmk_conv3x3_out": ("conv3x3_out",), "ldmk_winograd_input": ("wino_input",),
              "ldmk_winograd_output": ("wino_output",), "ldmk_upconv_gather": ("upconv_gather",),
              "ldmk_upconv_scatter": ("upconv_scatter",)}
 PEAK_F32_MFMA = 157.3
+PEAK_BF16_MFMA = 2516.6
 
 
 def join(d):
@@ -115,6 +116,8 @@ def join(d):
             key = f"igemm M={c['M']:6d} N={c['N']:5d} K={c['K']:6d} conv={c['conv']} tf={c['tf']} epi={c['epi']} cfg={c['cfg']} sk={c.get('sk', 1)}"
             if c.get("batch", 1) > 1:
                 key += f" x{c['batch']} ({'Winograd' if c['batch'] == 16 else 'upsample phases'})"
+            if c.get("compute", 0) == 2:
+                key += " bf16x3"
         else:
             key = c["name"]
         a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
@@ -130,12 +133,15 @@ def join(d):
     fam_t = fam_f = 0.0
     for key, (n, d_, fl, mn) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         tfs = fl / (d_ * 1e-6) / 1e12 if fl else 0.0
-        assert tfs <= PEAK_F32_MFMA, f"{key}: {tfs:.1f} TFLOP/s exceeds the f32 matrix peak -- the join is wrong"
+        # bf16x3 rows: six bf16 MFMAs per fp32-equivalent product -> ceiling = bf16 peak / 6
+        peak = PEAK_BF16_MFMA / 6.0 if key.endswith("bf16x3") else PEAK_F32_MFMA
+        assert tfs <= peak, f"{key}: {tfs:.1f} TFLOP/s exceeds the matrix peak of its arithmetic ({peak:.1f}) -- the join is wrong"
         fam_t += d_ if fl else 0.0
         fam_f += fl
         print(f"{key:75s} {n:3d} {d_:10.1f} {100 * d_ / tot:6.2f} {tfs:8.1f}  main {mn / n:6.1f} us/call" if fl else f"{key:75s} {n:3d} {d_:10.1f} {100 * d_ / tot:6.2f}")
-    print(f"GEMM family (LDS-tiled igemm + row GEMM): {fam_f * 1e-9:.1f} GFLOP executed in {fam_t / 1e3:.3f} ms = "
-          f"{fam_f / (fam_t * 1e-6) / 1e12:.1f} TFLOP/s = {fam_f / (fam_t * 1e-6) / 1e12 / PEAK_F32_MFMA:.3f} of the f32 matrix peak")
+    print(f"GEMM family (LDS-tiled igemm + row GEMM): {fam_f * 1e-9:.1f} GFLOP (fp32-equivalent 2MNK) in {fam_t / 1e3:.3f} ms = "
+          f"{fam_f / (fam_t * 1e-6) / 1e12:.1f} TFLOP/s = {fam_f / (fam_t * 1e-6) / 1e12 / PEAK_F32_MFMA:.3f} of the f32 matrix peak "
+          f"(rows marked bf16x3 execute 6 bf16 MFMA FLOPs per counted FLOP: their ceiling is {PEAK_BF16_MFMA / 6:.1f})")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,121 @@
+"""Diagnostic: LDMK_COMPUTE_F32 vs LDMK_COMPUTE_BF16X3 on representative GEMM shapes of the 64x64 / 32x32 B=16 step, timed as
+replays of a hipGraph holding 10 launches.   python tools/x3_probe.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from dsml_thesis_amd import lib as L, ops  # noqa: E402
+from dsml_thesis_amd.engine import GraphedProgram  # noqa: E402
+
+# (M, N, K, conv(h,w) or None, batch)
+SHAPES = [
+    (65536, 160, 1440, (64, 64), 1), (16384, 320, 2880, (32, 32), 1), (65536, 1280, 160, None, 1), (16384, 2560, 320, None, 1),
+    (65536, 160, 640, None, 1), (16384, 320, 1280, None, 1), (4096, 640, 2560, None, 1), (65536, 160, 160, None, 1),
+    (16384, 320, 320, None, 1), (4096, 640, 640, None, 1), (4096, 320, 320, None, 16), (1024, 640, 640, None, 16),
+    (1024, 640, 640, None, 1), (4096, 320, 320, None, 1), (16384, 160, 160, None, 1), (16384, 160, 1440, (32, 32), 1),
+]
+
+
+def time_graph(fn, reps=5):
+    g = GraphedProgram(fn)
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps / 10)
+    return best
+
+
+def accuracy():
+    """max |y - float64 product| of the two arithmetics, operands N(0,1) (plus a mean) x N(0,1)/sqrt(K)"""
+    for M, K, N, mean in [(512, 160, 160, 0.0), (512, 640, 640, 0.0), (512, 2560, 640, 0.0), (512, 5760, 640, 0.0),
+                          (512, 11520, 1280, 0.0), (512, 640, 640, 0.5), (512, 640, 640, 3.0), (512, 2560, 640, 3.0)]:
+        g = torch.Generator().manual_seed(2)
+        x = (torch.randn(M, K, generator=g) + mean).cuda()
+        w = (torch.randn(K, N, generator=g) / np.sqrt(K)).cuda().contiguous()
+        ops.pack_wsplit(w)
+        ref = x.double() @ w.double()
+        errs = []
+        for compute in (L.COMPUTE_F32, L.COMPUTE_BF16X3):
+            out = torch.empty(M, N, device="cuda")
+            a = ops.make_igemm_args(M, N, K, x, K, w, out, N, M, tile_cfg=5, splitk=1, compute=compute)
+            ops.igemm(a)
+            errs.append((out.double() - ref).abs().max().item())
+        t32 = (x @ w).double()
+        print(f"accuracy M={M} K={K:5d} N={N:4d} mean={mean}: |ref|max {ref.abs().max().item():.2f}  f32 MFMA {errs[0]:.2e}  "
+              f"bf16x3 {errs[1]:.2e}  torch fp32 matmul {(t32 - ref).abs().max().item():.2e}", flush=True)
+
+
+def main():
+    accuracy()
+    lib = L.load()
+    import ctypes as C
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(256 * 1024 * 1024, device="cuda")
+    for M, N, K, conv, batch in SHAPES:
+        g = torch.Generator().manual_seed(1)
+        if conv:
+            h, w_ = conv
+            cin = K // 9
+            n = M // (h * w_)
+            x = torch.randn(n, h, w_, cin, generator=g).cuda()
+            cv = (h, w_, h, w_, 1, 1, 0)
+            c0 = cin
+        else:
+            x = torch.randn(batch, M, K, generator=g).cuda()
+            cv, c0 = None, K
+        w = (torch.randn(batch, K, N, generator=g) / np.sqrt(K)).cuda().contiguous()
+        wv = w if batch > 1 else w[0]
+        ops.pack_wsplit(wv, batch=batch)
+        out = torch.empty(batch, M, N, device="cuda")
+        ref = None
+        res = {}
+        for compute in (L.COMPUTE_F32, L.COMPUTE_BF16X3):
+            best = None
+            for cfg in (1, 2, 4, 5):
+                for sk in (1, 2, 3, 4, 6):
+                    if batch * sk * M * N > ws.numel():
+                        continue
+                    a = ops.make_igemm_args(M, N, K, x, c0, wv, out, N, (conv[0] * conv[1]) if conv else M, conv=cv, batch=batch,
+                                            a_bstride=M * K, w_bstride=K * N, out_bstride=M * N, tile_cfg=cfg, splitk=sk,
+                                            splitk_ws=ws, compute=compute)
+                    if lib.ldmk_igemm_check(C.byref(a)) != 0:
+                        continue
+
+                    def fn(a=a):
+                        for _ in range(10):
+                            lib.ldmk_igemm(C.byref(a), torch.cuda.current_stream().cuda_stream)
+                    t = time_graph(fn)
+                    if best is None or t < best[0]:
+                        best = (t, cfg, sk)
+            res[compute] = best
+            a = ops.make_igemm_args(M, N, K, x, c0, wv, out, N, (conv[0] * conv[1]) if conv else M, conv=cv, batch=batch,
+                                    a_bstride=M * K, w_bstride=K * N, out_bstride=M * N, tile_cfg=best[1], splitk=best[2],
+                                    splitk_ws=ws, compute=compute)
+            ops.igemm(a)
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = out.clone()
+            else:
+                diff = (out - ref).abs().max().item()
+        fl = 2.0 * M * N * K * batch
+        t0, t1 = res[L.COMPUTE_F32], res[L.COMPUTE_BF16X3]
+        print(f"M={M:6d} N={N:5d} K={K:5d} conv={'y' if conv else 'n'} x{batch:2d}:  f32 cfg={t0[1]} sk={t0[2]} {t0[0]:8.1f} us "
+              f"{fl / t0[0] * 1e-6:6.1f} TF | x3 cfg={t1[1]} sk={t1[2]} {t1[0]:8.1f} us {fl / t1[0] * 1e-6:6.1f} TF-equivalent | "
+              f"x{t0[0] / t1[0]:.2f}  max|x3 - f32| = {diff:.2e}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
