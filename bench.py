@@ -125,14 +125,19 @@ class StepRunner:
             if best is None or tot < best:
                 best = tot
                 self.winograd_transform_ms = sum(a.elapsed_time(b) for a, b in tevs)
+                # the same launches by arithmetic: LDMK_COMPUTE_BF16X3 (six bf16 MFMAs per fp32-accurate product) vs f32 MFMA
+                x3 = [c[2].compute == 2 for c in pg.calls if c[3] == "ldmk_igemm"]
+                self.x3_ms = sum(a.elapsed_time(b) for (a, b), f in zip(evs, x3) if f)
+                self.x3_launches = sum(x3)
         return best, n_ig
 
 
-def executed_gemm_flops(pg):
-    """FLOPs the GEMM launches of one step actually execute: sum of 2 M N K (x batch) over the launch program."""
+def executed_gemm_flops(pg, compute=None):
+    """fp32-equivalent FLOPs of the GEMM launches of one step: sum of 2 M N K (x batch) over the launch program (compute:
+    only the launches of that arithmetic).  A bf16x3 launch issues SIX bf16 MFMA FLOPs per FLOP counted here."""
     fl = 0.0
     for _, _, a, name in pg.calls:
-        if name == "ldmk_igemm":
+        if name == "ldmk_igemm" and (compute is None or a.compute == compute):
             fl += 2.0 * a.M * a.N * a.K * max(1, a.batch)
     return fl
 
@@ -487,6 +492,12 @@ def main():
         "value": round(value, 2), "unit": "sample-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        # every tensor, accumulation, norm and softmax is fp32; with LDMK_SPLIT_BF16 on (default) the large GEMMs and the self
+        # attention form their fp32 products from exact three-way bf16 splits on the bf16 matrix cores (include/ldmk.h,
+        # LDMK_COMPUTE_BF16X3): same accuracy class as the f32 MFMA form (tests/test_split_gpu.py), same parity bounds
+        "arithmetic": ("fp32 storage/accumulate; matrix products: bf16x3 exact split (6 bf16 MFMAs per product) where the x3 plan "
+                       "table lists the shape, f32 MFMA elsewhere") if os.environ.get("LDMK_SPLIT_BF16", "1") != "0" else
+                      "fp32 throughout (f32 MFMA)",
         "config": {"workload": f"face_reenactment emotion-conditioned LDM (AffectNet config), DDIM-200 schedule, "
                                f"{a.batch} samples/GPU, {a.latent}x{a.latent}x{run.x_T.shape[1]} latent, CFG off, "
                                f"eta 0, random-init weights", "batch_per_gpu": a.batch, "global_batch": a.batch * world,
@@ -514,6 +525,19 @@ def main():
                     tnote = (f"bytes per step over the GEMM family, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE passes of this "
                              f"command (profiles/{tname}); L2<->fabric, Infinity-Cache hits included")
                     break
+        t_x3, n_x3 = getattr(run, "x3_ms", 0.0), getattr(run, "x3_launches", 0)
+        fl_x3 = executed_gemm_flops(run.pg, 2) * 1e-12
+        split = None
+        if n_x3 and t_x3 > 0.5 * t_ig:
+            # the dominant kernel is the bf16x3 igemm: price IT against the bf16 matrix peak on the bf16 MFMA FLOPs it issues
+            # (6 per fp32-equivalent FLOP); the f32-MFMA launches that remain are reported beside it against their own peak
+            ach3 = 6.0 * fl_x3 / (t_x3 * 1e-3)
+            t_f, fl_f = t_ig - t_x3, fl_exec - fl_x3
+            split = {"bf16x3": {"launches": n_x3, "ms_per_step": round(t_x3, 4), "fp32_equivalent_tflops": round(fl_x3 / (t_x3 * 1e-3), 2),
+                                "bf16_mfma_tflops_issued": round(ach3, 2), "peak": PEAK_BF16_MFMA, "frac": round(ach3 / PEAK_BF16_MFMA, 4)},
+                     "f32_mfma": {"launches": n_ig - n_x3, "ms_per_step": round(t_f, 4), "tflops": round(fl_f / (t_f * 1e-3), 2) if t_f > 0 else None,
+                                  "peak": PEAK_F32_MFMA, "frac": round(fl_f / (t_f * 1e-3) / PEAK_F32_MFMA, 4) if t_f > 0 else None},
+                     "family_fp32_equivalent_tflops": round(ach, 2)}
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": traffic, "traffic_note": tnote,
                            "kernel": "ldmk::igemm_kernel<...> + ldmk::rgemm_kernel<...> (every Conv2d / Linear launch of the step)",
@@ -532,6 +556,13 @@ def main():
                            "reference_gflop_per_sample_step": GFLOP_IGEMM[a.latent],     # a count, no rate is formed on it
                            "launches_per_step": n_ig, "avg_launch_us": round(1e3 * t_ig / n_ig, 2),
                            "sum_launch_ms_per_step": round(t_ig, 4)}
+        if split is not None:
+            r = out["roofline"]
+            r["achieved"], r["peak"], r["frac"] = split["bf16x3"]["bf16_mfma_tflops_issued"], PEAK_BF16_MFMA, split["bf16x3"]["frac"]
+            r["kernel"] = ("ldmk::igemm_kernel<..., BF = 3> (LDMK_COMPUTE_BF16X3: fp32-accurate products from six bf16 MFMAs, "
+                           "include/ldmk.h) -- the launches that hold most of the GEMM time; `achieved` counts the bf16 MFMA FLOPs they "
+                           "issue (6 x 2MNK) against the dense bf16 matrix peak")
+            r["by_arithmetic"] = split
     del run
     torch.cuda.empty_cache()
     if not a.no_secondary and world == 1:

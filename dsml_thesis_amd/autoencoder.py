@@ -221,6 +221,17 @@ class VQModelInterface(nn.Module):
                     P[k] = v.reshape(v.shape[0], v.shape[1]).contiguous()      # narrow NCHW 1x1: [cout][cin]
                 else:
                     P[k] = ops.pack_linear(v)
+        # bf16x3 images of the GEMM weights (LDMK_COMPUTE_BF16X3): used for the shapes igemm_plans_x3.json lists
+        from .engine import split_enabled
+        if split_enabled():
+            for k in list(P):
+                w = P[k]
+                if k.startswith(("quant_conv", "post_quant_conv")) or not k.split("#")[0].endswith(".weight"):
+                    continue
+                if k.endswith(("#wg", "#up")):
+                    P[k + "#s"] = ops.pack_wsplit(w, batch=w.shape[0])
+                elif w.dim() == 2 and w.shape[0] % 32 == 0 and w.shape[1] % 4 == 0 and w.shape[1] > 4:
+                    P[k + "#s"] = ops.pack_wsplit(w)
         self._sd, self._packed, self._pack_sig, self._programs = sd, P, self._signature(), {}
 
     def _ensure(self):

@@ -132,6 +132,44 @@ def test_unet_winograd_route_against_the_reference_fixtures(monkeypatch):
     close(eps, g["ns_eps"], 3e-5, 3e-5)
 
 
+def test_unet_split_arithmetic_routes_against_the_reference_fixtures(monkeypatch):
+    """The batched program runs its large GEMMs and its self attention in the fp32-accurate bf16x3 arithmetic (the shapes
+    igemm_plans_x3.json lists).  (a) that route is what the golden tests above exercised; (b) with EVERY eligible GEMM forced
+    into it (Winograd planes, upsample phases, GEGLU, LayerNorm-folded, GroupNorm prologues) the same fixtures hold with the
+    same bound; (c) LDMK_SPLIT_BF16=0 gives the f32 matrix-core program, and the two agree far inside the bound."""
+    from dsml_thesis_amd import engine, lib as L
+    g = golden("g4_unet_fr.npz")
+    x, t, ctx = rnd(41, 2, 3, 32, 32), torch.tensor([3, 981]), rnd(42, 2, 1, 512)
+
+    def run(policy=16):
+        m, _ = make_unet(W.FR_UNET)
+        m.policy_batch = policy
+        eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
+        pg = m.program(2, 32, 32, 1, 0)
+        n3 = sum(1 for c in pg.calls if c[3] == "ldmk_igemm" and c[2].compute == L.COMPUTE_BF16X3)
+        ng = sum(1 for c in pg.calls if c[3] == "ldmk_igemm")
+        return eps, n3, ng, [c[3] for c in pg.calls]
+
+    eps_a, n3, ng, names = run()
+    assert n3 >= 40 and "ldmk_attn_self_x3" in names and "ldmk_attn_self" not in names, (n3, ng)
+    close(eps_a, g["fr_eps"], 3e-5, 3e-5)
+    # (b) everything eligible
+    monkeypatch.setattr(engine, "x3_plan", lambda a, m: (1, 1) if a.epi == L.EPI_GEGLU else (5, 1))
+    eps_b, n3b, ngb, _ = run()
+    assert n3b > n3 and n3b >= ngb - 4, (n3b, ngb)
+    close(eps_b, g["fr_eps"], 3e-5, 3e-5)
+    monkeypatch.undo()
+    # (c) the f32 matrix-core program
+    monkeypatch.setenv("LDMK_SPLIT_BF16", "0")
+    monkeypatch.setattr(engine, "_X3_TABLE", None)
+    eps_c, n3c, _, names_c = run()
+    assert n3c == 0 and "ldmk_attn_self" in names_c and "ldmk_attn_self_x3" not in names_c
+    close(eps_c, g["fr_eps"], 3e-5, 3e-5)
+    assert (eps_a - eps_c).abs().max().item() < 1.5e-5
+    monkeypatch.undo()
+    engine._X3_TABLE = None
+
+
 def test_unet_multi_token_context_vs_oracle():
     # L_ctx = 3 exercises the general cross-attention kernel (the shipped configs use L_ctx = 1)
     m, sd = make_unet(W.FR_UNET)
