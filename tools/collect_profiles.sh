@@ -7,6 +7,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03p
 rm -rf $O && mkdir -p $O
 python3 $R/bench.py > $O/r03_bench_default.json 2> $O/bench_default.err
+# the same command with every product on the f32 matrix cores (the round-2 arithmetic), for the A/B on one box
+LDMK_SPLIT_BF16=0 python3 $R/bench.py --no-cpu-baseline > $O/r03_bench_default_f32_mfma.json 2>> $O/bench_default.err
 B="python3 $R/bench.py --no-secondary --no-cpu-baseline --no-clip"
 for lat in 64 32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks$lat -- $B --latent $lat > $O/r03_bench${lat}_under_rocprof.json 2> $O/ks$lat.log

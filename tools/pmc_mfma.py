@@ -11,8 +11,10 @@ import glob
 import os
 import sys
 
-FAM = (("igemm_kernel", "igemm (LDS-tiled, all tiles)"), ("rgemm_kernel", "row GEMM (all wave tiles)"), ("attn_self", "attention forward"), ("wgrad_kernel", "wgrad"),
-       ("attn_bwd", "attention backward"))
+# (first match wins: the bf16x3 instantiations of igemm_kernel carry BF = 3 as their 9th template argument)
+FAM = (("false, 3, true>", "igemm bf16x3 (six bf16 MFMAs per product)"), ("igemm_kernel", "igemm f32 MFMA (LDS-tiled, all tiles)"),
+       ("rgemm_kernel", "row GEMM (all wave tiles)"), ("sgemm_kernel", "slab GEMM"), ("attn_x3", "attention forward, bf16x3"),
+       ("attn_self", "attention forward, f32 MFMA"), ("wgrad_kernel", "wgrad"), ("attn_bwd", "attention backward"))
 
 
 def main(d):
@@ -29,9 +31,9 @@ def main(d):
         a[0] += c["SQ_VALU_MFMA_BUSY_CYCLES"]
         a[1] += c["GRBM_GUI_ACTIVE"]
         a[2] += 1
-    print(f"{'kernel family':28s} {'dispatches':>10s} {'MFMA busy cycles':>18s} {'GPU active cycles':>18s} {'MFMA pipe busy':>15s}")
+    print(f"{'kernel family':44s} {'dispatches':>10s} {'MFMA busy cycles':>18s} {'GPU active cycles':>18s} {'MFMA pipe busy':>15s}")
     for fam, (busy, act, n) in acc.items():
-        print(f"{fam:28s} {n:10d} {busy:18.4g} {act:18.4g} {100.0 * busy / (act / 8.0 * 1024.0):14.1f}%")
+        print(f"{fam:44s} {n:10d} {busy:18.4g} {act:18.4g} {100.0 * busy / (act / 8.0 * 1024.0):14.1f}%")
 
 
 if __name__ == "__main__":
