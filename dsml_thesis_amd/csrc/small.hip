@@ -703,13 +703,12 @@ extern "C" int ldmk_dense_small(const float* x, int ldx, const float* w, const f
   LDMK_REQUIRE(ldx >= K && ldo >= N, "ldmk_dense_small: leading dims");
   using namespace ldmk;
   // 16-byte weight loads whenever the layout allows (every UNet / encoder Linear does)
-  if (N % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0)) {
-    if (rows <= 4)
-      hipLaunchKernelGGL(dense_small4_kernel<4>, dim3((N + 63) / 64, 1), dim3(64 * DS_NW), 0, (hipStream_t)stream, x, ldx, w, bias, out,
-                         ldo, rows, K, N, silu_in);
-    else
-      hipLaunchKernelGGL(dense_small4_kernel<16>, dim3((N + 63) / 64, (rows + 15) / 16), dim3(64 * DS_NW), 0, (hipStream_t)stream, x, ldx,
-                         w, bias, out, ldo, rows, K, N, silu_in);
+  // (up to 4 batch rows: the batch-1/2 route, 13.7 -> 6.9 us per call.  With 16 rows per workgroup the 64 accumulators per lane
+  //  and their cross-group sums made it SLOWER than the scalar form, 33 vs 20 us per call at batch 16 -- measured, not shipped.)
+  if (rows <= 4 && N % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
+      (!bias || ((uintptr_t)bias & 15) == 0)) {
+    hipLaunchKernelGGL(dense_small4_kernel<4>, dim3((N + 63) / 64, 1), dim3(64 * DS_NW), 0, (hipStream_t)stream, x, ldx, w, bias, out,
+                       ldo, rows, K, N, silu_in);
     return check_launch("ldmk_dense_small");
   }
   dim3 grid((N + 63) / 64, (rows + DS_ROWS - 1) / DS_ROWS);
