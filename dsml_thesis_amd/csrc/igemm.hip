@@ -1093,6 +1093,10 @@ constexpr int kNumRCfg = 6;
 const char* sgemm_unsupported(const ldmk_igemm_args& a, int scfg, int splitk);
 int sgemm_dispatch(const ldmk_igemm_args& a, int scfg, int splitk, float* ws, hipStream_t st);
 constexpr int kNumSCfg = 8;
+// the warp-specialised bf16x3 tiles (igemm_ws.hip): tile_cfg kNumCfg+kNumRCfg+kNumSCfg+1 .. +2 (256x160, 256x128)
+const char* igemm_ws_unsupported(const ldmk_igemm_args& a, int wcfg, int splitk);
+int igemm_ws_dispatch(const ldmk_igemm_args& a, int wcfg, int splitk, float* ws, hipStream_t st);
+constexpr int kNumWCfg = 2;
 
 }  // namespace ldmk
 
@@ -1128,6 +1132,8 @@ extern "C" long long ldmk_igemm_workspace_elems(const ldmk_igemm_args* args) {
     plan(a, &c2, &sk, 1LL << 50);          // what the planner would use with unlimited scratch
     if (cfg == 0) cfg = c2;
   }
+  if (cfg > kNumCfg + kNumRCfg + kNumSCfg)                                  // warp-specialised bf16x3 tiles: split like the LDS-tiled ones
+    return sk <= 1 || a.epi == LDMK_EPI_GEGLU ? 0 : (long long)(a.batch > 1 ? a.batch : 1) * sk * (long long)a.M * a.N;
   if (cfg > kNumCfg + kNumRCfg) {                                           // slab GEMM: GEGLU may split when the consumer reduces
     if (sk <= 1 || (a.epi == LDMK_EPI_GEGLU && !a.raw_slabs)) return 0;
     return (long long)sk * (long long)a.M * a.N;
@@ -1179,8 +1185,8 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   if (a.stats_out)
     LDMK_REQUIRE(a.M % 32 == 0 && a.rows_per_sample % 32 == 0 && a.epi == LDMK_EPI_NONE && a.batch <= 1,
                  "ldmk_igemm: stats_out needs M%%32==0, rows_per_sample%%32==0, no GEGLU, no batching");
-  LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg + kNumRCfg + kNumSCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]", a.tile_cfg,
-               kNumCfg + kNumRCfg + kNumSCfg);
+  LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg + kNumRCfg + kNumSCfg + kNumWCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]", a.tile_cfg,
+               kNumCfg + kNumRCfg + kNumSCfg + kNumWCfg);
   LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 64, "ldmk_igemm: splitk=%d outside [0,64]", a.splitk);
   LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.compute == LDMK_COMPUTE_BF16 || a.compute == LDMK_COMPUTE_BF16X3, "ldmk_igemm: compute=%d", a.compute);
   if (a.compute == LDMK_COMPUTE_BF16X3) {
@@ -1190,13 +1196,30 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
     LDMK_REQUIRE(igemm_fast_gather_ok(a), "ldmk_igemm: LDMK_COMPUTE_BF16X3 needs the fast gather (no zero-insertion, two-source "
                  "upsampling or operands beyond 4 GB)");
   }
-  LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.tile_cfg <= kNumCfg, "ldmk_igemm: the row / slab GEMM tiles are fp32 only");
+  LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.tile_cfg <= kNumCfg || a.tile_cfg > kNumCfg + kNumRCfg + kNumSCfg,
+               "ldmk_igemm: the row / slab GEMM tiles are fp32 only");
   if (a.alpha == 0.f) a.alpha = 1.f;
   int cfg = 0, sk = 1;
   plan(a, &cfg, &sk, a.splitk_ws ? a.splitk_ws_elems : 0);
   if (a.tile_cfg > 0) cfg = a.tile_cfg;
   if (g_force_cfg > 0 && (g_force_cfg <= kNumCfg || !rgemm_unsupported(a, g_force_cfg - kNumCfg - 1))) cfg = g_force_cfg;
   LDMK_REQUIRE(!a.skip_a0 || cfg > kNumCfg + kNumRCfg, "ldmk_igemm: the fused skip connection runs on the slab GEMM only (tile_cfg 13..20)");
+  if (cfg > kNumCfg + kNumRCfg + kNumSCfg) {      // warp-specialised bf16x3 tile: producer / consumer waves, split-K over workgroups
+    const int wcfg = cfg - kNumCfg - kNumRCfg - kNumSCfg - 1;
+    int wsk = a.splitk > 0 ? a.splitk : 1;
+    const char* why = igemm_ws_unsupported(a, wcfg, wsk);
+    LDMK_REQUIRE(why == nullptr, "ldmk_igemm: tile_cfg=%d splitk=%d (warp-specialised bf16x3 tile) cannot run this problem: %s", cfg, wsk,
+                 why ? why : "");
+    LDMK_REQUIRE(!a.raw_slabs || wsk >= 2, "ldmk_igemm: raw_slabs needs a split-K plan");
+    if (wsk > 1) {
+      const long long b = a.batch > 1 ? a.batch : 1;
+      LDMK_REQUIRE_MEM(a.splitk_ws && b * wsk * (long long)a.M * a.N <= a.splitk_ws_elems,
+                       "ldmk_igemm: splitk=%d needs a workspace of %lld floats (ldmk_igemm_workspace_elems), %lld given", wsk,
+                       b * wsk * (long long)a.M * a.N, a.splitk_ws ? a.splitk_ws_elems : 0LL);
+    }
+    if (!launch) return LDMK_OK;
+    return igemm_ws_dispatch(a, wcfg, wsk, a.splitk_ws, (hipStream_t)stream);
+  }
   if (cfg > kNumCfg + kNumRCfg) {      // slab GEMM: wave-autonomous, K split over the waves of a workgroup and over workgroups
     const int scfg = cfg - kNumCfg - kNumRCfg - 1;
     int ssk = a.splitk > 0 ? a.splitk : 1;

@@ -142,3 +142,105 @@ def test_split_attention_matches_float64_like_the_fp32_kernel(ops, n, tokens, he
     e32, e3 = _err(y32, ref), _err(y3, ref)
     _same_class(e32, e3, 2e-6)
     close(y3, ref.float(), 3e-6, 3e-6)
+
+
+# ---- the warp-specialised tiles (csrc/igemm_ws.hip, tile_cfg 21 = 256x160, 22 = 256x128): producer / consumer waves, two
+# 16-deep LDS stages.  Every accumulator sees the same sequence of matrix instructions as in igemm_kernel<BF = 3> with a
+# 32-deep slice per iteration (tile_cfg 5 / 1), so the results are BITWISE equal to those tiles at the same split-K.
+@pytest.mark.parametrize("M,K,N,sk,ws_cfg,ref_cfg", [(300, 320, 160, 1, 21, 5), (4096, 160, 480, 1, 21, 5), (1024, 2560, 640, 4, 21, 5),
+                                                     (520, 640, 1920, 1, 22, 1), (64, 1280, 1280, 5, 22, 1), (8192, 160, 160, 1, 21, 5)])
+def test_warp_specialised_tiles_are_bitwise_the_lds_tiled_split_form(ops, M, K, N, sk, ws_cfg, ref_cfg):
+    from dsml_thesis_amd import lib as L
+    x, w, b = rnd(600, M, K), rnd(601, N, K) / np.sqrt(K), 0.1 * rnd(602, N)
+    res = rnd(603, M, N)
+    wp = ops.pack_linear(w.cuda())
+    ops.pack_wsplit(wp)
+    ws = torch.empty(8 * M * N, device="cuda")
+    rows = 64 if M % 64 == 0 else M
+    vec = rnd(604, -(-M // rows), N).cuda()
+    outs = []
+    for cfg in (ref_cfg, ws_cfg):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        a = ops.make_igemm_args(M, N, K, x.cuda(), K, wp, out, N, rows, bias=b.cuda(), residual=res.cuda(), batch_vec=vec,
+                                batch_vec_ld=N, tile_cfg=cfg, splitk=sk, splitk_ws=ws, compute=L.COMPUTE_BF16X3)
+        if M % 32 == 0 and rows % 32 == 0:
+            st = torch.zeros(M // 32, N, 3, device="cuda")
+            a.stats_out = st.data_ptr()
+            out._st = st
+        ops.igemm(a)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    if hasattr(outs[0], "_st"):
+        assert torch.equal(outs[0]._st, outs[1]._st)
+    ref = x.double() @ w.double().t() + b.double() + res.double() + vec.cpu().double().repeat_interleave(rows, 0)[:M]
+    close(outs[1], ref.float(), 6e-6, 6e-6)          # (four fp32 terms of magnitude ~1-4 summed in the epilogue)
+
+
+@pytest.mark.parametrize("case", [(2, 160, 320, 16, 16, 1), (2, 64, 96, 9, 7, 1), (1, 160, 160, 16, 16, 2), (3, 640, 640, 8, 8, 1),
+                                  (2, 320, 160, 32, 32, 1)])
+def test_warp_specialised_conv3x3_with_prologue_and_two_sources(ops, case):
+    from dsml_thesis_amd import lib as L
+    n, cin, cout, h, w, stride = case
+    x, wt, b = rnd(610, n, cin, h, w), rnd(611, cout, cin, 3, 3) / np.sqrt(9 * cin), 0.1 * rnd(612, cout)
+    scale, shift = 1.0 + 0.2 * rnd(613, n, cin), 0.3 * rnd(614, n, cin)
+    coef = torch.stack([scale, shift], 1).contiguous().cuda()
+    wp = ops.pack_conv3x3(wt.cuda())
+    ops.pack_wsplit(wp)
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    xs = nhwc(x)
+    two = cin % 64 == 0                                     # also as a channel concat of two tensors
+    outs = []
+    for cfg in (5, 21):
+        out = torch.full((n, oh, ow, cout), float("nan"), device="cuda")
+        if two:
+            x0, x1 = xs[..., :cin // 2].contiguous(), xs[..., cin // 2:].contiguous()
+            a = ops.make_igemm_args(n * oh * ow, cout, 9 * cin, x0, cin // 2, wp, out, cout, oh * ow, a1=x1, c1=cin // 2,
+                                    conv=(h, w, oh, ow, stride, 1, 0), tf=L.TF_AFFINE_SILU, tf_coef=coef, bias=b.cuda(), tile_cfg=cfg,
+                                    splitk=1, compute=L.COMPUTE_BF16X3)
+        else:
+            a = ops.make_igemm_args(n * oh * ow, cout, 9 * cin, xs, cin, wp, out, cout, oh * ow, conv=(h, w, oh, ow, stride, 1, 0),
+                                    tf=L.TF_AFFINE_SILU, tf_coef=coef, bias=b.cuda(), tile_cfg=cfg, splitk=1, compute=L.COMPUTE_BF16X3)
+        ops.igemm(a)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    xa = F.silu(x.double() * scale.double()[:, :, None, None] + shift.double()[:, :, None, None])
+    ref = F.conv2d(xa, wt.double(), b.double(), stride=stride, padding=1)
+    close(nchw(outs[1]), ref.float(), 5e-6, 5e-6)
+
+
+def test_warp_specialised_geglu_folded_layernorm_and_batched_planes(ops):
+    from dsml_thesis_amd import lib as L
+    M, K, inner = 512, 320, 1280
+    x = rnd(620, M, K) + 0.5
+    w, b = rnd(621, 2 * inner, K) / np.sqrt(K), 0.1 * rnd(622, 2 * inner)
+    gamma, beta = 1.0 + 0.1 * rnd(623, K), 0.1 * rnd(624, K)
+    wp, bp = ops.pack_geglu(w.cuda(), b.cuda())
+    w2, cs, b2 = ops.fold_layernorm(wp, gamma.cuda(), beta.cuda(), bp)
+    ops.pack_wsplit(w2)
+    st = ops.ln_stats(x.cuda())
+    y1 = ops.linear(x.cuda(), w2, b2, row_stats=st, ln_colsum=cs, geglu=True, compute=L.COMPUTE_BF16X3, tile_cfg=1)
+    y22 = ops.linear(x.cuda(), w2, b2, row_stats=st, ln_colsum=cs, geglu=True, compute=L.COMPUTE_BF16X3, tile_cfg=22)
+    assert torch.equal(y1, y22)
+    # unfolded LayerNorm prologue (the training form) through the producer waves
+    wl = ops.pack_linear((rnd(625, 160, K) / np.sqrt(K)).cuda())
+    ops.pack_wsplit(wl)
+    y5 = ops.linear(x.cuda(), wl, None, row_stats=st, ln_gamma=gamma.cuda(), ln_beta=beta.cuda(), compute=L.COMPUTE_BF16X3, tile_cfg=5)
+    y21 = ops.linear(x.cuda(), wl, None, row_stats=st, ln_gamma=gamma.cuda(), ln_beta=beta.cuda(), compute=L.COMPUTE_BF16X3, tile_cfg=21)
+    assert torch.equal(y5, y21)
+    # 16 independent products in one launch (the Winograd form), split-K 2
+    B, Mb, Kb, Nb = 16, 256, 320, 640
+    a_, w_ = rnd(630, B, Mb, Kb).cuda().contiguous(), (rnd(631, B, Kb, Nb) / np.sqrt(Kb)).cuda().contiguous()
+    ops.pack_wsplit(w_, batch=B)
+    wsb = torch.empty(4 * B * Mb * Nb, device="cuda")
+    outs = []
+    for cfg in (5, 21):
+        out = torch.empty(B, Mb, Nb, device="cuda")
+        ar = ops.make_igemm_args(Mb, Nb, Kb, a_, Kb, w_, out, Nb, Mb, batch=B, a_bstride=Mb * Kb, w_bstride=Kb * Nb, out_bstride=Mb * Nb,
+                                 tile_cfg=cfg, splitk=2, splitk_ws=wsb, compute=L.COMPUTE_BF16X3)
+        ops.igemm(ar)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    # and what they cannot run is refused with a message
+    bad = ops.make_igemm_args(M, 2 * inner, K, x.cuda(), K, w2, torch.empty(M, inner, device="cuda"), inner, M, epi=L.EPI_GEGLU,
+                              compute=L.COMPUTE_BF16X3, tile_cfg=21)
+    assert L.load().ldmk_igemm_check(__import__("ctypes").byref(bad)) != 0 and b"GEGLU" in L.load().ldmk_last_error()

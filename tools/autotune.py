@@ -145,10 +145,10 @@ def tune_x3(pg, xtable):
         best = None
         ops.set_split(a)
         nkc = a.K // 32
-        for cfg in (1, 2, 4, 5):
-            if a.epi == 1 and cfg not in EVEN_TN:
+        for cfg in (1, 2, 4, 5, 21, 22):          # 21 / 22: the warp-specialised 256x160 / 256x128 tiles (csrc/igemm_ws.hip)
+            if a.epi == 1 and cfg not in EVEN_TN and cfg != 22:
                 continue
-            iters = -(-nkc // CFG_WK[cfg])
+            iters = -(-nkc // CFG_WK.get(cfg, 1))
             for sk in SKS:
                 if sk > 1 and (a.epi == 1 or iters // sk < 1 or nb * sk * a.M * a.N > ws.numel()):
                     continue

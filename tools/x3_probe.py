@@ -59,7 +59,8 @@ def accuracy():
 
 
 def main():
-    accuracy()
+    if "--no-acc" not in sys.argv:
+        accuracy()
     lib = L.load()
     import ctypes as C
     st = torch.cuda.current_stream().cuda_stream
@@ -82,9 +83,12 @@ def main():
         out = torch.empty(batch, M, N, device="cuda")
         ref = None
         res = {}
-        for compute in (L.COMPUTE_F32, L.COMPUTE_BF16X3):
+        for compute in (L.COMPUTE_F32, L.COMPUTE_BF16X3, 102):       # 102: the warp-specialised bf16x3 tiles only (tile_cfg 21 / 22)
             best = None
-            for cfg in (1, 2, 4, 5):
+            cfgs = (21, 22) if compute == 102 else (1, 2, 4, 5)
+            key = compute
+            compute = L.COMPUTE_BF16X3 if compute == 102 else compute
+            for cfg in cfgs:
                 for sk in (1, 2, 3, 4, 6):
                     if batch * sk * M * N > ws.numel():
                         continue
@@ -100,7 +104,9 @@ def main():
                     t = time_graph(fn)
                     if best is None or t < best[0]:
                         best = (t, cfg, sk)
-            res[compute] = best
+            res[key] = best
+            if best is None:
+                continue
             a = ops.make_igemm_args(M, N, K, x, c0, wv, out, N, (conv[0] * conv[1]) if conv else M, conv=cv, batch=batch,
                                     a_bstride=M * K, w_bstride=K * N, out_bstride=M * N, tile_cfg=best[1], splitk=best[2],
                                     splitk_ws=ws, compute=compute)
@@ -114,7 +120,7 @@ def main():
         t0, t1 = res[L.COMPUTE_F32], res[L.COMPUTE_BF16X3]
         print(f"M={M:6d} N={N:5d} K={K:5d} conv={'y' if conv else 'n'} x{batch:2d}:  f32 cfg={t0[1]} sk={t0[2]} {t0[0]:8.1f} us "
               f"{fl / t0[0] * 1e-6:6.1f} TF | x3 cfg={t1[1]} sk={t1[2]} {t1[0]:8.1f} us {fl / t1[0] * 1e-6:6.1f} TF-equivalent | "
-              f"x{t0[0] / t1[0]:.2f}  max|x3 - f32| = {diff:.2e}", flush=True)
+              f"x{t0[0] / t1[0]:.2f}  max|x3 - f32| = {diff:.2e}" + (f" | ws cfg={res[102][1]} sk={res[102][2]} {res[102][0]:8.1f} us" if res.get(102) else ""), flush=True)
 
 
 if __name__ == "__main__":
