@@ -60,11 +60,17 @@ __device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf
 // staged (three bf16 images [img][tile row][KC + 8]); the weights arrive pre-split and K-contiguous (args.w_split,
 // [3][N][ld] bf16), so their staging is a 16-byte copy; per 16 k a wave issues 6 TM TN MFMAs of 32 cycles where the fp32 form
 // issues 8 TM TN of 64.
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0, bool FG = true>
+// ASP (X3 only): the A operand arrives PRE-SPLIT too (args.a_split: three bf16 images [3][M][ld] written once by the tensor's
+// statistics pass, ldmk_ln_stats_split) -- rows mode, one source, no staging prologue.  Its staging is then a 16-byte copy like
+// B's: no split arithmetic per N-tile (a GEGLU projection re-split every A element N/BN = 8..40 times), 6 + 8 loads and
+// LDS stores per thread and slice instead of 4 + 8 loads, ~90 vector operations and 12 + 8 stores.
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0, bool FG = true, bool ASP = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws) {
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr bool X3 = BF == 3;
+  static_assert(!ASP || X3, "a pre-split A operand belongs to the bf16x3 form");
+  constexpr int ASI = ASP ? (3 * BM * 4 + 255) / 256 : 1;    // ASP: 16-byte items of the three A images per thread and 32-k slice
   constexpr int BSI = X3 ? (3 * BN * 4 + 255) / 256 : 1;     // X3: 16-byte items of the three B images per thread and 32-k slice
   constexpr int NS = WK * KS;           // 32-wide K slices staged per iteration (KS per wave-group)
   constexpr int KC = 32 * NS;           // K elements staged per iteration
@@ -159,6 +165,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   float4 areg[NS][AROWS];
   float4 breg[X3 ? 1 : NS][X3 ? 1 : BROWS];
   u32x4_t bxreg[NS][BSI];               // X3: the next slice's pre-split weight items
+  u32x4_t axreg[NS][ASI];               // ASP: ... and pre-split activation items
 
   // ---- fast gather (every launch except the upsampling convolutions).  Measured with s_memtime stamps
   // (tools/igemm_probe.hip) on the ResBlock convolutions: of 7400 cycles per 32-deep slice the generic gather below spent
@@ -194,6 +201,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       const bool ok = idx < 3 * BN * 4 && n0 + nn < p.N;
       bxoff[i] = ok ? (unsigned)((((long long)img * p.N + n0 + nn) * p.w_split_ld + q * 8) * 2) : 0xFFFFFFFFu;
       bxlds[i] = (unsigned)((img * BIMG + nn * RS + q * 8) * 2);                  // byte offset inside the B images
+    }
+  }
+  unsigned axoff[ASI], axlds[ASI];
+  __amdgpu_buffer_rsrc_t rs_ax = rs_w;
+  if constexpr (ASP) {
+    const __bf16* ax = reinterpret_cast<const __bf16*>(p.a_split);
+    rs_ax = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(ax), 0, (int)(unsigned)(3LL * p.M * p.a_split_ld * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < ASI; ++i) {
+      const int idx = tid + 256 * i;
+      const int img = idx / (BM * 4), rem = idx - img * (BM * 4);
+      const int rr = rem >> 2, q = rem & 3;
+      const bool ok = idx < 3 * BM * 4 && m0 + rr < p.M;
+      axoff[i] = ok ? (unsigned)((((long long)img * p.M + m0 + rr) * p.a_split_ld + q * 8) * 2) : 0xFFFFFFFFu;
+      axlds[i] = (unsigned)((img * AIMG + rr * RS + q * 8) * 2);                   // byte offset inside the A images
     }
   }
   if constexpr (FG) {
@@ -259,9 +281,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         unsigned ox[BSI];
 #pragma unroll
         for (int i = 0; i < BSI; ++i) ox[i] = (kvalid && bxoff[i] != 0xFFFFFFFFu) ? bxoff[i] + (unsigned)(kc * 64) : 0xFFFFFFFFu;
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ASP) {
+          unsigned oy_[ASI];
 #pragma unroll
-        for (int i = 0; i < AROWS; ++i) areg[j][i] = second ? bload(rs_a1, oa[i]) : bload(rs_a0, oa[i]);
+          for (int i = 0; i < ASI; ++i) oy_[i] = (kvalid && axoff[i] != 0xFFFFFFFFu) ? axoff[i] + (unsigned)(kc * 64) : 0xFFFFFFFFu;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < ASI; ++i) axreg[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ax, (int)oy_[i], 0, 0);
+        } else {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < AROWS; ++i) areg[j][i] = second ? bload(rs_a1, oa[i]) : bload(rs_a0, oa[i]);
+        }
 #pragma unroll
         for (int i = 0; i < BSI; ++i) bxreg[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wx, (int)ox[i], 0, 0);
       } else {
@@ -361,6 +392,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
             }
           }
         }
+      }
+      if constexpr (ASP) {
+#pragma unroll
+        for (int i = 0; i < ASI; ++i) {
+          if (tid + 256 * i < 3 * BM * 4)
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(As16) + axlds[i] + j * 64) = axreg[j][i];
+        }
+#pragma unroll
+        for (int i = 0; i < BSI; ++i) {
+          if (tid + 256 * i < 3 * BN * 4)
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(Bx16) + bxlds[i] + j * 64) = bxreg[j][i];
+        }
+        continue;
       }
       if constexpr (X3) {
 #pragma unroll
@@ -930,17 +974,17 @@ static size_t cfg_lds_bytes() {
   return stage > red ? stage : red;
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0, bool FG = true>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0, bool FG = true, bool ASP = false>
 static bool& cfg_attr_done() {
   static bool done = false;
   return done;
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0, bool FG = true>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0, bool FG = true, bool ASP = false>
 static void cfg_set_attr() {
-  bool& done = cfg_attr_done<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG>();
+  bool& done = cfg_attr_done<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG, ASP>();
   if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG, ASP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg_lds_bytes<TM, TN, WM, WN, WK, KS, DB, BT, BF>());
     done = true;
   }
@@ -968,7 +1012,7 @@ int launch_splitk_reduce(const ldmk_igemm_args& a, int splitk, float* ws, hipStr
   return check_launch("ldmk_igemm(reduce)");
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF, bool FG>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF, bool FG, bool ASP = false>
 static int launch_cfg_g(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st);
 
 template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0>
@@ -977,14 +1021,14 @@ static int launch_cfg(const ldmk_igemm_args& a, int splitk, float* ws, hipStream
                                  : launch_cfg_g<TM, TN, WM, WN, WK, KS, DB, BT, BF, false>(a, splitk, ws, st);
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF, bool FG>
+template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF, bool FG, bool ASP>
 static int launch_cfg_g(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   size_t lds = cfg_lds_bytes<TM, TN, WM, WN, WK, KS, DB, BT, BF>();
   int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid(tiles, splitk, a.batch > 1 ? a.batch : 1);
-  auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG>;
-  cfg_set_attr<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG>();
+  auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG, ASP>;
+  cfg_set_attr<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG, ASP>();
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, splitk, ws);
   if (splitk > 1 && !a.splitk_counters && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
   // (splitk_counters: the last-arriving workgroup of each tile combined the slabs and ran the epilogue inside the launch;
@@ -1046,6 +1090,14 @@ static int dispatch_x3(const ldmk_igemm_args& a, int cfg, int splitk, float* ws,
   if (cfg == 3) cfg = 4;
   if (cfg == 6) cfg = geglu ? 2 : 5;
   if (geglu && !kCfg[cfg - 1].even_tn) cfg = 1;
+  if (a.a_split) {                             // the A operand pre-split as well (ldmk_ln_stats_split): copies only
+    switch (cfg) {
+      case 1: return launch_cfg_g<2, 2, 2, 2, 1, 1, false, false, 3, true, true>(a, splitk, ws, st);
+      case 2: return launch_cfg_g<1, 2, 2, 2, 1, 2, false, false, 3, true, true>(a, splitk, ws, st);
+      case 4: return launch_cfg_g<1, 1, 2, 2, 1, 2, false, false, 3, true, true>(a, splitk, ws, st);
+      default: return launch_cfg_g<1, 5, 4, 1, 1, 1, false, false, 3, true, true>(a, splitk, ws, st);
+    }
+  }
   switch (cfg) {
     case 1: return launch_cfg_g<2, 2, 2, 2, 1, 1, false, false, 3, true>(a, splitk, ws, st);
     case 2: return launch_cfg_g<1, 2, 2, 2, 1, 2, false, false, 3, true>(a, splitk, ws, st);
@@ -1195,6 +1247,14 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
     LDMK_REQUIRE(3LL * a.N * a.w_split_ld * 2 < (1LL << 32), "ldmk_igemm: w_split exceeds 4 GB per batch entry");
     LDMK_REQUIRE(igemm_fast_gather_ok(a), "ldmk_igemm: LDMK_COMPUTE_BF16X3 needs the fast gather (no zero-insertion, two-source "
                  "upsampling or operands beyond 4 GB)");
+  }
+  if (a.a_split) {
+    LDMK_REQUIRE(a.compute == LDMK_COMPUTE_BF16X3 && a.a_mode == LDMK_A_ROWS && a.c1 == 0 && a.batch <= 1 &&
+                 (a.a_tf == LDMK_TF_NONE || a.a_tf == LDMK_TF_LAYERNORM_FOLDED) && a.tile_cfg <= kNumCfg,
+                 "ldmk_igemm: a_split (pre-split A) needs LDMK_COMPUTE_BF16X3 on an LDS-tiled shape (tile_cfg 0..6), rows mode, one "
+                 "source, no staging prologue, no batching");
+    LDMK_REQUIRE(a.a_split_ld >= a.K && a.a_split_ld % 8 == 0 && 3LL * a.M * a.a_split_ld * 2 < (1LL << 32),
+                 "ldmk_igemm: a_split_ld=%d must be >= K, a multiple of 8, and the three images below 4 GB", a.a_split_ld);
   }
   LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.tile_cfg <= kNumCfg || a.tile_cfg > kNumCfg + kNumRCfg + kNumSCfg,
                "ldmk_igemm: the row / slab GEMM tiles are fp32 only");

@@ -80,8 +80,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 
 // LayerNorm statistics: one half-wave (32 lanes x float4 = 512 B per load instruction) per row, exact
 // two-pass in registers (C <= 1024, C % 4 == 0); the generic scalar form handles other widths.
+typedef __bf16 nbf16x4 __attribute__((ext_vector_type(4)));
+// SPLIT: also write the row as the three bf16 images of its exact split x = hi + mid + lo (round to nearest even, the split
+// igemm_kernel<BF = 3> makes while staging): split[img][row][ld], the a_split operand of LDMK_COMPUTE_BF16X3
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int rows, int C, float eps,
-                                                       float* __restrict__ stats) {
+                                                       float* __restrict__ stats, __bf16* __restrict__ split, int ld_split) {
   const int lane = threadIdx.x & 63, l31 = lane & 31;
   const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
   const bool ok = row < rows;
@@ -112,6 +116,25 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
   if (ok && l31 == 0) {
     stats[2 * row] = mean;
     stats[2 * row + 1] = 1.0f / sqrtf(q / (float)C + eps);
+  }
+  if constexpr (SPLIT) {
+    if (ok) {
+      const long long img = (long long)rows * ld_split;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c4 = l31 + 32 * i;
+        if (c4 < c4n) {
+          const nbf16x4 h = {(__bf16)v[i].x, (__bf16)v[i].y, (__bf16)v[i].z, (__bf16)v[i].w};
+          const float r0 = v[i].x - (float)h[0], r1 = v[i].y - (float)h[1], r2 = v[i].z - (float)h[2], r3 = v[i].w - (float)h[3];
+          const nbf16x4 m = {(__bf16)r0, (__bf16)r1, (__bf16)r2, (__bf16)r3};
+          const nbf16x4 l = {(__bf16)(r0 - (float)m[0]), (__bf16)(r1 - (float)m[1]), (__bf16)(r2 - (float)m[2]), (__bf16)(r3 - (float)m[3])};
+          __bf16* d = split + row * ld_split + 4 * c4;
+          *reinterpret_cast<nbf16x4*>(d) = h;
+          *reinterpret_cast<nbf16x4*>(d + img) = m;
+          *reinterpret_cast<nbf16x4*>(d + 2 * img) = l;
+        }
+      }
+    }
   }
 }
 
@@ -227,8 +250,19 @@ extern "C" int ldmk_ln_stats(const float* x, int rows, int c, float eps, float* 
   using namespace ldmk;
   LDMK_REQUIRE(x && stats && rows > 0 && c > 0 && c <= 1024, "ldmk_ln_stats: bad args (C<=1024)");
   if (c % 4 == 0)
-    hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats);
+    hipLaunchKernelGGL(ln_stats_kernel<false>, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats,
+                       (__bf16*)nullptr, 0);
   else
     hipLaunchKernelGGL(ln_stats_scalar_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats);
   return check_launch("ldmk_ln_stats");
+}
+
+extern "C" int ldmk_ln_stats_split(const float* x, int rows, int c, float eps, float* stats, void* split, int ld_split, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(x && stats && split && rows > 0 && c > 0 && c <= 1024 && c % 4 == 0, "ldmk_ln_stats_split: bad args (C<=1024, C%%4==0)");
+  LDMK_REQUIRE(ld_split >= c && ld_split % 8 == 0, "ldmk_ln_stats_split: ld_split=%d must be >= C and a multiple of 8", ld_split);
+  hipLaunchKernelGGL(ln_stats_kernel<true>, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats,
+                     reinterpret_cast<__bf16*>(split), ld_split);
+  return check_launch("ldmk_ln_stats_split");
 }

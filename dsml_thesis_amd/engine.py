@@ -182,6 +182,8 @@ class Program:
                 from . import ops as _ops
                 saved = (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems)
                 args.M, args.batch = m, nbatch
+                if int(xp[0]) > 6:
+                    args.a_split, args.a_split_ld = 0, 0          # the warp-specialised tiles split A themselves
                 ok = _ops.set_split(args)
                 if ok:
                     args.tile_cfg, args.splitk = int(xp[0]), int(xp[1])
@@ -192,6 +194,8 @@ class Program:
                     args.M, args.batch = m, nbatch
                     args.tile_cfg, args.splitk = int(xp[0]), max(1, int(xp[1]))
                     args.splitk_ws, args.splitk_ws_elems = 0, 0
+                    if args.tile_cfg > 6:
+                        args.a_split, args.a_split_ld = 0, 0      # the warp-specialised tiles split A themselves
                     return args.tile_cfg, args.splitk
                 args.compute, args.w_split, args.w_split_ld, args.w_split_bstride = L.COMPUTE_F32, 0, 0, 0
         # (a batch that is not per sample -- the 16 transform positions of a Winograd convolution -- is part of the plan key)
@@ -219,6 +223,7 @@ class Program:
         args.M, args.batch = m, nbatch
         args.tile_cfg, args.splitk = cfg.value, max(1, sk.value)
         args.splitk_ws, args.splitk_ws_elems = 0, 0
+        args.a_split, args.a_split_ld = 0, 0          # (pre-split A belongs to the bf16x3 LDS-tiled plans, returned above)
         return args.tile_cfg, args.splitk
 
     def igemm(self, args, scale_m=None, allow_splitk=True, batch_is_samples=True):

@@ -36,6 +36,7 @@ class IgemmArgs(C.Structure):
         ("raw_slabs", C.c_int),
         ("skip_a0", _fp), ("skip_a1", _fp), ("skip_c0", C.c_int), ("skip_c1", C.c_int),
         ("w_split", _fp), ("w_split_ld", C.c_int), ("w_split_bstride", C.c_longlong),
+        ("a_split", _fp), ("a_split_ld", C.c_int),
     ]
 
 
@@ -85,6 +86,7 @@ _SIGS = {
     "ldmk_gn_finalize": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp]),
     "ldmk_gn_coef": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _fp]),
     "ldmk_ln_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp]),
+    "ldmk_ln_stats_split": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp, C.c_int, _fp]),
     "ldmk_gn_apply": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_post": (C.c_int, [C.POINTER(PostArgs), _fp]),
     "ldmk_post_scratch_elems": (C.c_longlong, [C.POINTER(PostArgs)]),

@@ -108,11 +108,15 @@ def gn_apply(x0, x1, coef, n, hw, silu=True, out=None):
     return out
 
 
-def ln_stats(x2d, eps=1e-5, out=None):
+def ln_stats(x2d, eps=1e-5, out=None, split=None):
+    """(mean, rstd) per row; split: a bf16 tensor [3][rows][ld] that receives the rows' exact three-way split (a_split operand)."""
     rows, c = x2d.shape
     if out is None:
         out = torch.empty(rows, 2, device=x2d.device, dtype=torch.float32)
-    L.call("ldmk_ln_stats", _ptr(x2d), rows, c, float(eps), _ptr(out), stream())
+    if split is not None:
+        L.call("ldmk_ln_stats_split", _ptr(x2d), rows, c, float(eps), _ptr(out), _ptr(split), split.shape[-1], stream())
+    else:
+        L.call("ldmk_ln_stats", _ptr(x2d), rows, c, float(eps), _ptr(out), stream())
     return out
 
 
@@ -148,7 +152,7 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
                     tf_coef=None, row_stats=None, ln_gamma=None, ln_beta=None, b_trans=False, ldb=None, bias=None,
                     batch_vec=None, batch_vec_ld=0, residual=None, epi=L.EPI_NONE, batch=1, a_bstride=0, w_bstride=0,
                     out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None, w_frag=None, tile_cfg=0, compute=0, ln_colsum=None,
-                    splitk_counters=None, raw_slabs=False):
+                    splitk_counters=None, raw_slabs=False, a_split=None):
     a = L.IgemmArgs()
     a.M, a.N, a.K = M, N, K
     a.a0, a.a1, a.c0, a.c1 = _ptr(a0), _ptr(a1), c0, c1
@@ -175,6 +179,8 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
         a.splitk_counters, a.splitk_counters_len = splitk_counters.data_ptr(), splitk_counters.numel()
     if splitk_ws is not None:
         a.splitk_ws, a.splitk_ws_elems = splitk_ws.data_ptr(), splitk_ws.numel()
+    if a_split is not None:       # [3][M][ld] bf16 images of a0 (ln_stats(..., split=...)); used by the bf16x3 LDS-tiled plans only
+        a.a_split, a.a_split_ld = _ptr(a_split), a_split.shape[-1]
     if compute == L.COMPUTE_BF16X3 and not set_split(a):
         raise ValueError("COMPUTE_BF16X3: no split images registered for this weight (ops.pack_wsplit) or b_trans set")
     return a
@@ -254,7 +260,7 @@ def conv3x3(x, wp, bias=None, x1=None, stride=1, pad_lo=1, upsample=False, coef=
 
 def linear(x2d, wp, bias=None, x1=None, rows_per_sample=None, coef=None, silu=False, row_stats=None, ln_gamma=None,
            ln_beta=None, batch_vec=None, residual=None, geglu=False, out=None, b_trans=False, w_frag=None, tile_cfg=0,
-           stats_out=None, compute=0, ln_colsum=None):
+           stats_out=None, compute=0, ln_colsum=None, a_split=None):
     """x2d: [M][c0] (+ x1 [M][c1]); wp: [K][N] (or torch [N][K] with b_trans) -> [M][N] (N/2 for geglu)."""
     M, c0 = x2d.shape
     c1 = 0 if x1 is None else x1.shape[-1]
@@ -272,7 +278,7 @@ def linear(x2d, wp, bias=None, x1=None, rows_per_sample=None, coef=None, silu=Fa
                         row_stats=row_stats, ln_gamma=ln_gamma, ln_beta=ln_beta, b_trans=b_trans, bias=bias,
                         batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0),
                         residual=residual, epi=L.EPI_GEGLU if geglu else L.EPI_NONE, w_frag=w_frag, tile_cfg=tile_cfg,
-                        compute=compute, ln_colsum=ln_colsum)
+                        compute=compute, ln_colsum=ln_colsum, a_split=a_split)
     if stats_out is not None:
         a.stats_out = _ptr(stats_out)
     igemm(a)

@@ -390,16 +390,44 @@ class UNetModel(nn.Module):
             hcur = lin(xr, P[prefix + "pin"], sd[prefix + "proj_in.bias"], hw, tf=L.TF_AFFINE, tf_coef=coef, wf=P.get(prefix + "pin#f"))
             nb_.release(coef)
             stats = pg.alloc(rows, 2)
+
+            def ln_lin(x2d, wkey, geglu):
+                """LayerNorm statistics + the Linear the LayerNorm is folded through.  Optionally (see below) the statistics pass
+                also writes the rows pre-split (three bf16 images) and the bf16x3 GEMM COPIES its A operand instead of splitting
+                every element once per N-tile."""
+                wp, xs = P[wkey], None
+                N_ = wp.shape[1]
+                # Measured at 64x64x4, B = 16 (r03 layer tables, one box): the GEGLU projections 269.0 / 198.5 / 209.6 -> 269.6 /
+                # 188.8 / 204.2 us, the QKV projections 99.5 / 90.6 / 70.4 -> 108.8 / 101.2 / 79.6 us, the statistics pass +4.5 us
+                # per call: 23.89 -> 24.45 ms per step.  Three 64-byte row streams of bf16 coalesce worse than one 128-byte fp32
+                # stream and are 1.5x the bytes; the split arithmetic they save was not what bounds the kernel.  OFF
+                # (LDMK_PRESPLIT_A=1 turns it on for experiments); the kernel path stays tested.
+                if engine_split_enabled() and C_ % 8 == 0 and os.environ.get("LDMK_PRESPLIT_A"):
+                    probe = ops.make_igemm_args(rows, N_, C_, x2d, C_, wp, x2d, N_ // 2 if geglu else N_, hw, bias=P[wkey + "#b"],
+                                                tf=L.TF_LAYERNORM_FOLDED, row_stats=stats, ln_colsum=P[wkey + "#cs"],
+                                                epi=L.EPI_GEGLU if geglu else L.EPI_NONE, w_frag=P.get(wkey + "#f"))
+                    pg.plan(probe, nb_.pin)
+                    if probe.compute == L.COMPUTE_BF16X3 and probe.tile_cfg <= 6:
+                        xs = pg.alloc(3, rows, C_, dtype=torch.bfloat16)
+                if xs is not None:
+                    pg.add("ldmk_ln_stats_split", p_(x2d), rows, C_, 1e-5, p_(stats), p_(xs), C_)
+                else:
+                    pg.add("ldmk_ln_stats", p_(x2d), rows, C_, 1e-5, p_(stats))
+                y = lin(x2d, wp, P[wkey + "#b"], hw, geglu=geglu, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
+                        ln_colsum=P[wkey + "#cs"], wf=P.get(wkey + "#f"), a_split=xs)
+                if xs is not None:
+                    nb_.release(xs)
+                return y
+
             for d in range(m.depth):
                 q = f"{prefix}transformer_blocks.{d}."
                 # --- attn1 (self): LN1 folded into the fused QKV GEMM, flash attention, to_out + residual
-                pg.add("ldmk_ln_stats", p_(hcur), rows, C_, 1e-5, p_(stats))
                 if _UNFOLDED:
+                    pg.add("ldmk_ln_stats", p_(hcur), rows, C_, 1e-5, p_(stats))
                     qkv = lin(hcur, P[q + "qkv"], None, hw, tf=L.TF_LAYERNORM, row_stats=stats,
                               ln_gamma=sd[q + "norm1.weight"], ln_beta=sd[q + "norm1.bias"], wf=P.get(q + "qkv#f"))
                 else:
-                    qkv = lin(hcur, P[q + "qkv_ln"], P[q + "qkv_ln#b"], hw, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
-                              ln_colsum=P[q + "qkv_ln#cs"], wf=P.get(q + "qkv_ln#f"))
+                    qkv = ln_lin(hcur, q + "qkv_ln", False)
                 att = pg.alloc(rows, C_)
                 # both attention products in the fp32-accurate bf16x3 arithmetic (24 bf16 MFMAs of 32 cycles per 32 keys
                 # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel
@@ -436,13 +464,12 @@ class UNetModel(nn.Module):
                     h2 = lin(a2, P[q + "o2"], sd[q + "attn2.to_out.0.bias"], hw, residual=h1, out=h1, wf=P.get(q + "o2#f"))
                     nb_.release(att, a2)
                 # --- GEGLU feed-forward: LN3 folded into the first GEMM, gate in its epilogue
-                pg.add("ldmk_ln_stats", p_(h2), rows, C_, 1e-5, p_(stats))
                 if _UNFOLDED:
+                    pg.add("ldmk_ln_stats", p_(h2), rows, C_, 1e-5, p_(stats))
                     f = lin(h2, P[q + "ff1"], P[q + "ff1b"], hw, geglu=True, tf=L.TF_LAYERNORM, row_stats=stats,
                             ln_gamma=sd[q + "norm3.weight"], ln_beta=sd[q + "norm3.bias"], wf=P.get(q + "ff1#f"))
                 else:
-                    f = lin(h2, P[q + "ff1_ln"], P[q + "ff1_ln#b"], hw, geglu=True, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
-                            ln_colsum=P[q + "ff1_ln#cs"], wf=P.get(q + "ff1_ln#f"))
+                    f = ln_lin(h2, q + "ff1_ln", True)
                 hcur = lin(f, P[q + "ff2"], sd[q + "ff.net.2.bias"], hw, residual=h2, out=h2, wf=P.get(q + "ff2#f"))
                 nb_.release(f)
             out = lin(hcur, P[prefix + "pout"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True, wf=P.get(prefix + "pout#f"))

@@ -134,6 +134,10 @@ typedef struct ldmk_igemm_args {
   const void* w_split;       /* LDMK_COMPUTE_BF16X3 (b_trans = 0, tile_cfg 0..6): the weights as three bf16 images (hi, mid, lo)   */
   int w_split_ld;            /*   [3][N][w_split_ld], K-contiguous rows (w_split_ld >= K, a multiple of 8), made by               */
   long long w_split_bstride; /*   ldmk_pack_wsplit from `w`; batched GEMMs step w_split_bstride bf16 ELEMENTS per batch entry      */
+  const void* a_split;       /* optional, LDMK_COMPUTE_BF16X3 on tile_cfg 0..6, rows mode, one source, a_tf NONE / LAYERNORM_FOLDED:  */
+  int a_split_ld;            /*   the A operand pre-split as well, three bf16 images [3][M][a_split_ld] of a0 (ldmk_ln_stats_split   */
+                             /*   writes them next to the row statistics): the kernel copies instead of splitting per N-tile.        */
+                             /*   Results are bitwise those of the in-kernel split.                                                  */
 } ldmk_igemm_args;
 
 /* w[K][ldb] fp32 (row-major, as ldmk_igemm reads it with b_trans = 0; `batch` matrices w_bstride floats apart) -> the three
@@ -212,6 +216,9 @@ int ldmk_gn_finalize(const float* partial0, int c0, const float* partial1, int c
 int ldmk_gn_coef(const float* x0, int c0, const float* x1, int c1, int n, int hw, int groups, float eps,
                  const float* gamma, const float* beta, float* partial, float* coef, void* stream);
 int ldmk_ln_stats(const float* x, int rows, int c, float eps, float* stats, void* stream);
+/* the same statistics, and the rows themselves as the three bf16 images [3][rows][ld_split] of their exact split
+ * (LDMK_COMPUTE_BF16X3's a_split operand): the pass reads every element anyway.  C % 4 == 0, C <= 1024, ld_split >= C, % 8 == 0. */
+int ldmk_ln_stats_split(const float* x, int rows, int C, float eps, float* stats, void* split, int ld_split, void* stream);
 /* ldmk_gn_apply: y[n][hw][c0+c1] = act(x*scale + shift) with the planes of ldmk_gn_coef, reading the
  *   (virtual) channel concat of x0|x1 and writing one contiguous NHWC tensor; silu != 0 applies SiLU
  *   (openaimodel.py:201-203, model.py:118-131).  One HBM-bound pass: each element is normalised once

@@ -244,3 +244,37 @@ def test_warp_specialised_geglu_folded_layernorm_and_batched_planes(ops):
     bad = ops.make_igemm_args(M, 2 * inner, K, x.cuda(), K, w2, torch.empty(M, inner, device="cuda"), inner, M, epi=L.EPI_GEGLU,
                               compute=L.COMPUTE_BF16X3, tile_cfg=21)
     assert L.load().ldmk_igemm_check(__import__("ctypes").byref(bad)) != 0 and b"GEGLU" in L.load().ldmk_last_error()
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 4, 5])
+@pytest.mark.parametrize("M,K,N,geglu", [(512, 320, 960, False), (300, 160, 480, False), (4096, 640, 2560, True), (1024, 160, 1280, True)])
+def test_pre_split_activations_are_bitwise_the_in_kernel_split(ops, M, K, N, geglu, cfg):
+    """ldmk_ln_stats_split writes the rows as three bf16 images next to their statistics; the bf16x3 GEMM then copies its A
+    operand (a_split) instead of splitting it once per N-tile -- same split, same products, same bits."""
+    from dsml_thesis_amd import lib as L
+    if geglu and cfg not in (1, 2):
+        pytest.skip("GEGLU needs an even-TN tile")
+    x = rnd(700, M, K) + 0.3
+    gamma, beta = 1.0 + 0.1 * rnd(701, K), 0.1 * rnd(702, K)
+    if geglu:
+        w, b = rnd(703, N, K) / np.sqrt(K), 0.1 * rnd(704, N)
+        wp, bp = ops.pack_geglu(w.cuda(), b.cuda())
+    else:
+        w, b = rnd(703, N, K) / np.sqrt(K), 0.1 * rnd(704, N)
+        wp, bp = ops.pack_linear(w.cuda()), b.cuda()
+    w2, cs, b2 = ops.fold_layernorm(wp, gamma.cuda(), beta.cuda(), bp)
+    ops.pack_wsplit(w2)
+    xc = x.cuda()
+    st0 = ops.ln_stats(xc)
+    xs = torch.zeros(3, M, K, device="cuda", dtype=torch.bfloat16)
+    st1 = ops.ln_stats(xc, split=xs)
+    assert torch.equal(st0, st1)
+    assert torch.equal(xs.double().sum(0).cpu(), x.double())                     # exact split
+    y0 = ops.linear(xc, w2, b2, row_stats=st0, ln_colsum=cs, geglu=geglu, compute=L.COMPUTE_BF16X3, tile_cfg=cfg)
+    y1 = ops.linear(xc, w2, b2, row_stats=st0, ln_colsum=cs, geglu=geglu, compute=L.COMPUTE_BF16X3, tile_cfg=cfg, a_split=xs)
+    assert torch.equal(y0, y1)
+    # refused where it cannot apply: f32 arithmetic, the warp-specialised tiles, a staging prologue
+    import ctypes
+    for kw in (dict(compute=L.COMPUTE_F32), dict(compute=L.COMPUTE_BF16X3, tile_cfg=21)):
+        a = ops.make_igemm_args(M, N, K, xc, K, w2, y0, y0.shape[1], M, a_split=xs, **kw)
+        assert L.load().ldmk_igemm_check(ctypes.byref(a)) != 0
