@@ -21,10 +21,11 @@
 //     are bitwise reproducible.  That is what keeps 256 CUs busy on the low-resolution layers
 //     (M = 64 rows per sample at 8x8, K up to 9*1280).
 #include "ldmk_common.h"
+#include <type_traits>
 
 // Diagnostic build only (tools/igemm_probe.hip defines LDMK_IG_STAMPS): per-wave cycle totals of the main loop's phases
 // (barrier 1, LDS store, barrier 2, global-load issue, MFMA block) go to args.splitk_ws (split-K off in the probe) as [wave][8] 64-bit ticks.
-#if defined(LDMK_IG_STAMPS) && LDMK_IG_STAMPS == 1
+#if defined(LDMK_IG_STAMPS) && (LDMK_IG_STAMPS == 1 || LDMK_IG_STAMPS == 3)
 #define IG_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ig_acc[i] += t_ - ig_last; ig_last = t_; } while (0)
 #elif defined(LDMK_IG_STAMPS)      /* 2: only the loop's begin / end stamps (the schedule stays the shipped one) */
 #define IG_T(i) do { (void)ig_acc; (void)ig_last; } while (0)
@@ -38,6 +39,14 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {          // round-to-nearest-even (v_cvt_pk_bf16_f32)
   return bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void ig_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    ig_static_for<I + 1, N>(f);
+  }
 }
 
 // exact three-way split x = hi + mid + lo (each difference below is exact in fp32: the subtrahend is the leading part of x)
@@ -355,6 +364,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
     }
   };
 
+#ifdef LDMK_IG_STAMPS
+  unsigned long long ig_acc[6] = {0, 0, 0, 0, 0, 0}, ig_last = 0;
+#endif
   // A-side prologue (norm) on the loaded registers, then registers -> LDS
   auto store_slices = [&](int it, int boff) {
 #pragma unroll
@@ -407,6 +419,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         continue;
       }
       if constexpr (X3) {
+#if defined(LDMK_IG_STAMPS) && LDMK_IG_STAMPS == 3      /* probe: the wait for the slice's global loads goes to phase 0 */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        IG_T(0);
+#endif
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
           bf16x4 h, m, l;
@@ -416,6 +432,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
           *reinterpret_cast<bf16x4*>(d + AIMG) = m;
           *reinterpret_cast<bf16x4*>(d + 2 * AIMG) = l;
         }
+#if defined(LDMK_IG_STAMPS) && LDMK_IG_STAMPS == 3      /* probe: split + A stores end here (phase 1); the B copies go to phase 2 */
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        IG_T(1);
+#endif
 #pragma unroll
         for (int i = 0; i < BSI; ++i) {
           if (tid + 256 * i < 3 * BN * 4)
@@ -473,30 +493,45 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
     if constexpr (X3) {
       const __bf16* Aw16 = As16 + (wm * (32 * TM) + l31) * RS + 8 * half;
       const __bf16* Bw16 = Bx16 + (wn * (32 * TN) + l31) * RS + 8 * half;
-#pragma unroll
-      for (int s = 0; s < KC / 16; ++s) {
-        bf16x8 a8[3][TM];
+      // Operand fragments are double-buffered in registers and the reads of step t + 1 are pinned in front of the matrix
+      // instructions of step t (sched_group_barrier): the first version read b8, waited (lgkmcnt(0)) and multiplied, a dozen
+      // exposed LDS round trips per 16 k -- 2734 cycles in the MFMA block for 1920 of matrix work (s_memtime stamps).
+      constexpr int NSTEP = (KC / 16) * TN;          // one step = one B column tile of one 16-deep k group: 6 TM matrix instructions
+      bf16x8 a8[2][3][TM], b8[2][3];
+      auto fa = [&](int s, int q) {
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a8[g][i] = *reinterpret_cast<const bf16x8*>(Aw16 + g * AIMG + i * 32 * RS + 16 * s);
+          for (int i = 0; i < TM; ++i) a8[q][g][i] = *reinterpret_cast<const bf16x8*>(Aw16 + g * AIMG + i * 32 * RS + 16 * s);
+      };
+      auto fb = [&](int t, int q) {
+        const int s = t / TN, j = t - s * TN;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          bf16x8 b8[3];
+        for (int g = 0; g < 3; ++g) b8[q][g] = *reinterpret_cast<const bf16x8*>(Bw16 + g * BIMG + j * 32 * RS + 16 * s);
+      };
+      fa(0, 0);
+      fb(0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * TM + 3, 0);       // (the first step's own reads: they open the sequence)
+      ig_static_for<0, NSTEP>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int s = t / TN, j = t - s * TN;
+        constexpr bool more = t + 1 < NSTEP, newk = more && (t + 1) % TN == 0;
+        constexpr int nread = more ? 3 + (newk ? 3 * TM : 0) : 0;
+        if constexpr (more) fb(t + 1, (t + 1) & 1);
+        if constexpr (newk) fa((t + 1) / TN, ((t + 1) / TN) & 1);
 #pragma unroll
-          for (int g = 0; g < 3; ++g) b8[g] = *reinterpret_cast<const bf16x8*>(Bw16 + g * BIMG + j * 32 * RS + 16 * s);
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            // smallest partial products first (images: 0 = hi, 1 = mid, 2 = lo)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][i], b8[0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[2], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[1], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[1], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[0], acc[i][j], 0, 0, 0);
-          }
+        for (int i = 0; i < TM; ++i) {
+          // smallest partial products first (images: 0 = hi, 1 = mid, 2 = lo)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][2][i], b8[t & 1][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][0][i], b8[t & 1][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][1][i], b8[t & 1][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][1][i], b8[t & 1][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][0][i], b8[t & 1][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][0][i], b8[t & 1][0], acc[i][j], 0, 0, 0);
         }
-      }
+        if constexpr (nread > 0) __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);     // the next step's LDS reads ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM, 0);                               // ... then this step's matrix instructions
+      });
       return;
     }
     if constexpr (BF) {
@@ -583,7 +618,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
     // one copy of the loop per gather form, so that the loads and the MFMA block are ONE basic block (scheduling region)
     auto run_loop = [&](auto&& loader) {
 #ifdef LDMK_IG_STAMPS
-      unsigned long long ig_acc[6] = {0, 0, 0, 0, 0, 0}, ig_last = __builtin_amdgcn_s_memtime();
+      ig_last = __builtin_amdgcn_s_memtime();
       const unsigned long long ig_t0 = ig_last, ig_rt0 = __builtin_amdgcn_s_memrealtime();    // 100 MHz reference
 #endif
       for (int it = it_begin; it < it_end; ++it) {

@@ -12,6 +12,8 @@ const char* rgemm_unsupported(const ldmk_igemm_args&, int) { return "n/a"; }
 int rgemm_dispatch(const ldmk_igemm_args&, int, hipStream_t) { return -1; }
 const char* sgemm_unsupported(const ldmk_igemm_args&, int, int) { return "n/a"; }
 int sgemm_dispatch(const ldmk_igemm_args&, int, int, float*, hipStream_t) { return -1; }
+const char* igemm_ws_unsupported(const ldmk_igemm_args&, int, int) { return "n/a"; }
+int igemm_ws_dispatch(const ldmk_igemm_args&, int, int, float*, hipStream_t) { return -1; }
 }
 int main(int argc, char** argv) {
   const int n = atoi(argv[1]), cin = atoi(argv[2]), cout = atoi(argv[3]), hw = atoi(argv[4]);
