@@ -703,10 +703,17 @@ extern "C" int ldmk_dense_small(const float* x, int ldx, const float* w, const f
   LDMK_REQUIRE(ldx >= K && ldo >= N, "ldmk_dense_small: leading dims");
   using namespace ldmk;
   // 16-byte weight loads whenever the layout allows (every UNet / encoder Linear does)
-  // (up to 4 batch rows: the batch-1/2 route, 13.7 -> 6.9 us per call.  With 16 rows per workgroup the 64 accumulators per lane
-  //  and their cross-group sums made it SLOWER than the scalar form, 33 vs 20 us per call at batch 16 -- measured, not shipped.)
-  if (rows <= 4 && N % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
-      (!bias || ((uintptr_t)bias & 15) == 0)) {
+  // silu_in bit 1 (value 2): the 16-byte-load form for up to 4 batch rows (the batch-1/2 route: 13.7 -> 6.9 us per call).  It is
+  // REQUESTED by the caller, never chosen from `rows`: the two forms sum K in different orders, and a sample's result must not
+  // depend on how many samples share the launch (a sharded job runs fewer rows per rank than the unsharded one).  With 16 rows
+  // per workgroup the form's 64 accumulators per lane and their cross-group sums were SLOWER than the scalar form (33 vs 20 us
+  // per call at batch 16) -- measured, not shipped.
+  const int want4 = silu_in & 2;
+  silu_in &= 1;
+  if (want4) {
+    LDMK_REQUIRE(rows <= 4 && N % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
+                 (!bias || ((uintptr_t)bias & 15) == 0),
+                 "ldmk_dense_small: the 16-byte form (silu_in & 2) needs rows <= 4, N and ldo multiples of 4, 16-byte aligned w / bias / out");
     hipLaunchKernelGGL(dense_small4_kernel<4>, dim3((N + 63) / 64, 1), dim3(64 * DS_NW), 0, (hipStream_t)stream, x, ldx, w, bias, out,
                        ldo, rows, K, N, silu_in);
     return check_launch("ldmk_dense_small");

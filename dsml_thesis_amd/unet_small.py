@@ -140,6 +140,9 @@ class SmallBuilder:
 def build_small(unet, n, H, W_, L_ctx, c_concat, policy_n):
     assert L_ctx == 1
     pack_small(unet)
+    # ldmk_dense_small's 16-byte-load form (<= 4 batch rows per launch): requested from the JOB's batch, so that every shard of
+    # a job makes the same choice (the two forms sum K in different orders)
+    ds4 = 2 if max(policy_n, n) <= 4 else 0
     P, sd = unet._packed, unet._sd
     dev = next(unet.parameters()).device
     pg = Program(dev)
@@ -163,12 +166,12 @@ def build_small(unet, n, H, W_, L_ctx, c_concat, policy_n):
     temb = pg.alloc(n, mc)
     pg.add("ldmk_timestep_embedding", p_(t_in), p_(P["freqs"]), p_(temb), n, mc)
     e1 = pg.alloc(n, emb_ch)
-    pg.add("ldmk_dense_small", p_(temb), mc, p_(P["te0"]), p_(sd["time_embed.0.bias"]), p_(e1), emb_ch, n, mc, emb_ch, 0)
+    pg.add("ldmk_dense_small", p_(temb), mc, p_(P["te0"]), p_(sd["time_embed.0.bias"]), p_(e1), emb_ch, n, mc, emb_ch, ds4)
     emb = pg.alloc(n, emb_ch)
-    pg.add("ldmk_dense_small", p_(e1), emb_ch, p_(P["te2"]), p_(sd["time_embed.2.bias"]), p_(emb), emb_ch, n, emb_ch, emb_ch, 1)
+    pg.add("ldmk_dense_small", p_(e1), emb_ch, p_(P["te2"]), p_(sd["time_embed.2.bias"]), p_(emb), emb_ch, n, emb_ch, emb_ch, 1 | ds4)
     emb_all = pg.alloc(n, unet._emb_total)
     pg.add("ldmk_dense_small", p_(emb), emb_ch, p_(P["emb_all"]), p_(P["emb_all_b"]), p_(emb_all), unet._emb_total, n,
-           emb_ch, unet._emb_total, 1)
+           emb_ch, unet._emb_total, 1 | ds4)
 
     def conv_args(a_in, cin, wp, wf, cout, h, w, stride=1, upsample=False):
         oh, ow = (2 * h, 2 * w) if upsample else ((h - 1) // stride + 1, (w - 1) // stride + 1)
@@ -236,9 +239,9 @@ def build_small(unet, n, H, W_, L_ctx, c_concat, policy_n):
             pg.release(qkv)
             # --- attn2 with a single context token == a per-sample vector (exact), added with to_out's bias
             v = ctx_pg.alloc(n, C_)
-            ctx_pg.add("ldmk_dense_small", p_(ctx_in), unet.context_dim, p_(P[q + "v2"]), 0, p_(v), C_, n, unet.context_dim, C_, 0)
+            ctx_pg.add("ldmk_dense_small", p_(ctx_in), unet.context_dim, p_(P[q + "v2"]), 0, p_(v), C_, n, unet.context_dim, C_, ds4)
             cvec = ctx_pg.alloc(n, C_)
-            ctx_pg.add("ldmk_dense_small", p_(v), C_, p_(P[q + "o2"]), p_(sd[q + "attn2.to_out.0.bias"]), p_(cvec), C_, n, C_, C_, 0)
+            ctx_pg.add("ldmk_dense_small", p_(v), C_, p_(P[q + "o2"]), p_(sd[q + "attn2.to_out.0.bias"]), p_(cvec), C_, n, C_, C_, ds4)
             g = ops.make_igemm_args(rows, C_, C_, att, C_, P[q + "o1"], None, C_, hw, w_frag=P.get(q + "o1#f"))
             h1 = sb.raw([g], rows, C_, hw, bias=sd[q + "attn1.to_out.0.bias"], bvec=cvec.data_ptr(), bvec_ld=C_, residual=hl.raw)
             pg.release(att)
