@@ -103,7 +103,9 @@ typedef struct ldmk_igemm_args {
                                 a row-GEMM wave tile (32 TM x 32 TN: 1x5, 2x5, 1x4, 2x4, 1x2, 1x1), 13..20 = pin a
                                 slab-GEMM shape for small row counts (csrc/sgemm.hip; wave tile x waves that split K
                                 inside the workgroup: 2x1x4, 2x2x4, 1x1x4, 1x2x4, 1x1x8, 1x1x16, 2x1x8, 1x2x8; needs
-                                w_frag; stride-1 3x3 convolutions and rows mode).  The K-summation
+                                w_frag; stride-1 3x3 convolutions and rows mode), 21..22 = pin a warp-specialised tile of
+                                the LDMK_COMPUTE_BF16X3 arithmetic (csrc/igemm_ws.hip: 256x160 / 256x128, four consumer +
+                                four producer waves; bitwise the results of tile_cfg 5 / 1 at equal splitk).  The K-summation
                                 order depends on (tile_cfg, splitk), so a caller that needs results that are
                                 bitwise independent of the batch size pins both (ldmk_igemm_plan)          */
   int splitk;                /* 0 = choose; 1 = none; 2..64 = split K over that many workgroups            */

@@ -135,6 +135,31 @@ def test_tuned_plan_table_is_legal_and_nearest():
     assert engine.tuned_plan(a, 7) is None        # far from anything tuned: the C++ heuristic decides
 
 
+def test_x3_plan_table_is_legal(monkeypatch):
+    """dsml_thesis_amd/igemm_plans_x3.json (tools/autotune.py --x3): the shapes that run in the fp32-accurate bf16x3 arithmetic.
+    Only the tiles that implement it (LDS-tiled 1 / 2 / 4 / 5, warp-specialised 21 / 22), never a b_trans shape, GEGLU on an
+    even-TN tile without split-K, every slab at least one 32-deep chunk; LDMK_SPLIT_BF16=0 empties the table."""
+    from dsml_thesis_amd import engine
+    monkeypatch.setattr(engine, "_X3_TABLE", None)
+    monkeypatch.delenv("LDMK_SPLIT_BF16", raising=False)
+    monkeypatch.delenv("LDMK_X3_TABLE", raising=False)
+    table = engine.x3_table()
+    assert len(table) > 50, "x3 plan table missing"
+    for key, rows in table.items():
+        n, k, mode, tf, epi, nb = (int(v) for v in key.split(",")[:6])
+        assert "bt" not in key and k % 32 == 0 and n % 4 == 0
+        for m, cfg, sk in rows:
+            assert cfg in (1, 2, 4, 5, 21, 22) and 1 <= sk <= 64 and sk <= k // 32
+            if epi == 1:
+                assert cfg in (1, 2, 22) and sk == 1
+            if cfg in (21, 22):
+                assert ",s" not in key or "u0" in key          # no upsampling folded into the gather on those tiles
+    monkeypatch.setattr(engine, "_X3_TABLE", None)
+    monkeypatch.setenv("LDMK_SPLIT_BF16", "0")
+    assert engine.x3_table() == {} and not engine.split_enabled()
+    monkeypatch.setattr(engine, "_X3_TABLE", None)
+
+
 def test_product_side_recipe_matches_the_oracle_copy():
     """dsml_thesis_amd/synth.py (benchmarks, tools, smoke) and oracle/weights.py (checker) must describe the same models."""
     from dsml_thesis_amd import synth as S
