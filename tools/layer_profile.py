@@ -46,7 +46,7 @@ def dump(latent, batch, path, graph=False):
     torch.cuda.synchronize()
 
 
-KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "rgemm_kernel", "sgemm_kernel"), "ldmk_post": ("post_",),
+KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "igemm_ws_kernel", "rgemm_kernel", "sgemm_kernel"), "ldmk_post": ("post_",),
              "ldmk_attn_self_small": ("attn_small",), "ldmk_conv3x3_out_small": ("conv3x3_out_small",), "ldmk_gn_finalize": ("gn_finalize",), "ldmk_gn_apply": ("gn_apply",),
              "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_ln_stats_split": ("ln_stats",), "ldmk_attn_self": ("attn_self",), "ldmk_attn_self_x3": ("attn_x3",),
              "ldmk_attn_cross": ("attn_cross",), "ldmk_dense_small": ("dense_small",),
@@ -90,7 +90,7 @@ def join(d):
             assert "post_gnapply" in last[i]["Kernel_Name"], last[i]["Kernel_Name"]
             d_ += dur(last[i])
             i += 1
-        if (c["name"] == "ldmk_igemm" and ("igemm_kernel" in r["Kernel_Name"] or "sgemm_kernel" in r["Kernel_Name"])
+        if (c["name"] == "ldmk_igemm" and any(k in r["Kernel_Name"] for k in ("igemm_kernel", "igemm_ws_kernel", "sgemm_kernel"))
                 and c.get("sk", 1) > 1 and not c.get("raw")):
             assert "igemm_reduce" in last[i]["Kernel_Name"], (c, last[i]["Kernel_Name"])
             c["main_us"] = d_

@@ -11,8 +11,9 @@ import glob
 import os
 import sys
 
-# (first match wins: the bf16x3 instantiations of igemm_kernel carry BF = 3 as their 9th template argument)
-FAM = (("false, 3, true>", "igemm bf16x3 (six bf16 MFMAs per product)"), ("igemm_kernel", "igemm f32 MFMA (LDS-tiled, all tiles)"),
+# (first match wins: the bf16x3 instantiations of igemm_kernel carry BF = 3 as their 9th template argument: '..., false, false, 3, true, false>')
+FAM = (("false, 3, true", "igemm bf16x3 (six bf16 MFMAs per product)"), ("igemm_ws_kernel", "igemm bf16x3, warp-specialised tiles"),
+       ("igemm_kernel", "igemm f32 MFMA (LDS-tiled, all tiles)"),
        ("rgemm_kernel", "row GEMM (all wave tiles)"), ("sgemm_kernel", "slab GEMM"), ("attn_x3", "attention forward, bf16x3"),
        ("attn_self", "attention forward, f32 MFMA"), ("wgrad_kernel", "wgrad"), ("attn_bwd", "attention backward"))
 
