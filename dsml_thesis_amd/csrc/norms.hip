@@ -46,6 +46,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cpg = C / groups;
   const int items = cpg * chunks;
+  // gamma / beta of this thread's output channel are requested BEFORE the record loop: they do not depend on it, and a load
+  // issued after the reduction would be a second dependent memory round trip in a kernel that is nothing but latency
+  const int cmine = g * cpg + min((int)threadIdx.x, cpg - 1);
+  const float gam = gamma[cmine], bet = beta[cmine];
   double sum = 0.0, sumsq = 0.0;
   for (int i = threadIdx.x; i < items; i += 256) {
     const int ch = i / cpg, cc = i - ch * cpg;
@@ -72,9 +76,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   const float meanf = (float)mean;
   for (int cc = threadIdx.x; cc < cpg; cc += 256) {
     const int c = g * cpg + cc;
-    const float sc = rstd * gamma[c];
+    const bool first = cc == (int)threadIdx.x;                 // (cpg <= 256 in every model here: one channel per thread)
+    const float sc = rstd * (first ? gam : gamma[c]);
     coef[((long long)n * 2) * C + c] = sc;
-    coef[((long long)n * 2 + 1) * C + c] = fmaf(-meanf, sc, beta[c]);
+    coef[((long long)n * 2 + 1) * C + c] = fmaf(-meanf, sc, first ? bet : beta[c]);
   }
 }
 
