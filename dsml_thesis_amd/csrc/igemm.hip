@@ -77,10 +77,14 @@ template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int 
 __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws) {
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
-  constexpr bool X3 = BF == 3;
-  static_assert(!ASP || X3, "a pre-split A operand belongs to the bf16x3 form");
+  // BF = 2: plain bf16 compute (one image) with the weights PRE-PACKED like the split form's -- bf16, transposed, K-contiguous
+  // (ldmk_pack_wbf16t, once per optimiser step): the training step's forward GEMMs.  BF = 1 reads fp32 W as it lies and gathers
+  // every B fragment with eight ds_read_b32 + conversions; here a fragment is one ds_read_b128.
+  constexpr bool X3 = BF >= 2;               // (named for the split form; "pre-packed bf16 weight images" is what it selects)
+  constexpr int NI = BF == 3 ? 3 : 1;        // bf16 images per operand
+  static_assert(!ASP || BF == 3, "a pre-split A operand belongs to the bf16x3 form");
   constexpr int ASI = ASP ? (3 * BM * 4 + 255) / 256 : 1;    // ASP: 16-byte items of the three A images per thread and 32-k slice
-  constexpr int BSI = X3 ? (3 * BN * 4 + 255) / 256 : 1;     // X3: 16-byte items of the three B images per thread and 32-k slice
+  constexpr int BSI = X3 ? (NI * BN * 4 + 255) / 256 : 1;     // X3: 16-byte items of the three B images per thread and 32-k slice
   constexpr int NS = WK * KS;           // 32-wide K slices staged per iteration (KS per wave-group)
   constexpr int KC = 32 * NS;           // K elements staged per iteration
   constexpr int ASTR = BM + 1;          // odd stride: conflict-free transposed writes + reads
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   float* Bs32 = smem + BM * RS / 2;                             // BF, !BT: [KC][BN] fp32 as it lies in HBM (n-contiguous);
                                                                 // fragments are gathered from it, see compute()
   constexpr int AIMG = BM * RS, BIMG = BN * RS;                 // X3: elements per image; A images first, then the B images
-  __bf16* Bx16 = reinterpret_cast<__bf16*>(smem) + 3 * AIMG;
+  __bf16* Bx16 = reinterpret_cast<__bf16*>(smem) + NI * AIMG;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -201,13 +205,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   __amdgpu_buffer_rsrc_t rs_wx = rs_w;
   if constexpr (X3) {
     const __bf16* wx = reinterpret_cast<const __bf16*>(p.w_split) + (long long)bz * p.w_split_bstride;
-    rs_wx = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wx), 0, (int)(unsigned)(3LL * p.N * p.w_split_ld * 2), 0x00020000);
+    rs_wx = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wx), 0, (int)(unsigned)((long long)NI * p.N * p.w_split_ld * 2), 0x00020000);
 #pragma unroll
     for (int i = 0; i < BSI; ++i) {
       const int idx = tid + 256 * i;
       const int img = idx / (BN * 4), rem = idx - img * (BN * 4);
       const int nn = rem >> 2, q = rem & 3;
-      const bool ok = idx < 3 * BN * 4 && n0 + nn < p.N;
+      const bool ok = idx < NI * BN * 4 && n0 + nn < p.N;
       bxoff[i] = ok ? (unsigned)((((long long)img * p.N + n0 + nn) * p.w_split_ld + q * 8) * 2) : 0xFFFFFFFFu;
       bxlds[i] = (unsigned)((img * BIMG + nn * RS + q * 8) * 2);                  // byte offset inside the B images
     }
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         }
 #pragma unroll
         for (int i = 0; i < BSI; ++i) {
-          if (tid + 256 * i < 3 * BN * 4)
+          if (tid + 256 * i < NI * BN * 4)
             *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(Bx16) + bxlds[i] + j * 64) = bxreg[j][i];
         }
         continue;
@@ -425,12 +429,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
 #endif
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
-          bf16x4 h, m, l;
-          split3(areg[j][i], h, m, l);
           __bf16* d = As16 + (arow + 32 * i) * RS + j * 32 + acol;
-          *reinterpret_cast<bf16x4*>(d) = h;
-          *reinterpret_cast<bf16x4*>(d + AIMG) = m;
-          *reinterpret_cast<bf16x4*>(d + 2 * AIMG) = l;
+          if constexpr (NI == 3) {
+            bf16x4 h, m, l;
+            split3(areg[j][i], h, m, l);
+            *reinterpret_cast<bf16x4*>(d) = h;
+            *reinterpret_cast<bf16x4*>(d + AIMG) = m;
+            *reinterpret_cast<bf16x4*>(d + 2 * AIMG) = l;
+          } else {
+            *reinterpret_cast<bf16x4*>(d) = to_bf16x4(areg[j][i]);
+          }
         }
 #if defined(LDMK_IG_STAMPS) && LDMK_IG_STAMPS == 3      /* probe: split + A stores end here (phase 1); the B copies go to phase 2 */
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
 #endif
 #pragma unroll
         for (int i = 0; i < BSI; ++i) {
-          if (tid + 256 * i < 3 * BN * 4)
+          if (tid + 256 * i < NI * BN * 4)
             *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(Bx16) + bxlds[i] + j * 64) = bxreg[j][i];
         }
         continue;
@@ -496,41 +504,44 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       // Operand fragments are double-buffered in registers and the reads of step t + 1 are pinned in front of the matrix
       // instructions of step t (sched_group_barrier): the first version read b8, waited (lgkmcnt(0)) and multiplied, a dozen
       // exposed LDS round trips per 16 k -- 2734 cycles in the MFMA block for 1920 of matrix work (s_memtime stamps).
-      constexpr int NSTEP = (KC / 16) * TN;          // one step = one B column tile of one 16-deep k group: 6 TM matrix instructions
-      bf16x8 a8[2][3][TM], b8[2][3];
+      constexpr int NSTEP = (KC / 16) * TN;          // one step = one B column tile of one 16-deep k group: 6 TM (1 TM) matrix instructions
+      constexpr int NMM = NI == 3 ? 6 : 1;
+      bf16x8 a8[2][NI][TM], b8[2][NI];
       auto fa = [&](int s, int q) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < NI; ++g)
 #pragma unroll
           for (int i = 0; i < TM; ++i) a8[q][g][i] = *reinterpret_cast<const bf16x8*>(Aw16 + g * AIMG + i * 32 * RS + 16 * s);
       };
       auto fb = [&](int t, int q) {
         const int s = t / TN, j = t - s * TN;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) b8[q][g] = *reinterpret_cast<const bf16x8*>(Bw16 + g * BIMG + j * 32 * RS + 16 * s);
+        for (int g = 0; g < NI; ++g) b8[q][g] = *reinterpret_cast<const bf16x8*>(Bw16 + g * BIMG + j * 32 * RS + 16 * s);
       };
       fa(0, 0);
       fb(0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 3 * TM + 3, 0);       // (the first step's own reads: they open the sequence)
+      __builtin_amdgcn_sched_group_barrier(0x100, NI * TM + NI, 0);       // (the first step's own reads: they open the sequence)
       ig_static_for<0, NSTEP>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         constexpr int s = t / TN, j = t - s * TN;
         constexpr bool more = t + 1 < NSTEP, newk = more && (t + 1) % TN == 0;
-        constexpr int nread = more ? 3 + (newk ? 3 * TM : 0) : 0;
+        constexpr int nread = more ? NI + (newk ? NI * TM : 0) : 0;
         if constexpr (more) fb(t + 1, (t + 1) & 1);
         if constexpr (newk) fa((t + 1) / TN, ((t + 1) / TN) & 1);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          // smallest partial products first (images: 0 = hi, 1 = mid, 2 = lo)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][2][i], b8[t & 1][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][0][i], b8[t & 1][2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][1][i], b8[t & 1][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][1][i], b8[t & 1][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][0][i], b8[t & 1][1], acc[i][j], 0, 0, 0);
+          if constexpr (NI == 3) {
+            // smallest partial products first (images: 0 = hi, 1 = mid, 2 = lo)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][2][i], b8[t & 1][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][0][i], b8[t & 1][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][1][i], b8[t & 1][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][1][i], b8[t & 1][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][0][i], b8[t & 1][1], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][0][i], b8[t & 1][0], acc[i][j], 0, 0, 0);
         }
         if constexpr (nread > 0) __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);     // the next step's LDS reads ...
-        __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM, 0);                               // ... then this step's matrix instructions
+        __builtin_amdgcn_sched_group_barrier(0x008, NMM * TM, 0);                             // ... then this step's matrix instructions
       });
       return;
     }
@@ -960,12 +971,13 @@ __global__ __launch_bounds__(256) void igemm_reduce_stats_kernel(const ldmk_igem
 }
 
 // W[K][ldb] fp32 -> the three bf16 images [3][N][ld_out] of its exact split, K-contiguous (LDMK_COMPUTE_BF16X3)
+template <int NIMG>
 __global__ __launch_bounds__(256) void pack_wsplit_kernel(const float* __restrict__ w, int K, int N, int ldb, long long w_bstride,
                                                           __bf16* __restrict__ out, int ld_out) {
   __shared__ float tile[32][33];
   const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   const float* wb = w + (long long)blockIdx.z * w_bstride;
-  __bf16* ob = out + (long long)blockIdx.z * 3 * N * ld_out;
+  __bf16* ob = out + (long long)blockIdx.z * NIMG * N * ld_out;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int k = (threadIdx.x >> 5) + 8 * r, n = threadIdx.x & 31;
@@ -978,9 +990,11 @@ __global__ __launch_bounds__(256) void pack_wsplit_kernel(const float* __restric
     bf16x4 h, m, l;
     split3(v, h, m, l);
     __bf16* d = ob + (long long)(n0 + n) * ld_out + k0 + kq;
-    *reinterpret_cast<bf16x4*>(d) = h;
-    *reinterpret_cast<bf16x4*>(d + (long long)N * ld_out) = m;
-    *reinterpret_cast<bf16x4*>(d + 2LL * N * ld_out) = l;
+    *reinterpret_cast<bf16x4*>(d) = h;                       // (NIMG = 1: the round-to-nearest-even bf16 image alone)
+    if constexpr (NIMG == 3) {
+      *reinterpret_cast<bf16x4*>(d + (long long)N * ld_out) = m;
+      *reinterpret_cast<bf16x4*>(d + 2LL * N * ld_out) = l;
+    }
   }
 }
 
@@ -1003,6 +1017,7 @@ static size_t cfg_lds_bytes() {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KC = 32 * WK * KS;
   constexpr int ASTR = BM + 1, BSTR = BN + (BT ? 1 : 0);
   if (BF == 3) return (size_t)3 * (BM + BN) * (KC + 8) * 2;
+  if (BF == 2) return (size_t)(BM + BN) * (KC + 8) * 2;
   if (BF) return BT ? (size_t)(BM + BN) * (KC + 8) * 2 : (size_t)BM * (KC + 8) * 2 + (size_t)KC * BN * 4;
   size_t stage = (size_t)KC * (ASTR + BSTR) * sizeof(float) * (DB ? 2 : 1);
   size_t red = WK > 1 ? (size_t)(WK - 1) * WM * WN * TM * TN * 16 * 64 * sizeof(float) : 0;
@@ -1141,8 +1156,23 @@ static int dispatch_x3(const ldmk_igemm_args& a, int cfg, int splitk, float* ws,
   }
 }
 
+// bf16 compute with the weights pre-packed (args.w_split = one bf16 image, ldmk_pack_wbf16t): the training step's forward GEMMs
+static int dispatch_bf16_packed(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hipStream_t st) {
+  const bool geglu = a.epi == LDMK_EPI_GEGLU;
+  if (cfg == 3) cfg = 4;
+  if (cfg == 6) cfg = geglu ? 2 : 5;
+  if (geglu && !kCfg[cfg - 1].even_tn) cfg = 1;
+  switch (cfg) {
+    case 1: return launch_cfg_g<2, 2, 2, 2, 1, 1, false, false, 2, true>(a, splitk, ws, st);
+    case 2: return launch_cfg_g<1, 2, 2, 2, 1, 2, false, false, 2, true>(a, splitk, ws, st);
+    case 4: return launch_cfg_g<1, 1, 2, 2, 1, 2, false, false, 2, true>(a, splitk, ws, st);
+    default: return launch_cfg_g<1, 5, 4, 1, 1, 1, false, false, 2, true>(a, splitk, ws, st);
+  }
+}
+
 template <bool BT>
 static int dispatch(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hipStream_t st) {
+  if (a.compute == LDMK_COMPUTE_BF16 && a.w_split && !BT && igemm_fast_gather_ok(a)) return dispatch_bf16_packed(a, cfg, splitk, ws, st);
   if (a.compute == LDMK_COMPUTE_BF16) return dispatch_bf16<BT>(a, cfg, splitk, ws, st);
   if (a.compute == LDMK_COMPUTE_BF16X3) return dispatch_x3(a, cfg, splitk, ws, st);
   if (a.epi == LDMK_EPI_GEGLU && !kCfg[cfg - 1].even_tn) cfg = 3;   // GEGLU needs (value, gate) tile pairs
@@ -1192,9 +1222,18 @@ extern "C" int ldmk_pack_wsplit(const float* w, int K, int N, int ldb, int batch
   LDMK_ENTER();
   LDMK_REQUIRE(w && out && K > 0 && N > 0 && ldb >= N && batch >= 1, "ldmk_pack_wsplit: bad args");
   LDMK_REQUIRE(ld_out >= K && ld_out % 8 == 0, "ldmk_pack_wsplit: ld_out=%d must be >= K=%d and a multiple of 8", ld_out, K);
-  hipLaunchKernelGGL(ldmk::pack_wsplit_kernel, dim3((ld_out + 31) / 32, (N + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, w, K,
+  hipLaunchKernelGGL(ldmk::pack_wsplit_kernel<3>, dim3((ld_out + 31) / 32, (N + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, w, K,
                      N, ldb, w_bstride, reinterpret_cast<__bf16*>(out), ld_out);
   return ldmk::check_launch("ldmk_pack_wsplit");
+}
+
+extern "C" int ldmk_pack_wbf16t(const float* w, int K, int N, int ldb, void* out, int ld_out, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(w && out && K > 0 && N > 0 && ldb >= N, "ldmk_pack_wbf16t: bad args");
+  LDMK_REQUIRE(ld_out >= K && ld_out % 8 == 0, "ldmk_pack_wbf16t: ld_out=%d must be >= K=%d and a multiple of 8", ld_out, K);
+  hipLaunchKernelGGL(ldmk::pack_wsplit_kernel<1>, dim3((ld_out + 31) / 32, (N + 31) / 32, 1), dim3(256), 0, (hipStream_t)stream, w, K, N,
+                     ldb, 0LL, reinterpret_cast<__bf16*>(out), ld_out);
+  return ldmk::check_launch("ldmk_pack_wbf16t");
 }
 
 // test hook: force a tile configuration (0 = heuristic)
@@ -1283,6 +1322,10 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
     LDMK_REQUIRE(igemm_fast_gather_ok(a), "ldmk_igemm: LDMK_COMPUTE_BF16X3 needs the fast gather (no zero-insertion, two-source "
                  "upsampling or operands beyond 4 GB)");
   }
+  if (a.compute == LDMK_COMPUTE_BF16 && a.w_split)
+    LDMK_REQUIRE(!a.b_trans && a.w_split_ld >= a.K && a.w_split_ld % 8 == 0 && (long long)a.N * a.w_split_ld * 2 < (1LL << 32) && a.batch <= 1,
+                 "ldmk_igemm: LDMK_COMPUTE_BF16 with w_split (ldmk_pack_wbf16t) needs b_trans = 0, w_split_ld >= K and a multiple of 8, "
+                 "no batching");
   if (a.a_split) {
     LDMK_REQUIRE(a.compute == LDMK_COMPUTE_BF16X3 && a.a_mode == LDMK_A_ROWS && a.c1 == 0 && a.batch <= 1 &&
                  (a.a_tf == LDMK_TF_NONE || a.a_tf == LDMK_TF_LAYERNORM_FOLDED) && a.tile_cfg <= kNumCfg,

@@ -74,6 +74,7 @@ _SIGS = {
     "ldmk_wfrag_elems": (C.c_longlong, [C.c_int, C.c_int]),
     "ldmk_pack_wfrag": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ldmk_pack_wsplit": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, _fp, C.c_int, _fp]),
+    "ldmk_pack_wbf16t": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp]),
     "ldmk_winograd_tiles": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "ldmk_winograd_input": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ldmk_winograd_output": (C.c_int, [_fp, _fp, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

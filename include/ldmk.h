@@ -146,6 +146,10 @@ typedef struct ldmk_igemm_args {
  * bf16 images [batch][3][N][ld_out] of its exact three-way split, transposed so that every output column's K run is
  * contiguous.  ld_out >= K, a multiple of 8; columns K..ld_out-1 are zero-filled. */
 int ldmk_pack_wsplit(const float* w, int K, int N, int ldb, int batch, long long w_bstride, void* out, int ld_out, void* stream);
+/* the first image alone: w rounded to bf16 (nearest even), transposed, K-contiguous -- [N][ld_out].  Passed as args.w_split with
+ * compute = LDMK_COMPUTE_BF16 (b_trans = 0) it replaces the in-kernel conversion of the fp32 weights: the training step packs
+ * its forward weights once per optimiser step and every GEMM reads B fragments as single 16-byte LDS vectors. */
+int ldmk_pack_wbf16t(const float* w, int K, int N, int ldb, void* out, int ld_out, void* stream);
 
 int ldmk_igemm(const ldmk_igemm_args* args, void* stream);
 /* Scratch (in floats) ldmk_igemm(args) needs in args->splitk_ws: batch * splitk * M * N for a split-K plan, 0 otherwise.
