@@ -152,7 +152,7 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
                     tf_coef=None, row_stats=None, ln_gamma=None, ln_beta=None, b_trans=False, ldb=None, bias=None,
                     batch_vec=None, batch_vec_ld=0, residual=None, epi=L.EPI_NONE, batch=1, a_bstride=0, w_bstride=0,
                     out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None, w_frag=None, tile_cfg=0, compute=0, ln_colsum=None,
-                    splitk_counters=None, raw_slabs=False, a_split=None):
+                    splitk_counters=None, raw_slabs=False, a_split=None, w_bf16t=None):
     a = L.IgemmArgs()
     a.M, a.N, a.K = M, N, K
     a.a0, a.a1, a.c0, a.c1 = _ptr(a0), _ptr(a1), c0, c1
@@ -179,6 +179,8 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
         a.splitk_counters, a.splitk_counters_len = splitk_counters.data_ptr(), splitk_counters.numel()
     if splitk_ws is not None:
         a.splitk_ws, a.splitk_ws_elems = splitk_ws.data_ptr(), splitk_ws.numel()
+    if w_bf16t is not None:       # [N][ld] bf16 image of w (pack_wbf16t) for LDMK_COMPUTE_BF16
+        a.w_split, a.w_split_ld = _ptr(w_bf16t), w_bf16t.shape[-1]
     if a_split is not None:       # [3][M][ld] bf16 images of a0 (ln_stats(..., split=...)); used by the bf16x3 LDS-tiled plans only
         a.a_split, a.a_split_ld = _ptr(a_split), a_split.shape[-1]
     if compute == L.COMPUTE_BF16X3 and not set_split(a):
@@ -207,6 +209,17 @@ def pack_wsplit(w, batch=1):
     out = torch.empty(batch, 3, N, ld, device=w.device, dtype=torch.bfloat16)
     L.call("ldmk_pack_wsplit", _ptr(w), K, N, N, batch, K * N, _ptr(out), ld, stream())
     _SPLIT[w.data_ptr()] = (out, ld, 3 * N * ld, weakref.ref(w), w._version)
+    return out
+
+
+def pack_wbf16t(w):
+    """w: [K][N] fp32 on the GPU -> bf16 [N][ld] (rounded to nearest even, transposed, K-contiguous; ldmk_pack_wbf16t): the
+    w_split operand of an LDMK_COMPUTE_BF16 GEMM (the training step's forward weights, train.repack_bf16_weights)."""
+    assert w.dim() == 2 and w.is_contiguous()
+    K, N = w.shape
+    ld = (K + 7) // 8 * 8
+    out = torch.empty(N, ld, device=w.device, dtype=torch.bfloat16)
+    L.call("ldmk_pack_wbf16t", _ptr(w), K, N, N, _ptr(out), ld, stream())
     return out
 
 

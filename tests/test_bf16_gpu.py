@@ -167,3 +167,23 @@ def test_latent_diffusion_trains_in_bf16_through_the_facade():
                                               noise=rnd(93, 2, 3, 32, 32).cuda())
         losses.append(loss.item())
     assert model.trainer().compute == 1 and all(np.isfinite(losses)) and losses[2] < losses[0], losses
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 4, 5])
+@pytest.mark.parametrize("M,K,N", [(300, 320, 160), (1024, 640, 1920), (4096, 160, 480)])
+def test_bf16_forward_gemm_with_prepacked_weight_image_is_bitwise_the_in_kernel_conversion(ops, M, K, N, cfg):
+    """The training step packs its forward weights once per optimiser step (bf16, transposed, K-contiguous: ldmk_pack_wbf16t);
+    the GEMM then copies the image instead of converting fp32 W fragment by fragment.  Same rounding, same products."""
+    from dsml_thesis_amd import lib as L
+    x, w, b = rnd(450, M, K), rnd(451, N, K) / np.sqrt(K), 0.1 * rnd(452, N)
+    wp = ops.pack_linear(w.cuda())
+    img = ops.pack_wbf16t(wp)
+    assert torch.equal(img[:, :K].float(), wp.t().to(torch.bfloat16).float()) and torch.count_nonzero(img[:, K:]).item() == 0
+    outs = []
+    for packed in (None, img):
+        out = torch.empty(M, N, device="cuda")
+        a = ops.make_igemm_args(M, N, K, x.cuda(), K, wp, out, N, M, bias=b.cuda(), tile_cfg=cfg, splitk=1, compute=L.COMPUTE_BF16,
+                                w_bf16t=packed)
+        ops.igemm(a)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
