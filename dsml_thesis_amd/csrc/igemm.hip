@@ -300,14 +300,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
           for (int i = 0; i < ASI; ++i) oy_[i] = (kvalid && axoff[i] != 0xFFFFFFFFu) ? axoff[i] + (unsigned)(kc * 64) : 0xFFFFFFFFu;
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
+          for (int i = 0; i < BSI; ++i) bxreg[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wx, (int)ox[i], 0, 0);
+#pragma unroll
           for (int i = 0; i < ASI; ++i) axreg[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ax, (int)oy_[i], 0, 0);
         } else {
+          // the weight items FIRST: loads return in order, so the store phase can copy B to LDS (vmcnt = the A loads still in
+          // flight) while the A rows -- the gather, the longer latency -- are still arriving
           __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < BSI; ++i) bxreg[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wx, (int)ox[i], 0, 0);
 #pragma unroll
           for (int i = 0; i < AROWS; ++i) areg[j][i] = second ? bload(rs_a1, oa[i]) : bload(rs_a0, oa[i]);
         }
-#pragma unroll
-        for (int i = 0; i < BSI; ++i) bxreg[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wx, (int)ox[i], 0, 0);
       } else {
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) ob[i] = (kvalid && boff[i] != 0xFFFFFFFFu) ? boff[i] + sb : 0xFFFFFFFFu;
@@ -428,6 +432,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         IG_T(0);
 #endif
 #pragma unroll
+        for (int i = 0; i < BSI; ++i) {                 // B first: its loads were issued first (see load_slices_fast)
+          if (tid + 256 * i < NI * BN * 4)
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(Bx16) + bxlds[i] + j * 64) = bxreg[j][i];
+        }
+#pragma unroll
         for (int i = 0; i < AROWS; ++i) {
           __bf16* d = As16 + (arow + 32 * i) * RS + j * 32 + acol;
           if constexpr (NI == 3) {
@@ -439,15 +448,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
           } else {
             *reinterpret_cast<bf16x4*>(d) = to_bf16x4(areg[j][i]);
           }
-        }
-#if defined(LDMK_IG_STAMPS) && LDMK_IG_STAMPS == 3      /* probe: split + A stores end here (phase 1); the B copies go to phase 2 */
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        IG_T(1);
-#endif
-#pragma unroll
-        for (int i = 0; i < BSI; ++i) {
-          if (tid + 256 * i < NI * BN * 4)
-            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(Bx16) + bxlds[i] + j * 64) = bxreg[j][i];
         }
         continue;
       }
