@@ -542,6 +542,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         }
         if constexpr (nread > 0) __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);     // the next step's LDS reads ...
         __builtin_amdgcn_sched_group_barrier(0x008, NMM * TM, 0);                             // ... then this step's matrix instructions
+        // (Also measured, A/B on one box: the loads issued BEFORE the second barrier, as soon as the registers are free --
+        //  -2.9 % with __syncthreads (a fence: it drains them) and -2.5 % with LDS-only barriers (s_waitcnt lgkmcnt(0); s_barrier);
+        //  LDS-only barriers alone +0.15 %, not kept.)
         // (The next slice's global loads stay in ONE burst in front of this block.  Spreading them behind the steps with
         //  sched_group_barrier(0x020, ...), which pays in the f32 form, costs 2.2 % here -- 686 -> 671 sample-steps/s, A/B on one
         //  box: this form waits ~1200 cycles per slice for those loads as it is, and later issue means later arrival.)
