@@ -148,7 +148,8 @@ def test_split_attention_matches_float64_like_the_fp32_kernel(ops, n, tokens, he
 # 16-deep LDS stages.  Every accumulator sees the same sequence of matrix instructions as in igemm_kernel<BF = 3> with a
 # 32-deep slice per iteration (tile_cfg 5 / 1), so the results are BITWISE equal to those tiles at the same split-K.
 @pytest.mark.parametrize("M,K,N,sk,ws_cfg,ref_cfg", [(300, 320, 160, 1, 21, 5), (4096, 160, 480, 1, 21, 5), (1024, 2560, 640, 4, 21, 5),
-                                                     (520, 640, 1920, 1, 22, 1), (64, 1280, 1280, 5, 22, 1), (8192, 160, 160, 1, 21, 5)])
+                                                     (520, 640, 1920, 1, 22, 1), (64, 1280, 1280, 5, 22, 1), (8192, 160, 160, 1, 21, 5),
+                                                     (130, 96, 224, 1, 21, 5), (130, 96, 100, 3, 22, 1)])
 def test_warp_specialised_tiles_are_bitwise_the_lds_tiled_split_form(ops, M, K, N, sk, ws_cfg, ref_cfg):
     from dsml_thesis_amd import lib as L
     x, w, b = rnd(600, M, K), rnd(601, N, K) / np.sqrt(K), 0.1 * rnd(602, N)
