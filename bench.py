@@ -572,6 +572,22 @@ def main():
                             "value": round(a.batch * max(5, a.steps // 2) / el2, 2), "unit": "sample-steps/s",
                             "ms_per_step": round(1e3 * el2 / max(5, a.steps // 2), 4)}
         del run2
+        if os.environ.get("LDMK_SPLIT_BF16", "1") != "0":
+            # the same step with EVERY product on the f32 matrix cores (the arithmetic of rounds 1-2), measured in this very process
+            # on this very box, so that `value` (bf16x3 split products, fp32-accurate: DESIGN section 11) has its f32-MFMA twin next to it
+            from dsml_thesis_amd import engine as _eng
+            torch.cuda.empty_cache()
+            os.environ["LDMK_SPLIT_BF16"] = "0"
+            _eng._X3_TABLE = None
+            try:
+                n3 = max(5, a.steps // 2)
+                run3, el3 = measure(a.latent, n3, 2, graph)
+                out["f32_mfma_form"] = {"workload": "the primary workload with LDMK_SPLIT_BF16=0 (every GEMM and the attention on v_mfma_f32_32x32x2_f32)",
+                                        "value": round(a.batch * n3 / el3, 2), "unit": "sample-steps/s", "ms_per_step": round(1e3 * el3 / n3, 4)}
+                del run3
+            finally:
+                del os.environ["LDMK_SPLIT_BF16"]
+                _eng._X3_TABLE = None
     if not a.no_clip:
         torch.cuda.empty_cache()
         out["clip"] = clip_leg(rank, world, dev, dist, barrier, frames=a.clip_frames, ddim_steps=a.clip_steps)
