@@ -208,6 +208,30 @@ def test_first_stage_winograd_route_golden(monkeypatch):
     close(m.encode_first_stage(x), golden("g6_vqgan.npz")["encoded"], 1e-4, 1e-4)
 
 
+def test_first_stage_split_arithmetic_golden(monkeypatch):
+    """VQGAN decoder and encoder with EVERY eligible GEMM (ResnetBlock convolutions, Winograd planes, upsampling phases, the
+    AttnBlock's 1x1 projections) in the fp32-accurate bf16x3 arithmetic -- the clip / decode benchmarks run the large ones in
+    it -- against the same reference fixtures and bounds as the f32 matrix-core form; the codebook indices stay bit-exact."""
+    from dsml_thesis_amd import engine, lib as L
+    from dsml_thesis_amd.engine import NetBuilder
+    monkeypatch.setattr(engine, "x3_plan", lambda a, m: (1, 1) if a.epi == L.EPI_GEGLU else (5, 1))
+    for wino in (False, True):
+        if wino:
+            monkeypatch.setattr(NetBuilder, "WINO_MIN_TILES", 1)
+            monkeypatch.setattr(NetBuilder, "UP_MIN_PIXELS", 1)
+        m = make_fr_model()
+        z = rnd(61, 1, 3, 32, 32).cuda()
+        img, idx = m.first_stage_model.decode(z, return_indices=True)
+        fs = m.first_stage_model
+        gemms = [c[2] for pg in fs._programs.values() for c in pg.calls if c[3] == "ldmk_igemm"]
+        n3 = sum(1 for a in gemms if a.compute == L.COMPUTE_BF16X3)
+        assert n3 >= 0.7 * len(gemms), (n3, len(gemms))
+        assert np.array_equal(idx.cpu().numpy(), golden("g6_vqgan.npz")["vq_idx"].reshape(-1))
+        close(img, golden("g11_northstar.npz")["decoded128"], 1e-4, 1e-4)
+        x = torch.tanh(rnd(64, 1, 3, 128, 128)).cuda()
+        close(m.encode_first_stage(x), golden("g6_vqgan.npz")["encoded"], 1e-4, 1e-4)
+
+
 def test_first_stage_decode_encode_golden():
     g = golden("g6_vqgan.npz")
     m = make_fr_model()
