@@ -331,6 +331,33 @@ def test_northstar_trajectory_and_decode_golden():
     close(m.decode_first_stage(z, force_not_quantize=True), g["decoded256_noquant"], 1e-4, 1e-4)
 
 
+def test_northstar_trajectory_in_the_split_arithmetic(monkeypatch):
+    """The same S = 4 trajectory at 64x64x4 with the batched program (job batch 16) and EVERY eligible GEMM of the UNet forced
+    into the bf16x3 arithmetic, eager and hipGraph: held to the reference's trajectory with the unchanged bounds, and the two
+    launch modes equal bit for bit."""
+    from dsml_thesis_amd import engine, lib as L, synth
+    from dsml_thesis_amd.ddim import DDIMSampler
+    monkeypatch.setattr(engine, "x3_plan", lambda a, m: (1, 1) if a.epi == L.EPI_GEGLU else (5, 1))
+    g = golden("g11_northstar.npz")
+    m = make_fr_model(gain=0.25, unet=synth.NS_UNET, vq=synth.VQ_F4_256)
+    m.model.diffusion_model.policy_batch = 16
+    labels = torch.tensor([3, 4], device="cuda")
+    c = m.cond_stage_model.embedding(labels[:, None])
+    xT = rnd(111, 2, 4, 64, 64).cuda()
+    outs = []
+    for use_graph in (False, True):
+        out, inter = DDIMSampler(m).sample(S=4, batch_size=2, shape=[4, 64, 64], conditioning=c, eta=0.0, x_T=xT,
+                                           verbose=False, log_every_t=1, use_graph=use_graph)
+        close(inter["x_inter"][1], g["x_inter_1"], 2e-4, 2e-4)
+        close(out, g["sample_S4"], 1.5e-4, 1.5e-4)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    pgs = [pg for pg in m.model.diffusion_model._programs.values()]
+    gemms = [c_[2] for pg in pgs for c_ in pg.calls if c_[3] == "ldmk_igemm"]
+    assert gemms and sum(1 for a in gemms if a.compute == L.COMPUTE_BF16X3) >= len(gemms) - 8
+    assert any(c_[3] == "ldmk_attn_self_x3" for pg in pgs for c_ in pg.calls)
+
+
 def test_sharded_sampling_bitwise_equals_single_gpu(fr):
     """Config 4's invariant on one GPU: the per-rank blocks of an 8-way / 3-way sharded job, computed one after
     the other with the job-wide tile policy, concatenate to exactly the single-GPU result (latents and frames)."""
