@@ -294,7 +294,7 @@ def batch1_leg(dev, frames=4, ddim_steps=50, window=8):
             "frames": T, "ddim_steps": ddim_steps, "seconds": round(el, 4), "ms_per_step": round(1e3 * el / (T * ddim_steps), 4),
             "sample_steps_per_s": round(T * ddim_steps / el, 1),
             "frames_per_s_at_ddim200": round(1.0 / (200 * el / (T * ddim_steps)), 3),
-            "launches_per_unet_eval": len(pg.calls) + len(getattr(pg, "side_calls", None) or []),
+            "launches_per_unet_eval": len(pg.calls),
             "route": "small-batch program (unet_small.py)" if getattr(pg, "small_route", False) else "batched program"}
 
 

@@ -41,16 +41,35 @@ def build_lib(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
+    # per-object stamps: a source is recompiled only when it, a header or its flags changed (igemm.hip alone takes minutes)
+    hdr = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".h"):
+            hdr.update(open(os.path.join(CSRC, f), "rb").read())
+    hdr.update(open(os.path.join(HERE, "..", "include", "ldmk.h"), "rb").read())
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        flags = FLAGS + EXTRA_FLAGS.get(src, [])
+        h = hashlib.sha256(hdr.digest())
+        h.update(open(os.path.join(CSRC, src), "rb").read())
+        h.update(" ".join(flags).encode())
+        ostamp = obj + ".sha256"
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == h.hexdigest():
+            continue
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for src, p in procs:
+        procs.append((src, subprocess.Popen(cmd), ostamp, h.hexdigest()))
+    failed = []
+    for src, p, ostamp, dg in procs:
         if p.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {src}")
+            failed.append(src)
+        else:
+            with open(ostamp, "w") as fh:
+                fh.write(dg)
+    if failed:
+        raise RuntimeError(f"hipcc failed on {failed}")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -88,9 +88,13 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 typedef __bf16 nbf16x4 __attribute__((ext_vector_type(4)));
 // SPLIT: also write the row as the three bf16 images of its exact split x = hi + mid + lo (round to nearest even, the split
 // igemm_kernel<BF = 3> makes while staging): split[img][row][ld], the a_split operand of LDMK_COMPUTE_BF16X3
+// GUARD (flag != nullptr): rows whose |mean| exceeds `guard` standard deviations set *flag -- the consumer that folds the
+// LayerNorm through its product (LDMK_TF_LAYERNORM_FOLDED) subtracts mean * colsum(W') from x W' in fp32 and loses
+// ~|mean| / std ulps on such rows; the host reads the flag once per program and switches the model to the unfolded prologue.
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int rows, int C, float eps,
-                                                       float* __restrict__ stats, __bf16* __restrict__ split, int ld_split) {
+                                                       float* __restrict__ stats, __bf16* __restrict__ split, int ld_split,
+                                                       float guard, int* __restrict__ flag) {
   const int lane = threadIdx.x & 63, l31 = lane & 31;
   const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
   const bool ok = row < rows;
@@ -119,8 +123,10 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   if (ok && l31 == 0) {
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
     stats[2 * row] = mean;
-    stats[2 * row + 1] = 1.0f / sqrtf(q / (float)C + eps);
+    stats[2 * row + 1] = rstd;
+    if (flag && !(fabsf(mean) * rstd <= guard)) *flag = 1;       // (NaN statistics raise it too)
   }
   if constexpr (SPLIT) {
     if (ok) {
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void ln_stats_scalar_kernel(const float* __restrict__ x, int rows, int C, float eps,
-                                                              float* __restrict__ stats) {
+                                                              float* __restrict__ stats, float guard, int* __restrict__ flag) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -168,8 +174,10 @@ __global__ __launch_bounds__(256) void ln_stats_scalar_kernel(const float* __res
   }
   q = wave_sum(q);
   if (lane == 0) {
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
     stats[2 * row] = mean;
-    stats[2 * row + 1] = 1.0f / sqrtf(q / (float)C + eps);
+    stats[2 * row + 1] = rstd;
+    if (flag && !(fabsf(mean) * rstd <= guard)) *flag = 1;
   }
 }
 
@@ -250,16 +258,22 @@ extern "C" int ldmk_gn_coef(const float* x0, int c0, const float* x1, int c1, in
   return rc;
 }
 
-extern "C" int ldmk_ln_stats(const float* x, int rows, int c, float eps, float* stats, void* stream) {
+extern "C" int ldmk_ln_stats_guard(const float* x, int rows, int c, float eps, float* stats, float guard, int* flag, void* stream) {
   LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(x && stats && rows > 0 && c > 0 && c <= 1024, "ldmk_ln_stats: bad args (C<=1024)");
+  LDMK_REQUIRE(!flag || guard > 0.f, "ldmk_ln_stats_guard: guard=%g must be positive", (double)guard);
   if (c % 4 == 0)
     hipLaunchKernelGGL(ln_stats_kernel<false>, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats,
-                       (__bf16*)nullptr, 0);
+                       (__bf16*)nullptr, 0, guard, flag);
   else
-    hipLaunchKernelGGL(ln_stats_scalar_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats);
+    hipLaunchKernelGGL(ln_stats_scalar_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats,
+                       guard, flag);
   return check_launch("ldmk_ln_stats");
+}
+
+extern "C" int ldmk_ln_stats(const float* x, int rows, int c, float eps, float* stats, void* stream) {
+  return ldmk_ln_stats_guard(x, rows, c, eps, stats, 0.f, nullptr, stream);
 }
 
 extern "C" int ldmk_ln_stats_split(const float* x, int rows, int c, float eps, float* stats, void* split, int ld_split, void* stream) {
@@ -268,6 +282,6 @@ extern "C" int ldmk_ln_stats_split(const float* x, int rows, int c, float eps, f
   LDMK_REQUIRE(x && stats && split && rows > 0 && c > 0 && c <= 1024 && c % 4 == 0, "ldmk_ln_stats_split: bad args (C<=1024, C%%4==0)");
   LDMK_REQUIRE(ld_split >= c && ld_split % 8 == 0, "ldmk_ln_stats_split: ld_split=%d must be >= C and a multiple of 8", ld_split);
   hipLaunchKernelGGL(ln_stats_kernel<true>, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, rows, c, eps, stats,
-                     reinterpret_cast<__bf16*>(split), ld_split);
+                     reinterpret_cast<__bf16*>(split), ld_split, 0.f, (int*)nullptr);
   return check_launch("ldmk_ln_stats_split");
 }

@@ -16,6 +16,7 @@ import torch
 from . import lib as L
 from . import schedule as S_
 from .engine import GraphedProgram
+from .unet import rerun_if_layernorm_guard_tripped
 
 C12, C34 = "class_label_&_audio", "motion_&_id"
 
@@ -98,6 +99,7 @@ class DDIMSampler(object):
                                   mask_noise=kwargs.get("mask_noise"))
 
     @torch.no_grad()
+    @rerun_if_layernorm_guard_tripped(lambda self: self.model.model.diffusion_model)
     def ddim_sampling(self, cond, shape, x_T=None, callback=None, img_callback=None, log_every_t=100,
                       unconditional_guidance_scale=1., unconditional_conditioning=None, noise=None,
                       use_graph=False, policy_batch=None, return_x_inter_only=False, invert=False, mask=None, x0=None,
@@ -173,7 +175,7 @@ class DDIMSampler(object):
             step_idx.fill_(first)
             pg.inputs["t"].fill_(int(self.ddim_timesteps[first]))
 
-        mnz = torch.empty_like(img0) if mask is not None else None
+        mnz = torch.zeros_like(img0) if mask is not None else None      # (zeros: the graph warm-up steps run before the first fill)
         sqrt_ac, sqrt_1mac = self.model.sqrt_alphas_cumprod, self.model.sqrt_one_minus_alphas_cumprod
         eps_c = torch.empty_like(img0) if score_corrector is not None else None
 
@@ -324,8 +326,12 @@ class DDIMSampler(object):
     @torch.no_grad()
     def progressive_sampling(self, c1, xid, xmasks, audio_feats, S, batch_size, num_frames, shape, audio_window,
                              eta=0., verbose=True, unconditional_guidance_scale=1., unconditional_conditioning=None,
-                             x_T=None, fixed_identity=False, use_graph=True, **kwargs):
+                             x_T=None, fixed_identity=False, use_graph=True, policy_batch=None, clips=None, **kwargs):
         """Talking-face clip generation, progressive_sampling_difftalk.py:245-319.
+
+        clips=V: V independent videos advanced in lock step (see `_progressive_clips`; the reference's run is a loop over 150
+          test videos, progressive_sampling_difftalk.py:336): c1 (V,1,D), xid (V,c,h,w), xmasks / audio_feats / x_T lists of V
+          per-clip tensors; returns a list of V frame lists.
 
         fixed_identity=False: the reference's behaviour -- frames are a serial chain, the identity latent of
           frame k+1 is the latent generated for frame k (:316-317); batch 1, one captured step replayed S times
@@ -340,6 +346,10 @@ class DDIMSampler(object):
         if unconditional_guidance_scale != 1. and unconditional_conditioning is not None:
             raise NotImplementedError("progressive_sampling: the reference's CFG branch raises (torch.cat(..., dim=21), "
                                       "progressive_sampling_difftalk.py:299); only scale=1 is defined")
+        if clips is not None:
+            assert not fixed_identity, "fixed-identity frames are independent already: one batched sample() call"
+            return self._progressive_clips(int(clips), c1, xid, xmasks, audio_feats, S, shape, audio_window, eta, x_T,
+                                           use_graph, policy_batch), None
         m = self.model
         if audio_feats.dim() == 3:
             assert audio_feats.shape[0] == 1
@@ -357,13 +367,56 @@ class DDIMSampler(object):
         if fixed_identity:
             c34 = torch.cat([c3_all, xid.expand(T, -1, -1, -1)], dim=1)
             out, _ = self.sample(S, T, shape, {C12: c12_all, C34: c34}, eta=eta, x_T=x_T[:, 0], verbose=False,
-                                 use_graph=use_graph)
+                                 use_graph=use_graph, policy_batch=policy_batch)
             return [out[f:f + 1] for f in range(T)], None
         zid = xid.clone()
         frames = []
         for f in range(T):
             c = {C12: c12_all[f:f + 1], C34: torch.cat([c3_all[f:f + 1], zid], dim=1)}
-            img, _ = self.sample(S, batch_size, shape, c, eta=eta, x_T=x_T[f], verbose=False, use_graph=use_graph)
+            img, _ = self.sample(S, batch_size, shape, c, eta=eta, x_T=x_T[f], verbose=False, use_graph=use_graph,
+                                 policy_batch=policy_batch)
             frames.append(img)
             zid = img.clone()
         return frames, None
+
+    @torch.no_grad()
+    def _progressive_clips(self, V, c1, xid, xmasks, audio_feats, S, shape, audio_window, eta, x_T, use_graph, policy_batch):
+        """V independent talking-face videos, each the reference's serial chain (frame k+1's identity latent = frame k's
+        result, progressive_sampling_difftalk.py:282-317), advanced frame by frame TOGETHER: frame f of every clip that still has
+        one is ONE batch of the batched program, so the autoregressive mode runs at the batched rate instead of batch 1.  Clips
+        may have different lengths: a finished clip leaves the batch.  Tile plans are made for `policy_batch` (default V) whatever
+        the active count, so every clip's frames are bit for bit those of `progressive_sampling` on that clip alone with the same
+        `policy_batch` (a sample's result does not depend on what else is in its batch).  Across GPUs: replicas only -- different
+        clips per rank, no collective."""
+        m = self.model
+        assert len(xmasks) == V and len(audio_feats) == V and c1.shape[0] == V and xid.shape[0] == V
+        C_, H, W_ = shape
+        dev = m.device
+        pol = V if policy_batch is None else policy_batch
+        c12, c3, Ts = [], [], []
+        for v in range(V):                                   # per-clip conditioning, exactly the single-clip calls
+            af = audio_feats[v]
+            if af.dim() == 3:
+                assert af.shape[0] == 1
+                af = af.squeeze(0)
+            T = af.shape[0]
+            idx = torch.tensor([[min(max(f + i, 0), T - 1) for i in range(-audio_window, audio_window + 1)]
+                                for f in range(T)], device=af.device)
+            c2_all = m.cond_stage_model_2(af[idx])
+            c12.append(torch.cat([c1[v:v + 1].expand(T, -1, -1), c2_all], dim=2))
+            c3.append(m.encode_first_stage(xmasks[v]))
+            Ts.append(T)
+        if x_T is None:
+            x_T = [torch.randn(T, 1, C_, H, W_, device=dev) for T in Ts]
+        zid = [xid[v:v + 1].clone() for v in range(V)]
+        frames = [[] for _ in range(V)]
+        for f in range(max(Ts)):
+            act = [v for v in range(V) if f < Ts[v]]
+            c = {C12: torch.cat([c12[v][f:f + 1] for v in act]),
+                 C34: torch.cat([torch.cat([c3[v][f:f + 1], zid[v]], dim=1) for v in act])}
+            img, _ = self.sample(S, len(act), shape, c, eta=eta, x_T=torch.cat([x_T[v][f] for v in act]), verbose=False,
+                                 use_graph=use_graph, policy_batch=pol)
+            for i, v in enumerate(act):
+                frames[v].append(img[i:i + 1].clone())
+                zid[v] = img[i:i + 1].clone()
+        return frames

@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import schedule as S_
+from .unet import rerun_if_layernorm_guard_tripped
 from .util import instantiate_from_config
 
 try:  # north_star: keep the pl.LightningModule surface when Lightning exists
@@ -308,6 +309,7 @@ class LatentDiffusion(_Base):
         return (out, x_recon) if return_x0 else out
 
     @torch.no_grad()
+    @rerun_if_layernorm_guard_tripped(lambda self: self.model.diffusion_model)
     def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None,
                       timesteps=None, quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None,
                       log_every_t=None, noise=None, use_graph=False, mask_noise=None):

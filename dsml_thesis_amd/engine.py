@@ -273,29 +273,10 @@ class Program:
 
     def run(self, stream=None):
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
-        side = getattr(self, "side_calls", None)
-        if side and stream is None:
-            # Launches that do not depend on the activations (the timestep-embedding MLP + emb_layers: they only read `t`) go
-            # to a second stream, forked here and joined in front of their first consumer: inside a captured hipGraph that
-            # is a parallel branch, so they run under the first convolution instead of in front of it.
-            cur = torch.cuda.current_stream()
-            if getattr(self, "_side_stream", None) is None:
-                self._side_stream = torch.cuda.Stream(device=self.device)
-            self._side_stream.wait_stream(cur)
-            sst = self._side_stream.cuda_stream
-            for fn, args, _, name in side:
-                rc = fn(*args, sst)
-                if rc != 0:
-                    L.check(rc, name)
-        join_at = getattr(self, "side_join", -1) if (side and stream is None) else -1
-        for i, (fn, args, _, name) in enumerate(self.calls):
-            if i == join_at:
-                torch.cuda.current_stream().wait_stream(self._side_stream)
+        for fn, args, _, name in self.calls:
             rc = fn(*args, st)
             if rc != 0:
                 L.check(rc, name)
-        if side and stream is not None:           # an explicit stream: no fork, the side launches simply run first
-            raise L.LdmkError("Program.run: a program with side launches runs on the current torch stream only")
 
 
 class NetBuilder:

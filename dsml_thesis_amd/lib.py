@@ -87,6 +87,7 @@ _SIGS = {
     "ldmk_gn_finalize": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp]),
     "ldmk_gn_coef": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _fp]),
     "ldmk_ln_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp]),
+    "ldmk_ln_stats_guard": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, C.c_float, _fp, _fp]),
     "ldmk_ln_stats_split": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp, C.c_int, _fp]),
     "ldmk_gn_apply": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_post": (C.c_int, [C.POINTER(PostArgs), _fp]),

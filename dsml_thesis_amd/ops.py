@@ -137,11 +137,13 @@ def make_post_args(src, M, N, rows_per_sample, nslab=1, slab_stride=None, bias=N
     return a
 
 
-def post(args):
-    """ldmk_post; the row-tiled GroupNorm form (large images) gets its scratch here (programs allocate it from their pool)."""
+def post(args, device=None):
+    """ldmk_post; the row-tiled GroupNorm form (large images) gets its scratch here (programs allocate it from their pool).
+    `device`: where the operands live (default: the current CUDA device, which is the rank's own under torchrun)."""
     need = L.load().ldmk_post_scratch_elems(C.byref(args))
     if need > 0 and not args.gn_scratch:
-        scratch = torch.empty(need, device="cuda", dtype=torch.float32)
+        scratch = torch.empty(need, device=device if device is not None else torch.device("cuda", torch.cuda.current_device()),
+                              dtype=torch.float32)
         args.gn_scratch, args.gn_scratch_elems = scratch.data_ptr(), need
         args._scratch = scratch
     L.call("ldmk_post", C.byref(args), stream())
@@ -208,8 +210,19 @@ def pack_wsplit(w, batch=1):
     ld = (K + 7) // 8 * 8
     out = torch.empty(batch, 3, N, ld, device=w.device, dtype=torch.bfloat16)
     L.call("ldmk_pack_wsplit", _ptr(w), K, N, N, batch, K * N, _ptr(out), ld, stream())
-    _SPLIT[w.data_ptr()] = (out, ld, 3 * N * ld, weakref.ref(w), w._version)
+    ptr = w.data_ptr()
+    _SPLIT[ptr] = (out, ld, 3 * N * ld, weakref.ref(w), w._version)
+    # the images die with the weight they were made from (a deleted model must give back its ~6 bytes per parameter); the
+    # entry is dropped only if it still is THIS weight's (the allocator may have handed the address to a newer weight).
+    # Packed weights must not be written through raw pointers after this call: only in-place torch writes move _version.
+    weakref.finalize(w, _drop_split, ptr, out.data_ptr())
     return out
+
+
+def _drop_split(ptr, img_ptr):
+    hit = _SPLIT.get(ptr)
+    if hit is not None and hit[0].data_ptr() == img_ptr:
+        del _SPLIT[ptr]
 
 
 def pack_wbf16t(w):

@@ -42,28 +42,47 @@ def _splitk_ws(dev, elems=64 * 1024 * 1024):
 # A weight is registered the first time a forward GEMM meets it; repack_bf16_weights() refreshes every registered image and
 # is the first thing of a forward pass (the optimiser writes the fp32 masters through raw pointers, so there is no version to
 # watch: the images are simply rebuilt every step -- 0.94 GB of traffic for the 157 M parameters of this UNet).
-_WT16 = {}          # device pointer of a packed fp32 weight [K][ldb] -> (bf16 image [N][ld], ld, K, N, ldb)
+# The registry belongs to ONE trainer (UNetTrainer._wt16, made current by its forward / backward) and only holds weights that
+# live inside that trainer's flat parameter buffer: it dies with the trainer, a second trainer never repacks (or reads) the
+# first one's addresses, and temporaries (mirrored-tap data-gradient weights, another model's frozen weights) never enter it.
+class Bf16Images:
+    def __init__(self, flat):
+        self.flat = flat                 # keeps the owner's parameter buffer alive as long as its images exist
+        self.lo = flat.data_ptr()
+        self.hi = self.lo + flat.numel() * flat.element_size()
+        self.images = {}                 # device pointer of a packed fp32 weight [K][ldb] -> (bf16 image [N][ld], ld, K, N, ldb)
+
+    def owns(self, ptr):
+        return self.lo <= ptr < self.hi
+
+
+_WT16 = None        # the current trainer's Bf16Images (None: no pre-packed images, the GEMM converts in the kernel)
+
+
+def activate_bf16_images(reg):
+    global _WT16
+    _WT16 = reg
 
 
 def repack_bf16_weights():
-    if T.COMPUTE != L.COMPUTE_BF16:
+    if T.COMPUTE != L.COMPUTE_BF16 or _WT16 is None:
         return
     st = ops.stream()
-    for wptr, (img, ld, K, N, ldb) in _WT16.items():
+    for wptr, (img, ld, K, N, ldb) in _WT16.images.items():
         L.call("ldmk_pack_wbf16t", wptr, K, N, ldb, img.data_ptr(), ld, st)
 
 
 def _bf16_image(a, dev):
     """The pre-packed bf16 image of this forward GEMM's weight, or None on first sight (it is registered for the next pass)."""
-    if a.b_trans or a.batch > 1 or a.K % 8 or os.environ.get("LDMK_TRAIN_NO_PACKED_W"):
+    if _WT16 is None or a.b_trans or a.batch > 1 or a.K % 8 or os.environ.get("LDMK_TRAIN_NO_PACKED_W") or not _WT16.owns(a.w):
         return None
-    hit = _WT16.get(a.w)
+    hit = _WT16.images.get(a.w)
     if hit is not None and hit[2:] == (a.K, a.N, a.ldb):
         return hit
     if torch.cuda.is_current_stream_capturing():
         return None                                     # never allocate / register inside a capture: the next eager pass will
     ld = (a.K + 7) // 8 * 8
-    _WT16[a.w] = (torch.zeros(a.N, ld, device=dev, dtype=torch.bfloat16), ld, a.K, a.N, a.ldb)
+    _WT16.images[a.w] = (torch.zeros(a.N, ld, device=dev, dtype=torch.bfloat16), ld, a.K, a.N, a.ldb)
     return None
 
 
@@ -150,6 +169,7 @@ class UNetTrainer:
         self.P = FlatParams()
         self._collect()
         self.P.finalize(self.dev)
+        self._wt16 = Bf16Images(self.P.flat)      # bf16 forward-weight images: this trainer's, freed with it
         self.freqs = unet._packed["freqs"]
         self.tape = []
         self.G = {}            # activation data_ptr -> (grad tensor)
@@ -508,6 +528,7 @@ class UNetTrainer:
         T.set_compute(self.compute)
         if not x.is_cuda:
             raise L.LdmkError("UNetTrainer.forward: CUDA tensors only (no CPU fallback)")
+        activate_bf16_images(self._wt16)
         repack_bf16_weights()            # (bf16 step only) the forward weights' bf16 images follow the optimiser's last update
         if context is None:
             raise L.LdmkError("UNetTrainer.forward: context is required")
@@ -598,6 +619,7 @@ class UNetTrainer:
         collectives suit the xGMI rings) is handed to an asynchronous all-reduce while earlier layers still compute."""
         ps = self.last_pass if pass_ is None else pass_
         T.set_compute(self.compute)
+        activate_bf16_images(self._wt16)
         self.tape, self.G, self.ginit, self.eps_pad, self.dctx = ps["tape"], ps["G"], ps["ginit"], ps["eps_pad"], ps["dctx"]
         self._dctx_init = False
         self._alias_grad(self.eps_pad, deps_pad)

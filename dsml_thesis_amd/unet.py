@@ -18,8 +18,17 @@ from . import lib as L
 from . import ops
 from .engine import NetBuilder, Program, split_enabled as engine_split_enabled
 
-# diagnostic A/B switch: LayerNorm applied while the A operand is staged (round-1 form) instead of folded through the product
-_UNFOLDED = bool(os.environ.get("LDMK_LN_UNFOLDED"))
+# LayerNorm is folded algebraically through the Linear behind it (LDMK_TF_LAYERNORM_FOLDED): exact for well-conditioned rows,
+# but it subtracts mean * colsum(W') from x W' in fp32, so rows whose |mean| is many standard deviations lose accuracy
+# (measured, one K = 640 GEMM: max error 6e-6 at |mean|/std = 1, 3e-5 near 5, 1.7e-4 at 30, 4.6e-4 at 100).  The statistics
+# pass raises a device flag for rows beyond LN_GUARD_RATIO; UNetModel reads it once per program (and once per sampling run) and
+# rebuilds itself with the unfolded prologue (LayerNorm applied while the A operand is staged), with a warning.
+# LDMK_LN_UNFOLDED=1 starts every model in the unfolded form (A/B switch).
+LN_GUARD_RATIO = float(os.environ.get("LDMK_LN_GUARD_RATIO", "4.0"))
+
+
+def ln_unfolded_default():
+    return bool(os.environ.get("LDMK_LN_UNFOLDED"))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -90,6 +99,177 @@ def _seq(*mods):
         s.add_module(str(i), m)
     s.layers = list(mods)
     return s
+
+
+def pack_spatial_transformer(P, sd, prefix, m):
+    """Kernel layouts of one SpatialTransformer's weights (attention.py:218-261) into P, keyed by the reference's names."""
+    P[prefix + "pin"] = ops.pack_linear(sd[prefix + "proj_in.weight"])
+    P[prefix + "pout"] = ops.pack_linear(sd[prefix + "proj_out.weight"])
+    for d in range(m.depth):
+        q = f"{prefix}transformer_blocks.{d}."
+        wqkv = torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0)
+        P[q + "qkv"] = ops.pack_linear(wqkv.contiguous())
+        P[q + "o1"] = ops.pack_linear(sd[q + "attn1.to_out.0.weight"])
+        P[q + "q2"] = ops.pack_linear(sd[q + "attn2.to_q.weight"])
+        P[q + "k2"] = ops.pack_linear(sd[q + "attn2.to_k.weight"])
+        P[q + "v2"] = ops.pack_linear(sd[q + "attn2.to_v.weight"])
+        P[q + "o2"] = ops.pack_linear(sd[q + "attn2.to_out.0.weight"])
+        P[q + "ff1"], P[q + "ff1b"] = ops.pack_geglu(sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"])
+        P[q + "ff2"] = ops.pack_linear(sd[q + "ff.net.2.weight"])
+        # LayerNorm folded through the Linear that follows it (LDMK_TF_LAYERNORM_FOLDED): gamma-scaled weights,
+        # their column sums and beta^T W + bias; the unfolded copies above stay for the training step
+        for k, nrm, b in (("qkv", "norm1", None), ("q2", "norm2", None), ("ff1", "norm3", P[q + "ff1b"])):
+            P[q + k + "_ln"], P[q + k + "_ln#cs"], P[q + k + "_ln#b"] = ops.fold_layernorm(
+                P[q + k], sd[q + nrm + ".weight"], sd[q + nrm + ".bias"], b)
+
+
+def pack_gemm_copies(P, unfolded=False):
+    """The second copies of the GEMM weights the plans may ask for, keyed `<weight key>#f` / `#s`."""
+    # fragment-order copies of the token-row Linear weights: the row GEMM (csrc/rgemm.hip) reads these
+    # (and the slab GEMM of the small-batch route, csrc/sgemm.hip, which also takes the ResBlock convolutions: c1 / c2)
+    for k in [k for k in P if k.rsplit(".", 1)[-1] in ("pin", "pout", "qkv_ln", "o1", "q2_ln", "o2", "ff1_ln", "ff2", "skip",
+                                                        "c1", "c2")
+              or (unfolded and k.rsplit(".", 1)[-1] in ("qkv", "ff1", "q2"))]:
+        wf = ops.pack_wfrag(P[k])
+        if wf is not None:
+            P[k + "#f"] = wf
+    # bf16x3 images of the GEMM weights (LDMK_COMPUTE_BF16X3, include/ldmk.h): fp32-accurate products at the bf16 matrix
+    # rate; engine.Program.plan() uses them for the shapes dsml_thesis_amd/igemm_plans_x3.json lists
+    if engine_split_enabled():
+        for k in list(P):
+            tail = k.rsplit(".", 1)[-1]
+            if tail in ("pin", "pout", "qkv_ln", "o1", "ff1_ln", "ff2", "skip", "c1", "c2", "w") or (unfolded and tail in ("qkv", "ff1")):
+                if P[k].dim() == 2:
+                    P[k + "#s"] = ops.pack_wsplit(P[k])
+            elif tail in ("c1#wg", "c2#wg", "w#up"):
+                P[k + "#s"] = ops.pack_wsplit(P[k], batch=P[k].shape[0])
+
+
+def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_in, context_dim, unfolded=False, ln_flag=None):
+    """SpatialTransformer.forward (attention.py:250-261) as launches into nb_.pg: GroupNorm folded into proj_in, per block
+    LN1 -> fused QKV -> flash self-attention -> to_out (+ residual, + the 1-token cross-attention vector), [LN2 -> to_q ->
+    cross-attention -> to_out for longer contexts], LN3 -> GEGLU projection -> ff.net.2 (+ residual), then proj_out (+ the
+    block input, + the GroupNorm records of the result).  Context-only projections go to `ctx_pg` (run once per sample() call).
+    x: NHWC (n, h, w, C) -> NHWC.  `unfolded`: LayerNorm in the A staging instead of folded through the product; `ln_flag`:
+    device int the folded form's statistics passes raise for mean-dominated rows (LN_GUARD_RATIO)."""
+    pg, n = nb_.pg, nb_.n
+    gn, lin = nb_.gn, nb_.lin
+    p_ = lambda t: 0 if t is None else t.data_ptr()
+    hw = h * w
+    C_ = m.heads * m.d_head
+    rows = n * hw
+    xr = x.reshape(rows, m.ch)
+    coef = gn(x, None, hw, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-6)
+    hcur = lin(xr, P[prefix + "pin"], sd[prefix + "proj_in.bias"], hw, tf=L.TF_AFFINE, tf_coef=coef, wf=P.get(prefix + "pin#f"))
+    nb_.release(coef)
+    stats = pg.alloc(rows, 2)
+
+    def ln_lin(x2d, wkey, geglu):
+        """LayerNorm statistics + the Linear the LayerNorm is folded through.  Optionally (see below) the statistics pass
+        also writes the rows pre-split (three bf16 images) and the bf16x3 GEMM COPIES its A operand instead of splitting
+        every element once per N-tile."""
+        wp, xs = P[wkey], None
+        N_ = wp.shape[1]
+        # Measured at 64x64x4, B = 16 (r03 layer tables, one box): the GEGLU projections 269.0 / 198.5 / 209.6 -> 269.6 /
+        # 188.8 / 204.2 us, the QKV projections 99.5 / 90.6 / 70.4 -> 108.8 / 101.2 / 79.6 us, the statistics pass +4.5 us
+        # per call: 23.89 -> 24.45 ms per step.  Three 64-byte row streams of bf16 coalesce worse than one 128-byte fp32
+        # stream and are 1.5x the bytes; the split arithmetic they save was not what bounds the kernel.  OFF
+        # (LDMK_PRESPLIT_A=1 turns it on for experiments); the kernel path stays tested.
+        if engine_split_enabled() and C_ % 8 == 0 and os.environ.get("LDMK_PRESPLIT_A"):
+            probe = ops.make_igemm_args(rows, N_, C_, x2d, C_, wp, x2d, N_ // 2 if geglu else N_, hw, bias=P[wkey + "#b"],
+                                        tf=L.TF_LAYERNORM_FOLDED, row_stats=stats, ln_colsum=P[wkey + "#cs"],
+                                        epi=L.EPI_GEGLU if geglu else L.EPI_NONE, w_frag=P.get(wkey + "#f"))
+            pg.plan(probe, nb_.pin)
+            if probe.compute == L.COMPUTE_BF16X3 and probe.tile_cfg <= 6:
+                xs = pg.alloc(3, rows, C_, dtype=torch.bfloat16)
+        if xs is not None:
+            pg.add("ldmk_ln_stats_split", p_(x2d), rows, C_, 1e-5, p_(stats), p_(xs), C_)
+        else:
+            pg.add("ldmk_ln_stats_guard", p_(x2d), rows, C_, 1e-5, p_(stats), LN_GUARD_RATIO, p_(ln_flag))
+        y = lin(x2d, wp, P[wkey + "#b"], hw, geglu=geglu, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
+                ln_colsum=P[wkey + "#cs"], wf=P.get(wkey + "#f"), a_split=xs)
+        if xs is not None:
+            nb_.release(xs)
+        return y
+
+    for d in range(m.depth):
+        q = f"{prefix}transformer_blocks.{d}."
+        # --- attn1 (self): LN1 folded into the fused QKV GEMM, flash attention, to_out + residual
+        if unfolded:
+            pg.add("ldmk_ln_stats", p_(hcur), rows, C_, 1e-5, p_(stats))
+            qkv = lin(hcur, P[q + "qkv"], None, hw, tf=L.TF_LAYERNORM, row_stats=stats,
+                      ln_gamma=sd[q + "norm1.weight"], ln_beta=sd[q + "norm1.bias"], wf=P.get(q + "qkv#f"))
+        else:
+            qkv = ln_lin(hcur, q + "qkv_ln", False)
+        att = pg.alloc(rows, C_)
+        # both attention products in the fp32-accurate bf16x3 arithmetic (24 bf16 MFMAs of 32 cycles per 32 keys
+        # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel
+        pg.add("ldmk_attn_self_x3" if engine_split_enabled() else "ldmk_attn_self", p_(qkv), p_(att), n, hw, m.heads,
+               m.d_head ** -0.5)
+        nb_.release(qkv)
+        if L_ctx == 1:
+            # --- attn2 with a single context token: softmax over one key == 1, so the block adds
+            # to_out(to_v(ctx)) to every position (exact); to_q/norm2 are dead.
+            v = ctx_pg.alloc(n, C_)
+            ctx_pg.add("ldmk_dense_small", p_(ctx_in), context_dim, p_(P[q + "v2"]), 0, p_(v), C_, n,
+                       context_dim, C_, 0)
+            cvec = ctx_pg.alloc(n, C_)
+            ctx_pg.add("ldmk_dense_small", p_(v), C_, p_(P[q + "o2"]), p_(sd[q + "attn2.to_out.0.bias"]), p_(cvec),
+                       C_, n, C_, C_, 0)
+            h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur,
+                     batch_vec=cvec, batch_vec_ld=C_, wf=P.get(q + "o1#f"))   # + the per-sample cross-attention vector
+            nb_.release(att)
+            h2 = h1
+        else:
+            h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur, wf=P.get(q + "o1#f"))
+            kk = ctx_pg.alloc(n * L_ctx, C_)
+            vv = ctx_pg.alloc(n * L_ctx, C_)
+            ctx_pg.add("ldmk_dense_small", p_(ctx_in), context_dim, p_(P[q + "k2"]), 0, p_(kk), C_,
+                       n * L_ctx, context_dim, C_, 0)
+            ctx_pg.add("ldmk_dense_small", p_(ctx_in), context_dim, p_(P[q + "v2"]), 0, p_(vv), C_,
+                       n * L_ctx, context_dim, C_, 0)
+            if unfolded:
+                pg.add("ldmk_ln_stats", p_(h1), rows, C_, 1e-5, p_(stats))
+                q2 = lin(h1, P[q + "q2"], None, hw, tf=L.TF_LAYERNORM, row_stats=stats, ln_gamma=sd[q + "norm2.weight"],
+                         ln_beta=sd[q + "norm2.bias"], out=att, wf=P.get(q + "q2#f"))
+            else:
+                pg.add("ldmk_ln_stats_guard", p_(h1), rows, C_, 1e-5, p_(stats), LN_GUARD_RATIO, p_(ln_flag))
+                q2 = lin(h1, P[q + "q2_ln"], P[q + "q2_ln#b"], hw, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
+                         ln_colsum=P[q + "q2_ln#cs"], out=att, wf=P.get(q + "q2_ln#f"))
+            a2 = pg.alloc(rows, C_)
+            pg.add("ldmk_attn_cross", p_(q2), C_, p_(kk), p_(vv), C_, p_(a2), C_, n, hw, L_ctx, m.heads,
+                   m.d_head ** -0.5)
+            h2 = lin(a2, P[q + "o2"], sd[q + "attn2.to_out.0.bias"], hw, residual=h1, out=h1, wf=P.get(q + "o2#f"))
+            nb_.release(att, a2)
+        # --- GEGLU feed-forward: LN3 folded into the first GEMM, gate in its epilogue
+        if unfolded:
+            pg.add("ldmk_ln_stats", p_(h2), rows, C_, 1e-5, p_(stats))
+            f = lin(h2, P[q + "ff1"], P[q + "ff1b"], hw, geglu=True, tf=L.TF_LAYERNORM, row_stats=stats,
+                    ln_gamma=sd[q + "norm3.weight"], ln_beta=sd[q + "norm3.bias"], wf=P.get(q + "ff1#f"))
+        else:
+            f = ln_lin(h2, q + "ff1_ln", True)
+        hcur = lin(f, P[q + "ff2"], sd[q + "ff.net.2.bias"], hw, residual=h2, out=h2, wf=P.get(q + "ff2#f"))
+        nb_.release(f)
+    out = lin(hcur, P[prefix + "pout"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True, wf=P.get(prefix + "pout#f"))
+    nb_.release(hcur, stats)
+    return out.view(n, h, w, m.ch)
+
+
+def rerun_if_layernorm_guard_tripped(unet_of):
+    """Decorator for a sampling loop (a method whose object leads to the UNetModel through `unet_of(self)`): after the run,
+    one host read of the folded-LayerNorm guard; if mean-dominated rows showed up anywhere along the trajectory the model has
+    switched to the unfolded prologue (UNetModel.layernorm_guard_tripped) and the run is repeated with it."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(self, *args, **kwargs):
+            out = fn(self, *args, **kwargs)
+            if not torch.cuda.is_current_stream_capturing() and unet_of(self).layernorm_guard_tripped():
+                out = fn(self, *args, **kwargs)
+            return out
+        return wrapped
+    return deco
 
 
 class UNetModel(nn.Module):
@@ -193,6 +373,9 @@ class UNetModel(nn.Module):
         self._programs = {}
         self._ctx_sig = None
         self.auto_repack = True
+        # LayerNorm folded through the product unless the guard (LN_GUARD_RATIO) has found mean-dominated rows in this model
+        self.ln_unfolded = ln_unfolded_default()
+        self._ln_flag = None
         # tile shapes are chosen from the problem size; set policy_batch = G to choose them as if the batch
         # were G, which makes per-sample results bitwise identical however a G-sample job is sharded
         self.policy_batch = None
@@ -244,24 +427,7 @@ class UNetModel(nn.Module):
                 P[prefix + "skip"] = ops.pack_linear(sd[prefix + "skip_connection.weight"])
 
         def stp(prefix, m):
-            P[prefix + "pin"] = ops.pack_linear(sd[prefix + "proj_in.weight"])
-            P[prefix + "pout"] = ops.pack_linear(sd[prefix + "proj_out.weight"])
-            for d in range(m.depth):
-                q = f"{prefix}transformer_blocks.{d}."
-                wqkv = torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0)
-                P[q + "qkv"] = ops.pack_linear(wqkv.contiguous())
-                P[q + "o1"] = ops.pack_linear(sd[q + "attn1.to_out.0.weight"])
-                P[q + "q2"] = ops.pack_linear(sd[q + "attn2.to_q.weight"])
-                P[q + "k2"] = ops.pack_linear(sd[q + "attn2.to_k.weight"])
-                P[q + "v2"] = ops.pack_linear(sd[q + "attn2.to_v.weight"])
-                P[q + "o2"] = ops.pack_linear(sd[q + "attn2.to_out.0.weight"])
-                P[q + "ff1"], P[q + "ff1b"] = ops.pack_geglu(sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"])
-                P[q + "ff2"] = ops.pack_linear(sd[q + "ff.net.2.weight"])
-                # LayerNorm folded through the Linear that follows it (LDMK_TF_LAYERNORM_FOLDED): gamma-scaled weights,
-                # their column sums and beta^T W + bias; the unfolded copies above stay for the training step
-                for k, nrm, b in (("qkv", "norm1", None), ("q2", "norm2", None), ("ff1", "norm3", P[q + "ff1b"])):
-                    P[q + k + "_ln"], P[q + k + "_ln#cs"], P[q + k + "_ln#b"] = ops.fold_layernorm(
-                        P[q + k], sd[q + nrm + ".weight"], sd[q + nrm + ".bias"], b)
+            pack_spatial_transformer(P, sd, prefix, m)
 
         emb_w, emb_b = [], []
         self._emb_off = {}
@@ -291,24 +457,8 @@ class UNetModel(nn.Module):
         P["te2"] = ops.pack_linear(sd["time_embed.2.weight"])
         P["out"] = ops.pack_conv3x3_narrow(sd["out.2.weight"])
         P["freqs"] = ops.timestep_freqs(self.model_channels, device=dev)
-        # fragment-order copies of the token-row Linear weights: the row GEMM (csrc/rgemm.hip) reads these
-        # (and the slab GEMM of the small-batch route, csrc/sgemm.hip, which also takes the ResBlock convolutions: c1 / c2)
-        for k in [k for k in P if k.rsplit(".", 1)[-1] in ("pin", "pout", "qkv_ln", "o1", "q2_ln", "o2", "ff1_ln", "ff2", "skip",
-                                                            "c1", "c2")
-                  or (_UNFOLDED and k.rsplit(".", 1)[-1] in ("qkv", "ff1"))]:
-            wf = ops.pack_wfrag(P[k])
-            if wf is not None:
-                P[k + "#f"] = wf
-        # bf16x3 images of the GEMM weights (LDMK_COMPUTE_BF16X3, include/ldmk.h): fp32-accurate products at the bf16 matrix
-        # rate; engine.Program.plan() uses them for the shapes dsml_thesis_amd/igemm_plans_x3.json lists
-        if engine_split_enabled():
-            for k in list(P):
-                tail = k.rsplit(".", 1)[-1]
-                if tail in ("pin", "pout", "qkv_ln", "o1", "ff1_ln", "ff2", "skip", "c1", "c2", "w"):
-                    if P[k].dim() == 2:
-                        P[k + "#s"] = ops.pack_wsplit(P[k])
-                elif tail in ("c1#wg", "c2#wg", "w#up"):
-                    P[k + "#s"] = ops.pack_wsplit(P[k], batch=P[k].shape[0])
+        pack_gemm_copies(P, self.ln_unfolded)
+        self._ln_flag = torch.zeros(1, device=dev, dtype=torch.int32)
         self._sd = sd
         self._packed = P
         self._pack_sig = self._signature()
@@ -382,99 +532,8 @@ class UNetModel(nn.Module):
             return out
 
         def spatial_tf(prefix, m, x, h, w):
-            hw = h * w
-            C_ = m.heads * m.d_head
-            rows = n * hw
-            xr = x.reshape(rows, m.ch)
-            coef = gn(x, None, hw, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-6)
-            hcur = lin(xr, P[prefix + "pin"], sd[prefix + "proj_in.bias"], hw, tf=L.TF_AFFINE, tf_coef=coef, wf=P.get(prefix + "pin#f"))
-            nb_.release(coef)
-            stats = pg.alloc(rows, 2)
-
-            def ln_lin(x2d, wkey, geglu):
-                """LayerNorm statistics + the Linear the LayerNorm is folded through.  Optionally (see below) the statistics pass
-                also writes the rows pre-split (three bf16 images) and the bf16x3 GEMM COPIES its A operand instead of splitting
-                every element once per N-tile."""
-                wp, xs = P[wkey], None
-                N_ = wp.shape[1]
-                # Measured at 64x64x4, B = 16 (r03 layer tables, one box): the GEGLU projections 269.0 / 198.5 / 209.6 -> 269.6 /
-                # 188.8 / 204.2 us, the QKV projections 99.5 / 90.6 / 70.4 -> 108.8 / 101.2 / 79.6 us, the statistics pass +4.5 us
-                # per call: 23.89 -> 24.45 ms per step.  Three 64-byte row streams of bf16 coalesce worse than one 128-byte fp32
-                # stream and are 1.5x the bytes; the split arithmetic they save was not what bounds the kernel.  OFF
-                # (LDMK_PRESPLIT_A=1 turns it on for experiments); the kernel path stays tested.
-                if engine_split_enabled() and C_ % 8 == 0 and os.environ.get("LDMK_PRESPLIT_A"):
-                    probe = ops.make_igemm_args(rows, N_, C_, x2d, C_, wp, x2d, N_ // 2 if geglu else N_, hw, bias=P[wkey + "#b"],
-                                                tf=L.TF_LAYERNORM_FOLDED, row_stats=stats, ln_colsum=P[wkey + "#cs"],
-                                                epi=L.EPI_GEGLU if geglu else L.EPI_NONE, w_frag=P.get(wkey + "#f"))
-                    pg.plan(probe, nb_.pin)
-                    if probe.compute == L.COMPUTE_BF16X3 and probe.tile_cfg <= 6:
-                        xs = pg.alloc(3, rows, C_, dtype=torch.bfloat16)
-                if xs is not None:
-                    pg.add("ldmk_ln_stats_split", p_(x2d), rows, C_, 1e-5, p_(stats), p_(xs), C_)
-                else:
-                    pg.add("ldmk_ln_stats", p_(x2d), rows, C_, 1e-5, p_(stats))
-                y = lin(x2d, wp, P[wkey + "#b"], hw, geglu=geglu, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
-                        ln_colsum=P[wkey + "#cs"], wf=P.get(wkey + "#f"), a_split=xs)
-                if xs is not None:
-                    nb_.release(xs)
-                return y
-
-            for d in range(m.depth):
-                q = f"{prefix}transformer_blocks.{d}."
-                # --- attn1 (self): LN1 folded into the fused QKV GEMM, flash attention, to_out + residual
-                if _UNFOLDED:
-                    pg.add("ldmk_ln_stats", p_(hcur), rows, C_, 1e-5, p_(stats))
-                    qkv = lin(hcur, P[q + "qkv"], None, hw, tf=L.TF_LAYERNORM, row_stats=stats,
-                              ln_gamma=sd[q + "norm1.weight"], ln_beta=sd[q + "norm1.bias"], wf=P.get(q + "qkv#f"))
-                else:
-                    qkv = ln_lin(hcur, q + "qkv_ln", False)
-                att = pg.alloc(rows, C_)
-                # both attention products in the fp32-accurate bf16x3 arithmetic (24 bf16 MFMAs of 32 cycles per 32 keys
-                # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel
-                pg.add("ldmk_attn_self_x3" if engine_split_enabled() else "ldmk_attn_self", p_(qkv), p_(att), n, hw, m.heads,
-                       m.d_head ** -0.5)
-                nb_.release(qkv)
-                if L_ctx == 1:
-                    # --- attn2 with a single context token: softmax over one key == 1, so the block adds
-                    # to_out(to_v(ctx)) to every position (exact); to_q/norm2 are dead (SURVEY K11).
-                    v = ctx_pg.alloc(n, C_)
-                    ctx_pg.add("ldmk_dense_small", p_(ctx_in), self.context_dim, p_(P[q + "v2"]), 0, p_(v), C_, n,
-                               self.context_dim, C_, 0)
-                    cvec = ctx_pg.alloc(n, C_)
-                    ctx_pg.add("ldmk_dense_small", p_(v), C_, p_(P[q + "o2"]), p_(sd[q + "attn2.to_out.0.bias"]), p_(cvec),
-                               C_, n, C_, C_, 0)
-                    h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur,
-                             batch_vec=cvec, batch_vec_ld=C_, wf=P.get(q + "o1#f"))   # + the per-sample cross-attention vector
-                    nb_.release(att)
-                    h2 = h1
-                else:
-                    h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur, wf=P.get(q + "o1#f"))
-                    kk = ctx_pg.alloc(n * L_ctx, C_)
-                    vv = ctx_pg.alloc(n * L_ctx, C_)
-                    ctx_pg.add("ldmk_dense_small", p_(ctx_in), self.context_dim, p_(P[q + "k2"]), 0, p_(kk), C_,
-                               n * L_ctx, self.context_dim, C_, 0)
-                    ctx_pg.add("ldmk_dense_small", p_(ctx_in), self.context_dim, p_(P[q + "v2"]), 0, p_(vv), C_,
-                               n * L_ctx, self.context_dim, C_, 0)
-                    pg.add("ldmk_ln_stats", p_(h1), rows, C_, 1e-5, p_(stats))
-                    q2 = lin(h1, P[q + "q2_ln"], P[q + "q2_ln#b"], hw, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
-                             ln_colsum=P[q + "q2_ln#cs"], out=att, wf=P.get(q + "q2_ln#f"))
-                    a2 = pg.alloc(rows, C_)
-                    pg.add("ldmk_attn_cross", p_(q2), C_, p_(kk), p_(vv), C_, p_(a2), C_, n, hw, L_ctx, m.heads,
-                           m.d_head ** -0.5)
-                    h2 = lin(a2, P[q + "o2"], sd[q + "attn2.to_out.0.bias"], hw, residual=h1, out=h1, wf=P.get(q + "o2#f"))
-                    nb_.release(att, a2)
-                # --- GEGLU feed-forward: LN3 folded into the first GEMM, gate in its epilogue
-                if _UNFOLDED:
-                    pg.add("ldmk_ln_stats", p_(h2), rows, C_, 1e-5, p_(stats))
-                    f = lin(h2, P[q + "ff1"], P[q + "ff1b"], hw, geglu=True, tf=L.TF_LAYERNORM, row_stats=stats,
-                            ln_gamma=sd[q + "norm3.weight"], ln_beta=sd[q + "norm3.bias"], wf=P.get(q + "ff1#f"))
-                else:
-                    f = ln_lin(h2, q + "ff1_ln", True)
-                hcur = lin(f, P[q + "ff2"], sd[q + "ff.net.2.bias"], hw, residual=h2, out=h2, wf=P.get(q + "ff2#f"))
-                nb_.release(f)
-            out = lin(hcur, P[prefix + "pout"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True, wf=P.get(prefix + "pout#f"))
-            nb_.release(hcur, stats)
-            return out.view(n, h, w, m.ch)
+            return emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_in, self.context_dim,
+                                            unfolded=self.ln_unfolded, ln_flag=self._ln_flag)
 
         def run_layers(prefix, layers, x0, x1, h, w, keep_input):
             """Returns (out, h, w). Releases intermediate tensors that no skip connection holds."""
@@ -518,9 +577,12 @@ class UNetModel(nn.Module):
             hcur = new
         coef = gn(hcur, None, ch_ * cw_, sd["out.0.weight"], sd["out.0.bias"], 1e-5)
         eps = pg.alloc(n, self.out_channels, H, W_)
-        # latent-sized images: 4x4-pixel workgroups with the weights in LDS (16x the workgroups of the 16x16-pixel form: 60 -> ~15 us at
-        # 32x32, B = 16); the choice depends on the image and channel counts only, never on the batch
-        co_small = H * W_ <= 64 * 64 and self._final_ch % 4 == 0 and 9 * self._final_ch * self.out_channels * 4 <= 60 * 1024
+        # 4x4-pixel workgroups with the weights in LDS while the 16x16-pixel form would leave CUs without a workgroup (16x the
+        # workgroups: 60 -> ~15 us at 32x32, B = 16); from one 16x16-pixel workgroup per CU up the larger tile wins (64x64, B = 16:
+        # 58 us against 166 us, r02 / r03 layer tables).  Decided on the plan-policy batch like every plan, so a sample's result
+        # does not depend on how its job is sharded.
+        co_small = (policy_n * H * W_ < 256 * 256 and self._final_ch % 4 == 0
+                    and 9 * self._final_ch * self.out_channels * 4 <= 60 * 1024)
         pg.add("ldmk_conv3x3_out_small" if co_small else "ldmk_conv3x3_out", p_(hcur), p_(coef), p_(P["out"]), p_(sd["out.2.bias"]),
                p_(eps), n, H, W_, self._final_ch, self.out_channels)
         pg.outputs = dict(eps=eps)
@@ -528,6 +590,20 @@ class UNetModel(nn.Module):
         return pg
 
     # ---- public surface ---------------------------------------------------------------------------
+    def layernorm_guard_tripped(self):
+        """Host read (one sync) of the flag the folded-LayerNorm statistics passes raise for rows with |mean| > LN_GUARD_RATIO
+        standard deviations.  If it is up, the model switches to the unfolded prologue for good (weights re-packed, programs
+        dropped) and True is returned: whatever was just computed with the folded form should be computed again."""
+        if self.ln_unfolded or self._ln_flag is None or int(self._ln_flag.item()) == 0:
+            return False
+        import warnings
+        warnings.warn(f"UNetModel: token rows with |mean| > {LN_GUARD_RATIO:g} standard deviations reached a LayerNorm; the folded "
+                      "form (LayerNorm through the product) loses accuracy on them -- switching this model to the unfolded "
+                      "prologue (LDMK_LN_UNFOLDED=1 starts there)", RuntimeWarning, stacklevel=3)
+        self.ln_unfolded = True
+        self.pack_weights()
+        return True
+
     def program(self, n, H, W_, L_ctx, c_concat=0):
         if self._packed is None or (self.auto_repack and self._pack_sig != self._signature()):
             self.pack_weights()
@@ -560,12 +636,20 @@ class UNetModel(nn.Module):
         cc = 0 if c_concat is None else c_concat.shape[1]
         assert cx + cc == self.in_channels, f"got {cx}+{cc} input channels, model has {self.in_channels}"
         assert context.shape[0] == n and context.shape[2] == self.context_dim
-        pg = self.program(n, H, W_, context.shape[1], cc)
-        pg.inputs["x"].copy_(x)
-        if cc:
-            pg.inputs["c_concat"].copy_(c_concat)
-        pg.inputs["t"].copy_(timesteps.to(torch.int64))
-        pg.inputs["context"].copy_(context.reshape(n * context.shape[1], self.context_dim))
-        pg.ctx_program.run()
-        pg.run()
+        for _ in range(2):
+            pg = self.program(n, H, W_, context.shape[1], cc)
+            pg.inputs["x"].copy_(x)
+            if cc:
+                pg.inputs["c_concat"].copy_(c_concat)
+            pg.inputs["t"].copy_(timesteps.to(torch.int64))
+            pg.inputs["context"].copy_(context.reshape(n * context.shape[1], self.context_dim))
+            pg.ctx_program.run()
+            pg.run()
+            # the first evaluation of every program checks the folded-LayerNorm guard (one host sync per program, none later;
+            # the samplers check once per run instead) and, if it tripped, evaluates again with the unfolded prologue
+            if getattr(pg, "ln_checked", False) or torch.cuda.is_current_stream_capturing():
+                break
+            pg.ln_checked = True
+            if not self.layernorm_guard_tripped():
+                break
         return pg.outputs["eps"].clone()

@@ -222,6 +222,11 @@ int ldmk_gn_finalize(const float* partial0, int c0, const float* partial1, int c
 int ldmk_gn_coef(const float* x0, int c0, const float* x1, int c1, int n, int hw, int groups, float eps,
                  const float* gamma, const float* beta, float* partial, float* coef, void* stream);
 int ldmk_ln_stats(const float* x, int rows, int c, float eps, float* stats, void* stream);
+/* the same pass with a guard for LDMK_TF_LAYERNORM_FOLDED consumers: rows with |mean| * rstd > guard (and NaN statistics) set
+ * *flag = 1 (device int, never cleared by the library).  The folded form subtracts mean * colsum(W') from x W' in fp32 and
+ * loses accuracy ~ |mean| / std on such rows; the caller reads the flag on the host once per program and rebuilds it with
+ * the unfolded prologue (LDMK_TF_LAYERNORM).  flag == NULL: plain ldmk_ln_stats. */
+int ldmk_ln_stats_guard(const float* x, int rows, int c, float eps, float* stats, float guard, int* flag, void* stream);
 /* the same statistics, and the rows themselves as the three bf16 images [3][rows][ld_split] of their exact split
  * (LDMK_COMPUTE_BF16X3's a_split operand): the pass reads every element anyway.  C % 4 == 0, C <= 1024, ld_split >= C, % 8 == 0. */
 int ldmk_ln_stats_split(const float* x, int rows, int C, float eps, float* stats, void* split, int ld_split, void* stream);

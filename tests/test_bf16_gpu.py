@@ -187,3 +187,40 @@ def test_bf16_forward_gemm_with_prepacked_weight_image_is_bitwise_the_in_kernel_
         ops.igemm(a)
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_bf16_weight_images_belong_to_their_trainer():
+    """The pre-packed bf16 forward-weight images are registered per trainer (train.Bf16Images), only for weights inside that
+    trainer's flat parameter buffer.  Build one bf16 trainer, run it, free it and return its memory to the driver; a second
+    trainer then repacks ONLY its own weights (the first one's addresses are gone) and computes the loss of a fresh trainer."""
+    import gc
+    with torch.enable_grad():
+        from test_train_gpu import SMALL, _setup
+        from dsml_thesis_amd import train as TR
+        m, _, sd, x0, noise, ctx, t = _setup(SMALL, 2, 16)
+        from oracle import ldm_oracle as O
+        from oracle import weights as W
+        sched = O.register_schedule(**W.SCHEDULE)
+        sa, sb = sched["sqrt_alphas_cumprod"].cuda(), sched["sqrt_one_minus_alphas_cumprod"].cuda()
+        args = (x0.cuda(), ctx.cuda(), t.cuda(), noise.cuda(), sa, sb)
+        tr1 = TR.UNetTrainer(m, compute="bf16")
+        l_first = tr1.p_losses(*args).item()          # registers the images
+        l1 = tr1.p_losses(*args).item()               # uses them
+        assert l_first == l1, "pre-packed images reproduce the in-kernel conversion bit for bit"
+        reg1 = tr1._wt16
+        assert reg1.images and all(reg1.owns(p) for p in reg1.images)
+        n_images = len(reg1.images)
+        del tr1, reg1
+        gc.collect()
+        torch.cuda.empty_cache()                      # the first trainer's parameter segment goes back to the driver
+        tr2 = TR.UNetTrainer(m, compute="bf16")
+        assert not tr2._wt16.images
+        l2a = tr2.p_losses(*args).item()
+        l2b = tr2.p_losses(*args).item()
+        assert TR._WT16 is tr2._wt16 and len(tr2._wt16.images) == n_images
+        assert l2a == l2b == l1
+        # two live trainers do not repack each other's weights
+        tr3 = TR.UNetTrainer(m, compute="bf16")
+        tr3.p_losses(*args)
+        assert set(tr3._wt16.images).isdisjoint(tr2._wt16.images)
+        assert tr2.p_losses(*args).item() == l1

@@ -394,7 +394,28 @@ def test_linear_layernorm_folded_through_the_product(ops, cfg, splitk, case):
         ops.linear(xc, w2, b2, ln_colsum=cs, row_stats=kw["row_stats"], stats_out=torch.zeros(M // 32 + 1, N, 3, device="cuda"))
 
 
-@pytest.mark.parametrize("ratio", [1.0, 30.0, 100.0])
+def test_layernorm_guard_flags_mean_dominated_rows(ops):
+    """ldmk_ln_stats_guard: same statistics as ldmk_ln_stats, and the device flag goes up exactly when some row has
+    |mean| * rstd above the limit (or NaN statistics); widths on the float4 path and on the scalar path."""
+    from dsml_thesis_amd import lib as L
+    for K in (160, 90):
+        x = rnd(96, 64, K)
+        x[17] += 3.0 * x[17].std()
+        st_ref = ops.ln_stats(x.cuda())
+        ratio = (st_ref[:, 0].abs() * st_ref[:, 1]).max().item()
+        assert 2.5 < ratio < 3.6
+        for limit, want in ((ratio * 1.05, 0), (ratio * 0.95, 1)):
+            flag, st = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.empty(64, 2, device="cuda")
+            L.call("ldmk_ln_stats_guard", x.cuda().data_ptr(), 64, K, 1e-5, st.data_ptr(), limit, flag.data_ptr(), ops.stream())
+            assert torch.equal(st, st_ref) and flag.item() == want, (K, limit)
+        xn = x.clone()
+        xn[3, 5] = float("nan")
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        L.call("ldmk_ln_stats_guard", xn.cuda().data_ptr(), 64, K, 1e-5, st.data_ptr(), 1e9, flag.data_ptr(), ops.stream())
+        assert flag.item() == 1
+
+
+@pytest.mark.parametrize("ratio", [1.0, 4.0, 8.0, 30.0, 100.0])
 def test_layernorm_folded_error_growth_with_mean_dominated_rows(ops, ratio):
     """The folded form subtracts mean * colsum(W') from x W' in fp32: when a row's |mean| is `ratio` times its spread the two
     terms cancel and the error grows ~ ratio * sqrt(K) * eps relative to the output scale.  This pins the growth (what a
@@ -414,6 +435,9 @@ def test_layernorm_folded_error_growth_with_mean_dominated_rows(ops, ratio):
     print(f"|mean|/std = {ratio:5.0f}: folded max error {err_f:.2e}, unfolded {err_u:.2e} (outputs up to {ref.abs().max().item():.1f})")
     assert err_u < 1e-4                                        # the unfolded prologue normalises before it multiplies
     assert err_f < 1e-4 * max(1.0, ratio / 5.0)                # measured: see DESIGN section 5
+    from dsml_thesis_amd.unet import LN_GUARD_RATIO
+    if ratio <= LN_GUARD_RATIO:                                # below the guard's limit the folded form stays inside the UNet bound
+        assert err_f < 3e-5, (ratio, err_f)
 
 
 def _linear_pinned(ops, x, wp, bias, splitk, **kw):

@@ -72,6 +72,16 @@ def test_config0_ddim50_batch1_end_to_end(fr, latent):
     out_g, _ = s.sample(S=50, batch_size=1, shape=[ch, latent, latent], conditioning=uc, eta=0.0, x_T=xT, verbose=False,
                         use_graph=True)
     assert torch.equal(out, out_g), "hipGraph replay must be bitwise identical to eager launches"
+    if latent == 64:
+        # the reference's own 50-step chain at the metric's shape (tests/golden/g13_config0.npz, tools/make_golden.py --tree
+        # config0: DDIMSampler.sample of the real reference, ~50 CPU evaluations at 64x64, generated in the build container)
+        g = golden("g13_config0.npz")
+        ref = T(g["ns_ddim50"])
+        d, top = (out.cpu() - ref).abs().max().item(), ref.abs().max().item()
+        print(f"config0 64x64x4: max |diff| vs the reference after 50 steps {d:.3e} (|x| up to {top:.2f})")
+        # 50 chained evaluations with random weights: |x| grows to ~350 and every element carries the trajectory's error, so
+        # the bound is relative to the tensor's scale: 1e-4 of max |x| (the oracle restatement itself is within 7e-7 of it)
+        assert d <= 1e-4 * top, (d, top)
     if latent == 32:
         usd = W.synth_state_dict(W.unet_param_shapes(W.FR_UNET), gain=0.25)
         ucw = torch.from_numpy(W.synth_tensor("uncond_embedding.weight", (1, 512)))
@@ -278,12 +288,56 @@ def test_talking_face_progressive_golden():
         frames, _ = s.progressive_sampling(c1, xid, masked.cuda(), audio, S, 1, Tn, [3, 32, 32], 1, eta=0.0, x_T=xT,
                                            fixed_identity=fixed, verbose=False)
         close(torch.cat(frames), g[f"frames_{tag}"], 2e-4, 2e-4)
+    # the batched TF program with the plan set of the 128-frame clip (configs[2]/[3] run fixed-identity frames at
+    # policy_batch = 128: bf16x3 table shapes, Winograd at every level) against the same reference frames
+    frames, _ = s.progressive_sampling(c1, xid, masked.cuda(), audio, S, 1, Tn, [3, 32, 32], 1, eta=0.0, x_T=xT,
+                                       fixed_identity=True, verbose=False, policy_batch=128)
+    unet = m.model.diffusion_model
+    assert unet.policy_batch == 128 and not getattr(unet.program(Tn, 32, 32, 1, 6), "small_route", False)
+    close(torch.cat(frames), g["frames_fixed"], 2e-4, 2e-4)
     # eager launches == captured graph, frame chain included
     fr_e, _ = s.progressive_sampling(c1, xid, masked.cuda(), audio, S, 1, Tn, [3, 32, 32], 1, eta=0.0, x_T=xT,
                                      use_graph=False, verbose=False)
     fr_g, _ = s.progressive_sampling(c1, xid, masked.cuda(), audio, S, 1, Tn, [3, 32, 32], 1, eta=0.0, x_T=xT,
                                      use_graph=True, verbose=False)
     assert torch.equal(torch.cat(fr_e), torch.cat(fr_g))
+
+
+@pytest.mark.parametrize("policy", [16, None])
+def test_talking_face_clips_in_lock_step(policy):
+    """progressive_sampling(..., clips=V): V independent videos (the reference loops over 150 of them,
+    progressive_sampling_difftalk.py:336), each its own autoregressive chain, advanced frame by frame as ONE batch.  Clip 0
+    is the g7 fixture's clip (reference frames); lengths are ragged (3, 2, 3 frames: the short clip leaves the batch); every
+    clip's frames equal bit for bit those of progressive_sampling on that clip alone at the same plan policy."""
+    from dsml_thesis_amd.ddim import DDIMSampler
+    g = golden("g7_talking_face.npz")
+    m = make_tf_model(gain=0.25, seq_len=3)
+    S, lens = 4, [3, 2, 3]
+    V = len(lens)
+    audio = [rnd(75 + 100 * v, T_, 768).cuda() for v, T_ in enumerate(lens)]
+    masked = []
+    for v, T_ in enumerate(lens):
+        mk = torch.tanh(rnd(76 + 100 * v, T_, 3, 128, 128))
+        mk[:, :, 70:, :] = -1.0
+        masked.append(mk.cuda())
+    ident = torch.cat([torch.tanh(rnd(77 + 100 * v, 1, 3, 128, 128)) for v in range(V)]).cuda()
+    labels = torch.tensor([[4], [1], [7]], device="cuda")
+    c1 = m.cond_stage_model_1.embedding(labels)                               # (V,1,256)
+    xid = torch.cat([m.encode_first_stage(ident[v:v + 1]) for v in range(V)])
+    xT = [rnd(78 + 100 * v, T_, 1, 3, 32, 32).cuda() for v, T_ in enumerate(lens)]
+    s = DDIMSampler(m)
+    clips, _ = s.progressive_sampling(c1, xid, masked, audio, S, 1, None, [3, 32, 32], 1, eta=0.0, x_T=xT, clips=V,
+                                      policy_batch=policy, verbose=False)
+    assert [len(f) for f in clips] == lens
+    close(torch.cat(clips[0]), g["frames_autoreg"], 2e-4, 2e-4)
+    for v in range(V):
+        alone, _ = s.progressive_sampling(c1[v:v + 1], xid[v:v + 1], masked[v], audio[v], S, 1, lens[v], [3, 32, 32], 1,
+                                          eta=0.0, x_T=xT[v], policy_batch=V if policy is None else policy, verbose=False)
+        assert torch.equal(torch.cat(alone), torch.cat(clips[v])), f"clip {v}"
+    # eager launches == hipGraph replay (one captured step per active count)
+    eager, _ = s.progressive_sampling(c1, xid, masked, audio, S, 1, None, [3, 32, 32], 1, eta=0.0, x_T=xT, clips=V,
+                                      policy_batch=policy, use_graph=False, verbose=False)
+    assert all(torch.equal(torch.cat(a), torch.cat(b)) for a, b in zip(eager, clips))
 
 
 def test_ema_scope_swaps_weights_and_repacks(fr):
@@ -303,6 +357,24 @@ def test_ema_scope_swaps_weights_and_repacks(fr):
     again = fr.apply_model(x, t, c[:1])
     close(ema, ref, 1.5e-4, 1.5e-4)
     assert not torch.allclose(base, ema) and torch.equal(base, again)
+    # the batched program (job batch 16): inside the scope the bf16x3 weight images and the Winograd / phase planes must be
+    # the EMA weights' too (ops.pack_wsplit follows the re-pack), and the live ones again after it
+    unet = fr.model.diffusion_model
+    unet.policy_batch = 16
+    try:
+        base16 = fr.apply_model(x, t, c[:1])
+        pg = unet.program(1, 32, 32, 1, 0)
+        assert not getattr(pg, "small_route", False)
+        from dsml_thesis_amd import lib as L
+        assert sum(1 for cl in pg.calls if cl[3] == "ldmk_igemm" and cl[2].compute == L.COMPUTE_BF16X3) >= 40
+        with fr.ema_scope():
+            ema16 = fr.apply_model(x, t, c[:1])
+        again16 = fr.apply_model(x, t, c[:1])
+    finally:
+        unet.policy_batch = None
+    close(ema16, ref, 1.5e-4, 1.5e-4)
+    close(base16, base, 3e-5, 3e-5)
+    assert not torch.allclose(base16, ema16) and torch.equal(base16, again16)
     keys = fr.state_dict().keys()
     assert "model.diffusion_model.input_blocks.1.0.in_layers.2.weight" in keys
     assert "model_ema.diffusion_modelinput_blocks10in_layers2weight" in keys

@@ -55,13 +55,49 @@ def test_resblock_golden_through_the_launch_program():
     assert torch.equal(out, first)
 
 
+@pytest.mark.parametrize("pin", [None, (16, 2), (128, 2)])
+@pytest.mark.parametrize("L_ctx", [1, 3])
+def test_spatial_transformer_golden_through_the_launch_program(L_ctx, pin):
+    """SURVEY row A8 on its own: SpatialTransformer(160, 5 heads x 32, context 512) at 8x8 (attention.py:218-261) against the
+    reference's outputs (g3 `spatial_transformer`, 1 context token: the fast path; `spatial_transformer_L3`, 3 tokens: the
+    general cross-attention), emitted by the same function UNetModel._build calls (unet.emit_spatial_transformer): GroupNorm
+    folded into proj_in, LayerNorm folded into QKV / GEGLU, flash attention, the per-sample cross-attention vector.  `pin`:
+    the job batch the plans are made for (None: this batch; 16 / 128: the plan sets of the benchmark / clip batches)."""
+    from dsml_thesis_amd import unet as U
+    from dsml_thesis_amd.engine import NetBuilder, Program
+    g = golden("g3_ops.npz")
+    keys = {}
+    W._spatial_transformer(keys, "", 160, 5, 32, 1, 512)
+    sd = {k: v.cuda() for k, v in W.synth_state_dict(keys, seed=7).items()}
+    m = U._spatial_transformer(160, 5, 32, 1, 512)
+    P = {}
+    U.pack_spatial_transformer(P, sd, "", m)
+    U.pack_gemm_copies(P)
+    n, h, w = 2, 8, 8
+    x, ctx = rnd(21, n, 160, h, w), rnd(22 if L_ctx == 1 else 23, n, L_ctx, 512)
+    pg, ctx_pg = Program("cuda"), Program("cuda")
+    nb = NetBuilder(pg, n, pin)
+    x0 = x.permute(0, 2, 3, 1).contiguous().cuda()
+    ctx_in = ctx.reshape(n * L_ctx, 512).cuda()
+    out = U.emit_spatial_transformer(nb, ctx_pg, P, sd, "", m, x0, h, w, L_ctx, ctx_in, 512)
+    names = [c[3] for c in pg.calls]
+    assert ("ldmk_attn_cross" in names) == (L_ctx == 3) and names.count("ldmk_ln_stats") == (2 if L_ctx == 1 else 3)
+    ctx_pg.run()
+    pg.run()
+    close(out.permute(0, 3, 1, 2), g["spatial_transformer" if L_ctx == 1 else "spatial_transformer_L3"], 1e-4, 1e-4)
+    first = out.clone()
+    pg.run()
+    assert torch.equal(out, first)
+
+
 ROUTES = ["small", "batched"]
 
 
 def _route(m, route, n, h, w, c_concat=0):
     """Pin the launch program the fixtures are held against: batch 1-2 takes the small-batch route (unet_small.py: slab
-    GEMMs + ldmk_post, the reference's talking-face mode), a job batch of 16 the batched program (unet.py)."""
-    m.policy_batch = None if route == "small" else 16
+    GEMMs + ldmk_post, the reference's talking-face mode), a job batch of 16 the batched program (unet.py); "batched128" is
+    the batched program with the plan set of the 128-frame clip (BASELINE configs[2]/[3]: policy_batch = 128)."""
+    m.policy_batch = {"small": None, "batched": 16, "batched128": 128}[route]
     pg = m.program(n, h, w, 1, c_concat)
     names = [c[3] for c in pg.calls]
     if route == "small":
@@ -87,11 +123,16 @@ def test_unet_fr_golden(route):
     assert torch.equal(eps, eps2)
 
 
-@pytest.mark.parametrize("route", ROUTES)
+@pytest.mark.parametrize("route", ROUTES + ["batched128"])
 def test_unet_tf_concat_golden(route):
     g = golden("g7_talking_face.npz")
     m, _ = make_unet(W.TF_UNET)
-    _route(m, route, 2, 32, 32, 6)
+    pg = _route(m, route, 2, 32, 32, 6)
+    if route == "batched128":             # the clip's program: bf16x3 table shapes of the B = 128 rows, Winograd at every level
+        from dsml_thesis_amd import lib as L
+        gemms = [c[2] for c in pg.calls if c[3] == "ldmk_igemm"]
+        assert sum(1 for a in gemms if a.compute == L.COMPUTE_BF16X3) >= 40
+        assert [c[3] for c in pg.calls].count("ldmk_winograd_input") >= 20
     x, t = rnd(71, 2, 3, 32, 32), torch.tensor([11, 756])
     c12, c34 = rnd(72, 2, 1, 1024), rnd(73, 2, 6, 32, 32)
     eps = m(x.cuda(), t.cuda(), context=c12.cuda(), c_concat=c34.cuda())
@@ -168,6 +209,38 @@ def test_unet_split_arithmetic_routes_against_the_reference_fixtures(monkeypatch
     assert (eps_a - eps_c).abs().max().item() < 1.5e-5
     monkeypatch.undo()
     engine._X3_TABLE = None
+
+
+def test_folded_layernorm_guard_switches_mean_dominated_models_to_the_unfolded_prologue():
+    """LayerNorm is folded through the Linear behind it by default; on rows whose |mean| is many standard deviations that form
+    cancels in fp32.  A checkpoint whose proj_in biases put the token rows at |mean| / std ~ 50 must still meet the oracle at the
+    UNet bound with NO environment variable set: the statistics passes raise the guard flag, the first evaluation reads it,
+    warns, re-packs with the unfolded prologue and evaluates again.  A well-conditioned model never leaves the folded form."""
+    import warnings
+    x, t, ctx = rnd(41, 2, 3, 32, 32), torch.tensor([3, 981]), rnd(42, 2, 1, 512)
+    m, sd = make_unet(W.FR_UNET)
+    m.policy_batch = 16                                  # the batched program (the small-batch route materialises LayerNorm anyway)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m(x.cuda(), t.cuda(), context=ctx.cuda())
+    assert not m.ln_unfolded and m._ln_flag.item() == 0
+    sd2 = {k: (v + 50.0 if k.endswith(".proj_in.bias") else v) for k, v in sd.items()}
+    from dsml_thesis_amd.unet import UNetModel
+    m2 = UNetModel(**W.FR_UNET)
+    m2.load_state_dict(sd2, strict=True)
+    m2 = m2.cuda().eval()
+    m2.policy_batch = 16
+    assert not m2.ln_unfolded
+    with pytest.warns(RuntimeWarning, match="unfolded"):
+        eps = m2(x.cuda(), t.cuda(), context=ctx.cuda())
+    assert m2.ln_unfolded
+    names = [c[3] for c in m2.program(2, 32, 32, 1, 0).calls]
+    assert "ldmk_ln_stats_guard" not in names and names.count("ldmk_ln_stats") == 32
+    ref = O.unet_forward(sd2, W.FR_UNET, x, t, ctx)
+    close(eps, ref, 3e-5, 3e-5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                   # decided once: later evaluations neither warn nor re-pack
+        assert torch.equal(m2(x.cuda(), t.cuda(), context=ctx.cuda()), eps)
 
 
 def test_unet_multi_token_context_vs_oracle():

@@ -665,6 +665,50 @@ def gen_northstar():
     save("g11_northstar.npz", **g)
 
 
+# --------------------------------------------------------------------------- BASELINE configs[0] at the metric's shape
+def gen_config0():
+    """G13: BASELINE configs[0] -- DDIM 50 steps, batch 1 -- at the 64x64x4 latent, from the real reference's
+    DDIMSampler.sample on the FR UNet's null-class token (DESIGN F8: a spatial-transformer UNet cannot run context=None),
+    weights gain 0.25 as in the 32x32x3 test.  ~50 CPU UNet evaluations at 64x64: minutes, so it is generated here and not
+    recomputed by the oracle on the GPU box."""
+    from tools import ref_shims
+    ref_shims.install("face_reenactment")
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    torch.set_grad_enabled(False)
+    unet_cfg = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(W.NS_UNET))
+    fs_cfg = dict(target="ldm.models.autoencoder.VQModelInterface",
+                  params=dict(embed_dim=4, n_embed=16384, ddconfig=dict(W.VQ_F4_256["ddconfig"]),
+                              lossconfig=dict(target="torch.nn.Identity")))
+    cond_cfg = dict(target="ldm.modules.encoders.modules.ClassEmbedder3",
+                    params=dict(embed_dim=512, n_classes=8, key="class_label", p_uncond=0.2))
+    ld = LatentDiffusion(first_stage_config=fs_cfg, cond_stage_config=cond_cfg, num_timesteps_cond=1,
+                         cond_stage_key="class_label", cond_stage_trainable=True,
+                         conditioning_key="crossattn", unet_config=unet_cfg, image_size=64, channels=4,
+                         first_stage_key="image", log_every_t=200, monitor="val_loss_ema", **W.SCHEDULE)
+    sched = O.register_schedule(**W.SCHEDULE)
+
+    class CPUDDIM(DDIMSampler):
+        def register_buffer(self, n, a):
+            setattr(self, n, a)
+
+    g = {}
+    print("[G13] configs[0]: DDIM-50, batch 1, 64x64x4, null-class token")
+    usd = load_recipe(ld.model.diffusion_model, seed=0, gain=0.25, prefix_check=W.unet_param_shapes(W.NS_UNET))
+    csd = load_recipe(ld.cond_stage_model, seed=0)
+    uc = ld.cond_stage_model.uncond_embedding(torch.zeros(1, 1, dtype=torch.long))
+    assert torch.equal(uc[0], csd["uncond_embedding.weight"])
+    xT = rnd(0, 1, 4, 64, 64)
+    ref, inter = CPUDDIM(ld).sample(S=50, batch_size=1, shape=[4, 64, 64], conditioning=uc, eta=0.0, x_T=xT, verbose=False,
+                                    log_every_t=10)
+    mine = O.ddim_sample(usd, W.NS_UNET, sched, 50, xT, cond=csd["uncond_embedding.weight"][None])
+    check("DDIMSampler.sample S=50 @64x64x4, B=1", ref, mine, 1e-3, 1e-3)
+    g["ns_ddim50"] = ref
+    g["ns_ddim50_x_inter"] = torch.stack(inter["x_inter"])
+    print("  |x| final", float(ref.abs().max()), "x_inter", len(inter["x_inter"]))
+    save("g13_config0.npz", **g)
+
+
 # --------------------------------------------------------------------------- sampler options (ddim.py:112-203, ddpm.py:1049-1216)
 class ShiftCorrector:
     """A deterministic stand-in for the (unshipped) score-corrector plugin: modify_score(model, e_t, x, t, c)."""
@@ -768,7 +812,7 @@ def gen_options():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar", "options"])
+    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0"])
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -784,6 +828,8 @@ if __name__ == "__main__":
         gen_northstar()
     elif a.tree == "options":
         gen_options()
+    elif a.tree == "config0":
+        gen_config0()
     else:
-        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar", "options"):
+        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", tree], cwd=ROOT)

@@ -42,7 +42,7 @@ def main():
     model, ucfg = build_model(a.latent, torch.device("cuda", 0))
     run = StepRunner(model, ucfg, a.batch, graph=False)
     pg = run.pg
-    calls = list(getattr(pg, "side_calls", None) or []) + list(pg.calls)      # (here the side launches run in line)
+    calls = list(pg.calls)
     names = sorted({c[3] for c in calls})
 
     def runner(skip):
