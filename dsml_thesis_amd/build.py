@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libldmk.so")
-SOURCES = ["igemm.hip", "rgemm.hip", "norms.hip", "attention.hip", "small.hip", "wgrad.hip", "backward.hip", "attention_bwd.hip", "winograd.hip", "post.hip", "sgemm.hip", "attention_small.hip", "attention_bf16.hip", "igemm_ws.hip"]
+SOURCES = ["igemm.hip", "rgemm.hip", "norms.hip", "attention.hip", "small.hip", "wgrad.hip", "backward.hip", "attention_bwd.hip", "winograd.hip", "post.hip", "sgemm.hip", "attention_small.hip", "attention_bf16.hip", "igemm_ws.hip", "igemm_ps.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
 # The attention kernels run their softmax on the MFMA results: keep the accumulators in VGPRs (MFMA VGPR form) instead of
 # AGPRs, otherwise every score / output tile costs a v_accvgpr_read + v_accvgpr_write round trip per register

@@ -1220,6 +1220,10 @@ constexpr int kNumSCfg = 8;
 const char* igemm_ws_unsupported(const ldmk_igemm_args& a, int wcfg, int splitk);
 int igemm_ws_dispatch(const ldmk_igemm_args& a, int wcfg, int splitk, float* ws, hipStream_t st);
 constexpr int kNumWCfg = 2;
+// the pre-split bf16x3 tiles (igemm_ps.hip): tile_cfg kNumCfg+kNumRCfg+kNumSCfg+kNumWCfg+1 .. +6
+const char* igemm_ps_unsupported(const ldmk_igemm_args& a, int pcfg, int splitk);
+int igemm_ps_dispatch(const ldmk_igemm_args& a, int pcfg, int splitk, float* ws, hipStream_t st);
+constexpr int kNumPCfg = 11;
 
 }  // namespace ldmk
 
@@ -1317,11 +1321,12 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   if (a.stats_out)
     LDMK_REQUIRE(a.M % 32 == 0 && a.rows_per_sample % 32 == 0 && a.epi == LDMK_EPI_NONE && a.batch <= 1,
                  "ldmk_igemm: stats_out needs M%%32==0, rows_per_sample%%32==0, no GEGLU, no batching");
-  LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg + kNumRCfg + kNumSCfg + kNumWCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]", a.tile_cfg,
-               kNumCfg + kNumRCfg + kNumSCfg + kNumWCfg);
+  LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg + kNumRCfg + kNumSCfg + kNumWCfg + kNumPCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]",
+               a.tile_cfg, kNumCfg + kNumRCfg + kNumSCfg + kNumWCfg + kNumPCfg);
   LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 64, "ldmk_igemm: splitk=%d outside [0,64]", a.splitk);
   LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.compute == LDMK_COMPUTE_BF16 || a.compute == LDMK_COMPUTE_BF16X3, "ldmk_igemm: compute=%d", a.compute);
-  if (a.compute == LDMK_COMPUTE_BF16X3) {
+  const bool ps_tile = a.tile_cfg > kNumCfg + kNumRCfg + kNumSCfg + kNumWCfg;
+  if (a.compute == LDMK_COMPUTE_BF16X3 && !ps_tile) {
     LDMK_REQUIRE(a.w_split && !a.b_trans && a.w_split_ld >= a.K && a.w_split_ld % 8 == 0,
                  "ldmk_igemm: LDMK_COMPUTE_BF16X3 needs w_split (ldmk_pack_wsplit), b_trans = 0, w_split_ld >= K and a multiple of 8");
     LDMK_REQUIRE(3LL * a.N * a.w_split_ld * 2 < (1LL << 32), "ldmk_igemm: w_split exceeds 4 GB per batch entry");
@@ -1348,6 +1353,21 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   if (a.tile_cfg > 0) cfg = a.tile_cfg;
   if (g_force_cfg > 0 && (g_force_cfg <= kNumCfg || !rgemm_unsupported(a, g_force_cfg - kNumCfg - 1))) cfg = g_force_cfg;
   LDMK_REQUIRE(!a.skip_a0 || cfg > kNumCfg + kNumRCfg, "ldmk_igemm: the fused skip connection runs on the slab GEMM only (tile_cfg 13..20)");
+  if (cfg > kNumCfg + kNumRCfg + kNumSCfg + kNumWCfg) {      // pre-split bf16x3 tile: both operands in the PS layout, LDS-DMA staging
+    const int pcfg = cfg - kNumCfg - kNumRCfg - kNumSCfg - kNumWCfg - 1;
+    int psk = a.splitk > 0 ? a.splitk : 1;
+    const char* why = igemm_ps_unsupported(a, pcfg, psk);
+    LDMK_REQUIRE(why == nullptr, "ldmk_igemm: tile_cfg=%d splitk=%d (pre-split bf16x3 tile) cannot run this problem: %s", cfg, psk, why ? why : "");
+    LDMK_REQUIRE(!a.raw_slabs || psk >= 2, "ldmk_igemm: raw_slabs needs a split-K plan");
+    if (psk > 1) {
+      const long long b = a.batch > 1 ? a.batch : 1;
+      LDMK_REQUIRE_MEM(a.splitk_ws && b * psk * (long long)a.M * a.N <= a.splitk_ws_elems,
+                       "ldmk_igemm: splitk=%d needs a workspace of %lld floats (ldmk_igemm_workspace_elems), %lld given", psk,
+                       b * psk * (long long)a.M * a.N, a.splitk_ws ? a.splitk_ws_elems : 0LL);
+    }
+    if (!launch) return LDMK_OK;
+    return igemm_ps_dispatch(a, pcfg, psk, a.splitk_ws, (hipStream_t)stream);
+  }
   if (cfg > kNumCfg + kNumRCfg + kNumSCfg) {      // warp-specialised bf16x3 tile: producer / consumer waves, split-K over workgroups
     const int wcfg = cfg - kNumCfg - kNumRCfg - kNumSCfg - 1;
     int wsk = a.splitk > 0 ? a.splitk : 1;

@@ -1,0 +1,818 @@
+// Implicit GEMM of the fp32-accurate bf16x3 arithmetic (LDMK_COMPUTE_BF16X3, include/ldmk.h) on PRE-SPLIT operands:
+// tile_cfg 23..30.
+//
+// Round 3 found the bf16x3 kernels (igemm.hip BF = 3, igemm_ws.hip) bound by what surrounds their matrix instructions: every
+// A element is loaded to registers, split three ways (~5.5 vector operations) and stored to LDS once per N-tile, next to waves
+// that try to issue MFMAs on the same SIMD (matrix pipe 34 % busy over a step).  Here NO operand passes through a register on
+// its way to LDS and no arithmetic is done on it:
+//   * both operands arrive already split, in the "PS" layout (include/ldmk.h): for a matrix X[R][K], the three bf16 planes of
+//     each (32-row block, 16-deep k-slab) are 3 x 1 KiB contiguous, each KiB in the lane order of the MFMA operand
+//     (lane = 32 (k / 8 % 2) + row % 32 holds 8 consecutive k: 16 bytes).  Producers write it: ldmk_pack_ps (weights, once),
+//     ldmk_ln_stats_ps (the LayerNorm statistics pass), the transposed epilogue of this kernel (out_ps), the Winograd /
+//     GroupNorm-apply passes;
+//   * a stage (16 k of a BM x BN tile) is filled by `buffer_load_dwordx4 ... lds` (LDS-DMA): one wave instruction moves one
+//     plane of one block, 1 KiB, memory -> LDS; a wave issues 2-3 groups of three per stage and nothing else;
+//   * fragments are read back with one conflict-free ds_read_b128 per operand (the LDS image IS the fragment order);
+//   * NS-deep ring of stages, the DMA of stage s + NS - 1 issued right after the barrier that frees its buffer, completion
+//     counted with s_waitcnt vmcnt(N) (the loads are inline asm: the compiler neither counts nor drains them), one raw
+//     s_barrier per stage.
+// The products, their order inside an accumulator (six bf16 MFMAs per 16 k, smallest partial product first) and the split-K
+// partition are those of igemm_kernel<BF = 3>: results are bitwise equal to tile_cfg 1 / 5 at equal splitk
+// (tests/test_ps_gpu.py).  Epilogues: the lane = column form of igemm_ws.hip (bias, per-sample vector, residual, folded
+// LayerNorm, GEGLU, GroupNorm records) or, TR = true, with the accumulators TRANSPOSED (operands swapped in the MFMA: lane =
+// row, registers = 4 x 4 consecutive columns), which stores float4 rows and can write the result pre-split in the PS layout
+// for the next GEMM (args.out_ps) -- each activation element is then split exactly once, by its producer.
+#include "ldmk_common.h"
+#include <stdlib.h>
+
+namespace ldmk {
+
+typedef __bf16 pbf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned PS_OOB = 0x80000000u;      // a byte offset beyond every buffer here (< 2 GiB each): reads as zeros, no memory traffic
+
+__device__ __forceinline__ pu32x4 ps_rsrc(const void* ptr, unsigned bytes) {      // raw buffer descriptor, uniform -> SGPRs
+  const unsigned long long a = (unsigned long long)ptr;
+  pu32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+
+// One unit = the three planes of one 32-row block at one k-slab: 3 KiB contiguous in memory and in the LDS stage.
+// LDS destination = M0 + instruction offset + 16 lane; memory address = base + voff + instruction offset (probed on gfx950:
+// tools/probe/dma_probe.hip); M0 is saved / restored around the group (the compiler owns it outside the statement).
+__device__ __forceinline__ void ps_dma3(unsigned voff, const pu32x4& rs, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+               "buffer_load_dwordx4 %1, %2, 0 offen offset:1024 lds\n\t"
+               "buffer_load_dwordx4 %1, %2, 0 offen offset:2048 lds\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void ps_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+
+__device__ __forceinline__ pbf16x4 ps_bf4(const float4& v) { return pbf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w}; }
+__device__ __forceinline__ void ps_split3(const float4& v, pbf16x4& h, pbf16x4& m, pbf16x4& l) {      // exact: h + m + l == v
+  h = ps_bf4(v);
+  const float4 r = make_float4(v.x - (float)h[0], v.y - (float)h[1], v.z - (float)h[2], v.w - (float)h[3]);
+  m = ps_bf4(r);
+  l = ps_bf4(make_float4(r.x - (float)m[0], r.y - (float)m[1], r.z - (float)m[2], r.w - (float)m[3]));
+}
+
+// Zeros for the optional epilogue operands: a NULL bias / column sum / per-sample vector / residual reads these instead, so the
+// epilogue has no branch around its loads (they are all requested before the first use) and adds exact zeros.
+__device__ __attribute__((aligned(16))) const float kPsZeros[4] = {0.f, 0.f, 0.f, 0.f};
+
+// The epilogue of one wave: acc[TM][TN] 32x32 tiles at (rowbase, colbase).  TR: transposed accumulators (lane = row).
+template <int TM, int TN, bool TR>
+__device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&acc)[TM][TN], const int rowbase, const int colbase,
+                                            const int splitk, const int ks, const int bz, float* __restrict__ ws, const int lane) {
+  const int l31 = lane & 31, half = lane >> 5;
+  const float alpha = p.alpha;
+  const bool lnf = p.a_tf == LDMK_TF_LAYERNORM_FOLDED;
+  const float2* __restrict__ stats2 = reinterpret_cast<const float2*>(p.row_stats);
+
+  if constexpr (TR) {
+    // ---- transposed accumulators: acc[i][j][r] = C[rowbase + 32 i + l31][colbase + 32 j + 8 (r >> 2) + 4 half + (r & 3)]
+    if (splitk > 1) {
+      float* slab = ws + ((long long)bz * splitk + ks) * p.M * p.N;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = rowbase + 32 * i + l31;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = colbase + 32 * j + 8 * q + 4 * half;
+            if (col < p.N)
+              *reinterpret_cast<float4*>(slab + (long long)row * p.N + col) =
+                  make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          }
+      }
+      return;
+    }
+    float* __restrict__ outp = p.out ? p.out + (long long)bz * p.out_bstride : nullptr;
+    unsigned char* __restrict__ ops_ = reinterpret_cast<unsigned char*>(p.out_ps);
+    const bool geglu = p.epi == LDMK_EPI_GEGLU;
+    const int Kbo = p.ldc / 16;                     // k-slabs per row block of the PS output (ldc = its column count)
+    // optional operands: a missing one reads kPsZeros (column / row offsets masked to 0), so every load below is unconditional
+    const float* __restrict__ csp = lnf ? p.ln_colsum : kPsZeros;
+    const float* __restrict__ bip = p.bias ? p.bias : kPsZeros;
+    const float* __restrict__ rsp = p.residual ? p.residual + (long long)bz * p.out_bstride : kPsZeros;
+    const unsigned mcs = lnf ? ~0u : 0u, mbi = p.bias ? ~0u : 0u, mrs = p.residual ? ~0u : 0u, mbv = p.batch_vec ? ~0u : 0u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = rowbase + 32 * i + l31;
+      const bool rok = row < p.M;
+      const int rr = rok ? row : p.M - 1;
+      float mean = 0.f, rstd = 1.f;
+      if (lnf) { const float2 st = stats2[rr]; mean = st.x; rstd = st.y; }
+      const float* __restrict__ bvp = p.batch_vec ? p.batch_vec + (long long)(rr / p.rows_per_sample) * p.batch_vec_ld : kPsZeros;
+      const unsigned rowoff = (unsigned)rr * (unsigned)p.ldc;
+      const long long psrow = ((long long)((rowbase + 32 * i) >> 5) * Kbo) * 3072 + l31 * 16 + half * 8;
+      constexpr int JS = (TN % 2 == 0) ? 2 : 1;      // GEGLU (even TN only): tile j = values, tile j + 1 = gates
+#pragma unroll
+      for (int j = 0; j < TN; j += JS) {
+#pragma unroll
+        for (int jj = 0; jj < JS; ++jj) {
+          if (geglu && jj == 1) break;
+          const int jt = j + jj;
+          const int ctile = colbase + 32 * jt;
+          if (ctile >= p.N) continue;
+          const int otile = geglu ? (ctile >> 1) : ctile;            // first output column of this tile
+#pragma unroll
+          for (int qh = 0; qh < 4; qh += 2) {                        // (two column groups at a time: registers)
+          float4 cs[4], bi[4], bv[4], rs[4], csg[4], big[4];
+#pragma unroll
+          for (int q = qh; q < qh + 2; ++q) {                        // their operands are all requested before the first use
+            const unsigned c = (unsigned)(ctile + 8 * q + 4 * half), oc = (unsigned)(otile + 8 * q + 4 * half);
+            cs[q] = *reinterpret_cast<const float4*>(csp + (c & mcs));
+            bi[q] = *reinterpret_cast<const float4*>(bip + (c & mbi));
+            bv[q] = *reinterpret_cast<const float4*>(bvp + (oc & mbv));
+            rs[q] = *reinterpret_cast<const float4*>(rsp + ((rowoff + oc) & mrs));
+            if constexpr (TN % 2 == 0) {
+              if (geglu) {
+                csg[q] = *reinterpret_cast<const float4*>(csp + ((c + 32) & mcs));
+                big[q] = *reinterpret_cast<const float4*>(bip + ((c + 32) & mbi));
+              }
+            }
+          }
+#pragma unroll
+          for (int q = qh; q < qh + 2; ++q) {
+            float4 v = make_float4(acc[i][jt][4 * q] * alpha, acc[i][jt][4 * q + 1] * alpha, acc[i][jt][4 * q + 2] * alpha,
+                                   acc[i][jt][4 * q + 3] * alpha);
+            if (lnf) {      // same arithmetic as igemm.hip / rgemm.hip / igemm_reduce_kernel
+              v.x = fmaf(-mean, cs[q].x, v.x) * rstd; v.y = fmaf(-mean, cs[q].y, v.y) * rstd;
+              v.z = fmaf(-mean, cs[q].z, v.z) * rstd; v.w = fmaf(-mean, cs[q].w, v.w) * rstd;
+            }
+            v.x += bi[q].x; v.y += bi[q].y; v.z += bi[q].z; v.w += bi[q].w;
+            if constexpr (TN % 2 == 0) {
+              if (geglu) {
+                constexpr int TNm1 = TN - 1;
+                const int jg = jt + 1 < TN ? jt + 1 : TNm1;       // (jt + 1 < TN whenever this branch runs)
+                float4 g = make_float4(acc[i][jg][4 * q] * alpha, acc[i][jg][4 * q + 1] * alpha, acc[i][jg][4 * q + 2] * alpha,
+                                       acc[i][jg][4 * q + 3] * alpha);
+                if (lnf) {
+                  g.x = fmaf(-mean, csg[q].x, g.x) * rstd; g.y = fmaf(-mean, csg[q].y, g.y) * rstd;
+                  g.z = fmaf(-mean, csg[q].z, g.z) * rstd; g.w = fmaf(-mean, csg[q].w, g.w) * rstd;
+                }
+                g.x += big[q].x; g.y += big[q].y; g.z += big[q].z; g.w += big[q].w;
+                v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w);
+              }
+            }
+            v.x += bv[q].x; v.y += bv[q].y; v.z += bv[q].z; v.w += bv[q].w;
+            v.x += rs[q].x; v.y += rs[q].y; v.z += rs[q].z; v.w += rs[q].w;
+            if (rok) {
+              const int oc = otile + 8 * q + 4 * half;               // output column
+              if (outp) *reinterpret_cast<float4*>(outp + rowoff + oc) = v;
+              if (ops_) {
+                pbf16x4 h, m, l;
+                ps_split3(v, h, m, l);
+                unsigned char* d = ops_ + psrow + (long long)((otile >> 4) + (q >> 1)) * 3072 + (q & 1) * 512;
+                *reinterpret_cast<pbf16x4*>(d) = h;
+                *reinterpret_cast<pbf16x4*>(d + 1024) = m;
+                *reinterpret_cast<pbf16x4*>(d + 2048) = l;
+              }
+            }
+          }
+          }
+        }
+      }
+    }
+    return;
+  } else {
+    // ---- epilogue, lane = column (igemm_ws.hip's).  C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    if (splitk > 1) {   // raw partial slab [ks][M][N]; igemm_reduce_kernel (or the consumer, raw_slabs) sums them
+      float* slab = ws + ((long long)bz * splitk + ks) * p.M * p.N;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = colbase + j * 32 + l31;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < p.M) slab[(long long)row * p.N + col] = acc[i][j][r];
+          }
+      }
+      return;
+    }
+    float* __restrict__ outp = p.out + (long long)bz * p.out_bstride;
+    const float* resp = p.residual ? p.residual + (long long)bz * p.out_bstride : nullptr;
+    if (p.epi == LDMK_EPI_GEGLU) {
+      if constexpr (TN % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; j += 2) {
+          const int cv = colbase + j * 32 + l31;        // packed value column
+          const int cg = cv + 32;                       // packed gate column
+          if (cv >= p.N) continue;
+          const int oc = ((colbase + j * 32) >> 1) + l31;
+          const float bv = p.bias ? p.bias[cv] : 0.f, bg = p.bias ? p.bias[cg] : 0.f;
+          const float csv = lnf ? p.ln_colsum[cv] : 0.f, csg = lnf ? p.ln_colsum[cg] : 0.f;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            float2 st[16];
+            if (lnf) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) st[r] = stats2[min(rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.M - 1)];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              if (row < p.M) {
+                float v = acc[i][j][r] * alpha, g = acc[i][j + 1][r] * alpha;
+                if (lnf) {
+                  v = fmaf(-st[r].x, csv, v) * st[r].y;
+                  g = fmaf(-st[r].x, csg, g) * st[r].y;
+                }
+                v += bv;
+                g += bg;
+                outp[(long long)row * p.ldc + oc] = v * gelu_erf_f(g);
+              }
+            }
+          }
+        }
+      }
+      return;
+    }
+    const bool tile_in_sample = p.rows_per_sample % 32 == 0;
+    int smp[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) smp[i] = p.batch_vec ? min(rowbase + i * 32, p.M - 1) / p.rows_per_sample : 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = colbase + j * 32 + l31;
+      if (col >= p.N) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+      const float cs = lnf ? p.ln_colsum[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float vals[16];
+        const int r0 = rowbase + i * 32 + 4 * half;
+        if (lnf) {
+          float2 st[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[r] = stats2[min(r0 + (r & 3) + 8 * (r >> 2), p.M - 1)];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(-st[r].x, cs, acc[i][j][r] * alpha) * st[r].y;
+        }
+        const unsigned obase = (unsigned)r0 * (unsigned)p.ldc + (unsigned)col;
+        const float vec = (p.batch_vec && tile_in_sample) ? p.batch_vec[(long long)smp[i] * p.batch_vec_ld + col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          float v = 0.f;
+          if (r0 + dr < p.M) {
+            v = (lnf ? acc[i][j][r] : acc[i][j][r] * alpha) + bv;
+            if (p.batch_vec) v += tile_in_sample ? vec : p.batch_vec[(long long)((r0 + dr) / p.rows_per_sample) * p.batch_vec_ld + col];
+            const unsigned o = obase + (unsigned)(dr * p.ldc);
+            if (resp) v += resp[o];
+            outp[o] = v;
+          }
+          vals[r] = v;
+        }
+        if (p.stats_out && rowbase + i * 32 < p.M) {
+          // GroupNorm partial record of this 32-row tile x column (the record of gn_partial_kernel / igemm_kernel)
+          const float shift = __shfl(vals[0], l31, 64);      // row 0 of the tile
+          float sm = 0.f, sq = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = vals[r] - shift;
+            sm += d;
+            sq = fmaf(d, d, sq);
+          }
+          sm += __shfl_xor(sm, 32, 64);
+          sq += __shfl_xor(sq, 32, 64);
+          if (half == 0) {
+            float* d = p.stats_out + ((long long)((rowbase + i * 32) >> 5) * p.N + col) * 3;
+            d[0] = shift; d[1] = sm; d[2] = sq;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NWM, int NWN, int TM, int TN, int NS, bool TR>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int dbg) {
+  constexpr int NW = NWM * NWN;
+  constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN;
+  constexpr int FA = BM / 32, FB = BN / 32, U = FA + FB;          // units (3-plane blocks) per stage
+  constexpr int UHI = (U + NW - 1) / NW, ULO = U / NW;            // units a wave fetches per stage
+  constexpr int STAGE = U * 3072;                                   // bytes
+  static_assert(3 * UHI * (NS - 1) <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_ps[];      // [NS][STAGE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / NWN, wn = wave - wm * NWN;
+
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (bid % tiles_m) * BM;
+  const int n0 = (bid / tiles_m) * BN;
+  const int ks = blockIdx.y, bz = blockIdx.z;
+
+  const int nkc = p.K / 32;
+  const int it_per = (nkc + splitk - 1) / splitk;
+  const int it_begin = ks * it_per;
+  const int it_end = min(nkc, it_begin + it_per);
+  const int n16 = it_end > it_begin ? 2 * (it_end - it_begin) : 0;
+  const int Kb = p.K / 16;
+  const int Mb = (p.M + 31) / 32, Nb = p.N / 32;
+
+  // (dbg, probe runs only -- LDMK_PS_DEBUG: bit 0 = zero-record descriptors: every DMA is issued but dropped by the range check,
+  //  no memory traffic; bit 1 = no DMA instructions at all; bit 2 = no matrix instructions.  Results are garbage then.)
+  const pu32x4 rs_a = ps_rsrc(reinterpret_cast<const unsigned char*>(p.a_ps) + (long long)bz * p.a_ps_bstride, (dbg & 1) ? 0u : (unsigned)Mb * (unsigned)Kb * 3072u);
+  const pu32x4 rs_b = ps_rsrc(reinterpret_cast<const unsigned char*>(p.w_ps) + (long long)bz * p.w_ps_bstride, (dbg & 1) ? 0u : (unsigned)Nb * (unsigned)Kb * 3072u);
+  // this wave's units u = wave + NW i: byte offset of the block's first k-slab (wave-uniform), or PS_OOB for blocks past the edge
+  unsigned ubase[UHI];
+#pragma unroll
+  for (int i = 0; i < UHI; ++i) {
+    const int u = wave + NW * i;
+    const int blk = u < FA ? m0 / 32 + u : n0 / 32 + (u - FA);
+    const bool ok = u < U && (u < FA ? blk < Mb : blk < Nb);
+    ubase[i] = ok ? (unsigned)blk * (unsigned)Kb * 3072u + (unsigned)(2 * it_begin) * 3072u : PS_OOB;
+  }
+  const unsigned lane16 = lane * 16;
+  const unsigned lds0 = (unsigned)(size_t)smem_ps;
+  auto issue = [&](int s) {                     // the DMA of local stage s into ring buffer s % NS (stages past the end: zeros)
+    const unsigned buf = lds0 + (unsigned)(s % NS) * STAGE;
+    const bool live = s < n16;
+#pragma unroll
+    for (int i = 0; i < UHI; ++i) {
+      const int u = wave + NW * i;
+      if (u < U && !(dbg & 2)) {                 // (wave-uniform)
+        const unsigned off = (live && ubase[i] != PS_OOB) ? ubase[i] + (unsigned)s * 3072u : PS_OOB;
+        ps_dma3(lane16 + off, u < FA ? rs_a : rs_b, buf + (unsigned)u * 3072u);
+      }
+    }
+  };
+  const bool hi_wave = wave + NW * (UHI - 1) < U;       // fetches UHI units per stage (else ULO)
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s);
+  for (int it = 0; it < n16; ++it) {
+    // stage `it` of THIS wave has landed when all but the (NS - 2) younger stages' loads are done; the barrier then makes
+    // every wave's part visible and certifies that buffer (it - 1) % NS is no longer read
+    if (hi_wave) ps_wait_vm<3 * UHI * (NS - 2)>(); else ps_wait_vm<3 * ULO * (NS - 2)>();
+    asm volatile("s_barrier" ::: "memory");
+    issue(it + NS - 1);
+    const unsigned char* sb = smem_ps + (it % NS) * STAGE + lane16;
+    pbf16x8 a8[3][TM];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a8[g][i] = *reinterpret_cast<const pbf16x8*>(sb + ((wm * TM + i) * 3 + g) * 1024);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      pbf16x8 b8[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) b8[g] = *reinterpret_cast<const pbf16x8*>(sb + ((FA + wn * TN + j) * 3 + g) * 1024);
+      if (dbg & 4) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int g = 0; g < 3; ++g) asm volatile("" :: "v"(a8[g][i]), "v"(b8[g]));
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        // smallest partial products first (planes: 0 = hi, 1 = mid, 2 = lo) -- the order of igemm_kernel<BF = 3>
+        if constexpr (TR) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[0], a8[2][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[2], a8[0][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[1], a8[1][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[0], a8[1][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[1], a8[0][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[0], a8[0][i], acc[i][j], 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][i], b8[0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[0], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  ps_wait_vm<0>();             // (the trailing out-of-range loads still target this workgroup's LDS)
+  ps_epilogue<TM, TN, TR>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same GEMM, warp-specialised (tile_cfg 29 / 30): probes of the kernel above (LDMK_PS_DEBUG) showed its fragment reads and
+// its matrix instructions taking TURNS -- every wave reads after the barrier, then multiplies; with the matrix work removed
+// a stage still costs what the matrix work alone costs -- and the DMA issue (~100 cycles of stall per piece) sitting in the
+// same in-order stream.  Here:
+//   * waves 0-3 are CONSUMERS, one per SIMD with the whole 512-register budget: each owns 64 rows x BN columns of a 256 x BN
+//     tile (BN = 160 / 128) and runs ONE continuous software pipeline over all stages -- the fragments of MFMA group j + 1
+//     (and, at a stage's last group, the first fragments of the NEXT stage) are requested before group j is issued, so no
+//     matrix instruction waits for LDS, also not across the stage boundary;
+//   * waves 4-7 are PRODUCERS: nothing but the LDS-DMA pieces of the ring (NS = 4 stages of 16 k), the counted wait and the
+//     barrier; their issue stalls cost no matrix time;
+//   * one barrier per stage, and it certifies the stage AFTER the one about to be multiplied (that is what lets the consumer
+//     read ahead across the boundary): at barrier `it` the producers have waited for stage it + 1 and the consumers have
+//     finished reading stage it - 1, whose buffer the producers then refill with stage it + 3.
+// Same products in the same order into every accumulator as the kernel above: bitwise equal results.
+template <int TM, int TN, int NS, bool TR>
+__global__ __launch_bounds__(512) void igemm_pw_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int dbg) {
+  constexpr int BM = 128 * TM, BN = 32 * TN;
+  constexpr int FA = BM / 32, FB = TN, U = FA + FB;
+  constexpr int UHI = (U + 3) / 4, ULO = U / 4;                   // units a producer wave fetches per stage
+  constexpr int STAGE = U * 3072;
+  static_assert(NS >= 3 && 3 * UHI * (NS - 2) <= 63, "ring depth / vmcnt range");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_ps[];      // [NS][STAGE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (bid % tiles_m) * BM;
+  const int n0 = (bid / tiles_m) * BN;
+  const int ks = blockIdx.y, bz = blockIdx.z;
+  const int nkc = p.K / 32;
+  const int it_per = (nkc + splitk - 1) / splitk;
+  const int it_begin = ks * it_per;
+  const int it_end = min(nkc, it_begin + it_per);
+  const int n16 = it_end > it_begin ? 2 * (it_end - it_begin) : 0;      // even
+  const unsigned lane16 = lane * 16;
+
+  if (wave >= 4) {
+    // ---------------------------------------------------------------- producers
+    const int pw = wave - 4;
+    const int Kb = p.K / 16;
+    const int Mb = (p.M + 31) / 32, Nb = p.N / 32;
+    const pu32x4 rs_a = ps_rsrc(reinterpret_cast<const unsigned char*>(p.a_ps) + (long long)bz * p.a_ps_bstride, (dbg & 1) ? 0u : (unsigned)Mb * (unsigned)Kb * 3072u);
+    const pu32x4 rs_b = ps_rsrc(reinterpret_cast<const unsigned char*>(p.w_ps) + (long long)bz * p.w_ps_bstride, (dbg & 1) ? 0u : (unsigned)Nb * (unsigned)Kb * 3072u);
+    unsigned ubase[UHI];
+#pragma unroll
+    for (int i = 0; i < UHI; ++i) {
+      const int u = pw + 4 * i;
+      const int blk = u < FA ? m0 / 32 + u : n0 / 32 + (u - FA);
+      const bool ok = u < U && (u < FA ? blk < Mb : blk < Nb);
+      ubase[i] = ok ? (unsigned)blk * (unsigned)Kb * 3072u + (unsigned)(2 * it_begin) * 3072u : PS_OOB;
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem_ps;
+    auto issue = [&](int s) {
+      const unsigned buf = lds0 + (unsigned)(s % NS) * STAGE;
+      const bool live = s < n16;
+#pragma unroll
+      for (int i = 0; i < UHI; ++i) {
+        const int u = pw + 4 * i;
+        if (u < U && !(dbg & 2)) {
+          const unsigned off = (live && ubase[i] != PS_OOB) ? ubase[i] + (unsigned)s * 3072u : PS_OOB;
+          ps_dma3(lane16 + off, u < FA ? rs_a : rs_b, buf + (unsigned)u * 3072u);
+        }
+      }
+    };
+    const bool hi_wave = pw + 4 * (UHI - 1) < U;
+    // (dbg & 8, probe runs: cycle totals of the phases go to args.splitk_counters as [workgroup][wave][4] 64-bit ticks)
+    unsigned long long t_acc[3] = {0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = t_last;
+#define PW_T(i) do { if (dbg & 8) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[i] += t_ - t_last; t_last = t_; } } while (0)
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s);
+    PW_T(0);
+    if (hi_wave) ps_wait_vm<3 * UHI * (NS - 2)>(); else ps_wait_vm<3 * ULO * (NS - 2)>();      // stage 0
+    PW_T(1);
+    asm volatile("s_barrier" ::: "memory");
+    PW_T(2);
+    for (int it = 0; it < n16; ++it) {
+      if (hi_wave) ps_wait_vm<3 * UHI * (NS - 3)>(); else ps_wait_vm<3 * ULO * (NS - 3)>();    // stage it + 1
+      PW_T(1);
+      asm volatile("s_barrier" ::: "memory");
+      PW_T(2);
+      issue(it + NS - 1);
+      PW_T(0);
+    }
+    ps_wait_vm<0>();
+    if ((dbg & 8) && lane == 0 && p.splitk_counters) {
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(p.splitk_counters) + ((long long)blockIdx.x * 8 + wave) * 4;
+      d[0] = t_acc[0]; d[1] = t_acc[1]; d[2] = t_acc[2]; d[3] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ consumers
+  const int wm = wave;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const unsigned char* abase = smem_ps + wm * TM * 3072 + lane16;
+  const unsigned char* bbase = smem_ps + FA * 3072 + lane16;
+  pbf16x8 A2[2][3][TM], B2[2][3];
+  auto ldA = [&](pbf16x8 (&a)[3][TM], int buf) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[g][i] = *reinterpret_cast<const pbf16x8*>(abase + buf * STAGE + (i * 3 + g) * 1024);
+  };
+  auto ldB = [&](pbf16x8 (&b)[3], int buf, int j) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) b[g] = *reinterpret_cast<const pbf16x8*>(bbase + buf * STAGE + (j * 3 + g) * 1024);
+  };
+  unsigned long long t_acc[3] = {0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = t_last;
+  asm volatile("s_barrier" ::: "memory");                     // stage 0 is in LDS
+  PW_T(2);
+  ldA(A2[0], 0);
+  ldB(B2[0], 0, 0);
+  int buf = 0;
+  for (int it = 0; it < n16; it += 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                             // two stages per trip: the register roles come back
+      const int nbuf = buf + 1 == NS ? 0 : buf + 1;
+      PW_T(0);
+      asm volatile("s_barrier" ::: "memory");                 // stage it + h + 1 is in LDS, stage it + h - 1 may be overwritten
+      PW_T(2);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        constexpr int unused = 0;
+        (void)unused;
+        const int cur = (h * TN + j) & 1;
+        // request the next group's fragments before this group's matrix instructions
+        if (j + 1 < TN) {
+          ldB(B2[cur ^ 1], buf, j + 1);
+        } else {
+          ldA(A2[h ^ 1], nbuf);
+          ldB(B2[cur ^ 1], nbuf, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            // smallest partial products first (planes: 0 = hi, 1 = mid, 2 = lo) -- the order of igemm_kernel<BF = 3>
+            if constexpr (TR) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B2[cur][0], A2[h][2][i], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B2[cur][2], A2[h][0][i], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B2[cur][1], A2[h][1][i], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B2[cur][0], A2[h][1][i], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B2[cur][1], A2[h][0][i], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B2[cur][0], A2[h][0][i], acc[i][j], 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[h][2][i], B2[cur][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[h][0][i], B2[cur][2], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[h][1][i], B2[cur][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[h][1][i], B2[cur][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[h][0][i], B2[cur][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[h][0][i], B2[cur][0], acc[i][j], 0, 0, 0);
+            }
+        }
+      }
+      buf = nbuf;
+    }
+  }
+  PW_T(0);
+  ps_epilogue<TM, TN, TR>(p, acc, m0 + wm * 32 * TM, n0, splitk, ks, bz, ws, lane);
+  PW_T(1);
+  if ((dbg & 8) && lane == 0 && p.splitk_counters) {
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(p.splitk_counters) + ((long long)blockIdx.x * 8 + wave) * 4;
+    d[0] = t_acc[0]; d[1] = t_acc[1]; d[2] = t_acc[2]; d[3] = __builtin_amdgcn_s_memtime() - t_begin;
+  }
+#undef PW_T
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Producers of the PS layout.
+//   element (r, k), plane g of X[R][K] -> bf16 index (((r / 32) (K / 16) + k / 16) 3 + g) 512 + ((k / 8 % 2) 32 + r % 32) 8 + k % 8
+
+// generic packer: X[r][k] = src[r rs + k ks] (weights W[K][N]: rs = 1, ks = ldb; row-major activations: rs = ld, ks = 1).
+// Workgroup = one 32-row block x 64 k; thread = (row, 8 consecutive k): 128-byte runs on the store side.
+__global__ __launch_bounds__(256) void pack_ps_kernel(const float* __restrict__ src, int R, int K, long long rs, long long ks,
+                                                      long long src_bstride, unsigned char* __restrict__ dst, long long dst_bstride) {
+  const int rb = blockIdx.x, kc = blockIdx.y;
+  src += (long long)blockIdx.z * src_bstride;
+  dst += (long long)blockIdx.z * dst_bstride;
+  const int r = threadIdx.x >> 3, o = threadIdx.x & 7;
+  const int row = rb * 32 + r, k0 = kc * 64 + o * 8;
+  if (k0 >= K) return;
+  float v[8];
+  if (row < R) {
+    if (ks == 1) {
+      const float4 a = *reinterpret_cast<const float4*>(src + row * rs + k0), b = *reinterpret_cast<const float4*>(src + row * rs + k0 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = src[row * rs + (long long)(k0 + e) * ks];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  }
+  pbf16x4 h0, m0, l0, h1, m1, l1;
+  ps_split3(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
+  ps_split3(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+  unsigned char* d = dst + ((long long)rb * (K / 16) + (k0 >> 4)) * 3072 + ((o & 1) * 32 + r) * 16;
+  *reinterpret_cast<pbf16x8*>(d) = pbf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+  *reinterpret_cast<pbf16x8*>(d + 1024) = pbf16x8{m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+  *reinterpret_cast<pbf16x8*>(d + 2048) = pbf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+}
+
+// LayerNorm statistics (the two-pass form of ln_stats_kernel, values held in registers) AND the rows in the PS layout: the pass
+// reads every element anyway.  Workgroup = one 32-row block; thread = (row, k-octet o of every 64-wide chunk); the 8 threads
+// of a row are 8 consecutive lanes (3 shuffle steps).  K % 16 == 0, K <= 64 KCH.
+template <int KCH>
+__global__ __launch_bounds__(256) void ln_stats_ps_kernel(const float* __restrict__ x, int rows, int K, float eps, float* __restrict__ stats,
+                                                          unsigned char* __restrict__ dst, float guard, int* __restrict__ flag) {
+  const int rb = blockIdx.x;
+  const int r = threadIdx.x >> 3, o = threadIdx.x & 7;
+  const int row = rb * 32 + r;
+  const bool rok = row < rows;
+  const float* px = x + (long long)(rok ? row : 0) * K;
+  float4 v[KCH][2];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < KCH; ++c) {
+    const int k0 = c * 64 + o * 8;
+    if (rok && k0 < K) {
+      v[c][0] = *reinterpret_cast<const float4*>(px + k0);
+      v[c][1] = *reinterpret_cast<const float4*>(px + k0 + 4);
+    } else {
+      v[c][0] = v[c][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    s += ((v[c][0].x + v[c][0].y) + (v[c][0].z + v[c][0].w)) + ((v[c][1].x + v[c][1].y) + (v[c][1].z + v[c][1].w));
+  }
+#pragma unroll
+  for (int d = 4; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  const float mean = s / (float)K;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < KCH; ++c) {
+    if (c * 64 + o * 8 < K) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float a = v[c][e].x - mean, b = v[c][e].y - mean, cc = v[c][e].z - mean, d = v[c][e].w - mean;
+        q = fmaf(a, a, q); q = fmaf(b, b, q); q = fmaf(cc, cc, q); q = fmaf(d, d, q);
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 4; d > 0; d >>= 1) q += __shfl_xor(q, d, 64);
+  if (rok && o == 0) {
+    const float rstd = 1.0f / sqrtf(q / (float)K + eps);
+    stats[2 * (long long)row] = mean;
+    stats[2 * (long long)row + 1] = rstd;
+    if (flag && !(fabsf(mean) * rstd <= guard)) *flag = 1;
+  }
+#pragma unroll
+  for (int c = 0; c < KCH; ++c) {
+    const int k0 = c * 64 + o * 8;
+    if (k0 < K) {
+      pbf16x4 h0, m0, l0, h1, m1, l1;
+      ps_split3(v[c][0], h0, m0, l0);
+      ps_split3(v[c][1], h1, m1, l1);
+      unsigned char* d = dst + ((long long)rb * (K / 16) + (k0 >> 4)) * 3072 + ((o & 1) * 32 + r) * 16;
+      *reinterpret_cast<pbf16x8*>(d) = pbf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      *reinterpret_cast<pbf16x8*>(d + 1024) = pbf16x8{m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+      *reinterpret_cast<pbf16x8*>(d + 2048) = pbf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+int launch_splitk_reduce(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st);
+
+struct PsCfg { int bm, bn; bool even_tn; };
+// pcfg 0: 256x160 (8 x 1 waves of 32 x 160), 1: 256x320 (4 x 2 waves of 64 x 160), 2: 256x256 (4 x 2 waves of 64 x 128: GEGLU pairs),
+//      3: 128x320 (4 x 2 waves of 32 x 160), 4: 128x160 (4 x 1 waves of 32 x 160, two workgroups per CU), 5: 128x256 (4 x 2 waves of 32 x 128)
+//      6: 256x160, 7: 256x128 (GEGLU pairs): the warp-specialised form (igemm_pw_kernel: 4 consumer waves of 64 x BN + 4 DMA waves)
+static const PsCfg kPsCfg[] = {{256, 160, false}, {256, 320, false}, {256, 256, true}, {128, 320, false}, {128, 160, false}, {128, 256, true},
+                               {256, 160, false}, {256, 128, true},
+                               // 8: 256x160, 9: 256x128, 10: 128x256 with FOUR waves of 64 x 160 / 64 x 128 and a 2-deep ring: two workgroups per
+                               // CU, whose DMA issue / barrier / epilogue phases overlap the other one's matrix work
+                               {256, 160, false}, {256, 128, true}, {128, 256, true}};
+
+template <int NWM, int NWN, int TM, int TN, int NS, bool TR>
+static int ps_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
+  constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN;
+  constexpr size_t lds = (size_t)NS * (BM / 32 + BN / 32) * 3072;
+  static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  static const int dbg = getenv("LDMK_PS_DEBUG") ? atoi(getenv("LDMK_PS_DEBUG")) : 0;
+  hipLaunchKernelGGL((igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR>), dim3(tiles, splitk, a.batch > 1 ? a.batch : 1), dim3(64 * NWM * NWN), lds,
+                     st, a, splitk, ws, dbg);
+  if (splitk > 1 && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
+  return check_launch("ldmk_igemm(ps)");
+}
+
+template <int TM, int TN, int NS, bool TR>
+static int pw_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
+  constexpr int BM = 128 * TM, BN = 32 * TN;
+  constexpr size_t lds = (size_t)NS * (BM / 32 + TN) * 3072;
+  static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_pw_kernel<TM, TN, NS, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  static const int dbg = getenv("LDMK_PS_DEBUG") ? atoi(getenv("LDMK_PS_DEBUG")) : 0;
+  hipLaunchKernelGGL((igemm_pw_kernel<TM, TN, NS, TR>), dim3(tiles, splitk, a.batch > 1 ? a.batch : 1), dim3(512), lds, st, a, splitk, ws, dbg);
+  if (splitk > 1 && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
+  return check_launch("ldmk_igemm(pw)");
+}
+
+const char* igemm_ps_unsupported(const ldmk_igemm_args& a, int pcfg, int splitk) {
+  if (a.compute != LDMK_COMPUTE_BF16X3) return "the pre-split tiles run the bf16x3 arithmetic only (compute)";
+  if (!a.a_ps || !a.w_ps) return "a_ps / w_ps (operands in the PS layout: ldmk_pack_ps, ldmk_ln_stats_ps, out_ps of a producer GEMM)";
+  if (a.a_mode != LDMK_A_ROWS) return "rows mode only";
+  if (a.b_trans || a.upsample || a.skip_a0 || (a.splitk_counters && !getenv("LDMK_PS_DEBUG"))) return "b_trans / upsample / fused skip / in-launch combine";
+  if (a.a_tf != LDMK_TF_NONE && a.a_tf != LDMK_TF_LAYERNORM_FOLDED) return "no staging prologue: a_ps is what gets multiplied";
+  if (a.K % 32 || a.N % 32) return "K and N must be multiples of 32";
+  const long long kb = a.K / 16;
+  if ((long long)((a.M + 31) / 32) * kb * 3072 >= (1LL << 31) || (long long)(a.N / 32) * kb * 3072 >= (1LL << 31)) return "an operand of 2 GiB or more";
+  if (a.epi == LDMK_EPI_GEGLU && (!kPsCfg[pcfg].even_tn || splitk > 1)) return "GEGLU needs a tile of (value, gate) pairs (256x256, 128x256) and no split-K";
+  if (splitk > a.K / 32) return "more K slices than 32-deep chunks";
+  if (a.out_ps) {
+    if (splitk > 1 || a.batch > 1 || a.stats_out) return "out_ps: no split-K, no batching, no GroupNorm records (transposed epilogue)";
+    if (a.ldc % 16) return "out_ps: ldc (the PS output's column count) must be a multiple of 16";
+  } else if (!a.out && splitk <= 1) {
+    return "no output";
+  }
+  if (a.stats_out && !a.out) return "stats_out needs out";
+  return nullptr;
+}
+
+int igemm_ps_dispatch(const ldmk_igemm_args& a, int pcfg, int splitk, float* ws, hipStream_t st) {
+  // the transposed epilogue serves every call but those that want GroupNorm records
+  const bool tr = !a.stats_out;
+  switch (pcfg) {
+    case 0: return tr ? ps_launch<8, 1, 1, 5, 3, true>(a, splitk, ws, st) : ps_launch<8, 1, 1, 5, 3, false>(a, splitk, ws, st);
+    case 1: return tr ? ps_launch<4, 2, 2, 5, 2, true>(a, splitk, ws, st) : ps_launch<4, 2, 2, 5, 2, false>(a, splitk, ws, st);
+    case 2: return tr ? ps_launch<4, 2, 2, 4, 3, true>(a, splitk, ws, st) : ps_launch<4, 2, 2, 4, 3, false>(a, splitk, ws, st);
+    case 3: return tr ? ps_launch<4, 2, 1, 5, 3, true>(a, splitk, ws, st) : ps_launch<4, 2, 1, 5, 3, false>(a, splitk, ws, st);
+    case 4: return tr ? ps_launch<4, 1, 1, 5, 2, true>(a, splitk, ws, st) : ps_launch<4, 1, 1, 5, 2, false>(a, splitk, ws, st);
+    case 6: return tr ? pw_launch<2, 5, 4, true>(a, splitk, ws, st) : pw_launch<2, 5, 4, false>(a, splitk, ws, st);
+    case 7: return tr ? pw_launch<2, 4, 4, true>(a, splitk, ws, st) : pw_launch<2, 4, 4, false>(a, splitk, ws, st);
+    case 8: return tr ? ps_launch<4, 1, 2, 5, 2, true>(a, splitk, ws, st) : ps_launch<4, 1, 2, 5, 2, false>(a, splitk, ws, st);
+    case 9: return tr ? ps_launch<4, 1, 2, 4, 2, true>(a, splitk, ws, st) : ps_launch<4, 1, 2, 4, 2, false>(a, splitk, ws, st);
+    case 10: return tr ? ps_launch<2, 2, 2, 4, 2, true>(a, splitk, ws, st) : ps_launch<2, 2, 2, 4, 2, false>(a, splitk, ws, st);
+    default: return tr ? ps_launch<4, 2, 1, 4, 3, true>(a, splitk, ws, st) : ps_launch<4, 2, 1, 4, 3, false>(a, splitk, ws, st);
+  }
+}
+
+}  // namespace ldmk
+
+extern "C" long long ldmk_ps_bytes(int rows, int k) {
+  if (rows <= 0 || k <= 0 || k % 16) return -1;
+  return (long long)((rows + 31) / 32) * (k / 16) * 3072;
+}
+
+extern "C" int ldmk_pack_ps(const float* src, int rows, int k, long long row_stride, long long k_stride, int batch, long long src_bstride,
+                            void* dst, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(src && dst && rows > 0 && k > 0 && batch >= 1, "ldmk_pack_ps: bad args");
+  LDMK_REQUIRE(k % 16 == 0, "ldmk_pack_ps: k=%d must be a multiple of 16", k);
+  LDMK_REQUIRE(k_stride != 1 || (row_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && src_bstride % 4 == 0),
+               "ldmk_pack_ps: row-major sources are read as float4 (16-byte aligned rows)");
+  const long long bytes = ldmk_ps_bytes(rows, k);
+  hipLaunchKernelGGL(pack_ps_kernel, dim3((rows + 31) / 32, (k + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, src, rows, k, row_stride,
+                     k_stride, src_bstride, reinterpret_cast<unsigned char*>(dst), bytes);
+  return check_launch("ldmk_pack_ps");
+}
+
+extern "C" int ldmk_ln_stats_ps(const float* x, int rows, int c, float eps, float* stats, void* dst, float guard, int* flag, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(x && stats && dst && rows > 0 && c > 0, "ldmk_ln_stats_ps: bad args");
+  LDMK_REQUIRE(c % 16 == 0 && c <= 1280, "ldmk_ln_stats_ps: C=%d must be a multiple of 16, at most 1280", c);
+  LDMK_REQUIRE(!flag || guard > 0.f, "ldmk_ln_stats_ps: guard=%g must be positive", (double)guard);
+  const dim3 grid((rows + 31) / 32);
+  unsigned char* d = reinterpret_cast<unsigned char*>(dst);
+  hipStream_t st = (hipStream_t)stream;
+  if (c <= 192) hipLaunchKernelGGL(ln_stats_ps_kernel<3>, grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag);
+  else if (c <= 320) hipLaunchKernelGGL(ln_stats_ps_kernel<5>, grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag);
+  else if (c <= 640) hipLaunchKernelGGL(ln_stats_ps_kernel<10>, grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag);
+  else hipLaunchKernelGGL(ln_stats_ps_kernel<20>, grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag);
+  return check_launch("ldmk_ln_stats_ps");
+}

@@ -76,6 +76,99 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   }
 }
 
+// The same transform writing V in the PS layout (include/ldmk.h; csrc/igemm_ps.hip): 16 position planes, each the PS image of a
+// [tiles][C] matrix (three bf16 planes of the exact split, MFMA-operand order).  thread <-> (tile, 8 channels): lanes 0-31 of a
+// wave are 32 consecutive tiles at channels 16 s .. 16 s + 7, lanes 32-63 the same tiles at 16 s + 8 .. 16 s + 15, so every store
+// instruction writes ONE whole fragment plane, 1 KiB contiguous; a workgroup = 32 tiles x 4 k-slabs.  Same arithmetic (and
+// order) as wino_input_kernel: V is bit for bit the same matrix, split exactly.
+typedef __bf16 wbf16x8_ __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void wino_store_ps(unsigned char* d, const float4& a, const float4& b) {
+  float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  wbf16x8_ h, m, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = (__bf16)v[e];
+    const float r = v[e] - (float)h[e];
+    m[e] = (__bf16)r;
+    l[e] = (__bf16)(r - (float)m[e]);
+  }
+  *reinterpret_cast<wbf16x8_*>(d) = h;
+  *reinterpret_cast<wbf16x8_*>(d + 1024) = m;
+  *reinterpret_cast<wbf16x8_*>(d + 2048) = l;
+}
+
+__global__ __launch_bounds__(256) void wino_input_ps_kernel(const float* __restrict__ x0, int c0, const float* __restrict__ x1, int c1,
+                                                            const float* __restrict__ coef, int silu, int H, int W, long long tiles,
+                                                            unsigned char* __restrict__ V, long long plane_bytes) {
+  const int C = c0 + c1, Kb = C >> 4;
+  const int tw = W >> 1, th = H >> 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int slab = blockIdx.y * 4 + wave;
+  if (slab >= Kb) return;
+  const long long t = (long long)blockIdx.x * 32 + r;
+  const int c = slab * 16 + hh * 8;
+  float4 d[4][4][2];
+  const bool tok = t < tiles;
+  if (tok) {
+    const int tx = (int)(t % tw);
+    const long long t2 = t / tw;
+    const int ty = (int)(t2 % th), n = (int)(t2 / th);
+    const float* src = c < c0 ? x0 + (long long)n * H * W * c0 + c : x1 + (long long)n * H * W * c1 + (c - c0);
+    const int cs = c < c0 ? c0 : c1;
+    float4 sc[2] = {make_float4(1.f, 1.f, 1.f, 1.f), make_float4(1.f, 1.f, 1.f, 1.f)};
+    float4 sh[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (coef) {
+      const float* cf = coef + ((long long)n * 2) * C + c;
+      sc[0] = *reinterpret_cast<const float4*>(cf); sc[1] = *reinterpret_cast<const float4*>(cf + 4);
+      sh[0] = *reinterpret_cast<const float4*>(cf + C); sh[1] = *reinterpret_cast<const float4*>(cf + C + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = 2 * ty - 1 + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = 2 * tx - 1 + j;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (in) {
+            v = *reinterpret_cast<const float4*>(src + ((long long)y * W + x) * cs + 4 * e);
+            if (coef) { v.x = fmaf(v.x, sc[e].x, sh[e].x); v.y = fmaf(v.y, sc[e].y, sh[e].y); v.z = fmaf(v.z, sc[e].z, sh[e].z); v.w = fmaf(v.w, sc[e].w, sh[e].w); }
+            if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+          }
+          d[i][j][e] = v;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[i][j][0] = d[i][j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
+  auto add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+  unsigned char* dst = V + ((long long)blockIdx.x * Kb + slab) * 3072 + lane * 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 rr[4][2];                    // row i of B^T d
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        rr[j][e] = i == 0 ? sub(d[0][j][e], d[2][j][e]) : i == 1 ? add(d[1][j][e], d[2][j][e]) : i == 2 ? sub(d[2][j][e], d[1][j][e])
+                                                                                                          : sub(d[1][j][e], d[3][j][e]);
+      }
+    // (B^T d) B, positions 4 i .. 4 i + 3
+    wino_store_ps(dst + (4 * i + 0) * plane_bytes, sub(rr[0][0], rr[2][0]), sub(rr[0][1], rr[2][1]));
+    wino_store_ps(dst + (4 * i + 1) * plane_bytes, add(rr[1][0], rr[2][0]), add(rr[1][1], rr[2][1]));
+    wino_store_ps(dst + (4 * i + 2) * plane_bytes, sub(rr[2][0], rr[1][0]), sub(rr[2][1], rr[1][1]));
+    wino_store_ps(dst + (4 * i + 3) * plane_bytes, sub(rr[1][0], rr[3][0]), sub(rr[1][1], rr[3][1]));
+  }
+}
+
 // One workgroup = (sample, band of 2R image rows); thread <-> channel (coalesced over N), walking the band's tiles left to
 // right.  The band is a whole number of 32-pixel GroupNorm chunks (W = 8: R = 2; W >= 16: R = 1), so the partial records of
 // the result (same records as gn_partial_kernel: shift, sum, sum of squares of the chunk) are complete per workgroup.
@@ -172,6 +265,25 @@ extern "C" int ldmk_winograd_input(const float* x0, int c0, const float* x1, int
   return check_launch("ldmk_winograd_input");
 }
 
+extern "C" long long ldmk_ps_bytes(int rows, int k);
+
+extern "C" int ldmk_winograd_input_ps(const float* x0, int c0, const float* x1, int c1, const float* coef, int silu, int n, int h,
+                                      int w, void* v_ps, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(x0 && v_ps && n > 0 && c0 > 0, "ldmk_winograd_input_ps: bad args");
+  LDMK_REQUIRE((c1 == 0) == (x1 == nullptr), "ldmk_winograd_input_ps: x1/c1 mismatch");
+  LDMK_REQUIRE(h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "ldmk_winograd_input_ps: H=%d W=%d must be even", h, w);
+  LDMK_REQUIRE(c0 % 16 == 0 && c1 % 16 == 0, "ldmk_winograd_input_ps: channel counts must be multiples of 16 (k-slabs of the PS layout)");
+  const long long tiles = ldmk_winograd_tiles(n, h, w);
+  LDMK_REQUIRE(tiles < (1LL << 31), "ldmk_winograd_input_ps: too many tiles");
+  const int C = c0 + c1;
+  const long long plane = ldmk_ps_bytes((int)tiles, C);
+  hipLaunchKernelGGL(wino_input_ps_kernel, dim3((unsigned)((tiles + 31) / 32), (C / 16 + 3) / 4), dim3(256), 0, (hipStream_t)stream, x0, c0, x1,
+                     c1, coef, silu, h, w, tiles, reinterpret_cast<unsigned char*>(v_ps), plane);
+  return check_launch("ldmk_winograd_input_ps");
+}
+
 extern "C" int ldmk_winograd_output(const float* m, const float* bias, const float* batch_vec, int batch_vec_ld,
                                     const float* residual, float* out, float* stats_out, int n, int h, int w, int cout,
                                     void* stream) {
@@ -236,6 +348,51 @@ __global__ __launch_bounds__(256) void upconv_gather_kernel(const float* __restr
   }
 }
 
+// the gather writing its four phase operands in the PS layout (csrc/igemm_ps.hip): per phase the PS image of [pix][4 C]; thread <->
+// (pixel, 8 channels) with the lane order of wino_input_ps_kernel, so every store is one whole 1-KiB fragment plane
+__global__ __launch_bounds__(256) void upconv_gather_ps_kernel(const float* __restrict__ x, int C, int H, int W, long long pix,
+                                                               unsigned char* __restrict__ A, long long plane_bytes) {
+  const int Kc = C >> 4;                 // k-slabs per tap
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int slab = blockIdx.y * 4 + wave;
+  if (slab >= Kc) return;
+  const long long p = (long long)blockIdx.x * 32 + r;
+  const int c = slab * 16 + hh * 8;
+  float4 d[3][3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) d[i][j][0] = d[i][j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p < pix) {
+    const int xx = (int)(p % W);
+    const long long p2 = p / W;
+    const int yy = (int)(p2 % H), n = (int)(p2 / H);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int y = yy - 1 + i, x_ = xx - 1 + j;
+        if (y >= 0 && y < H && x_ >= 0 && x_ < W) {
+          const float* s = x + (((long long)n * H + y) * W + x_) * C + c;
+          d[i][j][0] = *reinterpret_cast<const float4*>(s);
+          d[i][j][1] = *reinterpret_cast<const float4*>(s + 4);
+        }
+      }
+  }
+  const int Kb = 4 * Kc;                  // k-slabs per row of the [pix][4 C] operand
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      unsigned char* dst = A + (long long)(2 * a + b) * plane_bytes + ((long long)blockIdx.x * Kb + slab) * 3072 + lane * 16;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wino_store_ps(dst + (long long)(2 * i + j) * Kc * 3072, d[a + i][b + j][0], d[a + i][b + j][1]);
+    }
+}
+
 // workgroup = (sample, low-resolution row): two output rows of 2W pixels = 2W/16 whole 32-pixel chunks; thread <-> channel
 __global__ __launch_bounds__(256) void upconv_scatter_kernel(const float* __restrict__ Pm, const float* __restrict__ bias,
                                                              float* __restrict__ out, float* __restrict__ stats, int H, int W,
@@ -298,6 +455,18 @@ extern "C" int ldmk_upconv_gather(const float* x, int c, int n, int h, int w, fl
   if (g > 16384) g = 16384;
   hipLaunchKernelGGL(upconv_gather_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, c, h, w, pix, a);
   return check_launch("ldmk_upconv_gather");
+}
+
+extern "C" int ldmk_upconv_gather_ps(const float* x, int c, int n, int h, int w, void* a_ps, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(x && a_ps && n > 0 && h > 0 && w > 0 && c > 0 && c % 16 == 0, "ldmk_upconv_gather_ps: bad args (C a multiple of 16)");
+  const long long pix = (long long)n * h * w;
+  LDMK_REQUIRE(pix < (1LL << 31), "ldmk_upconv_gather_ps: too many pixels");
+  const long long plane = ldmk_ps_bytes((int)pix, 4 * c);
+  hipLaunchKernelGGL(upconv_gather_ps_kernel, dim3((unsigned)((pix + 31) / 32), (c / 16 + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, c, h,
+                     w, pix, reinterpret_cast<unsigned char*>(a_ps), plane);
+  return check_launch("ldmk_upconv_gather_ps");
 }
 
 extern "C" int ldmk_upconv_scatter(const float* planes, const float* bias, float* out, float* stats_out, int n, int h, int w,

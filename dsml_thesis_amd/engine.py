@@ -41,7 +41,8 @@ def plan_table():
         _PLAN_TABLE = {}
         if os.path.exists(path) and not os.environ.get("LDMK_NO_PLAN_TABLE"):
             try:
-                raw = json.load(open(path))
+                with open(path) as fh:
+                    raw = json.load(fh)
             except Exception:
                 raw = {}
             for k, (cfg, sk) in raw.items():
@@ -71,7 +72,8 @@ def x3_table():
         _X3_TABLE = {}
         if os.path.exists(path) and split_enabled():
             try:
-                raw = json.load(open(path))
+                with open(path) as fh:
+                    raw = json.load(fh)
             except Exception:
                 raw = {}
             for k, (cfg, sk) in raw.items():
@@ -86,6 +88,49 @@ def x3_plan(a, m):
     """(cfg, splitk) of the bf16x3 plan for this shape, or None: same bucket rule as tuned_plan, but only an exact or
     within-2x row count of a shape that was measured faster in this arithmetic."""
     rows = x3_table().get(plan_key(a, m).split(",", 1)[1])
+    if not rows:
+        return None
+    best = min(rows, key=lambda r: (abs(math.log(r[0] / m)), r[0]))
+    if max(best[0], m) > 2 * min(best[0], m):
+        return None
+    return best[1], best[2]
+
+
+_PS_TABLE = None
+
+
+def ps_enabled():
+    """Pre-split operands (csrc/igemm_ps.hip, tile_cfg 23+): activations written in the PS layout by their producers and moved
+    memory -> LDS by LDS-DMA, for the shapes dsml_thesis_amd/igemm_plans_ps.json lists.  LDMK_PS=0 keeps the round-3 kernels."""
+    return split_enabled() and os.environ.get("LDMK_PS", "1") != "0"
+
+
+def ps_table():
+    """{shape key: [(M, cfg, splitk)]}: GEMM shapes measured faster on the pre-split tiles than on their best other plan
+    (dsml_thesis_amd/igemm_plans_ps.json; LDMK_PS_TABLE overrides the path).  Same key as the other tables (plan_key)."""
+    global _PS_TABLE
+    if _PS_TABLE is None:
+        import json
+        path = os.environ.get("LDMK_PS_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans_ps.json")
+        _PS_TABLE = {}
+        if os.path.exists(path) and ps_enabled():
+            try:
+                with open(path) as fh:
+                    raw = json.load(fh)
+            except Exception:
+                raw = {}
+            for k, (cfg, sk) in raw.items():
+                m, rest = k.split(",", 1)
+                _PS_TABLE.setdefault(rest, []).append((int(m), int(cfg), int(sk)))
+            for v in _PS_TABLE.values():
+                v.sort()
+    return _PS_TABLE
+
+
+def ps_plan(rest, m):
+    """(cfg, splitk) of the pre-split plan for the shape key `rest` ("N,K,mode,tf,epi,batch") at m rows, or None: exact or within
+    2x of a measured row count, like x3_plan."""
+    rows = ps_table().get(rest)
     if not rows:
         return None
     best = min(rows, key=lambda r: (abs(math.log(r[0] / m)), r[0]))
@@ -136,6 +181,12 @@ class Program:
             if t is None:
                 continue
             self._free.setdefault((t.numel(), t.dtype), []).append(t.reshape(-1))
+
+    def alloc_ps(self, rows, k, batch=1):
+        """A pool buffer for a [rows][k] matrix (x batch) in the PS layout (include/ldmk.h): uint8 [batch * ldmk_ps_bytes]."""
+        nb = self.lib.ldmk_ps_bytes(int(rows), int(k))
+        assert nb > 0, (rows, k)
+        return self.alloc(int(batch) * nb, dtype=torch.uint8)
 
     def workspace_bytes(self):
         return sum(t.numel() * t.element_size() for t in self._all)
@@ -244,6 +295,19 @@ class Program:
             if os.environ.get("LDMK_SPLITK_IN_LAUNCH"):
                 cnt = self.splitk_counters()
                 args.splitk_counters, args.splitk_counters_len = cnt.data_ptr(), cnt.numel()
+        self.calls.append((self.lib.ldmk_igemm, (C.byref(args),), args, "ldmk_igemm"))
+
+    def igemm_ps(self, args, cfg, sk):
+        """Record a GEMM on a pre-split tile (args carry a_ps / w_ps; the plan comes from the PS table, decided by the caller
+        BEFORE it had the producer write the A operand in that layout)."""
+        args.tile_cfg, args.splitk = int(cfg), max(1, int(sk))
+        args.compute = L.COMPUTE_BF16X3
+        if args.splitk > 1:
+            ws = self.splitk_workspace(max(1, args.batch) * args.splitk * args.M * args.N)
+            args.splitk_ws, args.splitk_ws_elems = ws.data_ptr(), ws.numel()
+        rc = self.lib.ldmk_igemm_check(C.byref(args))
+        if rc != 0:
+            L.check(rc, "ldmk_igemm_check (pre-split plan)")
         self.calls.append((self.lib.ldmk_igemm, (C.byref(args),), args, "ldmk_igemm"))
 
     def igemm_raw(self, args, slabs):
@@ -390,7 +454,7 @@ class NetBuilder:
                 and w in (8, 16, 32, 64, 128) and (h * w) % 32 == 0 and (w >= 16 or (h // 2) % 2 == 0))
 
     def gn_conv(self, x0, x1, h, w, gamma, beta, eps, wp, u, bias, batch_vec=None, bv_ld=0, residual=None, out=None,
-                stats=False, wf=None):
+                stats=False, wf=None, u_ps=None):
         """GroupNorm(32)+SiLU of (the concat of) x0 | x1, then the 3x3 convolution with packed weights `wp` (implicit GEMM)
         or, when `u` (ops.pack_winograd) is given and the problem is large enough, through Winograd."""
         pg, n, ops, p_ = self.pg, self.n, self.ops, self.ptr
@@ -406,15 +470,28 @@ class NetBuilder:
         cout = u.shape[2]
         tiles = n * (h // 2) * (w // 2)
         coef = self.gn(x0, x1, h * w, gamma, beta, eps)
-        V, Mb = pg.alloc(16, tiles, cin), pg.alloc(16, tiles, cout)
+        Mb = pg.alloc(16, tiles, cout)
         if out is None:
             out = pg.alloc(n, h, w, cout)
-        pg.add("ldmk_winograd_input", p_(x0), c0, p_(x1), c1, p_(coef), 1, n, h, w, p_(V))
-        a = ops.make_igemm_args(tiles, cout, cin, V, cin, u, Mb, cout, tiles, batch=16, a_bstride=tiles * cin,
-                                w_bstride=cin * cout, out_bstride=tiles * cout)
+        # with a pre-split plan for the 16 plane GEMMs (csrc/igemm_ps.hip) the input transform writes V in the PS layout: same
+        # matrix, split once here instead of once per N-tile inside the GEMM
+        plan = self.ps_query(tiles, cout, cin, batch=16) if (u_ps is not None and c0 % 16 == 0 and c1 % 16 == 0) else None
+        if plan is not None:
+            V = pg.alloc_ps(tiles, cin, batch=16)
+            pg.add("ldmk_winograd_input_ps", p_(x0), c0, p_(x1), c1, p_(coef), 1, n, h, w, p_(V))
+            a = ops.make_igemm_args(tiles, cout, cin, None, cin, u, Mb, cout, tiles, batch=16, w_bstride=cin * cout,
+                                    out_bstride=tiles * cout, a_ps=V.view(16, -1), w_ps=u_ps)
+        else:
+            V = pg.alloc(16, tiles, cin)
+            pg.add("ldmk_winograd_input", p_(x0), c0, p_(x1), c1, p_(coef), 1, n, h, w, p_(V))
+            a = ops.make_igemm_args(tiles, cout, cin, V, cin, u, Mb, cout, tiles, batch=16, a_bstride=tiles * cin,
+                                    w_bstride=cin * cout, out_bstride=tiles * cout)
         a._winograd = True            # (tools/autotune.py sweeps these batched problems; per-sample batches are not planned by table)
         a._algo_flops = 2.0 * (4 * tiles) * cout * (9 * cin)      # the direct convolution's arithmetic (bench.py)
-        pg.igemm(a, self.pin, batch_is_samples=False)
+        if plan is not None:
+            pg.igemm_ps(a, *plan)
+        else:
+            pg.igemm(a, self.pin, batch_is_samples=False)
         part = None
         out2d = out.view(-1, cout)
         if stats:
@@ -427,7 +504,7 @@ class NetBuilder:
         pg.release(V, Mb)
         return out
 
-    def up_conv(self, x, h, w, wp, w4, bias, stats=False):
+    def up_conv(self, x, h, w, wp, w4, bias, stats=False, w4_ps=None):
         """Upsample (nearest x2) + Conv2d 3x3: the implicit GEMM with the upsampling folded into its gather, or -- `w4`
         (ops.pack_upconv) given, >= 320 channels, >= UP_MIN_PIXELS low-resolution pixels at the plan-policy batch -- four 2x2-tap phase
         convolutions on the low-resolution input: 4/9 of the multiplications, exact (measured: 898 -> 522 us for 640->640 at
@@ -441,14 +518,25 @@ class NetBuilder:
             return self.conv(x, None, wp, bias, h, w, upsample=True, stats=stats)
         cout = w4.shape[2]
         pix = n * h * w
-        A, Pm = pg.alloc(4, pix, 4 * c), pg.alloc(4, pix, cout)
+        Pm = pg.alloc(4, pix, cout)
         out = pg.alloc(n, 2 * h, 2 * w, cout)
-        pg.add("ldmk_upconv_gather", p_(x), c, n, h, w, p_(A))
-        a = ops.make_igemm_args(pix, cout, 4 * c, A, 4 * c, w4, Pm, cout, pix, batch=4, a_bstride=pix * 4 * c,
-                                w_bstride=4 * c * cout, out_bstride=pix * cout)
+        plan = self.ps_query(pix, cout, 4 * c, batch=4) if (w4_ps is not None and c % 16 == 0) else None
+        if plan is not None:          # the gather writes its phase operands in the PS layout (csrc/igemm_ps.hip)
+            A = pg.alloc_ps(pix, 4 * c, batch=4)
+            pg.add("ldmk_upconv_gather_ps", p_(x), c, n, h, w, p_(A))
+            a = ops.make_igemm_args(pix, cout, 4 * c, None, 4 * c, w4, Pm, cout, pix, batch=4, w_bstride=4 * c * cout,
+                                    out_bstride=pix * cout, a_ps=A.view(4, -1), w_ps=w4_ps)
+        else:
+            A = pg.alloc(4, pix, 4 * c)
+            pg.add("ldmk_upconv_gather", p_(x), c, n, h, w, p_(A))
+            a = ops.make_igemm_args(pix, cout, 4 * c, A, 4 * c, w4, Pm, cout, pix, batch=4, a_bstride=pix * 4 * c,
+                                    w_bstride=4 * c * cout, out_bstride=pix * cout)
         a._winograd = True            # a batch of transform planes, not of samples: planned by table like the Winograd GEMMs
         a._algo_flops = 2.0 * (4 * pix) * cout * (9 * c)
-        pg.igemm(a, self.pin, batch_is_samples=False)
+        if plan is not None:
+            pg.igemm_ps(a, *plan)
+        else:
+            pg.igemm(a, self.pin, batch_is_samples=False)
         part = None
         out2d = out.view(-1, cout)
         if stats:
@@ -466,6 +554,32 @@ class NetBuilder:
             part = self.stats_buffer(a.M, a.N)
             a.stats_out = part.data_ptr()
             self.attach_stats(out2d, part)
+
+    def ps_query(self, M, N, K, tf=L.TF_NONE, epi=L.EPI_NONE, batch=1, per_sample=True):
+        """(tile_cfg, splitk) of the pre-split plan (csrc/igemm_ps.hip) for a rows-mode GEMM of this shape, looked up at the
+        plan-policy row count like every plan -- or None.  Asked BEFORE the producer of the A operand is emitted: with a plan the
+        producer writes the operand in the PS layout."""
+        if not ps_enabled():
+            return None
+        m = M
+        if self.pin is not None and self.pin[0] != self.pin[1] and per_sample:
+            m = max(1, M * self.pin[0] // self.pin[1])
+        return ps_plan(f"{N},{K},{L.A_ROWS},{tf},{epi},{max(1, batch)}", m)
+
+    def lin_ps(self, plan, M, K, a_ps, wp, w_ps, bias, rows_per_sample, out=None, out_ps=None, geglu=False, stats=False, **kw):
+        """Linear on a pre-split tile: a_ps = the [M][K] input in the PS layout, w_ps = ops.pack_wps(wp).  `out` None with out_ps
+        given: the result exists in the PS layout only (its one consumer is another pre-split GEMM)."""
+        pg, ops = self.pg, self.ops
+        N = wp.shape[1]
+        ncol = N // 2 if geglu else N
+        if out is None and out_ps is None:
+            out = pg.alloc(M, ncol)
+        a = ops.make_igemm_args(M, N, K, None, K, wp, out, ncol, rows_per_sample, bias=bias,
+                                epi=L.EPI_GEGLU if geglu else L.EPI_NONE, a_ps=a_ps, w_ps=w_ps, out_ps=out_ps, **kw)
+        if out is not None:
+            self._maybe_stats(a, out, rows_per_sample, stats)
+        pg.igemm_ps(a, *plan)
+        return out
 
     def lin(self, x0, wp, bias, rows_per_sample, x1=None, out=None, geglu=False, stats=False, wf=None, **kw):
         """Linear / 1x1 conv on token rows, with the igemm prologue/epilogue options passed through.  `wf`: the

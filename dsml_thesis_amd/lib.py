@@ -37,6 +37,7 @@ class IgemmArgs(C.Structure):
         ("skip_a0", _fp), ("skip_a1", _fp), ("skip_c0", C.c_int), ("skip_c1", C.c_int),
         ("w_split", _fp), ("w_split_ld", C.c_int), ("w_split_bstride", C.c_longlong),
         ("a_split", _fp), ("a_split_ld", C.c_int),
+        ("a_ps", _fp), ("a_ps_bstride", C.c_longlong), ("w_ps", _fp), ("w_ps_bstride", C.c_longlong), ("out_ps", _fp),
     ]
 
 
@@ -77,8 +78,10 @@ _SIGS = {
     "ldmk_pack_wbf16t": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp]),
     "ldmk_winograd_tiles": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "ldmk_winograd_input": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ldmk_winograd_input_ps": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ldmk_winograd_output": (C.c_int, [_fp, _fp, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_upconv_gather": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ldmk_upconv_gather_ps": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ldmk_upconv_scatter": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_fold_layernorm": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "ldmk_attn_force_qt": (None, [C.c_int]),
@@ -88,6 +91,9 @@ _SIGS = {
     "ldmk_gn_coef": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _fp]),
     "ldmk_ln_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp]),
     "ldmk_ln_stats_guard": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, C.c_float, _fp, _fp]),
+    "ldmk_ps_bytes": (C.c_longlong, [C.c_int, C.c_int]),
+    "ldmk_pack_ps": (C.c_int, [_fp, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_longlong, _fp, _fp]),
+    "ldmk_ln_stats_ps": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp, C.c_float, _fp, _fp]),
     "ldmk_ln_stats_split": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp, C.c_int, _fp]),
     "ldmk_gn_apply": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_post": (C.c_int, [C.POINTER(PostArgs), _fp]),

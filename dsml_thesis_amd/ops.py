@@ -120,6 +120,61 @@ def ln_stats(x2d, eps=1e-5, out=None, split=None):
     return out
 
 
+# ---- the PS layout (include/ldmk.h, csrc/igemm_ps.hip): operands of the pre-split bf16x3 tiles (tile_cfg 23..28) ------------
+PS_TILE0 = 23                     # tile_cfg of the first pre-split tile (256x160); 24: 256x320, 25: 256x256, 26: 128x320, 27: 128x160, 28: 128x256
+
+
+def ps_empty(rows, k, batch=1, device="cuda"):
+    """Uninitialised PS-layout buffer(s) for a [rows][k] matrix: uint8 [batch][ldmk_ps_bytes]."""
+    nb = L.load().ldmk_ps_bytes(int(rows), int(k))
+    assert nb > 0, (rows, k)
+    return torch.empty(batch, nb, device=device, dtype=torch.uint8)
+
+
+def pack_ps(x, out=None):
+    """x: fp32 [rows][k] (or [batch][rows][k]) row-major on the GPU -> the PS layout of its exact three-way bf16 split."""
+    batch = x.shape[0] if x.dim() == 3 else 1
+    rows, k = x.shape[-2], x.shape[-1]
+    assert x.is_contiguous()
+    if out is None:
+        out = ps_empty(rows, k, batch, x.device)
+    L.call("ldmk_pack_ps", _ptr(x), rows, k, k, 1, batch, rows * k, _ptr(out), stream())
+    return out
+
+
+def pack_wps(w, batch=1):
+    """Packed weights w[K][N] (pack_linear / pack_conv3x3 layout; or [batch][K][N]) -> PS layout of X[N][K] (row = output column):
+    the w_ps operand of the pre-split tiles."""
+    if batch > 1:
+        assert w.dim() == 3 and w.shape[0] == batch and w.is_contiguous()
+        K, N = w.shape[1], w.shape[2]
+    else:
+        assert w.dim() == 2 and w.is_contiguous()
+        K, N = w.shape
+    out = ps_empty(N, K, batch, w.device)
+    L.call("ldmk_pack_ps", _ptr(w), N, K, 1, N, batch, K * N, _ptr(out), stream())
+    return out
+
+
+def ln_stats_ps(x2d, eps=1e-5, out=None, ps=None, guard=0.0, flag=None):
+    """LayerNorm (mean, rstd) per row AND the rows in the PS layout (one pass); returns (stats, ps)."""
+    rows, c = x2d.shape
+    if out is None:
+        out = torch.empty(rows, 2, device=x2d.device, dtype=torch.float32)
+    if ps is None:
+        ps = ps_empty(rows, c, 1, x2d.device)
+    L.call("ldmk_ln_stats_ps", _ptr(x2d), rows, c, float(eps), _ptr(out), _ptr(ps), float(guard), _ptr(flag), stream())
+    return out, ps
+
+
+def unpack_ps(ps, rows, k):
+    """Test helper: PS layout -> (hi, mid, lo) float32 [rows][k] tensors (host-side index arithmetic, any device)."""
+    nb = (rows + 31) // 32
+    t = ps.reshape(-1).view(torch.bfloat16).reshape(nb, k // 16, 3, 2, 32, 8)       # [row block][k slab][plane][k half][row][8 k]
+    t = t.permute(2, 0, 4, 1, 3, 5).reshape(3, nb * 32, k)[:, :rows]
+    return t[0].float(), t[1].float(), t[2].float()
+
+
 def make_post_args(src, M, N, rows_per_sample, nslab=1, slab_stride=None, bias=None, batch_vec=None, batch_vec_ld=0,
                    residual=None, ldr=None, geglu=False, raw_out=None, ld_raw=None, norm=L.POST_NONE, x1=None, c1=0,
                    gamma=None, beta=None, eps=1e-5, silu=False, norm_out=None, ld_norm=None, groups=32, alpha=1.0):
@@ -154,7 +209,7 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
                     tf_coef=None, row_stats=None, ln_gamma=None, ln_beta=None, b_trans=False, ldb=None, bias=None,
                     batch_vec=None, batch_vec_ld=0, residual=None, epi=L.EPI_NONE, batch=1, a_bstride=0, w_bstride=0,
                     out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None, w_frag=None, tile_cfg=0, compute=0, ln_colsum=None,
-                    splitk_counters=None, raw_slabs=False, a_split=None, w_bf16t=None):
+                    splitk_counters=None, raw_slabs=False, a_split=None, w_bf16t=None, a_ps=None, w_ps=None, out_ps=None):
     a = L.IgemmArgs()
     a.M, a.N, a.K = M, N, K
     a.a0, a.a1, a.c0, a.c1 = _ptr(a0), _ptr(a1), c0, c1
@@ -185,6 +240,12 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
         a.w_split, a.w_split_ld = _ptr(w_bf16t), w_bf16t.shape[-1]
     if a_split is not None:       # [3][M][ld] bf16 images of a0 (ln_stats(..., split=...)); used by the bf16x3 LDS-tiled plans only
         a.a_split, a.a_split_ld = _ptr(a_split), a_split.shape[-1]
+    if a_ps is not None:          # pre-split tiles (tile_cfg 23..28): both operands in the PS layout
+        a.a_ps, a.w_ps, a.out_ps = _ptr(a_ps), _ptr(w_ps), _ptr(out_ps)
+        if batch > 1:
+            a.a_ps_bstride, a.w_ps_bstride = a_ps.shape[-1], w_ps.shape[-1]
+        a.compute = L.COMPUTE_BF16X3
+        return a
     if compute == L.COMPUTE_BF16X3 and not set_split(a):
         raise ValueError("COMPUTE_BF16X3: no split images registered for this weight (ops.pack_wsplit) or b_trans set")
     return a

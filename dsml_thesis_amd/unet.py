@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
-from .engine import NetBuilder, Program, split_enabled as engine_split_enabled
+from .engine import NetBuilder, Program, split_enabled as engine_split_enabled, ps_enabled as engine_ps_enabled
 
 # LayerNorm is folded algebraically through the Linear behind it (LDMK_TF_LAYERNORM_FOLDED): exact for well-conditioned rows,
 # but it subtracts mean * colsum(W') from x W' in fp32, so rows whose |mean| is many standard deviations lose accuracy
@@ -143,6 +143,15 @@ def pack_gemm_copies(P, unfolded=False):
                     P[k + "#s"] = ops.pack_wsplit(P[k])
             elif tail in ("c1#wg", "c2#wg", "w#up"):
                 P[k + "#s"] = ops.pack_wsplit(P[k], batch=P[k].shape[0])
+    # PS-layout copies (csrc/igemm_ps.hip: both operands pre-split, moved to LDS by LDS-DMA) for the GEMMs whose A operand a
+    # producer can write in that layout: LayerNorm-folded projections (the statistics pass writes it), ff.net.2 (the GEGLU epilogue)
+    if engine_ps_enabled():
+        for k in list(P):
+            tail = k.rsplit(".", 1)[-1]
+            if tail in ("qkv_ln", "ff1_ln", "ff2") and P[k].dim() == 2 and P[k].shape[0] % 32 == 0 and P[k].shape[1] % 32 == 0:
+                P[k + "#p"] = ops.pack_wps(P[k])
+            elif tail in ("c1#wg", "c2#wg", "w#up") and P[k].shape[1] % 32 == 0 and P[k].shape[2] % 32 == 0:
+                P[k + "#p"] = ops.pack_wps(P[k], batch=P[k].shape[0])     # Winograd planes / upsampling phases (transforms write V in PS)
 
 
 def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_in, context_dim, unfolded=False, ln_flag=None):
@@ -164,33 +173,25 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
     nb_.release(coef)
     stats = pg.alloc(rows, 2)
 
-    def ln_lin(x2d, wkey, geglu):
-        """LayerNorm statistics + the Linear the LayerNorm is folded through.  Optionally (see below) the statistics pass
-        also writes the rows pre-split (three bf16 images) and the bf16x3 GEMM COPIES its A operand instead of splitting
-        every element once per N-tile."""
-        wp, xs = P[wkey], None
+    def ln_lin(x2d, wkey, geglu, out_ps=None):
+        """LayerNorm statistics + the Linear the LayerNorm is folded through.  With a pre-split plan for the GEMM
+        (engine.ps_query: csrc/igemm_ps.hip) the statistics pass also writes the rows in the PS layout and the GEMM moves them
+        to LDS by LDS-DMA -- every element is split once, by this pass, instead of once per N-tile inside the GEMM.
+        `out_ps`: (GEGLU only) the result goes out in the PS layout ONLY, for ff.net.2."""
+        wp = P[wkey]
         N_ = wp.shape[1]
-        # Measured at 64x64x4, B = 16 (r03 layer tables, one box): the GEGLU projections 269.0 / 198.5 / 209.6 -> 269.6 /
-        # 188.8 / 204.2 us, the QKV projections 99.5 / 90.6 / 70.4 -> 108.8 / 101.2 / 79.6 us, the statistics pass +4.5 us
-        # per call: 23.89 -> 24.45 ms per step.  Three 64-byte row streams of bf16 coalesce worse than one 128-byte fp32
-        # stream and are 1.5x the bytes; the split arithmetic they save was not what bounds the kernel.  OFF
-        # (LDMK_PRESPLIT_A=1 turns it on for experiments); the kernel path stays tested.
-        if engine_split_enabled() and C_ % 8 == 0 and os.environ.get("LDMK_PRESPLIT_A"):
-            probe = ops.make_igemm_args(rows, N_, C_, x2d, C_, wp, x2d, N_ // 2 if geglu else N_, hw, bias=P[wkey + "#b"],
-                                        tf=L.TF_LAYERNORM_FOLDED, row_stats=stats, ln_colsum=P[wkey + "#cs"],
-                                        epi=L.EPI_GEGLU if geglu else L.EPI_NONE, w_frag=P.get(wkey + "#f"))
-            pg.plan(probe, nb_.pin)
-            if probe.compute == L.COMPUTE_BF16X3 and probe.tile_cfg <= 6:
-                xs = pg.alloc(3, rows, C_, dtype=torch.bfloat16)
-        if xs is not None:
-            pg.add("ldmk_ln_stats_split", p_(x2d), rows, C_, 1e-5, p_(stats), p_(xs), C_)
-        else:
-            pg.add("ldmk_ln_stats_guard", p_(x2d), rows, C_, 1e-5, p_(stats), LN_GUARD_RATIO, p_(ln_flag))
-        y = lin(x2d, wp, P[wkey + "#b"], hw, geglu=geglu, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
-                ln_colsum=P[wkey + "#cs"], wf=P.get(wkey + "#f"), a_split=xs)
-        if xs is not None:
+        plan = nb_.ps_query(rows, N_, C_, tf=L.TF_LAYERNORM_FOLDED, epi=L.EPI_GEGLU if geglu else L.EPI_NONE) if wkey + "#p" in P else None
+        if plan is not None:
+            xs = pg.alloc_ps(rows, C_)
+            pg.add("ldmk_ln_stats_ps", p_(x2d), rows, C_, 1e-5, p_(stats), p_(xs), LN_GUARD_RATIO, p_(ln_flag))
+            y = nb_.lin_ps(plan, rows, C_, xs, wp, P[wkey + "#p"], P[wkey + "#b"], hw, geglu=geglu, out_ps=out_ps,
+                           tf=L.TF_LAYERNORM_FOLDED, row_stats=stats, ln_colsum=P[wkey + "#cs"])
             nb_.release(xs)
-        return y
+            return y
+        assert out_ps is None
+        pg.add("ldmk_ln_stats_guard", p_(x2d), rows, C_, 1e-5, p_(stats), LN_GUARD_RATIO, p_(ln_flag))
+        return lin(x2d, wp, P[wkey + "#b"], hw, geglu=geglu, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
+                   ln_colsum=P[wkey + "#cs"], wf=P.get(wkey + "#f"))
 
     for d in range(m.depth):
         q = f"{prefix}transformer_blocks.{d}."
@@ -242,14 +243,27 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
             h2 = lin(a2, P[q + "o2"], sd[q + "attn2.to_out.0.bias"], hw, residual=h1, out=h1, wf=P.get(q + "o2#f"))
             nb_.release(att, a2)
         # --- GEGLU feed-forward: LN3 folded into the first GEMM, gate in its epilogue
-        if unfolded:
-            pg.add("ldmk_ln_stats", p_(h2), rows, C_, 1e-5, p_(stats))
-            f = lin(h2, P[q + "ff1"], P[q + "ff1b"], hw, geglu=True, tf=L.TF_LAYERNORM, row_stats=stats,
-                    ln_gamma=sd[q + "norm3.weight"], ln_beta=sd[q + "norm3.bias"], wf=P.get(q + "ff1#f"))
+        # GEGLU projection -> ff.net.2: when both run on pre-split tiles (engine.ps_query) the intermediate exists in the PS
+        # layout only -- written by the GEGLU epilogue, split once -- never as an fp32 tensor
+        Nf = P[q + "ff2"].shape[0]
+        plan_g = plan_f = None
+        if not unfolded and q + "ff1_ln#p" in P and q + "ff2#p" in P:
+            plan_g = nb_.ps_query(rows, 2 * Nf, C_, tf=L.TF_LAYERNORM_FOLDED, epi=L.EPI_GEGLU)
+            plan_f = nb_.ps_query(rows, C_, Nf)
+        if plan_g is not None and plan_f is not None:
+            f_ps = pg.alloc_ps(rows, Nf)
+            ln_lin(h2, q + "ff1_ln", True, out_ps=f_ps)
+            hcur = nb_.lin_ps(plan_f, rows, Nf, f_ps, P[q + "ff2"], P[q + "ff2#p"], sd[q + "ff.net.2.bias"], hw, out=h2, residual=h2)
+            nb_.release(f_ps)
         else:
-            f = ln_lin(h2, q + "ff1_ln", True)
-        hcur = lin(f, P[q + "ff2"], sd[q + "ff.net.2.bias"], hw, residual=h2, out=h2, wf=P.get(q + "ff2#f"))
-        nb_.release(f)
+            if unfolded:
+                pg.add("ldmk_ln_stats", p_(h2), rows, C_, 1e-5, p_(stats))
+                f = lin(h2, P[q + "ff1"], P[q + "ff1b"], hw, geglu=True, tf=L.TF_LAYERNORM, row_stats=stats,
+                        ln_gamma=sd[q + "norm3.weight"], ln_beta=sd[q + "norm3.bias"], wf=P.get(q + "ff1#f"))
+            else:
+                f = ln_lin(h2, q + "ff1_ln", True)
+            hcur = lin(f, P[q + "ff2"], sd[q + "ff.net.2.bias"], hw, residual=h2, out=h2, wf=P.get(q + "ff2#f"))
+            nb_.release(f)
     out = lin(hcur, P[prefix + "pout"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True, wf=P.get(prefix + "pout#f"))
     nb_.release(hcur, stats)
     return out.view(n, h, w, m.ch)
@@ -515,7 +529,7 @@ class UNetModel(nn.Module):
             bv = emb_all.data_ptr() + 4 * self._emb_off[prefix]
             h1 = nb_.gn_conv(x0, x1, h, w, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5,
                              P[prefix + "c1"], P.get(prefix + "c1#wg"), sd[prefix + "in_layers.2.bias"], batch_vec=bv,
-                             bv_ld=self._emb_total, stats=True, wf=P.get(prefix + "c1#f"))
+                             bv_ld=self._emb_total, stats=True, wf=P.get(prefix + "c1#f"), u_ps=P.get(prefix + "c1#wg#p"))
             g2, b2 = sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"]
             if m.cin != m.cout:
                 x0r = x0.reshape(n * hw, -1)
@@ -523,11 +537,12 @@ class UNetModel(nn.Module):
                 skip = lin(x0r, P[prefix + "skip"], sd[prefix + "skip_connection.bias"], hw, x1=x1r, wf=P.get(prefix + "skip#f"))
                 out = nb_.gn_conv(h1, None, h, w, g2, b2, 1e-5, P[prefix + "c2"], P.get(prefix + "c2#wg"),
                                   sd[prefix + "out_layers.3.bias"], residual=skip, out=skip.view(n, h, w, m.cout), stats=True,
-                                  wf=P.get(prefix + "c2#f"))
+                                  wf=P.get(prefix + "c2#f"), u_ps=P.get(prefix + "c2#wg#p"))
             else:
                 assert x1 is None
                 out = nb_.gn_conv(h1, None, h, w, g2, b2, 1e-5, P[prefix + "c2"], P.get(prefix + "c2#wg"),
-                                  sd[prefix + "out_layers.3.bias"], residual=x0, stats=True, wf=P.get(prefix + "c2#f"))
+                                  sd[prefix + "out_layers.3.bias"], residual=x0, stats=True, wf=P.get(prefix + "c2#f"),
+                                  u_ps=P.get(prefix + "c2#wg#p"))
             nb_.release(h1)
             return out
 
@@ -549,7 +564,7 @@ class UNetModel(nn.Module):
                     out = conv(cur0, None, P[p + "w"], sd[p + "op.bias"], h, w, stride=2, stats=True)
                     h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
                 elif m.kind == "up":
-                    out = nb_.up_conv(cur0, h, w, P[p + "w"], P.get(p + "w#up"), sd[p + "conv.bias"], stats=True)
+                    out = nb_.up_conv(cur0, h, w, P[p + "w"], P.get(p + "w#up"), sd[p + "conv.bias"], stats=True, w4_ps=P.get(p + "w#up#p"))
                     h, w = 2 * h, 2 * w
                 else:
                     raise AssertionError(m.kind)

@@ -105,7 +105,10 @@ typedef struct ldmk_igemm_args {
                                 inside the workgroup: 2x1x4, 2x2x4, 1x1x4, 1x2x4, 1x1x8, 1x1x16, 2x1x8, 1x2x8; needs
                                 w_frag; stride-1 3x3 convolutions and rows mode), 21..22 = pin a warp-specialised tile of
                                 the LDMK_COMPUTE_BF16X3 arithmetic (csrc/igemm_ws.hip: 256x160 / 256x128, four consumer +
-                                four producer waves; bitwise the results of tile_cfg 5 / 1 at equal splitk).  The K-summation
+                                four producer waves; bitwise the results of tile_cfg 5 / 1 at equal splitk), 23..30 = pin a
+                                pre-split tile (csrc/igemm_ps.hip: 256x160, 256x320, 256x256, 128x320, 128x160, 128x256, and the
+                                warp-specialised 256x160 / 256x128 with four consumer + four LDS-DMA waves;
+                                needs a_ps and w_ps, see the end of this struct).  The K-summation
                                 order depends on (tile_cfg, splitk), so a caller that needs results that are
                                 bitwise independent of the batch size pins both (ldmk_igemm_plan)          */
   int splitk;                /* 0 = choose; 1 = none; 2..64 = split K over that many workgroups            */
@@ -140,7 +143,31 @@ typedef struct ldmk_igemm_args {
   int a_split_ld;            /*   the A operand pre-split as well, three bf16 images [3][M][a_split_ld] of a0 (ldmk_ln_stats_split   */
                              /*   writes them next to the row statistics): the kernel copies instead of splitting per N-tile.        */
                              /*   Results are bitwise those of the in-kernel split.                                                  */
+  /* ---- tile_cfg 23..30 (csrc/igemm_ps.hip): LDMK_COMPUTE_BF16X3 on operands that are BOTH pre-split, in the PS layout:
+   * for a matrix X[R][K] (K % 16 == 0) plane g (0 hi, 1 mid, 2 lo) of element (r, k) is the bf16 at index
+   *     (((r / 32) (K / 16) + k / 16) 3 + g) 512 + ((k / 8 % 2) 32 + r % 32) 8 + k % 8
+   * i.e. per (32-row block, 16-deep k-slab) three consecutive 1-KiB planes, each in the lane order of the MFMA operand; rows
+   * R .. 32 ceil(R / 32) - 1 are padding (any finite or non-finite content: it only reaches output rows that are masked).
+   * ldmk_ps_bytes(R, K) is the size.  The kernel moves these planes memory -> LDS with LDS-DMA loads and does no arithmetic
+   * on them: rows mode, a_tf NONE or LAYERNORM_FOLDED, K % 32 == 0, N % 32 == 0.  Same products, product order and split-K
+   * partition as tile_cfg 1 / 5: bitwise equal results at equal splitk. */
+  const void* a_ps;          /* A[M][K] in the PS layout (ldmk_pack_ps, ldmk_ln_stats_ps, out_ps of a producer GEMM, ...); a0 is not read */
+  long long a_ps_bstride;    /*   BYTES between batch entries                                                               */
+  const void* w_ps;          /* the weights as X[N][K] (row = output column) in the PS layout: ldmk_pack_ps(w, N, K, 1, ldb)   */
+  long long w_ps_bstride;    /*   BYTES between batch entries                                                               */
+  void* out_ps;              /* optional: the result [M][ldc] written in the PS layout too (the A operand of the next GEMM; every  */
+                             /*   element is split once, by its producer); `out` may then be NULL.  No split-K / batch / stats_out. */
 } ldmk_igemm_args;
+
+/* size in bytes of the PS layout of a [rows][k] matrix (-1: k not a multiple of 16) */
+long long ldmk_ps_bytes(int rows, int k);
+/* X[r][k] = src[r row_stride + k k_stride] (fp32; `batch` matrices src_bstride floats apart) -> PS layout, ldmk_ps_bytes(rows, k)
+ * bytes per batch entry.  Activations [rows][ld]: (ld, 1); packed weights w[K][ldb] as X[N][K]: rows = N, (1, ldb). */
+int ldmk_pack_ps(const float* src, int rows, int k, long long row_stride, long long k_stride, int batch, long long src_bstride,
+                 void* dst, void* stream);
+/* ldmk_ln_stats_guard and the rows themselves in the PS layout (the statistics pass reads every element anyway): what the
+ * LDMK_TF_LAYERNORM_FOLDED GEMMs on tile_cfg 23..28 take as a_ps.  C % 16 == 0, C <= 1280; two-pass statistics in registers. */
+int ldmk_ln_stats_ps(const float* x, int rows, int c, float eps, float* stats, void* dst, float guard, int* flag, void* stream);
 
 /* w[K][ldb] fp32 (row-major, as ldmk_igemm reads it with b_trans = 0; `batch` matrices w_bstride floats apart) -> the three
  * bf16 images [batch][3][N][ld_out] of its exact three-way split, transposed so that every output column's K run is
@@ -191,6 +218,11 @@ int ldmk_igemm_plan(const ldmk_igemm_args* args, int* tile_cfg, int* splitk);
 long long ldmk_winograd_tiles(int n, int h, int w);
 int ldmk_winograd_input(const float* x0, int c0, const float* x1, int c1, const float* coef, int silu, int n, int h, int w,
                         float* v, void* stream);
+/* ldmk_winograd_input writing V in the PS layout: 16 planes of ldmk_ps_bytes(tiles, c0 + c1) bytes each -- the a_ps operand
+ * (a_ps_bstride = that size) of the batched GEMM on the pre-split tiles.  c0, c1 multiples of 16.  V is bit for bit the matrix
+ * ldmk_winograd_input writes, split exactly. */
+int ldmk_winograd_input_ps(const float* x0, int c0, const float* x1, int c1, const float* coef, int silu, int n, int h, int w,
+                           void* v_ps, void* stream);
 int ldmk_winograd_output(const float* m, const float* bias, const float* batch_vec, int batch_vec_ld, const float* residual,
                          float* out, float* stats_out, int n, int h, int w, int cout, void* stream);
 
@@ -200,6 +232,8 @@ int ldmk_winograd_output(const float* m, const float* bias, const float* batch_v
  *   ldmk_igemm         : batch = 4, M = n h w, K = 4 c, N = cout, w from dsml_thesis_amd.ops.pack_upconv (w_bstride = K N)
  *   ldmk_upconv_scatter: out (n, 2h, 2w, cout) NHWC = the 4 planes interleaved + bias; optional GroupNorm partial records */
 int ldmk_upconv_gather(const float* x, int c, int n, int h, int w, float* a, void* stream);
+/* ldmk_upconv_gather writing the four phase operands in the PS layout: 4 planes of ldmk_ps_bytes(n h w, 4 c) bytes. c % 16 == 0. */
+int ldmk_upconv_gather_ps(const float* x, int c, int n, int h, int w, void* a_ps, void* stream);
 int ldmk_upconv_scatter(const float* planes, const float* bias, float* out, float* stats_out, int n, int h, int w, int cout,
                         void* stream);
 

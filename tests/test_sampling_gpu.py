@@ -373,7 +373,7 @@ def test_ema_scope_swaps_weights_and_repacks(fr):
     finally:
         unet.policy_batch = None
     close(ema16, ref, 1.5e-4, 1.5e-4)
-    close(base16, base, 3e-5, 3e-5)
+    close(base16, base.cpu(), 3e-5, 3e-5)
     assert not torch.allclose(base16, ema16) and torch.equal(base16, again16)
     keys = fr.state_dict().keys()
     assert "model.diffusion_model.input_blocks.1.0.in_layers.2.weight" in keys

@@ -46,12 +46,12 @@ def dump(latent, batch, path, graph=False):
     torch.cuda.synchronize()
 
 
-KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "igemm_ws_kernel", "rgemm_kernel", "sgemm_kernel"), "ldmk_post": ("post_",),
+KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "igemm_ws_kernel", "igemm_ps_kernel", "igemm_pw_kernel", "rgemm_kernel", "sgemm_kernel"), "ldmk_post": ("post_",),
              "ldmk_attn_self_small": ("attn_small",), "ldmk_conv3x3_out_small": ("conv3x3_out_small",), "ldmk_gn_finalize": ("gn_finalize",), "ldmk_gn_apply": ("gn_apply",),
-             "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_ln_stats_split": ("ln_stats",), "ldmk_attn_self": ("attn_self",), "ldmk_attn_self_x3": ("attn_x3",),
+             "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_ln_stats_guard": ("ln_stats",), "ldmk_ln_stats_split": ("ln_stats",), "ldmk_ln_stats_ps": ("ln_stats_ps",), "ldmk_pack_ps": ("pack_ps",), "ldmk_attn_self": ("attn_self",), "ldmk_attn_self_x3": ("attn_x3",),
              "ldmk_attn_cross": ("attn_cross",), "ldmk_dense_small": ("dense_small",),
              "ldmk_timestep_embedding": ("timestep_embedding",), "ldmk_conv3x3_in": ("conv3x3_in",),
-             "ldmk_conv3x3_out": ("conv3x3_out",), "ldmk_winograd_input": ("wino_input",),
+             "ldmk_conv3x3_out": ("conv3x3_out",), "ldmk_winograd_input": ("wino_input",), "ldmk_winograd_input_ps": ("wino_input_ps",), "ldmk_upconv_gather_ps": ("upconv_gather_ps",),
              "ldmk_winograd_output": ("wino_output",), "ldmk_upconv_gather": ("upconv_gather",),
              "ldmk_upconv_scatter": ("upconv_scatter",)}
 PEAK_F32_MFMA = 157.3
@@ -90,7 +90,7 @@ def join(d):
             assert "post_gnapply" in last[i]["Kernel_Name"], last[i]["Kernel_Name"]
             d_ += dur(last[i])
             i += 1
-        if (c["name"] == "ldmk_igemm" and any(k in r["Kernel_Name"] for k in ("igemm_kernel", "igemm_ws_kernel", "sgemm_kernel"))
+        if (c["name"] == "ldmk_igemm" and any(k in r["Kernel_Name"] for k in ("igemm_kernel", "igemm_ws_kernel", "igemm_ps_kernel", "igemm_pw_kernel", "sgemm_kernel"))
                 and c.get("sk", 1) > 1 and not c.get("raw")):
             assert "igemm_reduce" in last[i]["Kernel_Name"], (c, last[i]["Kernel_Name"])
             c["main_us"] = d_
