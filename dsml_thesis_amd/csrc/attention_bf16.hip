@@ -444,6 +444,183 @@ __global__ __launch_bounds__(256) void attn_x3_fwd_kernel(const float* __restric
   store_rows_bf(ts, o, 1.0f / l_run, out + (long long)b * tokens * C + h * BA_D, C, q0, tokens, l31, half);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel with K and V PRE-SPLIT (round 4).  attn_x3_fwd_kernel re-splits every K / V element once per 128-query
+// workgroup -- tokens / 128 times (32 x at 4096 tokens) -- and stores the V^T images with 2-byte LDS writes: ~44 of its ~250
+// vector operations per 32 keys and wave, plus 15 LDS stores.  Here a pre-pass (attn_kv_split_kernel) splits K and V ONCE
+// per (sample, head, 64-key tile) and writes the six images in MFMA-operand order -- per tile 8 fragments x 3 planes of 1 KiB:
+//   fragment 2 sub + t      : K  rows (keys)  sub 32 + l31, d = 16 t + 8 half .. + 7                  (A operand of S^T = K Q^T)
+//   fragment 4 + 2 sub + t  : V^T rows d = l31, keys sub 32 + 16 t + 4 half + (j & 3) + 8 (j >> 2)    (A operand of O^T += V^T P^T:
+//                             the order in which the probabilities leave the first product's accumulator)
+// and the attention kernel moves a tile memory -> LDS with LDS-DMA (`buffer_load_dwordx4 ... lds`, 6 pieces per wave), double
+// buffered, and reads every operand with one conflict-free ds_read_b128.  Same split values, same instruction sequence per
+// accumulator: bitwise the results of attn_x3_fwd_kernel.
+typedef unsigned int au32x4 __attribute__((ext_vector_type(4)));
+constexpr int X3P_TILE = 24 * 1024;           // bytes per 64-key tile: (4 K + 4 V^T fragments) x 3 planes x 1 KiB
+
+__global__ __launch_bounds__(256) void attn_kv_split_kernel(const float* __restrict__ qkv, unsigned char* __restrict__ kv, int tokens, int heads) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int C = heads * BA_D, ld = 3 * C;
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int ntiles = gridDim.x;
+  const float* base = qkv + (long long)b * tokens * ld + h * BA_D;
+  unsigned char* dst = kv + (((long long)b * heads + h) * ntiles + kt) * X3P_TILE;
+  const int sub = wave >> 1, t = wave & 1;
+  // K fragment (sub, t): this lane's key row, 8 consecutive d
+  {
+    const int key = kt * BA_T + sub * 32 + l31;
+    float v[8];
+    if (key < tokens) {
+      const float* p = base + C + (long long)key * ld + 16 * t + 8 * half;
+      const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    bf16x8_t g[3];
+    split8(v, g);
+    unsigned char* d = dst + (2 * sub + t) * 3072 + lane * 16;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8_t*>(d + q * 1024) = g[q];
+  }
+  // V^T fragment (sub, t): this lane's d, 8 keys in accumulator order
+  {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int key = kt * BA_T + sub * 32 + 16 * t + 4 * half + (j & 3) + 8 * (j >> 2);
+      v[j] = key < tokens ? base[2 * C + (long long)key * ld + l31] : 0.f;
+    }
+    bf16x8_t g[3];
+    split8(v, g);
+    unsigned char* d = dst + (4 + 2 * sub + t) * 3072 + lane * 16;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8_t*>(d + q * 1024) = g[q];
+  }
+}
+
+__device__ __forceinline__ void x3p_dma3(unsigned voff, const au32x4& rs, unsigned lds_dst) {     // 3 x 1 KiB, contiguous both sides
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+               "buffer_load_dwordx4 %1, %2, 0 offen offset:1024 lds\n\t"
+               "buffer_load_dwordx4 %1, %2, 0 offen offset:2048 lds\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+}
+
+__global__ __launch_bounds__(256) void attn_x3p_fwd_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ kv,
+                                                           float* __restrict__ out, int tokens, int heads, float scale) {
+  // two tile buffers; after the key loop the same memory is the four output transpose buffers
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_p[2 * X3P_TILE];
+  static_assert(2 * X3P_TILE >= 4 * 32 * BA_FS * 4, "transpose buffers alias the tile buffers");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
+  const int C = heads * BA_D, ld = 3 * C;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float* base = qkv + (long long)b * tokens * ld;
+  const bool wave_active = q0 < tokens;
+  const bool q_valid = q0 + l31 < tokens;
+  constexpr float LOG2E = 1.4426950408889634f;
+  bf16x8_t qf[2][3];
+  {
+    const float* rowp = base + (long long)(q_valid ? q0 + l31 : 0) * ld + h * BA_D;
+    const float mul = q_valid ? scale * LOG2E : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 a = *reinterpret_cast<const float4*>(rowp + 16 * t + 8 * half), c = *reinterpret_cast<const float4*>(rowp + 16 * t + 8 * half + 4);
+      const float v[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, c.x * mul, c.y * mul, c.z * mul, c.w * mul};
+      split8(v, qf[t]);
+    }
+  }
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int ntiles = (tokens + BA_T - 1) / BA_T;
+  // this (sample, head)'s tiles as one buffer; wave w moves fragments 2w, 2w + 1 of a tile (6 KiB contiguous)
+  const unsigned char* kvh = kv + ((long long)b * heads + h) * ntiles * X3P_TILE;
+  au32x4 rs;
+  {
+    const unsigned long long a = (unsigned long long)kvh;
+    rs.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    rs.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+    rs.z = __builtin_amdgcn_readfirstlane((unsigned)ntiles * (unsigned)X3P_TILE);
+    rs.w = 0x00020000u;
+  }
+  const unsigned lds0 = (unsigned)(size_t)smem_p;
+  const unsigned woff = (unsigned)wave * 6144u + (unsigned)lane * 16u;
+  auto fetch = [&](int kt) {                      // LDS-DMA of tile kt into buffer kt & 1 (tiles past the end: out of range, zeros)
+    const unsigned dstb = lds0 + (unsigned)(kt & 1) * X3P_TILE + (unsigned)wave * 6144u;
+    const unsigned src = (unsigned)kt * (unsigned)X3P_TILE + woff;
+    x3p_dma3(src, rs, dstb);
+    x3p_dma3(src + 3072u, rs, dstb + 3072u);
+  };
+  fetch(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
+    asm volatile("s_barrier" ::: "memory");               // ... everyone's have, and the other buffer is no longer read
+    fetch(kt + 1);                                        // in flight under this tile's products
+    if (!wave_active) continue;
+    const unsigned char* tb = smem_p + (kt & 1) * X3P_TILE + lane * 16;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int key0 = kt * BA_T + sub * 32;
+      if (key0 >= tokens) break;
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8_t ka[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ka[q] = *reinterpret_cast<const bf16x8_t*>(tb + ((2 * sub + t) * 3 + q) * 1024);
+        s = mm6(ka, qf[t], s);                                                          // S^T[key][q], log2 domain
+      }
+      if (key0 + 32 > tokens) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s[r] = -INFINITY;
+      }
+      float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+      for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); psum += s[r]; }
+      psum += __shfl_xor(psum, 32, 64);
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {      // rescale only when some lane's maximum moved
+        const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= corr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= corr;
+        m_run = m_new;
+      }
+      l_run += psum;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv[j] = s[8 * t + j];
+        bf16x8_t pb[3], va[3];
+        split8(pv, pb);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) va[q] = *reinterpret_cast<const bf16x8_t*>(tb + ((4 + 2 * sub + t) * 3 + q) * 1024);
+        o = mm6(va, pb, o);                                                             // O^T[d][q] += V^T P^T
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the trailing out-of-range fetch)
+  __syncthreads();                     // every wave is done with the tile buffers: their memory becomes the transpose buffers
+  if (!wave_active) return;
+  float* ts = reinterpret_cast<float*>(smem_p) + wave * (32 * BA_FS);
+  store_rows_bf(ts, o, 1.0f / l_run, out + (long long)b * tokens * C + h * BA_D, C, q0, tokens, l31, half);
+}
+
 }  // namespace ldmk
 
 extern "C" int ldmk_attn_self_x3(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream) {
@@ -453,6 +630,24 @@ extern "C" int ldmk_attn_self_x3(const float* qkv, float* out, int n, int tokens
   dim3 grid((tokens + 127) / 128, heads, n);
   hipLaunchKernelGGL(attn_x3_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, tokens, heads, scale);
   return check_launch("ldmk_attn_self_x3");
+}
+
+extern "C" long long ldmk_attn_kv_split_bytes(int n, int tokens, int heads) {
+  if (n <= 0 || tokens <= 0 || heads <= 0) return -1;
+  return (long long)n * heads * ((tokens + ldmk::BA_T - 1) / ldmk::BA_T) * ldmk::X3P_TILE;
+}
+
+extern "C" int ldmk_attn_self_x3p(const float* qkv, void* kv_scratch, float* out, int n, int tokens, int heads, float scale, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(qkv && kv_scratch && out && n > 0 && tokens > 0 && heads > 0 && heads <= 65535 && n <= 65535, "ldmk_attn_self_x3p: bad args");
+  const int ntiles = (tokens + BA_T - 1) / BA_T;
+  LDMK_REQUIRE((long long)ntiles * X3P_TILE < (1LL << 31), "ldmk_attn_self_x3p: %d tokens: a head's pre-split K / V exceeds 2 GiB", tokens);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_kv_split_kernel, dim3(ntiles, heads, n), dim3(256), 0, st, qkv, reinterpret_cast<unsigned char*>(kv_scratch), tokens, heads);
+  hipLaunchKernelGGL(attn_x3p_fwd_kernel, dim3((tokens + 127) / 128, heads, n), dim3(256), 0, st, qkv,
+                     reinterpret_cast<const unsigned char*>(kv_scratch), out, tokens, heads, scale);
+  return check_launch("ldmk_attn_self_x3p");
 }
 
 extern "C" int ldmk_attn_self_lse_bf16(const float* qkv, float* out, float* lse, int n, int tokens, int heads, float scale,

@@ -100,6 +100,8 @@ _SIGS = {
     "ldmk_post_scratch_elems": (C.c_longlong, [C.POINTER(PostArgs)]),
     "ldmk_attn_self": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_self_x3": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    "ldmk_attn_kv_split_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "ldmk_attn_self_x3p": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_self_small": (C.c_int, [_fp, C.c_int, C.c_longlong, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_cross": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_float, _fp]),

@@ -471,11 +471,16 @@ def bmm(a, b, b_trans, alpha=1.0, out=None):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def attn_self(qkv, n, tokens, heads, out=None, x3=False):
-    """x3: both products in the fp32-accurate three-way bf16 split arithmetic (ldmk_attn_self_x3)."""
+def attn_self(qkv, n, tokens, heads, out=None, x3=False, presplit=False):
+    """x3: both products in the fp32-accurate three-way bf16 split arithmetic (ldmk_attn_self_x3); presplit: its form with K / V
+    split once by a pre-pass and moved to LDS by LDS-DMA (ldmk_attn_self_x3p: bitwise the same result)."""
     C_ = heads * 32
     if out is None:
         out = torch.empty(n * tokens, C_, device=qkv.device, dtype=torch.float32)
+    if presplit:
+        kv = torch.empty(L.load().ldmk_attn_kv_split_bytes(n, tokens, heads), device=qkv.device, dtype=torch.uint8)
+        L.call("ldmk_attn_self_x3p", _ptr(qkv), _ptr(kv), _ptr(out), n, tokens, heads, 32 ** -0.5, stream())
+        return out
     L.call("ldmk_attn_self_x3" if x3 else "ldmk_attn_self", _ptr(qkv), _ptr(out), n, tokens, heads, 32 ** -0.5, stream())
     return out
 

@@ -27,6 +27,11 @@ from .engine import NetBuilder, Program, split_enabled as engine_split_enabled, 
 LN_GUARD_RATIO = float(os.environ.get("LDMK_LN_GUARD_RATIO", "4.0"))
 
 
+# self attention with K / V pre-split by a pre-pass (csrc/attention_bf16.hip: attn_x3p_fwd_kernel): the pre-pass costs one sweep
+# over K and V, the key loop saves its K / V splits tokens / 128 times: from this many tokens per sample
+ATTN_PRESPLIT_MIN_TOKENS = int(os.environ.get("LDMK_ATTN_PRESPLIT_MIN_TOKENS", "256"))
+
+
 def ln_unfolded_default():
     return bool(os.environ.get("LDMK_LN_UNFOLDED"))
 
@@ -205,8 +210,15 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
         att = pg.alloc(rows, C_)
         # both attention products in the fp32-accurate bf16x3 arithmetic (24 bf16 MFMAs of 32 cycles per 32 keys
         # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel
-        pg.add("ldmk_attn_self_x3" if engine_split_enabled() else "ldmk_attn_self", p_(qkv), p_(att), n, hw, m.heads,
-               m.d_head ** -0.5)
+        # (from 1024 tokens at the plan-policy batch: K / V split once by a pre-pass instead of once per 128-query workgroup,
+        #  tiles moved to LDS by LDS-DMA -- ldmk_attn_self_x3p, bitwise the same result; LDMK_ATTN_PRESPLIT=0 turns it off)
+        if engine_split_enabled() and hw >= ATTN_PRESPLIT_MIN_TOKENS and os.environ.get("LDMK_ATTN_PRESPLIT", "1") != "0":
+            kvs = pg.alloc(pg.lib.ldmk_attn_kv_split_bytes(n, hw, m.heads), dtype=torch.uint8)
+            pg.add("ldmk_attn_self_x3p", p_(qkv), p_(kvs), p_(att), n, hw, m.heads, m.d_head ** -0.5)
+            nb_.release(kvs)
+        else:
+            pg.add("ldmk_attn_self_x3" if engine_split_enabled() else "ldmk_attn_self", p_(qkv), p_(att), n, hw, m.heads,
+                   m.d_head ** -0.5)
         nb_.release(qkv)
         if L_ctx == 1:
             # --- attn2 with a single context token: softmax over one key == 1, so the block adds

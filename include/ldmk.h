@@ -334,6 +334,12 @@ int ldmk_attn_self(const float* qkv, float* out, int n, int tokens, int heads, f
  *   (LDMK_COMPUTE_BF16X3 above: Q, K, V and the probabilities are exact sums of three bf16 values, six partial products each,
  *   fp32 accumulation, fp32 softmax): the accuracy class of ldmk_attn_self at the bf16 matrix rate. */
 int ldmk_attn_self_x3(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream);
+/* ldmk_attn_self_x3p: ldmk_attn_self_x3 with K and V split ONCE, by a pre-pass, instead of once per 128-query workgroup: the
+ *   pre-pass writes the three bf16 planes of every 64-key tile of every (sample, head) in MFMA-operand order into `kv_scratch`
+ *   (ldmk_attn_kv_split_bytes(n, tokens, heads) bytes, caller-owned), the attention kernel moves tiles memory -> LDS with
+ *   LDS-DMA loads and does no arithmetic on K / V.  Bitwise the results of ldmk_attn_self_x3. */
+long long ldmk_attn_kv_split_bytes(int n, int tokens, int heads);
+int ldmk_attn_self_x3p(const float* qkv, void* kv_scratch, float* out, int n, int tokens, int heads, float scale, void* stream);
 /* ldmk_attn_self_small: the same product for SMALL problems (batch 1-2: the reference's talking-face mode runs batch 1,
  *   talking_face/progressive_sampling_difftalk.py:350).  One workgroup per 32-query tile of a (sample, head), the keys split
  *   over its 4 / 8 waves and streamed from global memory without LDS staging, partial (max, sum, O) merged in wave order

@@ -279,3 +279,14 @@ def test_pre_split_activations_are_bitwise_the_in_kernel_split(ops, M, K, N, geg
     for kw in (dict(compute=L.COMPUTE_F32), dict(compute=L.COMPUTE_BF16X3, tile_cfg=21)):
         a = ops.make_igemm_args(M, N, K, xc, K, w2, y0, y0.shape[1], M, a_split=xs, **kw)
         assert L.load().ldmk_igemm_check(ctypes.byref(a)) != 0
+
+
+@pytest.mark.parametrize("n,tokens,heads", [(2, 4096, 5), (1, 1024, 10), (3, 256, 20), (1, 960, 5), (2, 60, 5), (1, 4, 5), (1, 129, 10)])
+def test_presplit_attention_is_bitwise_the_split_attention(ops, n, tokens, heads):
+    """ldmk_attn_self_x3p: K / V split once by a pre-pass into MFMA-operand-order planes, tiles moved to LDS by LDS-DMA.  Same
+    split values and the same instruction sequence per accumulator as ldmk_attn_self_x3: equal bit for bit, ragged token counts
+    (partial 64-key tiles, partial 128-query workgroups) included."""
+    qkv = (rnd(560, n * tokens, 3 * heads * 32) * 1.5).cuda()
+    ref = ops.attn_self(qkv, n, tokens, heads, x3=True)
+    out = ops.attn_self(qkv, n, tokens, heads, presplit=True)
+    assert torch.equal(out, ref)
