@@ -199,11 +199,13 @@ def cpu_baseline(latent, budget_s=30.0, min_steps=20):
                        f"{latent}x{latent}x{cfg['in_channels']} latent, FR UNet; step times {min(times):.2f}-{max(times):.2f} s")
 
 
-def clip_leg(rank, world, dev, dist, barrier, frames=128, ddim_steps=20, window=8):
+def clip_leg(rank, world, dev, dist, barrier, frames=128, ddim_steps=20, window=8, policy="shard"):
     """BASELINE configs[2] (N = 1) / configs[3] (N > 1): the talking-face clip in fixed-identity mode, frames
     sharded contiguously over the ranks, per-frame start noise from (seed, global frame index), hipGraph-captured DDIM
-    step, decode, and ONE all-gather of the decoded frames -- all inside the timed region.  Tile plans are pinned to the
-    whole clip (policy_batch), so the gathered result and its checksum do not depend on N."""
+    step, decode, and ONE all-gather of the decoded frames -- all inside the timed region.  policy "shard" (the default of
+    the timed leg): every rank runs the launch plans tuned for ITS frames/GPU batch, result equal to the 1-GPU run within the
+    sampling tolerance; policy "job" (--clip-policy job): plans pinned to the whole clip, gathered result and checksum bitwise
+    independent of N (what the rank-count test compares)."""
     from dsml_thesis_amd.synth import make_tf_model
     from dsml_thesis_amd.ddim import DDIMSampler, C12, C34
     from dsml_thesis_amd.parallel import sample_sharded
@@ -226,12 +228,13 @@ def clip_leg(rank, world, dev, dist, barrier, frames=128, ddim_steps=20, window=
             c12 = torch.cat([c1.expand(hi - lo, -1, -1), c2], dim=2)
             c34 = torch.cat([m.encode_first_stage(masked[lo:hi]), xid.expand(hi - lo, -1, -1, -1)], dim=1)
             return {C12: c12, C34: c34}
-        return sample_sharded(s, ddim_steps, T, (3, 32, 32), cond, seed=5, rank=rank, world_size=world)
+        return sample_sharded(s, ddim_steps, T, (3, 32, 32), cond, seed=5, rank=rank, world_size=world, policy=policy)
 
     job()                                   # builds the launch programs and captures the step graph (untimed)
     els = []
-    for _ in range(3):                      # three whole jobs, each between barriers; the median is reported (a single job
-        barrier()                           # varied by +-7 % from run to run: host-side start noise, allocator state)
+    njobs = 1 if ddim_steps >= 100 else 3   # the shipped DDIM-200 job takes seconds: one timed job; short ones: the median of three
+    for _ in range(njobs):                  # whole jobs, each between barriers (a single SHORT job varied by +-7 % from run to
+        barrier()                           # run: host-side start noise, allocator state)
         t0 = time.perf_counter()
         out = job()
         barrier()
@@ -241,17 +244,51 @@ def clip_leg(rank, world, dev, dist, barrier, frames=128, ddim_steps=20, window=
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = tt.item()
         els.append(el)
-    el = sorted(els)[1]
+    el = sorted(els)[len(els) // 2]
     assert out.shape == (T, 128, 128, 3) and torch.isfinite(out).all()
     per = -(-T // world)
     return {"workload": f"talking_face audio-conditioned LDM, {T}-frame clip (fixed identity), DDIM-{ddim_steps}, encode + "
                         f"{ddim_steps} steps + decode + gather, {per} frames/GPU", "frames": T, "ddim_steps": ddim_steps,
-            "scaling": "strong", "seconds": round(el, 4), "seconds_of_3_jobs": [round(e, 4) for e in els],
+            "scaling": "strong", "plan_policy": policy, "seconds": round(el, 4), "seconds_of_jobs": [round(e, 4) for e in els],
             "frames_per_s": round(T / el, 2),
             "sample_steps_per_s": round(T * ddim_steps / el, 1),
             "collective": ("none (1 rank)" if world == 1 else
                            f"one all_gather_into_tensor of the decoded frames, {per}x128x128x3 fp32 per rank"),
             "checksum": float(out.double().sum())}
+
+
+def shard_cost_leg(dev, ddim_steps, frames=16, job_frames=128, window=8):
+    """One rank's share of configs[3] on this one GPU: 16 frames of the 128-frame clip, DDIM steps + decode, timed with the
+    launch plans of the whole job (policy "job": bitwise equal to the 1-GPU clip) and with the plans of a 16-frame batch
+    (policy "shard")."""
+    from dsml_thesis_amd.synth import make_tf_model
+    from dsml_thesis_amd.ddim import DDIMSampler, C12, C34
+    from dsml_thesis_amd.parallel import sample_sharded
+    T, W_ = frames, window
+    m = make_tf_model(gain=0.25, seq_len=2 * W_ + 1, device=dev)
+    rs = np.random.RandomState(2)
+    audio = torch.from_numpy(rs.standard_normal((T, 768)).astype(np.float32)).to(dev)
+    masked = torch.tanh(torch.from_numpy(rs.standard_normal((T, 3, 128, 128)).astype(np.float32))).to(dev)
+    ident = torch.tanh(torch.from_numpy(rs.standard_normal((1, 3, 128, 128)).astype(np.float32))).to(dev)
+    c1 = m.cond_stage_model_1.embedding(torch.tensor([[4]], device=dev))
+    s = DDIMSampler(m)
+    idx = torch.tensor([[min(max(f + i, 0), T - 1) for i in range(-W_, W_ + 1)] for f in range(T)], device=dev)
+    xid = m.encode_first_stage(ident)
+    c2 = m.cond_stage_model_2(audio[idx])
+    cond = {C12: torch.cat([c1.expand(T, -1, -1), c2], dim=2), C34: torch.cat([m.encode_first_stage(masked), xid.expand(T, -1, -1, -1)], dim=1)}
+    res = {}
+    for pol, items in (("job", job_frames), ("shard", frames)):
+        fn = lambda: sample_sharded(s, ddim_steps, T, (3, 32, 32), lambda lo, hi: {k: v[lo:hi] for k, v in cond.items()}, seed=5,
+                                    _policy_items=items)
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        res[pol] = round(time.perf_counter() - t0, 4)
+        assert torch.isfinite(out).all()
+    return {"workload": f"{frames} frames (one rank's block of the {job_frames}-frame clip on 8 GPUs), DDIM-{ddim_steps} + decode, one GPU",
+            "seconds_plans_of_the_job": res["job"], "seconds_plans_of_the_shard": res["shard"]}
 
 
 def batch1_leg(dev, frames=4, ddim_steps=50, window=8):
@@ -289,7 +326,34 @@ def batch1_leg(dev, frames=4, ddim_steps=50, window=8):
     el = sorted(els)[1]
     assert len(fr) == T and all(torch.isfinite(f).all() for f in fr)
     pg = m.model.diffusion_model.program(1, 32, 32, 1, 6)
-    return {"workload": f"talking_face autoregressive clip (the reference's shipped mode), batch 1, {T} frames x DDIM-{ddim_steps}, "
+    # the reference's real job is a LOOP over 150 test videos (progressive_sampling_difftalk.py:336): V independent clips advanced
+    # frame by frame together (progressive_sampling(..., clips=V)) run the same serial chains at the batched rate
+    V = 16
+    audio_v = [torch.from_numpy(np.random.RandomState(30 + v).standard_normal((T, 768)).astype(np.float32)).to(dev) for v in range(V)]
+    masked_v = [masked for _ in range(V)]
+    ident_v = torch.tanh(torch.from_numpy(np.random.RandomState(50).standard_normal((V, 3, 128, 128)).astype(np.float32))).to(dev)
+    xT_v = [torch.from_numpy(np.random.RandomState(60 + v).standard_normal((T, 1, 3, 32, 32)).astype(np.float32)).to(dev) for v in range(V)]
+    c1_v = m.cond_stage_model_1.embedding((torch.arange(V, device=dev) % 8)[:, None])
+
+    def clips():
+        xid = torch.cat([m.encode_first_stage(ident_v[v:v + 1]) for v in range(V)])
+        fr, _ = s.progressive_sampling(c1_v, xid, masked_v, audio_v, ddim_steps, 1, None, (3, 32, 32), W_, eta=0.0, x_T=xT_v,
+                                       clips=V, use_graph=True)
+        return fr
+    clips()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frv = clips()
+    torch.cuda.synchronize()
+    elv = time.perf_counter() - t0
+    assert len(frv) == V and all(len(f) == T for f in frv) and all(torch.isfinite(x).all() for f in frv for x in f)
+    clips16 = {"workload": f"{V} independent autoregressive clips in lock step (progressive_sampling(clips={V})): every frame of every clip is "
+                           f"its own serial chain, one batch of {V} per DDIM step; {T} frames x DDIM-{ddim_steps} each",
+               "clips": V, "seconds": round(elv, 4), "sample_steps_per_s": round(V * T * ddim_steps / elv, 1),
+               "ms_per_step": round(1e3 * elv / (T * ddim_steps), 4),
+               "frames_per_s_at_ddim200": round(V / (200 * elv / (T * ddim_steps)), 3)}
+    return {"clips16": clips16,
+            "workload": f"talking_face autoregressive clip (the reference's shipped mode), batch 1, {T} frames x DDIM-{ddim_steps}, "
                         f"32x32x3 latent, hipGraph step; conditioning encoders included, decode not",
             "frames": T, "ddim_steps": ddim_steps, "seconds": round(el, 4), "ms_per_step": round(1e3 * el / (T * ddim_steps), 4),
             "sample_steps_per_s": round(T * ddim_steps / el, 1),
@@ -298,11 +362,57 @@ def batch1_leg(dev, frames=4, ddim_steps=50, window=8):
             "route": "small-batch program (unet_small.py)" if getattr(pg, "small_route", False) else "batched program"}
 
 
+def end_to_end_leg(dev, latent, batch, ddim_steps=200):
+    """BASELINE configs[1] END TO END, the native counterpart of face_reenactment/sample_affectnet.py:66-137 (what
+    tools/sample_faces.py prints): inside ema_scope, DDIMSampler.sample (hipGraph step) at classifier-free-guidance scale 1.0
+    and 3.0 (batch doubled: two UNet evaluations per sample-step), then decode_first_stage + clamp to [0,1] NHWC.  Each setting
+    runs twice; the second run (programs built, graph captured) is timed."""
+    from dsml_thesis_amd.ddim import DDIMSampler
+    from dsml_thesis_amd import ops
+    model, ucfg = build_model(latent, dev)
+    sampler = DDIMSampler(model)
+    labels = (torch.arange(batch, device=dev) % 8)[:, None]
+    res = {}
+    with model.ema_scope():
+        c = model.cond_stage_model.embedding(labels)
+        for scale in (1.0, 3.0):
+            uc = model.cond_stage_model.uncond_embedding(torch.zeros_like(labels)) if scale > 1.0 else None
+            for rep in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                z, _ = sampler.sample(S=ddim_steps, batch_size=batch, shape=[ucfg["in_channels"], latent, latent], conditioning=c, eta=0.0,
+                                      unconditional_guidance_scale=scale, unconditional_conditioning=uc, verbose=False, use_graph=True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                x = ops.postprocess_frames(model.decode_first_stage(z))
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+            assert torch.isfinite(x).all()
+            res[f"cfg{scale:g}"] = {"seconds": round(t2 - t0, 3), "frames_per_s": round(batch / (t2 - t0), 3),
+                                    "sampling_seconds": round(t1 - t0, 3), "sample_steps_per_s": round(batch * ddim_steps / (t1 - t0), 1),
+                                    "unet_evals_per_sample_step": 2 if scale > 1.0 else 1, "decode_seconds": round(t2 - t1, 4),
+                                    "decode_frames_per_s": round(batch / (t2 - t1), 1), "shape": list(x.shape)}
+    res["workload"] = (f"class-conditional faces, {batch} samples, DDIM-{ddim_steps}, {latent}x{latent}x{ucfg['in_channels']} latent -> "
+                       f"{x.shape[1]}x{x.shape[2]} frames, ema_scope, sample() + decode_first_stage + clamp")
+    return res
+
+
 def train_mode(a, rank, world, dev, dist, backend, barrier, graph, emit):
-    """BASELINE configs[4] (SURVEY §8f N1): one optimisation step = q_sample + UNet forward + hand-written backward
-    (hipGraph-captured) + gradient all-reduce over the ranks + AdamW + EMA, fixed batch per GPU (weak scaling)."""
-    from dsml_thesis_amd.train import UNetTrainer
+    """`bench.py --train`: BASELINE configs[4] as the one JSON line."""
     latent = 32 if a.latent == 64 and "--latent" not in " ".join(sys.argv) else a.latent
+    out = train_measure(a, latent, rank, world, dev, dist, backend, barrier, graph)
+    if rank == 0:
+        emit(out)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_measure(a, latent, rank, world, dev, dist, backend, barrier, graph):
+    """BASELINE configs[4] (SURVEY §8f N1): one optimisation step = q_sample + UNet forward + hand-written backward
+    (hipGraph-captured) + gradient all-reduce over the ranks + AdamW + EMA, fixed batch per GPU (weak scaling).
+    `a`: anything with .batch / .bf16 / .steps / .warmup."""
+    from dsml_thesis_amd.train import UNetTrainer
     model, ucfg = build_model(latent, dev)
     tr = UNetTrainer(model.model.diffusion_model, compute="bf16" if a.bf16 else "f32")
     sa, sb = model.sqrt_alphas_cumprod, model.sqrt_one_minus_alphas_cumprod
@@ -375,11 +485,7 @@ def train_mode(a, rank, world, dev, dist, backend, barrier, graph, emit):
                         "frac": round(flops / world / (ms * 1e-3) / 1e12 / (PEAK_BF16_MFMA if a.bf16 else PEAK_F32_MFMA), 4),
                         "traffic": None, "kernel": "whole step (igemm + wgrad + attention fwd/bwd), 3x forward GEMM FLOPs"},
            "cpu_baseline": None, "loss": float(loss_buf.item())}
-    if rank == 0:
-        emit(out)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
 
 
 def main():
@@ -393,10 +499,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-clip", action="store_true", help="skip the talking-face clip leg (BASELINE configs[2]/[3])")
+    ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end (configs[1] sample + decode) and train_bf16 (configs[4]) legs")
     ap.add_argument("--clip-steps", type=int, default=None,
-                    help="DDIM steps of the clip leg; default: the shipped 200 (talking_face/sample.sh:27) when --gpus > 1, "
-                         "so a scaling run measures the shipped setting, and 20 at N=1 to keep the default run short")
+                    help="DDIM steps of the clip leg; default: the shipped 200 (talking_face/sample.sh:27)")
     ap.add_argument("--clip-frames", type=int, default=128)
+    ap.add_argument("--clip-policy", default="shard", choices=["shard", "job"],
+                    help="launch plans of the sharded clip: tuned for the rank's own frames (shard) or pinned to the whole clip (job: "
+                         "bitwise rank-count independence)")
     ap.add_argument("--bf16", action="store_true", help="with --train: bf16 matrix-core compute for every GEMM of the step "
                     "(BASELINE configs[4]); fp32 master weights, accumulation, normalisations and attention")
     ap.add_argument("--train", action="store_true",
@@ -404,7 +513,7 @@ def main():
                          "parallel with one all-reduce of the flat gradient buffer); not the default metric")
     a = ap.parse_args()
     if a.clip_steps is None:
-        a.clip_steps = 200 if (a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1) else 20
+        a.clip_steps = 200
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Not under a launcher: start the ranks ourselves.  This process has not initialised the GPU (importing torch
@@ -514,7 +623,7 @@ def main():
         fl_alg = algorithmic_gemm_flops(run.pg) * 1e-12           # the same layers in the reference's arithmetic
         t_tr = getattr(run, "winograd_transform_ms", 0.0)
         traffic, tnote = None, None
-        for tname in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+        for tname in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 try:
@@ -528,7 +637,7 @@ def main():
         t_x3, n_x3 = getattr(run, "x3_ms", 0.0), getattr(run, "x3_launches", 0)
         fl_x3 = executed_gemm_flops(run.pg, 2) * 1e-12
         split = None
-        if n_x3 and t_x3 > 0.5 * t_ig:
+        if n_x3:
             # the dominant kernel is the bf16x3 igemm: price IT against the bf16 matrix peak on the bf16 MFMA FLOPs it issues
             # (6 per fp32-equivalent FLOP); the f32-MFMA launches that remain are reported beside it against their own peak
             ach3 = 6.0 * fl_x3 / (t_x3 * 1e-3)
@@ -538,8 +647,11 @@ def main():
                      "f32_mfma": {"launches": n_ig - n_x3, "ms_per_step": round(t_f, 4), "tflops": round(fl_f / (t_f * 1e-3), 2) if t_f > 0 else None,
                                   "peak": PEAK_F32_MFMA, "frac": round(fl_f / (t_f * 1e-3) / PEAK_F32_MFMA, 4) if t_f > 0 else None},
                      "family_fp32_equivalent_tflops": round(ach, 2)}
+        # ONE fixed basis per arithmetic setting (never chosen from measured times): with the bf16x3 split arithmetic on (default),
+        # `achieved` = the bf16 MFMA FLOPs the bf16x3 launches ISSUE (6 x 2MNK) over their summed duration against the dense bf16
+        # matrix peak; with LDMK_SPLIT_BF16=0, executed fp32 FLOPs of the whole family against the f32 matrix peak
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": traffic, "traffic_note": tnote,
+                           "frac": round(ach / PEAK_F32_MFMA, 4), "basis": "f32_mfma_executed", "traffic": traffic, "traffic_note": tnote,
                            "kernel": "ldmk::igemm_kernel<...> + ldmk::rgemm_kernel<...> (every Conv2d / Linear launch of the step)",
                            "flops_basis": "executed: sum of 2*M*N*K (x batch) over the step's GEMM launches -- what the matrix "
                                           "cores do.  The wide 3x3 convolutions run through Winograd F(2x2,3x3), which executes 4/9 "
@@ -559,9 +671,11 @@ def main():
         if split is not None:
             r = out["roofline"]
             r["achieved"], r["peak"], r["frac"] = split["bf16x3"]["bf16_mfma_tflops_issued"], PEAK_BF16_MFMA, split["bf16x3"]["frac"]
-            r["kernel"] = ("ldmk::igemm_kernel<..., BF = 3> (LDMK_COMPUTE_BF16X3: fp32-accurate products from six bf16 MFMAs, "
-                           "include/ldmk.h) -- the launches that hold most of the GEMM time; `achieved` counts the bf16 MFMA FLOPs they "
-                           "issue (6 x 2MNK) against the dense bf16 matrix peak")
+            r["basis"] = "bf16_mfma_issued"
+            r["kernel"] = ("ldmk::igemm_kernel<..., BF = 3> / igemm_ps_kernel / igemm_pw_kernel (LDMK_COMPUTE_BF16X3: fp32-accurate "
+                           "products from six bf16 MFMAs, include/ldmk.h; the ps / pw forms take both operands pre-split and stage them by "
+                           "LDS-DMA) -- the launches that hold most of the GEMM time; `achieved` counts the bf16 MFMA FLOPs they issue "
+                           "(6 x 2MNK) against the dense bf16 matrix peak")
             r["by_arithmetic"] = split
     del run
     torch.cuda.empty_cache()
@@ -590,10 +704,26 @@ def main():
                 _eng._X3_TABLE = None
     if not a.no_clip:
         torch.cuda.empty_cache()
-        out["clip"] = clip_leg(rank, world, dev, dist, barrier, frames=a.clip_frames, ddim_steps=a.clip_steps)
+        out["clip"] = clip_leg(rank, world, dev, dist, barrier, frames=a.clip_frames, ddim_steps=a.clip_steps, policy=a.clip_policy)
+        if rank == 0 and world == 1 and a.clip_frames >= 64 and not a.no_extras:
+            # what bitwise rank-count independence costs a shard: ONE GPU's 16-frame block of the 8-GPU job with the plans of
+            # the whole 128-frame clip ("job") against the plans of its own batch ("shard")
+            from dsml_thesis_amd.parallel import sample_sharded as _ss   # noqa: F401  (documented in clip_leg)
+            out["clip"]["shard16_of_128"] = shard_cost_leg(dev, a.clip_steps)
         if rank == 0 and world == 1:
             torch.cuda.empty_cache()
             out["batch1"] = batch1_leg(dev)
+    if rank == 0 and world == 1 and not a.no_extras:
+        # BASELINE configs[1] end to end and configs[4] (one GPU: forward + backward + AdamW + EMA, bf16 matrix-core compute)
+        torch.cuda.empty_cache()
+        out["end_to_end"] = end_to_end_leg(dev, a.latent, a.batch)
+        torch.cuda.empty_cache()
+
+        class _T:
+            batch, bf16, steps, warmup = a.batch, True, 3, 1
+        tb = train_measure(_T, a.latent, rank, world, dev, None, backend, barrier, graph)
+        out["train_bf16"] = {k: tb[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "step_tflops", "roofline", "loss")}
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.latent)
     elif rank == 0:

@@ -72,7 +72,9 @@ class DDIMSampler(object):
             ct = torch.cat(ct, 1) if isinstance(ct, (list, tuple)) else ct
             return cc, ct
         if isinstance(cond, (list, tuple)):
-            return torch.cat(list(cond), 1), None
+            cond = torch.cat(list(cond), 1)
+        if cond is not None and getattr(self.model.model, "conditioning_key", None) == "concat":
+            return None, cond                    # DiffusionWrapper 'concat': the conditioning is the channel concat (ddpm.py:1407-1409)
         return cond, None
 
     @torch.no_grad()
@@ -81,12 +83,14 @@ class DDIMSampler(object):
                noise_dropout=0., score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None,
                log_every_t=100, unconditional_guidance_scale=1., unconditional_conditioning=None,
                noise=None, use_graph=False, policy_batch=None, **kwargs):
-        if conditioning is None:
-            raise L.LdmkError("DDIMSampler.sample: conditioning is required (the shipped UNets are cross-attention "
-                              "conditioned; the reference asserts the same in ddim2cond.py:80)")
-        ctx, _ = self._split_cond(conditioning)
-        if ctx.shape[0] != batch_size:
-            print(f"Warning: Got {ctx.shape[0]} conditionings but batch-size is {batch_size}")
+        if conditioning is None and getattr(self.model.model, "conditioning_key", "crossattn") is not None:
+            raise L.LdmkError("DDIMSampler.sample: conditioning is required (this model is cross-attention / concat "
+                              "conditioned; the reference asserts the same in ddim2cond.py:80).  Only an unconditional LDM "
+                              "(cond_stage_config '__is_unconditional__') samples with conditioning=None (ddim.py:77-84)")
+        ctx, cat0 = self._split_cond(conditioning)
+        first = ctx if ctx is not None else cat0
+        if first is not None and first.shape[0] != batch_size:
+            print(f"Warning: Got {first.shape[0]} conditionings but batch-size is {batch_size}")
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
         C_, H, W_ = shape
         size = (batch_size, C_, H, W_)
@@ -125,17 +129,22 @@ class DDIMSampler(object):
         cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
         nb = 2 * b if cfg else b
         if cfg:
-            uc, _ = self._split_cond(unconditional_conditioning)
-            ctx_in = torch.cat([uc, ctx])                  # ddim.py:175: [uncond | cond]
-            cat_in = None if cat is None else torch.cat([cat] * 2)
+            uc, ucat = self._split_cond(unconditional_conditioning)
+            if ctx is None:                                # 'concat' conditioning: the guidance halves differ in the concat tensor
+                ctx_in, cat_in = None, torch.cat([ucat, cat])
+            else:
+                ctx_in = torch.cat([uc, ctx])              # ddim.py:175: [uncond | cond]
+                cat_in = None if cat is None else torch.cat([cat] * 2)
         else:
             ctx_in, cat_in = ctx, cat
         ncat = 0 if cat_in is None else cat_in.shape[1]
+        L_ctx = 0 if ctx_in is None else ctx_in.shape[1]          # 0: unconditional UNet (no cross-attention)
         unet.policy_batch = None if policy_batch is None else (2 * policy_batch if cfg else policy_batch)
-        pg = unet.program(nb, shape[2], shape[3], ctx_in.shape[1], ncat)
+        pg = unet.program(nb, shape[2], shape[3], L_ctx, ncat)
         lib = pg.lib
         x_buf = pg.inputs["x"]
-        pg.inputs["context"].copy_(ctx_in.reshape(nb * ctx_in.shape[1], -1))
+        if L_ctx:
+            pg.inputs["context"].copy_(ctx_in.reshape(nb * L_ctx, -1))
         if ncat:
             pg.inputs["c_concat"].copy_(cat_in)
         pg.ctx_program.run()                               # context-only projections: once per sample() call

@@ -92,13 +92,18 @@ class DiffusionWrapper(_Base):
         assert self.conditioning_key in [None, "concat", "crossattn", "hybrid", "adm"]
 
     def forward(self, x, t, c_concat: list = None, c_crossattn: list = None):
-        if self.conditioning_key in (None, "concat", "adm"):
-            raise NotImplementedError(f"DiffusionWrapper: conditioning_key={self.conditioning_key!r} is not used by the "
-                                      "shipped configs (all are cross-attention conditioned)")
-        cc = torch.cat(c_crossattn, 1)
+        """ddpm.py:1404-1423.  None: the unconditional UNet, `diffusion_model(x, t)`; 'concat': channel concat only (the UNet's
+        first convolution reads both tensors, nothing is materialised); 'crossattn' / 'hybrid': context (+ concat)."""
+        if self.conditioning_key == "adm":
+            raise NotImplementedError("DiffusionWrapper: conditioning_key='adm' (class-conditional `y`) is not used by the shipped configs")
         cat = None
-        if c_concat is not None:
+        if c_concat is not None and self.conditioning_key in ("concat", "hybrid", "crossattn"):
             cat = c_concat[0] if len(c_concat) == 1 else torch.cat(c_concat, 1)
+        if self.conditioning_key is None:
+            return self.diffusion_model(x, t)
+        if self.conditioning_key == "concat":
+            return self.diffusion_model(x, t, c_concat=cat)
+        cc = torch.cat(c_crossattn, 1)
         return self.diffusion_model(x, t, context=cc, c_concat=cat)
 
 
@@ -216,7 +221,9 @@ class LatentDiffusion(_Base):
     @torch.no_grad()
     def apply_model(self, x_noisy, t, cond, cond_concat=None, return_ids=False):
         """ddpm.py:893-994 (`apply_model(x,t,c)`) and ddpm2cond.py:911-945 (`apply_model(x,t,c12,c34)`)."""
-        if isinstance(cond, dict):
+        if cond is None:                                 # unconditional LDM (conditioning_key None)
+            kwargs = {}
+        elif isinstance(cond, dict):
             kwargs = dict(cond)
         else:
             if not isinstance(cond, list):
@@ -351,12 +358,16 @@ class LatentDiffusion(_Base):
             cat = cond.get("c_concat")
             ctx = torch.cat(ctx, 1) if isinstance(ctx, (list, tuple)) else ctx
             cat = torch.cat(cat, 1) if isinstance(cat, (list, tuple)) else cat
+        elif self.model.conditioning_key == "concat":
+            ctx, cat = None, (torch.cat(cond, 1) if isinstance(cond, (list, tuple)) else cond)
         else:
-            ctx, cat = (torch.cat(cond, 1) if isinstance(cond, (list, tuple)) else cond), None
+            ctx, cat = (torch.cat(cond, 1) if isinstance(cond, (list, tuple)) else cond), None      # (None: unconditional)
         unet = self.model.diffusion_model
         ncat = 0 if cat is None else cat.shape[1]
-        pg = unet.program(b, shape[2], shape[3], ctx.shape[1], ncat)
-        pg.inputs["context"].copy_(ctx.reshape(b * ctx.shape[1], -1))
+        L_ctx = 0 if ctx is None else ctx.shape[1]
+        pg = unet.program(b, shape[2], shape[3], L_ctx, ncat)
+        if L_ctx:
+            pg.inputs["context"].copy_(ctx.reshape(b * L_ctx, -1))
         if ncat:
             pg.inputs["c_concat"].copy_(cat)
         pg.ctx_program.run()

@@ -62,18 +62,30 @@ def gathered_item_shape(model, shape, decode=True, postprocess=True):
 
 @torch.no_grad()
 def sample_sharded(sampler, S, n_items, shape, conditioning_fn, seed=0, eta=0.0, decode=True, use_graph=True,
-                   rank=0, world_size=1, group=None, postprocess=True, _noise_offset=0, _policy_items=None,
+                   rank=0, world_size=1, group=None, postprocess=True, policy="job", _noise_offset=0, _policy_items=None,
                    **sample_kw):
     """Sample `n_items` independent items (class-conditional faces or fixed-identity clip frames) across ranks.
 
     conditioning_fn(lo, hi) -> conditioning for global items [lo, hi) (tensor or the TF dict).
     Returns the gathered frames (n_items, H, W, 3) in [0,1] (or latents when decode=False) on every rank.
+    policy: which batch the launch plans (tile shapes, split-K depths, Winograd / phase routes, pre-split tiles) are made for.
+      "job"   -- the whole job's n_items on every rank: the K-summation orders are those of the 1-GPU run, so the gathered
+                 result equals it BIT FOR BIT whatever the rank count (stricter than the task's fp32 tolerance) -- at the price
+                 of running a 16-frame shard with the plans tuned for 128 frames;
+      "shard" -- the rank's own ceil(n_items / world_size) items: every rank runs the plans tuned for ITS batch; the result
+                 equals the 1-GPU run within the sampling tolerance (same arithmetic, other summation orders: 1.5e-4 on a
+                 short trajectory, tests/test_sampling_gpu.py) and still does not depend on which rank computed an item
+                 beyond that.  What `bench.py --gpus N` times.
     """
     from . import ops
+    assert policy in ("job", "shard"), policy
     lo, hi = shard_range(n_items, world_size, rank)
     model = sampler.model
     dev = model.device
-    policy = _policy_items or n_items          # (test hook: emulate one rank's block of a larger job)
+    if policy == "shard":
+        policy = -(-n_items // world_size)     # every rank plans for the common block size (the last block may be shorter)
+    else:
+        policy = _policy_items or n_items      # (test hook: emulate one rank's block of a larger job)
     if hi > lo:
         x_T = batch_noise(seed, _noise_offset + lo, _noise_offset + hi, shape).to(dev)
         z, _ = sampler.sample(S, hi - lo, list(shape), conditioning_fn(lo, hi), eta=eta, x_T=x_T, verbose=False,

@@ -15,6 +15,9 @@ FR_UNET = dict(image_size=32, in_channels=3, out_channels=3, model_channels=160,
                transformer_depth=1, context_dim=512)
 TF_UNET = dict(FR_UNET, in_channels=9, context_dim=1024)
 NS_UNET = dict(FR_UNET, image_size=64, in_channels=4, out_channels=4)          # north-star 64x64x4 latent
+# BASELINE configs[0] as worded: a genuinely unconditional LDM -- no SpatialTransformer / context, AttentionBlock with 32-channel heads
+UNCOND_UNET = dict(image_size=64, in_channels=4, out_channels=4, model_channels=160, attention_resolutions=[4, 2, 1],
+                   num_res_blocks=2, channel_mult=[1, 2, 4], num_head_channels=32)
 VQ_F4 = dict(embed_dim=3, n_embed=16384,
              ddconfig=dict(double_z=False, z_channels=3, resolution=128, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4],
                            num_res_blocks=2, attn_resolutions=[32], dropout=0.0))
@@ -63,6 +66,22 @@ def fr_config(unet=None, vq=None):
         num_timesteps_cond=1, cond_stage_key="class_label", cond_stage_trainable=True, conditioning_key="crossattn",
         image_size=unet["image_size"], channels=unet["out_channels"], first_stage_key="image", log_every_t=200,
         monitor="val_loss_ema", **SCHEDULE)
+
+
+def uncond_config(unet=None, vq=None):
+    """cond_stage_config '__is_unconditional__' -> conditioning_key None (ddpm.py:443-444): DiffusionWrapper calls the UNet as
+    diffusion_model(x, t)."""
+    cfg = fr_config(unet or UNCOND_UNET, vq or VQ_F4_256)
+    cfg.update(cond_stage_config="__is_unconditional__", cond_stage_trainable=False, conditioning_key=None)
+    return cfg
+
+
+def make_uncond_model(gain=1.0, unet=None, vq=None, device="cuda"):
+    from .ddpm import LatentDiffusion
+    m = LatentDiffusion(**uncond_config(unet, vq))
+    load_recipe(m.model.diffusion_model, gain=gain)
+    load_recipe(m.first_stage_model)
+    return m.to(device).eval()
 
 
 def tf_config(seq_len=17):

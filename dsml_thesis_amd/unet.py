@@ -98,6 +98,14 @@ def _spatial_transformer(ch, heads, d_head, depth, context_dim):
     return m
 
 
+def _attention_block(ch, heads):
+    """AttentionBlock (openaimodel.py:278-324): norm, qkv (Conv1d ch -> 3 ch, kernel 1), proj_out (Conv1d ch -> ch)."""
+    m = _Slots(norm=_norm_params(ch), qkv=_Params(weight=(3 * ch, ch, 1), bias=(3 * ch,)),
+               proj_out=_Params(weight=(ch, ch, 1), bias=(ch,)))
+    m.kind, m.ch, m.heads, m.d_head = "attn", ch, heads, ch // heads
+    return m
+
+
 def _seq(*mods):
     s = nn.Module()
     for i, m in enumerate(mods):
@@ -128,12 +136,60 @@ def pack_spatial_transformer(P, sd, prefix, m):
                 P[q + k], sd[q + nrm + ".weight"], sd[q + nrm + ".bias"], b)
 
 
+def emit_self_attention(nb_, qkv, att, hw, heads, d_head):
+    """softmax(q k^T / sqrt d) v over token rows [q | k | v] (n hw x 3 C) -> att (n hw x C).  With the split arithmetic on: both
+    products fp32-accurate on the bf16 matrix cores; from ATTN_PRESPLIT_MIN_TOKENS tokens per sample K / V are split once by a
+    pre-pass instead of once per 128-query workgroup and moved to LDS by LDS-DMA (ldmk_attn_self_x3p: bitwise the same result;
+    LDMK_ATTN_PRESPLIT=0 turns it off).  LDMK_SPLIT_BF16=0: the f32 matrix-core kernel."""
+    pg, n = nb_.pg, nb_.n
+    scale = d_head ** -0.5
+    if engine_split_enabled() and hw >= ATTN_PRESPLIT_MIN_TOKENS and os.environ.get("LDMK_ATTN_PRESPLIT", "1") != "0":
+        kvs = pg.alloc(pg.lib.ldmk_attn_kv_split_bytes(n, hw, heads), dtype=torch.uint8)
+        pg.add("ldmk_attn_self_x3p", qkv.data_ptr(), kvs.data_ptr(), att.data_ptr(), n, hw, heads, scale)
+        nb_.release(kvs)
+    else:
+        pg.add("ldmk_attn_self_x3" if engine_split_enabled() else "ldmk_attn_self", qkv.data_ptr(), att.data_ptr(), n, hw, heads, scale)
+
+
+def pack_attention_block(P, sd, prefix, m):
+    """AttentionBlock weights in kernel layouts.  The reference's qkv Conv1d orders its 3 ch output channels
+    [head][q | k | v][32] (QKVAttentionLegacy splits the heads first, openaimodel.py:366-367); the attention kernels read token
+    rows [q of every head | k of every head | v of every head], so the output channels (and the bias) are permuted here."""
+    ch, heads = m.ch, m.heads
+    d = ch // heads
+    w = sd[prefix + "qkv.weight"].reshape(heads, 3, d, ch).permute(1, 0, 2, 3).reshape(3 * ch, ch).contiguous()
+    P[prefix + "aqkv"] = ops.pack_linear(w)
+    P[prefix + "aqkv#b"] = sd[prefix + "qkv.bias"].reshape(heads, 3, d).permute(1, 0, 2).reshape(3 * ch).contiguous()
+    P[prefix + "apout"] = ops.pack_linear(sd[prefix + "proj_out.weight"].reshape(ch, ch).contiguous())
+
+
+def emit_attention_block(nb_, P, sd, prefix, m, x, h, w):
+    """AttentionBlock._forward (openaimodel.py:316-324) as launches into nb_.pg: GroupNorm32 (eps 1e-5, no activation) folded
+    into the qkv projection's A staging, flash self-attention (q and k each scaled by d^-1/4 in the reference = the logits by
+    d^-1/2, which is the kernels' pre-scale of Q), proj_out + the block input + the GroupNorm records of the result.
+    x: NHWC (n, h, w, C) -> NHWC."""
+    pg, n = nb_.pg, nb_.n
+    p_ = lambda t: 0 if t is None else t.data_ptr()
+    hw = h * w
+    rows = n * hw
+    xr = x.reshape(rows, m.ch)
+    coef = nb_.gn(x, None, hw, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-5)
+    qkv = nb_.lin(xr, P[prefix + "aqkv"], P[prefix + "aqkv#b"], hw, tf=L.TF_AFFINE, tf_coef=coef, wf=P.get(prefix + "aqkv#f"))
+    nb_.release(coef)
+    att = pg.alloc(rows, m.ch)
+    emit_self_attention(nb_, qkv, att, hw, m.heads, m.d_head)
+    nb_.release(qkv)
+    out = nb_.lin(att, P[prefix + "apout"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True, wf=P.get(prefix + "apout#f"))
+    nb_.release(att)
+    return out.view(n, h, w, m.ch)
+
+
 def pack_gemm_copies(P, unfolded=False):
     """The second copies of the GEMM weights the plans may ask for, keyed `<weight key>#f` / `#s`."""
     # fragment-order copies of the token-row Linear weights: the row GEMM (csrc/rgemm.hip) reads these
     # (and the slab GEMM of the small-batch route, csrc/sgemm.hip, which also takes the ResBlock convolutions: c1 / c2)
     for k in [k for k in P if k.rsplit(".", 1)[-1] in ("pin", "pout", "qkv_ln", "o1", "q2_ln", "o2", "ff1_ln", "ff2", "skip",
-                                                        "c1", "c2")
+                                                        "c1", "c2", "aqkv", "apout")
               or (unfolded and k.rsplit(".", 1)[-1] in ("qkv", "ff1", "q2"))]:
         wf = ops.pack_wfrag(P[k])
         if wf is not None:
@@ -143,7 +199,7 @@ def pack_gemm_copies(P, unfolded=False):
     if engine_split_enabled():
         for k in list(P):
             tail = k.rsplit(".", 1)[-1]
-            if tail in ("pin", "pout", "qkv_ln", "o1", "ff1_ln", "ff2", "skip", "c1", "c2", "w") or (unfolded and tail in ("qkv", "ff1")):
+            if tail in ("pin", "pout", "qkv_ln", "o1", "ff1_ln", "ff2", "skip", "c1", "c2", "w", "aqkv", "apout") or (unfolded and tail in ("qkv", "ff1")):
                 if P[k].dim() == 2:
                     P[k + "#s"] = ops.pack_wsplit(P[k])
             elif tail in ("c1#wg", "c2#wg", "w#up"):
@@ -210,15 +266,7 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
         att = pg.alloc(rows, C_)
         # both attention products in the fp32-accurate bf16x3 arithmetic (24 bf16 MFMAs of 32 cycles per 32 keys
         # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel
-        # (from 1024 tokens at the plan-policy batch: K / V split once by a pre-pass instead of once per 128-query workgroup,
-        #  tiles moved to LDS by LDS-DMA -- ldmk_attn_self_x3p, bitwise the same result; LDMK_ATTN_PRESPLIT=0 turns it off)
-        if engine_split_enabled() and hw >= ATTN_PRESPLIT_MIN_TOKENS and os.environ.get("LDMK_ATTN_PRESPLIT", "1") != "0":
-            kvs = pg.alloc(pg.lib.ldmk_attn_kv_split_bytes(n, hw, m.heads), dtype=torch.uint8)
-            pg.add("ldmk_attn_self_x3p", p_(qkv), p_(kvs), p_(att), n, hw, m.heads, m.d_head ** -0.5)
-            nb_.release(kvs)
-        else:
-            pg.add("ldmk_attn_self_x3" if engine_split_enabled() else "ldmk_attn_self", p_(qkv), p_(att), n, hw, m.heads,
-                   m.d_head ** -0.5)
+        emit_self_attention(nb_, qkv, att, hw, m.heads, m.d_head)
         nb_.release(qkv)
         if L_ctx == 1:
             # --- attn2 with a single context token: softmax over one key == 1, so the block adds
@@ -312,15 +360,19 @@ class UNetModel(nn.Module):
         if resblock_updown or use_scale_shift_norm or num_classes is not None or n_embed is not None:
             raise NotImplementedError("UNetModel: resblock_updown / use_scale_shift_norm / num_classes / n_embed "
                                       "are not part of the sampling path built here")
-        if not use_spatial_transformer:
-            raise NotImplementedError("UNetModel: only the SpatialTransformer attention variant (all shipped configs)")
+        if use_new_attention_order:
+            raise NotImplementedError("UNetModel: use_new_attention_order (QKVAttention) -- the legacy order is built")
         if not conv_resample:
             raise NotImplementedError("UNetModel: conv_resample=False")
         if use_fp16:
             raise NotImplementedError("UNetModel: fp32 only (reference precision)")
         if dropout != 0 and self.training:
             pass  # inference path: dropout is the identity
-        assert context_dim is not None, "use_spatial_transformer needs context_dim (openaimodel.py:471-472)"
+        if use_spatial_transformer:
+            assert context_dim is not None, "use_spatial_transformer needs context_dim (openaimodel.py:471-472)"
+        else:
+            assert context_dim is None, "context_dim needs use_spatial_transformer (openaimodel.py:474-475)"
+        self.use_spatial_transformer = bool(use_spatial_transformer)
         if isinstance(context_dim, (list, tuple)) or type(context_dim).__name__ == "ListConfig":
             context_dim = list(context_dim)
             assert len(context_dim) == 1, "a single context dim is supported"
@@ -353,6 +405,13 @@ class UNetModel(nn.Module):
             return n, d
 
         def st(ch):
+            if not use_spatial_transformer:
+                # AttentionBlock(ch, num_heads, num_head_channels = dim_head): heads = ch // num_head_channels when that is set,
+                # else num_heads (openaimodel.py:296-303,545-556; legacy: dim_head = num_head_channels)
+                n = num_heads if num_head_channels == -1 else ch // num_head_channels
+                if ch // n != 32:
+                    raise NotImplementedError(f"UNetModel: attention head dim {ch // n}; the flash kernel is built for 32")
+                return _attention_block(ch, n)
             n, d = heads_for(ch)
             return _spatial_transformer(ch, n, d, transformer_depth, context_dim)
 
@@ -467,6 +526,8 @@ class UNetModel(nn.Module):
                 off += m.cout
             elif m.kind == "st":
                 stp(prefix, m)
+            elif m.kind == "attn":
+                pack_attention_block(P, sd, prefix, m)
             elif m.kind == "conv_in":
                 P[prefix + "w"] = ops.pack_conv3x3_narrow(sd[prefix + "weight"])
             elif m.kind == "down":
@@ -512,7 +573,7 @@ class UNetModel(nn.Module):
         x_in = pg.alloc(n, cx, H, W_)
         cc_in = pg.alloc(n, c_concat, H, W_) if c_concat else None
         t_in = pg.alloc(n, dtype=torch.int64)
-        ctx_in = pg.alloc(n * L_ctx, self.context_dim)
+        ctx_in = pg.alloc(n * L_ctx, self.context_dim) if L_ctx else None      # (unconditional UNet: no context)
         pg.inputs = dict(x=x_in, c_concat=cc_in, t=t_in, context=ctx_in)
         ctx_pg = Program(dev)     # context-only work: re-run only when the context changes
         ctx_pg._all = pg._all     # share accounting
@@ -572,6 +633,8 @@ class UNetModel(nn.Module):
                     out = res_block(p, m, cur0, cur1, h, w)
                 elif m.kind == "st":
                     out = spatial_tf(p, m, cur0, h, w)
+                elif m.kind == "attn":
+                    out = emit_attention_block(nb_, P, sd, p, m, cur0, h, w)
                 elif m.kind == "down":
                     out = conv(cur0, None, P[p + "w"], sd[p + "op.bias"], h, w, stride=2, stats=True)
                     h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
@@ -654,22 +717,26 @@ class UNetModel(nn.Module):
         DiffusionWrapper does `torch.cat([x] + c_concat, 1)`, ddpm2cond.py:1309); passing an already
         concatenated x works too."""
         assert y is None, "class-conditional (y) UNets are not part of this path"
-        if context is None:
+        if context is None and self.use_spatial_transformer:
             raise L.LdmkError("UNetModel.forward: context is required (the reference raises a shape error for "
                               "context=None when context_dim != inner dim, attention.py:174-175)")
+        if context is not None and not self.use_spatial_transformer:
+            raise L.LdmkError("UNetModel.forward: this UNet has no cross-attention (use_spatial_transformer=False): context must be None")
         if not x.is_cuda:
             raise L.LdmkError("UNetModel.forward: input must be a CUDA tensor (no CPU fallback)")
         n, cx, H, W_ = x.shape
         cc = 0 if c_concat is None else c_concat.shape[1]
         assert cx + cc == self.in_channels, f"got {cx}+{cc} input channels, model has {self.in_channels}"
-        assert context.shape[0] == n and context.shape[2] == self.context_dim
+        assert context is None or (context.shape[0] == n and context.shape[2] == self.context_dim)
+        L_ctx = 0 if context is None else context.shape[1]
         for _ in range(2):
-            pg = self.program(n, H, W_, context.shape[1], cc)
+            pg = self.program(n, H, W_, L_ctx, cc)
             pg.inputs["x"].copy_(x)
             if cc:
                 pg.inputs["c_concat"].copy_(c_concat)
             pg.inputs["t"].copy_(timesteps.to(torch.int64))
-            pg.inputs["context"].copy_(context.reshape(n * context.shape[1], self.context_dim))
+            if L_ctx:
+                pg.inputs["context"].copy_(context.reshape(n * L_ctx, self.context_dim))
             pg.ctx_program.run()
             pg.run()
             # the first evaluation of every program checks the folded-LayerNorm guard (one host sync per program, none later;

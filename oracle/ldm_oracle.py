@@ -192,6 +192,22 @@ def spatial_transformer(sd, p, x, context, heads, depth=1):
     return x + x_in
 
 
+def attention_block(sd, p, x, heads):
+    """AttentionBlock._forward + QKVAttentionLegacy.forward, openaimodel.py:316-324,358-372: GroupNorm32 (eps 1e-5, no
+    activation), qkv Conv1d, heads split BEFORE q/k/v ([head][q|k|v][ch] channel order), q and k each scaled by ch^-1/4,
+    softmax over the keys, proj_out Conv1d, residual."""
+    b, c, h, w = x.shape
+    xr = x.reshape(b, c, h * w)
+    qkv = F.conv1d(F.group_norm(xr.float(), 32, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5).type(xr.dtype),
+                   sd[p + "qkv.weight"], sd[p + "qkv.bias"])
+    ch = c // heads
+    q, k, v = qkv.reshape(b * heads, 3 * ch, h * w).split(ch, dim=1)
+    scale = 1 / math.sqrt(math.sqrt(ch))
+    weight = torch.softmax(torch.einsum("bct,bcs->bts", q * scale, k * scale).float(), dim=-1).type(qkv.dtype)
+    a = torch.einsum("bts,bcs->bct", weight, v).reshape(b, c, h * w)
+    return (xr + F.conv1d(a, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])).reshape(b, c, h, w)
+
+
 def _run_layers(sd, cfg, prefix, layers, h, emb, context):
     """TimestepEmbedSequential.forward, openaimodel.py:80-88."""
     for j, l in enumerate(layers):
@@ -202,6 +218,8 @@ def _run_layers(sd, cfg, prefix, layers, h, emb, context):
             h = resblock(sd, p, h, emb)
         elif l[0] == "st":
             h = spatial_transformer(sd, p, h, context, l[2], cfg.get("transformer_depth", 1))
+        elif l[0] == "attn":
+            h = attention_block(sd, p, h, l[2])
         elif l[0] == "down":   # Downsample, openaimodel.py:150-160
             h = F.conv2d(h, sd[p + "op.weight"], sd[p + "op.bias"], stride=2, padding=1)
         elif l[0] == "up":     # Upsample, openaimodel.py:107-118

@@ -67,13 +67,24 @@ def _spatial_transformer(keys, p, ch, n_heads, d_head, depth, context_dim):
     keys[p + "proj_out.bias"] = (ch,)
 
 
+def _attention_block(keys, p, ch):
+    """AttentionBlock (openaimodel.py:278-324): GroupNorm32, qkv = Conv1d(ch, 3 ch, 1), proj_out = Conv1d(ch, ch, 1)."""
+    keys[p + "norm.weight"] = (ch,)
+    keys[p + "norm.bias"] = (ch,)
+    keys[p + "qkv.weight"] = (3 * ch, ch, 1)
+    keys[p + "qkv.bias"] = (3 * ch,)
+    keys[p + "proj_out.weight"] = (ch, ch, 1)
+    keys[p + "proj_out.bias"] = (ch,)
+
+
 def unet_layout(cfg):
     """Walk the UNet exactly like openaimodel.py:505-692 and return a block description.
 
     Returns dict(input=[...], middle=[...], output=[...]) where each entry is a list of
     layer tuples: ("conv", cin, cout) | ("res", cin, cout) | ("st", ch, heads, d_head) |
-    ("down", ch) | ("up", ch).  Only the spatial-transformer configuration the shipped
-    YAMLs use is covered (use_spatial_transformer=True, num_head_channels set, legacy=True).
+    ("down", ch) | ("up", ch) | ("attn", ch, heads, d_head).  The spatial-transformer configuration the shipped YAMLs use
+    (use_spatial_transformer=True, num_head_channels set, legacy=True) and the unconditional variant
+    (use_spatial_transformer=False: AttentionBlock / QKVAttentionLegacy, openaimodel.py:549-559) are covered.
     """
     mc = cfg["model_channels"]
     mult = list(cfg["channel_mult"])
@@ -82,11 +93,14 @@ def unet_layout(cfg):
     nhc = cfg.get("num_head_channels", -1)
     nh = cfg.get("num_heads", -1)
 
+    st = cfg.get("use_spatial_transformer", False)
+    kind = "st" if st else "attn"
+
     def heads(ch):
         if nhc == -1:
             return nh, ch // nh
         n = ch // nhc
-        return n, ch // n  # legacy branch, openaimodel.py:545-549
+        return n, ch // n  # legacy branch, openaimodel.py:545-549 (AttentionBlock: heads = ch // num_head_channels, :297-301)
 
     inp = [[("conv", cfg["in_channels"], mc)]]
     chans = [mc]
@@ -97,7 +111,7 @@ def unet_layout(cfg):
             ch = m * mc
             if ds in attn_res:
                 n, d = heads(ch)
-                layers.append(("st", ch, n, d))
+                layers.append((kind, ch, n, d))
             inp.append(layers)
             chans.append(ch)
         if level != len(mult) - 1:
@@ -105,7 +119,7 @@ def unet_layout(cfg):
             chans.append(ch)
             ds *= 2
     n, d = heads(ch)
-    mid = [("res", ch, ch), ("st", ch, n, d), ("res", ch, ch)]
+    mid = [("res", ch, ch), (kind, ch, n, d), ("res", ch, ch)]
     out = []
     for level, m in list(enumerate(mult))[::-1]:
         for i in range(nrb + 1):
@@ -114,7 +128,7 @@ def unet_layout(cfg):
             ch = mc * m
             if ds in attn_res:
                 n, d = heads(ch)
-                layers.append(("st", ch, n, d))
+                layers.append((kind, ch, n, d))
             if level and i == nrb:
                 layers.append(("up", ch))
                 ds //= 2
@@ -144,6 +158,8 @@ def unet_param_shapes(cfg):
                 _resblock(keys, p, l[1], l[2], emb)
             elif l[0] == "st":
                 _spatial_transformer(keys, p, l[1], l[2], l[3], depth, cd)
+            elif l[0] == "attn":
+                _attention_block(keys, p, l[1])
             elif l[0] == "down":
                 keys[p + "op.weight"] = (l[1], l[1], 3, 3)
                 keys[p + "op.bias"] = (l[1],)
@@ -317,6 +333,10 @@ FR_UNET = dict(image_size=32, in_channels=3, out_channels=3, model_channels=160,
 TF_UNET = dict(FR_UNET, in_channels=9, context_dim=1024)
 # north-star variant: same code, 64x64x4 latent
 NS_UNET = dict(FR_UNET, image_size=64, in_channels=4, out_channels=4)
+# BASELINE configs[0] as worded: a genuinely UNCONDITIONAL LDM (cond_stage_config "__is_unconditional__" -> conditioning_key None,
+# ddpm.py:443-444): no SpatialTransformer, AttentionBlock / QKVAttentionLegacy with 32-channel heads, no context
+UNCOND_UNET = dict(image_size=64, in_channels=4, out_channels=4, model_channels=160, attention_resolutions=[4, 2, 1],
+                   num_res_blocks=2, channel_mult=[1, 2, 4], num_head_channels=32)
 VQ_F4 = dict(embed_dim=3, n_embed=16384,
              ddconfig=dict(double_z=False, z_channels=3, resolution=128, in_channels=3, out_ch=3,
                            ch=128, ch_mult=[1, 2, 4], num_res_blocks=2, attn_resolutions=[32],

@@ -29,6 +29,8 @@ def _contract(d, split):
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # ONE basis per arithmetic setting, named in the line (never chosen from measured times)
+    assert r["basis"] == ("bf16_mfma_issued" if split else "f32_mfma_executed")
     assert 0.05 < r["frac"] < 1.0 and d["value"] > 50
     # the numerator is what the launches execute (sum of 2 M N K), printed next to the reference algorithm's count
     assert r["flops_basis"].startswith("executed") and 100 < r["executed_gflop_per_sample_step"] < r["reference_gflop_per_sample_step"]
@@ -55,7 +57,7 @@ def _contract(d, split):
 
 
 def test_bench_line_has_the_contract_fields():
-    d = _run("--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-clip")
+    d = _run("--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-clip", "--no-extras")
     _contract(d, split=True)
     # value is consistent with the timed region: batch * steps / time
     assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
@@ -63,7 +65,7 @@ def test_bench_line_has_the_contract_fields():
 
 def test_bench_line_f32_matrix_core_form():
     """LDMK_SPLIT_BF16=0: every GEMM on v_mfma_f32_32x32x2_f32, priced against the f32 matrix peak."""
-    d = _run("--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-clip", env={"LDMK_SPLIT_BF16": "0"})
+    d = _run("--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-clip", "--no-extras", env={"LDMK_SPLIT_BF16": "0"})
     _contract(d, split=False)
 
 
@@ -80,9 +82,29 @@ def test_bench_self_launches_two_ranks_and_the_clip_checksum_does_not_depend_on_
     """`python bench.py --gpus 2` starts its own ranks (here both on the one GPU, gloo collectives): n_gpus = 2, the clip
     leg runs sharded with its all-gather inside the timed region, and its checksum equals the 1-rank run's bit for bit."""
     flags = ("--steps", "2", "--warmup", "1", "--batch", "2", "--latent", "32", "--no-secondary", "--no-cpu-baseline",
-             "--clip-frames", "6", "--clip-steps", "4")
+             "--clip-frames", "6", "--clip-steps", "4", "--no-extras", "--clip-policy", "job")
     one = _run(*flags)
     two = _run("--gpus", "2", *flags, env={"LDMK_BENCH_BACKEND": "gloo"})
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["global_batch"] == 4
     assert two["clip"]["scaling"] == "strong" and "all_gather" in two["clip"]["collective"]
-    assert one["clip"]["checksum"] == two["clip"]["checksum"] and one["clip"]["frames"] == 6
+    assert one["clip"]["checksum"] == two["clip"]["checksum"] and one["clip"]["frames"] == 6 and two["clip"]["plan_policy"] == "job"
+    # the timed default: every rank runs the plans of its own batch -- the same frames within the sampling tolerance
+    shard = _run("--gpus", "2", *flags[:-2], env={"LDMK_BENCH_BACKEND": "gloo"})
+    assert shard["clip"]["plan_policy"] == "shard"
+    assert abs(shard["clip"]["checksum"] - one["clip"]["checksum"]) <= 1e-4 * abs(one["clip"]["checksum"])
+
+
+def test_default_line_carries_every_baseline_config():
+    """The driver's one line (default legs, short timed region): configs[1] headline + its end-to-end sample() + decode at CFG
+    1.0 and 3.0, configs[2] the 128-frame clip AT ITS SHIPPED DDIM-200, the reference's batch-1 autoregressive mode and its
+    16-clip lock-step form, configs[4] one GPU of the bf16 training step with its own roofline."""
+    d = _run("--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline")
+    assert d["clip"]["ddim_steps"] == 200 and d["clip"]["frames"] == 128 and d["clip"]["frames_per_s"] > 5
+    b1 = d["batch1"]
+    assert b1["ms_per_step"] < 10 and b1["clips16"]["clips"] == 16 and b1["clips16"]["sample_steps_per_s"] > 2 * b1["sample_steps_per_s"]
+    e = d["end_to_end"]
+    assert e["cfg1"]["unet_evals_per_sample_step"] == 1 and e["cfg3"]["unet_evals_per_sample_step"] == 2
+    assert e["cfg1"]["shape"] == [16, 256, 256, 3] and e["cfg3"]["sampling_seconds"] > 1.5 * e["cfg1"]["sampling_seconds"]
+    t = d["train_bf16"]
+    assert t["dtype"] == "bf16" and t["unit"] == "samples/s" and t["value"] > 50 and t["roofline"]["peak"] > 2000
+    assert 0.0 < t["roofline"]["frac"] < 1.0 and "64x64x4" in t["config"]["workload"]

@@ -69,10 +69,18 @@ def test_state_dict_keys_equal_reference_enumeration():
 def test_unsupported_options_fail_loudly():
     from dsml_thesis_amd.unet import UNetModel
     from dsml_thesis_amd.autoencoder import VQModelInterface
-    for bad in (dict(dims=3), dict(resblock_updown=True), dict(use_spatial_transformer=False), dict(use_fp16=True),
+    for bad in (dict(dims=3), dict(resblock_updown=True), dict(use_new_attention_order=True), dict(use_fp16=True),
                 dict(num_head_channels=64)):
         with pytest.raises(NotImplementedError):
             UNetModel(**dict(W.FR_UNET, **bad))
+    with pytest.raises(AssertionError):                      # openaimodel.py:474-475: context_dim needs the spatial transformer
+        UNetModel(**dict(W.FR_UNET, use_spatial_transformer=False))
+    # the unconditional variant (AttentionBlock instead of SpatialTransformer) is built: the reference's key set
+    u = UNetModel(**W.UNCOND_UNET)
+    assert set(u.state_dict().keys()) == set(W.unet_param_shapes(W.UNCOND_UNET).keys())
+    assert u.state_dict()["middle_block.1.qkv.weight"].shape == (1920, 640, 1)
+    with pytest.raises(NotImplementedError):
+        UNetModel(**dict(W.UNCOND_UNET, num_head_channels=64))
     with pytest.raises(NotImplementedError):
         VQModelInterface(embed_dim=3, n_embed=16, ddconfig=dict(W.VQ_F4["ddconfig"], attn_type="linear"))
 

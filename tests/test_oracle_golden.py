@@ -339,3 +339,18 @@ def test_g12_sampler_options():
     mine = O.p_sample_loop(usd, W.FR_UNET, sched, xT, cond=c, timesteps=3, noise=T(g["ddpm_noise"]), clip_denoised=True,
                            quantize_codebook=code, mask=mask, x0=x0, mask_noise=T(g["ddpm_mask_noise"]))
     close(mine, g["ddpm_clip_quant_mask"], 1e-4, 1e-4)
+
+
+def test_g13_unconditional_unet_and_attention_block():
+    """BASELINE configs[0] as worded (tests/golden/g13_config0.npz, from the real reference's unconditional LatentDiffusion):
+    the oracle's AttentionBlock / QKVAttentionLegacy restatement (openaimodel.py:278-324,347-372) and the unconditional UNet
+    built on it reproduce the reference's outputs.  (The 50-step chains of that file were checked against the oracle when the
+    fixture was generated -- ~50 CPU evaluations at 64x64 each -- and are what the GPU tests are held to.)"""
+    g = golden("g13_config0.npz")
+    keys = {}
+    W._attention_block(keys, "", 160)
+    close(O.attention_block(recipe(keys, seed=11), "", rnd(131, 2, 160, 8, 8), 5), g["attention_block"], 1e-5, 2e-5)
+    sd = recipe(W.unet_param_shapes(W.UNCOND_UNET), gain=0.25)
+    out = O.unet_forward(sd, W.UNCOND_UNET, rnd(130, 2, 4, 64, 64), torch.tensor([7, 640]), None)
+    close(out, g["uncond_eps"], 1e-4, 1e-4)
+    assert g["uncond_ddim50"].shape == (1, 4, 64, 64) and g["ns_ddim50"].shape == (1, 4, 64, 64)

@@ -205,7 +205,7 @@ def test_unet_split_arithmetic_routes_against_the_reference_fixtures(monkeypatch
     monkeypatch.setenv("LDMK_SPLIT_BF16", "0")
     monkeypatch.setattr(engine, "_X3_TABLE", None)
     eps_c, n3c, _, names_c = run()
-    assert n3c == 0 and "ldmk_attn_self" in names_c and "ldmk_attn_self_x3" not in names_c
+    assert n3c == 0 and "ldmk_attn_self" in names_c and "ldmk_attn_self_x3" not in names_c and "ldmk_attn_self_x3p" not in names_c
     close(eps_c, g["fr_eps"], 3e-5, 3e-5)
     assert (eps_a - eps_c).abs().max().item() < 1.5e-5
     monkeypatch.undo()
@@ -242,6 +242,54 @@ def test_folded_layernorm_guard_switches_mean_dominated_models_to_the_unfolded_p
     with warnings.catch_warnings():
         warnings.simplefilter("error")                   # decided once: later evaluations neither warn nor re-pack
         assert torch.equal(m2(x.cuda(), t.cuda(), context=ctx.cuda()), eps)
+
+
+def test_attention_block_golden_through_the_launch_program():
+    """AttentionBlock(160, 5 heads x 32) at 8x8 (openaimodel.py:278-324, QKVAttentionLegacy :347-372) against the reference's
+    output (g13 `attention_block`), emitted by the function UNetModel._build calls for the unconditional UNet: GroupNorm folded
+    into the qkv projection (output channels permuted from the reference's [head][q|k|v][32] order), flash attention with the
+    logits scaled by d^-1/2 (the reference scales q and k by d^-1/4 each), proj_out + residual."""
+    from dsml_thesis_amd import unet as U
+    from dsml_thesis_amd.engine import NetBuilder, Program
+    g = golden("g13_config0.npz")
+    keys = {}
+    W._attention_block(keys, "", 160)
+    sd = {k: v.cuda() for k, v in W.synth_state_dict(keys, seed=11).items()}
+    m = U._attention_block(160, 5)
+    P = {}
+    U.pack_attention_block(P, sd, "", m)
+    U.pack_gemm_copies(P)
+    n, h, w = 2, 8, 8
+    x = rnd(131, n, 160, h, w)
+    pg = Program("cuda")
+    out = U.emit_attention_block(NetBuilder(pg, n), P, sd, "", m, x.permute(0, 2, 3, 1).contiguous().cuda(), h, w)
+    pg.run()
+    close(out.permute(0, 3, 1, 2), g["attention_block"], 1e-4, 1e-4)
+    ref = O.attention_block({k: v.cpu() for k, v in sd.items()}, "", x, 5)
+    close(out.permute(0, 3, 1, 2), ref, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("policy", [None, 16])
+def test_unconditional_unet_golden(policy):
+    """BASELINE configs[0] as worded: the UNet of a genuinely unconditional LDM (use_spatial_transformer=False, no context:
+    AttentionBlock instead of SpatialTransformer) against the real reference's eps (g13 `uncond_eps`, B = 2 at 64x64x4), with
+    the plans of this batch and with the plan set of the benchmark batch; conditional UNets still refuse context=None and this
+    one refuses a context."""
+    from dsml_thesis_amd import lib as L
+    g = golden("g13_config0.npz")
+    m, sd = make_unet(W.UNCOND_UNET, gain=0.25)
+    m.policy_batch = policy
+    x, t = rnd(130, 2, 4, 64, 64), torch.tensor([7, 640])
+    eps = m(x.cuda(), t.cuda())
+    close(eps, g["uncond_eps"], 3e-5, 3e-5)
+    assert torch.equal(eps, m(x.cuda(), t.cuda(), context=None))
+    names = [c[3] for c in m.program(2, 64, 64, 0, 0).calls]
+    assert "ldmk_attn_cross" not in names and not any(n_.startswith("ldmk_ln_stats") for n_ in names)
+    with pytest.raises(L.LdmkError, match="no cross-attention"):
+        m(x.cuda(), t.cuda(), context=torch.zeros(2, 1, 512, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        from dsml_thesis_amd.unet import UNetModel
+        UNetModel(**dict(W.UNCOND_UNET, num_head_channels=64))
 
 
 def test_unet_multi_token_context_vs_oracle():

@@ -706,6 +706,31 @@ def gen_config0():
     g["ns_ddim50"] = ref
     g["ns_ddim50_x_inter"] = torch.stack(inter["x_inter"])
     print("  |x| final", float(ref.abs().max()), "x_inter", len(inter["x_inter"]))
+
+    print("[G13] configs[0] as worded: the UNCONDITIONAL LDM (cond_stage_config __is_unconditional__, AttentionBlock UNet)")
+    ucfg = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(W.UNCOND_UNET))
+    ldu = LatentDiffusion(first_stage_config=fs_cfg, cond_stage_config="__is_unconditional__", num_timesteps_cond=1,
+                          unet_config=ucfg, image_size=64, channels=4, first_stage_key="image", log_every_t=200,
+                          monitor="val_loss_ema", **W.SCHEDULE)
+    assert ldu.model.conditioning_key is None
+    usd_u = load_recipe(ldu.model.diffusion_model, seed=0, gain=0.25, prefix_check=W.unet_param_shapes(W.UNCOND_UNET))
+    xe, te = rnd(130, 2, 4, 64, 64), torch.tensor([7, 640])
+    ref_eps = ldu.apply_model(xe, te, None)
+    check("unconditional UNet eps (B=2, 64x64x4)", ref_eps, O.unet_forward(usd_u, W.UNCOND_UNET, xe, te, None), 1e-4, 1e-4)
+    g["uncond_eps"] = ref_eps
+    # one AttentionBlock on its own (160 channels, 5 heads of 32, 8x8), the unit under the UNet
+    from ldm.modules.diffusionmodules.openaimodel import AttentionBlock
+    ab = AttentionBlock(160, num_heads=-1, num_head_channels=32)
+    absd = load_recipe(ab, seed=11)
+    xa = rnd(131, 2, 160, 8, 8)
+    ref_ab = ab._forward(xa)
+    check("AttentionBlock(160, heads 5)", ref_ab, O.attention_block(absd, "", xa, 5), 1e-5, 2e-5)
+    g["attention_block"] = ref_ab
+    ref_u, _ = CPUDDIM(ldu).sample(S=50, batch_size=1, shape=[4, 64, 64], conditioning=None, eta=0.0, x_T=xT, verbose=False)
+    mine_u = O.ddim_sample(usd_u, W.UNCOND_UNET, sched, 50, xT, cond=None)
+    check("unconditional DDIMSampler.sample S=50 @64x64x4, B=1", ref_u, mine_u, 1e-3, 1e-3)
+    g["uncond_ddim50"] = ref_u
+    print("  |x| final (unconditional)", float(ref_u.abs().max()))
     save("g13_config0.npz", **g)
 
 
