@@ -510,8 +510,15 @@ __device__ __forceinline__ void x3p_dma3(unsigned voff, const au32x4& rs, unsign
                : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
 }
 
+// a * b rounded to fp32 on its own (no contraction into a following subtraction: hipcc's default is -ffp-contract=fast)
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
 __global__ __launch_bounds__(256) void attn_x3p_fwd_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ kv,
-                                                           float* __restrict__ out, int tokens, int heads, float scale) {
+                                                           float* __restrict__ out, unsigned char* __restrict__ out_ps, int tokens, int heads,
+                                                           float scale) {
   // two tile buffers; after the key loop the same memory is the four output transpose buffers
   __shared__ __attribute__((aligned(1024))) unsigned char smem_p[2 * X3P_TILE];
   static_assert(2 * X3P_TILE >= 4 * 32 * BA_FS * 4, "transpose buffers alias the tile buffers");
@@ -617,8 +624,33 @@ __global__ __launch_bounds__(256) void attn_x3p_fwd_kernel(const float* __restri
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the trailing out-of-range fetch)
   __syncthreads();                     // every wave is done with the tile buffers: their memory becomes the transpose buffers
   if (!wave_active) return;
-  float* ts = reinterpret_cast<float*>(smem_p) + wave * (32 * BA_FS);
-  store_rows_bf(ts, o, 1.0f / l_run, out + (long long)b * tokens * C + h * BA_D, C, q0, tokens, l31, half);
+  if (out_ps) {
+    // the result in the PS layout (include/ldmk.h) of the [n tokens][C] matrix -- the pre-split A operand of attn1.to_out on the
+    // pre-split GEMM tiles (csrc/igemm_ps.hip).  The accumulator already has the layout its transposed epilogue writes from:
+    // lane = (query, half), registers 4 g .. 4 g + 3 = d 8 g + 4 half .. + 3: one 8-byte store per (g, plane), no LDS pass.
+    // (tokens % 32 == 0: a wave's 32 queries are one row block)
+    const float inv = 1.0f / l_run;
+    unsigned char* d0 = out_ps + ((((long long)b * tokens + q0) >> 5) * (C / 16) + 2 * h) * 3072 + l31 * 16 + half * 8;
+    if (q_valid) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4_t hh, mm_, ll;
+        // (the fp32 product is rounded BEFORE it is split -- no fused multiply-subtract into the residuals -- so the planes sum
+        //  to exactly the value the fp32 output holds)
+        float4 v4 = make_float4(mul_rounded(o[4 * g], inv), mul_rounded(o[4 * g + 1], inv), mul_rounded(o[4 * g + 2], inv), mul_rounded(o[4 * g + 3], inv));
+        asm volatile("" : "+v"(v4.x), "+v"(v4.y), "+v"(v4.z), "+v"(v4.w));
+        split4(v4, hh, mm_, ll);
+        unsigned char* d = d0 + (g >> 1) * 3072 + (g & 1) * 512;
+        *reinterpret_cast<bf16x4_t*>(d) = hh;
+        *reinterpret_cast<bf16x4_t*>(d + 1024) = mm_;
+        *reinterpret_cast<bf16x4_t*>(d + 2048) = ll;
+      }
+    }
+  }
+  if (out) {
+    float* ts = reinterpret_cast<float*>(smem_p) + wave * (32 * BA_FS);
+    store_rows_bf(ts, o, 1.0f / l_run, out + (long long)b * tokens * C + h * BA_D, C, q0, tokens, l31, half);
+  }
 }
 
 }  // namespace ldmk
@@ -638,15 +670,21 @@ extern "C" long long ldmk_attn_kv_split_bytes(int n, int tokens, int heads) {
 }
 
 extern "C" int ldmk_attn_self_x3p(const float* qkv, void* kv_scratch, float* out, int n, int tokens, int heads, float scale, void* stream) {
+  return ldmk_attn_self_x3p_ps(qkv, kv_scratch, out, nullptr, n, tokens, heads, scale, stream);
+}
+
+extern "C" int ldmk_attn_self_x3p_ps(const float* qkv, void* kv_scratch, float* out, void* out_ps, int n, int tokens, int heads, float scale,
+                                     void* stream) {
   LDMK_ENTER();
   using namespace ldmk;
-  LDMK_REQUIRE(qkv && kv_scratch && out && n > 0 && tokens > 0 && heads > 0 && heads <= 65535 && n <= 65535, "ldmk_attn_self_x3p: bad args");
+  LDMK_REQUIRE(qkv && kv_scratch && (out || out_ps) && n > 0 && tokens > 0 && heads > 0 && heads <= 65535 && n <= 65535, "ldmk_attn_self_x3p: bad args");
+  LDMK_REQUIRE(!out_ps || tokens % 32 == 0, "ldmk_attn_self_x3p_ps: out_ps needs tokens %% 32 == 0 (%d)", tokens);
   const int ntiles = (tokens + BA_T - 1) / BA_T;
   LDMK_REQUIRE((long long)ntiles * X3P_TILE < (1LL << 31), "ldmk_attn_self_x3p: %d tokens: a head's pre-split K / V exceeds 2 GiB", tokens);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_kv_split_kernel, dim3(ntiles, heads, n), dim3(256), 0, st, qkv, reinterpret_cast<unsigned char*>(kv_scratch), tokens, heads);
   hipLaunchKernelGGL(attn_x3p_fwd_kernel, dim3((tokens + 127) / 128, heads, n), dim3(256), 0, st, qkv,
-                     reinterpret_cast<const unsigned char*>(kv_scratch), out, tokens, heads, scale);
+                     reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale);
   return check_launch("ldmk_attn_self_x3p");
 }
 

@@ -368,6 +368,18 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Phase stagger (stagger = dbg >> 8, in units of 64 cycles per stage; 0 = off): every workgroup of a launch does the same
+  // work, so the co-resident workgroups of a CU -- and all CUs of the chip -- run their main loops together and then their
+  // epilogues together: the memory system idles while the matrix cores work and vice versa (probe: GEGLU at K = 160 takes
+  // 116 us without its epilogue, 192 us with it).  Waves in an odd hardware wave slot (the second workgroup of a CU) start
+  // half a tile period late, and since every tile takes the same time the offset persists over the rounds of the launch.
+  if ((dbg >> 8) != 0) {
+    const unsigned slot = __builtin_amdgcn_s_getreg(6148);      // HW_REG_HW_ID[3:0]: wave slot within the SIMD
+    if (slot & 1) {
+      const int n = (dbg >> 8) * n16;                             // 64-cycle units
+      for (int i = 0; i < n; i += 64) __builtin_amdgcn_s_sleep(64);
+    }
+  }
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) issue(s);
   for (int it = 0; it < n16; ++it) {
@@ -416,6 +428,17 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
     }
   }
   ps_wait_vm<0>();             // (the trailing out-of-range loads still target this workgroup's LDS)
+  if (dbg & 16) {              // probe: no epilogue (one never-taken store keeps the accumulators live)
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
+    if (keep == 12345.678f && ws) ws[0] = keep;
+    return;
+  }
   ps_epilogue<TM, TN, TR>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
 }
 
@@ -717,7 +740,7 @@ static int ps_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_
     attr = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  static const int dbg = getenv("LDMK_PS_DEBUG") ? atoi(getenv("LDMK_PS_DEBUG")) : 0;
+  static const int dbg = (getenv("LDMK_PS_DEBUG") ? atoi(getenv("LDMK_PS_DEBUG")) : 0) | ((getenv("LDMK_PS_STAGGER") ? atoi(getenv("LDMK_PS_STAGGER")) : 0) << 8);
   hipLaunchKernelGGL((igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR>), dim3(tiles, splitk, a.batch > 1 ? a.batch : 1), dim3(64 * NWM * NWN), lds,
                      st, a, splitk, ws, dbg);
   if (splitk > 1 && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);

@@ -211,6 +211,10 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
                     out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None, w_frag=None, tile_cfg=0, compute=0, ln_colsum=None,
                     splitk_counters=None, raw_slabs=False, a_split=None, w_bf16t=None, a_ps=None, w_ps=None, out_ps=None):
     a = L.IgemmArgs()
+    # the struct holds raw device pointers: keep every operand alive as long as the args object lives (a temporary passed
+    # inline -- bias=b.cuda() -- would otherwise be freed, and its block possibly re-used, before the launch is enqueued)
+    a._keep = (a0, a1, w, out, tf_coef, row_stats, ln_gamma, ln_beta, bias, batch_vec, residual, splitk_ws, w_frag, ln_colsum,
+               splitk_counters, a_split, w_bf16t, a_ps, w_ps, out_ps)
     a.M, a.N, a.K = M, N, K
     a.a0, a.a1, a.c0, a.c1 = _ptr(a0), _ptr(a1), c0, c1
     if conv is not None:

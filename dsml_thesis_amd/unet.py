@@ -136,18 +136,27 @@ def pack_spatial_transformer(P, sd, prefix, m):
                 P[q + k], sd[q + nrm + ".weight"], sd[q + nrm + ".bias"], b)
 
 
-def emit_self_attention(nb_, qkv, att, hw, heads, d_head):
+def attention_presplit(hw):
+    return engine_split_enabled() and hw >= ATTN_PRESPLIT_MIN_TOKENS and os.environ.get("LDMK_ATTN_PRESPLIT", "1") != "0"
+
+
+def emit_self_attention(nb_, qkv, att, hw, heads, d_head, att_ps=None):
     """softmax(q k^T / sqrt d) v over token rows [q | k | v] (n hw x 3 C) -> att (n hw x C).  With the split arithmetic on: both
     products fp32-accurate on the bf16 matrix cores; from ATTN_PRESPLIT_MIN_TOKENS tokens per sample K / V are split once by a
     pre-pass instead of once per 128-query workgroup and moved to LDS by LDS-DMA (ldmk_attn_self_x3p: bitwise the same result;
     LDMK_ATTN_PRESPLIT=0 turns it off).  LDMK_SPLIT_BF16=0: the f32 matrix-core kernel."""
     pg, n = nb_.pg, nb_.n
     scale = d_head ** -0.5
-    if engine_split_enabled() and hw >= ATTN_PRESPLIT_MIN_TOKENS and os.environ.get("LDMK_ATTN_PRESPLIT", "1") != "0":
+    if attention_presplit(hw):
         kvs = pg.alloc(pg.lib.ldmk_attn_kv_split_bytes(n, hw, heads), dtype=torch.uint8)
-        pg.add("ldmk_attn_self_x3p", qkv.data_ptr(), kvs.data_ptr(), att.data_ptr(), n, hw, heads, scale)
+        if att_ps is not None:       # the result in the PS layout (only): the A operand of attn1.to_out on a pre-split tile
+            pg.add("ldmk_attn_self_x3p_ps", qkv.data_ptr(), kvs.data_ptr(), 0 if att is None else att.data_ptr(), att_ps.data_ptr(), n, hw,
+                   heads, scale)
+        else:
+            pg.add("ldmk_attn_self_x3p", qkv.data_ptr(), kvs.data_ptr(), att.data_ptr(), n, hw, heads, scale)
         nb_.release(kvs)
     else:
+        assert att_ps is None
         pg.add("ldmk_attn_self_x3" if engine_split_enabled() else "ldmk_attn_self", qkv.data_ptr(), att.data_ptr(), n, hw, heads, scale)
 
 
@@ -209,7 +218,7 @@ def pack_gemm_copies(P, unfolded=False):
     if engine_ps_enabled():
         for k in list(P):
             tail = k.rsplit(".", 1)[-1]
-            if tail in ("qkv_ln", "ff1_ln", "ff2") and P[k].dim() == 2 and P[k].shape[0] % 32 == 0 and P[k].shape[1] % 32 == 0:
+            if tail in ("qkv_ln", "ff1_ln", "ff2", "o1", "pout") and P[k].dim() == 2 and P[k].shape[0] % 32 == 0 and P[k].shape[1] % 32 == 0:
                 P[k + "#p"] = ops.pack_wps(P[k])
             elif tail in ("c1#wg", "c2#wg", "w#up") and P[k].shape[1] % 32 == 0 and P[k].shape[2] % 32 == 0:
                 P[k + "#p"] = ops.pack_wps(P[k], batch=P[k].shape[0])     # Winograd planes / upsampling phases (transforms write V in PS)
@@ -254,6 +263,7 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
         return lin(x2d, wp, P[wkey + "#b"], hw, geglu=geglu, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
                    ln_colsum=P[wkey + "#cs"], wf=P.get(wkey + "#f"))
 
+    hc_ps = plan_p = None
     for d in range(m.depth):
         q = f"{prefix}transformer_blocks.{d}."
         # --- attn1 (self): LN1 folded into the fused QKV GEMM, flash attention, to_out + residual
@@ -263,10 +273,13 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
                       ln_gamma=sd[q + "norm1.weight"], ln_beta=sd[q + "norm1.bias"], wf=P.get(q + "qkv#f"))
         else:
             qkv = ln_lin(hcur, q + "qkv_ln", False)
-        att = pg.alloc(rows, C_)
         # both attention products in the fp32-accurate bf16x3 arithmetic (24 bf16 MFMAs of 32 cycles per 32 keys
-        # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel
-        emit_self_attention(nb_, qkv, att, hw, m.heads, m.d_head)
+        # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel.  With a pre-split plan for
+        # attn1.to_out the attention kernel writes its result in the PS layout only (from its accumulators, no LDS pass)
+        plan_o = (nb_.ps_query(rows, C_, C_) if (q + "o1#p" in P and L_ctx == 1 and hw % 32 == 0 and attention_presplit(hw)) else None)
+        att = None if plan_o is not None else pg.alloc(rows, C_)
+        att_ps = pg.alloc_ps(rows, C_) if plan_o is not None else None
+        emit_self_attention(nb_, qkv, att, hw, m.heads, m.d_head, att_ps=att_ps)
         nb_.release(qkv)
         if L_ctx == 1:
             # --- attn2 with a single context token: softmax over one key == 1, so the block adds
@@ -277,9 +290,14 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
             cvec = ctx_pg.alloc(n, C_)
             ctx_pg.add("ldmk_dense_small", p_(v), C_, p_(P[q + "o2"]), p_(sd[q + "attn2.to_out.0.bias"]), p_(cvec),
                        C_, n, C_, C_, 0)
-            h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur,
-                     batch_vec=cvec, batch_vec_ld=C_, wf=P.get(q + "o1#f"))   # + the per-sample cross-attention vector
-            nb_.release(att)
+            if plan_o is not None:
+                h1 = nb_.lin_ps(plan_o, rows, C_, att_ps, P[q + "o1"], P[q + "o1#p"], sd[q + "attn1.to_out.0.bias"], hw, out=hcur,
+                                residual=hcur, batch_vec=cvec, batch_vec_ld=C_)
+                nb_.release(att_ps)
+            else:
+                h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur,
+                         batch_vec=cvec, batch_vec_ld=C_, wf=P.get(q + "o1#f"))   # + the per-sample cross-attention vector
+                nb_.release(att)
             h2 = h1
         else:
             h1 = lin(att, P[q + "o1"], sd[q + "attn1.to_out.0.bias"], hw, residual=hcur, out=hcur, wf=P.get(q + "o1#f"))
@@ -313,7 +331,12 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
         if plan_g is not None and plan_f is not None:
             f_ps = pg.alloc_ps(rows, Nf)
             ln_lin(h2, q + "ff1_ln", True, out_ps=f_ps)
-            hcur = nb_.lin_ps(plan_f, rows, Nf, f_ps, P[q + "ff2"], P[q + "ff2#p"], sd[q + "ff.net.2.bias"], hw, out=h2, residual=h2)
+            # the last block's ff.net.2 also writes its result pre-split when proj_out runs on a pre-split tile
+            last = d == m.depth - 1
+            plan_p = nb_.ps_query(rows, m.ch, C_) if (last and prefix + "pout#p" in P and plan_f[1] <= 1) else None   # (a split-K ff.net.2 has no PS epilogue)
+            hc_ps = pg.alloc_ps(rows, C_) if plan_p is not None else None
+            hcur = nb_.lin_ps(plan_f, rows, Nf, f_ps, P[q + "ff2"], P[q + "ff2#p"], sd[q + "ff.net.2.bias"], hw, out=h2, residual=h2,
+                              out_ps=hc_ps)
             nb_.release(f_ps)
         else:
             if unfolded:
@@ -324,7 +347,12 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
                 f = ln_lin(h2, q + "ff1_ln", True)
             hcur = lin(f, P[q + "ff2"], sd[q + "ff.net.2.bias"], hw, residual=h2, out=h2, wf=P.get(q + "ff2#f"))
             nb_.release(f)
-    out = lin(hcur, P[prefix + "pout"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True, wf=P.get(prefix + "pout#f"))
+    if hc_ps is not None:
+        out = nb_.lin_ps(plan_p, rows, C_, hc_ps, P[prefix + "pout"], P[prefix + "pout#p"], sd[prefix + "proj_out.bias"], hw, residual=xr,
+                         stats=True)
+        nb_.release(hc_ps)
+    else:
+        out = lin(hcur, P[prefix + "pout"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True, wf=P.get(prefix + "pout#f"))
     nb_.release(hcur, stats)
     return out.view(n, h, w, m.ch)
 

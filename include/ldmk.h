@@ -340,6 +340,10 @@ int ldmk_attn_self_x3(const float* qkv, float* out, int n, int tokens, int heads
  *   LDS-DMA loads and does no arithmetic on K / V.  Bitwise the results of ldmk_attn_self_x3. */
 long long ldmk_attn_kv_split_bytes(int n, int tokens, int heads);
 int ldmk_attn_self_x3p(const float* qkv, void* kv_scratch, float* out, int n, int tokens, int heads, float scale, void* stream);
+/* the same, with the result ALSO (out != NULL) or ONLY (out == NULL) in the PS layout of the [n tokens][heads 32] matrix (out_ps,
+ * ldmk_ps_bytes(n tokens, heads 32) bytes): the pre-split A operand of attn1.to_out on tile_cfg 23+.  tokens % 32 == 0. */
+int ldmk_attn_self_x3p_ps(const float* qkv, void* kv_scratch, float* out, void* out_ps, int n, int tokens, int heads, float scale,
+                          void* stream);
 /* ldmk_attn_self_small: the same product for SMALL problems (batch 1-2: the reference's talking-face mode runs batch 1,
  *   talking_face/progressive_sampling_difftalk.py:350).  One workgroup per 32-query tile of a (sample, head), the keys split
  *   over its 4 / 8 waves and streamed from global memory without LDS staging, partial (max, sum, O) merged in wave order

@@ -162,7 +162,8 @@ def test_warp_specialised_tiles_are_bitwise_the_lds_tiled_split_form(ops, M, K, 
     outs = []
     for cfg in (ref_cfg, ws_cfg):
         out = torch.full((M, N), float("nan"), device="cuda")
-        a = ops.make_igemm_args(M, N, K, x.cuda(), K, wp, out, N, rows, bias=b.cuda(), residual=res.cuda(), batch_vec=vec,
+        xc, bc, rc = x.cuda(), b.cuda(), res.cuda()       # (named: the args hold raw pointers, and `st` below is allocated before the launch)
+        a = ops.make_igemm_args(M, N, K, xc, K, wp, out, N, rows, bias=bc, residual=rc, batch_vec=vec,
                                 batch_vec_ld=N, tile_cfg=cfg, splitk=sk, splitk_ws=ws, compute=L.COMPUTE_BF16X3)
         if M % 32 == 0 and rows % 32 == 0:
             st = torch.zeros(M // 32, N, 3, device="cuda")
@@ -290,3 +291,23 @@ def test_presplit_attention_is_bitwise_the_split_attention(ops, n, tokens, heads
     ref = ops.attn_self(qkv, n, tokens, heads, x3=True)
     out = ops.attn_self(qkv, n, tokens, heads, presplit=True)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("n,tokens,heads", [(2, 1024, 5), (1, 256, 20), (1, 4096, 5)])
+def test_presplit_attention_writes_its_result_in_the_ps_layout(ops, n, tokens, heads):
+    """ldmk_attn_self_x3p_ps: the attention result written straight from the accumulators in the PS layout (the pre-split A
+    operand of attn1.to_out) -- exactly pack_ps of the fp32 result, with or without the fp32 copy."""
+    from dsml_thesis_amd import lib as L
+    C_ = heads * 32
+    qkv = (rnd(570, n * tokens, 3 * C_) * 1.2).cuda()
+    ref = ops.attn_self(qkv, n, tokens, heads, presplit=True)
+    kv = torch.empty(L.load().ldmk_attn_kv_split_bytes(n, tokens, heads), device="cuda", dtype=torch.uint8)
+    for with_fp32 in (True, False):
+        out = torch.zeros(n * tokens, C_, device="cuda")
+        ps = ops.ps_empty(n * tokens, C_)
+        L.call("ldmk_attn_self_x3p_ps", qkv.data_ptr(), kv.data_ptr(), out.data_ptr() if with_fp32 else 0, ps.data_ptr(), n, tokens, heads,
+               32 ** -0.5, ops.stream())
+        assert torch.equal(ps, ops.pack_ps(ref))
+        assert torch.equal(out, ref) if with_fp32 else out.abs().max().item() == 0.0
+    with pytest.raises(L.LdmkError, match="tokens"):
+        L.call("ldmk_attn_self_x3p_ps", qkv.data_ptr(), kv.data_ptr(), 0, ps.data_ptr(), 1, 60, heads, 0.1, ops.stream())

@@ -1,7 +1,7 @@
 #!/bin/bash
 # what-if probes of the pre-split GEMM (LDMK_PS_DEBUG, csrc/igemm_ps.hip): 0 = real, 1 = DMA issued but dropped (no memory traffic),
-# 2 = no DMA instructions, 4 = no matrix instructions, 6 = neither (fragment reads + barriers + epilogue only)
-for d in 0 1 2 4 6; do
+# 2 = no DMA instructions, 4 = no matrix instructions, 6 = neither (fragment reads + barriers + epilogue only), 16 = no epilogue
+for d in ${PROBES:-0 1 2 4 6 16}; do
   echo "=== LDMK_PS_DEBUG=$d"
   LDMK_PS_DEBUG=$d timeout -k 10 200 python tools/ps_bench.py --probe 2>&1 | grep -v amdgpu.ids
 done
