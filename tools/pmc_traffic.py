@@ -1,4 +1,4 @@
-"""HBM traffic of the GEMM family (LDS-tiled igemm + row GEMM) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), corrected as
+"""HBM traffic of the GEMM family (LDS-tiled / warp-specialised / pre-split igemm + row GEMM) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), corrected as
 MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads:
 doubled; both counters are in KiB).  Usage: python tools/pmc_traffic.py FETCH_DIR WRITE_DIR LAUNCHES_PER_STEP KEY OUT.json"""
 import csv
@@ -12,7 +12,7 @@ def collect(d, counter):
     tot, n = 0.0, 0
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == counter and any(k in r.get("Kernel_Name", "") for k in ("igemm_kernel", "rgemm_kernel")):
+            if r.get("Counter_Name") == counter and any(k in r.get("Kernel_Name", "") for k in ("igemm_kernel", "igemm_ws_kernel", "igemm_ps_kernel", "igemm_pw_kernel", "rgemm_kernel")):
                 tot += float(r["Counter_Value"])
                 n += 1
     return tot, n
