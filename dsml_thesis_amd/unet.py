@@ -28,8 +28,10 @@ LN_GUARD_RATIO = float(os.environ.get("LDMK_LN_GUARD_RATIO", "4.0"))
 
 
 # self attention with K / V pre-split by a pre-pass (csrc/attention_bf16.hip: attn_x3p_fwd_kernel): the pre-pass costs one sweep
-# over K and V, the key loop saves its K / V splits tokens / 128 times: from this many tokens per sample
-ATTN_PRESPLIT_MIN_TOKENS = int(os.environ.get("LDMK_ATTN_PRESPLIT_MIN_TOKENS", "256"))
+# over K and V (and a launch), the key loop saves its K / V splits tokens / 128 times.  Measured in the 64x64x4 step, B = 16
+# (profiles/r04_layers64.txt, kernel + pre-pass against ldmk_attn_self_x3): 4096 tokens 1062 -> 994 us per call, 1024 tokens
+# 145 -> 152, 256 tokens 28 -> 38: it pays from a few thousand tokens per sample.
+ATTN_PRESPLIT_MIN_TOKENS = int(os.environ.get("LDMK_ATTN_PRESPLIT_MIN_TOKENS", "2048"))
 
 
 def ln_unfolded_default():
