@@ -18,7 +18,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-val
 # (208 such moves per key tile in the forward kernel).  The GEMM kernels only touch their accumulators in the epilogue.
 EXTRA_FLAGS = {"rgemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attention_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "attention_small.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "attention_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+               "attention_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}   # (no NaNs: see x3_softmax)
 
 
 def _digest():

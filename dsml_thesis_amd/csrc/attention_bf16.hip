@@ -319,6 +319,77 @@ __device__ __forceinline__ f32x16 mm6(const bf16x8_t (&a)[3], const bf16x8_t (&b
   return mm(a[0], b[0], c);
 }
 
+// ---- the softmax step of one 32-key block, written for the instruction count: the key loop of these kernels is bound by its
+// vector work next to the matrix cores (s_memtime / PMC), so
+//  * the two 32-lane halves of a wave exchange maxima and sums with v_permlane32_swap (one VALU operation) instead of a
+//    ds_bpermute round trip through the LDS,
+//  * score - max, the row sums and the residuals of the split are packed fp32 operations (v_pk_add_f32: two elements each),
+//  * the maxima are v_max3 chains (the file is compiled with -fno-honor-nans: no canonicalising v_max x, x per input; a
+//    query column always sees at least one unmasked key, so no NaN can arise),
+//  * the bf16 images of a pair of probabilities are one v_cvt_pk_bf16_f32 each, widened back with a shift / a mask.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4a __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void both_halves(float x, float& a, float& b) {       // a, b = the value of lane l31 / of lane l31 + 32
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ unsigned cvt_pk_bf16(f32x2 p) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t v = {(__bf16)p.x, (__bf16)p.y};
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  asm("" : "+v"(u));                 // (opaque: otherwise the low half is converted a second time on its own)
+  return u;
+}
+__device__ __forceinline__ f32x2 widen_pk_bf16(unsigned u) { return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+template <bool NO_EXP = false>
+__device__ __forceinline__ void x3_softmax(f32x16& s, f32x16& o, float& m_run, float& l_run) {
+  float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+  for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+  mx = fmaxf(mx, s[15]);
+  float a, b;
+  both_halves(mx, a, b);
+  const float m_new = fmaxf(fmaxf(m_run, a), b);
+  const f32x2 mm2 = {m_new, m_new};
+  f32x2 ps = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f32x2 d = f32x2{s[2 * i], s[2 * i + 1]} - mm2;
+    if constexpr (!NO_EXP) {
+      d.x = __builtin_amdgcn_exp2f(d.x);
+      d.y = __builtin_amdgcn_exp2f(d.y);
+    }
+    s[2 * i] = d.x;
+    s[2 * i + 1] = d.y;
+    ps += d;
+  }
+  both_halves(ps.x + ps.y, a, b);
+  if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {      // rescale only when some lane's maximum moved
+    const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+    l_run *= corr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= corr;
+    m_run = m_new;
+  }
+  l_run += a + b;
+}
+// probabilities s[8 t .. 8 t + 7] as their three bf16 images (the exact split of split8, two elements per operation)
+__device__ __forceinline__ void split_p8(const f32x16& s, int t, bf16x8_t (&o)[3]) {
+  u32x4a h, m, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 p = {s[8 * t + 2 * j], s[8 * t + 2 * j + 1]};
+    h[j] = cvt_pk_bf16(p);
+    const f32x2 r = p - widen_pk_bf16(h[j]);
+    m[j] = cvt_pk_bf16(r);
+    l[j] = cvt_pk_bf16(r - widen_pk_bf16(m[j]));
+  }
+  o[0] = __builtin_bit_cast(bf16x8_t, h);
+  o[1] = __builtin_bit_cast(bf16x8_t, m);
+  o[2] = __builtin_bit_cast(bf16x8_t, l);
+}
+
 constexpr int X3_KIMG = BA_T * BA_RS, X3_VIMG = BA_D * BA_TS;       // bf16 elements per K / V image
 
 __global__ __launch_bounds__(256) void attn_x3_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int tokens,
@@ -408,30 +479,11 @@ __global__ __launch_bounds__(256) void attn_x3_fwd_kernel(const float* __restric
         for (int r = 0; r < 16; ++r)
           if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s[r] = -INFINITY;
       }
-      float mx = fmaxf(s[0], s[1]);
-#pragma unroll
-      for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); psum += s[r]; }
-      psum += __shfl_xor(psum, 32, 64);
-      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {      // rescale only when some lane's maximum moved
-        const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= corr;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] *= corr;
-        m_run = m_new;
-      }
-      l_run += psum;
+      x3_softmax(s, o, m_run, l_run);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        float pv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pv[j] = s[8 * t + j];
         bf16x8_t pb[3], va[3];
-        split8(pv, pb);
+        split_p8(s, t, pb);
 #pragma unroll
         for (int q = 0; q < 3; ++q) va[q] = op_cols(Vt + q * X3_VIMG, sub, l31, half, t);
         o = mm6(va, pb, o);                                                             // O^T[d][q] += V^T P^T
@@ -456,6 +508,7 @@ __global__ __launch_bounds__(256) void attn_x3_fwd_kernel(const float* __restric
 // buffered, and reads every operand with one conflict-free ds_read_b128.  Same split values, same instruction sequence per
 // accumulator: bitwise the results of attn_x3_fwd_kernel.
 typedef unsigned int au32x4 __attribute__((ext_vector_type(4)));
+constexpr int X3P_QB2_MIN_TOKENS = 2048;
 constexpr int X3P_TILE = 24 * 1024;           // bytes per 64-key tile: (4 K + 4 V^T fragments) x 3 planes x 1 KiB
 
 __global__ __launch_bounds__(256) void attn_kv_split_kernel(const float* __restrict__ qkv, unsigned char* __restrict__ kv, int tokens, int heads) {
@@ -516,35 +569,46 @@ __device__ __forceinline__ float mul_rounded(float a, float b) {
   return a * b;
 }
 
-__global__ __launch_bounds__(256) void attn_x3p_fwd_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ kv,
-                                                           float* __restrict__ out, unsigned char* __restrict__ out_ps, int tokens, int heads,
-                                                           float scale) {
+// QB = query blocks of 32 per wave.  With QB = 2 a wave owns 64 queries: every K / V^T fragment read from the LDS feeds two
+// products, the two blocks' accumulator chains are independent (the matrix pipe never waits for the previous product of the
+// same accumulator) and one block's softmax issues next to the other block's products.  The LDS (2 x 24 KiB) allows three
+// workgroups per CU either way, i.e. 168 registers per lane.
+// (DBG, probe builds only -- tools/probe/attn_x3p_probe.hip: bit 0 = no S^T products, 1 = no exponentials, 2 = no split of the
+//  probabilities, 3 = no O^T products, 4 = no LDS operand reads, 5 = no softmax at all.  Results are garbage then; the product
+//  library instantiates DBG = 0 only.)
+template <int QB, int DBG = 0>
+__global__ __launch_bounds__(256, 3) void attn_x3p_fwd_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ kv,
+                                                              float* __restrict__ out, unsigned char* __restrict__ out_ps, int tokens, int heads,
+                                                              float scale) {
   // two tile buffers; after the key loop the same memory is the four output transpose buffers
   __shared__ __attribute__((aligned(1024))) unsigned char smem_p[2 * X3P_TILE];
   static_assert(2 * X3P_TILE >= 4 * 32 * BA_FS * 4, "transpose buffers alias the tile buffers");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
   const int C = heads * BA_D, ld = 3 * C;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
   const float* base = qkv + (long long)b * tokens * ld;
   const bool wave_active = q0 < tokens;
-  const bool q_valid = q0 + l31 < tokens;
   constexpr float LOG2E = 1.4426950408889634f;
-  bf16x8_t qf[2][3];
-  {
-    const float* rowp = base + (long long)(q_valid ? q0 + l31 : 0) * ld + h * BA_D;
+  bf16x8_t qf[QB][2][3];
+  f32x16 o[QB];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const bool q_valid = q0 + 32 * j + l31 < tokens;
+    const float* rowp = base + (long long)(q_valid ? q0 + 32 * j + l31 : 0) * ld + h * BA_D;
     const float mul = q_valid ? scale * LOG2E : 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const float4 a = *reinterpret_cast<const float4*>(rowp + 16 * t + 8 * half), c = *reinterpret_cast<const float4*>(rowp + 16 * t + 8 * half + 4);
       const float v[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, c.x * mul, c.y * mul, c.z * mul, c.w * mul};
-      split8(v, qf[t]);
+      split8(v, qf[j][t]);
     }
-  }
-  f32x16 o;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+    m_run[j] = -INFINITY;
+    l_run[j] = 0.f;
+  }
   const int ntiles = (tokens + BA_T - 1) / BA_T;
   // this (sample, head)'s tiles as one buffer; wave w moves fragments 2w, 2w + 1 of a tile (6 KiB contiguous)
   const unsigned char* kvh = kv + ((long long)b * heads + h) * ntiles * X3P_TILE;
@@ -575,81 +639,118 @@ __global__ __launch_bounds__(256) void attn_x3p_fwd_kernel(const float* __restri
     for (int sub = 0; sub < 2; ++sub) {
       const int key0 = kt * BA_T + sub * 32;
       if (key0 >= tokens) break;
-      f32x16 s;
+      f32x16 s[QB];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      for (int j = 0; j < QB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         bf16x8_t ka[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) ka[q] = *reinterpret_cast<const bf16x8_t*>(tb + ((2 * sub + t) * 3 + q) * 1024);
-        s = mm6(ka, qf[t], s);                                                          // S^T[key][q], log2 domain
+        for (int q = 0; q < 3; ++q) {
+          if constexpr (DBG & 16) { ka[q] = qf[0][t][q]; asm volatile("" : "+v"(ka[q])); }
+          else ka[q] = *reinterpret_cast<const bf16x8_t*>(tb + ((2 * sub + t) * 3 + q) * 1024);
+        }
+        if constexpr (DBG & 1) {
+#pragma unroll
+          for (int j = 0; j < QB; ++j) asm volatile("" : "+v"(s[j]) : "v"(ka[0]), "v"(ka[1]), "v"(ka[2]));
+        } else if constexpr (QB == 1) {
+          s[0] = mm6(ka, qf[0][t], s[0]);                                                 // S^T[key][q], log2 domain
+        } else {                                 // the two blocks' chains interleaved, each in its own (bitwise) order
+          s[0] = mm(ka[2], qf[0][t][0], s[0]); s[1] = mm(ka[2], qf[1][t][0], s[1]);
+          s[0] = mm(ka[0], qf[0][t][2], s[0]); s[1] = mm(ka[0], qf[1][t][2], s[1]);
+          s[0] = mm(ka[1], qf[0][t][1], s[0]); s[1] = mm(ka[1], qf[1][t][1], s[1]);
+          s[0] = mm(ka[1], qf[0][t][0], s[0]); s[1] = mm(ka[1], qf[1][t][0], s[1]);
+          s[0] = mm(ka[0], qf[0][t][1], s[0]); s[1] = mm(ka[0], qf[1][t][1], s[1]);
+          s[0] = mm(ka[0], qf[0][t][0], s[0]); s[1] = mm(ka[0], qf[1][t][0], s[1]);
+        }
       }
       if (key0 + 32 > tokens) {
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s[r] = -INFINITY;
+        for (int j = 0; j < QB; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s[j][r] = -INFINITY;
       }
-      float mx = fmaxf(s[0], s[1]);
 #pragma unroll
-      for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); psum += s[r]; }
-      psum += __shfl_xor(psum, 32, 64);
-      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {      // rescale only when some lane's maximum moved
-        const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= corr;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] *= corr;
-        m_run = m_new;
+      for (int j = 0; j < QB; ++j) {
+        if constexpr (DBG & 32) asm volatile("" : "+v"(s[j]));
+        else x3_softmax<(DBG & 2) != 0>(s[j], o[j], m_run[j], l_run[j]);
       }
-      l_run += psum;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        float pv[8];
+        bf16x8_t va[3];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pv[j] = s[8 * t + j];
-        bf16x8_t pb[3], va[3];
-        split8(pv, pb);
+        for (int q = 0; q < 3; ++q) {
+          if constexpr (DBG & 16) { va[q] = qf[0][t][q]; asm volatile("" : "+v"(va[q])); }
+          else va[q] = *reinterpret_cast<const bf16x8_t*>(tb + ((4 + 2 * sub + t) * 3 + q) * 1024);
+        }
+        if constexpr ((DBG & 12) != 0) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) va[q] = *reinterpret_cast<const bf16x8_t*>(tb + ((4 + 2 * sub + t) * 3 + q) * 1024);
-        o = mm6(va, pb, o);                                                             // O^T[d][q] += V^T P^T
+          for (int j = 0; j < QB; ++j) {
+            bf16x8_t pb[3];
+            if constexpr (DBG & 4) {
+#pragma unroll
+              for (int q = 0; q < 3; ++q) pb[q] = __builtin_bit_cast(bf16x8_t, u32x4a{__float_as_uint(s[j][8 * t + q]), __float_as_uint(s[j][8 * t + q + 1]), __float_as_uint(s[j][8 * t + q + 2]), __float_as_uint(s[j][8 * t + q + 3])});
+            } else split_p8(s[j], t, pb);
+            if constexpr (DBG & 8) asm volatile("" : "+v"(o[j]) : "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(va[0]), "v"(va[1]), "v"(va[2]));
+            else o[j] = mm6(va, pb, o[j]);
+          }
+        } else if constexpr (QB == 1) {
+          bf16x8_t pb[3];
+          split_p8(s[0], t, pb);
+          o[0] = mm6(va, pb, o[0]);                                                       // O^T[d][q] += V^T P^T
+        } else {
+          bf16x8_t pb[2][3];
+          split_p8(s[0], t, pb[0]);
+          split_p8(s[1], t, pb[1]);
+          o[0] = mm(va[2], pb[0][0], o[0]); o[1] = mm(va[2], pb[1][0], o[1]);
+          o[0] = mm(va[0], pb[0][2], o[0]); o[1] = mm(va[0], pb[1][2], o[1]);
+          o[0] = mm(va[1], pb[0][1], o[0]); o[1] = mm(va[1], pb[1][1], o[1]);
+          o[0] = mm(va[1], pb[0][0], o[0]); o[1] = mm(va[1], pb[1][0], o[1]);
+          o[0] = mm(va[0], pb[0][1], o[0]); o[1] = mm(va[0], pb[1][1], o[1]);
+          o[0] = mm(va[0], pb[0][0], o[0]); o[1] = mm(va[0], pb[1][0], o[1]);
+        }
       }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the trailing out-of-range fetch)
   __syncthreads();                     // every wave is done with the tile buffers: their memory becomes the transpose buffers
   if (!wave_active) return;
-  if (out_ps) {
-    // the result in the PS layout (include/ldmk.h) of the [n tokens][C] matrix -- the pre-split A operand of attn1.to_out on the
-    // pre-split GEMM tiles (csrc/igemm_ps.hip).  The accumulator already has the layout its transposed epilogue writes from:
-    // lane = (query, half), registers 4 g .. 4 g + 3 = d 8 g + 4 half .. + 3: one 8-byte store per (g, plane), no LDS pass.
-    // (tokens % 32 == 0: a wave's 32 queries are one row block)
-    const float inv = 1.0f / l_run;
-    unsigned char* d0 = out_ps + ((((long long)b * tokens + q0) >> 5) * (C / 16) + 2 * h) * 3072 + l31 * 16 + half * 8;
-    if (q_valid) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4_t hh, mm_, ll;
-        // (the fp32 product is rounded BEFORE it is split -- no fused multiply-subtract into the residuals -- so the planes sum
-        //  to exactly the value the fp32 output holds)
-        float4 v4 = make_float4(mul_rounded(o[4 * g], inv), mul_rounded(o[4 * g + 1], inv), mul_rounded(o[4 * g + 2], inv), mul_rounded(o[4 * g + 3], inv));
-        asm volatile("" : "+v"(v4.x), "+v"(v4.y), "+v"(v4.z), "+v"(v4.w));
-        split4(v4, hh, mm_, ll);
-        unsigned char* d = d0 + (g >> 1) * 3072 + (g & 1) * 512;
-        *reinterpret_cast<bf16x4_t*>(d) = hh;
-        *reinterpret_cast<bf16x4_t*>(d + 1024) = mm_;
-        *reinterpret_cast<bf16x4_t*>(d + 2048) = ll;
+  for (int j = 0; j < QB; ++j) {
+    const int qb0 = q0 + 32 * j;
+    if (qb0 >= tokens) break;
+    const bool q_valid = qb0 + l31 < tokens;
+    if (out_ps) {
+      // the result in the PS layout (include/ldmk.h) of the [n tokens][C] matrix -- the pre-split A operand of attn1.to_out on the
+      // pre-split GEMM tiles (csrc/igemm_ps.hip).  The accumulator already has the layout its transposed epilogue writes from:
+      // lane = (query, half), registers 4 g .. 4 g + 3 = d 8 g + 4 half .. + 3: one 8-byte store per (g, plane), no LDS pass.
+      // (tokens % 32 == 0: a wave's 32 queries are one row block)
+      const float inv = 1.0f / l_run[j];
+      unsigned char* d0 = out_ps + ((((long long)b * tokens + qb0) >> 5) * (C / 16) + 2 * h) * 3072 + l31 * 16 + half * 8;
+      if (q_valid) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4_t hh, mm_, ll;
+          // (the fp32 product is rounded BEFORE it is split -- no fused multiply-subtract into the residuals -- so the planes sum
+          //  to exactly the value the fp32 output holds)
+          float4 v4 = make_float4(mul_rounded(o[j][4 * g], inv), mul_rounded(o[j][4 * g + 1], inv), mul_rounded(o[j][4 * g + 2], inv), mul_rounded(o[j][4 * g + 3], inv));
+          asm volatile("" : "+v"(v4.x), "+v"(v4.y), "+v"(v4.z), "+v"(v4.w));
+          split4(v4, hh, mm_, ll);
+          unsigned char* d = d0 + (g >> 1) * 3072 + (g & 1) * 512;
+          *reinterpret_cast<bf16x4_t*>(d) = hh;
+          *reinterpret_cast<bf16x4_t*>(d + 1024) = mm_;
+          *reinterpret_cast<bf16x4_t*>(d + 2048) = ll;
+        }
       }
     }
-  }
-  if (out) {
-    float* ts = reinterpret_cast<float*>(smem_p) + wave * (32 * BA_FS);
-    store_rows_bf(ts, o, 1.0f / l_run, out + (long long)b * tokens * C + h * BA_D, C, q0, tokens, l31, half);
+    if (out) {
+      float* ts = reinterpret_cast<float*>(smem_p) + wave * (32 * BA_FS);
+      store_rows_bf(ts, o[j], 1.0f / l_run[j], out + (long long)b * tokens * C + h * BA_D, C, qb0, tokens, l31, half);
+    }
   }
 }
 
@@ -683,8 +784,16 @@ extern "C" int ldmk_attn_self_x3p_ps(const float* qkv, void* kv_scratch, float* 
   LDMK_REQUIRE((long long)ntiles * X3P_TILE < (1LL << 31), "ldmk_attn_self_x3p: %d tokens: a head's pre-split K / V exceeds 2 GiB", tokens);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_kv_split_kernel, dim3(ntiles, heads, n), dim3(256), 0, st, qkv, reinterpret_cast<unsigned char*>(kv_scratch), tokens, heads);
-  hipLaunchKernelGGL(attn_x3p_fwd_kernel, dim3((tokens + 127) / 128, heads, n), dim3(256), 0, st, qkv,
-                     reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale);
+  // 64 queries per wave from X3P_QB2_MIN_TOKENS tokens (below, the grid of 256-query workgroups no longer fills the chip);
+  // LDMK_ATTN_QB = 1 | 2 pins the form (measurements).  The result does not depend on it, bit for bit.
+  static const int qb_env = [] { const char* e = getenv("LDMK_ATTN_QB"); return e ? atoi(e) : 0; }();
+  const int qb = qb_env == 1 || qb_env == 2 ? qb_env : (tokens >= X3P_QB2_MIN_TOKENS ? 2 : 1);
+  if (qb == 2)
+    hipLaunchKernelGGL(attn_x3p_fwd_kernel<2>, dim3((tokens + 255) / 256, heads, n), dim3(256), 0, st, qkv,
+                       reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale);
+  else
+    hipLaunchKernelGGL(attn_x3p_fwd_kernel<1>, dim3((tokens + 127) / 128, heads, n), dim3(256), 0, st, qkv,
+                       reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale);
   return check_launch("ldmk_attn_self_x3p");
 }
 

@@ -282,11 +282,13 @@ def test_pre_split_activations_are_bitwise_the_in_kernel_split(ops, M, K, N, geg
         assert L.load().ldmk_igemm_check(ctypes.byref(a)) != 0
 
 
-@pytest.mark.parametrize("n,tokens,heads", [(2, 4096, 5), (1, 1024, 10), (3, 256, 20), (1, 960, 5), (2, 60, 5), (1, 4, 5), (1, 129, 10)])
+@pytest.mark.parametrize("n,tokens,heads", [(2, 4096, 5), (1, 1024, 10), (3, 256, 20), (1, 960, 5), (2, 60, 5), (1, 4, 5), (1, 129, 10),
+                                            (1, 2100, 5), (1, 2081, 3), (1, 2304, 2), (1, 2049, 1)])
 def test_presplit_attention_is_bitwise_the_split_attention(ops, n, tokens, heads):
     """ldmk_attn_self_x3p: K / V split once by a pre-pass into MFMA-operand-order planes, tiles moved to LDS by LDS-DMA.  Same
     split values and the same instruction sequence per accumulator as ldmk_attn_self_x3: equal bit for bit, ragged token counts
-    (partial 64-key tiles, partial 128-query workgroups) included."""
+    (partial 64-key tiles, partial 128-query workgroups) included.  From 2048 tokens a wave owns two 32-query blocks
+    (attn_x3p_fwd_kernel<2>): a partial second block, a second block of one query, an absent second block."""
     qkv = (rnd(560, n * tokens, 3 * heads * 32) * 1.5).cuda()
     ref = ops.attn_self(qkv, n, tokens, heads, x3=True)
     out = ops.attn_self(qkv, n, tokens, heads, presplit=True)

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--lib", help="another build of libldmk.so to time instead (A/B on one box)")
+    ap.add_argument("--mode", default="f32", choices=("f32", "x3", "x3p"), help="f32 matrix cores / bf16x3 / bf16x3 with the K, V pre-pass")
     a = ap.parse_args()
     if a.lib:
         from dsml_thesis_amd import lib as L
@@ -27,7 +28,12 @@ def main():
         tokens = (a.latent >> lvl) ** 2
         qkv = torch.randn(a.batch * tokens, 3 * heads * 32, device="cuda")
         out = torch.empty(a.batch * tokens, heads * 32, device="cuda")
-        t = timeit(lambda: ops.attn_self(qkv, a.batch, tokens, heads, out=out))
+        if a.mode == "x3p":
+            from dsml_thesis_amd import lib as L
+            kv = torch.empty(L.load().ldmk_attn_kv_split_bytes(a.batch, tokens, heads), device="cuda", dtype=torch.uint8)
+            t = timeit(lambda: L.call("ldmk_attn_self_x3p", qkv.data_ptr(), kv.data_ptr(), out.data_ptr(), a.batch, tokens, heads, 32 ** -0.5, ops.stream()))
+        else:
+            t = timeit(lambda: ops.attn_self(qkv, a.batch, tokens, heads, out=out, x3=a.mode == "x3"))
         gf = 4.0 * tokens * tokens * 32 * heads * a.batch * 1e-9
         tot += t * calls
         print(f"tokens {tokens:5d} heads {heads:2d}: {t:8.1f} us  {gf / t * 1e3:6.1f} TFLOP/s  (x{calls} per step)", flush=True)
