@@ -126,10 +126,29 @@ class StepRunner:
                 best = tot
                 self.winograd_transform_ms = sum(a.elapsed_time(b) for a, b in tevs)
                 # the same launches by arithmetic: LDMK_COMPUTE_BF16X3 (six bf16 MFMAs per fp32-accurate product) vs f32 MFMA
-                x3 = [c[2].compute == 2 for c in pg.calls if c[3] == "ldmk_igemm"]
-                self.x3_ms = sum(a.elapsed_time(b) for (a, b), f in zip(evs, x3) if f)
-                self.x3_launches = sum(x3)
+                comp = [c[2].compute for c in pg.calls if c[3] == "ldmk_igemm"]
+                self.x3_ms = sum(a.elapsed_time(b) for (a, b), f in zip(evs, comp) if f == 2)
+                self.x3_launches = sum(1 for f in comp if f == 2)
+                # ... and LDMK_COMPUTE_F16X2 (three fp16 MFMAs per product)
+                self.h2_ms = sum(a.elapsed_time(b) for (a, b), f in zip(evs, comp) if f == 3)
+                self.h2_launches = sum(1 for f in comp if f == 3)
         return best, n_ig
+
+
+def sustained_mfma16_tflops():
+    """Median TFLOP/s of the register-only v_mfma_f32_32x32x16_bf16 loop on pseudo-random operands (profiles/r04_clock_bf16.txt)."""
+    import re
+    try:
+        vals = []
+        mode = None
+        for ln in open(os.path.join(ROOT, "profiles", "r04_clock_bf16.txt")):
+            m = re.search(r"MFMAs per wave: [\d.]+ ms = ([\d.]+) TFLOP/s; shader clock median (\d+) MHz", ln)
+            if m and float(m.group(1)) > 400 and int(m.group(2)) < 2000:      # (bf16 rows on real operands: the zero-operand runs hold > 2.1 GHz)
+                vals.append(float(m.group(1)))
+        vals.sort()
+        return round(vals[len(vals) // 2], 1) if vals else None
+    except Exception:
+        return None
 
 
 def executed_gemm_flops(pg, compute=None):
@@ -604,7 +623,7 @@ def main():
         # every tensor, accumulation, norm and softmax is fp32; with LDMK_SPLIT_BF16 on (default) the large GEMMs and the self
         # attention form their fp32 products from exact three-way bf16 splits on the bf16 matrix cores (include/ldmk.h,
         # LDMK_COMPUTE_BF16X3): same accuracy class as the f32 MFMA form (tests/test_split_gpu.py), same parity bounds
-        "arithmetic": ("fp32 storage/accumulate; matrix products: bf16x3 exact split (6 bf16 MFMAs per product) where the x3 plan "
+        "arithmetic": ("fp32 storage/accumulate; matrix products: f16x2 split (3 fp16 MFMAs per product, fp32 accuracy class; LDMK_F16X2=0: bf16x3 exact split, 6 bf16 MFMAs) where the x3 plan "
                        "table lists the shape, f32 MFMA elsewhere") if os.environ.get("LDMK_SPLIT_BF16", "1") != "0" else
                       "fp32 throughout (f32 MFMA)",
         "config": {"workload": f"face_reenactment emotion-conditioned LDM (AffectNet config), DDIM-200 schedule, "
@@ -635,18 +654,24 @@ def main():
                              f"command (profiles/{tname}); L2<->fabric, Infinity-Cache hits included")
                     break
         t_x3, n_x3 = getattr(run, "x3_ms", 0.0), getattr(run, "x3_launches", 0)
+        t_h2, n_h2 = getattr(run, "h2_ms", 0.0), getattr(run, "h2_launches", 0)
         fl_x3 = executed_gemm_flops(run.pg, 2) * 1e-12
+        fl_h2 = executed_gemm_flops(run.pg, 3) * 1e-12
         split = None
-        if n_x3:
-            # the dominant kernel is the bf16x3 igemm: price IT against the bf16 matrix peak on the bf16 MFMA FLOPs it issues
-            # (6 per fp32-equivalent FLOP); the f32-MFMA launches that remain are reported beside it against their own peak
-            ach3 = 6.0 * fl_x3 / (t_x3 * 1e-3)
-            t_f, fl_f = t_ig - t_x3, fl_exec - fl_x3
-            split = {"bf16x3": {"launches": n_x3, "ms_per_step": round(t_x3, 4), "fp32_equivalent_tflops": round(fl_x3 / (t_x3 * 1e-3), 2),
-                                "bf16_mfma_tflops_issued": round(ach3, 2), "peak": PEAK_BF16_MFMA, "frac": round(ach3 / PEAK_BF16_MFMA, 4)},
-                     "f32_mfma": {"launches": n_ig - n_x3, "ms_per_step": round(t_f, 4), "tflops": round(fl_f / (t_f * 1e-3), 2) if t_f > 0 else None,
+        if n_x3 or n_h2:
+            # the dominant kernel is a split-arithmetic igemm: price IT against the 16-bit matrix peak on the MFMA FLOPs it issues
+            # (bf16x3: 6 per fp32-equivalent FLOP, f16x2: 3); the f32-MFMA launches that remain are reported beside it against
+            # their own peak
+            t_f, fl_f = t_ig - t_x3 - t_h2, fl_exec - fl_x3 - fl_h2
+            split = {"f32_mfma": {"launches": n_ig - n_x3 - n_h2, "ms_per_step": round(t_f, 4), "tflops": round(fl_f / (t_f * 1e-3), 2) if t_f > 0 else None,
                                   "peak": PEAK_F32_MFMA, "frac": round(fl_f / (t_f * 1e-3) / PEAK_F32_MFMA, 4) if t_f > 0 else None},
                      "family_fp32_equivalent_tflops": round(ach, 2)}
+            for key, mult, n_, t_, fl_ in (("bf16x3", 6.0, n_x3, t_x3, fl_x3), ("f16x2", 3.0, n_h2, t_h2, fl_h2)):
+                if n_:
+                    iss = mult * fl_ / (t_ * 1e-3)
+                    split[key] = {"launches": n_, "ms_per_step": round(t_, 4), "fp32_equivalent_tflops": round(fl_ / (t_ * 1e-3), 2),
+                                  "mfma_instructions_per_product": int(mult), "mfma_tflops_issued": round(iss, 2), "peak": PEAK_BF16_MFMA,
+                                  "frac": round(iss / PEAK_BF16_MFMA, 4)}
         # ONE fixed basis per arithmetic setting (never chosen from measured times): with the bf16x3 split arithmetic on (default),
         # `achieved` = the bf16 MFMA FLOPs the bf16x3 launches ISSUE (6 x 2MNK) over their summed duration against the dense bf16
         # matrix peak; with LDMK_SPLIT_BF16=0, executed fp32 FLOPs of the whole family against the f32 matrix peak
@@ -670,12 +695,25 @@ def main():
                            "sum_launch_ms_per_step": round(t_ig, 4)}
         if split is not None:
             r = out["roofline"]
-            r["achieved"], r["peak"], r["frac"] = split["bf16x3"]["bf16_mfma_tflops_issued"], PEAK_BF16_MFMA, split["bf16x3"]["frac"]
-            r["basis"] = "bf16_mfma_issued"
-            r["kernel"] = ("ldmk::igemm_kernel<..., BF = 3> / igemm_ps_kernel / igemm_pw_kernel (LDMK_COMPUTE_BF16X3: fp32-accurate "
+            dom = "f16x2" if t_h2 >= t_x3 else "bf16x3"
+            r["achieved"], r["peak"], r["frac"] = split[dom]["mfma_tflops_issued"], PEAK_BF16_MFMA, split[dom]["frac"]
+            r["basis"] = "f16_mfma_issued" if dom == "f16x2" else "bf16_mfma_issued"
+            r["fp32_equivalent_tflops"] = split[dom]["fp32_equivalent_tflops"]
+            r["kernel"] = ("ldmk::igemm_kernel<..., BF = 4> (LDMK_COMPUTE_F16X2: fp32-accurate products from THREE fp16 MFMAs, include/ldmk.h) "
+                           "-- the launches that hold most of the GEMM time; `achieved` counts the fp16 MFMA FLOPs they issue (3 x 2MNK) "
+                           "against the nominal dense 16-bit matrix peak.  Fewer issued FLOPs per product is the point of this arithmetic: "
+                           "`fp32_equivalent_tflops` is the rate of useful work, `sustained` what the chip holds on this instruction"
+                           if dom == "f16x2" else
+                           "ldmk::igemm_kernel<..., BF = 3> / igemm_ps_kernel / igemm_pw_kernel (LDMK_COMPUTE_BF16X3: fp32-accurate "
                            "products from six bf16 MFMAs, include/ldmk.h; the ps / pw forms take both operands pre-split and stage them by "
                            "LDS-DMA) -- the launches that hold most of the GEMM time; `achieved` counts the bf16 MFMA FLOPs they issue "
                            "(6 x 2MNK) against the dense bf16 matrix peak")
+            # what the chip SUSTAINS on back-to-back 16-bit MFMAs from registers with real operands (power-limited: tools/clock_probe.hip,
+            # measured on another box of this pool and committed; the nominal peak assumes 2.4 GHz)
+            sus = sustained_mfma16_tflops()
+            if sus is not None:
+                r["sustained"] = {"mfma16_tflops_register_loop": sus, "source": "profiles/r04_clock_bf16.txt (tools/clock_probe.hip, median of the "
+                                  "bf16 runs on pseudo-random operands)", "frac_of_sustained": round(r["achieved"] / sus, 4)}
             r["by_arithmetic"] = split
     del run
     torch.cuda.empty_cache()

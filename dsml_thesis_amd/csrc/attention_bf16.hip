@@ -754,6 +754,263 @@ __global__ __launch_bounds__(256, 3) void attn_x3p_fwd_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32-accurate self attention from THREE fp16 products per term (LDMK_COMPUTE_F16X2 of include/ldmk.h applied to the two
+// attention products).  gfx950 sustains only 0.60-0.69 of its nominal bf16 / fp16 matrix rate on real operands (power:
+// tools/clock_probe.hip, profiles/r04_clock_bf16.txt), so the lever left is the NUMBER of matrix instructions per product.
+// An operand scaled by a power of two into fp16's range is written x' = hi + lo with hi = fp16(x'), lo = fp16(x' - hi)
+// (round-to-nearest-even; x' - hi is exact in fp32): 2 x 11 significand bits, |x' - hi - lo| <= 2^-23 |x'| -- one fp32 ulp, the
+// size of an fp32 rounding error, where the three-way bf16 split is exact.  hi hi, hi lo, lo hi accumulate in one fp32 accumulator
+// (fp16 x fp16 products are exact in fp32), smallest first; lo lo (<= 2^-22 of the product) is dropped.  Measured against
+// float64 the error is 1.0-1.7 x that of an fp32 dot product (the larger figure at K = 160; tests/test_f16x2_gpu.py).
+//   scales: K, V and the pre-scaled Q by 2^6 (|x| < 1000 required: the pre-pass raises *range_flag otherwise and the caller
+//   re-runs in the bf16x3 arithmetic; an element below 2^-9 keeps an ABSOLUTE precision of 2^-31), the probabilities by 2^14
+//   (the exponent argument is offset by 14).  Scores live in the domain scaled by 2^12; the output is rescaled at the end.
+// Tiles: per 64 keys 8 fragments x 2 planes of 1 KiB (16 KiB), same fragment order as the bf16x3 tiles above.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+constexpr int H2_TILE = 16 * 1024;
+constexpr float H2_S = 64.f;                  // 2^6: K, V, Q
+constexpr float H2_RANGE = 1000.f;            // |K|, |V|, |scale log2(e) Q| below this (x 64 < 65504, fp16's largest finite value)
+constexpr float H2_PEXP = 14.f;               // probabilities scaled by 2^14
+
+__device__ __forceinline__ unsigned cvt_pk_f16(f32x2 p) {
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  const f16x2_t v = {(_Float16)p.x, (_Float16)p.y};
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  asm("" : "+v"(u));
+  return u;
+}
+__device__ __forceinline__ f32x2 widen_pk_f16(unsigned u) {
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  const f16x2_t v = __builtin_bit_cast(f16x2_t, u);
+  return f32x2{(float)v.x, (float)v.y};
+}
+// 8 (already scaled) values as their two fp16 images
+__device__ __forceinline__ void split8_h2(const float* v, f16x8_t (&o)[2]) {
+  u32x4a h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 p = {v[2 * j], v[2 * j + 1]};
+    h[j] = cvt_pk_f16(p);
+    l[j] = cvt_pk_f16(p - widen_pk_f16(h[j]));
+  }
+  o[0] = __builtin_bit_cast(f16x8_t, h);
+  o[1] = __builtin_bit_cast(f16x8_t, l);
+}
+__device__ __forceinline__ bool out_of_h2_range(float v) { return (__float_as_uint(v) & 0x7fffffffu) >= __float_as_uint(H2_RANGE); }   // (inf, NaN too)
+__device__ __forceinline__ f32x16 mmh(const f16x8_t a, const f16x8_t b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mmh3(const f16x8_t (&a)[2], const f16x8_t (&b)[2], f32x16 c) {
+  c = mmh(a[1], b[0], c);
+  c = mmh(a[0], b[1], c);
+  return mmh(a[0], b[0], c);
+}
+
+__global__ __launch_bounds__(256) void attn_kv_split_h2_kernel(const float* __restrict__ qkv, unsigned char* __restrict__ kv, int tokens, int heads,
+                                                               int* __restrict__ range_flag) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int C = heads * BA_D, ld = 3 * C;
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int ntiles = gridDim.x;
+  const float* base = qkv + (long long)b * tokens * ld + h * BA_D;
+  unsigned char* dst = kv + (((long long)b * heads + h) * ntiles + kt) * H2_TILE;
+  const int sub = wave >> 1, t = wave & 1;
+  bool bad = false;
+  {
+    const int key = kt * BA_T + sub * 32 + l31;
+    float v[8];
+    if (key < tokens) {
+      const float* p = base + C + (long long)key * ld + 16 * t + 8 * half;
+      const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bad |= out_of_h2_range(v[j]); v[j] *= H2_S; }
+    f16x8_t g[2];
+    split8_h2(v, g);
+    unsigned char* d = dst + (2 * sub + t) * 2048 + lane * 16;
+    *reinterpret_cast<f16x8_t*>(d) = g[0];
+    *reinterpret_cast<f16x8_t*>(d + 1024) = g[1];
+  }
+  {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int key = kt * BA_T + sub * 32 + 16 * t + 4 * half + (j & 3) + 8 * (j >> 2);
+      v[j] = key < tokens ? base[2 * C + (long long)key * ld + l31] : 0.f;
+      bad |= out_of_h2_range(v[j]);
+      v[j] *= H2_S;
+    }
+    f16x8_t g[2];
+    split8_h2(v, g);
+    unsigned char* d = dst + (4 + 2 * sub + t) * 2048 + lane * 16;
+    *reinterpret_cast<f16x8_t*>(d) = g[0];
+    *reinterpret_cast<f16x8_t*>(d + 1024) = g[1];
+  }
+  if (bad) *range_flag = 1;
+}
+
+__device__ __forceinline__ void h2_dma4(unsigned voff, const au32x4& rs, unsigned lds_dst) {     // 4 x 1 KiB, contiguous both sides
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+               "buffer_load_dwordx4 %1, %2, 0 offen offset:1024 lds\n\t"
+               "buffer_load_dwordx4 %1, %2, 0 offen offset:2048 lds\n\t"
+               "buffer_load_dwordx4 %1, %2, 0 offen offset:3072 lds\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+}
+
+// the softmax step of one 32-key block in the scaled domains: s holds 2^12 x the log2-domain scores on entry, 2^14 x the
+// probabilities on exit; m_run is kept in the scores' scaled domain, l_run sums the scaled probabilities
+__device__ __forceinline__ void h2_softmax(f32x16& s, f32x16& o, float& m_run, float& l_run) {
+  constexpr float INV = 1.0f / (H2_S * H2_S);
+  float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+  for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+  mx = fmaxf(mx, s[15]);
+  float a, b;
+  both_halves(mx, a, b);
+  const float m_new = fmaxf(fmaxf(m_run, a), b);
+  const f32x2 mm2 = {m_new, m_new}, inv2 = {INV, INV}, off2 = {H2_PEXP, H2_PEXP};
+  f32x2 ps = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f32x2 d = (f32x2{s[2 * i], s[2 * i + 1]} - mm2) * inv2 + off2;      // (s - m) exact, x 2^-12 exact, + 14: one rounding
+    d.x = __builtin_amdgcn_exp2f(d.x);
+    d.y = __builtin_amdgcn_exp2f(d.y);
+    s[2 * i] = d.x;
+    s[2 * i + 1] = d.y;
+    ps += d;
+  }
+  both_halves(ps.x + ps.y, a, b);
+  if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+    const float corr = __builtin_amdgcn_exp2f((m_run - m_new) * INV);
+    l_run *= corr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= corr;
+    m_run = m_new;
+  }
+  l_run += a + b;
+}
+
+template <int QB>
+__global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ kv, float* __restrict__ out,
+                                                          int tokens, int heads, float scale, int* __restrict__ range_flag) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_h[2 * H2_TILE];
+  static_assert(2 * H2_TILE >= 4 * 32 * BA_FS * 4, "transpose buffers alias the tile buffers");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
+  const int C = heads * BA_D, ld = 3 * C;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
+  const float* base = qkv + (long long)b * tokens * ld;
+  const bool wave_active = q0 < tokens;
+  constexpr float LOG2E = 1.4426950408889634f;
+  f16x8_t qf[QB][2][2];
+  f32x16 o[QB];
+  float m_run[QB], l_run[QB];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const bool q_valid = q0 + 32 * j + l31 < tokens;
+    const float* rowp = base + (long long)(q_valid ? q0 + 32 * j + l31 : 0) * ld + h * BA_D;
+    const float mul = q_valid ? scale * LOG2E : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 a = *reinterpret_cast<const float4*>(rowp + 16 * t + 8 * half), c = *reinterpret_cast<const float4*>(rowp + 16 * t + 8 * half + 4);
+      float v[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, c.x * mul, c.y * mul, c.z * mul, c.w * mul};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { bad |= out_of_h2_range(v[i]); v[i] *= H2_S; }
+      split8_h2(v, qf[j][t]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+    m_run[j] = -INFINITY;
+    l_run[j] = 0.f;
+  }
+  if (bad) *range_flag = 1;
+  const int ntiles = (tokens + BA_T - 1) / BA_T;
+  const unsigned char* kvh = kv + ((long long)b * heads + h) * ntiles * H2_TILE;
+  au32x4 rs;
+  {
+    const unsigned long long a = (unsigned long long)kvh;
+    rs.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    rs.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+    rs.z = __builtin_amdgcn_readfirstlane((unsigned)ntiles * (unsigned)H2_TILE);
+    rs.w = 0x00020000u;
+  }
+  const unsigned lds0 = (unsigned)(size_t)smem_h;
+  const unsigned woff = (unsigned)wave * 4096u + (unsigned)lane * 16u;
+  auto fetch = [&](int kt) {                      // LDS-DMA of tile kt into buffer kt & 1 (tiles past the end: out of range, zeros)
+    h2_dma4((unsigned)kt * (unsigned)H2_TILE + woff, rs, lds0 + (unsigned)(kt & 1) * H2_TILE + (unsigned)wave * 4096u);
+  };
+  fetch(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    fetch(kt + 1);
+    if (!wave_active) continue;
+    const unsigned char* tb = smem_h + (kt & 1) * H2_TILE + lane * 16;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int key0 = kt * BA_T + sub * 32;
+      if (key0 >= tokens) break;
+      f32x16 s[QB];
+#pragma unroll
+      for (int j = 0; j < QB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f16x8_t ka[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ka[q] = *reinterpret_cast<const f16x8_t*>(tb + ((2 * sub + t) * 2 + q) * 1024);
+#pragma unroll
+        for (int j = 0; j < QB; ++j) s[j] = mmh3(ka, qf[j][t], s[j]);                      // 2^12 S^T[key][q], log2 domain
+      }
+      if (key0 + 32 > tokens) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < QB; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (key0 + (r & 3) + 8 * (r >> 2) + 4 * half >= tokens) s[j][r] = -INFINITY;
+      }
+#pragma unroll
+      for (int j = 0; j < QB; ++j) h2_softmax(s[j], o[j], m_run[j], l_run[j]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f16x8_t va[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) va[q] = *reinterpret_cast<const f16x8_t*>(tb + ((4 + 2 * sub + t) * 2 + q) * 1024);
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+          float pv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) pv[i] = s[j][8 * t + i];
+          f16x8_t pb[2];
+          split8_h2(pv, pb);
+          o[j] = mmh3(va, pb, o[j]);                                                       // 2^20 O^T[d][q] += V^T P^T
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (!wave_active) return;
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const int qb0 = q0 + 32 * j;
+    if (qb0 >= tokens) break;
+    float* ts = reinterpret_cast<float*>(smem_h) + wave * (32 * BA_FS);
+    store_rows_bf(ts, o[j], (1.0f / H2_S) / l_run[j], out + (long long)b * tokens * C + h * BA_D, C, qb0, tokens, l31, half);
+  }
+}
+
 }  // namespace ldmk
 
 extern "C" int ldmk_attn_self_x3(const float* qkv, float* out, int n, int tokens, int heads, float scale, void* stream) {
@@ -795,6 +1052,32 @@ extern "C" int ldmk_attn_self_x3p_ps(const float* qkv, void* kv_scratch, float* 
     hipLaunchKernelGGL(attn_x3p_fwd_kernel<1>, dim3((tokens + 127) / 128, heads, n), dim3(256), 0, st, qkv,
                        reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale);
   return check_launch("ldmk_attn_self_x3p");
+}
+
+extern "C" long long ldmk_attn_kv_split_h2_bytes(int n, int tokens, int heads) {
+  if (n <= 0 || tokens <= 0 || heads <= 0) return -1;
+  return (long long)n * heads * ((tokens + ldmk::BA_T - 1) / ldmk::BA_T) * ldmk::H2_TILE;
+}
+
+extern "C" int ldmk_attn_self_h2(const float* qkv, void* kv_scratch, float* out, int* range_flag, int n, int tokens, int heads, float scale,
+                                 void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(qkv && kv_scratch && out && range_flag && n > 0 && tokens > 0 && heads > 0 && heads <= 65535 && n <= 65535, "ldmk_attn_self_h2: bad args");
+  const int ntiles = (tokens + BA_T - 1) / BA_T;
+  LDMK_REQUIRE((long long)ntiles * H2_TILE < (1LL << 31), "ldmk_attn_self_h2: %d tokens: a head's pre-split K / V exceeds 2 GiB", tokens);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_kv_split_h2_kernel, dim3(ntiles, heads, n), dim3(256), 0, st, qkv, reinterpret_cast<unsigned char*>(kv_scratch), tokens, heads,
+                     range_flag);
+  static const int qb_env = [] { const char* e = getenv("LDMK_ATTN_QB"); return e ? atoi(e) : 0; }();
+  const int qb = qb_env == 1 || qb_env == 2 ? qb_env : (tokens >= X3P_QB2_MIN_TOKENS ? 2 : 1);
+  if (qb == 2)
+    hipLaunchKernelGGL(attn_h2_fwd_kernel<2>, dim3((tokens + 255) / 256, heads, n), dim3(256), 0, st, qkv,
+                       reinterpret_cast<const unsigned char*>(kv_scratch), out, tokens, heads, scale, range_flag);
+  else
+    hipLaunchKernelGGL(attn_h2_fwd_kernel<1>, dim3((tokens + 127) / 128, heads, n), dim3(256), 0, st, qkv,
+                       reinterpret_cast<const unsigned char*>(kv_scratch), out, tokens, heads, scale, range_flag);
+  return check_launch("ldmk_attn_self_h2");
 }
 
 extern "C" int ldmk_attn_self_lse_bf16(const float* qkv, float* out, float* lse, int n, int tokens, int heads, float scale,

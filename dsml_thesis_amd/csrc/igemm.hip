@@ -41,6 +41,20 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {          // round
   return bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
 }
 
+// LDMK_COMPUTE_F16X2: x' = 2^6 x = hi + lo, hi = fp16(x'), lo = fp16(x' - hi) (round-to-nearest-even; x' - hi exact in fp32)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float H2_A_SCALE = 64.f;            // 2^LDMK_F16X2_A_EXP
+__device__ __forceinline__ void split2h(const float4& v, f16x4& h, f16x4& l) {     // v already scaled
+  h = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  l = f16x4{(_Float16)(v.x - (float)h[0]), (_Float16)(v.y - (float)h[1]), (_Float16)(v.z - (float)h[2]), (_Float16)(v.w - (float)h[3])};
+}
+__device__ __forceinline__ bool h2_out_of_range(const float4& v) {                 // |x| >= LDMK_F16X2_RANGE, inf or NaN
+  constexpr unsigned LIM = 0x447a0000u;       // 1000.0f
+  return (__float_as_uint(v.x) & 0x7fffffffu) >= LIM || (__float_as_uint(v.y) & 0x7fffffffu) >= LIM ||
+         (__float_as_uint(v.z) & 0x7fffffffu) >= LIM || (__float_as_uint(v.w) & 0x7fffffffu) >= LIM;
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void ig_static_for(F&& f) {
   if constexpr (I < N) {
@@ -81,7 +95,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   // (ldmk_pack_wbf16t, once per optimiser step): the training step's forward GEMMs.  BF = 1 reads fp32 W as it lies and gathers
   // every B fragment with eight ds_read_b32 + conversions; here a fragment is one ds_read_b128.
   constexpr bool X3 = BF >= 2;               // (named for the split form; "pre-packed bf16 weight images" is what it selects)
-  constexpr int NI = BF == 3 ? 3 : 1;        // bf16 images per operand
+  // BF = 4: LDMK_COMPUTE_F16X2 -- the structure of BF = 3 with TWO fp16 images per operand (A scaled by 2^6 and split while
+  // staged, range-checked; W pre-split by ldmk_pack_wsplit_h2) and THREE matrix instructions per product.
+  constexpr bool H2 = BF == 4;
+  constexpr int NI = BF == 3 ? 3 : (H2 ? 2 : 1);        // 16-bit images per operand
   static_assert(!ASP || BF == 3, "a pre-split A operand belongs to the bf16x3 form");
   constexpr int ASI = ASP ? (3 * BM * 4 + 255) / 256 : 1;    // ASP: 16-byte items of the three A images per thread and 32-k slice
   constexpr int BSI = X3 ? (NI * BN * 4 + 255) / 256 : 1;     // X3: 16-byte items of the three B images per thread and 32-k slice
@@ -375,6 +392,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
 #ifdef LDMK_IG_STAMPS
   unsigned long long ig_acc[6] = {0, 0, 0, 0, 0, 0}, ig_last = 0;
 #endif
+  bool h2_bad = false;          // H2: a staged A element outside the scaled fp16 range
   // A-side prologue (norm) on the loaded registers, then registers -> LDS
   auto store_slices = [&](int it, int boff) {
 #pragma unroll
@@ -445,6 +463,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
             *reinterpret_cast<bf16x4*>(d) = h;
             *reinterpret_cast<bf16x4*>(d + AIMG) = m;
             *reinterpret_cast<bf16x4*>(d + 2 * AIMG) = l;
+          } else if constexpr (H2) {
+            h2_bad |= h2_out_of_range(areg[j][i]);
+            const float4 v = areg[j][i];
+            f16x4 h, l;
+            split2h(make_float4(v.x * H2_A_SCALE, v.y * H2_A_SCALE, v.z * H2_A_SCALE, v.w * H2_A_SCALE), h, l);
+            *reinterpret_cast<f16x4*>(d) = h;
+            *reinterpret_cast<f16x4*>(d + AIMG) = l;
           } else {
             *reinterpret_cast<bf16x4*>(d) = to_bf16x4(areg[j][i]);
           }
@@ -505,7 +530,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
       // instructions of step t (sched_group_barrier): the first version read b8, waited (lgkmcnt(0)) and multiplied, a dozen
       // exposed LDS round trips per 16 k -- 2734 cycles in the MFMA block for 1920 of matrix work (s_memtime stamps).
       constexpr int NSTEP = (KC / 16) * TN;          // one step = one B column tile of one 16-deep k group: 6 TM (1 TM) matrix instructions
-      constexpr int NMM = NI == 3 ? 6 : 1;
+      constexpr int NMM = NI == 3 ? 6 : (NI == 2 ? 3 : 1);
       bf16x8 a8[2][NI][TM], b8[2][NI];
       auto fa = [&](int s, int q) {
 #pragma unroll
@@ -530,6 +555,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
         if constexpr (newk) fa((t + 1) / TN, ((t + 1) / TN) & 1);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+          if constexpr (H2) {
+            // lo hi, hi lo, hi hi (images: 0 = hi, 1 = lo)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a8[s & 1][1][i]), __builtin_bit_cast(f16x8, b8[t & 1][0]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a8[s & 1][0][i]), __builtin_bit_cast(f16x8, b8[t & 1][1]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a8[s & 1][0][i]), __builtin_bit_cast(f16x8, b8[t & 1][0]), acc[i][j], 0, 0, 0);
+            continue;
+          }
           if constexpr (NI == 3) {
             // smallest partial products first (images: 0 = hi, 1 = mid, 2 = lo)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s & 1][2][i], b8[t & 1][0], acc[i][j], 0, 0, 0);
@@ -691,6 +723,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
             for (int r = 0; r < 16; ++r) acc[i][j][r] += s[((i * TN + j) * 16 + r) * 64];
       }
     }
+  }
+  if constexpr (H2) {
+    if (h2_bad) *p.range_flag = 1;
   }
   // ---- epilogue.  C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int rowbase = m0 + wm * (32 * TM);
@@ -1004,6 +1039,29 @@ __global__ __launch_bounds__(256) void pack_wsplit_kernel(const float* __restric
   }
 }
 
+// W[K][ldb] fp32 -> the two fp16 images [2][N][ld_out] of 2^scale_exp W, K-contiguous (LDMK_COMPUTE_F16X2)
+__global__ __launch_bounds__(256) void pack_wsplit_h2_kernel(const float* __restrict__ w, int K, int N, int ldb, long long w_bstride, float scale,
+                                                             _Float16* __restrict__ out, int ld_out) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const float* wb = w + (long long)blockIdx.z * w_bstride;
+  _Float16* ob = out + (long long)blockIdx.z * 2 * N * ld_out;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = (threadIdx.x >> 5) + 8 * r, n = threadIdx.x & 31;
+    tile[k][n] = (k0 + k < K && n0 + n < N) ? wb[(long long)(k0 + k) * ldb + n0 + n] * scale : 0.f;
+  }
+  __syncthreads();
+  const int n = threadIdx.x >> 3, kq = (threadIdx.x & 7) * 4;
+  if (n0 + n < N && k0 + kq < ld_out) {
+    f16x4 h, l;
+    split2h(make_float4(tile[kq][n], tile[kq + 1][n], tile[kq + 2][n], tile[kq + 3][n]), h, l);
+    _Float16* d = ob + (long long)(n0 + n) * ld_out + k0 + kq;
+    *reinterpret_cast<f16x4*>(d) = h;
+    *reinterpret_cast<f16x4*>(d + (long long)N * ld_out) = l;
+  }
+}
+
 struct TileCfg { int bm, bn, ns; bool even_tn; float eff; };
 // eff: measured sustained fraction of the f32 MFMA peak on long-K problems (profiles/r01_layers*_v2.txt, refined with
 // the tools/autotune.py sweeps: the 128x128 tile reaches 0.76 on the VQGAN decoder convolutions).  Shapes the
@@ -1023,6 +1081,7 @@ static size_t cfg_lds_bytes() {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KC = 32 * WK * KS;
   constexpr int ASTR = BM + 1, BSTR = BN + (BT ? 1 : 0);
   if (BF == 3) return (size_t)3 * (BM + BN) * (KC + 8) * 2;
+  if (BF == 4) return (size_t)2 * (BM + BN) * (KC + 8) * 2;
   if (BF == 2) return (size_t)(BM + BN) * (KC + 8) * 2;
   if (BF) return BT ? (size_t)(BM + BN) * (KC + 8) * 2 : (size_t)BM * (KC + 8) * 2 + (size_t)KC * BN * 4;
   size_t stage = (size_t)KC * (ASTR + BSTR) * sizeof(float) * (DB ? 2 : 1);
@@ -1162,6 +1221,20 @@ static int dispatch_x3(const ldmk_igemm_args& a, int cfg, int splitk, float* ws,
   }
 }
 
+// fp32-accurate two-way fp16 split (args.compute = LDMK_COMPUTE_F16X2): the same tile shapes, three matrix instructions per product
+static int dispatch_h2(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hipStream_t st) {
+  const bool geglu = a.epi == LDMK_EPI_GEGLU;
+  if (cfg == 3) cfg = 4;
+  if (cfg == 6) cfg = geglu ? 2 : 5;
+  if (geglu && !kCfg[cfg - 1].even_tn) cfg = 1;
+  switch (cfg) {
+    case 1: return launch_cfg_g<2, 2, 2, 2, 1, 1, false, false, 4, true>(a, splitk, ws, st);
+    case 2: return launch_cfg_g<1, 2, 2, 2, 1, 2, false, false, 4, true>(a, splitk, ws, st);
+    case 4: return launch_cfg_g<1, 1, 2, 2, 1, 2, false, false, 4, true>(a, splitk, ws, st);
+    default: return launch_cfg_g<1, 5, 4, 1, 1, 1, false, false, 4, true>(a, splitk, ws, st);
+  }
+}
+
 // bf16 compute with the weights pre-packed (args.w_split = one bf16 image, ldmk_pack_wbf16t): the training step's forward GEMMs
 static int dispatch_bf16_packed(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hipStream_t st) {
   const bool geglu = a.epi == LDMK_EPI_GEGLU;
@@ -1181,6 +1254,7 @@ static int dispatch(const ldmk_igemm_args& a, int cfg, int splitk, float* ws, hi
   if (a.compute == LDMK_COMPUTE_BF16 && a.w_split && !BT && igemm_fast_gather_ok(a)) return dispatch_bf16_packed(a, cfg, splitk, ws, st);
   if (a.compute == LDMK_COMPUTE_BF16) return dispatch_bf16<BT>(a, cfg, splitk, ws, st);
   if (a.compute == LDMK_COMPUTE_BF16X3) return dispatch_x3(a, cfg, splitk, ws, st);
+  if (a.compute == LDMK_COMPUTE_F16X2) return dispatch_h2(a, cfg, splitk, ws, st);
   if (a.epi == LDMK_EPI_GEGLU && !kCfg[cfg - 1].even_tn) cfg = 3;   // GEGLU needs (value, gate) tile pairs
   switch (cfg) {
     case 1: return launch_cfg<2, 2, 2, 2, 1, 1, false, BT>(a, splitk, ws, st);   // 128x128
@@ -1235,6 +1309,17 @@ extern "C" int ldmk_pack_wsplit(const float* w, int K, int N, int ldb, int batch
   hipLaunchKernelGGL(ldmk::pack_wsplit_kernel<3>, dim3((ld_out + 31) / 32, (N + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, w, K,
                      N, ldb, w_bstride, reinterpret_cast<__bf16*>(out), ld_out);
   return ldmk::check_launch("ldmk_pack_wsplit");
+}
+
+extern "C" int ldmk_pack_wsplit_h2(const float* w, int K, int N, int ldb, int batch, long long w_bstride, int scale_exp, void* out, int ld_out,
+                                   void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(w && out && K > 0 && N > 0 && ldb >= N && batch >= 1, "ldmk_pack_wsplit_h2: bad args");
+  LDMK_REQUIRE(ld_out >= K && ld_out % 8 == 0, "ldmk_pack_wsplit_h2: ld_out=%d must be >= K=%d and a multiple of 8", ld_out, K);
+  LDMK_REQUIRE(scale_exp >= -60 && scale_exp <= 60, "ldmk_pack_wsplit_h2: scale_exp=%d outside [-60, 60]", scale_exp);
+  hipLaunchKernelGGL(ldmk::pack_wsplit_h2_kernel, dim3((ld_out + 31) / 32, (N + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, w, K, N, ldb,
+                     w_bstride, ldexpf(1.f, scale_exp), reinterpret_cast<_Float16*>(out), ld_out);
+  return ldmk::check_launch("ldmk_pack_wsplit_h2");
 }
 
 extern "C" int ldmk_pack_wbf16t(const float* w, int K, int N, int ldb, void* out, int ld_out, void* stream) {
@@ -1324,7 +1409,8 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   LDMK_REQUIRE(a.tile_cfg >= 0 && a.tile_cfg <= kNumCfg + kNumRCfg + kNumSCfg + kNumWCfg + kNumPCfg, "ldmk_igemm: tile_cfg=%d outside [0,%d]",
                a.tile_cfg, kNumCfg + kNumRCfg + kNumSCfg + kNumWCfg + kNumPCfg);
   LDMK_REQUIRE(a.splitk >= 0 && a.splitk <= 64, "ldmk_igemm: splitk=%d outside [0,64]", a.splitk);
-  LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.compute == LDMK_COMPUTE_BF16 || a.compute == LDMK_COMPUTE_BF16X3, "ldmk_igemm: compute=%d", a.compute);
+  LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.compute == LDMK_COMPUTE_BF16 || a.compute == LDMK_COMPUTE_BF16X3 || a.compute == LDMK_COMPUTE_F16X2,
+               "ldmk_igemm: compute=%d", a.compute);
   const bool ps_tile = a.tile_cfg > kNumCfg + kNumRCfg + kNumSCfg + kNumWCfg;
   if (a.compute == LDMK_COMPUTE_BF16X3 && !ps_tile) {
     LDMK_REQUIRE(a.w_split && !a.b_trans && a.w_split_ld >= a.K && a.w_split_ld % 8 == 0,
@@ -1332,6 +1418,15 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
     LDMK_REQUIRE(3LL * a.N * a.w_split_ld * 2 < (1LL << 32), "ldmk_igemm: w_split exceeds 4 GB per batch entry");
     LDMK_REQUIRE(igemm_fast_gather_ok(a), "ldmk_igemm: LDMK_COMPUTE_BF16X3 needs the fast gather (no zero-insertion, two-source "
                  "upsampling or operands beyond 4 GB)");
+  }
+  if (a.compute == LDMK_COMPUTE_F16X2) {
+    LDMK_REQUIRE(a.tile_cfg <= kNumCfg, "ldmk_igemm: LDMK_COMPUTE_F16X2 runs on the LDS-tiled shapes (tile_cfg 0..6), not tile_cfg=%d", a.tile_cfg);
+    LDMK_REQUIRE(a.w_split && !a.b_trans && a.w_split_ld >= a.K && a.w_split_ld % 8 == 0 && 2LL * a.N * a.w_split_ld * 2 < (1LL << 32),
+                 "ldmk_igemm: LDMK_COMPUTE_F16X2 needs w_split (ldmk_pack_wsplit_h2), b_trans = 0, w_split_ld >= K and a multiple of 8, below 4 GB");
+    LDMK_REQUIRE(a.range_flag != nullptr, "ldmk_igemm: LDMK_COMPUTE_F16X2 needs range_flag");
+    LDMK_REQUIRE(!a.a_split && a.w_scale_exp >= -60 && a.w_scale_exp <= 60, "ldmk_igemm: LDMK_COMPUTE_F16X2: a_split is not taken; w_scale_exp=%d", a.w_scale_exp);
+    LDMK_REQUIRE(igemm_fast_gather_ok(a), "ldmk_igemm: LDMK_COMPUTE_F16X2 needs the fast gather (no zero-insertion, two-source upsampling or "
+                 "operands beyond 4 GB)");
   }
   if (a.compute == LDMK_COMPUTE_BF16 && a.w_split)
     LDMK_REQUIRE(!a.b_trans && a.w_split_ld >= a.K && a.w_split_ld % 8 == 0 && (long long)a.N * a.w_split_ld * 2 < (1LL << 32) && a.batch <= 1,
@@ -1348,6 +1443,7 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
   LDMK_REQUIRE(a.compute == LDMK_COMPUTE_F32 || a.tile_cfg <= kNumCfg || a.tile_cfg > kNumCfg + kNumRCfg + kNumSCfg,
                "ldmk_igemm: the row / slab GEMM tiles are fp32 only");
   if (a.alpha == 0.f) a.alpha = 1.f;
+  if (a.compute == LDMK_COMPUTE_F16X2) a.alpha *= ldexpf(1.f, -(LDMK_F16X2_A_EXP + a.w_scale_exp));     // the operands' scales leave in the epilogue (exact)
   int cfg = 0, sk = 1;
   plan(a, &cfg, &sk, a.splitk_ws ? a.splitk_ws_elems : 0);
   if (a.tile_cfg > 0) cfg = a.tile_cfg;

@@ -62,6 +62,12 @@ def split_enabled():
     return os.environ.get("LDMK_SPLIT_BF16", "1") != "0"
 
 
+def f16x2_enabled():
+    """The F16X2 arithmetic (include/ldmk.h: fp32-accurate products from three fp16 matrix instructions per term, operands scaled
+    into fp16's range, a device flag raised when one leaves it) where a kernel offers it; LDMK_F16X2=0 keeps the bf16x3 forms."""
+    return split_enabled() and os.environ.get("LDMK_F16X2", "1") != "0"
+
+
 def x3_table():
     """{shape key: [(M, cfg, splitk)]}: shapes that tools/autotune.py --x3 measured FASTER in the bf16x3 arithmetic than their
     best f32 plan (dsml_thesis_amd/igemm_plans_x3.json; LDMK_X3_TABLE overrides the path)."""
@@ -235,7 +241,14 @@ class Program:
                 args.M, args.batch = m, nbatch
                 if int(xp[0]) > 6:
                     args.a_split, args.a_split_ld = 0, 0          # the warp-specialised tiles split A themselves
-                ok = _ops.set_split(args)
+                # the F16X2 arithmetic (three fp16 products per term, include/ldmk.h) while the owner's range flag is down:
+                # same shapes, the LDS-tiled form of the tile (the warp-specialised 256-row tiles map to 128x160 / 128x128)
+                h2_flag = getattr(self, "h2_flag", None)
+                ok = h2_flag is not None and not args.a_split and _ops.set_split_h2(args, h2_flag)
+                if ok:
+                    xp = ({21: 5, 22: 1}.get(int(xp[0]), int(xp[0])), xp[1])
+                else:
+                    ok = _ops.set_split(args)
                 if ok:
                     args.tile_cfg, args.splitk = int(xp[0]), int(xp[1])
                     args.splitk_ws, args.splitk_ws_elems = 1, 1 << 40
@@ -249,6 +262,7 @@ class Program:
                         args.a_split, args.a_split_ld = 0, 0      # the warp-specialised tiles split A themselves
                     return args.tile_cfg, args.splitk
                 args.compute, args.w_split, args.w_split_ld, args.w_split_bstride = L.COMPUTE_F32, 0, 0, 0
+                args.w_scale_exp, args.range_flag = 0, 0
         # (a batch that is not per sample -- the 16 transform positions of a Winograd convolution -- is part of the plan key)
         tuned = tuned_plan(args, args.M) if (nbatch <= 1 or not batch_is_samples) and args.M > 0 else None
         if tuned is not None and tuned[0] > 6:
@@ -560,6 +574,10 @@ class NetBuilder:
         plan-policy row count like every plan -- or None.  Asked BEFORE the producer of the A operand is emitted: with a plan the
         producer writes the operand in the PS layout."""
         if not ps_enabled():
+            return None
+        # (with the F16X2 arithmetic on, the LDS-tiled kernels in it replace the bf16x3 pre-split tiles: three matrix instructions
+        #  per product instead of six; LDMK_PS_WITH_F16X2=1 keeps the pre-split plans for the A/B)
+        if getattr(self.pg, "h2_flag", None) is not None and os.environ.get("LDMK_PS_WITH_F16X2", "0") != "1":
             return None
         m = M
         if self.pin is not None and self.pin[0] != self.pin[1] and per_sample:

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("LDMK_LIBRARY") or os.path.join(_HERE, "libldmk.so")
 A_ROWS, A_CONV3X3 = 0, 1
 TF_NONE, TF_AFFINE, TF_AFFINE_SILU, TF_LAYERNORM, TF_LAYERNORM_FOLDED = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GEGLU = 0, 1
-COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3, COMPUTE_F16X2 = 0, 1, 2, 3
 POST_NONE, POST_GROUPNORM, POST_LAYERNORM = 0, 1, 2
 
 _fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
@@ -38,6 +38,7 @@ class IgemmArgs(C.Structure):
         ("w_split", _fp), ("w_split_ld", C.c_int), ("w_split_bstride", C.c_longlong),
         ("a_split", _fp), ("a_split_ld", C.c_int),
         ("a_ps", _fp), ("a_ps_bstride", C.c_longlong), ("w_ps", _fp), ("w_ps_bstride", C.c_longlong), ("out_ps", _fp),
+        ("w_scale_exp", C.c_int), ("range_flag", _fp),
     ]
 
 
@@ -75,6 +76,7 @@ _SIGS = {
     "ldmk_wfrag_elems": (C.c_longlong, [C.c_int, C.c_int]),
     "ldmk_pack_wfrag": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ldmk_pack_wsplit": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, _fp, C.c_int, _fp]),
+    "ldmk_pack_wsplit_h2": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, _fp, C.c_int, _fp]),
     "ldmk_pack_wbf16t": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp]),
     "ldmk_winograd_tiles": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "ldmk_winograd_input": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
@@ -103,6 +105,8 @@ _SIGS = {
     "ldmk_attn_kv_split_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "ldmk_attn_self_x3p": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_self_x3p_ps": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    "ldmk_attn_kv_split_h2_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "ldmk_attn_self_h2": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_self_small": (C.c_int, [_fp, C.c_int, C.c_longlong, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_cross": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_float, _fp]),

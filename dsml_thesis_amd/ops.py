@@ -209,7 +209,8 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
                     tf_coef=None, row_stats=None, ln_gamma=None, ln_beta=None, b_trans=False, ldb=None, bias=None,
                     batch_vec=None, batch_vec_ld=0, residual=None, epi=L.EPI_NONE, batch=1, a_bstride=0, w_bstride=0,
                     out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None, w_frag=None, tile_cfg=0, compute=0, ln_colsum=None,
-                    splitk_counters=None, raw_slabs=False, a_split=None, w_bf16t=None, a_ps=None, w_ps=None, out_ps=None):
+                    splitk_counters=None, raw_slabs=False, a_split=None, w_bf16t=None, a_ps=None, w_ps=None, out_ps=None,
+                    range_flag=None):
     a = L.IgemmArgs()
     # the struct holds raw device pointers: keep every operand alive as long as the args object lives (a temporary passed
     # inline -- bias=b.cuda() -- would otherwise be freed, and its block possibly re-used, before the launch is enqueued)
@@ -252,6 +253,8 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
         return a
     if compute == L.COMPUTE_BF16X3 and not set_split(a):
         raise ValueError("COMPUTE_BF16X3: no split images registered for this weight (ops.pack_wsplit) or b_trans set")
+    if compute == L.COMPUTE_F16X2 and not set_split_h2(a, range_flag):
+        raise ValueError("COMPUTE_F16X2: no fp16 images registered for this weight (ops.pack_wsplit_h2), b_trans set, or no range_flag")
     return a
 
 
@@ -314,6 +317,61 @@ def split_of(w_ptr):
     return hit
 
 
+# ---- LDMK_COMPUTE_F16X2: the weights as two fp16 images of 2^e w (include/ldmk.h) ---------------------------------------------
+_SPLIT_H2 = {}       # data_ptr of a packed fp32 weight -> (f16 tensor, ld, batch stride in elements, weakref, version, scale exponent)
+
+
+def pack_wsplit_h2(w, batch=1):
+    """w: [K][N] fp32 (or [batch][K][N]) on the GPU -> fp16 [batch][2][N][ld] (ldmk_pack_wsplit_h2): the images hi, lo of 2^e w
+    with e chosen so that max |2^e w| lies in [2^13, 2^14) (one host read of max |w| at pack time); registered under w's address."""
+    if batch > 1:
+        assert w.dim() == 3 and w.shape[0] == batch and w.is_contiguous()
+        K, N = w.shape[1], w.shape[2]
+    else:
+        assert w.dim() == 2 and w.is_contiguous()
+        K, N = w.shape
+    mx = float(w.abs().max().item())
+    import math
+    e = 13 - math.floor(math.log2(mx)) if mx > 0.0 and math.isfinite(mx) else 0
+    e = max(-60, min(60, e))
+    ld = (K + 7) // 8 * 8
+    out = torch.empty(batch, 2, N, ld, device=w.device, dtype=torch.float16)
+    L.call("ldmk_pack_wsplit_h2", _ptr(w), K, N, N, batch, K * N, e, _ptr(out), ld, stream())
+    ptr = w.data_ptr()
+    _SPLIT_H2[ptr] = (out, ld, 2 * N * ld, weakref.ref(w), w._version, e)
+    weakref.finalize(w, _drop_split_h2, ptr, out.data_ptr())
+    return out
+
+
+def _drop_split_h2(ptr, img_ptr):
+    hit = _SPLIT_H2.get(ptr)
+    if hit is not None and hit[0].data_ptr() == img_ptr:
+        del _SPLIT_H2[ptr]
+
+
+def split_h2_of(w_ptr):
+    hit = _SPLIT_H2.get(w_ptr)
+    if hit is None:
+        return None
+    src = hit[3]()
+    if src is None or src.data_ptr() != w_ptr or src._version != hit[4]:
+        del _SPLIT_H2[w_ptr]
+        return None
+    return hit
+
+
+def set_split_h2(a, range_flag, w_ptr=None):
+    """Switch igemm args to the F16X2 arithmetic when the weight's fp16 images exist; returns True if it did."""
+    hit = split_h2_of(a.w if w_ptr is None else w_ptr)
+    if hit is None or a.b_trans or range_flag is None:
+        return False
+    a.w_split, a.w_split_ld, a.w_split_bstride = hit[0].data_ptr(), hit[1], hit[2]
+    a.w_scale_exp, a.range_flag = hit[5], range_flag.data_ptr()
+    a.compute = L.COMPUTE_F16X2
+    a._keep = getattr(a, "_keep", ()) + (range_flag,)
+    return True
+
+
 def set_split(a, w_ptr=None):
     """Switch igemm args to the fp32-accurate bf16x3 arithmetic when the weight's split images exist; returns True if it did."""
     hit = split_of(a.w if w_ptr is None else w_ptr)
@@ -325,7 +383,7 @@ def set_split(a, w_ptr=None):
 
 
 def conv3x3(x, wp, bias=None, x1=None, stride=1, pad_lo=1, upsample=False, coef=None, silu=True, batch_vec=None,
-            residual=None, out=None, out_hw=None, compute=0):
+            residual=None, out=None, out_hw=None, compute=0, range_flag=None):
     """x: (n,h,w,c0) [+ x1 (n,h,w,c1) channel-concat]; wp: [9*(c0+c1)][cout] -> (n,oh,ow,cout)."""
     n, h, w_, c0 = x.shape
     c1 = 0 if x1 is None else x1.shape[-1]
@@ -344,14 +402,14 @@ def conv3x3(x, wp, bias=None, x1=None, stride=1, pad_lo=1, upsample=False, coef=
     a = make_igemm_args(n * oh * ow, cout, 9 * (c0 + c1), x, c0, wp, out, cout, oh * ow, a1=x1, c1=c1,
                         conv=(h, w_, oh, ow, stride, pad_lo, 1 if upsample else 0), tf=tf, tf_coef=coef, bias=bias,
                         batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0),
-                        residual=residual, compute=compute)
+                        residual=residual, compute=compute, range_flag=range_flag)
     igemm(a)
     return out
 
 
 def linear(x2d, wp, bias=None, x1=None, rows_per_sample=None, coef=None, silu=False, row_stats=None, ln_gamma=None,
            ln_beta=None, batch_vec=None, residual=None, geglu=False, out=None, b_trans=False, w_frag=None, tile_cfg=0,
-           stats_out=None, compute=0, ln_colsum=None, a_split=None):
+           stats_out=None, compute=0, ln_colsum=None, a_split=None, range_flag=None):
     """x2d: [M][c0] (+ x1 [M][c1]); wp: [K][N] (or torch [N][K] with b_trans) -> [M][N] (N/2 for geglu)."""
     M, c0 = x2d.shape
     c1 = 0 if x1 is None else x1.shape[-1]
@@ -369,7 +427,7 @@ def linear(x2d, wp, bias=None, x1=None, rows_per_sample=None, coef=None, silu=Fa
                         row_stats=row_stats, ln_gamma=ln_gamma, ln_beta=ln_beta, b_trans=b_trans, bias=bias,
                         batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0),
                         residual=residual, epi=L.EPI_GEGLU if geglu else L.EPI_NONE, w_frag=w_frag, tile_cfg=tile_cfg,
-                        compute=compute, ln_colsum=ln_colsum, a_split=a_split)
+                        compute=compute, ln_colsum=ln_colsum, a_split=a_split, range_flag=range_flag)
     if stats_out is not None:
         a.stats_out = _ptr(stats_out)
     igemm(a)
@@ -475,12 +533,18 @@ def bmm(a, b, b_trans, alpha=1.0, out=None):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def attn_self(qkv, n, tokens, heads, out=None, x3=False, presplit=False):
+def attn_self(qkv, n, tokens, heads, out=None, x3=False, presplit=False, h2_flag=None):
     """x3: both products in the fp32-accurate three-way bf16 split arithmetic (ldmk_attn_self_x3); presplit: its form with K / V
-    split once by a pre-pass and moved to LDS by LDS-DMA (ldmk_attn_self_x3p: bitwise the same result)."""
+    split once by a pre-pass and moved to LDS by LDS-DMA (ldmk_attn_self_x3p: bitwise the same result); h2_flag (device int32
+    tensor): the two-way fp16 split with three products per term (ldmk_attn_self_h2), the flag raised when an operand leaves
+    its range."""
     C_ = heads * 32
     if out is None:
         out = torch.empty(n * tokens, C_, device=qkv.device, dtype=torch.float32)
+    if h2_flag is not None:
+        kv = torch.empty(L.load().ldmk_attn_kv_split_h2_bytes(n, tokens, heads), device=qkv.device, dtype=torch.uint8)
+        L.call("ldmk_attn_self_h2", _ptr(qkv), _ptr(kv), _ptr(out), _ptr(h2_flag), n, tokens, heads, 32 ** -0.5, stream())
+        return out
     if presplit:
         kv = torch.empty(L.load().ldmk_attn_kv_split_bytes(n, tokens, heads), device=qkv.device, dtype=torch.uint8)
         L.call("ldmk_attn_self_x3p", _ptr(qkv), _ptr(kv), _ptr(out), n, tokens, heads, 32 ** -0.5, stream())

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
-from .engine import NetBuilder, Program, split_enabled as engine_split_enabled, ps_enabled as engine_ps_enabled
+from .engine import NetBuilder, Program, split_enabled as engine_split_enabled, ps_enabled as engine_ps_enabled, f16x2_enabled
 
 # LayerNorm is folded algebraically through the Linear behind it (LDMK_TF_LAYERNORM_FOLDED): exact for well-conditioned rows,
 # but it subtracts mean * colsum(W') from x W' in fp32, so rows whose |mean| is many standard deviations lose accuracy
@@ -32,6 +32,9 @@ LN_GUARD_RATIO = float(os.environ.get("LDMK_LN_GUARD_RATIO", "4.0"))
 # (profiles/r04_layers64.txt, kernel + pre-pass against ldmk_attn_self_x3): 4096 tokens 1062 -> 994 us per call, 1024 tokens
 # 145 -> 152, 256 tokens 28 -> 38: it pays from a few thousand tokens per sample.
 ATTN_PRESPLIT_MIN_TOKENS = int(os.environ.get("LDMK_ATTN_PRESPLIT_MIN_TOKENS", "2048"))
+# the F16X2 attention (ldmk_attn_self_h2; it always runs the K / V pre-pass).  Kernel + pre-pass against ldmk_attn_self_x3, B = 16
+# (profiles/r04_ab_attn.txt): 4096 tokens 1127 -> 695 us, 1024 tokens 183 -> 122, 256 tokens 38.9 -> 39.4
+ATTN_H2_MIN_TOKENS = int(os.environ.get("LDMK_ATTN_H2_MIN_TOKENS", "512"))
 
 
 def ln_unfolded_default():
@@ -144,12 +147,19 @@ def attention_presplit(hw):
 
 def emit_self_attention(nb_, qkv, att, hw, heads, d_head, att_ps=None):
     """softmax(q k^T / sqrt d) v over token rows [q | k | v] (n hw x 3 C) -> att (n hw x C).  With the split arithmetic on: both
-    products fp32-accurate on the bf16 matrix cores; from ATTN_PRESPLIT_MIN_TOKENS tokens per sample K / V are split once by a
-    pre-pass instead of once per 128-query workgroup and moved to LDS by LDS-DMA (ldmk_attn_self_x3p: bitwise the same result;
-    LDMK_ATTN_PRESPLIT=0 turns it off).  LDMK_SPLIT_BF16=0: the f32 matrix-core kernel."""
+    products fp32-accurate on the 16-bit matrix cores.  From ATTN_H2_MIN_TOKENS tokens per sample, while the model's range flag
+    is down (nb_.h2_flag): the F16X2 form -- three fp16 products per term, K / V split once by a pre-pass and moved to LDS by
+    LDS-DMA (ldmk_attn_self_h2; 1.47x the bf16x3 kernel at 4096 tokens).  Otherwise bf16x3: from ATTN_PRESPLIT_MIN_TOKENS tokens
+    with the K / V pre-pass (ldmk_attn_self_x3p, bitwise ldmk_attn_self_x3; LDMK_ATTN_PRESPLIT=0 turns it off).
+    LDMK_SPLIT_BF16=0: the f32 matrix-core kernel."""
     pg, n = nb_.pg, nb_.n
     scale = d_head ** -0.5
-    if attention_presplit(hw):
+    h2_flag = getattr(nb_, "h2_flag", None)
+    if h2_flag is not None and att_ps is None and hw >= ATTN_H2_MIN_TOKENS:
+        kvs = pg.alloc(pg.lib.ldmk_attn_kv_split_h2_bytes(n, hw, heads), dtype=torch.uint8)
+        pg.add("ldmk_attn_self_h2", qkv.data_ptr(), kvs.data_ptr(), att.data_ptr(), h2_flag.data_ptr(), n, hw, heads, scale)
+        nb_.release(kvs)
+    elif attention_presplit(hw):
         kvs = pg.alloc(pg.lib.ldmk_attn_kv_split_bytes(n, hw, heads), dtype=torch.uint8)
         if att_ps is not None:       # the result in the PS layout (only): the A operand of attn1.to_out on a pre-split tile
             pg.add("ldmk_attn_self_x3p_ps", qkv.data_ptr(), kvs.data_ptr(), 0 if att is None else att.data_ptr(), att_ps.data_ptr(), n, hw,
@@ -213,8 +223,12 @@ def pack_gemm_copies(P, unfolded=False):
             if tail in ("pin", "pout", "qkv_ln", "o1", "ff1_ln", "ff2", "skip", "c1", "c2", "w", "aqkv", "apout") or (unfolded and tail in ("qkv", "ff1")):
                 if P[k].dim() == 2:
                     P[k + "#s"] = ops.pack_wsplit(P[k])
+                    if f16x2_enabled():          # ... and the two fp16 images of the F16X2 arithmetic
+                        P[k + "#h"] = ops.pack_wsplit_h2(P[k])
             elif tail in ("c1#wg", "c2#wg", "w#up"):
                 P[k + "#s"] = ops.pack_wsplit(P[k], batch=P[k].shape[0])
+                if f16x2_enabled():
+                    P[k + "#h"] = ops.pack_wsplit_h2(P[k], batch=P[k].shape[0])
     # PS-layout copies (csrc/igemm_ps.hip: both operands pre-split, moved to LDS by LDS-DMA) for the GEMMs whose A operand a
     # producer can write in that layout: LayerNorm-folded projections (the statistics pass writes it), ff.net.2 (the GEGLU epilogue)
     if engine_ps_enabled():
@@ -491,6 +505,8 @@ class UNetModel(nn.Module):
         # LayerNorm folded through the product unless the guard (LN_GUARD_RATIO) has found mean-dominated rows in this model
         self.ln_unfolded = ln_unfolded_default()
         self._ln_flag = None
+        self.f16x2 = f16x2_enabled()        # the F16X2 arithmetic where a kernel offers it, until its range flag goes up
+        self._h2_flag = None
         # tile shapes are chosen from the problem size; set policy_batch = G to choose them as if the batch
         # were G, which makes per-sample results bitwise identical however a G-sample job is sharded
         self.policy_batch = None
@@ -576,6 +592,7 @@ class UNetModel(nn.Module):
         P["freqs"] = ops.timestep_freqs(self.model_channels, device=dev)
         pack_gemm_copies(P, self.ln_unfolded)
         self._ln_flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        self._h2_flag = torch.zeros(1, device=dev, dtype=torch.int32)
         self._sd = sd
         self._packed = P
         self._pack_sig = self._signature()
@@ -597,6 +614,7 @@ class UNetModel(nn.Module):
         P, sd = self._packed, self._sd
         dev = next(self.parameters()).device
         pg = Program(dev)
+        pg.h2_flag = self._h2_flag if self.f16x2 else None        # engine.Program.plan: the F16X2 arithmetic for the x3 table's shapes
         mc = self.model_channels
         emb_ch = 4 * mc
         cx = self.in_channels - c_concat
@@ -622,6 +640,7 @@ class UNetModel(nn.Module):
                emb_ch, self._emb_total, 1)
 
         nb_ = NetBuilder(pg, n, pin)
+        nb_.h2_flag = self._h2_flag if self.f16x2 else None
         gn, conv, lin = nb_.gn, nb_.conv, nb_.lin
 
         def res_block(prefix, m, x0, x1, h, w):
@@ -711,18 +730,28 @@ class UNetModel(nn.Module):
 
     # ---- public surface ---------------------------------------------------------------------------
     def layernorm_guard_tripped(self):
-        """Host read (one sync) of the flag the folded-LayerNorm statistics passes raise for rows with |mean| > LN_GUARD_RATIO
-        standard deviations.  If it is up, the model switches to the unfolded prologue for good (weights re-packed, programs
-        dropped) and True is returned: whatever was just computed with the folded form should be computed again."""
-        if self.ln_unfolded or self._ln_flag is None or int(self._ln_flag.item()) == 0:
-            return False
+        """Host read (one sync) of the two device flags the launch programs raise.  (1) The folded-LayerNorm statistics passes:
+        rows with |mean| > LN_GUARD_RATIO standard deviations -- the model switches to the unfolded prologue for good (weights
+        re-packed, programs dropped).  (2) The F16X2 kernels: an operand outside the scaled fp16 range (include/ldmk.h) -- the
+        model goes back to the bf16x3 arithmetic for good.  True if either was up: whatever was just computed should be computed
+        again."""
+        tripped = False
         import warnings
-        warnings.warn(f"UNetModel: token rows with |mean| > {LN_GUARD_RATIO:g} standard deviations reached a LayerNorm; the folded "
-                      "form (LayerNorm through the product) loses accuracy on them -- switching this model to the unfolded "
-                      "prologue (LDMK_LN_UNFOLDED=1 starts there)", RuntimeWarning, stacklevel=3)
-        self.ln_unfolded = True
-        self.pack_weights()
-        return True
+        if self.f16x2 and self._h2_flag is not None and int(self._h2_flag.item()) != 0:
+            warnings.warn("UNetModel: an operand left the range of the F16X2 arithmetic (|x| >= 1000 in an attention operand); "
+                          "switching this model to the bf16x3 arithmetic (LDMK_F16X2=0 starts there)", RuntimeWarning, stacklevel=3)
+            self.f16x2 = False
+            self._h2_flag.zero_()
+            self._programs.clear()
+            tripped = True
+        if not (self.ln_unfolded or self._ln_flag is None or int(self._ln_flag.item()) == 0):
+            warnings.warn(f"UNetModel: token rows with |mean| > {LN_GUARD_RATIO:g} standard deviations reached a LayerNorm; the folded "
+                          "form (LayerNorm through the product) loses accuracy on them -- switching this model to the unfolded "
+                          "prologue (LDMK_LN_UNFOLDED=1 starts there)", RuntimeWarning, stacklevel=3)
+            self.ln_unfolded = True
+            self.pack_weights()
+            tripped = True
+        return tripped
 
     def program(self, n, H, W_, L_ctx, c_concat=0):
         if self._packed is None or (self.auto_repack and self._pack_sig != self._signature()):

@@ -60,7 +60,23 @@ enum { LDMK_EPI_NONE = 0, LDMK_EPI_GEGLU = 1 };
 /* arithmetic of the product.  F32: v_mfma_f32_32x32x2_f32, bit-identical to an fp32 fmaf chain -- the sampling path and
  * every parity test.  BF16: operands rounded to bf16 (RNE) while staged, v_mfma_f32_32x32x16_bf16 with fp32 accumulation
  * and fp32 prologue / epilogue -- the mixed-precision training step (BASELINE configs[4]); HBM tensors stay fp32. */
-enum { LDMK_COMPUTE_F32 = 0, LDMK_COMPUTE_BF16 = 1, LDMK_COMPUTE_BF16X3 = 2 };
+enum { LDMK_COMPUTE_F32 = 0, LDMK_COMPUTE_BF16 = 1, LDMK_COMPUTE_BF16X3 = 2, LDMK_COMPUTE_F16X2 = 3 };
+/* F16X2 -- fp32-accurate products from THREE fp16 matrix instructions.  Measured on MI355X (tools/clock_probe.hip,
+ * profiles/r04_clock_bf16.txt): a register-only loop of v_mfma_f32_32x32x16_{bf16,f16} on real operands sustains 1.5-1.7 of the
+ * nominal 2.5 PFLOP/s -- the chip is power-limited there (2.3 PFLOP/s on all-zero operands) -- so past BF16X3 the lever is the
+ * NUMBER of matrix instructions per product.  Each operand is scaled by a power of two into fp16's range and written
+ *     x' = 2^e x = hi + lo,   hi = fp16(x'), lo = fp16(x' - hi)     (round-to-nearest-even; x' - hi is exact in fp32)
+ * 2 x 11 significand bits: |x' - hi - lo| <= 2^-23 |x'| -- one fp32 ulp, the size of an fp32 rounding error -- for |x'| >= 2^-3
+ * (below, lo is subnormal: an absolute 2^-25), where the BF16X3 split is exact.  fp16 x fp16 products are exact in fp32;
+ *     a*b ~= 2^-(ea+eb) (lo*hi + hi*lo + hi*hi)                    (dropped: lo*lo <= 2^-22 |a*b|, typically 2^-24)
+ * accumulate in one fp32 accumulator, the scales leave in the epilogue (exact).  Against float64 the result has 1.0-1.7 x the
+ * RMS error of an fp32 dot product (1.7 at K = 160, 1.1 from K = 1440; tests/test_f16x2_gpu.py bounds it at 2 x) -- the fp32
+ * accuracy class, a little behind BF16X3.  Scales: activations 2^LDMK_F16X2_A_EXP, fixed; weights 2^w_scale_exp, chosen per
+ * matrix when it is packed (ldmk_pack_wsplit_h2) so that max |w'| lies in [2^13, 2^14).  An activation with |x| >=
+ * LDMK_F16X2_RANGE (or inf / NaN) would leave fp16: the kernels then write 1 to *range_flag (a device int the caller zeroes
+ * once; never cleared here) and the caller repeats the work in BF16X3.  tile_cfg 0..6. */
+#define LDMK_F16X2_A_EXP 6
+#define LDMK_F16X2_RANGE 1000.0f
 /* BF16X3 -- fp32-accurate products on the bf16 matrix cores (the f32 MFMA of gfx950 peaks at 157 TFLOP/s, the bf16 one at
  * 2.5 PFLOP/s).  Every fp32 operand is written as the EXACT sum of three bf16 values
  *     x = hi + mid + lo,   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)      (3 x 8 significand bits = 24)
@@ -116,7 +132,7 @@ typedef struct ldmk_igemm_args {
   long long splitk_ws_elems; /* capacity of splitk_ws in floats                                           */
   float* stats_out;          /* optional [M/32][N][3] GroupNorm partial records of the *output* (after the
                                 epilogue), one per 32-row tile and column; needs M%32==0, rows_per_sample%32==0 */
-  int compute;               /* LDMK_COMPUTE_*: F32 (default), BF16 or BF16X3 matrix-core arithmetic (tile_cfg 1..6 only) */
+  int compute;               /* LDMK_COMPUTE_*: F32 (default), BF16, BF16X3 or F16X2 matrix-core arithmetic (tile_cfg 1..6 only) */
   int* splitk_counters;      /* optional: >= ceil(M/64)*ceil(N/64)*batch ints, ZEROED once by the caller.  With it a split-K
                                 GEMM is ONE launch: each tile's last-arriving workgroup sums the slabs (fixed order: bitwise
                                 reproducible) and runs the epilogue; every launch leaves the counters zeroed again, so one
@@ -157,6 +173,9 @@ typedef struct ldmk_igemm_args {
   long long w_ps_bstride;    /*   BYTES between batch entries                                                               */
   void* out_ps;              /* optional: the result [M][ldc] written in the PS layout too (the A operand of the next GEMM; every  */
                              /*   element is split once, by its producer); `out` may then be NULL.  No split-K / batch / stats_out. */
+  /* ---- LDMK_COMPUTE_F16X2 */
+  int w_scale_exp;           /* the exponent ldmk_pack_wsplit_h2 scaled the weights by (w_split = the two fp16 images of 2^e W)    */
+  int* range_flag;           /* device int: set to 1 when a staged activation leaves the scaled fp16 range (see above)              */
 } ldmk_igemm_args;
 
 /* size in bytes of the PS layout of a [rows][k] matrix (-1: k not a multiple of 16) */
@@ -173,6 +192,10 @@ int ldmk_ln_stats_ps(const float* x, int rows, int c, float eps, float* stats, v
  * bf16 images [batch][3][N][ld_out] of its exact three-way split, transposed so that every output column's K run is
  * contiguous.  ld_out >= K, a multiple of 8; columns K..ld_out-1 are zero-filled. */
 int ldmk_pack_wsplit(const float* w, int K, int N, int ldb, int batch, long long w_bstride, void* out, int ld_out, void* stream);
+/* LDMK_COMPUTE_F16X2: the two fp16 images [batch][2][N][ld_out] (hi, lo) of 2^scale_exp w, same transposed layout.  The caller
+ * picks scale_exp so that max |2^scale_exp w| lies in [2^13, 2^14) and passes it on as args.w_scale_exp. */
+int ldmk_pack_wsplit_h2(const float* w, int K, int N, int ldb, int batch, long long w_bstride, int scale_exp, void* out, int ld_out,
+                        void* stream);
 /* the first image alone: w rounded to bf16 (nearest even), transposed, K-contiguous -- [N][ld_out].  Passed as args.w_split with
  * compute = LDMK_COMPUTE_BF16 (b_trans = 0) it replaces the in-kernel conversion of the fp32 weights: the training step packs
  * its forward weights once per optimiser step and every GEMM reads B fragments as single 16-byte LDS vectors. */
@@ -344,6 +367,18 @@ int ldmk_attn_self_x3p(const float* qkv, void* kv_scratch, float* out, int n, in
  * ldmk_ps_bytes(n tokens, heads 32) bytes): the pre-split A operand of attn1.to_out on tile_cfg 23+.  tokens % 32 == 0. */
 int ldmk_attn_self_x3p_ps(const float* qkv, void* kv_scratch, float* out, void* out_ps, int n, int tokens, int heads, float scale,
                           void* stream);
+/* ldmk_attn_self_h2: the same product, fp32-accurate from THREE fp16 products per term (the F16X2 arithmetic: gfx950 sustains
+ *   0.60-0.69 of its nominal 16-bit matrix rate on real operands -- power --, so what is left to cut is the number of matrix
+ *   instructions).  An operand scaled by a power of two into fp16's range is x' = hi + lo, hi = fp16(x'), lo = fp16(x' - hi):
+ *   2 x 11 significand bits, |x' - hi - lo| <= 2^-23 |x'|, the size of an fp32 rounding error (the three-way bf16 split is
+ *   exact); hi hi + hi lo + lo hi accumulate in one fp32 accumulator, lo lo (<= 2^-22 of the product) is dropped.  Error against
+ *   float64: 1.0-1.7 x that of an fp32 dot product (tests/test_f16x2_gpu.py).  K, V and the pre-scaled Q are scaled by 2^6, the
+ *   probabilities by 2^14; |K|, |V|, |scale log2(e) Q| must stay below 1000: the kernels write 1 to *range_flag (device int,
+ *   caller-zeroed, never cleared here) when an element is not, and the caller repeats the product with ldmk_attn_self_x3p.
+ *   K / V pre-pass and LDS-DMA tiles as ldmk_attn_self_x3p; kv_scratch: ldmk_attn_kv_split_h2_bytes(n, tokens, heads) bytes. */
+long long ldmk_attn_kv_split_h2_bytes(int n, int tokens, int heads);
+int ldmk_attn_self_h2(const float* qkv, void* kv_scratch, float* out, int* range_flag, int n, int tokens, int heads, float scale,
+                      void* stream);
 /* ldmk_attn_self_small: the same product for SMALL problems (batch 1-2: the reference's talking-face mode runs batch 1,
  *   talking_face/progressive_sampling_difftalk.py:350).  One workgroup per 32-query tile of a (sample, head), the keys split
  *   over its 4 / 8 waves and streamed from global memory without LDS staging, partial (max, sum, O) merged in wave order

@@ -30,7 +30,7 @@ def _contract(d, split):
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # ONE basis per arithmetic setting, named in the line (never chosen from measured times)
-    assert r["basis"] == ("bf16_mfma_issued" if split else "f32_mfma_executed")
+    assert r["basis"] == ({"f16x2": "f16_mfma_issued", "bf16x3": "bf16_mfma_issued"}[split] if split else "f32_mfma_executed")
     assert 0.05 < r["frac"] < 1.0 and d["value"] > 50
     # the numerator is what the launches execute (sum of 2 M N K), printed next to the reference algorithm's count
     assert r["flops_basis"].startswith("executed") and 100 < r["executed_gflop_per_sample_step"] < r["reference_gflop_per_sample_step"]
@@ -42,14 +42,20 @@ def _contract(d, split):
     assert not any("frac" in k for k in alg) and "achieved_on_reference_flops" not in r
     family = r["executed_gflop_per_sample_step"] * 16 / r["sum_launch_ms_per_step"]         # fp32-equivalent TFLOP/s of all GEMM launches
     if split:
-        # dominant kernel = the bf16x3 igemm: priced against the bf16 matrix peak on the bf16 MFMA FLOPs it issues (6 x 2MNK)
+        # dominant kernel = the split-arithmetic igemm: priced against the 16-bit matrix peak on the MFMA FLOPs it ISSUES
+        # (f16x2: 3 x 2MNK, bf16x3: 6 x 2MNK); the useful rate and the chip's sustained rate on that instruction are printed beside it
         ba = r["by_arithmetic"]
-        assert r["peak"] > 2000 and "bf16x3" in d["arithmetic"] and "BF = 3" in r["kernel"]
+        mult, tag = {"f16x2": (3, "BF = 4"), "bf16x3": (6, "BF = 3")}[split]
+        assert r["peak"] > 2000 and split in d["arithmetic"] and tag in r["kernel"]
         assert abs(ba["family_fp32_equivalent_tflops"] - family) / family < 1e-3
-        x3, f32 = ba["bf16x3"], ba["f32_mfma"]
-        assert abs(x3["bf16_mfma_tflops_issued"] - 6 * x3["fp32_equivalent_tflops"]) < 0.1 and r["achieved"] == x3["bf16_mfma_tflops_issued"]
-        assert x3["ms_per_step"] > f32["ms_per_step"] and x3["fp32_equivalent_tflops"] < 2516.6 / 6 and f32["frac"] < 1.0
-        assert abs(x3["ms_per_step"] + f32["ms_per_step"] - r["sum_launch_ms_per_step"]) < 1e-2
+        x3, f32 = ba[split], ba["f32_mfma"]
+        assert x3["mfma_instructions_per_product"] == mult
+        assert abs(x3["mfma_tflops_issued"] - mult * x3["fp32_equivalent_tflops"]) < 0.1 and r["achieved"] == x3["mfma_tflops_issued"]
+        assert r["fp32_equivalent_tflops"] == x3["fp32_equivalent_tflops"]
+        assert x3["ms_per_step"] > f32["ms_per_step"] and x3["fp32_equivalent_tflops"] < 2516.6 / mult and f32["frac"] < 1.0
+        assert abs(sum(ba[k]["ms_per_step"] for k in ("f16x2", "bf16x3", "f32_mfma") if k in ba) - r["sum_launch_ms_per_step"]) < 1e-2
+        sus = r["sustained"]
+        assert 1000 < sus["mfma16_tflops_register_loop"] < 2516.6 and abs(sus["frac_of_sustained"] - r["achieved"] / sus["mfma16_tflops_register_loop"]) < 1e-3
     else:
         assert r["peak"] < 200 and "by_arithmetic" not in r and "f32 MFMA" in d["arithmetic"]
         assert alg["effective_tflops_reference_basis"] > r["achieved"]
@@ -58,7 +64,7 @@ def _contract(d, split):
 
 def test_bench_line_has_the_contract_fields():
     d = _run("--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-clip", "--no-extras")
-    _contract(d, split=True)
+    _contract(d, split="f16x2")
     # value is consistent with the timed region: batch * steps / time
     assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
 
@@ -67,6 +73,12 @@ def test_bench_line_f32_matrix_core_form():
     """LDMK_SPLIT_BF16=0: every GEMM on v_mfma_f32_32x32x2_f32, priced against the f32 matrix peak."""
     d = _run("--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-clip", "--no-extras", env={"LDMK_SPLIT_BF16": "0"})
     _contract(d, split=False)
+
+
+def test_bench_line_bf16x3_form():
+    """LDMK_F16X2=0: the round-3 arithmetic (six bf16 MFMAs per product), priced on the bf16 MFMA FLOPs it issues."""
+    d = _run("--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-clip", "--no-extras", env={"LDMK_F16X2": "0"})
+    _contract(d, split="bf16x3")
 
 
 def test_bench_train_mode_line():

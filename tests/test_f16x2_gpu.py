@@ -1,0 +1,241 @@
+"""GPU: the F16X2 arithmetic (include/ldmk.h) -- fp32-accurate products from THREE fp16 matrix instructions per term.  An operand,
+scaled by a power of two into fp16's range, is hi + lo with hi = fp16(x'), lo = fp16(x' - hi): 22 significand bits, the residual
+(<= 2^-23 |x'|, one fp32 ulp) is of the size of an fp32 rounding error; hi hi + hi lo + lo hi accumulate in fp32.  The bar, stated: against
+float64 the result is in the accuracy class of the fp32 matrix-core form -- RMS error within 2x (measured and simulated:
+1.0-1.7x, the larger figure at the shortest K), worst element within 3x -- and an operand outside the scaled fp16 range raises
+the range flag instead of producing infinities silently."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rnd
+from test_ops_gpu import close, ops  # noqa: F401  (the `ops` fixture)
+from test_split_gpu import _err
+
+pytestmark = pytest.mark.gpu
+
+
+def _f16x2_class(e32, eh, floor):
+    assert eh[1] <= max(2.0 * e32[1], 0.3 * floor), (e32, eh)
+    assert eh[0] <= max(3.0 * e32[0], floor), (e32, eh)
+
+
+def _attention_ref(qkv, n, tokens, heads):
+    C_ = heads * 32
+    q, k, v = [t.reshape(n, tokens, heads, 32).permute(0, 2, 1, 3).double() for t in qkv.cpu().split(C_, dim=1)]
+    att = torch.softmax(q @ k.transpose(-1, -2) * 32 ** -0.5, -1) @ v
+    return att.permute(0, 2, 1, 3).reshape(n * tokens, C_)
+
+
+@pytest.mark.parametrize("n,tokens,heads", [(2, 1024, 5), (1, 4096, 5), (3, 256, 10), (2, 64, 20), (2, 100, 2), (1, 130, 1),
+                                            (1, 2100, 5), (1, 2081, 3), (1, 2049, 1)])
+def test_f16x2_attention_matches_float64_like_the_fp32_kernel(ops, n, tokens, heads):
+    """ldmk_attn_self_h2 against float64 next to the f32 matrix-core kernel; ragged token counts (partial key tiles, partial
+    query blocks, the two-blocks-per-wave form from 2048 tokens)."""
+    qkv = (1.5 * rnd(550, n * tokens, 3 * heads * 32)).cuda()
+    ref = _attention_ref(qkv, n, tokens, heads)
+    flag = torch.zeros(1, device="cuda", dtype=torch.int32)
+    y32 = ops.attn_self(qkv, n, tokens, heads)
+    yh = ops.attn_self(qkv, n, tokens, heads, h2_flag=flag)
+    assert int(flag.item()) == 0
+    _f16x2_class(_err(y32, ref), _err(yh, ref), 2e-6)
+    close(yh, ref.float(), 3e-6, 3e-6)
+
+
+def test_f16x2_attention_peaked_and_flat_rows(ops):
+    """Rows whose softmax is one-hot (large score gaps) and rows that are flat (tiny scores): the scaled-domain bookkeeping
+    (scores x 2^12, probabilities x 2^14) holds at both ends."""
+    n, tokens, heads = 1, 512, 2
+    for mult in (1e-3, 12.0):
+        qkv = (mult * rnd(551, n * tokens, 3 * heads * 32)).cuda()
+        qkv[:, 2 * heads * 32:] = rnd(552, n * tokens, heads * 32).cuda()       # V of ordinary size
+        ref = _attention_ref(qkv, n, tokens, heads)
+        flag = torch.zeros(1, device="cuda", dtype=torch.int32)
+        y32 = ops.attn_self(qkv, n, tokens, heads)
+        yh = ops.attn_self(qkv, n, tokens, heads, h2_flag=flag)
+        assert int(flag.item()) == 0
+        _f16x2_class(_err(y32, ref), _err(yh, ref), 2e-6)
+
+
+@pytest.mark.parametrize("where", ["k", "v", "q"])
+def test_f16x2_attention_raises_the_range_flag(ops, where):
+    """|K|, |V| or the pre-scaled |Q| of 1000 or more (x 2^6 leaves fp16): the flag goes up (the caller repeats the product in
+    the bf16x3 arithmetic); operands just inside the range leave it down and the result stays in class."""
+    n, tokens, heads = 1, 256, 2
+    C_ = heads * 32
+    qkv = rnd(553, n * tokens, 3 * C_).cuda()
+    col = {"q": 3, "k": C_ + 5, "v": 2 * C_ + 7}[where]
+    big = {"q": 1001.0 / (32 ** -0.5 * 1.4426950408889634), "k": 1001.0, "v": -1001.0}[where]
+    flag = torch.zeros(1, device="cuda", dtype=torch.int32)
+    ops.attn_self(qkv, n, tokens, heads, h2_flag=flag)
+    assert int(flag.item()) == 0
+    q2 = qkv.clone()
+    q2[17, col] = big
+    ops.attn_self(q2, n, tokens, heads, h2_flag=flag)
+    assert int(flag.item()) == 1
+    flag.zero_()
+    q3 = qkv.clone()
+    q3[17, col] = big * 0.99
+    if where == "v":                       # a large V inside the range: the result is still fp32-class
+        yh = ops.attn_self(q3, n, tokens, heads, h2_flag=flag)
+        ref = _attention_ref(q3, n, tokens, heads)
+        y32 = ops.attn_self(q3, n, tokens, heads)
+        _f16x2_class(_err(y32, ref), _err(yh, ref), 2e-6)
+    else:
+        ops.attn_self(q3, n, tokens, heads, h2_flag=flag)
+    assert int(flag.item()) == 0
+
+
+# ---- GEMMs: LDMK_COMPUTE_F16X2 on the LDS-tiled shapes (csrc/igemm.hip, BF = 4): A scaled by 2^6 and split two ways while it is
+# staged (range-checked), W pre-split by ldmk_pack_wsplit_h2 with a per-matrix scale, three fp16 MFMAs per product
+import torch.nn.functional as F  # noqa: E402
+from test_ops_gpu import nchw, nhwc  # noqa: E402
+
+
+def _flag():
+    return torch.zeros(1, device="cuda", dtype=torch.int32)
+
+
+def test_pack_wsplit_h2_scales_into_range_and_splits_to_fp32_rounding(ops):
+    g = torch.Generator().manual_seed(6)
+    for mag in (3e-4, 0.05, 7.0, 900.0):
+        w = (torch.randn(96, 72, generator=g) * mag).cuda().contiguous()
+        s = ops.pack_wsplit_h2(w)                                # [1][2][N][ld]
+        e = ops.split_h2_of(w.data_ptr())[5]
+        assert s.shape == (1, 2, 72, 96) and s.dtype == torch.float16
+        mx = w.abs().max().item() * 2.0 ** e
+        assert 2.0 ** 13 <= mx < 2.0 ** 14
+        back = (s[0, 0].double() + s[0, 1].double()).t().cpu() * 2.0 ** -e
+        err = (back - w.double().cpu()).abs()
+        # hi + lo reproduces every weight to 2^-23 relative -- one fp32 ulp (elements below 2^-3 after scaling, whose lo is
+        # subnormal: an absolute 2^-25 of the scaled value)
+        bound = torch.maximum(w.double().cpu().abs() * 2.0 ** -23, torch.full_like(err, 2.0 ** -25 * 2.0 ** -e))
+        assert bool((err <= bound).all()), (mag, (err / bound).max().item())
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 4, 5])
+@pytest.mark.parametrize("M,K,N,sk", [(300, 320, 160, 1), (256, 640, 1920, 1), (4096, 160, 480, 1), (1024, 2560, 640, 3),
+                                      (64, 1280, 1280, 4)])
+def test_f16x2_linear_matches_float64_like_the_fp32_form(ops, M, K, N, sk, cfg):
+    from dsml_thesis_amd import lib as L
+    x, w, b = rnd(500, M, K), rnd(501, N, K) / np.sqrt(K), 0.1 * rnd(502, N)
+    res = rnd(503, M, N)
+    wp = ops.pack_linear(w.cuda())
+    ops.pack_wsplit_h2(wp)
+    ws = torch.empty(8 * M * N, device="cuda")
+    ref = x.double() @ w.double().t() + b.double() + res.double()
+    flag = _flag()
+    ys = []
+    for compute in (L.COMPUTE_F32, L.COMPUTE_F16X2):
+        out = torch.empty(M, N, device="cuda")
+        xc, bc, rc = x.cuda(), b.cuda(), res.cuda()
+        a = ops.make_igemm_args(M, N, K, xc, K, wp, out, N, M, bias=bc, residual=rc, tile_cfg=cfg, splitk=sk,
+                                splitk_ws=ws, compute=compute, range_flag=flag)
+        ops.igemm(a)
+        ys.append(out)
+    assert int(flag.item()) == 0
+    _f16x2_class(_err(ys[0], ref), _err(ys[1], ref), 2e-6)
+    close(ys[1], ref.float(), 3e-6, 3e-6)
+
+
+@pytest.mark.parametrize("case", [(2, 160, 320, 16, 16, 1), (2, 64, 96, 9, 7, 1), (1, 160, 160, 16, 16, 2), (3, 640, 640, 8, 8, 1),
+                                  (2, 320, 160, 32, 32, 1)])
+def test_f16x2_conv3x3_with_groupnorm_silu_prologue(ops, case):
+    from dsml_thesis_amd import lib as L
+    n, cin, cout, h, w, stride = case
+    x, wt, b = rnd(510, n, cin, h, w), rnd(511, cout, cin, 3, 3) / np.sqrt(9 * cin), 0.1 * rnd(512, cout)
+    scale, shift = 1.0 + 0.2 * rnd(513, n, cin), 0.3 * rnd(514, n, cin)
+    coef = torch.stack([scale, shift], 1).contiguous().cuda()
+    wp = ops.pack_conv3x3(wt.cuda())
+    ops.pack_wsplit_h2(wp)
+    xa = F.silu(x.double() * scale.double()[:, :, None, None] + shift.double()[:, :, None, None])
+    ref = F.conv2d(xa, wt.double(), b.double(), stride=stride, padding=1)
+    flag = _flag()
+    y32 = ops.conv3x3(nhwc(x), wp, b.cuda(), stride=stride, coef=coef)
+    yh = ops.conv3x3(nhwc(x), wp, b.cuda(), stride=stride, coef=coef, compute=L.COMPUTE_F16X2, range_flag=flag)
+    assert int(flag.item()) == 0
+    _f16x2_class(_err(nchw(y32), ref), _err(nchw(yh), ref), 3e-6)
+
+
+def test_f16x2_geglu_with_folded_layernorm(ops):
+    from dsml_thesis_amd import lib as L
+    M, K, inner = 512, 320, 1280
+    x = rnd(520, M, K) + 0.5
+    w, b = rnd(521, 2 * inner, K) / np.sqrt(K), 0.1 * rnd(522, 2 * inner)
+    gamma, beta = 1.0 + 0.1 * rnd(523, K), 0.1 * rnd(524, K)
+    wp, bp = ops.pack_geglu(w.cuda(), b.cuda())
+    w2, cs, b2 = ops.fold_layernorm(wp, gamma.cuda(), beta.cuda(), bp)
+    ops.pack_wsplit_h2(w2)
+    st = ops.ln_stats(x.cuda())
+    xn = F.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5)
+    hcat = xn @ w.double().t() + b.double()
+    ref = hcat[:, :inner] * F.gelu(hcat[:, inner:])
+    flag = _flag()
+    y32 = ops.linear(x.cuda(), w2, b2, row_stats=st, ln_colsum=cs, geglu=True)
+    yh = ops.linear(x.cuda(), w2, b2, row_stats=st, ln_colsum=cs, geglu=True, compute=L.COMPUTE_F16X2, range_flag=flag)
+    assert int(flag.item()) == 0
+    _f16x2_class(_err(y32, ref), _err(yh, ref), 3e-6)
+
+
+def test_f16x2_batched_gemm(ops):
+    """the Winograd form: 16 independent [M][K] x [K][N] products in one launch (one weight scale for the batch)."""
+    from dsml_thesis_amd import lib as L
+    B, M, K, N = 16, 256, 320, 640
+    a = rnd(530, B, M, K)
+    w = rnd(531, B, K, N) / np.sqrt(K)
+    ac, wc = a.cuda().contiguous(), w.cuda().contiguous()
+    ops.pack_wsplit_h2(wc, batch=B)
+    ref = torch.bmm(a.double(), w.double())
+    ws = torch.empty(4 * B * M * N, device="cuda")
+    flag = _flag()
+    outs = []
+    for compute in (L.COMPUTE_F32, L.COMPUTE_F16X2):
+        out = torch.empty(B, M, N, device="cuda")
+        ar = ops.make_igemm_args(M, N, K, ac, K, wc, out, N, M, batch=B, a_bstride=M * K, w_bstride=K * N, out_bstride=M * N,
+                                 tile_cfg=5, splitk=2, splitk_ws=ws, compute=compute, range_flag=flag)
+        ops.igemm(ar)
+        outs.append(out)
+    assert int(flag.item()) == 0
+    _f16x2_class(_err(outs[0], ref), _err(outs[1], ref), 2e-6)
+
+
+def test_f16x2_gemm_small_and_large_magnitudes_and_the_range_flag(ops):
+    """Operand magnitudes from 1e-4 to 500: the relative error stays in class (activations far below 2^-8 keep an ABSOLUTE precision,
+    which is what an fp32 accumulation resolves anyway); one element of 1000 or more raises the flag."""
+    from dsml_thesis_amd import lib as L
+    M, K, N = 256, 320, 160
+    w = rnd(541, N, K) / np.sqrt(K)
+    wp = ops.pack_linear(w.cuda())
+    ops.pack_wsplit_h2(wp)
+    for mag in (1e-4, 0.02, 30.0, 500.0 / 4.5):
+        x = rnd(540, M, K) * mag
+        ref = x.double() @ w.double().t()
+        flag = _flag()
+        y32 = ops.linear(x.cuda(), wp)
+        yh = ops.linear(x.cuda(), wp, compute=L.COMPUTE_F16X2, range_flag=flag)
+        assert int(flag.item()) == 0, mag
+        e32, eh = _err(y32, ref), _err(yh, ref)
+        _f16x2_class(e32, eh, 2e-6 * mag)
+    x = rnd(540, M, K)
+    x[100, 37] = -1000.5
+    flag = _flag()
+    ops.linear(x.cuda(), wp, compute=L.COMPUTE_F16X2, range_flag=flag)
+    assert int(flag.item()) == 1
+
+
+def test_f16x2_rejects_what_it_cannot_run(ops):
+    from dsml_thesis_amd import lib as L
+    import ctypes
+    x, w = rnd(540, 64, 64).cuda(), rnd(541, 64, 64).cuda().contiguous()
+    out = torch.empty(64, 64, device="cuda")
+    flag = _flag()
+    with pytest.raises(ValueError):
+        ops.make_igemm_args(64, 64, 64, x, 64, w, out, 64, 64, compute=L.COMPUTE_F16X2, range_flag=flag)       # no fp16 images registered
+    ops.pack_wsplit_h2(w)
+    with pytest.raises(ValueError):
+        ops.make_igemm_args(64, 64, 64, x, 64, w, out, 64, 64, compute=L.COMPUTE_F16X2)                        # no range flag
+    for cfg in (9, 21, 23):                                                                                    # row-GEMM, warp-specialised, pre-split tiles
+        a = ops.make_igemm_args(64, 64, 64, x, 64, w, out, 64, 64, compute=L.COMPUTE_F16X2, range_flag=flag, tile_cfg=cfg)
+        assert L.load().ldmk_igemm_check(ctypes.byref(a)) != 0
+    a = ops.make_igemm_args(64, 64, 64, x, 64, w, out, 64, 64, compute=L.COMPUTE_F16X2, range_flag=flag, tile_cfg=5)
+    assert L.load().ldmk_igemm_check(ctypes.byref(a)) == 0

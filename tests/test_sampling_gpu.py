@@ -286,7 +286,7 @@ def test_first_stage_split_arithmetic_golden(monkeypatch):
         img, idx = m.first_stage_model.decode(z, return_indices=True)
         fs = m.first_stage_model
         gemms = [c[2] for pg in fs._programs.values() for c in pg.calls if c[3] == "ldmk_igemm"]
-        n3 = sum(1 for a in gemms if a.compute == L.COMPUTE_BF16X3)
+        n3 = sum(1 for a in gemms if a.compute in (L.COMPUTE_BF16X3, L.COMPUTE_F16X2))
         assert n3 >= 0.7 * len(gemms), (n3, len(gemms))
         assert np.array_equal(idx.cpu().numpy(), golden("g6_vqgan.npz")["vq_idx"].reshape(-1))
         close(img, golden("g11_northstar.npz")["decoded128"], 1e-4, 1e-4)
@@ -418,7 +418,7 @@ def test_ema_scope_swaps_weights_and_repacks(fr):
         pg = unet.program(1, 32, 32, 1, 0)
         assert not getattr(pg, "small_route", False)
         from dsml_thesis_amd import lib as L
-        assert sum(1 for cl in pg.calls if cl[3] == "ldmk_igemm" and cl[2].compute == L.COMPUTE_BF16X3) >= 40
+        assert sum(1 for cl in pg.calls if cl[3] == "ldmk_igemm" and cl[2].compute in (L.COMPUTE_BF16X3, L.COMPUTE_F16X2)) >= 40
         with fr.ema_scope():
             ema16 = fr.apply_model(x, t, c[:1])
         again16 = fr.apply_model(x, t, c[:1])
@@ -478,8 +478,8 @@ def test_northstar_trajectory_in_the_split_arithmetic(monkeypatch):
     assert torch.equal(outs[0], outs[1])
     pgs = [pg for pg in m.model.diffusion_model._programs.values()]
     gemms = [c_[2] for pg in pgs for c_ in pg.calls if c_[3] == "ldmk_igemm"]
-    assert gemms and sum(1 for a in gemms if a.compute == L.COMPUTE_BF16X3) >= len(gemms) - 8
-    assert any(c_[3] in ("ldmk_attn_self_x3", "ldmk_attn_self_x3p") for pg in pgs for c_ in pg.calls)
+    assert gemms and sum(1 for a in gemms if a.compute in (L.COMPUTE_BF16X3, L.COMPUTE_F16X2)) >= len(gemms) - 8
+    assert any(c_[3] in ("ldmk_attn_self_x3", "ldmk_attn_self_x3p", "ldmk_attn_self_h2") for pg in pgs for c_ in pg.calls)
 
 
 def test_sharded_sampling_bitwise_equals_single_gpu(fr):

@@ -131,7 +131,7 @@ def test_unet_tf_concat_golden(route):
     if route == "batched128":             # the clip's program: bf16x3 table shapes of the B = 128 rows, Winograd at every level
         from dsml_thesis_amd import lib as L
         gemms = [c[2] for c in pg.calls if c[3] == "ldmk_igemm"]
-        assert sum(1 for a in gemms if a.compute == L.COMPUTE_BF16X3) >= 40
+        assert sum(1 for a in gemms if a.compute in (L.COMPUTE_BF16X3, L.COMPUTE_F16X2)) >= 40
         names = [c[3] for c in pg.calls]
         assert names.count("ldmk_winograd_input") + names.count("ldmk_winograd_input_ps") >= 20
     x, t = rnd(71, 2, 3, 32, 32), torch.tensor([11, 756])
@@ -188,12 +188,12 @@ def test_unet_split_arithmetic_routes_against_the_reference_fixtures(monkeypatch
         m.policy_batch = policy
         eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
         pg = m.program(2, 32, 32, 1, 0)
-        n3 = sum(1 for c in pg.calls if c[3] == "ldmk_igemm" and c[2].compute == L.COMPUTE_BF16X3)
+        n3 = sum(1 for c in pg.calls if c[3] == "ldmk_igemm" and c[2].compute in (L.COMPUTE_BF16X3, L.COMPUTE_F16X2))
         ng = sum(1 for c in pg.calls if c[3] == "ldmk_igemm")
         return eps, n3, ng, [c[3] for c in pg.calls]
 
     eps_a, n3, ng, names = run()
-    assert n3 >= 40 and "ldmk_attn_self_x3" in names and "ldmk_attn_self" not in names, (n3, ng)
+    assert n3 >= 40 and "ldmk_attn_self_x3" in names and "ldmk_attn_self_h2" in names and "ldmk_attn_self" not in names, (n3, ng)
     close(eps_a, g["fr_eps"], 3e-5, 3e-5)
     # (b) everything eligible
     monkeypatch.setattr(engine, "x3_plan", lambda a, m: (1, 1) if a.epi == L.EPI_GEGLU else (5, 1))
@@ -205,7 +205,7 @@ def test_unet_split_arithmetic_routes_against_the_reference_fixtures(monkeypatch
     monkeypatch.setenv("LDMK_SPLIT_BF16", "0")
     monkeypatch.setattr(engine, "_X3_TABLE", None)
     eps_c, n3c, _, names_c = run()
-    assert n3c == 0 and "ldmk_attn_self" in names_c and "ldmk_attn_self_x3" not in names_c and "ldmk_attn_self_x3p" not in names_c
+    assert n3c == 0 and "ldmk_attn_self" in names_c and not {"ldmk_attn_self_x3", "ldmk_attn_self_x3p", "ldmk_attn_self_h2"} & set(names_c)
     close(eps_c, g["fr_eps"], 3e-5, 3e-5)
     assert (eps_a - eps_c).abs().max().item() < 1.5e-5
     monkeypatch.undo()
@@ -242,6 +242,49 @@ def test_folded_layernorm_guard_switches_mean_dominated_models_to_the_unfolded_p
     with warnings.catch_warnings():
         warnings.simplefilter("error")                   # decided once: later evaluations neither warn nor re-pack
         assert torch.equal(m2(x.cuda(), t.cuda(), context=ctx.cuda()), eps)
+
+
+def test_f16x2_range_flag_sends_the_model_back_to_bf16x3(monkeypatch):
+    """The F16X2 attention needs |K|, |V|, |scaled Q| < 1000.  A checkpoint whose attn1.to_k weights of one block are 3000 x
+    larger (and its to_q weights as much smaller) must still meet the oracle with no environment variable set: the kernels raise the range flag, the first evaluation
+    reads it, warns, drops its programs and evaluates again in the bf16x3 arithmetic -- bit for bit what a model started with
+    LDMK_F16X2=0 computes.  A well-conditioned model stays in F16X2."""
+    import warnings
+    from dsml_thesis_amd.unet import UNetModel
+    x, t, ctx = rnd(43, 2, 3, 32, 32), torch.tensor([5, 700]), rnd(44, 2, 1, 512)
+    m, sd = make_unet(W.FR_UNET)
+    m.policy_batch = 16
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m(x.cuda(), t.cuda(), context=ctx.cuda())
+    assert m.f16x2 and m._h2_flag.item() == 0
+    assert "ldmk_attn_self_h2" in [c[3] for c in m.program(2, 32, 32, 1, 0).calls]
+    key = "input_blocks.1.1.transformer_blocks.0.attn1.to_k.weight"
+    keyq = key.replace("to_k", "to_q")
+    assert key in sd and keyq in sd
+    # (K x 3000 with Q / 3000: the logits -- and the conditioning of the softmax -- are those of the original checkpoint)
+    sd2 = {k: (v * 3000.0 if k == key else v / 3000.0 if k == keyq else v) for k, v in sd.items()}
+
+    def load():
+        m_ = UNetModel(**W.FR_UNET)
+        m_.load_state_dict(sd2, strict=True)
+        m_ = m_.cuda().eval()
+        m_.policy_batch = 16
+        return m_
+    m2 = load()
+    with pytest.warns(RuntimeWarning, match="F16X2"):
+        eps = m2(x.cuda(), t.cuda(), context=ctx.cuda())
+    assert not m2.f16x2
+    names = [c[3] for c in m2.program(2, 32, 32, 1, 0).calls]
+    assert "ldmk_attn_self_h2" not in names and "ldmk_attn_self_x3" in names
+    close(eps, O.unet_forward(sd2, W.FR_UNET, x, t, ctx), 3e-5, 3e-5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                   # decided once
+        assert torch.equal(m2(x.cuda(), t.cuda(), context=ctx.cuda()), eps)
+    monkeypatch.setenv("LDMK_F16X2", "0")
+    m3 = load()
+    assert not m3.f16x2
+    assert torch.equal(m3(x.cuda(), t.cuda(), context=ctx.cuda()), eps)
 
 
 def test_attention_block_golden_through_the_launch_program():

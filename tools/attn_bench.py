@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--lib", help="another build of libldmk.so to time instead (A/B on one box)")
-    ap.add_argument("--mode", default="f32", choices=("f32", "x3", "x3p"), help="f32 matrix cores / bf16x3 / bf16x3 with the K, V pre-pass")
+    ap.add_argument("--mode", default="f32", choices=("f32", "x3", "x3p", "h2"), help="f32 matrix cores / bf16x3 / bf16x3 with the K, V pre-pass")
     a = ap.parse_args()
     if a.lib:
         from dsml_thesis_amd import lib as L
@@ -32,6 +32,13 @@ def main():
             from dsml_thesis_amd import lib as L
             kv = torch.empty(L.load().ldmk_attn_kv_split_bytes(a.batch, tokens, heads), device="cuda", dtype=torch.uint8)
             t = timeit(lambda: L.call("ldmk_attn_self_x3p", qkv.data_ptr(), kv.data_ptr(), out.data_ptr(), a.batch, tokens, heads, 32 ** -0.5, ops.stream()))
+        elif a.mode == "h2":
+            from dsml_thesis_amd import lib as L
+            kv = torch.empty(L.load().ldmk_attn_kv_split_h2_bytes(a.batch, tokens, heads), device="cuda", dtype=torch.uint8)
+            flag = torch.zeros(1, device="cuda", dtype=torch.int32)
+            t = timeit(lambda: L.call("ldmk_attn_self_h2", qkv.data_ptr(), kv.data_ptr(), out.data_ptr(), flag.data_ptr(), a.batch, tokens, heads,
+                                      32 ** -0.5, ops.stream()))
+            assert int(flag.item()) == 0
         else:
             t = timeit(lambda: ops.attn_self(qkv, a.batch, tokens, heads, out=out, x3=a.mode == "x3"))
         gf = 4.0 * tokens * tokens * 32 * heads * a.batch * 1e-9

@@ -48,7 +48,7 @@ def dump(latent, batch, path, graph=False):
 
 KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "igemm_ws_kernel", "igemm_ps_kernel", "igemm_pw_kernel", "rgemm_kernel", "sgemm_kernel"), "ldmk_post": ("post_",),
              "ldmk_attn_self_small": ("attn_small",), "ldmk_conv3x3_out_small": ("conv3x3_out_small",), "ldmk_gn_finalize": ("gn_finalize",), "ldmk_gn_apply": ("gn_apply",),
-             "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_ln_stats_guard": ("ln_stats",), "ldmk_ln_stats_split": ("ln_stats",), "ldmk_ln_stats_ps": ("ln_stats_ps",), "ldmk_pack_ps": ("pack_ps",), "ldmk_attn_self": ("attn_self",), "ldmk_attn_self_x3": ("attn_x3",), "ldmk_attn_self_x3p": ("attn_kv_split",), "ldmk_attn_self_x3p_ps": ("attn_kv_split",),
+             "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_ln_stats_guard": ("ln_stats",), "ldmk_ln_stats_split": ("ln_stats",), "ldmk_ln_stats_ps": ("ln_stats_ps",), "ldmk_pack_ps": ("pack_ps",), "ldmk_attn_self": ("attn_self",), "ldmk_attn_self_x3": ("attn_x3",), "ldmk_attn_self_x3p": ("attn_kv_split",), "ldmk_attn_self_x3p_ps": ("attn_kv_split",), "ldmk_attn_self_h2": ("attn_kv_split_h2",),
              "ldmk_attn_cross": ("attn_cross",), "ldmk_dense_small": ("dense_small",),
              "ldmk_timestep_embedding": ("timestep_embedding",), "ldmk_conv3x3_in": ("conv3x3_in",),
              "ldmk_conv3x3_out": ("conv3x3_out",), "ldmk_winograd_input": ("wino_input",), "ldmk_winograd_input_ps": ("wino_input_ps",), "ldmk_upconv_gather_ps": ("upconv_gather_ps",),
@@ -66,7 +66,7 @@ def join(d):
     tr = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = [r for r in csv.DictReader(open(tr)) if "ldmk::" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    per = sum(2 if (c["name"] in ("ldmk_post", "ldmk_attn_self_x3p", "ldmk_attn_self_x3p_ps") or (c["name"] == "ldmk_igemm" and c.get("sk", 1) > 1 and not 7 <= c.get("cfg", 0) <= 12)) else 1
+    per = sum(2 if (c["name"] in ("ldmk_post", "ldmk_attn_self_x3p", "ldmk_attn_self_x3p_ps", "ldmk_attn_self_h2") or (c["name"] == "ldmk_igemm" and c.get("sk", 1) > 1 and not 7 <= c.get("cfg", 0) <= 12)) else 1
               for c in calls) + 1
     # the last step of the trace: find it by walking back from the end to the step's first kernel (timestep_embedding)
     starts = [i for i, r in enumerate(rows) if "timestep_embedding" in r["Kernel_Name"]]
@@ -86,8 +86,8 @@ def join(d):
         assert want is None or any(w in r["Kernel_Name"] for w in want), (c, r["Kernel_Name"])
         d_ = dur(r)
         i += 1
-        if c["name"] in ("ldmk_attn_self_x3p", "ldmk_attn_self_x3p_ps"):          # K / V pre-pass + attention kernel
-            assert "attn_x3p" in last[i]["Kernel_Name"], last[i]["Kernel_Name"]
+        if c["name"] in ("ldmk_attn_self_x3p", "ldmk_attn_self_x3p_ps", "ldmk_attn_self_h2"):          # K / V pre-pass + attention kernel
+            assert ("attn_h2_fwd" if c["name"] == "ldmk_attn_self_h2" else "attn_x3p") in last[i]["Kernel_Name"], last[i]["Kernel_Name"]
             c["prepass_us"] = d_
             d_ += dur(last[i])
             i += 1
@@ -123,6 +123,8 @@ def join(d):
                 key += f" x{c['batch']} ({'Winograd' if c['batch'] == 16 else 'upsample phases'})"
             if c.get("compute", 0) == 2:
                 key += " bf16x3"
+            elif c.get("compute", 0) == 3:
+                key += " f16x2"
         else:
             key = c["name"]
         a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
@@ -139,14 +141,14 @@ def join(d):
     for key, (n, d_, fl, mn) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         tfs = fl / (d_ * 1e-6) / 1e12 if fl else 0.0
         # bf16x3 rows: six bf16 MFMAs per fp32-equivalent product -> ceiling = bf16 peak / 6
-        peak = PEAK_BF16_MFMA / 6.0 if key.endswith("bf16x3") else PEAK_F32_MFMA
+        peak = PEAK_BF16_MFMA / 6.0 if key.endswith("bf16x3") else PEAK_BF16_MFMA / 3.0 if key.endswith("f16x2") else PEAK_F32_MFMA
         assert tfs <= peak, f"{key}: {tfs:.1f} TFLOP/s exceeds the matrix peak of its arithmetic ({peak:.1f}) -- the join is wrong"
         fam_t += d_ if fl else 0.0
         fam_f += fl
         print(f"{key:75s} {n:3d} {d_:10.1f} {100 * d_ / tot:6.2f} {tfs:8.1f}  main {mn / n:6.1f} us/call" if fl else f"{key:75s} {n:3d} {d_:10.1f} {100 * d_ / tot:6.2f}")
     print(f"GEMM family (LDS-tiled igemm + row GEMM): {fam_f * 1e-9:.1f} GFLOP (fp32-equivalent 2MNK) in {fam_t / 1e3:.3f} ms = "
           f"{fam_f / (fam_t * 1e-6) / 1e12:.1f} TFLOP/s = {fam_f / (fam_t * 1e-6) / 1e12 / PEAK_F32_MFMA:.3f} of the f32 matrix peak "
-          f"(rows marked bf16x3 execute 6 bf16 MFMA FLOPs per counted FLOP: their ceiling is {PEAK_BF16_MFMA / 6:.1f})")
+          f"(rows marked bf16x3 / f16x2 execute 6 / 3 16-bit MFMA FLOPs per counted FLOP: their ceilings are {PEAK_BF16_MFMA / 6:.1f} / {PEAK_BF16_MFMA / 3:.1f})")
 
 
 if __name__ == "__main__":
