@@ -102,6 +102,42 @@ def x3_plan(a, m):
     return best[1], best[2]
 
 
+_H2_TABLE = None
+
+
+def h2_table():
+    """{shape key: [(M, cfg, splitk)]}: shapes tools/autotune.py --h2 measured faster in the F16X2 arithmetic than their best f32
+    plan, with the F16X2 plan (dsml_thesis_amd/igemm_plans_h2.json; LDMK_H2_TABLE overrides the path).  A shape listed in the x3
+    table only runs in F16X2 too, on the x3 plan's tile."""
+    global _H2_TABLE
+    if _H2_TABLE is None:
+        import json
+        path = os.environ.get("LDMK_H2_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans_h2.json")
+        _H2_TABLE = {}
+        if os.path.exists(path) and f16x2_enabled():
+            try:
+                with open(path) as fh:
+                    raw = json.load(fh)
+            except Exception:
+                raw = {}
+            for k, (cfg, sk) in raw.items():
+                m, rest = k.split(",", 1)
+                _H2_TABLE.setdefault(rest, []).append((int(m), int(cfg), int(sk)))
+            for v in _H2_TABLE.values():
+                v.sort()
+    return _H2_TABLE
+
+
+def h2_plan(a, m):
+    rows = h2_table().get(plan_key(a, m).split(",", 1)[1])
+    if not rows:
+        return None
+    best = min(rows, key=lambda r: (abs(math.log(r[0] / m)), r[0]))
+    if max(best[0], m) > 2 * min(best[0], m):
+        return None
+    return best[1], best[2]
+
+
 _PS_TABLE = None
 
 
@@ -233,8 +269,10 @@ class Program:
         # bf16x3 arithmetic for the shapes measured faster in it (needs the weight's split images; decided on the policy row
         # count like every plan, so a sample's result does not depend on how the batch is sharded)
         if (args.compute == L.COMPUTE_F32 and not args.b_trans and not args.raw_slabs and (nbatch <= 1 or not batch_is_samples)
-                and args.M > 0 and x3_table()):
-            xp = x3_plan(args, args.M)
+                and args.M > 0 and (x3_table() or h2_table())):
+            h2_flag = getattr(self, "h2_flag", None)
+            hp = h2_plan(args, args.M) if h2_flag is not None else None       # a plan measured in the F16X2 arithmetic itself
+            xp = hp if hp is not None else x3_plan(args, args.M)
             if xp is not None:
                 from . import ops as _ops
                 saved = (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems)
@@ -243,7 +281,6 @@ class Program:
                     args.a_split, args.a_split_ld = 0, 0          # the warp-specialised tiles split A themselves
                 # the F16X2 arithmetic (three fp16 products per term, include/ldmk.h) while the owner's range flag is down:
                 # same shapes, the LDS-tiled form of the tile (the warp-specialised 256-row tiles map to 128x160 / 128x128)
-                h2_flag = getattr(self, "h2_flag", None)
                 ok = h2_flag is not None and not args.a_split and _ops.set_split_h2(args, h2_flag)
                 if ok:
                     xp = ({21: 5, 22: 1}.get(int(xp[0]), int(xp[0])), xp[1])

@@ -24,6 +24,8 @@ ROWS_RETUNE = False
 SLAB_RETUNE = False
 FORCE = False
 X3_TABLE = None
+H2_MODE = False       # --h2: the --x3 sweep in the F16X2 arithmetic
+H2_FLAG = None
 CANDS = {}
 CFG_WK = {1: 1, 2: 2, 3: 4, 4: 2, 5: 1, 6: 2}          # K slices of 32 staged per iteration
 EVEN_TN = {1, 2, 3}
@@ -118,11 +120,12 @@ def tune_x3(pg, xtable):
         if name != "ldmk_igemm":
             continue
         key = plan_key(a, a.M)
-        if key in seen or a.b_trans or a.raw_slabs or a.compute != L.COMPUTE_F32 or ops.split_of(a.w) is None:
+        if key in seen or a.b_trans or a.raw_slabs or a.compute != L.COMPUTE_F32 or (ops.split_h2_of(a.w) if H2_MODE else ops.split_of(a.w)) is None:
             continue
         seen.add(key)
         saved = (a.tile_cfg, a.splitk, a.splitk_ws, a.splitk_ws_elems, a.out, a.stats_out, a.residual, a.compute, a.w_split,
                  a.w_split_ld, a.w_split_bstride)
+        saved_h = (a.w_scale_exp, a.range_flag, a.a_split, a.a_split_ld)
         saved_a = (a.a0, a.a1)
         nb = max(1, a.batch)
         samples = -(-a.M // a.rows_per_sample)
@@ -144,9 +147,13 @@ def tune_x3(pg, xtable):
         base = time_call(lib, a, st, touch=touch)
         best = None
         tried = []
-        ops.set_split(a)
+        if H2_MODE:
+            a.a_split, a.a_split_ld = 0, 0
+            ops.set_split_h2(a, H2_FLAG)
+        else:
+            ops.set_split(a)
         nkc = a.K // 32
-        for cfg in (1, 2, 4, 5, 21, 22):          # 21 / 22: the warp-specialised 256x160 / 256x128 tiles (csrc/igemm_ws.hip)
+        for cfg in ((1, 2, 4, 5) if H2_MODE else (1, 2, 4, 5, 21, 22)):          # 21 / 22: the warp-specialised 256x160 / 256x128 tiles (csrc/igemm_ws.hip)
             if a.epi == 1 and cfg not in EVEN_TN and cfg != 22:
                 continue
             iters = -(-nkc // CFG_WK.get(cfg, 1))
@@ -162,6 +169,7 @@ def tune_x3(pg, xtable):
                     best = (t, cfg, sk)
         (a.tile_cfg, a.splitk, a.splitk_ws, a.splitk_ws_elems, a.out, a.stats_out, a.residual, a.compute, a.w_split, a.w_split_ld,
          a.w_split_bstride) = saved
+        a.w_scale_exp, a.range_flag, a.a_split, a.a_split_ld = saved_h
         a.a0, a.a1 = saved_a
         if base is None or best is None:
             continue
@@ -172,8 +180,9 @@ def tune_x3(pg, xtable):
             xtable[key] = [best[1], best[2]]
         elif key in xtable:
             del xtable[key]
-        print(f"{key:40s} f32 cfg={saved[0]} sk={saved[1]} {1e3 * base:8.1f} us | x3 cfg={best[1]} sk={best[2]} {1e3 * best[0]:8.1f} us"
-              f"  x{base / best[0]:.2f} {'-> x3' if win else ''}", flush=True)
+        tag = "h2" if H2_MODE else "x3"
+        print(f"{key:40s} f32 cfg={saved[0]} sk={saved[1]} {1e3 * base:8.1f} us | {tag} cfg={best[1]} sk={best[2]} {1e3 * best[0]:8.1f} us"
+              f"  x{base / best[0]:.2f} {'-> ' + tag if win else ''}", flush=True)
 
 
 def tune_program(pg, table):
@@ -293,7 +302,15 @@ if __name__ == "__main__":
     ap.add_argument("--x3", action="store_true", help="sweep the bf16x3 arithmetic (LDMK_COMPUTE_BF16X3) against the plans on record; "
                     "writes dsml_thesis_amd/igemm_plans_x3.json (or --x3-out)")
     ap.add_argument("--x3-out", default=os.path.join(ROOT, "dsml_thesis_amd", "igemm_plans_x3.json"))
+    ap.add_argument("--h2", action="store_true", help="the --x3 sweep in the F16X2 arithmetic (LDMK_COMPUTE_F16X2, tile_cfg 1 / 2 / 4 / 5); "
+                    "writes dsml_thesis_amd/igemm_plans_h2.json")
     a = ap.parse_args()
+    if a.h2:
+        a.x3, H2_MODE = True, True
+        if a.x3_out.endswith("igemm_plans_x3.json"):
+            a.x3_out = a.x3_out.replace("igemm_plans_x3.json", "igemm_plans_h2.json")
+        os.environ["LDMK_H2_TABLE"] = "/nonexistent"
+        H2_FLAG = torch.zeros(1, device="cuda", dtype=torch.int32)
     if a.x3:
         # the programs must be built with their f32 plans (table on, x3 table off) but with the split images packed
         os.environ["LDMK_X3_TABLE"] = "/nonexistent"
