@@ -742,8 +742,10 @@ class UNetModel(nn.Module):
                           "switching this model to the bf16x3 arithmetic (LDMK_F16X2=0 starts there)", RuntimeWarning, stacklevel=3)
             self.f16x2 = False
             self._h2_flag.zero_()
+            if self._ln_flag is not None:
+                self._ln_flag.zero_()       # (statistics of that run may be those of overflowed operands: the repeat decides afresh)
             self._programs.clear()
-            tripped = True
+            return True
         if not (self.ln_unfolded or self._ln_flag is None or int(self._ln_flag.item()) == 0):
             warnings.warn(f"UNetModel: token rows with |mean| > {LN_GUARD_RATIO:g} standard deviations reached a LayerNorm; the folded "
                           "form (LayerNorm through the product) loses accuracy on them -- switching this model to the unfolded "

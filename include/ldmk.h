@@ -72,7 +72,9 @@ enum { LDMK_COMPUTE_F32 = 0, LDMK_COMPUTE_BF16 = 1, LDMK_COMPUTE_BF16X3 = 2, LDM
  * accumulate in one fp32 accumulator, the scales leave in the epilogue (exact).  Against float64 the result has 1.0-1.7 x the
  * RMS error of an fp32 dot product (1.7 at K = 160, 1.1 from K = 1440; tests/test_f16x2_gpu.py bounds it at 2 x) -- the fp32
  * accuracy class, a little behind BF16X3.  Scales: activations 2^LDMK_F16X2_A_EXP, fixed; weights 2^w_scale_exp, chosen per
- * matrix when it is packed (ldmk_pack_wsplit_h2) so that max |w'| lies in [2^13, 2^14).  An activation with |x| >=
+ * matrix when it is packed (ldmk_pack_wsplit_h2) so that max |w'| lies in [2^13, 2^14).  An activation far below 2^-9 keeps
+ * an absolute precision of 2^-31 rather than a relative one: invisible next to O(1) elements of the same row (an fp32
+ * accumulation resolves 2^-24 of the sum), but a tensor that is uniformly ~1e-4 comes out with 8 x the fp32 form's error.  An activation with |x| >=
  * LDMK_F16X2_RANGE (or inf / NaN) would leave fp16: the kernels then write 1 to *range_flag (a device int the caller zeroes
  * once; never cleared here) and the caller repeats the work in BF16X3.  tile_cfg 0..6. */
 #define LDMK_F16X2_A_EXP 6
@@ -121,9 +123,10 @@ typedef struct ldmk_igemm_args {
                                 inside the workgroup: 2x1x4, 2x2x4, 1x1x4, 1x2x4, 1x1x8, 1x1x16, 2x1x8, 1x2x8; needs
                                 w_frag; stride-1 3x3 convolutions and rows mode), 21..22 = pin a warp-specialised tile of
                                 the LDMK_COMPUTE_BF16X3 arithmetic (csrc/igemm_ws.hip: 256x160 / 256x128, four consumer +
-                                four producer waves; bitwise the results of tile_cfg 5 / 1 at equal splitk), 23..30 = pin a
-                                pre-split tile (csrc/igemm_ps.hip: 256x160, 256x320, 256x256, 128x320, 128x160, 128x256, and the
-                                warp-specialised 256x160 / 256x128 with four consumer + four LDS-DMA waves;
+                                four producer waves; bitwise the results of tile_cfg 5 / 1 at equal splitk), 23..33 = pin a
+                                pre-split tile (csrc/igemm_ps.hip: 23..28 = 256x160, 256x320, 256x256, 128x320, 128x160,
+                                128x256; 29 / 30 = the warp-specialised 256x160 / 256x128 with four consumer + four LDS-DMA
+                                waves; 31..33 = 256x160, 256x128, 128x256 on four waves with 2x2 / 2x4 wave tiles;
                                 needs a_ps and w_ps, see the end of this struct).  The K-summation
                                 order depends on (tile_cfg, splitk), so a caller that needs results that are
                                 bitwise independent of the batch size pins both (ldmk_igemm_plan)          */
@@ -159,7 +162,7 @@ typedef struct ldmk_igemm_args {
   int a_split_ld;            /*   the A operand pre-split as well, three bf16 images [3][M][a_split_ld] of a0 (ldmk_ln_stats_split   */
                              /*   writes them next to the row statistics): the kernel copies instead of splitting per N-tile.        */
                              /*   Results are bitwise those of the in-kernel split.                                                  */
-  /* ---- tile_cfg 23..30 (csrc/igemm_ps.hip): LDMK_COMPUTE_BF16X3 on operands that are BOTH pre-split, in the PS layout:
+  /* ---- tile_cfg 23..33 (csrc/igemm_ps.hip): LDMK_COMPUTE_BF16X3 on operands that are BOTH pre-split, in the PS layout:
    * for a matrix X[R][K] (K % 16 == 0) plane g (0 hi, 1 mid, 2 lo) of element (r, k) is the bf16 at index
    *     (((r / 32) (K / 16) + k / 16) 3 + g) 512 + ((k / 8 % 2) 32 + r % 32) 8 + k % 8
    * i.e. per (32-row block, 16-deep k-slab) three consecutive 1-KiB planes, each in the lane order of the MFMA operand; rows
@@ -185,7 +188,7 @@ long long ldmk_ps_bytes(int rows, int k);
 int ldmk_pack_ps(const float* src, int rows, int k, long long row_stride, long long k_stride, int batch, long long src_bstride,
                  void* dst, void* stream);
 /* ldmk_ln_stats_guard and the rows themselves in the PS layout (the statistics pass reads every element anyway): what the
- * LDMK_TF_LAYERNORM_FOLDED GEMMs on tile_cfg 23..28 take as a_ps.  C % 16 == 0, C <= 1280; two-pass statistics in registers. */
+ * LDMK_TF_LAYERNORM_FOLDED GEMMs on tile_cfg 23..33 take as a_ps.  C % 16 == 0, C <= 1280; two-pass statistics in registers. */
 int ldmk_ln_stats_ps(const float* x, int rows, int c, float eps, float* stats, void* dst, float guard, int* flag, void* stream);
 
 /* w[K][ldb] fp32 (row-major, as ldmk_igemm reads it with b_trans = 0; `batch` matrices w_bstride floats apart) -> the three
