@@ -1420,13 +1420,16 @@ static int igemm_entry(const ldmk_igemm_args* args, void* stream, bool launch) {
                  "upsampling or operands beyond 4 GB)");
   }
   if (a.compute == LDMK_COMPUTE_F16X2) {
-    LDMK_REQUIRE(a.tile_cfg <= kNumCfg, "ldmk_igemm: LDMK_COMPUTE_F16X2 runs on the LDS-tiled shapes (tile_cfg 0..6), not tile_cfg=%d", a.tile_cfg);
-    LDMK_REQUIRE(a.w_split && !a.b_trans && a.w_split_ld >= a.K && a.w_split_ld % 8 == 0 && 2LL * a.N * a.w_split_ld * 2 < (1LL << 32),
-                 "ldmk_igemm: LDMK_COMPUTE_F16X2 needs w_split (ldmk_pack_wsplit_h2), b_trans = 0, w_split_ld >= K and a multiple of 8, below 4 GB");
-    LDMK_REQUIRE(a.range_flag != nullptr, "ldmk_igemm: LDMK_COMPUTE_F16X2 needs range_flag");
+    LDMK_REQUIRE(a.tile_cfg <= kNumCfg || ps_tile, "ldmk_igemm: LDMK_COMPUTE_F16X2 runs on the LDS-tiled shapes (tile_cfg 0..6) and the pre-split "
+                 "tiles (23..28, 31..33), not tile_cfg=%d", a.tile_cfg);
     LDMK_REQUIRE(!a.a_split && a.w_scale_exp >= -60 && a.w_scale_exp <= 60, "ldmk_igemm: LDMK_COMPUTE_F16X2: a_split is not taken; w_scale_exp=%d", a.w_scale_exp);
-    LDMK_REQUIRE(igemm_fast_gather_ok(a), "ldmk_igemm: LDMK_COMPUTE_F16X2 needs the fast gather (no zero-insertion, two-source upsampling or "
-                 "operands beyond 4 GB)");
+    if (!ps_tile) {
+      LDMK_REQUIRE(a.w_split && !a.b_trans && a.w_split_ld >= a.K && a.w_split_ld % 8 == 0 && 2LL * a.N * a.w_split_ld * 2 < (1LL << 32),
+                   "ldmk_igemm: LDMK_COMPUTE_F16X2 needs w_split (ldmk_pack_wsplit_h2), b_trans = 0, w_split_ld >= K and a multiple of 8, below 4 GB");
+      LDMK_REQUIRE(a.range_flag != nullptr, "ldmk_igemm: LDMK_COMPUTE_F16X2 needs range_flag");
+      LDMK_REQUIRE(igemm_fast_gather_ok(a), "ldmk_igemm: LDMK_COMPUTE_F16X2 needs the fast gather (no zero-insertion, two-source upsampling or "
+                   "operands beyond 4 GB)");
+    }
   }
   if (a.compute == LDMK_COMPUTE_BF16 && a.w_split)
     LDMK_REQUIRE(!a.b_trans && a.w_split_ld >= a.K && a.w_split_ld % 8 == 0 && (long long)a.N * a.w_split_ld * 2 < (1LL << 32) && a.batch <= 1,

@@ -56,6 +56,36 @@ __device__ __forceinline__ void ps_dma3(unsigned voff, const pu32x4& rs, unsigne
                : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
 }
 
+// PL = planes per operand: 3 (bf16x3: hi, mid, lo bf16) or 2 (F16X2: hi, lo fp16 of the operand scaled into fp16's range; the
+// same layout with 2-KiB units).  One unit = the PL planes of one 32-row block at one k-slab.
+template <int PL>
+__device__ __forceinline__ void ps_dma(unsigned voff, const pu32x4& rs, unsigned lds_dst) {
+  if constexpr (PL == 3) {
+    ps_dma3(voff, rs, lds_dst);
+  } else {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                 "buffer_load_dwordx4 %1, %2, 0 offen offset:1024 lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+  }
+}
+
+typedef _Float16 pf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+constexpr float PS_H2_SCALE = 64.f;            // 2^LDMK_F16X2_A_EXP
+__device__ __forceinline__ void ps_split2h(const float4& v, pf16x4& h, pf16x4& l) {       // v already scaled; the split of igemm.hip's split2h
+  h = pf16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  l = pf16x4{(_Float16)(v.x - (float)h[0]), (_Float16)(v.y - (float)h[1]), (_Float16)(v.z - (float)h[2]), (_Float16)(v.w - (float)h[3])};
+}
+__device__ __forceinline__ bool ps_h2_out_of_range(const float4& v) {                       // |x| >= LDMK_F16X2_RANGE, inf or NaN
+  constexpr unsigned LIM = 0x447a0000u;
+  return (__float_as_uint(v.x) & 0x7fffffffu) >= LIM || (__float_as_uint(v.y) & 0x7fffffffu) >= LIM ||
+         (__float_as_uint(v.z) & 0x7fffffffu) >= LIM || (__float_as_uint(v.w) & 0x7fffffffu) >= LIM;
+}
+__device__ __forceinline__ float4 ps_scaled(const float4& v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
+
 template <int N> __device__ __forceinline__ void ps_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 
 __device__ __forceinline__ pbf16x4 ps_bf4(const float4& v) { return pbf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w}; }
@@ -71,7 +101,7 @@ __device__ __forceinline__ void ps_split3(const float4& v, pbf16x4& h, pbf16x4& 
 __device__ __attribute__((aligned(16))) const float kPsZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
 // The epilogue of one wave: acc[TM][TN] 32x32 tiles at (rowbase, colbase).  TR: transposed accumulators (lane = row).
-template <int TM, int TN, bool TR>
+template <int TM, int TN, bool TR, int PL = 3>
 __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&acc)[TM][TN], const int rowbase, const int colbase,
                                             const int splitk, const int ks, const int bz, float* __restrict__ ws, const int lane) {
   const int l31 = lane & 31, half = lane >> 5;
@@ -117,7 +147,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
       if (lnf) { const float2 st = stats2[rr]; mean = st.x; rstd = st.y; }
       const float* __restrict__ bvp = p.batch_vec ? p.batch_vec + (long long)(rr / p.rows_per_sample) * p.batch_vec_ld : kPsZeros;
       const unsigned rowoff = (unsigned)rr * (unsigned)p.ldc;
-      const long long psrow = ((long long)((rowbase + 32 * i) >> 5) * Kbo) * 3072 + l31 * 16 + half * 8;
+      const long long psrow = ((long long)((rowbase + 32 * i) >> 5) * Kbo) * (PL * 1024) + l31 * 16 + half * 8;
       constexpr int JS = (TN % 2 == 0) ? 2 : 1;      // GEGLU (even TN only): tile j = values, tile j + 1 = gates
 #pragma unroll
       for (int j = 0; j < TN; j += JS) {
@@ -174,12 +204,20 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
               const int oc = otile + 8 * q + 4 * half;               // output column
               if (outp) *reinterpret_cast<float4*>(outp + rowoff + oc) = v;
               if (ops_) {
-                pbf16x4 h, m, l;
-                ps_split3(v, h, m, l);
-                unsigned char* d = ops_ + psrow + (long long)((otile >> 4) + (q >> 1)) * 3072 + (q & 1) * 512;
-                *reinterpret_cast<pbf16x4*>(d) = h;
-                *reinterpret_cast<pbf16x4*>(d + 1024) = m;
-                *reinterpret_cast<pbf16x4*>(d + 2048) = l;
+                unsigned char* d = ops_ + psrow + (long long)((otile >> 4) + (q >> 1)) * (PL * 1024) + (q & 1) * 512;
+                if constexpr (PL == 3) {
+                  pbf16x4 h, m, l;
+                  ps_split3(v, h, m, l);
+                  *reinterpret_cast<pbf16x4*>(d) = h;
+                  *reinterpret_cast<pbf16x4*>(d + 1024) = m;
+                  *reinterpret_cast<pbf16x4*>(d + 2048) = l;
+                } else {
+                  if (ps_h2_out_of_range(v)) *p.range_flag = 1;
+                  pf16x4 h, l;
+                  ps_split2h(ps_scaled(v, PS_H2_SCALE), h, l);
+                  *reinterpret_cast<pf16x4*>(d) = h;
+                  *reinterpret_cast<pf16x4*>(d + 1024) = l;
+                }
               }
             }
           }
@@ -302,14 +340,15 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
   }
 }
 
-template <int NWM, int NWN, int TM, int TN, int NS, bool TR>
+template <int NWM, int NWN, int TM, int TN, int NS, bool TR, int PL = 3>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int dbg) {
   constexpr int NW = NWM * NWN;
   constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN;
   constexpr int FA = BM / 32, FB = BN / 32, U = FA + FB;          // units (3-plane blocks) per stage
   constexpr int UHI = (U + NW - 1) / NW, ULO = U / NW;            // units a wave fetches per stage
-  constexpr int STAGE = U * 3072;                                   // bytes
-  static_assert(3 * UHI * (NS - 1) <= 63, "vmcnt is a 6-bit counter");
+  constexpr int UB = PL * 1024;                                     // bytes per unit
+  constexpr int STAGE = U * UB;                                     // bytes
+  static_assert(PL * UHI * (NS - 1) <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_ps[];      // [NS][STAGE]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -333,8 +372,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
 
   // (dbg, probe runs only -- LDMK_PS_DEBUG: bit 0 = zero-record descriptors: every DMA is issued but dropped by the range check,
   //  no memory traffic; bit 1 = no DMA instructions at all; bit 2 = no matrix instructions.  Results are garbage then.)
-  const pu32x4 rs_a = ps_rsrc(reinterpret_cast<const unsigned char*>(p.a_ps) + (long long)bz * p.a_ps_bstride, (dbg & 1) ? 0u : (unsigned)Mb * (unsigned)Kb * 3072u);
-  const pu32x4 rs_b = ps_rsrc(reinterpret_cast<const unsigned char*>(p.w_ps) + (long long)bz * p.w_ps_bstride, (dbg & 1) ? 0u : (unsigned)Nb * (unsigned)Kb * 3072u);
+  const pu32x4 rs_a = ps_rsrc(reinterpret_cast<const unsigned char*>(p.a_ps) + (long long)bz * p.a_ps_bstride, (dbg & 1) ? 0u : (unsigned)Mb * (unsigned)Kb * (unsigned)UB);
+  const pu32x4 rs_b = ps_rsrc(reinterpret_cast<const unsigned char*>(p.w_ps) + (long long)bz * p.w_ps_bstride, (dbg & 1) ? 0u : (unsigned)Nb * (unsigned)Kb * (unsigned)UB);
   // this wave's units u = wave + NW i: byte offset of the block's first k-slab (wave-uniform), or PS_OOB for blocks past the edge
   unsigned ubase[UHI];
 #pragma unroll
@@ -342,7 +381,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
     const int u = wave + NW * i;
     const int blk = u < FA ? m0 / 32 + u : n0 / 32 + (u - FA);
     const bool ok = u < U && (u < FA ? blk < Mb : blk < Nb);
-    ubase[i] = ok ? (unsigned)blk * (unsigned)Kb * 3072u + (unsigned)(2 * it_begin) * 3072u : PS_OOB;
+    ubase[i] = ok ? (unsigned)blk * (unsigned)Kb * (unsigned)UB + (unsigned)(2 * it_begin) * (unsigned)UB : PS_OOB;
   }
   const unsigned lane16 = lane * 16;
   const unsigned lds0 = (unsigned)(size_t)smem_ps;
@@ -353,8 +392,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
     for (int i = 0; i < UHI; ++i) {
       const int u = wave + NW * i;
       if (u < U && !(dbg & 2)) {                 // (wave-uniform)
-        const unsigned off = (live && ubase[i] != PS_OOB) ? ubase[i] + (unsigned)s * 3072u : PS_OOB;
-        ps_dma3(lane16 + off, u < FA ? rs_a : rs_b, buf + (unsigned)u * 3072u);
+        const unsigned off = (live && ubase[i] != PS_OOB) ? ubase[i] + (unsigned)s * (unsigned)UB : PS_OOB;
+        ps_dma<PL>(lane16 + off, u < FA ? rs_a : rs_b, buf + (unsigned)u * (unsigned)UB);
       }
     }
   };
@@ -385,31 +424,43 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
   for (int it = 0; it < n16; ++it) {
     // stage `it` of THIS wave has landed when all but the (NS - 2) younger stages' loads are done; the barrier then makes
     // every wave's part visible and certifies that buffer (it - 1) % NS is no longer read
-    if (hi_wave) ps_wait_vm<3 * UHI * (NS - 2)>(); else ps_wait_vm<3 * ULO * (NS - 2)>();
+    if (hi_wave) ps_wait_vm<PL * UHI * (NS - 2)>(); else ps_wait_vm<PL * ULO * (NS - 2)>();
     asm volatile("s_barrier" ::: "memory");
     issue(it + NS - 1);
     const unsigned char* sb = smem_ps + (it % NS) * STAGE + lane16;
-    pbf16x8 a8[3][TM];
+    pbf16x8 a8[PL][TM];
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < PL; ++g)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a8[g][i] = *reinterpret_cast<const pbf16x8*>(sb + ((wm * TM + i) * 3 + g) * 1024);
+      for (int i = 0; i < TM; ++i) a8[g][i] = *reinterpret_cast<const pbf16x8*>(sb + ((wm * TM + i) * PL + g) * 1024);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      pbf16x8 b8[3];
+      pbf16x8 b8[PL];
 #pragma unroll
-      for (int g = 0; g < 3; ++g) b8[g] = *reinterpret_cast<const pbf16x8*>(sb + ((FA + wn * TN + j) * 3 + g) * 1024);
+      for (int g = 0; g < PL; ++g) b8[g] = *reinterpret_cast<const pbf16x8*>(sb + ((FA + wn * TN + j) * PL + g) * 1024);
       if (dbg & 4) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int g = 0; g < 3; ++g) asm volatile("" :: "v"(a8[g][i]), "v"(b8[g]));
+          for (int g = 0; g < PL; ++g) asm volatile("" :: "v"(a8[g][i]), "v"(b8[g]));
         continue;
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        // smallest partial products first (planes: 0 = hi, 1 = mid, 2 = lo) -- the order of igemm_kernel<BF = 3>
-        if constexpr (TR) {
+        if constexpr (PL == 2) {
+          // F16X2: lo hi, hi lo, hi hi (planes: 0 = hi, 1 = lo) -- the order of igemm_kernel<BF = 4>
+          const pf16x8 ah = __builtin_bit_cast(pf16x8, a8[0][i]), al = __builtin_bit_cast(pf16x8, a8[1][i]);
+          const pf16x8 bh = __builtin_bit_cast(pf16x8, b8[0]), bl = __builtin_bit_cast(pf16x8, b8[1]);
+          if constexpr (TR) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+          }
+        } else if constexpr (TR) {       // smallest partial products first (planes: 0 = hi, 1 = mid, 2 = lo) -- the order of igemm_kernel<BF = 3>
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[0], a8[2][i], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[2], a8[0][i], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b8[1], a8[1][i], acc[i][j], 0, 0, 0);
@@ -439,7 +490,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
     if (keep == 12345.678f && ws) ws[0] = keep;
     return;
   }
-  ps_epilogue<TM, TN, TR>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+  ps_epilogue<TM, TN, TR, PL>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -624,8 +675,10 @@ __global__ __launch_bounds__(512) void igemm_pw_kernel(const ldmk_igemm_args p, 
 
 // generic packer: X[r][k] = src[r rs + k ks] (weights W[K][N]: rs = 1, ks = ldb; row-major activations: rs = ld, ks = 1).
 // Workgroup = one 32-row block x 64 k; thread = (row, 8 consecutive k): 128-byte runs on the store side.
+template <int PL>
 __global__ __launch_bounds__(256) void pack_ps_kernel(const float* __restrict__ src, int R, int K, long long rs, long long ks,
-                                                      long long src_bstride, unsigned char* __restrict__ dst, long long dst_bstride) {
+                                                      long long src_bstride, unsigned char* __restrict__ dst, long long dst_bstride,
+                                                      float scale, int* __restrict__ range_flag) {
   const int rb = blockIdx.x, kc = blockIdx.y;
   src += (long long)blockIdx.z * src_bstride;
   dst += (long long)blockIdx.z * dst_bstride;
@@ -645,21 +698,32 @@ __global__ __launch_bounds__(256) void pack_ps_kernel(const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
   }
-  pbf16x4 h0, m0, l0, h1, m1, l1;
-  ps_split3(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
-  ps_split3(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
-  unsigned char* d = dst + ((long long)rb * (K / 16) + (k0 >> 4)) * 3072 + ((o & 1) * 32 + r) * 16;
-  *reinterpret_cast<pbf16x8*>(d) = pbf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-  *reinterpret_cast<pbf16x8*>(d + 1024) = pbf16x8{m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
-  *reinterpret_cast<pbf16x8*>(d + 2048) = pbf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+  unsigned char* d = dst + ((long long)rb * (K / 16) + (k0 >> 4)) * (PL * 1024) + ((o & 1) * 32 + r) * 16;
+  if constexpr (PL == 2) {          // F16X2: the two fp16 images of scale x (activations: 2^6, range-checked; weights: 2^w_scale_exp)
+    const float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
+    if (range_flag && (ps_h2_out_of_range(v0) || ps_h2_out_of_range(v1))) *range_flag = 1;
+    pf16x4 h0, l0, h1, l1;
+    ps_split2h(ps_scaled(v0, scale), h0, l0);
+    ps_split2h(ps_scaled(v1, scale), h1, l1);
+    *reinterpret_cast<pf16x8*>(d) = pf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    *reinterpret_cast<pf16x8*>(d + 1024) = pf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+  } else {
+    pbf16x4 h0, m0, l0, h1, m1, l1;
+    ps_split3(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
+    ps_split3(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+    *reinterpret_cast<pbf16x8*>(d) = pbf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    *reinterpret_cast<pbf16x8*>(d + 1024) = pbf16x8{m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+    *reinterpret_cast<pbf16x8*>(d + 2048) = pbf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+  }
 }
 
 // LayerNorm statistics (the two-pass form of ln_stats_kernel, values held in registers) AND the rows in the PS layout: the pass
 // reads every element anyway.  Workgroup = one 32-row block; thread = (row, k-octet o of every 64-wide chunk); the 8 threads
 // of a row are 8 consecutive lanes (3 shuffle steps).  K % 16 == 0, K <= 64 KCH.
-template <int KCH>
+template <int KCH, int PL = 3>
 __global__ __launch_bounds__(256) void ln_stats_ps_kernel(const float* __restrict__ x, int rows, int K, float eps, float* __restrict__ stats,
-                                                          unsigned char* __restrict__ dst, float guard, int* __restrict__ flag) {
+                                                          unsigned char* __restrict__ dst, float guard, int* __restrict__ flag,
+                                                          int* __restrict__ range_flag) {
   const int rb = blockIdx.x;
   const int r = threadIdx.x >> 3, o = threadIdx.x & 7;
   const int row = rb * 32 + r;
@@ -704,13 +768,22 @@ __global__ __launch_bounds__(256) void ln_stats_ps_kernel(const float* __restric
   for (int c = 0; c < KCH; ++c) {
     const int k0 = c * 64 + o * 8;
     if (k0 < K) {
-      pbf16x4 h0, m0, l0, h1, m1, l1;
-      ps_split3(v[c][0], h0, m0, l0);
-      ps_split3(v[c][1], h1, m1, l1);
-      unsigned char* d = dst + ((long long)rb * (K / 16) + (k0 >> 4)) * 3072 + ((o & 1) * 32 + r) * 16;
-      *reinterpret_cast<pbf16x8*>(d) = pbf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-      *reinterpret_cast<pbf16x8*>(d + 1024) = pbf16x8{m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
-      *reinterpret_cast<pbf16x8*>(d + 2048) = pbf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+      unsigned char* d = dst + ((long long)rb * (K / 16) + (k0 >> 4)) * (PL * 1024) + ((o & 1) * 32 + r) * 16;
+      if constexpr (PL == 2) {
+        if (ps_h2_out_of_range(v[c][0]) || ps_h2_out_of_range(v[c][1])) *range_flag = 1;
+        pf16x4 h0, l0, h1, l1;
+        ps_split2h(ps_scaled(v[c][0], PS_H2_SCALE), h0, l0);
+        ps_split2h(ps_scaled(v[c][1], PS_H2_SCALE), h1, l1);
+        *reinterpret_cast<pf16x8*>(d) = pf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        *reinterpret_cast<pf16x8*>(d + 1024) = pf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+      } else {
+        pbf16x4 h0, m0, l0, h1, m1, l1;
+        ps_split3(v[c][0], h0, m0, l0);
+        ps_split3(v[c][1], h1, m1, l1);
+        *reinterpret_cast<pbf16x8*>(d) = pbf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        *reinterpret_cast<pbf16x8*>(d + 1024) = pbf16x8{m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+        *reinterpret_cast<pbf16x8*>(d + 2048) = pbf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+      }
     }
   }
 }
@@ -728,20 +801,20 @@ static const PsCfg kPsCfg[] = {{256, 160, false}, {256, 320, false}, {256, 256, 
                                // CU, whose DMA issue / barrier / epilogue phases overlap the other one's matrix work
                                {256, 160, false}, {256, 128, true}, {128, 256, true}};
 
-template <int NWM, int NWN, int TM, int TN, int NS, bool TR>
+template <int NWM, int NWN, int TM, int TN, int NS, bool TR, int PL = 3>
 static int ps_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
   constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN;
-  constexpr size_t lds = (size_t)NS * (BM / 32 + BN / 32) * 3072;
+  constexpr size_t lds = (size_t)NS * (BM / 32 + BN / 32) * PL * 1024;
   static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR, PL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   static const int dbg = (getenv("LDMK_PS_DEBUG") ? atoi(getenv("LDMK_PS_DEBUG")) : 0) | ((getenv("LDMK_PS_STAGGER") ? atoi(getenv("LDMK_PS_STAGGER")) : 0) << 8);
-  hipLaunchKernelGGL((igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR>), dim3(tiles, splitk, a.batch > 1 ? a.batch : 1), dim3(64 * NWM * NWN), lds,
+  hipLaunchKernelGGL((igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR, PL>), dim3(tiles, splitk, a.batch > 1 ? a.batch : 1), dim3(64 * NWM * NWN), lds,
                      st, a, splitk, ws, dbg);
   if (splitk > 1 && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
   return check_launch("ldmk_igemm(ps)");
@@ -765,14 +838,17 @@ static int pw_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_
 }
 
 const char* igemm_ps_unsupported(const ldmk_igemm_args& a, int pcfg, int splitk) {
-  if (a.compute != LDMK_COMPUTE_BF16X3) return "the pre-split tiles run the bf16x3 arithmetic only (compute)";
+  if (a.compute != LDMK_COMPUTE_BF16X3 && a.compute != LDMK_COMPUTE_F16X2) return "the pre-split tiles run the bf16x3 and the f16x2 arithmetic (compute)";
+  const int pl = a.compute == LDMK_COMPUTE_F16X2 ? 2 : 3;
+  if (pl == 2 && (pcfg == 6 || pcfg == 7)) return "the warp-specialised pre-split tiles (29 / 30) exist in the bf16x3 arithmetic only";
+  if (pl == 2 && a.out_ps && !a.range_flag) return "out_ps in the f16x2 arithmetic needs range_flag";
   if (!a.a_ps || !a.w_ps) return "a_ps / w_ps (operands in the PS layout: ldmk_pack_ps, ldmk_ln_stats_ps, out_ps of a producer GEMM)";
   if (a.a_mode != LDMK_A_ROWS) return "rows mode only";
   if (a.b_trans || a.upsample || a.skip_a0 || (a.splitk_counters && !getenv("LDMK_PS_DEBUG"))) return "b_trans / upsample / fused skip / in-launch combine";
   if (a.a_tf != LDMK_TF_NONE && a.a_tf != LDMK_TF_LAYERNORM_FOLDED) return "no staging prologue: a_ps is what gets multiplied";
   if (a.K % 32 || a.N % 32) return "K and N must be multiples of 32";
   const long long kb = a.K / 16;
-  if ((long long)((a.M + 31) / 32) * kb * 3072 >= (1LL << 31) || (long long)(a.N / 32) * kb * 3072 >= (1LL << 31)) return "an operand of 2 GiB or more";
+  if ((long long)((a.M + 31) / 32) * kb * pl * 1024 >= (1LL << 31) || (long long)(a.N / 32) * kb * pl * 1024 >= (1LL << 31)) return "an operand of 2 GiB or more";
   if (a.epi == LDMK_EPI_GEGLU && (!kPsCfg[pcfg].even_tn || splitk > 1)) return "GEGLU needs a tile of (value, gate) pairs (256x256, 128x256) and no split-K";
   if (splitk > a.K / 32) return "more K slices than 32-deep chunks";
   if (a.out_ps) {
@@ -788,6 +864,19 @@ const char* igemm_ps_unsupported(const ldmk_igemm_args& a, int pcfg, int splitk)
 int igemm_ps_dispatch(const ldmk_igemm_args& a, int pcfg, int splitk, float* ws, hipStream_t st) {
   // the transposed epilogue serves every call but those that want GroupNorm records
   const bool tr = !a.stats_out;
+  if (a.compute == LDMK_COMPUTE_F16X2) {       // two fp16 planes per operand, three matrix instructions per product; one more ring stage fits
+    switch (pcfg) {
+      case 0: return tr ? ps_launch<8, 1, 1, 5, 3, true, 2>(a, splitk, ws, st) : ps_launch<8, 1, 1, 5, 3, false, 2>(a, splitk, ws, st);
+      case 1: return tr ? ps_launch<4, 2, 2, 5, 3, true, 2>(a, splitk, ws, st) : ps_launch<4, 2, 2, 5, 3, false, 2>(a, splitk, ws, st);
+      case 2: return tr ? ps_launch<4, 2, 2, 4, 3, true, 2>(a, splitk, ws, st) : ps_launch<4, 2, 2, 4, 3, false, 2>(a, splitk, ws, st);
+      case 3: return tr ? ps_launch<4, 2, 1, 5, 3, true, 2>(a, splitk, ws, st) : ps_launch<4, 2, 1, 5, 3, false, 2>(a, splitk, ws, st);
+      case 4: return tr ? ps_launch<4, 1, 1, 5, 3, true, 2>(a, splitk, ws, st) : ps_launch<4, 1, 1, 5, 3, false, 2>(a, splitk, ws, st);
+      case 8: return tr ? ps_launch<4, 1, 2, 5, 3, true, 2>(a, splitk, ws, st) : ps_launch<4, 1, 2, 5, 3, false, 2>(a, splitk, ws, st);
+      case 9: return tr ? ps_launch<4, 1, 2, 4, 3, true, 2>(a, splitk, ws, st) : ps_launch<4, 1, 2, 4, 3, false, 2>(a, splitk, ws, st);
+      case 10: return tr ? ps_launch<2, 2, 2, 4, 3, true, 2>(a, splitk, ws, st) : ps_launch<2, 2, 2, 4, 3, false, 2>(a, splitk, ws, st);
+      default: return tr ? ps_launch<4, 2, 1, 4, 3, true, 2>(a, splitk, ws, st) : ps_launch<4, 2, 1, 4, 3, false, 2>(a, splitk, ws, st);
+    }
+  }
   switch (pcfg) {
     case 0: return tr ? ps_launch<8, 1, 1, 5, 3, true>(a, splitk, ws, st) : ps_launch<8, 1, 1, 5, 3, false>(a, splitk, ws, st);
     case 1: return tr ? ps_launch<4, 2, 2, 5, 2, true>(a, splitk, ws, st) : ps_launch<4, 2, 2, 5, 2, false>(a, splitk, ws, st);
@@ -810,6 +899,11 @@ extern "C" long long ldmk_ps_bytes(int rows, int k) {
   return (long long)((rows + 31) / 32) * (k / 16) * 3072;
 }
 
+extern "C" long long ldmk_ps_bytes_h2(int rows, int k) {
+  if (rows <= 0 || k <= 0 || k % 16) return -1;
+  return (long long)((rows + 31) / 32) * (k / 16) * 2048;
+}
+
 extern "C" int ldmk_pack_ps(const float* src, int rows, int k, long long row_stride, long long k_stride, int batch, long long src_bstride,
                             void* dst, void* stream) {
   LDMK_ENTER();
@@ -819,9 +913,25 @@ extern "C" int ldmk_pack_ps(const float* src, int rows, int k, long long row_str
   LDMK_REQUIRE(k_stride != 1 || (row_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && src_bstride % 4 == 0),
                "ldmk_pack_ps: row-major sources are read as float4 (16-byte aligned rows)");
   const long long bytes = ldmk_ps_bytes(rows, k);
-  hipLaunchKernelGGL(pack_ps_kernel, dim3((rows + 31) / 32, (k + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, src, rows, k, row_stride,
-                     k_stride, src_bstride, reinterpret_cast<unsigned char*>(dst), bytes);
+  hipLaunchKernelGGL(pack_ps_kernel<3>, dim3((rows + 31) / 32, (k + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, src, rows, k, row_stride,
+                     k_stride, src_bstride, reinterpret_cast<unsigned char*>(dst), bytes, 1.0f, (int*)nullptr);
   return check_launch("ldmk_pack_ps");
+}
+
+extern "C" int ldmk_pack_ps_h2(const float* src, int rows, int k, long long row_stride, long long k_stride, int batch, long long src_bstride,
+                               int scale_exp, int* range_flag, void* dst, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(src && dst && rows > 0 && k > 0 && batch >= 1, "ldmk_pack_ps_h2: bad args");
+  LDMK_REQUIRE(k % 16 == 0, "ldmk_pack_ps_h2: k=%d must be a multiple of 16", k);
+  LDMK_REQUIRE(k_stride != 1 || (row_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && src_bstride % 4 == 0),
+               "ldmk_pack_ps_h2: row-major sources are read as float4 (16-byte aligned rows)");
+  LDMK_REQUIRE(scale_exp >= -60 && scale_exp <= 60, "ldmk_pack_ps_h2: scale_exp=%d outside [-60, 60]", scale_exp);
+  LDMK_REQUIRE(!range_flag || scale_exp == LDMK_F16X2_A_EXP, "ldmk_pack_ps_h2: range_flag is the activations' check: scale_exp must be %d", LDMK_F16X2_A_EXP);
+  const long long bytes = ldmk_ps_bytes_h2(rows, k);
+  hipLaunchKernelGGL(pack_ps_kernel<2>, dim3((rows + 31) / 32, (k + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, src, rows, k, row_stride,
+                     k_stride, src_bstride, reinterpret_cast<unsigned char*>(dst), bytes, ldexpf(1.f, scale_exp), range_flag);
+  return check_launch("ldmk_pack_ps_h2");
 }
 
 extern "C" int ldmk_ln_stats_ps(const float* x, int rows, int c, float eps, float* stats, void* dst, float guard, int* flag, void* stream) {
@@ -833,9 +943,27 @@ extern "C" int ldmk_ln_stats_ps(const float* x, int rows, int c, float eps, floa
   const dim3 grid((rows + 31) / 32);
   unsigned char* d = reinterpret_cast<unsigned char*>(dst);
   hipStream_t st = (hipStream_t)stream;
-  if (c <= 192) hipLaunchKernelGGL(ln_stats_ps_kernel<3>, grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag);
-  else if (c <= 320) hipLaunchKernelGGL(ln_stats_ps_kernel<5>, grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag);
-  else if (c <= 640) hipLaunchKernelGGL(ln_stats_ps_kernel<10>, grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag);
-  else hipLaunchKernelGGL(ln_stats_ps_kernel<20>, grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag);
+  int* nf = nullptr;
+  if (c <= 192) hipLaunchKernelGGL(ln_stats_ps_kernel<3>, grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag, nf);
+  else if (c <= 320) hipLaunchKernelGGL(ln_stats_ps_kernel<5>, grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag, nf);
+  else if (c <= 640) hipLaunchKernelGGL(ln_stats_ps_kernel<10>, grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag, nf);
+  else hipLaunchKernelGGL(ln_stats_ps_kernel<20>, grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag, nf);
   return check_launch("ldmk_ln_stats_ps");
+}
+
+extern "C" int ldmk_ln_stats_ps_h2(const float* x, int rows, int c, float eps, float* stats, void* dst, float guard, int* flag, int* range_flag,
+                                   void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(x && stats && dst && range_flag && rows > 0 && c > 0, "ldmk_ln_stats_ps_h2: bad args");
+  LDMK_REQUIRE(c % 16 == 0 && c <= 1280, "ldmk_ln_stats_ps_h2: C=%d must be a multiple of 16, at most 1280", c);
+  LDMK_REQUIRE(!flag || guard > 0.f, "ldmk_ln_stats_ps_h2: guard=%g must be positive", (double)guard);
+  const dim3 grid((rows + 31) / 32);
+  unsigned char* d = reinterpret_cast<unsigned char*>(dst);
+  hipStream_t st = (hipStream_t)stream;
+  if (c <= 192) hipLaunchKernelGGL((ln_stats_ps_kernel<3, 2>), grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag, range_flag);
+  else if (c <= 320) hipLaunchKernelGGL((ln_stats_ps_kernel<5, 2>), grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag, range_flag);
+  else if (c <= 640) hipLaunchKernelGGL((ln_stats_ps_kernel<10, 2>), grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag, range_flag);
+  else hipLaunchKernelGGL((ln_stats_ps_kernel<20, 2>), grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag, range_flag);
+  return check_launch("ldmk_ln_stats_ps_h2");
 }

@@ -147,6 +147,30 @@ def ps_enabled():
     return split_enabled() and os.environ.get("LDMK_PS", "1") != "0"
 
 
+_PS_H2_TABLE = None
+
+
+def ps_h2_table():
+    """The same for the F16X2 form of the pre-split tiles (dsml_thesis_amd/igemm_plans_ps_h2.json; LDMK_PS_H2_TABLE overrides)."""
+    global _PS_H2_TABLE
+    if _PS_H2_TABLE is None:
+        import json
+        path = os.environ.get("LDMK_PS_H2_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans_ps_h2.json")
+        _PS_H2_TABLE = {}
+        if os.path.exists(path) and ps_enabled() and f16x2_enabled():
+            try:
+                with open(path) as fh:
+                    raw = json.load(fh)
+            except Exception:
+                raw = {}
+            for k, (cfg, sk) in raw.items():
+                m, rest = k.split(",", 1)
+                _PS_H2_TABLE.setdefault(rest, []).append((int(m), int(cfg), int(sk)))
+            for v in _PS_H2_TABLE.values():
+                v.sort()
+    return _PS_H2_TABLE
+
+
 def ps_table():
     """{shape key: [(M, cfg, splitk)]}: GEMM shapes measured faster on the pre-split tiles than on their best other plan
     (dsml_thesis_amd/igemm_plans_ps.json; LDMK_PS_TABLE overrides the path).  Same key as the other tables (plan_key)."""
@@ -169,10 +193,10 @@ def ps_table():
     return _PS_TABLE
 
 
-def ps_plan(rest, m):
+def ps_plan(rest, m, h2=False):
     """(cfg, splitk) of the pre-split plan for the shape key `rest` ("N,K,mode,tf,epi,batch") at m rows, or None: exact or within
-    2x of a measured row count, like x3_plan."""
-    rows = ps_table().get(rest)
+    2x of a measured row count, like x3_plan.  h2: the table of the F16X2 form."""
+    rows = (ps_h2_table() if h2 else ps_table()).get(rest)
     if not rows:
         return None
     best = min(rows, key=lambda r: (abs(math.log(r[0] / m)), r[0]))
@@ -225,8 +249,9 @@ class Program:
             self._free.setdefault((t.numel(), t.dtype), []).append(t.reshape(-1))
 
     def alloc_ps(self, rows, k, batch=1):
-        """A pool buffer for a [rows][k] matrix (x batch) in the PS layout (include/ldmk.h): uint8 [batch * ldmk_ps_bytes]."""
-        nb = self.lib.ldmk_ps_bytes(int(rows), int(k))
+        """A pool buffer for a [rows][k] matrix (x batch) in the PS layout (include/ldmk.h): uint8 [batch * ldmk_ps_bytes]; the
+        two-plane F16X2 form while the program runs in that arithmetic (h2_flag)."""
+        nb = (self.lib.ldmk_ps_bytes_h2 if getattr(self, "h2_flag", None) is not None else self.lib.ldmk_ps_bytes)(int(rows), int(k))
         assert nb > 0, (rows, k)
         return self.alloc(int(batch) * nb, dtype=torch.uint8)
 
@@ -352,7 +377,7 @@ class Program:
         """Record a GEMM on a pre-split tile (args carry a_ps / w_ps; the plan comes from the PS table, decided by the caller
         BEFORE it had the producer write the A operand in that layout)."""
         args.tile_cfg, args.splitk = int(cfg), max(1, int(sk))
-        args.compute = L.COMPUTE_BF16X3
+        assert args.compute in (L.COMPUTE_BF16X3, L.COMPUTE_F16X2)       # (set by ops.make_igemm_args from the form of w_ps)
         if args.splitk > 1:
             ws = self.splitk_workspace(max(1, args.batch) * args.splitk * args.M * args.N)
             args.splitk_ws, args.splitk_ws_elems = ws.data_ptr(), ws.numel()
@@ -612,14 +637,11 @@ class NetBuilder:
         producer writes the operand in the PS layout."""
         if not ps_enabled():
             return None
-        # (with the F16X2 arithmetic on, the LDS-tiled kernels in it replace the bf16x3 pre-split tiles: three matrix instructions
-        #  per product instead of six; LDMK_PS_WITH_F16X2=1 keeps the pre-split plans for the A/B)
-        if getattr(self.pg, "h2_flag", None) is not None and os.environ.get("LDMK_PS_WITH_F16X2", "0") != "1":
-            return None
         m = M
         if self.pin is not None and self.pin[0] != self.pin[1] and per_sample:
             m = max(1, M * self.pin[0] // self.pin[1])
-        return ps_plan(f"{N},{K},{L.A_ROWS},{tf},{epi},{max(1, batch)}", m)
+        # (a program in the F16X2 arithmetic has its own table: its operands are two fp16 planes, not three bf16 ones)
+        return ps_plan(f"{N},{K},{L.A_ROWS},{tf},{epi},{max(1, batch)}", m, h2=getattr(self.pg, "h2_flag", None) is not None)
 
     def lin_ps(self, plan, M, K, a_ps, wp, w_ps, bias, rows_per_sample, out=None, out_ps=None, geglu=False, stats=False, **kw):
         """Linear on a pre-split tile: a_ps = the [M][K] input in the PS layout, w_ps = ops.pack_wps(wp).  `out` None with out_ps
@@ -630,7 +652,8 @@ class NetBuilder:
         if out is None and out_ps is None:
             out = pg.alloc(M, ncol)
         a = ops.make_igemm_args(M, N, K, None, K, wp, out, ncol, rows_per_sample, bias=bias,
-                                epi=L.EPI_GEGLU if geglu else L.EPI_NONE, a_ps=a_ps, w_ps=w_ps, out_ps=out_ps, **kw)
+                                epi=L.EPI_GEGLU if geglu else L.EPI_NONE, a_ps=a_ps, w_ps=w_ps, out_ps=out_ps,
+                                range_flag=getattr(pg, "h2_flag", None), **kw)
         if out is not None:
             self._maybe_stats(a, out, rows_per_sample, stats)
         pg.igemm_ps(a, *plan)

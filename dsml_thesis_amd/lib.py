@@ -95,6 +95,9 @@ _SIGS = {
     "ldmk_ln_stats_guard": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, C.c_float, _fp, _fp]),
     "ldmk_ps_bytes": (C.c_longlong, [C.c_int, C.c_int]),
     "ldmk_pack_ps": (C.c_int, [_fp, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_longlong, _fp, _fp]),
+    "ldmk_ps_bytes_h2": (C.c_longlong, [C.c_int, C.c_int]),
+    "ldmk_pack_ps_h2": (C.c_int, [_fp, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_longlong, C.c_int, _fp, _fp, _fp]),
+    "ldmk_ln_stats_ps_h2": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp, C.c_float, _fp, _fp, _fp]),
     "ldmk_ln_stats_ps": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp, C.c_float, _fp, _fp]),
     "ldmk_ln_stats_split": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp, C.c_int, _fp]),
     "ldmk_gn_apply": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),

@@ -124,47 +124,84 @@ def ln_stats(x2d, eps=1e-5, out=None, split=None):
 PS_TILE0 = 23                     # tile_cfg of the first pre-split tile (256x160); 24: 256x320, 25: 256x256, 26: 128x320, 27: 128x160, 28: 128x256
 
 
-def ps_empty(rows, k, batch=1, device="cuda"):
-    """Uninitialised PS-layout buffer(s) for a [rows][k] matrix: uint8 [batch][ldmk_ps_bytes]."""
-    nb = L.load().ldmk_ps_bytes(int(rows), int(k))
+def ps_empty(rows, k, batch=1, device="cuda", h2=False):
+    """Uninitialised PS-layout buffer(s) for a [rows][k] matrix: uint8 [batch][ldmk_ps_bytes] (h2: the two-plane fp16 form of the
+    F16X2 arithmetic, ldmk_ps_bytes_h2)."""
+    nb = (L.load().ldmk_ps_bytes_h2 if h2 else L.load().ldmk_ps_bytes)(int(rows), int(k))
     assert nb > 0, (rows, k)
     return torch.empty(batch, nb, device=device, dtype=torch.uint8)
 
 
-def pack_ps(x, out=None):
-    """x: fp32 [rows][k] (or [batch][rows][k]) row-major on the GPU -> the PS layout of its exact three-way bf16 split."""
+F16X2_A_EXP = 6                   # LDMK_F16X2_A_EXP: activations are scaled by 2^6 in the F16X2 arithmetic
+
+
+def pack_ps(x, out=None, h2_flag=None):
+    """x: fp32 [rows][k] (or [batch][rows][k]) row-major on the GPU -> the PS layout of its exact three-way bf16 split; with h2_flag
+    (device int32 range flag): the two fp16 planes of 2^6 x (F16X2)."""
     batch = x.shape[0] if x.dim() == 3 else 1
     rows, k = x.shape[-2], x.shape[-1]
     assert x.is_contiguous()
     if out is None:
-        out = ps_empty(rows, k, batch, x.device)
-    L.call("ldmk_pack_ps", _ptr(x), rows, k, k, 1, batch, rows * k, _ptr(out), stream())
+        out = ps_empty(rows, k, batch, x.device, h2=h2_flag is not None)
+    if h2_flag is not None:
+        L.call("ldmk_pack_ps_h2", _ptr(x), rows, k, k, 1, batch, rows * k, F16X2_A_EXP, _ptr(h2_flag), _ptr(out), stream())
+    else:
+        L.call("ldmk_pack_ps", _ptr(x), rows, k, k, 1, batch, rows * k, _ptr(out), stream())
     return out
 
 
-def pack_wps(w, batch=1):
+_WPS_H2_EXP = {}                  # data_ptr of an F16X2 PS weight image -> (weakref, scale exponent)
+
+
+def h2_scale_exp(w):
+    """The exponent e with max |2^e w| in [2^13, 2^14) (one host read of max |w|)."""
+    import math
+    mx = float(w.abs().max().item())
+    e = 13 - math.floor(math.log2(mx)) if mx > 0.0 and math.isfinite(mx) else 0
+    return max(-60, min(60, e))
+
+
+def pack_wps(w, batch=1, h2=False):
     """Packed weights w[K][N] (pack_linear / pack_conv3x3 layout; or [batch][K][N]) -> PS layout of X[N][K] (row = output column):
-    the w_ps operand of the pre-split tiles."""
+    the w_ps operand of the pre-split tiles.  h2: the two fp16 planes of 2^e w, e per matrix (remembered for make_igemm_args)."""
     if batch > 1:
         assert w.dim() == 3 and w.shape[0] == batch and w.is_contiguous()
         K, N = w.shape[1], w.shape[2]
     else:
         assert w.dim() == 2 and w.is_contiguous()
         K, N = w.shape
-    out = ps_empty(N, K, batch, w.device)
-    L.call("ldmk_pack_ps", _ptr(w), N, K, 1, N, batch, K * N, _ptr(out), stream())
+    out = ps_empty(N, K, batch, w.device, h2=h2)
+    if h2:
+        e = h2_scale_exp(w)
+        L.call("ldmk_pack_ps_h2", _ptr(w), N, K, 1, N, batch, K * N, e, 0, _ptr(out), stream())
+        ptr = out.data_ptr()
+        _WPS_H2_EXP[ptr] = (weakref.ref(out), e)
+        weakref.finalize(out, _WPS_H2_EXP.pop, ptr, None)
+    else:
+        L.call("ldmk_pack_ps", _ptr(w), N, K, 1, N, batch, K * N, _ptr(out), stream())
     return out
 
 
-def ln_stats_ps(x2d, eps=1e-5, out=None, ps=None, guard=0.0, flag=None):
-    """LayerNorm (mean, rstd) per row AND the rows in the PS layout (one pass); returns (stats, ps)."""
+def ln_stats_ps(x2d, eps=1e-5, out=None, ps=None, guard=0.0, flag=None, h2_flag=None):
+    """LayerNorm (mean, rstd) per row AND the rows in the PS layout (one pass); returns (stats, ps).  h2_flag: the F16X2 planes."""
     rows, c = x2d.shape
     if out is None:
         out = torch.empty(rows, 2, device=x2d.device, dtype=torch.float32)
     if ps is None:
-        ps = ps_empty(rows, c, 1, x2d.device)
-    L.call("ldmk_ln_stats_ps", _ptr(x2d), rows, c, float(eps), _ptr(out), _ptr(ps), float(guard), _ptr(flag), stream())
+        ps = ps_empty(rows, c, 1, x2d.device, h2=h2_flag is not None)
+    if h2_flag is not None:
+        L.call("ldmk_ln_stats_ps_h2", _ptr(x2d), rows, c, float(eps), _ptr(out), _ptr(ps), float(guard), _ptr(flag), _ptr(h2_flag), stream())
+    else:
+        L.call("ldmk_ln_stats_ps", _ptr(x2d), rows, c, float(eps), _ptr(out), _ptr(ps), float(guard), _ptr(flag), stream())
     return out, ps
+
+
+def unpack_ps_h2(ps, rows, k):
+    """Test helper: F16X2 PS layout -> (hi, lo) float32 [rows][k] tensors of the SCALED operand."""
+    nb = (rows + 31) // 32
+    t = ps.reshape(-1).view(torch.float16).reshape(nb, k // 16, 2, 2, 32, 8)
+    t = t.permute(2, 0, 4, 1, 3, 5).reshape(2, nb * 32, k)[:, :rows]
+    return t[0].float(), t[1].float()
 
 
 def unpack_ps(ps, rows, k):
@@ -245,11 +282,16 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
         a.w_split, a.w_split_ld = _ptr(w_bf16t), w_bf16t.shape[-1]
     if a_split is not None:       # [3][M][ld] bf16 images of a0 (ln_stats(..., split=...)); used by the bf16x3 LDS-tiled plans only
         a.a_split, a.a_split_ld = _ptr(a_split), a_split.shape[-1]
-    if a_ps is not None:          # pre-split tiles (tile_cfg 23..28): both operands in the PS layout
+    if a_ps is not None:          # pre-split tiles (tile_cfg 23..33): both operands in the PS layout
         a.a_ps, a.w_ps, a.out_ps = _ptr(a_ps), _ptr(w_ps), _ptr(out_ps)
         if batch > 1:
             a.a_ps_bstride, a.w_ps_bstride = a_ps.shape[-1], w_ps.shape[-1]
-        a.compute = L.COMPUTE_BF16X3
+        hit = _WPS_H2_EXP.get(w_ps.data_ptr())
+        if hit is not None and hit[0]() is w_ps:        # F16X2 planes (pack_wps(h2=True)): a_ps / out_ps are in that form too
+            a.compute, a.w_scale_exp, a.range_flag = L.COMPUTE_F16X2, hit[1], _ptr(range_flag)
+            a._keep = a._keep + (range_flag,)
+        else:
+            a.compute = L.COMPUTE_BF16X3
         return a
     if compute == L.COMPUTE_BF16X3 and not set_split(a):
         raise ValueError("COMPUTE_BF16X3: no split images registered for this weight (ops.pack_wsplit) or b_trans set")

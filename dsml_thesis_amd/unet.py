@@ -238,6 +238,12 @@ def pack_gemm_copies(P, unfolded=False):
                 P[k + "#p"] = ops.pack_wps(P[k])
             elif tail in ("c1#wg", "c2#wg", "w#up") and P[k].shape[1] % 32 == 0 and P[k].shape[2] % 32 == 0:
                 P[k + "#p"] = ops.pack_wps(P[k], batch=P[k].shape[0])     # Winograd planes / upsampling phases (transforms write V in PS)
+        # ... and in the two-plane fp16 form of the F16X2 arithmetic (`#p2`; a program takes the form of its arithmetic)
+        if f16x2_enabled():
+            for k in list(P):
+                tail = k.rsplit(".", 1)[-1]
+                if tail in ("qkv_ln", "ff1_ln", "ff2", "pout") and P[k].dim() == 2 and P[k].shape[0] % 32 == 0 and P[k].shape[1] % 32 == 0:
+                    P[k + "#p2"] = ops.pack_wps(P[k], h2=True)
 
 
 def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_in, context_dim, unfolded=False, ln_flag=None):
@@ -259,6 +265,9 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
     nb_.release(coef)
     stats = pg.alloc(rows, 2)
 
+    h2_flag = getattr(nb_, "h2_flag", None)
+    psfx = "#p2" if h2_flag is not None else "#p"       # the PS weight copies in the form of the program's arithmetic
+
     def ln_lin(x2d, wkey, geglu, out_ps=None):
         """LayerNorm statistics + the Linear the LayerNorm is folded through.  With a pre-split plan for the GEMM
         (engine.ps_query: csrc/igemm_ps.hip) the statistics pass also writes the rows in the PS layout and the GEMM moves them
@@ -266,11 +275,14 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
         `out_ps`: (GEGLU only) the result goes out in the PS layout ONLY, for ff.net.2."""
         wp = P[wkey]
         N_ = wp.shape[1]
-        plan = nb_.ps_query(rows, N_, C_, tf=L.TF_LAYERNORM_FOLDED, epi=L.EPI_GEGLU if geglu else L.EPI_NONE) if wkey + "#p" in P else None
+        plan = nb_.ps_query(rows, N_, C_, tf=L.TF_LAYERNORM_FOLDED, epi=L.EPI_GEGLU if geglu else L.EPI_NONE) if wkey + psfx in P else None
         if plan is not None:
             xs = pg.alloc_ps(rows, C_)
-            pg.add("ldmk_ln_stats_ps", p_(x2d), rows, C_, 1e-5, p_(stats), p_(xs), LN_GUARD_RATIO, p_(ln_flag))
-            y = nb_.lin_ps(plan, rows, C_, xs, wp, P[wkey + "#p"], P[wkey + "#b"], hw, geglu=geglu, out_ps=out_ps,
+            if h2_flag is not None:
+                pg.add("ldmk_ln_stats_ps_h2", p_(x2d), rows, C_, 1e-5, p_(stats), p_(xs), LN_GUARD_RATIO, p_(ln_flag), p_(h2_flag))
+            else:
+                pg.add("ldmk_ln_stats_ps", p_(x2d), rows, C_, 1e-5, p_(stats), p_(xs), LN_GUARD_RATIO, p_(ln_flag))
+            y = nb_.lin_ps(plan, rows, C_, xs, wp, P[wkey + psfx], P[wkey + "#b"], hw, geglu=geglu, out_ps=out_ps,
                            tf=L.TF_LAYERNORM_FOLDED, row_stats=stats, ln_colsum=P[wkey + "#cs"])
             nb_.release(xs)
             return y
@@ -292,7 +304,7 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
         # both attention products in the fp32-accurate bf16x3 arithmetic (24 bf16 MFMAs of 32 cycles per 32 keys
         # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel.  With a pre-split plan for
         # attn1.to_out the attention kernel writes its result in the PS layout only (from its accumulators, no LDS pass)
-        plan_o = (nb_.ps_query(rows, C_, C_) if (q + "o1#p" in P and L_ctx == 1 and hw % 32 == 0 and attention_presplit(hw)) else None)
+        plan_o = (nb_.ps_query(rows, C_, C_) if (h2_flag is None and q + "o1#p" in P and L_ctx == 1 and hw % 32 == 0 and attention_presplit(hw)) else None)
         att = None if plan_o is not None else pg.alloc(rows, C_)
         att_ps = pg.alloc_ps(rows, C_) if plan_o is not None else None
         emit_self_attention(nb_, qkv, att, hw, m.heads, m.d_head, att_ps=att_ps)
@@ -341,7 +353,7 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
         # layout only -- written by the GEGLU epilogue, split once -- never as an fp32 tensor
         Nf = P[q + "ff2"].shape[0]
         plan_g = plan_f = None
-        if not unfolded and q + "ff1_ln#p" in P and q + "ff2#p" in P:
+        if not unfolded and q + "ff1_ln" + psfx in P and q + "ff2" + psfx in P:
             plan_g = nb_.ps_query(rows, 2 * Nf, C_, tf=L.TF_LAYERNORM_FOLDED, epi=L.EPI_GEGLU)
             plan_f = nb_.ps_query(rows, C_, Nf)
         if plan_g is not None and plan_f is not None:
@@ -349,9 +361,9 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
             ln_lin(h2, q + "ff1_ln", True, out_ps=f_ps)
             # the last block's ff.net.2 also writes its result pre-split when proj_out runs on a pre-split tile
             last = d == m.depth - 1
-            plan_p = nb_.ps_query(rows, m.ch, C_) if (last and prefix + "pout#p" in P and plan_f[1] <= 1) else None   # (a split-K ff.net.2 has no PS epilogue)
+            plan_p = nb_.ps_query(rows, m.ch, C_) if (last and prefix + "pout" + psfx in P and plan_f[1] <= 1) else None   # (a split-K ff.net.2 has no PS epilogue)
             hc_ps = pg.alloc_ps(rows, C_) if plan_p is not None else None
-            hcur = nb_.lin_ps(plan_f, rows, Nf, f_ps, P[q + "ff2"], P[q + "ff2#p"], sd[q + "ff.net.2.bias"], hw, out=h2, residual=h2,
+            hcur = nb_.lin_ps(plan_f, rows, Nf, f_ps, P[q + "ff2"], P[q + "ff2" + psfx], sd[q + "ff.net.2.bias"], hw, out=h2, residual=h2,
                               out_ps=hc_ps)
             nb_.release(f_ps)
         else:
@@ -364,7 +376,7 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
             hcur = lin(f, P[q + "ff2"], sd[q + "ff.net.2.bias"], hw, residual=h2, out=h2, wf=P.get(q + "ff2#f"))
             nb_.release(f)
     if hc_ps is not None:
-        out = nb_.lin_ps(plan_p, rows, C_, hc_ps, P[prefix + "pout"], P[prefix + "pout#p"], sd[prefix + "proj_out.bias"], hw, residual=xr,
+        out = nb_.lin_ps(plan_p, rows, C_, hc_ps, P[prefix + "pout"], P[prefix + "pout" + psfx], sd[prefix + "proj_out.bias"], hw, residual=xr,
                          stats=True)
         nb_.release(hc_ps)
     else:

@@ -191,6 +191,17 @@ int ldmk_pack_ps(const float* src, int rows, int k, long long row_stride, long l
  * LDMK_TF_LAYERNORM_FOLDED GEMMs on tile_cfg 23..33 take as a_ps.  C % 16 == 0, C <= 1280; two-pass statistics in registers. */
 int ldmk_ln_stats_ps(const float* x, int rows, int c, float eps, float* stats, void* dst, float guard, int* flag, void* stream);
 
+/* The PS layout of the F16X2 arithmetic: the same index arithmetic with TWO fp16 planes (hi, lo of 2^e x) per unit -- 2-KiB units,
+ * ldmk_ps_bytes_h2 bytes.  tile_cfg 23..28 / 31..33 with compute = LDMK_COMPUTE_F16X2 take a_ps / w_ps (and write out_ps) in this
+ * form: activations scaled by 2^LDMK_F16X2_A_EXP by their producers, which also raise range_flag (ldmk_pack_ps_h2 with
+ * scale_exp = LDMK_F16X2_A_EXP and a flag, ldmk_ln_stats_ps_h2, a GEMM's out_ps); weights by 2^w_scale_exp (ldmk_pack_ps_h2 with
+ * range_flag = NULL).  Same products in the same order as tile_cfg 1 / 5 in that arithmetic: bitwise equal results. */
+long long ldmk_ps_bytes_h2(int rows, int k);
+int ldmk_pack_ps_h2(const float* src, int rows, int k, long long row_stride, long long k_stride, int batch, long long src_bstride,
+                    int scale_exp, int* range_flag, void* dst, void* stream);
+int ldmk_ln_stats_ps_h2(const float* x, int rows, int c, float eps, float* stats, void* dst, float guard, int* flag, int* range_flag,
+                        void* stream);
+
 /* w[K][ldb] fp32 (row-major, as ldmk_igemm reads it with b_trans = 0; `batch` matrices w_bstride floats apart) -> the three
  * bf16 images [batch][3][N][ld_out] of its exact three-way split, transposed so that every output column's K run is
  * contiguous.  ld_out >= K, a multiple of 8; columns K..ld_out-1 are zero-filled. */

@@ -245,3 +245,111 @@ def test_f16x2_rejects_what_it_cannot_run(ops):
         assert L.load().ldmk_igemm_check(ctypes.byref(a)) != 0
     a = ops.make_igemm_args(64, 64, 64, x, 64, w, out, 64, 64, compute=L.COMPUTE_F16X2, range_flag=flag, tile_cfg=5)
     assert L.load().ldmk_igemm_check(ctypes.byref(a)) == 0
+
+
+# ---- the pre-split tiles in F16X2 (csrc/igemm_ps.hip, PL = 2): two fp16 planes per operand in 2-KiB units, LDS-DMA, three products
+@pytest.mark.parametrize("rows,k", [(64, 160), (100, 64), (33, 1280)])
+def test_pack_ps_h2_layout_and_split(ops, rows, k):
+    x = rnd(700, rows, k) * 3.0
+    flag = _flag()
+    ps = ops.pack_ps(x.cuda(), h2_flag=flag)
+    assert ps.numel() == -(-rows // 32) * (k // 16) * 2048 and int(flag.item()) == 0
+    hi, lo = ops.unpack_ps_h2(ps, rows, k)
+    xs = x.double() * 64.0
+    assert torch.equal(hi.cpu(), xs.float().half().float())                              # hi = fp16(2^6 x), nearest even
+    assert torch.equal(lo.cpu(), (xs.float() - hi.cpu()).half().float())                 # lo = fp16(2^6 x - hi)
+    err = (hi.cpu().double() + lo.cpu().double() - xs).abs()
+    assert bool((err <= torch.maximum(xs.abs() * 2.0 ** -23, torch.full_like(err, 2.0 ** -25))).all())
+    x[3, 5] = 1200.0
+    ops.pack_ps(x.cuda(), h2_flag=flag)
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("cfg", [23, 24, 26, 27, 31])
+@pytest.mark.parametrize("M,K,N,sk", [(300, 320, 160, 1), (512, 640, 1920, 1), (4096, 160, 480, 1), (1024, 2560, 640, 3), (33, 64, 32, 1)])
+def test_ps_h2_gemm_is_bitwise_the_lds_tiled_f16x2_gemm(ops, M, K, N, sk, cfg):
+    """Same split values, same three products in the same order per accumulator as igemm_kernel<BF = 4>: bit for bit tile_cfg 5 at
+    equal split-K (bias + per-sample vector + residual epilogue, ragged M, both epilogue forms)."""
+    from dsml_thesis_amd import lib as L
+    x, w, b = rnd(600, M, K), rnd(601, N, K) / np.sqrt(K), 0.1 * rnd(602, N)
+    res, vec = rnd(603, M, N).cuda(), rnd(604, 3, N).cuda()
+    rps = -(-M // 3)
+    wp = ops.pack_linear(w.cuda())
+    ops.pack_wsplit_h2(wp)
+    flag = _flag()
+    wps, xps = ops.pack_wps(wp, h2=True), ops.pack_ps(x.cuda(), h2_flag=flag)
+    ws = torch.empty(8 * M * N, device="cuda")
+    xc, bc = x.cuda(), b.cuda()
+    ref = torch.empty(M, N, device="cuda")
+    a = ops.make_igemm_args(M, N, K, xc, K, wp, ref, N, rps, tile_cfg=5, splitk=sk, splitk_ws=ws, compute=L.COMPUTE_F16X2, range_flag=flag,
+                            bias=bc, residual=res, batch_vec=vec, batch_vec_ld=N)
+    ops.igemm(a)
+    out = torch.empty(M, N, device="cuda")
+    a = ops.make_igemm_args(M, N, K, None, K, wp, out, N, rps, tile_cfg=cfg, splitk=sk, splitk_ws=ws, a_ps=xps, w_ps=wps, range_flag=flag,
+                            bias=bc, residual=res, batch_vec=vec, batch_vec_ld=N)
+    assert a.compute == L.COMPUTE_F16X2
+    ops.igemm(a)
+    assert int(flag.item()) == 0
+    assert torch.equal(out, ref)
+    if M % 32 == 0 and sk == 1:          # GroupNorm records: the lane = column form of the kernel
+        rec_ref, o2 = torch.zeros(M // 32, N, 3, device="cuda"), torch.empty(M, N, device="cuda")
+        a = ops.make_igemm_args(M, N, K, xc, K, wp, o2, N, M, tile_cfg=5, splitk=1, bias=bc, compute=L.COMPUTE_F16X2, range_flag=flag)
+        a.stats_out = rec_ref.data_ptr()
+        ops.igemm(a)
+        rec, o3 = torch.zeros(M // 32, N, 3, device="cuda"), torch.empty(M, N, device="cuda")
+        a = ops.make_igemm_args(M, N, K, None, K, wp, o3, N, M, tile_cfg=cfg, splitk=1, a_ps=xps, w_ps=wps, bias=bc, range_flag=flag)
+        a.stats_out = rec.data_ptr()
+        ops.igemm(a)
+        assert torch.equal(o3, o2) and torch.equal(rec, rec_ref)
+
+
+@pytest.mark.parametrize("cfg", [25, 28, 32, 33])
+@pytest.mark.parametrize("M,K,N", [(512, 160, 1280), (4096, 320, 2560), (96, 640, 5120)])
+def test_ps_h2_geglu_with_folded_layernorm_and_split_output(ops, M, K, N, cfg):
+    """The GEGLU projection as the transformer block runs it in F16X2: the statistics pass writes the rows as fp16 planes, the GEMM
+    is bitwise tile_cfg 1's F16X2 result, and out_ps is exactly pack_ps(h2) of the fp32 result (range-checked)."""
+    from dsml_thesis_amd import lib as L
+    x = rnd(610, M, K) + 0.5 * rnd(611, M, 1)
+    w, b = rnd(612, N, K) / np.sqrt(K), 0.1 * rnd(613, N)
+    g, be = 1 + 0.2 * rnd(614, K), 0.2 * rnd(615, K)
+    wp, bp = ops.pack_geglu(w.cuda(), b.cuda())
+    w2, cs, b2 = ops.fold_layernorm(wp, g.cuda(), be.cuda(), bp)
+    ops.pack_wsplit_h2(w2)
+    flag = _flag()
+    xc = x.cuda()
+    st, xps = ops.ln_stats_ps(xc, h2_flag=flag)
+    st0 = ops.ln_stats(xc)
+    close(st, st0.cpu(), 2e-6, 2e-6)                      # (another reduction order than ldmk_ln_stats)
+    assert torch.equal(xps, ops.pack_ps(xc, h2_flag=flag))
+    ref = torch.empty(M, N // 2, device="cuda")
+    a = ops.make_igemm_args(M, N, K, xc, K, w2, ref, N // 2, M, tf=L.TF_LAYERNORM_FOLDED, row_stats=st, ln_colsum=cs, bias=b2,
+                            epi=L.EPI_GEGLU, tile_cfg=1, splitk=1, compute=L.COMPUTE_F16X2, range_flag=flag)
+    ops.igemm(a)
+    wps = ops.pack_wps(w2, h2=True)
+    for with_fp32 in (True, False):
+        out = torch.zeros(M, N // 2, device="cuda")
+        ops_out = ops.ps_empty(M, N // 2, h2=True)
+        a = ops.make_igemm_args(M, N, K, None, K, w2, out if with_fp32 else None, N // 2, M, tf=L.TF_LAYERNORM_FOLDED, row_stats=st,
+                                ln_colsum=cs, bias=b2, epi=L.EPI_GEGLU, tile_cfg=cfg, splitk=1, a_ps=xps, w_ps=wps, out_ps=ops_out, range_flag=flag)
+        ops.igemm(a)
+        if with_fp32:
+            assert torch.equal(out, ref)
+        assert torch.equal(ops_out, ops.pack_ps(ref, h2_flag=flag))
+    assert int(flag.item()) == 0
+
+
+def test_ps_h2_rejections(ops):
+    from dsml_thesis_amd import lib as L
+    import ctypes
+    M, K, N = 64, 64, 64
+    x, w = rnd(620, M, K).cuda(), rnd(621, K, N).cuda().contiguous()
+    flag = _flag()
+    xps, wps = ops.pack_ps(x, h2_flag=flag), ops.pack_wps(w, h2=True)
+    out = torch.empty(M, N, device="cuda")
+    for cfg in (29, 30):                   # the warp-specialised pre-split tiles exist in bf16x3 only
+        a = ops.make_igemm_args(M, N, K, None, K, w, out, N, M, tile_cfg=cfg, splitk=1, a_ps=xps, w_ps=wps, range_flag=flag)
+        assert L.load().ldmk_igemm_check(ctypes.byref(a)) != 0
+    a = ops.make_igemm_args(M, N, K, None, K, w, out, N, M, tile_cfg=27, splitk=1, a_ps=xps, w_ps=wps, out_ps=ops.ps_empty(M, N, h2=True))
+    assert L.load().ldmk_igemm_check(ctypes.byref(a)) != 0        # out_ps in F16X2 without a range flag
+    a = ops.make_igemm_args(M, N, K, None, K, w, out, N, M, tile_cfg=27, splitk=1, a_ps=xps, w_ps=wps, range_flag=flag)
+    assert L.load().ldmk_igemm_check(ctypes.byref(a)) == 0

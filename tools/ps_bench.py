@@ -45,6 +45,9 @@ def timeit(fn, n_rot, reps=12):
 def main():
     quick = "--quick" in sys.argv
     probe = "--probe" in sys.argv          # the shapes tools/ps_probe.sh looks at: long K, short K + heavy epilogue, L2-resident batch
+    h2 = "--h2" in sys.argv                # the same comparison in the F16X2 arithmetic (two fp16 planes; tile_cfg 29 / 30 do not exist there)
+    flag = torch.zeros(1, device="cuda", dtype=torch.int32)
+    COMP = L.COMPUTE_F16X2 if h2 else L.COMPUTE_BF16X3
     shapes = SHAPES[:6] if quick else ([SHAPES[0], SHAPES[1], SHAPES[4], SHAPES[13]] if probe else SHAPES)
     for (M, N, K, geglu, lnf, B, label) in shapes:
         R = 3
@@ -52,9 +55,9 @@ def main():
         xs = [torch.randn(B, M, K, device="cuda", generator=g) for _ in range(R)]
         w = (torch.randn(B, K, N, device="cuda", generator=g) / np.sqrt(K)).contiguous()
         wp = w if B > 1 else w[0].contiguous()
-        ops.pack_wsplit(wp, batch=B)
-        wps = ops.pack_wps(wp, batch=B)
-        xps = [ops.pack_ps(x if B > 1 else x[0]) for x in xs]
+        (ops.pack_wsplit_h2 if h2 else ops.pack_wsplit)(wp, batch=B)
+        wps = ops.pack_wps(wp, batch=B, h2=h2)
+        xps = [ops.pack_ps(x if B > 1 else x[0], h2_flag=flag if h2 else None) for x in xs]
         ncol = N // 2 if geglu else N
         out = torch.empty(B, M, ncol, device="cuda")
         st = torch.stack([torch.zeros(M, device="cuda"), torch.ones(M, device="cuda")], 1).contiguous() if lnf else None
@@ -72,11 +75,14 @@ def main():
         if not geglu and M * N <= 4096 * 640 and K >= 640:
             cands += [(5, 2), (5, 4)]
             pcands += [(23, 2), (23, 4), (27, 2), (27, 4), (29, 2), (29, 4), (31, 2), (31, 4)]
+        if h2:
+            cands = [c for c in cands if c[0] <= 6] + ([(1, 1)] if not geglu else [])
+            pcands = [c for c in pcands if c[0] not in (29, 30)]
         for cfg, sk in cands:
             args = []
             for r in range(R):
                 a = ops.make_igemm_args(M, N, K, xs[r], K, wp, out, ncol, M, tile_cfg=cfg, splitk=sk, splitk_ws=ws if sk > 1 else None,
-                                        compute=L.COMPUTE_BF16X3, a_bstride=M * K if B > 1 else 0, **kw)
+                                        compute=COMP, range_flag=flag, a_bstride=M * K if B > 1 else 0, **kw)
                 args.append(a)
             try:
                 res[f"x3 cfg{cfg} sk{sk}"] = timeit(lambda r: ops.igemm(args[r]), R)
@@ -85,10 +91,10 @@ def main():
         for cfg, sk in pcands:
             for ops_out in ([False, True] if geglu else [False]):
                 args = []
-                ops_ps = ops.ps_empty(M, ncol) if ops_out else None
+                ops_ps = ops.ps_empty(M, ncol, h2=h2) if ops_out else None
                 for r in range(R):
                     a = ops.make_igemm_args(M, N, K, None, K, wp, None if ops_out else out, ncol, M, tile_cfg=cfg, splitk=sk,
-                                            splitk_ws=ws if sk > 1 else None, a_ps=xps[r], w_ps=wps, out_ps=ops_ps, **kw)
+                                            splitk_ws=ws if sk > 1 else None, a_ps=xps[r], w_ps=wps, out_ps=ops_ps, range_flag=flag, **kw)
                     args.append(a)
                 try:
                     res[f"ps cfg{cfg} sk{sk}" + (" ->ps" if ops_out else "")] = timeit(lambda r: ops.igemm(args[r]), R)
