@@ -111,7 +111,8 @@ class StepRunner:
         for _ in range(reps):
             evs, tevs = [], []
             for fn, args, _, name in pg.calls:
-                if name in ("ldmk_igemm", "ldmk_winograd_input", "ldmk_winograd_output", "ldmk_upconv_gather", "ldmk_upconv_scatter"):
+                if name in ("ldmk_igemm", "ldmk_winograd_input", "ldmk_winograd_input_ps", "ldmk_winograd_input_ps_h2", "ldmk_winograd_output",
+                            "ldmk_upconv_gather", "ldmk_upconv_gather_ps", "ldmk_upconv_gather_ps_h2", "ldmk_upconv_scatter"):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     rc = fn(*args, st)

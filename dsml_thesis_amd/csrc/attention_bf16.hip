@@ -900,7 +900,8 @@ __device__ __forceinline__ void h2_softmax(f32x16& s, f32x16& o, float& m_run, f
 
 template <int QB>
 __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ kv, float* __restrict__ out,
-                                                          int tokens, int heads, float scale, int* __restrict__ range_flag) {
+                                                          unsigned char* __restrict__ out_ps, int tokens, int heads, float scale,
+                                                          int* __restrict__ range_flag) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem_h[2 * H2_TILE];
   static_assert(2 * H2_TILE >= 4 * 32 * BA_FS * 4, "transpose buffers alias the tile buffers");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
@@ -1006,8 +1007,37 @@ __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restric
   for (int j = 0; j < QB; ++j) {
     const int qb0 = q0 + 32 * j;
     if (qb0 >= tokens) break;
-    float* ts = reinterpret_cast<float*>(smem_h) + wave * (32 * BA_FS);
-    store_rows_bf(ts, o[j], (1.0f / H2_S) / l_run[j], out + (long long)b * tokens * C + h * BA_D, C, qb0, tokens, l31, half);
+    const float mul = (1.0f / H2_S) / l_run[j];
+    if (out_ps) {
+      // the result as the pre-split A operand of attn1.to_out in the F16X2 form of the PS layout (two fp16 planes of 2^6 x, 2-KiB
+      // units; csrc/igemm_ps.hip): written from the accumulators as in attn_x3p_fwd_kernel; tokens % 32 == 0
+      unsigned char* d0 = out_ps + ((((long long)b * tokens + qb0) >> 5) * (C / 16) + 2 * h) * 2048 + l31 * 16 + half * 8;
+      if (qb0 + l31 < tokens) {
+        bool bad2 = false;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4] = {mul_rounded(o[j][4 * g], mul), mul_rounded(o[j][4 * g + 1], mul), mul_rounded(o[j][4 * g + 2], mul), mul_rounded(o[j][4 * g + 3], mul)};
+          asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+          typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+          f16x4_t hh, ll;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bad2 |= out_of_h2_range(v[e]);
+            const float sv = v[e] * H2_S;
+            hh[e] = (_Float16)sv;
+            ll[e] = (_Float16)(sv - (float)hh[e]);
+          }
+          unsigned char* d = d0 + (g >> 1) * 2048 + (g & 1) * 512;
+          *reinterpret_cast<f16x4_t*>(d) = hh;
+          *reinterpret_cast<f16x4_t*>(d + 1024) = ll;
+        }
+        if (bad2) *range_flag = 1;
+      }
+    }
+    if (out) {
+      float* ts = reinterpret_cast<float*>(smem_h) + wave * (32 * BA_FS);
+      store_rows_bf(ts, o[j], mul, out + (long long)b * tokens * C + h * BA_D, C, qb0, tokens, l31, half);
+    }
   }
 }
 
@@ -1059,11 +1089,21 @@ extern "C" long long ldmk_attn_kv_split_h2_bytes(int n, int tokens, int heads) {
   return (long long)n * heads * ((tokens + ldmk::BA_T - 1) / ldmk::BA_T) * ldmk::H2_TILE;
 }
 
+extern "C" int ldmk_attn_self_h2_ps(const float* qkv, void* kv_scratch, float* out, void* out_ps, int* range_flag, int n, int tokens, int heads,
+                                    float scale, void* stream);
+
 extern "C" int ldmk_attn_self_h2(const float* qkv, void* kv_scratch, float* out, int* range_flag, int n, int tokens, int heads, float scale,
                                  void* stream) {
+  return ldmk_attn_self_h2_ps(qkv, kv_scratch, out, nullptr, range_flag, n, tokens, heads, scale, stream);
+}
+
+extern "C" int ldmk_attn_self_h2_ps(const float* qkv, void* kv_scratch, float* out, void* out_ps, int* range_flag, int n, int tokens, int heads,
+                                    float scale, void* stream) {
   LDMK_ENTER();
   using namespace ldmk;
-  LDMK_REQUIRE(qkv && kv_scratch && out && range_flag && n > 0 && tokens > 0 && heads > 0 && heads <= 65535 && n <= 65535, "ldmk_attn_self_h2: bad args");
+  LDMK_REQUIRE(qkv && kv_scratch && (out || out_ps) && range_flag && n > 0 && tokens > 0 && heads > 0 && heads <= 65535 && n <= 65535,
+               "ldmk_attn_self_h2: bad args");
+  LDMK_REQUIRE(!out_ps || tokens % 32 == 0, "ldmk_attn_self_h2_ps: out_ps needs tokens %% 32 == 0 (%d)", tokens);
   const int ntiles = (tokens + BA_T - 1) / BA_T;
   LDMK_REQUIRE((long long)ntiles * H2_TILE < (1LL << 31), "ldmk_attn_self_h2: %d tokens: a head's pre-split K / V exceeds 2 GiB", tokens);
   hipStream_t st = (hipStream_t)stream;
@@ -1073,10 +1113,10 @@ extern "C" int ldmk_attn_self_h2(const float* qkv, void* kv_scratch, float* out,
   const int qb = qb_env == 1 || qb_env == 2 ? qb_env : (tokens >= X3P_QB2_MIN_TOKENS ? 2 : 1);
   if (qb == 2)
     hipLaunchKernelGGL(attn_h2_fwd_kernel<2>, dim3((tokens + 255) / 256, heads, n), dim3(256), 0, st, qkv,
-                       reinterpret_cast<const unsigned char*>(kv_scratch), out, tokens, heads, scale, range_flag);
+                       reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale, range_flag);
   else
     hipLaunchKernelGGL(attn_h2_fwd_kernel<1>, dim3((tokens + 127) / 128, heads, n), dim3(256), 0, st, qkv,
-                       reinterpret_cast<const unsigned char*>(kv_scratch), out, tokens, heads, scale, range_flag);
+                       reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale, range_flag);
   return check_launch("ldmk_attn_self_h2");
 }
 

@@ -81,9 +81,27 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 // wave are 32 consecutive tiles at channels 16 s .. 16 s + 7, lanes 32-63 the same tiles at 16 s + 8 .. 16 s + 15, so every store
 // instruction writes ONE whole fragment plane, 1 KiB contiguous; a workgroup = 32 tiles x 4 k-slabs.  Same arithmetic (and
 // order) as wino_input_kernel: V is bit for bit the same matrix, split exactly.
+// PL = 2: the F16X2 form of the layout (two fp16 planes of 2^6 x per 2-KiB unit; an element of 1000 or more raises *range_flag).
 typedef __bf16 wbf16x8_ __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void wino_store_ps(unsigned char* d, const float4& a, const float4& b) {
+typedef _Float16 wf16x8_ __attribute__((ext_vector_type(8)));
+template <int PL = 3>
+__device__ __forceinline__ void wino_store_ps(unsigned char* d, const float4& a, const float4& b, int* range_flag = nullptr) {
   float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  if constexpr (PL == 2) {
+    wf16x8_ h, l;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bad |= (__float_as_uint(v[e]) & 0x7fffffffu) >= 0x447a0000u;
+      const float s = v[e] * 64.f;
+      h[e] = (_Float16)s;
+      l[e] = (_Float16)(s - (float)h[e]);
+    }
+    if (bad) *range_flag = 1;
+    *reinterpret_cast<wf16x8_*>(d) = h;
+    *reinterpret_cast<wf16x8_*>(d + 1024) = l;
+    return;
+  }
   wbf16x8_ h, m, l;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -97,9 +115,10 @@ __device__ __forceinline__ void wino_store_ps(unsigned char* d, const float4& a,
   *reinterpret_cast<wbf16x8_*>(d + 2048) = l;
 }
 
+template <int PL>
 __global__ __launch_bounds__(256) void wino_input_ps_kernel(const float* __restrict__ x0, int c0, const float* __restrict__ x1, int c1,
                                                             const float* __restrict__ coef, int silu, int H, int W, long long tiles,
-                                                            unsigned char* __restrict__ V, long long plane_bytes) {
+                                                            unsigned char* __restrict__ V, long long plane_bytes, int* __restrict__ range_flag) {
   const int C = c0 + c1, Kb = C >> 4;
   const int tw = W >> 1, th = H >> 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -150,7 +169,7 @@ __global__ __launch_bounds__(256) void wino_input_ps_kernel(const float* __restr
   }
   auto sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
   auto add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
-  unsigned char* dst = V + ((long long)blockIdx.x * Kb + slab) * 3072 + lane * 16;
+  unsigned char* dst = V + ((long long)blockIdx.x * Kb + slab) * (PL * 1024) + lane * 16;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float4 rr[4][2];                    // row i of B^T d
@@ -162,10 +181,10 @@ __global__ __launch_bounds__(256) void wino_input_ps_kernel(const float* __restr
                                                                                                           : sub(d[1][j][e], d[3][j][e]);
       }
     // (B^T d) B, positions 4 i .. 4 i + 3
-    wino_store_ps(dst + (4 * i + 0) * plane_bytes, sub(rr[0][0], rr[2][0]), sub(rr[0][1], rr[2][1]));
-    wino_store_ps(dst + (4 * i + 1) * plane_bytes, add(rr[1][0], rr[2][0]), add(rr[1][1], rr[2][1]));
-    wino_store_ps(dst + (4 * i + 2) * plane_bytes, sub(rr[2][0], rr[1][0]), sub(rr[2][1], rr[1][1]));
-    wino_store_ps(dst + (4 * i + 3) * plane_bytes, sub(rr[1][0], rr[3][0]), sub(rr[1][1], rr[3][1]));
+    wino_store_ps<PL>(dst + (4 * i + 0) * plane_bytes, sub(rr[0][0], rr[2][0]), sub(rr[0][1], rr[2][1]), range_flag);
+    wino_store_ps<PL>(dst + (4 * i + 1) * plane_bytes, add(rr[1][0], rr[2][0]), add(rr[1][1], rr[2][1]), range_flag);
+    wino_store_ps<PL>(dst + (4 * i + 2) * plane_bytes, sub(rr[2][0], rr[1][0]), sub(rr[2][1], rr[1][1]), range_flag);
+    wino_store_ps<PL>(dst + (4 * i + 3) * plane_bytes, sub(rr[1][0], rr[3][0]), sub(rr[1][1], rr[3][1]), range_flag);
   }
 }
 
@@ -266,9 +285,25 @@ extern "C" int ldmk_winograd_input(const float* x0, int c0, const float* x1, int
 }
 
 extern "C" long long ldmk_ps_bytes(int rows, int k);
+extern "C" long long ldmk_ps_bytes_h2(int rows, int k);
+
+static int winograd_input_ps_any(const float* x0, int c0, const float* x1, int c1, const float* coef, int silu, int n, int h, int w, void* v_ps,
+                                 int* range_flag, void* stream);
 
 extern "C" int ldmk_winograd_input_ps(const float* x0, int c0, const float* x1, int c1, const float* coef, int silu, int n, int h,
                                       int w, void* v_ps, void* stream) {
+  return winograd_input_ps_any(x0, c0, x1, c1, coef, silu, n, h, w, v_ps, nullptr, stream);
+}
+
+extern "C" int ldmk_winograd_input_ps_h2(const float* x0, int c0, const float* x1, int c1, const float* coef, int silu, int n, int h,
+                                         int w, void* v_ps, int* range_flag, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(range_flag != nullptr, "ldmk_winograd_input_ps_h2: range_flag");
+  return winograd_input_ps_any(x0, c0, x1, c1, coef, silu, n, h, w, v_ps, range_flag, stream);
+}
+
+static int winograd_input_ps_any(const float* x0, int c0, const float* x1, int c1, const float* coef, int silu, int n, int h, int w, void* v_ps,
+                                 int* range_flag, void* stream) {
   LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(x0 && v_ps && n > 0 && c0 > 0, "ldmk_winograd_input_ps: bad args");
@@ -278,9 +313,13 @@ extern "C" int ldmk_winograd_input_ps(const float* x0, int c0, const float* x1, 
   const long long tiles = ldmk_winograd_tiles(n, h, w);
   LDMK_REQUIRE(tiles < (1LL << 31), "ldmk_winograd_input_ps: too many tiles");
   const int C = c0 + c1;
-  const long long plane = ldmk_ps_bytes((int)tiles, C);
-  hipLaunchKernelGGL(wino_input_ps_kernel, dim3((unsigned)((tiles + 31) / 32), (C / 16 + 3) / 4), dim3(256), 0, (hipStream_t)stream, x0, c0, x1,
-                     c1, coef, silu, h, w, tiles, reinterpret_cast<unsigned char*>(v_ps), plane);
+  const dim3 grid((unsigned)((tiles + 31) / 32), (C / 16 + 3) / 4);
+  if (range_flag)      // the F16X2 form: two fp16 planes of 2^6 V
+    hipLaunchKernelGGL(wino_input_ps_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x0, c0, x1, c1, coef, silu, h, w, tiles,
+                       reinterpret_cast<unsigned char*>(v_ps), ldmk_ps_bytes_h2((int)tiles, C), range_flag);
+  else
+    hipLaunchKernelGGL(wino_input_ps_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x0, c0, x1, c1, coef, silu, h, w, tiles,
+                       reinterpret_cast<unsigned char*>(v_ps), ldmk_ps_bytes((int)tiles, C), range_flag);
   return check_launch("ldmk_winograd_input_ps");
 }
 
@@ -350,8 +389,9 @@ __global__ __launch_bounds__(256) void upconv_gather_kernel(const float* __restr
 
 // the gather writing its four phase operands in the PS layout (csrc/igemm_ps.hip): per phase the PS image of [pix][4 C]; thread <->
 // (pixel, 8 channels) with the lane order of wino_input_ps_kernel, so every store is one whole 1-KiB fragment plane
+template <int PL>
 __global__ __launch_bounds__(256) void upconv_gather_ps_kernel(const float* __restrict__ x, int C, int H, int W, long long pix,
-                                                               unsigned char* __restrict__ A, long long plane_bytes) {
+                                                               unsigned char* __restrict__ A, long long plane_bytes, int* __restrict__ range_flag) {
   const int Kc = C >> 4;                 // k-slabs per tap
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -385,11 +425,12 @@ __global__ __launch_bounds__(256) void upconv_gather_ps_kernel(const float* __re
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      unsigned char* dst = A + (long long)(2 * a + b) * plane_bytes + ((long long)blockIdx.x * Kb + slab) * 3072 + lane * 16;
+      unsigned char* dst = A + (long long)(2 * a + b) * plane_bytes + ((long long)blockIdx.x * Kb + slab) * (PL * 1024) + lane * 16;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) wino_store_ps(dst + (long long)(2 * i + j) * Kc * 3072, d[a + i][b + j][0], d[a + i][b + j][1]);
+        for (int j = 0; j < 2; ++j)
+          wino_store_ps<PL>(dst + (long long)(2 * i + j) * Kc * (PL * 1024), d[a + i][b + j][0], d[a + i][b + j][1], range_flag);
     }
 }
 
@@ -457,16 +498,30 @@ extern "C" int ldmk_upconv_gather(const float* x, int c, int n, int h, int w, fl
   return check_launch("ldmk_upconv_gather");
 }
 
-extern "C" int ldmk_upconv_gather_ps(const float* x, int c, int n, int h, int w, void* a_ps, void* stream) {
+static int upconv_gather_ps_any(const float* x, int c, int n, int h, int w, void* a_ps, int* range_flag, void* stream) {
   LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(x && a_ps && n > 0 && h > 0 && w > 0 && c > 0 && c % 16 == 0, "ldmk_upconv_gather_ps: bad args (C a multiple of 16)");
   const long long pix = (long long)n * h * w;
   LDMK_REQUIRE(pix < (1LL << 31), "ldmk_upconv_gather_ps: too many pixels");
-  const long long plane = ldmk_ps_bytes((int)pix, 4 * c);
-  hipLaunchKernelGGL(upconv_gather_ps_kernel, dim3((unsigned)((pix + 31) / 32), (c / 16 + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, c, h,
-                     w, pix, reinterpret_cast<unsigned char*>(a_ps), plane);
+  const dim3 grid((unsigned)((pix + 31) / 32), (c / 16 + 3) / 4);
+  if (range_flag)
+    hipLaunchKernelGGL(upconv_gather_ps_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, c, h, w, pix, reinterpret_cast<unsigned char*>(a_ps),
+                       ldmk_ps_bytes_h2((int)pix, 4 * c), range_flag);
+  else
+    hipLaunchKernelGGL(upconv_gather_ps_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, c, h, w, pix, reinterpret_cast<unsigned char*>(a_ps),
+                       ldmk_ps_bytes((int)pix, 4 * c), range_flag);
   return check_launch("ldmk_upconv_gather_ps");
+}
+
+extern "C" int ldmk_upconv_gather_ps(const float* x, int c, int n, int h, int w, void* a_ps, void* stream) {
+  return upconv_gather_ps_any(x, c, n, h, w, a_ps, nullptr, stream);
+}
+
+extern "C" int ldmk_upconv_gather_ps_h2(const float* x, int c, int n, int h, int w, void* a_ps, int* range_flag, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(range_flag != nullptr, "ldmk_upconv_gather_ps_h2: range_flag");
+  return upconv_gather_ps_any(x, c, n, h, w, a_ps, range_flag, stream);
 }
 
 extern "C" int ldmk_upconv_scatter(const float* planes, const float* bias, float* out, float* stats_out, int n, int h, int w,

@@ -554,9 +554,13 @@ class NetBuilder:
         plan = self.ps_query(tiles, cout, cin, batch=16) if (u_ps is not None and c0 % 16 == 0 and c1 % 16 == 0) else None
         if plan is not None:
             V = pg.alloc_ps(tiles, cin, batch=16)
-            pg.add("ldmk_winograd_input_ps", p_(x0), c0, p_(x1), c1, p_(coef), 1, n, h, w, p_(V))
+            hf = getattr(pg, "h2_flag", None)          # (a program in the F16X2 arithmetic: V as two fp16 planes, range-checked)
+            if hf is not None:
+                pg.add("ldmk_winograd_input_ps_h2", p_(x0), c0, p_(x1), c1, p_(coef), 1, n, h, w, p_(V), p_(hf))
+            else:
+                pg.add("ldmk_winograd_input_ps", p_(x0), c0, p_(x1), c1, p_(coef), 1, n, h, w, p_(V))
             a = ops.make_igemm_args(tiles, cout, cin, None, cin, u, Mb, cout, tiles, batch=16, w_bstride=cin * cout,
-                                    out_bstride=tiles * cout, a_ps=V.view(16, -1), w_ps=u_ps)
+                                    out_bstride=tiles * cout, a_ps=V.view(16, -1), w_ps=u_ps, range_flag=hf)
         else:
             V = pg.alloc(16, tiles, cin)
             pg.add("ldmk_winograd_input", p_(x0), c0, p_(x1), c1, p_(coef), 1, n, h, w, p_(V))
@@ -599,9 +603,13 @@ class NetBuilder:
         plan = self.ps_query(pix, cout, 4 * c, batch=4) if (w4_ps is not None and c % 16 == 0) else None
         if plan is not None:          # the gather writes its phase operands in the PS layout (csrc/igemm_ps.hip)
             A = pg.alloc_ps(pix, 4 * c, batch=4)
-            pg.add("ldmk_upconv_gather_ps", p_(x), c, n, h, w, p_(A))
+            hf = getattr(pg, "h2_flag", None)
+            if hf is not None:
+                pg.add("ldmk_upconv_gather_ps_h2", p_(x), c, n, h, w, p_(A), p_(hf))
+            else:
+                pg.add("ldmk_upconv_gather_ps", p_(x), c, n, h, w, p_(A))
             a = ops.make_igemm_args(pix, cout, 4 * c, None, 4 * c, w4, Pm, cout, pix, batch=4, w_bstride=4 * c * cout,
-                                    out_bstride=pix * cout, a_ps=A.view(4, -1), w_ps=w4_ps)
+                                    out_bstride=pix * cout, a_ps=A.view(4, -1), w_ps=w4_ps, range_flag=hf)
         else:
             A = pg.alloc(4, pix, 4 * c)
             pg.add("ldmk_upconv_gather", p_(x), c, n, h, w, p_(A))

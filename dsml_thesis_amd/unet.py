@@ -155,9 +155,13 @@ def emit_self_attention(nb_, qkv, att, hw, heads, d_head, att_ps=None):
     pg, n = nb_.pg, nb_.n
     scale = d_head ** -0.5
     h2_flag = getattr(nb_, "h2_flag", None)
-    if h2_flag is not None and att_ps is None and hw >= ATTN_H2_MIN_TOKENS:
+    if h2_flag is not None and hw >= ATTN_H2_MIN_TOKENS:
         kvs = pg.alloc(pg.lib.ldmk_attn_kv_split_h2_bytes(n, hw, heads), dtype=torch.uint8)
-        pg.add("ldmk_attn_self_h2", qkv.data_ptr(), kvs.data_ptr(), att.data_ptr(), h2_flag.data_ptr(), n, hw, heads, scale)
+        if att_ps is not None:       # the result in the (F16X2) PS layout only: the A operand of attn1.to_out on a pre-split tile
+            pg.add("ldmk_attn_self_h2_ps", qkv.data_ptr(), kvs.data_ptr(), 0 if att is None else att.data_ptr(), att_ps.data_ptr(),
+                   h2_flag.data_ptr(), n, hw, heads, scale)
+        else:
+            pg.add("ldmk_attn_self_h2", qkv.data_ptr(), kvs.data_ptr(), att.data_ptr(), h2_flag.data_ptr(), n, hw, heads, scale)
         nb_.release(kvs)
     elif attention_presplit(hw):
         kvs = pg.alloc(pg.lib.ldmk_attn_kv_split_bytes(n, hw, heads), dtype=torch.uint8)
@@ -242,8 +246,10 @@ def pack_gemm_copies(P, unfolded=False):
         if f16x2_enabled():
             for k in list(P):
                 tail = k.rsplit(".", 1)[-1]
-                if tail in ("qkv_ln", "ff1_ln", "ff2", "pout") and P[k].dim() == 2 and P[k].shape[0] % 32 == 0 and P[k].shape[1] % 32 == 0:
+                if tail in ("qkv_ln", "ff1_ln", "ff2", "o1", "pout") and P[k].dim() == 2 and P[k].shape[0] % 32 == 0 and P[k].shape[1] % 32 == 0:
                     P[k + "#p2"] = ops.pack_wps(P[k], h2=True)
+                elif tail in ("c1#wg", "c2#wg", "w#up") and P[k].shape[1] % 32 == 0 and P[k].shape[2] % 32 == 0:
+                    P[k + "#p2"] = ops.pack_wps(P[k], batch=P[k].shape[0], h2=True)
 
 
 def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_in, context_dim, unfolded=False, ln_flag=None):
@@ -304,7 +310,8 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
         # both attention products in the fp32-accurate bf16x3 arithmetic (24 bf16 MFMAs of 32 cycles per 32 keys
         # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel.  With a pre-split plan for
         # attn1.to_out the attention kernel writes its result in the PS layout only (from its accumulators, no LDS pass)
-        plan_o = (nb_.ps_query(rows, C_, C_) if (h2_flag is None and q + "o1#p" in P and L_ctx == 1 and hw % 32 == 0 and attention_presplit(hw)) else None)
+        plan_o = (nb_.ps_query(rows, C_, C_) if (q + "o1" + psfx in P and L_ctx == 1 and hw % 32 == 0 and os.environ.get("LDMK_ATTN_PS", "1") != "0"
+                                                 and (hw >= ATTN_H2_MIN_TOKENS if h2_flag is not None else attention_presplit(hw))) else None)
         att = None if plan_o is not None else pg.alloc(rows, C_)
         att_ps = pg.alloc_ps(rows, C_) if plan_o is not None else None
         emit_self_attention(nb_, qkv, att, hw, m.heads, m.d_head, att_ps=att_ps)
@@ -319,7 +326,7 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
             ctx_pg.add("ldmk_dense_small", p_(v), C_, p_(P[q + "o2"]), p_(sd[q + "attn2.to_out.0.bias"]), p_(cvec),
                        C_, n, C_, C_, 0)
             if plan_o is not None:
-                h1 = nb_.lin_ps(plan_o, rows, C_, att_ps, P[q + "o1"], P[q + "o1#p"], sd[q + "attn1.to_out.0.bias"], hw, out=hcur,
+                h1 = nb_.lin_ps(plan_o, rows, C_, att_ps, P[q + "o1"], P[q + "o1" + psfx], sd[q + "attn1.to_out.0.bias"], hw, out=hcur,
                                 residual=hcur, batch_vec=cvec, batch_vec_ld=C_)
                 nb_.release(att_ps)
             else:
@@ -653,6 +660,7 @@ class UNetModel(nn.Module):
 
         nb_ = NetBuilder(pg, n, pin)
         nb_.h2_flag = self._h2_flag if self.f16x2 else None
+        psfx = "#p2" if self.f16x2 else "#p"          # pre-split weight copies in the form of the program's arithmetic
         gn, conv, lin = nb_.gn, nb_.conv, nb_.lin
 
         def res_block(prefix, m, x0, x1, h, w):
@@ -663,7 +671,7 @@ class UNetModel(nn.Module):
             bv = emb_all.data_ptr() + 4 * self._emb_off[prefix]
             h1 = nb_.gn_conv(x0, x1, h, w, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5,
                              P[prefix + "c1"], P.get(prefix + "c1#wg"), sd[prefix + "in_layers.2.bias"], batch_vec=bv,
-                             bv_ld=self._emb_total, stats=True, wf=P.get(prefix + "c1#f"), u_ps=P.get(prefix + "c1#wg#p"))
+                             bv_ld=self._emb_total, stats=True, wf=P.get(prefix + "c1#f"), u_ps=P.get(prefix + "c1#wg" + psfx))
             g2, b2 = sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"]
             if m.cin != m.cout:
                 x0r = x0.reshape(n * hw, -1)
@@ -671,12 +679,12 @@ class UNetModel(nn.Module):
                 skip = lin(x0r, P[prefix + "skip"], sd[prefix + "skip_connection.bias"], hw, x1=x1r, wf=P.get(prefix + "skip#f"))
                 out = nb_.gn_conv(h1, None, h, w, g2, b2, 1e-5, P[prefix + "c2"], P.get(prefix + "c2#wg"),
                                   sd[prefix + "out_layers.3.bias"], residual=skip, out=skip.view(n, h, w, m.cout), stats=True,
-                                  wf=P.get(prefix + "c2#f"), u_ps=P.get(prefix + "c2#wg#p"))
+                                  wf=P.get(prefix + "c2#f"), u_ps=P.get(prefix + "c2#wg" + psfx))
             else:
                 assert x1 is None
                 out = nb_.gn_conv(h1, None, h, w, g2, b2, 1e-5, P[prefix + "c2"], P.get(prefix + "c2#wg"),
                                   sd[prefix + "out_layers.3.bias"], residual=x0, stats=True, wf=P.get(prefix + "c2#f"),
-                                  u_ps=P.get(prefix + "c2#wg#p"))
+                                  u_ps=P.get(prefix + "c2#wg" + psfx))
             nb_.release(h1)
             return out
 
@@ -700,7 +708,7 @@ class UNetModel(nn.Module):
                     out = conv(cur0, None, P[p + "w"], sd[p + "op.bias"], h, w, stride=2, stats=True)
                     h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
                 elif m.kind == "up":
-                    out = nb_.up_conv(cur0, h, w, P[p + "w"], P.get(p + "w#up"), sd[p + "conv.bias"], stats=True, w4_ps=P.get(p + "w#up#p"))
+                    out = nb_.up_conv(cur0, h, w, P[p + "w"], P.get(p + "w#up"), sd[p + "conv.bias"], stats=True, w4_ps=P.get(p + "w#up" + psfx))
                     h, w = 2 * h, 2 * w
                 else:
                     raise AssertionError(m.kind)

@@ -260,6 +260,9 @@ int ldmk_winograd_input(const float* x0, int c0, const float* x1, int c1, const 
  * ldmk_winograd_input writes, split exactly. */
 int ldmk_winograd_input_ps(const float* x0, int c0, const float* x1, int c1, const float* coef, int silu, int n, int h, int w,
                            void* v_ps, void* stream);
+/* the same in the F16X2 form of the layout (16 planes of ldmk_ps_bytes_h2(tiles, c0 + c1) bytes; V scaled by 2^6, range-checked) */
+int ldmk_winograd_input_ps_h2(const float* x0, int c0, const float* x1, int c1, const float* coef, int silu, int n, int h, int w,
+                              void* v_ps, int* range_flag, void* stream);
 int ldmk_winograd_output(const float* m, const float* bias, const float* batch_vec, int batch_vec_ld, const float* residual,
                          float* out, float* stats_out, int n, int h, int w, int cout, void* stream);
 
@@ -271,6 +274,7 @@ int ldmk_winograd_output(const float* m, const float* bias, const float* batch_v
 int ldmk_upconv_gather(const float* x, int c, int n, int h, int w, float* a, void* stream);
 /* ldmk_upconv_gather writing the four phase operands in the PS layout: 4 planes of ldmk_ps_bytes(n h w, 4 c) bytes. c % 16 == 0. */
 int ldmk_upconv_gather_ps(const float* x, int c, int n, int h, int w, void* a_ps, void* stream);
+int ldmk_upconv_gather_ps_h2(const float* x, int c, int n, int h, int w, void* a_ps, int* range_flag, void* stream);   /* F16X2 form */
 int ldmk_upconv_scatter(const float* planes, const float* bias, float* out, float* stats_out, int n, int h, int w, int cout,
                         void* stream);
 
@@ -393,6 +397,10 @@ int ldmk_attn_self_x3p_ps(const float* qkv, void* kv_scratch, float* out, void* 
 long long ldmk_attn_kv_split_h2_bytes(int n, int tokens, int heads);
 int ldmk_attn_self_h2(const float* qkv, void* kv_scratch, float* out, int* range_flag, int n, int tokens, int heads, float scale,
                       void* stream);
+/* the same, with the result ALSO (out != NULL) or ONLY (out == NULL) in the F16X2 form of the PS layout (ldmk_ps_bytes_h2(n tokens,
+ * heads 32) bytes): the pre-split A operand of attn1.to_out.  tokens % 32 == 0. */
+int ldmk_attn_self_h2_ps(const float* qkv, void* kv_scratch, float* out, void* out_ps, int* range_flag, int n, int tokens, int heads,
+                         float scale, void* stream);
 /* ldmk_attn_self_small: the same product for SMALL problems (batch 1-2: the reference's talking-face mode runs batch 1,
  *   talking_face/progressive_sampling_difftalk.py:350).  One workgroup per 32-query tile of a (sample, head), the keys split
  *   over its 4 / 8 waves and streamed from global memory without LDS staging, partial (max, sum, O) merged in wave order

@@ -353,3 +353,89 @@ def test_ps_h2_rejections(ops):
     assert L.load().ldmk_igemm_check(ctypes.byref(a)) != 0        # out_ps in F16X2 without a range flag
     a = ops.make_igemm_args(M, N, K, None, K, w, out, N, M, tile_cfg=27, splitk=1, a_ps=xps, w_ps=wps, range_flag=flag)
     assert L.load().ldmk_igemm_check(ctypes.byref(a)) == 0
+
+
+@pytest.mark.parametrize("case", [(2, 320, 0, 16, 16), (1, 160, 160, 8, 8), (3, 64, 32, 4, 6), (1, 640, 0, 32, 32)])
+def test_winograd_input_in_the_f16x2_ps_layout(ops, case):
+    """ldmk_winograd_input_ps_h2: the 16 planes of V = B^T d B written as two fp16 planes of 2^6 V -- plane by plane exactly
+    pack_ps(h2) of what ldmk_winograd_input writes (whole row blocks), range-checked."""
+    from dsml_thesis_amd import lib as L
+    n, c0, c1, h, w = case
+    C = c0 + c1
+    x0 = rnd(700, n, h, w, c0).cuda()
+    x1 = rnd(701, n, h, w, c1).cuda() if c1 else None
+    coef = torch.stack([1.0 + 0.2 * rnd(702, n, C), 0.3 * rnd(703, n, C)], 1).contiguous().cuda()
+    tiles = n * (h // 2) * (w // 2)
+    V = torch.empty(16, tiles, C, device="cuda")
+    L.call("ldmk_winograd_input", x0.data_ptr(), c0, 0 if x1 is None else x1.data_ptr(), c1, coef.data_ptr(), 1, n, h, w, V.data_ptr(),
+           ops.stream())
+    flag = _flag()
+    Vps = ops.ps_empty(tiles, C, batch=16, h2=True)
+    L.call("ldmk_winograd_input_ps_h2", x0.data_ptr(), c0, 0 if x1 is None else x1.data_ptr(), c1, coef.data_ptr(), 1, n, h, w,
+           Vps.data_ptr(), flag.data_ptr(), ops.stream())
+    ref = ops.pack_ps(V, h2_flag=flag)
+    nb = (tiles // 32) * (C // 16) * 2048
+    assert torch.equal(Vps[:, :nb], ref[:, :nb]) and int(flag.item()) == 0
+    x0[0, 1, 1, 3] = 5000.0
+    L.call("ldmk_winograd_input_ps_h2", x0.data_ptr(), c0, 0 if x1 is None else x1.data_ptr(), c1, coef.data_ptr(), 1, n, h, w,
+           Vps.data_ptr(), flag.data_ptr(), ops.stream())
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("case", [(2, 320, 16, 16), (1, 64, 5, 7), (1, 640, 16, 16)])
+def test_upconv_gather_in_the_f16x2_ps_layout(ops, case):
+    from dsml_thesis_amd import lib as L
+    n, c, h, w = case
+    x = rnd(710, n, h, w, c).cuda()
+    pix = n * h * w
+    A = torch.empty(4, pix, 4 * c, device="cuda")
+    L.call("ldmk_upconv_gather", x.data_ptr(), c, n, h, w, A.data_ptr(), ops.stream())
+    flag = _flag()
+    Aps = ops.ps_empty(pix, 4 * c, batch=4, h2=True)
+    L.call("ldmk_upconv_gather_ps_h2", x.data_ptr(), c, n, h, w, Aps.data_ptr(), flag.data_ptr(), ops.stream())
+    ref = ops.pack_ps(A, h2_flag=flag)
+    nb = (pix // 32) * (4 * c // 16) * 2048
+    assert torch.equal(Aps[:, :nb], ref[:, :nb]) and int(flag.item()) == 0
+
+
+@pytest.mark.parametrize("cfg", [23, 24, 27, 31])
+def test_ps_h2_gemm_batched_planes(ops, cfg):
+    """The Winograd form on the pre-split tiles in F16X2: 16 plane products in one launch, one weight scale for the batch;
+    bitwise tile_cfg 5's F16X2 result."""
+    from dsml_thesis_amd import lib as L
+    B, M, K, N = 16, 256, 320, 640
+    a_ = rnd(530, B, M, K).cuda().contiguous()
+    w = (rnd(531, B, K, N) / np.sqrt(K)).cuda().contiguous()
+    ops.pack_wsplit_h2(w, batch=B)
+    flag = _flag()
+    wps, aps = ops.pack_wps(w, batch=B, h2=True), ops.pack_ps(a_, h2_flag=flag)
+    ref, out = torch.empty(B, M, N, device="cuda"), torch.empty(B, M, N, device="cuda")
+    ar = ops.make_igemm_args(M, N, K, a_, K, w, ref, N, M, batch=B, a_bstride=M * K, w_bstride=K * N, out_bstride=M * N, tile_cfg=5, splitk=1,
+                             compute=L.COMPUTE_F16X2, range_flag=flag)
+    ops.igemm(ar)
+    ar = ops.make_igemm_args(M, N, K, None, K, w, out, N, M, batch=B, w_bstride=K * N, out_bstride=M * N, tile_cfg=cfg, splitk=1,
+                             a_ps=aps, w_ps=wps, range_flag=flag)
+    ops.igemm(ar)
+    assert torch.equal(out, ref) and int(flag.item()) == 0
+
+
+@pytest.mark.parametrize("n,tokens,heads", [(2, 1024, 5), (1, 512, 20), (1, 4096, 5)])
+def test_f16x2_attention_writes_its_result_in_the_f16x2_ps_layout(ops, n, tokens, heads):
+    """ldmk_attn_self_h2_ps: the attention result straight from the accumulators as two fp16 planes of 2^6 x -- exactly pack_ps(h2)
+    of the fp32 result, with or without the fp32 copy."""
+    from dsml_thesis_amd import lib as L
+    C_ = heads * 32
+    qkv = (rnd(570, n * tokens, 3 * C_) * 1.2).cuda()
+    flag = _flag()
+    ref = ops.attn_self(qkv, n, tokens, heads, h2_flag=flag)
+    kv = torch.empty(L.load().ldmk_attn_kv_split_h2_bytes(n, tokens, heads), device="cuda", dtype=torch.uint8)
+    for with_fp32 in (True, False):
+        out = torch.zeros(n * tokens, C_, device="cuda")
+        ps = ops.ps_empty(n * tokens, C_, h2=True)
+        L.call("ldmk_attn_self_h2_ps", qkv.data_ptr(), kv.data_ptr(), out.data_ptr() if with_fp32 else 0, ps.data_ptr(), flag.data_ptr(), n, tokens,
+               heads, 32 ** -0.5, ops.stream())
+        assert torch.equal(ps, ops.pack_ps(ref, h2_flag=flag))
+        assert torch.equal(out, ref) if with_fp32 else out.abs().max().item() == 0.0
+    assert int(flag.item()) == 0
+    with pytest.raises(L.LdmkError, match="tokens"):
+        L.call("ldmk_attn_self_h2_ps", qkv.data_ptr(), kv.data_ptr(), 0, ps.data_ptr(), flag.data_ptr(), 1, 60, heads, 0.1, ops.stream())
