@@ -49,7 +49,9 @@ def main():
     flag = torch.zeros(1, device="cuda", dtype=torch.int32)
     COMP = L.COMPUTE_F16X2 if h2 else L.COMPUTE_BF16X3
     shapes = SHAPES[:6] if quick else ([SHAPES[0], SHAPES[1], SHAPES[4], SHAPES[13]] if probe else SHAPES)
+    mdiv = 4 if "--latent32" in sys.argv else 1      # the same layers at 32x32 (a quarter of the rows)
     for (M, N, K, geglu, lnf, B, label) in shapes:
+        M //= mdiv
         R = 3
         g = torch.Generator(device="cuda").manual_seed(1)
         xs = [torch.randn(B, M, K, device="cuda", generator=g) for _ in range(R)]
