@@ -9,8 +9,10 @@ rm -rf $O && mkdir -p $O
 python3 $R/bench.py > $O/r04_bench_default.json 2> $O/bench_default.err
 # the same command with every product on the f32 matrix cores (the round-2 arithmetic), for the A/B on one box
 LDMK_SPLIT_BF16=0 python3 $R/bench.py --no-cpu-baseline --no-clip --no-extras > $O/r04_bench_default_f32_mfma.json 2>> $O/bench_default.err
-# the round-3 kernels on this box (no pre-split tiles, attention splitting K / V in its key loop), for the A/B of this round's work
-LDMK_PS=0 LDMK_ATTN_PRESPLIT=0 python3 $R/bench.py --no-cpu-baseline --no-clip --no-extras > $O/r04_bench_round3_kernels.json 2>> $O/bench_default.err
+# the bf16x3 arithmetic of this round (LDMK_F16X2=0: six bf16 MFMAs per product, pre-split tiles + pre-split attention) and the round-3
+# kernels (no pre-split tiles, attention splitting K / V in its key loop) on this box, for the A/B of this round's work
+LDMK_F16X2=0 python3 $R/bench.py --no-cpu-baseline --no-clip --no-extras > $O/r04_bench_bf16x3.json 2>> $O/bench_default.err
+LDMK_F16X2=0 LDMK_PS=0 LDMK_ATTN_PRESPLIT=0 python3 $R/bench.py --no-cpu-baseline --no-clip --no-extras > $O/r04_bench_round3_kernels.json 2>> $O/bench_default.err
 B="python3 $R/bench.py --no-secondary --no-cpu-baseline --no-clip --no-extras"
 for lat in 64 32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks$lat -- $B --latent $lat > $O/r04_bench${lat}_under_rocprof.json 2> $O/ks$lat.log
@@ -29,9 +31,6 @@ rocprofv3 --kernel-trace --output-format csv -d $O/lpb1 -- python3 $R/tools/laye
 python3 $R/tools/layer_profile.py --join $O/lpb1 > $O/r04_layers32_b1.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tr -- python3 $R/bench.py --train --bf16 --latent 64 --batch 16 --steps 3 --warmup 1 > $O/r04_train_bf16_64.json 2> $O/tr.log
 python3 $R/tools/summarize_rocprof.py $O/tr $O/r04_train_step_bf16_kernel_stats.txt > /dev/null
-python3 $R/tools/marginal_cost.py --latent 32 --batch 1 > $O/r04_marginal_cost_b1.txt 2>&1
-LDMK_PS_DEBUG=8 python3 $R/tools/pw_stamps.py > $O/r04_pw_stamps.txt 2>&1
-python3 $R/tools/ps_bench.py > $O/r04_ps_bench.txt 2>&1
 # keep the merge small: drop the raw traces
 find $O -name "*.csv" -size +2M -delete
 find $O -name "*.db" -delete

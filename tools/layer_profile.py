@@ -48,7 +48,7 @@ def dump(latent, batch, path, graph=False):
 
 KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "igemm_ws_kernel", "igemm_ps_kernel", "igemm_pw_kernel", "rgemm_kernel", "sgemm_kernel"), "ldmk_post": ("post_",),
              "ldmk_attn_self_small": ("attn_small",), "ldmk_conv3x3_out_small": ("conv3x3_out_small",), "ldmk_gn_finalize": ("gn_finalize",), "ldmk_gn_apply": ("gn_apply",),
-             "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_ln_stats_guard": ("ln_stats",), "ldmk_ln_stats_split": ("ln_stats",), "ldmk_ln_stats_ps": ("ln_stats_ps",), "ldmk_ln_stats_ps_h2": ("ln_stats_ps",), "ldmk_pack_ps": ("pack_ps",), "ldmk_attn_self": ("attn_self",), "ldmk_attn_self_x3": ("attn_x3",), "ldmk_attn_self_x3p": ("attn_kv_split",), "ldmk_attn_self_x3p_ps": ("attn_kv_split",), "ldmk_attn_self_h2": ("attn_kv_split_h2",),
+             "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_ln_stats_guard": ("ln_stats",), "ldmk_ln_stats_split": ("ln_stats",), "ldmk_ln_stats_ps": ("ln_stats_ps",), "ldmk_ln_stats_ps_h2": ("ln_stats_ps",), "ldmk_pack_ps": ("pack_ps",), "ldmk_attn_self": ("attn_self",), "ldmk_attn_self_x3": ("attn_x3",), "ldmk_attn_self_x3p": ("attn_kv_split",), "ldmk_attn_self_x3p_ps": ("attn_kv_split",), "ldmk_attn_self_h2": ("attn_kv_split_h2",), "ldmk_attn_self_h2_ps": ("attn_kv_split_h2",),
              "ldmk_attn_cross": ("attn_cross",), "ldmk_dense_small": ("dense_small",),
              "ldmk_timestep_embedding": ("timestep_embedding",), "ldmk_conv3x3_in": ("conv3x3_in",),
              "ldmk_conv3x3_out": ("conv3x3_out",), "ldmk_winograd_input": ("wino_input",), "ldmk_winograd_input_ps": ("wino_input_ps",), "ldmk_upconv_gather_ps": ("upconv_gather_ps",), "ldmk_winograd_input_ps_h2": ("wino_input_ps",), "ldmk_upconv_gather_ps_h2": ("upconv_gather_ps",),
@@ -66,7 +66,7 @@ def join(d):
     tr = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = [r for r in csv.DictReader(open(tr)) if "ldmk::" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    per = sum(2 if (c["name"] in ("ldmk_post", "ldmk_attn_self_x3p", "ldmk_attn_self_x3p_ps", "ldmk_attn_self_h2") or (c["name"] == "ldmk_igemm" and c.get("sk", 1) > 1 and not 7 <= c.get("cfg", 0) <= 12)) else 1
+    per = sum(2 if (c["name"] in ("ldmk_post", "ldmk_attn_self_x3p", "ldmk_attn_self_x3p_ps", "ldmk_attn_self_h2", "ldmk_attn_self_h2_ps") or (c["name"] == "ldmk_igemm" and c.get("sk", 1) > 1 and not 7 <= c.get("cfg", 0) <= 12)) else 1
               for c in calls) + 1
     # the last step of the trace: find it by walking back from the end to the step's first kernel (timestep_embedding)
     starts = [i for i, r in enumerate(rows) if "timestep_embedding" in r["Kernel_Name"]]
@@ -86,8 +86,8 @@ def join(d):
         assert want is None or any(w in r["Kernel_Name"] for w in want), (c, r["Kernel_Name"])
         d_ = dur(r)
         i += 1
-        if c["name"] in ("ldmk_attn_self_x3p", "ldmk_attn_self_x3p_ps", "ldmk_attn_self_h2"):          # K / V pre-pass + attention kernel
-            assert ("attn_h2_fwd" if c["name"] == "ldmk_attn_self_h2" else "attn_x3p") in last[i]["Kernel_Name"], last[i]["Kernel_Name"]
+        if c["name"] in ("ldmk_attn_self_x3p", "ldmk_attn_self_x3p_ps", "ldmk_attn_self_h2", "ldmk_attn_self_h2_ps"):          # K / V pre-pass + attention kernel
+            assert ("attn_h2_fwd" if c["name"].startswith("ldmk_attn_self_h2") else "attn_x3p") in last[i]["Kernel_Name"], last[i]["Kernel_Name"]
             c["prepass_us"] = d_
             d_ += dur(last[i])
             i += 1
