@@ -368,7 +368,11 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
             ln_lin(h2, q + "ff1_ln", True, out_ps=f_ps)
             # the last block's ff.net.2 also writes its result pre-split when proj_out runs on a pre-split tile
             last = d == m.depth - 1
-            plan_p = nb_.ps_query(rows, m.ch, C_) if (last and prefix + "pout" + psfx in P and plan_f[1] <= 1) else None   # (a split-K ff.net.2 has no PS epilogue)
+            # (proj_out on a pre-split tile: built and tested, off by default -- its epilogue carries the GroupNorm records of the block
+            #  output, the lane = column form of the kernel, and loses to the row GEMM in the step: 951.5 vs 959.6 sample-steps/s with
+            #  attn1.to_out off as well, A/B on one box; LDMK_POUT_PS=1 turns it on.  A split-K ff.net.2 has no PS epilogue.)
+            plan_p = (nb_.ps_query(rows, m.ch, C_) if (last and prefix + "pout" + psfx in P and plan_f[1] <= 1
+                                                       and os.environ.get("LDMK_POUT_PS", "0") == "1") else None)
             hc_ps = pg.alloc_ps(rows, C_) if plan_p is not None else None
             hcur = nb_.lin_ps(plan_f, rows, Nf, f_ps, P[q + "ff2"], P[q + "ff2" + psfx], sd[q + "ff.net.2.bias"], hw, out=h2, residual=h2,
                               out_ps=hc_ps)

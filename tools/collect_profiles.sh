@@ -5,7 +5,10 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04p
-rm -rf $O && mkdir -p $O
+# two calls of at most 20 minutes each: PART=1 the bench lines (A/B of the arithmetics on one box), PART=2 the profiler passes
+PART=${PART:-12}
+mkdir -p $O
+if [[ $PART == *1* ]]; then
 python3 $R/bench.py > $O/r04_bench_default.json 2> $O/bench_default.err
 # the same command with every product on the f32 matrix cores (the round-2 arithmetic), for the A/B on one box
 LDMK_SPLIT_BF16=0 python3 $R/bench.py --no-cpu-baseline --no-clip --no-extras > $O/r04_bench_default_f32_mfma.json 2>> $O/bench_default.err
@@ -13,6 +16,8 @@ LDMK_SPLIT_BF16=0 python3 $R/bench.py --no-cpu-baseline --no-clip --no-extras > 
 # kernels (no pre-split tiles, attention splitting K / V in its key loop) on this box, for the A/B of this round's work
 LDMK_F16X2=0 python3 $R/bench.py --no-cpu-baseline --no-clip --no-extras > $O/r04_bench_bf16x3.json 2>> $O/bench_default.err
 LDMK_F16X2=0 LDMK_PS=0 LDMK_ATTN_PRESPLIT=0 python3 $R/bench.py --no-cpu-baseline --no-clip --no-extras > $O/r04_bench_round3_kernels.json 2>> $O/bench_default.err
+fi
+if [[ $PART != *2* ]]; then ls $O; exit 0; fi
 B="python3 $R/bench.py --no-secondary --no-cpu-baseline --no-clip --no-extras"
 for lat in 64 32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks$lat -- $B --latent $lat > $O/r04_bench${lat}_under_rocprof.json 2> $O/ks$lat.log
