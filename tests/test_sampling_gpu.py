@@ -52,6 +52,38 @@ def test_ddim_sample_S4_and_graph_replay(fr):
     assert torch.equal(out, out_g2), "a cached graph replays from a clean state"
 
 
+def test_f16x2_range_fallback_inside_a_graphed_sampling_run(monkeypatch):
+    """The F16X2 range flag in a SAMPLING run under hipGraph replay (no host read inside the loop): a checkpoint whose attn1.to_k
+    weights are 3000 x larger (to_q as much smaller: same logits) finishes its DDIM run, the sampler reads the flag once, warns,
+    and repeats the run in the bf16x3 arithmetic -- bit for bit the run of a model started with LDMK_F16X2=0, graph or eager."""
+    import warnings
+    from dsml_thesis_amd.ddim import DDIMSampler
+
+    def model():
+        m = make_fr_model(gain=0.25)
+        sd = m.model.diffusion_model.state_dict()
+        key = "input_blocks.1.1.transformer_blocks.0.attn1.to_k.weight"
+        sd[key] = sd[key] * 3000.0
+        sd[key.replace("to_k", "to_q")] = sd[key.replace("to_k", "to_q")] / 3000.0
+        m.model.diffusion_model.load_state_dict(sd, strict=True)
+        return m
+    xT = rnd(52, 16, 3, 32, 32).cuda()
+    m = model()
+    c, _ = _cond(m, labels=tuple(i % 7 for i in range(16)))       # (class ids of the 8-class embedder)
+    unet = m.model.diffusion_model
+    assert unet.f16x2
+    with pytest.warns(RuntimeWarning, match="F16X2"):
+        out, _ = DDIMSampler(m).sample(S=4, batch_size=16, shape=[3, 32, 32], conditioning=c, eta=0.0, x_T=xT, verbose=False, use_graph=True)
+    assert not unet.f16x2 and torch.isfinite(out).all()
+    monkeypatch.setenv("LDMK_F16X2", "0")
+    m0 = model()
+    assert not m0.model.diffusion_model.f16x2
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ref, _ = DDIMSampler(m0).sample(S=4, batch_size=16, shape=[3, 32, 32], conditioning=c, eta=0.0, x_T=xT, verbose=False, use_graph=False)
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("latent", [32, 64])
 def test_config0_ddim50_batch1_end_to_end(fr, latent):
     """BASELINE configs[0]: DDIM 50 steps, batch 1, the 'unconditional' plumbing case.  A spatial-transformer UNet fed
