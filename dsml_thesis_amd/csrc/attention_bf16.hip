@@ -1097,8 +1097,23 @@ extern "C" int ldmk_attn_self_h2(const float* qkv, void* kv_scratch, float* out,
   return ldmk_attn_self_h2_ps(qkv, kv_scratch, out, nullptr, range_flag, n, tokens, heads, scale, stream);
 }
 
+static int attn_self_h2_any(const float* qkv, void* kv_scratch, float* out, void* out_ps, int* range_flag, int n, int tokens, int heads,
+                            float scale, bool prepass, void* stream);
+
 extern "C" int ldmk_attn_self_h2_ps(const float* qkv, void* kv_scratch, float* out, void* out_ps, int* range_flag, int n, int tokens, int heads,
                                     float scale, void* stream) {
+  return attn_self_h2_any(qkv, kv_scratch, out, out_ps, range_flag, n, tokens, heads, scale, true, stream);
+}
+
+extern "C" int ldmk_attn_self_h2_tiles(const float* qkv, const void* kv_tiles, float* out, void* out_ps, int* range_flag, int n, int tokens,
+                                       int heads, float scale, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(tokens % 64 == 0, "ldmk_attn_self_h2_tiles: tokens=%d must be a multiple of 64 (whole K / V tiles)", tokens);
+  return attn_self_h2_any(qkv, const_cast<void*>(kv_tiles), out, out_ps, range_flag, n, tokens, heads, scale, false, stream);
+}
+
+static int attn_self_h2_any(const float* qkv, void* kv_scratch, float* out, void* out_ps, int* range_flag, int n, int tokens, int heads,
+                            float scale, bool prepass, void* stream) {
   LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(qkv && kv_scratch && (out || out_ps) && range_flag && n > 0 && tokens > 0 && heads > 0 && heads <= 65535 && n <= 65535,
@@ -1107,8 +1122,9 @@ extern "C" int ldmk_attn_self_h2_ps(const float* qkv, void* kv_scratch, float* o
   const int ntiles = (tokens + BA_T - 1) / BA_T;
   LDMK_REQUIRE((long long)ntiles * H2_TILE < (1LL << 31), "ldmk_attn_self_h2: %d tokens: a head's pre-split K / V exceeds 2 GiB", tokens);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_kv_split_h2_kernel, dim3(ntiles, heads, n), dim3(256), 0, st, qkv, reinterpret_cast<unsigned char*>(kv_scratch), tokens, heads,
-                     range_flag);
+  if (prepass)
+    hipLaunchKernelGGL(attn_kv_split_h2_kernel, dim3(ntiles, heads, n), dim3(256), 0, st, qkv, reinterpret_cast<unsigned char*>(kv_scratch), tokens,
+                       heads, range_flag);
   static const int qb_env = [] { const char* e = getenv("LDMK_ATTN_QB"); return e ? atoi(e) : 0; }();
   const int qb = qb_env == 1 || qb_env == 2 ? qb_env : (tokens >= X3P_QB2_MIN_TOKENS ? 2 : 1);
   if (qb == 2)

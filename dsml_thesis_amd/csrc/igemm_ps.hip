@@ -101,9 +101,17 @@ __device__ __forceinline__ void ps_split3(const float4& v, pbf16x4& h, pbf16x4& 
 __device__ __attribute__((aligned(16))) const float kPsZeros[4] = {0.f, 0.f, 0.f, 0.f};
 
 // The epilogue of one wave: acc[TM][TN] 32x32 tiles at (rowbase, colbase).  TR: transposed accumulators (lane = row).
-template <int TM, int TN, bool TR, int PL = 3>
+// KV (F16X2, transposed epilogue, the fused QKV projection): the K and V column tiles of the result are not stored as fp32 but written
+// straight as the self attention's pre-split tiles (csrc/attention_bf16.hip: attn_h2_fwd_kernel; per (sample, head, 64 keys) 8
+// fragments x 2 fp16 planes of 1 KiB) -- what ldmk_attn_self_h2's pre-pass would make of them, bit for bit, without the fp32 round
+// trip.  A K fragment wants lane = (key, half) with 8 consecutive d: the transposed accumulator has 4 + 4 of them in the two
+// half-lanes, one v_permlane32_swap per register pairs them up.  A V^T fragment wants lane = d: one pass through a per-wave LDS
+// scratch (`kv_ts`, 32 x 33 floats; the ring is free by then).
+constexpr int PS_KV_TILE = 16 * 1024;          // = H2_TILE of csrc/attention_bf16.hip
+template <int TM, int TN, bool TR, int PL = 3, bool KV = false>
 __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&acc)[TM][TN], const int rowbase, const int colbase,
-                                            const int splitk, const int ks, const int bz, float* __restrict__ ws, const int lane) {
+                                            const int splitk, const int ks, const int bz, float* __restrict__ ws, const int lane,
+                                            float* __restrict__ kv_ts = nullptr) {
   const int l31 = lane & 31, half = lane >> 5;
   const float alpha = p.alpha;
   const bool lnf = p.a_tf == LDMK_TF_LAYERNORM_FOLDED;
@@ -158,6 +166,8 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
           const int ctile = colbase + 32 * jt;
           if (ctile >= p.N) continue;
           const int otile = geglu ? (ctile >> 1) : ctile;            // first output column of this tile
+          float kvv[KV ? 16 : 1];                                    // KV: the finished values of a K / V tile (column 8 q + 4 half + e at [4 q + e])
+          const bool kv_tile = KV && ctile >= p.N / 3;
 #pragma unroll
           for (int qh = 0; qh < 4; qh += 2) {                        // (two column groups at a time: registers)
           float4 cs[4], bi[4], bv[4], rs[4], csg[4], big[4];
@@ -200,7 +210,10 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
             }
             v.x += bv[q].x; v.y += bv[q].y; v.z += bv[q].z; v.w += bv[q].w;
             v.x += rs[q].x; v.y += rs[q].y; v.z += rs[q].z; v.w += rs[q].w;
-            if (rok) {
+            if constexpr (KV) {
+              if (kv_tile) { kvv[4 * q] = v.x; kvv[4 * q + 1] = v.y; kvv[4 * q + 2] = v.z; kvv[4 * q + 3] = v.w; }
+            }
+            if (rok && !kv_tile) {
               const int oc = otile + 8 * q + 4 * half;               // output column
               if (outp) *reinterpret_cast<float4*>(outp + rowoff + oc) = v;
               if (ops_) {
@@ -221,6 +234,66 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
               }
             }
           }
+          }
+          if constexpr (KV) {
+            if (kv_tile && rowbase + 32 * i < p.M) {
+              const int Cq = p.N / 3;
+              const int sec = ctile / Cq;                            // 1 = K, 2 = V
+              const int hh = (ctile - sec * Cq) >> 5;
+              const int r0 = rowbase + 32 * i;
+              const int bsm = r0 / p.attn_tokens, key0 = r0 - bsm * p.attn_tokens;
+              const int ntl = p.attn_tokens >> 6;
+              unsigned char* dst = reinterpret_cast<unsigned char*>(p.attn_kv_out) +
+                                   (((long long)bsm * (Cq >> 5) + hh) * ntl + (key0 >> 6)) * PS_KV_TILE + lane * 16;
+              const int sub = (key0 >> 5) & 1;
+              bool bad = false;
+              if (sec == 1) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                  float vals[8];
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(kvv[8 * t + e]), __float_as_uint(kvv[8 * t + 4 + e]), false, false);
+                    vals[e] = __uint_as_float(r[0]);
+                    vals[4 + e] = __uint_as_float(r[1]);
+                  }
+                  const float4 v0 = make_float4(vals[0], vals[1], vals[2], vals[3]), v1 = make_float4(vals[4], vals[5], vals[6], vals[7]);
+                  bad |= ps_h2_out_of_range(v0) || ps_h2_out_of_range(v1);
+                  pf16x4 h0, l0, h1, l1;
+                  ps_split2h(ps_scaled(v0, PS_H2_SCALE), h0, l0);
+                  ps_split2h(ps_scaled(v1, PS_H2_SCALE), h1, l1);
+                  unsigned char* d = dst + (2 * sub + t) * 2048;
+                  *reinterpret_cast<pf16x8*>(d) = pf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                  *reinterpret_cast<pf16x8*>(d + 1024) = pf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                }
+              } else {
+                // V^T: [token = l31][d = 8 q + 4 half + e] -> LDS -> lane = d reads 8 keys in the order the probabilities leave
+                // the first product's accumulator (keys 16 t + 4 half + (j & 3) + 8 (j >> 2))
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) kv_ts[l31 * 33 + 8 * q + 4 * half + e] = kvv[4 * q + e];
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                  float vals[8];
+#pragma unroll
+                  for (int jx = 0; jx < 8; ++jx) vals[jx] = kv_ts[(16 * t + 4 * half + (jx & 3) + 8 * (jx >> 2)) * 33 + l31];
+                  const float4 v0 = make_float4(vals[0], vals[1], vals[2], vals[3]), v1 = make_float4(vals[4], vals[5], vals[6], vals[7]);
+                  bad |= ps_h2_out_of_range(v0) || ps_h2_out_of_range(v1);
+                  pf16x4 h0, l0, h1, l1;
+                  ps_split2h(ps_scaled(v0, PS_H2_SCALE), h0, l0);
+                  ps_split2h(ps_scaled(v1, PS_H2_SCALE), h1, l1);
+                  unsigned char* d = dst + (4 + 2 * sub + t) * 2048;
+                  *reinterpret_cast<pf16x8*>(d) = pf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                  *reinterpret_cast<pf16x8*>(d + 1024) = pf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_wave_barrier();
+              }
+              if (bad) *p.range_flag = 1;
+            }
           }
         }
       }
@@ -340,7 +413,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
   }
 }
 
-template <int NWM, int NWN, int TM, int TN, int NS, bool TR, int PL = 3>
+template <int NWM, int NWN, int TM, int TN, int NS, bool TR, int PL = 3, bool KV = false>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int dbg) {
   constexpr int NW = NWM * NWN;
   constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN;
@@ -490,7 +563,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
     if (keep == 12345.678f && ws) ws[0] = keep;
     return;
   }
-  ps_epilogue<TM, TN, TR, PL>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+  if constexpr (KV) {
+    __syncthreads();            // every wave is done with the ring: its memory becomes the per-wave V^T transpose scratch
+    ps_epilogue<TM, TN, TR, PL, true>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane,
+                                       reinterpret_cast<float*>(smem_ps) + wave * (32 * 33));
+  } else {
+    ps_epilogue<TM, TN, TR, PL>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -801,20 +880,21 @@ static const PsCfg kPsCfg[] = {{256, 160, false}, {256, 320, false}, {256, 256, 
                                // CU, whose DMA issue / barrier / epilogue phases overlap the other one's matrix work
                                {256, 160, false}, {256, 128, true}, {128, 256, true}};
 
-template <int NWM, int NWN, int TM, int TN, int NS, bool TR, int PL = 3>
+template <int NWM, int NWN, int TM, int TN, int NS, bool TR, int PL = 3, bool KV = false>
 static int ps_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
   constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN;
   constexpr size_t lds = (size_t)NS * (BM / 32 + BN / 32) * PL * 1024;
   static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR, PL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR, PL, KV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   static const int dbg = (getenv("LDMK_PS_DEBUG") ? atoi(getenv("LDMK_PS_DEBUG")) : 0) | ((getenv("LDMK_PS_STAGGER") ? atoi(getenv("LDMK_PS_STAGGER")) : 0) << 8);
-  hipLaunchKernelGGL((igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR, PL>), dim3(tiles, splitk, a.batch > 1 ? a.batch : 1), dim3(64 * NWM * NWN), lds,
+  static_assert(!KV || (size_t)NWM * NWN * 32 * 33 * 4 <= lds, "V^T transpose scratch fits the ring");
+  hipLaunchKernelGGL((igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR, PL, KV>), dim3(tiles, splitk, a.batch > 1 ? a.batch : 1), dim3(64 * NWM * NWN), lds,
                      st, a, splitk, ws, dbg);
   if (splitk > 1 && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
   return check_launch("ldmk_igemm(ps)");
@@ -858,12 +938,21 @@ const char* igemm_ps_unsupported(const ldmk_igemm_args& a, int pcfg, int splitk)
     return "no output";
   }
   if (a.stats_out && !a.out) return "stats_out needs out";
+  if (a.attn_kv_out) {
+    if (pl != 2 || (pcfg != 0 && pcfg != 4)) return "attn_kv_out: the F16X2 arithmetic on tile_cfg 23 / 27";
+    if (a.stats_out || splitk > 1 || a.batch > 1 || a.epi != LDMK_EPI_NONE || a.out_ps || !a.out || !a.range_flag)
+      return "attn_kv_out: the fused QKV projection (no split-K / batching / GEGLU / records / out_ps; out and range_flag required)";
+    if (a.attn_heads <= 0 || a.N != 3 * 32 * a.attn_heads) return "attn_kv_out: N must be 3 x 32 x attn_heads ([q | k | v] of d_head 32)";
+    if (a.attn_tokens <= 0 || a.attn_tokens % 64 || a.M % a.attn_tokens) return "attn_kv_out: attn_tokens a multiple of 64 that divides M";
+  }
   return nullptr;
 }
 
 int igemm_ps_dispatch(const ldmk_igemm_args& a, int pcfg, int splitk, float* ws, hipStream_t st) {
   // the transposed epilogue serves every call but those that want GroupNorm records
   const bool tr = !a.stats_out;
+  if (a.compute == LDMK_COMPUTE_F16X2 && a.attn_kv_out)      // the fused QKV projection writing the attention's K / V tiles (unsupported() admits 0 / 4)
+    return pcfg == 0 ? ps_launch<8, 1, 1, 5, 3, true, 2, true>(a, splitk, ws, st) : ps_launch<4, 1, 1, 5, 3, true, 2, true>(a, splitk, ws, st);
   if (a.compute == LDMK_COMPUTE_F16X2) {       // two fp16 planes per operand, three matrix instructions per product; one more ring stage fits
     switch (pcfg) {
       case 0: return tr ? ps_launch<8, 1, 1, 5, 3, true, 2>(a, splitk, ws, st) : ps_launch<8, 1, 1, 5, 3, false, 2>(a, splitk, ws, st);

@@ -39,6 +39,7 @@ class IgemmArgs(C.Structure):
         ("a_split", _fp), ("a_split_ld", C.c_int),
         ("a_ps", _fp), ("a_ps_bstride", C.c_longlong), ("w_ps", _fp), ("w_ps_bstride", C.c_longlong), ("out_ps", _fp),
         ("w_scale_exp", C.c_int), ("range_flag", _fp),
+        ("attn_kv_out", _fp), ("attn_tokens", C.c_int), ("attn_heads", C.c_int),
     ]
 
 
@@ -113,6 +114,7 @@ _SIGS = {
     "ldmk_attn_kv_split_h2_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "ldmk_attn_self_h2": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_self_h2_ps": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    "ldmk_attn_self_h2_tiles": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_self_small": (C.c_int, [_fp, C.c_int, C.c_longlong, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_cross": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_float, _fp]),

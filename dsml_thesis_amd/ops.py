@@ -247,7 +247,7 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
                     batch_vec=None, batch_vec_ld=0, residual=None, epi=L.EPI_NONE, batch=1, a_bstride=0, w_bstride=0,
                     out_bstride=0, alpha=1.0, splitk=0, splitk_ws=None, w_frag=None, tile_cfg=0, compute=0, ln_colsum=None,
                     splitk_counters=None, raw_slabs=False, a_split=None, w_bf16t=None, a_ps=None, w_ps=None, out_ps=None,
-                    range_flag=None):
+                    range_flag=None, attn_kv=None):
     a = L.IgemmArgs()
     # the struct holds raw device pointers: keep every operand alive as long as the args object lives (a temporary passed
     # inline -- bias=b.cuda() -- would otherwise be freed, and its block possibly re-used, before the launch is enqueued)
@@ -290,6 +290,9 @@ def make_igemm_args(M, N, K, a0, c0, w, out, ldc, rows_per_sample, a1=None, c1=0
         if hit is not None and hit[0]() is w_ps:        # F16X2 planes (pack_wps(h2=True)): a_ps / out_ps are in that form too
             a.compute, a.w_scale_exp, a.range_flag = L.COMPUTE_F16X2, hit[1], _ptr(range_flag)
             a._keep = a._keep + (range_flag,)
+            if attn_kv is not None:                     # (kv tile buffer, tokens per sample, heads): the fused QKV projection writes
+                a.attn_kv_out, a.attn_tokens, a.attn_heads = _ptr(attn_kv[0]), int(attn_kv[1]), int(attn_kv[2])     # the attention's K / V tiles
+                a._keep = a._keep + (attn_kv[0],)
         else:
             a.compute = L.COMPUTE_BF16X3
         return a

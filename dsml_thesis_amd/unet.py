@@ -145,7 +145,7 @@ def attention_presplit(hw):
     return engine_split_enabled() and hw >= ATTN_PRESPLIT_MIN_TOKENS and os.environ.get("LDMK_ATTN_PRESPLIT", "1") != "0"
 
 
-def emit_self_attention(nb_, qkv, att, hw, heads, d_head, att_ps=None):
+def emit_self_attention(nb_, qkv, att, hw, heads, d_head, att_ps=None, kv_tiles=None):
     """softmax(q k^T / sqrt d) v over token rows [q | k | v] (n hw x 3 C) -> att (n hw x C).  With the split arithmetic on: both
     products fp32-accurate on the 16-bit matrix cores.  From ATTN_H2_MIN_TOKENS tokens per sample, while the model's range flag
     is down (nb_.h2_flag): the F16X2 form -- three fp16 products per term, K / V split once by a pre-pass and moved to LDS by
@@ -155,7 +155,11 @@ def emit_self_attention(nb_, qkv, att, hw, heads, d_head, att_ps=None):
     pg, n = nb_.pg, nb_.n
     scale = d_head ** -0.5
     h2_flag = getattr(nb_, "h2_flag", None)
-    if h2_flag is not None and hw >= ATTN_H2_MIN_TOKENS:
+    if h2_flag is not None and kv_tiles is not None:
+        # the QKV projection's epilogue already wrote K / V as the kernel's pre-split tiles (ldmk_igemm_args.attn_kv_out): no pre-pass
+        pg.add("ldmk_attn_self_h2_tiles", qkv.data_ptr(), kv_tiles.data_ptr(), 0 if att is None else att.data_ptr(),
+               0 if att_ps is None else att_ps.data_ptr(), h2_flag.data_ptr(), n, hw, heads, scale)
+    elif h2_flag is not None and hw >= ATTN_H2_MIN_TOKENS:
         kvs = pg.alloc(pg.lib.ldmk_attn_kv_split_h2_bytes(n, hw, heads), dtype=torch.uint8)
         if att_ps is not None:       # the result in the (F16X2) PS layout only: the A operand of attn1.to_out on a pre-split tile
             pg.add("ldmk_attn_self_h2_ps", qkv.data_ptr(), kvs.data_ptr(), 0 if att is None else att.data_ptr(), att_ps.data_ptr(),
@@ -274,7 +278,9 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
     h2_flag = getattr(nb_, "h2_flag", None)
     psfx = "#p2" if h2_flag is not None else "#p"       # the PS weight copies in the form of the program's arithmetic
 
-    def ln_lin(x2d, wkey, geglu, out_ps=None):
+    kv_state = {"tiles": None}
+
+    def ln_lin(x2d, wkey, geglu, out_ps=None, attn_kv=None):
         """LayerNorm statistics + the Linear the LayerNorm is folded through.  With a pre-split plan for the GEMM
         (engine.ps_query: csrc/igemm_ps.hip) the statistics pass also writes the rows in the PS layout and the GEMM moves them
         to LDS by LDS-DMA -- every element is split once, by this pass, instead of once per N-tile inside the GEMM.
@@ -288,8 +294,13 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
                 pg.add("ldmk_ln_stats_ps_h2", p_(x2d), rows, C_, 1e-5, p_(stats), p_(xs), LN_GUARD_RATIO, p_(ln_flag), p_(h2_flag))
             else:
                 pg.add("ldmk_ln_stats_ps", p_(x2d), rows, C_, 1e-5, p_(stats), p_(xs), LN_GUARD_RATIO, p_(ln_flag))
+            kw = {}
+            if attn_kv is not None and h2_flag is not None and int(plan[0]) in (23, 27) and int(plan[1]) <= 1:
+                # the fused QKV projection writes K / V straight as the attention's pre-split tiles (no fp32 K / V, no pre-pass)
+                kw["attn_kv"] = attn_kv
+                kv_state["tiles"] = attn_kv[0]
             y = nb_.lin_ps(plan, rows, C_, xs, wp, P[wkey + psfx], P[wkey + "#b"], hw, geglu=geglu, out_ps=out_ps,
-                           tf=L.TF_LAYERNORM_FOLDED, row_stats=stats, ln_colsum=P[wkey + "#cs"])
+                           tf=L.TF_LAYERNORM_FOLDED, row_stats=stats, ln_colsum=P[wkey + "#cs"], **kw)
             nb_.release(xs)
             return y
         assert out_ps is None
@@ -306,7 +317,15 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
             qkv = lin(hcur, P[q + "qkv"], None, hw, tf=L.TF_LAYERNORM, row_stats=stats,
                       ln_gamma=sd[q + "norm1.weight"], ln_beta=sd[q + "norm1.bias"], wf=P.get(q + "qkv#f"))
         else:
-            qkv = ln_lin(hcur, q + "qkv_ln", False)
+            kv_state["tiles"] = None
+            kvt = None
+            if (h2_flag is not None and hw >= ATTN_H2_MIN_TOKENS and hw % 64 == 0 and m.d_head == 32
+                    and os.environ.get("LDMK_QKV_TILES", "1") != "0"):
+                kvt = pg.alloc(pg.lib.ldmk_attn_kv_split_h2_bytes(n, hw, m.heads), dtype=torch.uint8)
+            qkv = ln_lin(hcur, q + "qkv_ln", False, attn_kv=None if kvt is None else (kvt, hw, m.heads))
+            if kvt is not None and kv_state["tiles"] is None:
+                nb_.release(kvt)            # (no pre-split plan for this projection: the attention runs its own pre-pass)
+                kvt = None
         # both attention products in the fp32-accurate bf16x3 arithmetic (24 bf16 MFMAs of 32 cycles per 32 keys
         # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel.  With a pre-split plan for
         # attn1.to_out the attention kernel writes its result in the PS layout only (from its accumulators, no LDS pass)
@@ -314,8 +333,11 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
                                                  and (hw >= ATTN_H2_MIN_TOKENS if h2_flag is not None else attention_presplit(hw))) else None)
         att = None if plan_o is not None else pg.alloc(rows, C_)
         att_ps = pg.alloc_ps(rows, C_) if plan_o is not None else None
-        emit_self_attention(nb_, qkv, att, hw, m.heads, m.d_head, att_ps=att_ps)
+        kv_tiles = None if unfolded else kv_state["tiles"]
+        emit_self_attention(nb_, qkv, att, hw, m.heads, m.d_head, att_ps=att_ps, kv_tiles=kv_tiles)
         nb_.release(qkv)
+        if kv_tiles is not None:
+            nb_.release(kv_tiles)
         if L_ctx == 1:
             # --- attn2 with a single context token: softmax over one key == 1, so the block adds
             # to_out(to_v(ctx)) to every position (exact); to_q/norm2 are dead.

@@ -179,6 +179,11 @@ typedef struct ldmk_igemm_args {
   /* ---- LDMK_COMPUTE_F16X2 */
   int w_scale_exp;           /* the exponent ldmk_pack_wsplit_h2 scaled the weights by (w_split = the two fp16 images of 2^e W)    */
   int* range_flag;           /* device int: set to 1 when a staged activation leaves the scaled fp16 range (see above)              */
+  /* ---- the fused QKV projection feeding ldmk_attn_self_h2_tiles (LDMK_COMPUTE_F16X2 on tile_cfg 23 / 27, no split-K):      */
+  void* attn_kv_out;         /* optional: the K and V column thirds of the result ([q | k | v], N = 3 x 32 x attn_heads) are NOT   */
+  int attn_tokens;           /*   stored in `out` but written as the attention's pre-split K / V tiles                               */
+  int attn_heads;            /*   (ldmk_attn_kv_split_h2_bytes(M / attn_tokens, attn_tokens, attn_heads) bytes; attn_tokens % 64 == 0, */
+                             /*   dividing M): bit for bit what ldmk_attn_self_h2's pre-pass writes from the fp32 K / V               */
 } ldmk_igemm_args;
 
 /* size in bytes of the PS layout of a [rows][k] matrix (-1: k not a multiple of 16) */
@@ -401,6 +406,10 @@ int ldmk_attn_self_h2(const float* qkv, void* kv_scratch, float* out, int* range
  * heads 32) bytes): the pre-split A operand of attn1.to_out.  tokens % 32 == 0. */
 int ldmk_attn_self_h2_ps(const float* qkv, void* kv_scratch, float* out, void* out_ps, int* range_flag, int n, int tokens, int heads,
                          float scale, void* stream);
+/* the same on K / V tiles that already exist (written by the QKV projection's epilogue, ldmk_igemm_args.attn_kv_out): no pre-pass;
+ * only the q third of `qkv` is read. */
+int ldmk_attn_self_h2_tiles(const float* qkv, const void* kv_tiles, float* out, void* out_ps, int* range_flag, int n, int tokens, int heads,
+                            float scale, void* stream);
 /* ldmk_attn_self_small: the same product for SMALL problems (batch 1-2: the reference's talking-face mode runs batch 1,
  *   talking_face/progressive_sampling_difftalk.py:350).  One workgroup per 32-query tile of a (sample, head), the keys split
  *   over its 4 / 8 waves and streamed from global memory without LDS staging, partial (max, sum, O) merged in wave order

@@ -439,3 +439,45 @@ def test_f16x2_attention_writes_its_result_in_the_f16x2_ps_layout(ops, n, tokens
     assert int(flag.item()) == 0
     with pytest.raises(L.LdmkError, match="tokens"):
         L.call("ldmk_attn_self_h2_ps", qkv.data_ptr(), kv.data_ptr(), 0, ps.data_ptr(), flag.data_ptr(), 1, 60, heads, 0.1, ops.stream())
+
+
+@pytest.mark.parametrize("cfg", [23, 27])
+@pytest.mark.parametrize("n,tokens,heads", [(2, 1024, 5), (1, 4096, 5), (3, 64, 10), (1, 512, 20)])
+def test_qkv_projection_writes_the_attention_kv_tiles(ops, n, tokens, heads, cfg):
+    """The fused QKV projection on a pre-split F16X2 tile with attn_kv_out: the q third of the result is the fp32 result of the
+    plain projection, the K / V thirds come out as the attention's pre-split tiles -- bit for bit what ldmk_attn_self_h2's pre-pass
+    writes from the fp32 K / V -- and ldmk_attn_self_h2_tiles on them equals ldmk_attn_self_h2 on the fp32 projection."""
+    from dsml_thesis_amd import lib as L
+    C_ = heads * 32
+    M, K, N = n * tokens, C_, 3 * C_
+    x = rnd(800, M, K) + 0.3 * rnd(801, M, 1)
+    w, b = rnd(802, N, K) / np.sqrt(K), 0.1 * rnd(803, N)
+    g, be = 1 + 0.2 * rnd(804, K), 0.2 * rnd(805, K)
+    wp = ops.pack_linear(w.cuda())
+    w2, cs, b2 = ops.fold_layernorm(wp, g.cuda(), be.cuda(), b.cuda())
+    flag = _flag()
+    xc = x.cuda()
+    st, xps = ops.ln_stats_ps(xc, h2_flag=flag)
+    wps = ops.pack_wps(w2, h2=True)
+    kw = dict(tf=L.TF_LAYERNORM_FOLDED, row_stats=st, ln_colsum=cs, bias=b2, tile_cfg=cfg, splitk=1, a_ps=xps, w_ps=wps, range_flag=flag)
+    ref = torch.empty(M, N, device="cuda")
+    ops.igemm(ops.make_igemm_args(M, N, K, None, K, w2, ref, N, tokens, **kw))
+    out = torch.full((M, N), 7.0, device="cuda")
+    kv = torch.zeros(L.load().ldmk_attn_kv_split_h2_bytes(n, tokens, heads), device="cuda", dtype=torch.uint8)
+    a = ops.make_igemm_args(M, N, K, None, K, w2, out, N, tokens, attn_kv=(kv, tokens, heads), **kw)
+    assert L.load().ldmk_igemm_check(__import__("ctypes").byref(a)) == 0
+    ops.igemm(a)
+    assert torch.equal(out[:, :C_], ref[:, :C_]) and bool((out[:, C_:] == 7.0).all())          # K / V are not stored as fp32
+    att_ref = torch.empty(M, C_, device="cuda")
+    kv_ref = torch.zeros_like(kv)
+    L.call("ldmk_attn_self_h2", ref.data_ptr(), kv_ref.data_ptr(), att_ref.data_ptr(), flag.data_ptr(), n, tokens, heads, 32 ** -0.5, ops.stream())
+    assert torch.equal(kv, kv_ref)
+    att = torch.empty(M, C_, device="cuda")
+    L.call("ldmk_attn_self_h2_tiles", out.data_ptr(), kv.data_ptr(), att.data_ptr(), 0, flag.data_ptr(), n, tokens, heads, 32 ** -0.5, ops.stream())
+    assert torch.equal(att, att_ref) and int(flag.item()) == 0
+    # refused: other tiles, split-K, ragged token counts
+    for bad in (dict(tile_cfg=31), dict(splitk=2), dict(attn_kv=(kv, tokens - 32, heads))):
+        kw2 = dict(kw, attn_kv=(kv, tokens, heads))
+        kw2.update(bad)
+        a = ops.make_igemm_args(M, N, K, None, K, w2, out, N, tokens, splitk_ws=torch.empty(4 * M * N, device="cuda") if "splitk" in bad else None, **kw2)
+        assert L.load().ldmk_igemm_check(__import__("ctypes").byref(a)) != 0

@@ -512,7 +512,7 @@ def test_northstar_trajectory_in_the_split_arithmetic(monkeypatch):
     pgs = [pg for pg in m.model.diffusion_model._programs.values()]
     gemms = [c_[2] for pg in pgs for c_ in pg.calls if c_[3] == "ldmk_igemm"]
     assert gemms and sum(1 for a in gemms if a.compute in (L.COMPUTE_BF16X3, L.COMPUTE_F16X2)) >= len(gemms) - 8
-    assert any(c_[3] in ("ldmk_attn_self_x3", "ldmk_attn_self_x3p", "ldmk_attn_self_h2", "ldmk_attn_self_h2_ps") for pg in pgs for c_ in pg.calls)
+    assert any(c_[3] in ("ldmk_attn_self_x3", "ldmk_attn_self_x3p", "ldmk_attn_self_h2", "ldmk_attn_self_h2_ps", "ldmk_attn_self_h2_tiles") for pg in pgs for c_ in pg.calls)
 
 
 def test_sharded_sampling_bitwise_equals_single_gpu(fr):

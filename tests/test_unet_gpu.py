@@ -193,7 +193,7 @@ def test_unet_split_arithmetic_routes_against_the_reference_fixtures(monkeypatch
         return eps, n3, ng, [c[3] for c in pg.calls]
 
     eps_a, n3, ng, names = run()
-    assert n3 >= 40 and "ldmk_attn_self_x3" in names and {"ldmk_attn_self_h2", "ldmk_attn_self_h2_ps"} & set(names) and "ldmk_attn_self" not in names, (n3, ng)
+    assert n3 >= 40 and "ldmk_attn_self_x3" in names and {"ldmk_attn_self_h2", "ldmk_attn_self_h2_ps", "ldmk_attn_self_h2_tiles"} & set(names) and "ldmk_attn_self" not in names, (n3, ng)
     close(eps_a, g["fr_eps"], 3e-5, 3e-5)
     # (b) everything eligible
     monkeypatch.setattr(engine, "x3_plan", lambda a, m: (1, 1) if a.epi == L.EPI_GEGLU else (5, 1))
@@ -205,7 +205,7 @@ def test_unet_split_arithmetic_routes_against_the_reference_fixtures(monkeypatch
     monkeypatch.setenv("LDMK_SPLIT_BF16", "0")
     monkeypatch.setattr(engine, "_X3_TABLE", None)
     eps_c, n3c, _, names_c = run()
-    assert n3c == 0 and "ldmk_attn_self" in names_c and not {"ldmk_attn_self_x3", "ldmk_attn_self_x3p", "ldmk_attn_self_h2", "ldmk_attn_self_h2_ps"} & set(names_c)
+    assert n3c == 0 and "ldmk_attn_self" in names_c and not {"ldmk_attn_self_x3", "ldmk_attn_self_x3p", "ldmk_attn_self_h2", "ldmk_attn_self_h2_ps", "ldmk_attn_self_h2_tiles"} & set(names_c)
     close(eps_c, g["fr_eps"], 3e-5, 3e-5)
     assert (eps_a - eps_c).abs().max().item() < 1.5e-5
     monkeypatch.undo()
@@ -258,7 +258,7 @@ def test_f16x2_range_flag_sends_the_model_back_to_bf16x3(monkeypatch):
         warnings.simplefilter("error")
         m(x.cuda(), t.cuda(), context=ctx.cuda())
     assert m.f16x2 and m._h2_flag.item() == 0
-    assert {"ldmk_attn_self_h2", "ldmk_attn_self_h2_ps"} & {c[3] for c in m.program(2, 32, 32, 1, 0).calls}
+    assert {"ldmk_attn_self_h2", "ldmk_attn_self_h2_ps", "ldmk_attn_self_h2_tiles"} & {c[3] for c in m.program(2, 32, 32, 1, 0).calls}
     key = "input_blocks.1.1.transformer_blocks.0.attn1.to_k.weight"
     keyq = key.replace("to_k", "to_q")
     assert key in sd and keyq in sd
@@ -276,7 +276,7 @@ def test_f16x2_range_flag_sends_the_model_back_to_bf16x3(monkeypatch):
         eps = m2(x.cuda(), t.cuda(), context=ctx.cuda())
     assert not m2.f16x2
     names = [c[3] for c in m2.program(2, 32, 32, 1, 0).calls]
-    assert not {"ldmk_attn_self_h2", "ldmk_attn_self_h2_ps"} & set(names) and "ldmk_attn_self_x3" in names
+    assert not {"ldmk_attn_self_h2", "ldmk_attn_self_h2_ps", "ldmk_attn_self_h2_tiles"} & set(names) and "ldmk_attn_self_x3" in names
     close(eps, O.unet_forward(sd2, W.FR_UNET, x, t, ctx), 3e-5, 3e-5)
     with warnings.catch_warnings():
         warnings.simplefilter("error")                   # decided once

@@ -48,7 +48,7 @@ def dump(latent, batch, path, graph=False):
 
 KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "igemm_ws_kernel", "igemm_ps_kernel", "igemm_pw_kernel", "rgemm_kernel", "sgemm_kernel"), "ldmk_post": ("post_",),
              "ldmk_attn_self_small": ("attn_small",), "ldmk_conv3x3_out_small": ("conv3x3_out_small",), "ldmk_gn_finalize": ("gn_finalize",), "ldmk_gn_apply": ("gn_apply",),
-             "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_ln_stats_guard": ("ln_stats",), "ldmk_ln_stats_split": ("ln_stats",), "ldmk_ln_stats_ps": ("ln_stats_ps",), "ldmk_ln_stats_ps_h2": ("ln_stats_ps",), "ldmk_pack_ps": ("pack_ps",), "ldmk_attn_self": ("attn_self",), "ldmk_attn_self_x3": ("attn_x3",), "ldmk_attn_self_x3p": ("attn_kv_split",), "ldmk_attn_self_x3p_ps": ("attn_kv_split",), "ldmk_attn_self_h2": ("attn_kv_split_h2",), "ldmk_attn_self_h2_ps": ("attn_kv_split_h2",),
+             "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_ln_stats_guard": ("ln_stats",), "ldmk_ln_stats_split": ("ln_stats",), "ldmk_ln_stats_ps": ("ln_stats_ps",), "ldmk_ln_stats_ps_h2": ("ln_stats_ps",), "ldmk_pack_ps": ("pack_ps",), "ldmk_attn_self": ("attn_self",), "ldmk_attn_self_x3": ("attn_x3",), "ldmk_attn_self_x3p": ("attn_kv_split",), "ldmk_attn_self_x3p_ps": ("attn_kv_split",), "ldmk_attn_self_h2": ("attn_kv_split_h2",), "ldmk_attn_self_h2_ps": ("attn_kv_split_h2",), "ldmk_attn_self_h2_tiles": ("attn_h2_fwd",),
              "ldmk_attn_cross": ("attn_cross",), "ldmk_dense_small": ("dense_small",),
              "ldmk_timestep_embedding": ("timestep_embedding",), "ldmk_conv3x3_in": ("conv3x3_in",),
              "ldmk_conv3x3_out": ("conv3x3_out",), "ldmk_winograd_input": ("wino_input",), "ldmk_winograd_input_ps": ("wino_input_ps",), "ldmk_upconv_gather_ps": ("upconv_gather_ps",), "ldmk_winograd_input_ps_h2": ("wino_input_ps",), "ldmk_upconv_gather_ps_h2": ("upconv_gather_ps",),
