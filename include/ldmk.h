@@ -76,7 +76,8 @@ enum { LDMK_COMPUTE_F32 = 0, LDMK_COMPUTE_BF16 = 1, LDMK_COMPUTE_BF16X3 = 2, LDM
  * an absolute precision of 2^-31 rather than a relative one: invisible next to O(1) elements of the same row (an fp32
  * accumulation resolves 2^-24 of the sum), but a tensor that is uniformly ~1e-4 comes out with 8 x the fp32 form's error.  An activation with |x| >=
  * LDMK_F16X2_RANGE (or inf / NaN) would leave fp16: the kernels then write 1 to *range_flag (a device int the caller zeroes
- * once; never cleared here) and the caller repeats the work in BF16X3.  tile_cfg 0..6. */
+ * once; never cleared here) and the caller repeats the work in BF16X3.  tile_cfg 0..6 (A split while it is staged, w_split from
+ * ldmk_pack_wsplit_h2) and the pre-split tiles 23..28 / 31..33 (a_ps / w_ps / out_ps as two fp16 planes: ldmk_ps_bytes_h2 below). */
 #define LDMK_F16X2_A_EXP 6
 #define LDMK_F16X2_RANGE 1000.0f
 /* BF16X3 -- fp32-accurate products on the bf16 matrix cores (the f32 MFMA of gfx950 peaks at 157 TFLOP/s, the bf16 one at
