@@ -250,7 +250,9 @@ def clip_leg(rank, world, dev, dist, barrier, frames=128, ddim_steps=20, window=
             return {C12: c12, C34: c34}
         return sample_sharded(s, ddim_steps, T, (3, 32, 32), cond, seed=5, rank=rank, world_size=world, policy=policy)
 
+    from dsml_thesis_amd import parallel as _par
     job()                                   # builds the launch programs and captures the step graph (untimed)
+    issued0 = _par.COLLECTIVES_ISSUED
     els = []
     njobs = 1 if ddim_steps >= 100 else 3   # the shipped DDIM-200 job takes seconds: one timed job; short ones: the median of three
     for _ in range(njobs):                  # whole jobs, each between barriers (a single SHORT job varied by +-7 % from run to
@@ -272,8 +274,11 @@ def clip_leg(rank, world, dev, dist, barrier, frames=128, ddim_steps=20, window=
             "scaling": "strong", "plan_policy": policy, "seconds": round(el, 4), "seconds_of_jobs": [round(e, 4) for e in els],
             "frames_per_s": round(T / el, 2),
             "sample_steps_per_s": round(T * ddim_steps / el, 1),
-            "collective": ("none (1 rank)" if world == 1 else
-                           f"one all_gather_into_tensor of the decoded frames, {per}x128x128x3 fp32 per rank"),
+            "collective": ("none (1 rank)" if _par.COLLECTIVES_ISSUED == issued0 else
+                           f"one all_gather_into_tensor of the decoded frames per job, {per}x128x128x3 fp32 per rank"),
+            "collectives_issued_in_timed_jobs": _par.COLLECTIVES_ISSUED - issued0,
+            "ranks_seen": (dist.get_world_size() if dist is not None else 1),
+            "backend": (dist.get_backend() if dist is not None else None),
             "checksum": float(out.double().sum())}
 
 
@@ -570,6 +575,11 @@ def main():
     if world > 1 or os.environ.get("LDMK_BENCH_FORCE_DIST"):    # FORCE_DIST: rehearse the RCCL calls with a single rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if os.environ.get("LDMK_BENCH_FORCE_DIST"):
+            os.environ["LDMK_FORCE_COLLECTIVE"] = "1"          # parallel.all_gather_items: issue the real all-gather at world 1 too
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
         else:
@@ -602,6 +612,11 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = tt.item()
         assert torch.isfinite(run.pg.inputs["x"]).all(), "non-finite latent after the timed steps"
+        # the timed steps ran in the arithmetic the line names: no F16X2 range flag and no folded-LayerNorm guard went up
+        # during them, and no site had been moved to another arithmetic (a raised flag would mean saturated, i.e. wrong, products)
+        ast = model.model.diffusion_model.arithmetic_status()
+        assert not ast["flags_up"] and not ast["ln_flag_up"] and not ast["denied"], f"arithmetic flags after the timed steps: {ast}"
+        run.arithmetic_status = ast
         return run, el
 
     graph = not a.no_graph
@@ -633,6 +648,9 @@ def main():
                    "latent": [int(run.x_T.shape[1]), a.latent, a.latent], "ddim_steps": 200,
                    "hipgraph": graph, "parallelism": f"dp{world} (independent samples per rank, no data-path collective; the "
                                                    f"sharded-clip leg with its all-gather is reported under 'clip')"},
+        "arithmetic_flags": {"f16x2_sites": run.arithmetic_status["sites"], "sites_denied": len(run.arithmetic_status["denied"]),
+                             "range_flags_up_after_timed_region": len(run.arithmetic_status["flags_up"]),
+                             "layernorm_guard_up": run.arithmetic_status["ln_flag_up"]},
         "batch_steps_per_s": round(world * a.steps / el, 3),
         "step_tflops": round(world * GFLOP_STEP[a.latent] * a.batch * 1e-3 / (ms * 1e-3), 2),
     }
@@ -731,7 +749,7 @@ def main():
             from dsml_thesis_amd import engine as _eng
             torch.cuda.empty_cache()
             os.environ["LDMK_SPLIT_BF16"] = "0"
-            _eng._X3_TABLE = None
+            _eng.reset_tables()
             try:
                 n3 = max(5, a.steps // 2)
                 run3, el3 = measure(a.latent, n3, 2, graph)
@@ -740,7 +758,22 @@ def main():
                 del run3
             finally:
                 del os.environ["LDMK_SPLIT_BF16"]
-                _eng._X3_TABLE = None
+                _eng.reset_tables()
+            if os.environ.get("LDMK_F16X2", "1") != "0":
+                # ... and its OPERAND-EXACT twin on the same kernels: every split product from the exact three-way bf16 split (six
+                # bf16 MFMAs, no operand perturbed) instead of F16X2's three fp16 ones -- what a site runs after a range-flag fall-back
+                torch.cuda.empty_cache()
+                os.environ["LDMK_F16X2"] = "0"
+                _eng.reset_tables()
+                try:
+                    n4 = max(5, a.steps // 2)
+                    run4, el4 = measure(a.latent, n4, 2, graph)
+                    out["bf16x3_form"] = {"workload": "the primary workload with LDMK_F16X2=0 (every split product from the exact bf16x3 split: six bf16 MFMAs, operands bit-exact)",
+                                          "value": round(a.batch * n4 / el4, 2), "unit": "sample-steps/s", "ms_per_step": round(1e3 * el4 / n4, 4)}
+                    del run4
+                finally:
+                    del os.environ["LDMK_F16X2"]
+                    _eng.reset_tables()
     if not a.no_clip:
         torch.cuda.empty_cache()
         out["clip"] = clip_leg(rank, world, dev, dist, barrier, frames=a.clip_frames, ddim_steps=a.clip_steps, policy=a.clip_policy)

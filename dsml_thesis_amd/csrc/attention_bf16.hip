@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256) void attn_kv_split_h2_kernel(const float* __re
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { bad |= out_of_h2_range(v[j]); v[j] *= H2_S; }
+    for (int j = 0; j < 8; ++j) { bad |= out_of_h2_range(v[j]); v[j] = h2_clamp(v[j]) * H2_S; }
     f16x8_t g[2];
     split8_h2(v, g);
     unsigned char* d = dst + (2 * sub + t) * 2048 + lane * 16;
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256) void attn_kv_split_h2_kernel(const float* __re
       const int key = kt * BA_T + sub * 32 + 16 * t + 4 * half + (j & 3) + 8 * (j >> 2);
       v[j] = key < tokens ? base[2 * C + (long long)key * ld + l31] : 0.f;
       bad |= out_of_h2_range(v[j]);
-      v[j] *= H2_S;
+      v[j] = h2_clamp(v[j]) * H2_S;
     }
     f16x8_t g[2];
     split8_h2(v, g);
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restric
       const float4 a = *reinterpret_cast<const float4*>(rowp + 16 * t + 8 * half), c = *reinterpret_cast<const float4*>(rowp + 16 * t + 8 * half + 4);
       float v[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, c.x * mul, c.y * mul, c.z * mul, c.w * mul};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { bad |= out_of_h2_range(v[i]); v[i] *= H2_S; }
+      for (int i = 0; i < 8; ++i) { bad |= out_of_h2_range(v[i]); v[i] = h2_clamp(v[i]) * H2_S; }
       split8_h2(v, qf[j][t]);
     }
 #pragma unroll
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restric
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             bad2 |= out_of_h2_range(v[e]);
-            const float sv = v[e] * H2_S;
+            const float sv = h2_clamp(v[e]) * H2_S;
             hh[e] = (_Float16)sv;
             ll[e] = (_Float16)(sv - (float)hh[e]);
           }

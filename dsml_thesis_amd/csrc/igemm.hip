@@ -464,8 +464,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
             *reinterpret_cast<bf16x4*>(d + AIMG) = m;
             *reinterpret_cast<bf16x4*>(d + 2 * AIMG) = l;
           } else if constexpr (H2) {
-            h2_bad |= h2_out_of_range(areg[j][i]);
-            const float4 v = areg[j][i];
+            float4 v = areg[j][i];
+            if (__builtin_expect(h2_out_of_range(v), 0)) {      // a real branch (never taken on a healthy model): saturate, see h2_clamp
+              asm volatile("; f16x2 operand out of range");
+              h2_bad = true;
+              v = h2_clamp4(v);
+            }
             f16x4 h, l;
             split2h(make_float4(v.x * H2_A_SCALE, v.y * H2_A_SCALE, v.z * H2_A_SCALE, v.w * H2_A_SCALE), h, l);
             *reinterpret_cast<f16x4*>(d) = h;

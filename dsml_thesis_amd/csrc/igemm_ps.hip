@@ -31,6 +31,20 @@ typedef __bf16 pbf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
 
+// What-if probes (drop the DMA / the matrix instructions / the epilogue, phase stamps, phase stagger: results are garbage with them)
+// exist only in builds made with -DLDMK_PS_PROBES (tools/ps_probe.sh, tools/pw_stamps.py); the shipped library ignores LDMK_PS_DEBUG /
+// LDMK_PS_STAGGER and its kernels carry none of the branches.
+#ifdef LDMK_PS_PROBES
+constexpr bool PS_PROBES = true;
+#else
+constexpr bool PS_PROBES = false;
+#endif
+static int ps_probe_bits() {
+  if (!PS_PROBES) return 0;
+  const int dbg = ps_probe_bits();
+  return dbg;
+}
+
 constexpr unsigned PS_OOB = 0x80000000u;      // a byte offset beyond every buffer here (< 2 GiB each): reads as zeros, no memory traffic
 
 __device__ __forceinline__ pu32x4 ps_rsrc(const void* ptr, unsigned bytes) {      // raw buffer descriptor, uniform -> SGPRs
@@ -84,7 +98,11 @@ __device__ __forceinline__ bool ps_h2_out_of_range(const float4& v) {           
   return (__float_as_uint(v.x) & 0x7fffffffu) >= LIM || (__float_as_uint(v.y) & 0x7fffffffu) >= LIM ||
          (__float_as_uint(v.z) & 0x7fffffffu) >= LIM || (__float_as_uint(v.w) & 0x7fffffffu) >= LIM;
 }
+// (activations, s = 2^6: saturated just inside the range -- h2_clamp, ldmk_common.h; weights, any s: their exponent is chosen at pack time)
 __device__ __forceinline__ float4 ps_scaled(const float4& v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
+__device__ __forceinline__ float4 ps_scaled_sat(const float4& v) {
+  return make_float4(h2_clamp(v.x) * PS_H2_SCALE, h2_clamp(v.y) * PS_H2_SCALE, h2_clamp(v.z) * PS_H2_SCALE, h2_clamp(v.w) * PS_H2_SCALE);
+}
 
 template <int N> __device__ __forceinline__ void ps_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 
@@ -227,7 +245,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
                 } else {
                   if (ps_h2_out_of_range(v)) *p.range_flag = 1;
                   pf16x4 h, l;
-                  ps_split2h(ps_scaled(v, PS_H2_SCALE), h, l);
+                  ps_split2h(ps_scaled_sat(v), h, l);
                   *reinterpret_cast<pf16x4*>(d) = h;
                   *reinterpret_cast<pf16x4*>(d + 1024) = l;
                 }
@@ -260,8 +278,8 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
                   const float4 v0 = make_float4(vals[0], vals[1], vals[2], vals[3]), v1 = make_float4(vals[4], vals[5], vals[6], vals[7]);
                   bad |= ps_h2_out_of_range(v0) || ps_h2_out_of_range(v1);
                   pf16x4 h0, l0, h1, l1;
-                  ps_split2h(ps_scaled(v0, PS_H2_SCALE), h0, l0);
-                  ps_split2h(ps_scaled(v1, PS_H2_SCALE), h1, l1);
+                  ps_split2h(ps_scaled_sat(v0), h0, l0);
+                  ps_split2h(ps_scaled_sat(v1), h1, l1);
                   unsigned char* d = dst + (2 * sub + t) * 2048;
                   *reinterpret_cast<pf16x8*>(d) = pf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                   *reinterpret_cast<pf16x8*>(d + 1024) = pf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
@@ -283,8 +301,8 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
                   const float4 v0 = make_float4(vals[0], vals[1], vals[2], vals[3]), v1 = make_float4(vals[4], vals[5], vals[6], vals[7]);
                   bad |= ps_h2_out_of_range(v0) || ps_h2_out_of_range(v1);
                   pf16x4 h0, l0, h1, l1;
-                  ps_split2h(ps_scaled(v0, PS_H2_SCALE), h0, l0);
-                  ps_split2h(ps_scaled(v1, PS_H2_SCALE), h1, l1);
+                  ps_split2h(ps_scaled_sat(v0), h0, l0);
+                  ps_split2h(ps_scaled_sat(v1), h1, l1);
                   unsigned char* d = dst + (4 + 2 * sub + t) * 2048;
                   *reinterpret_cast<pf16x8*>(d) = pf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                   *reinterpret_cast<pf16x8*>(d + 1024) = pf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
@@ -414,7 +432,8 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
 }
 
 template <int NWM, int NWN, int TM, int TN, int NS, bool TR, int PL = 3, bool KV = false>
-__global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int dbg) {
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int dbg_arg) {
+  const int dbg = PS_PROBES ? dbg_arg : 0;        // (what-if switches: probe builds only, see PS_PROBES)
   constexpr int NW = NWM * NWN;
   constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN;
   constexpr int FA = BM / 32, FB = BN / 32, U = FA + FB;          // units (3-plane blocks) per stage
@@ -588,7 +607,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
 //     finished reading stage it - 1, whose buffer the producers then refill with stage it + 3.
 // Same products in the same order into every accumulator as the kernel above: bitwise equal results.
 template <int TM, int TN, int NS, bool TR>
-__global__ __launch_bounds__(512) void igemm_pw_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int dbg) {
+__global__ __launch_bounds__(512) void igemm_pw_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int dbg_arg) {
+  const int dbg = PS_PROBES ? dbg_arg : 0;
   constexpr int BM = 128 * TM, BN = 32 * TN;
   constexpr int FA = BM / 32, FB = TN, U = FA + FB;
   constexpr int UHI = (U + 3) / 4, ULO = U / 4;                   // units a producer wave fetches per stage
@@ -779,8 +799,12 @@ __global__ __launch_bounds__(256) void pack_ps_kernel(const float* __restrict__ 
   }
   unsigned char* d = dst + ((long long)rb * (K / 16) + (k0 >> 4)) * (PL * 1024) + ((o & 1) * 32 + r) * 16;
   if constexpr (PL == 2) {          // F16X2: the two fp16 images of scale x (activations: 2^6, range-checked; weights: 2^w_scale_exp)
-    const float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
-    if (range_flag && (ps_h2_out_of_range(v0) || ps_h2_out_of_range(v1))) *range_flag = 1;
+    float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
+    if (range_flag) {               // activations (scale 2^6): range-checked and saturated; weights carry their own exponent
+      if (ps_h2_out_of_range(v0) || ps_h2_out_of_range(v1)) *range_flag = 1;
+      v0 = h2_clamp4(v0);
+      v1 = h2_clamp4(v1);
+    }
     pf16x4 h0, l0, h1, l1;
     ps_split2h(ps_scaled(v0, scale), h0, l0);
     ps_split2h(ps_scaled(v1, scale), h1, l1);
@@ -851,8 +875,8 @@ __global__ __launch_bounds__(256) void ln_stats_ps_kernel(const float* __restric
       if constexpr (PL == 2) {
         if (ps_h2_out_of_range(v[c][0]) || ps_h2_out_of_range(v[c][1])) *range_flag = 1;
         pf16x4 h0, l0, h1, l1;
-        ps_split2h(ps_scaled(v[c][0], PS_H2_SCALE), h0, l0);
-        ps_split2h(ps_scaled(v[c][1], PS_H2_SCALE), h1, l1);
+        ps_split2h(ps_scaled_sat(v[c][0]), h0, l0);
+        ps_split2h(ps_scaled_sat(v[c][1]), h1, l1);
         *reinterpret_cast<pf16x8*>(d) = pf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
         *reinterpret_cast<pf16x8*>(d + 1024) = pf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
       } else {
@@ -892,7 +916,7 @@ static int ps_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_
     attr = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  static const int dbg = (getenv("LDMK_PS_DEBUG") ? atoi(getenv("LDMK_PS_DEBUG")) : 0) | ((getenv("LDMK_PS_STAGGER") ? atoi(getenv("LDMK_PS_STAGGER")) : 0) << 8);
+  const int dbg = ps_probe_bits();
   static_assert(!KV || (size_t)NWM * NWN * 32 * 33 * 4 <= lds, "V^T transpose scratch fits the ring");
   hipLaunchKernelGGL((igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR, PL, KV>), dim3(tiles, splitk, a.batch > 1 ? a.batch : 1), dim3(64 * NWM * NWN), lds,
                      st, a, splitk, ws, dbg);
@@ -911,7 +935,7 @@ static int pw_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_
     attr = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  static const int dbg = getenv("LDMK_PS_DEBUG") ? atoi(getenv("LDMK_PS_DEBUG")) : 0;
+  const int dbg = ps_probe_bits() & 0xff;
   hipLaunchKernelGGL((igemm_pw_kernel<TM, TN, NS, TR>), dim3(tiles, splitk, a.batch > 1 ? a.batch : 1), dim3(512), lds, st, a, splitk, ws, dbg);
   if (splitk > 1 && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
   return check_launch("ldmk_igemm(pw)");
@@ -924,7 +948,7 @@ const char* igemm_ps_unsupported(const ldmk_igemm_args& a, int pcfg, int splitk)
   if (pl == 2 && a.out_ps && !a.range_flag) return "out_ps in the f16x2 arithmetic needs range_flag";
   if (!a.a_ps || !a.w_ps) return "a_ps / w_ps (operands in the PS layout: ldmk_pack_ps, ldmk_ln_stats_ps, out_ps of a producer GEMM)";
   if (a.a_mode != LDMK_A_ROWS) return "rows mode only";
-  if (a.b_trans || a.upsample || a.skip_a0 || (a.splitk_counters && !getenv("LDMK_PS_DEBUG"))) return "b_trans / upsample / fused skip / in-launch combine";
+  if (a.b_trans || a.upsample || a.skip_a0 || (a.splitk_counters && !(ps_probe_bits() & 8))) return "b_trans / upsample / fused skip / in-launch combine";
   if (a.a_tf != LDMK_TF_NONE && a.a_tf != LDMK_TF_LAYERNORM_FOLDED) return "no staging prologue: a_ps is what gets multiplied";
   if (a.K % 32 || a.N % 32) return "K and N must be multiples of 32";
   const long long kb = a.K / 16;

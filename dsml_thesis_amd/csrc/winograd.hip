@@ -93,7 +93,7 @@ __device__ __forceinline__ void wino_store_ps(unsigned char* d, const float4& a,
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       bad |= (__float_as_uint(v[e]) & 0x7fffffffu) >= 0x447a0000u;
-      const float s = v[e] * 64.f;
+      const float s = h2_clamp(v[e]) * 64.f;      // (saturated: ldmk_common.h)
       h[e] = (_Float16)s;
       l[e] = (_Float16)(s - (float)h[e]);
     }

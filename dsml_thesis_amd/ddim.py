@@ -16,7 +16,7 @@ import torch
 from . import lib as L
 from . import schedule as S_
 from .engine import GraphedProgram
-from .unet import rerun_if_layernorm_guard_tripped
+from .unet import rerun_if_flags_tripped
 
 C12, C34 = "class_label_&_audio", "motion_&_id"
 
@@ -27,8 +27,9 @@ class DDIMSampler(object):
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
-        self._loops = {}
-        self._tables = {}
+        # device-resident schedule tables, shared by every sampler of this model (captured graphs keep pointing at them, so a
+        # second DDIMSampler(model) replays the step the first one captured instead of capturing it again)
+        self._tables = model.__dict__.setdefault("_ddim_tables", {})
 
     def register_buffer(self, name, attr):
         if isinstance(attr, torch.Tensor) and attr.device != self.model.device:
@@ -51,7 +52,7 @@ class DDIMSampler(object):
         self.ddim_sqrt_one_minus_alphas = np.sqrt(1. - al)
         # device-resident [S][4] coefficient table + timestep table for the update kernel
         dev = self.model.device
-        key = (ddim_num_steps, float(ddim_eta), ddim_discretize, strength)
+        key = (ddim_num_steps, float(ddim_eta), ddim_discretize, strength, str(dev))
         if key not in self._tables:     # persistent device tables: captured graphs keep pointing at them
             self._tables[key] = (torch.from_numpy(S_.ddim_step_table(ac.cpu(), self.ddim_timesteps, ddim_eta)).to(dev),
                                  torch.from_numpy(self.ddim_timesteps.astype(np.int64)).to(dev),
@@ -59,6 +60,24 @@ class DDIMSampler(object):
         self._table, self._ts_table, self._inv_table = self._tables[key]
         self._sched_key = key
         self._eta = ddim_eta
+
+    def _original_tables(self):
+        """`use_original_steps` (ddim.py:127,133-134,183-186; ddim2cond.py:175-178): the update walks all `ddpm_num_timesteps` of the
+        model's own schedule -- alphas_cumprod, alphas_cumprod_prev, sqrt_one_minus_alphas_cumprod and
+        `ddim_sigmas_for_original_num_steps` = eta sqrt((1 - a_prev) / (1 - a) (1 - a / a_prev)), formed in float32 from the float32
+        buffers like make_schedule does (ddim.py:50-53).  -> ([T][4] device table, arange(T) device, arange(T) host).
+        (The face-reenactment copy reads the sigmas off `self.model`, where nothing defines them -- ddim.py:186 raises
+        AttributeError; the talking-face copy, ddim2cond.py:178, reads its own buffer.  That working behaviour is what is built.)"""
+        m, dev = self.model, self.model.device
+        key = ("orig", float(self._eta), str(dev))
+        if key not in self._tables:
+            a = m.alphas_cumprod.to(dev, torch.float32)
+            ap = m.alphas_cumprod_prev.to(dev, torch.float32)
+            sig = self._eta * torch.sqrt((1 - ap) / (1 - a) * (1 - a / ap))
+            tab = torch.stack([a, ap, sig.to(torch.float32), m.sqrt_one_minus_alphas_cumprod.to(dev, torch.float32)], 1).contiguous()
+            self._tables[key] = (tab, torch.arange(self.ddpm_num_timesteps, dtype=torch.int64, device=dev), None)
+        tab, ts, _ = self._tables[key]
+        return tab, ts, np.arange(self.ddpm_num_timesteps)
 
     # ------------------------------------------------------------------------------------------
     def _split_cond(self, cond):
@@ -103,13 +122,15 @@ class DDIMSampler(object):
                                   mask_noise=kwargs.get("mask_noise"))
 
     @torch.no_grad()
-    @rerun_if_layernorm_guard_tripped(lambda self: self.model.model.diffusion_model)
+    @rerun_if_flags_tripped(lambda self: self.model.model.diffusion_model)
     def ddim_sampling(self, cond, shape, x_T=None, callback=None, img_callback=None, log_every_t=100,
                       unconditional_guidance_scale=1., unconditional_conditioning=None, noise=None,
                       use_graph=False, policy_batch=None, return_x_inter_only=False, invert=False, mask=None, x0=None,
                       quantize_denoised=False, temperature=1., noise_dropout=0., score_corrector=None,
-                      corrector_kwargs=None, mask_noise=None, **kwargs):
+                      corrector_kwargs=None, mask_noise=None, ddim_use_original_steps=False, timesteps=None, **kwargs):
         """invert=True runs the forward DDIM (inversion) direction: index 0 -> S-1 with q_sample_ddim's update.
+        ddim_use_original_steps / timesteps: ddim.py:127-134 -- every step of the model's own schedule (`timesteps`: only its first
+        so many), or the first `int(min(timesteps / S, 1) S) - 1` entries of the DDIM subsequence.
 
         The reference's rarely used options (ddim.py:112-203; no shipped script sets them) run as device-side elementwise
         work around the same captured step, never on the host:
@@ -161,20 +182,34 @@ class DDIMSampler(object):
             assert self.model.parameterization == "eps"
             use_graph = False                              # a host callback sits inside the step
         extras = mask is not None or quantize_denoised or score_corrector is not None or noise_dropout > 0. or temperature != 1.
-        lkey = (id(pg), cfg, float(unconditional_guidance_scale), self._sched_key, need_noise, bool(use_graph),
-                noise is None, bool(invert))
-        st = None if extras else self._loops.get(lkey)     # (option runs capture their own tensors: never cached)
+        table, ts_table, tsteps = (self._inv_table if invert else self._table), self._ts_table, self.ddim_timesteps
+        n_run = S
+        if ddim_use_original_steps:
+            assert not invert, "the inversion runs on the DDIM subsequence"
+            table, ts_table, tsteps = self._original_tables()
+            S = tsteps.shape[0]
+            n_run = S if timesteps is None else int(timesteps)
+        elif timesteps is not None:
+            assert not invert
+            n_run = int(min(timesteps / S, 1) * S) - 1       # ddim.py:129-131
+        assert 0 < n_run <= S, (n_run, S)
+        # loop state (buffers, the captured step) lives ON the launch program it was captured over and dies with it: when the model
+        # drops its programs (a re-pack, an arithmetic fall-back) nothing keeps the old workspace or its hipGraph alive, and a
+        # new program can never be handed buffers of another batch size (rounds 2-4 keyed a sampler-side cache by id(pg))
+        loops = pg.__dict__.setdefault("_ddim_loops", {})
+        lkey = (cfg, float(unconditional_guidance_scale), self._sched_key, need_noise, bool(use_graph), noise is None, bool(invert),
+                bool(ddim_use_original_steps), n_run)
+        st = None if extras else loops.get(lkey)           # (option runs capture their own tensors: never cached)
         if st is None:
             st = dict(pred_x0=torch.empty_like(img0), step_idx=torch.zeros(1, dtype=torch.int32, device=dev),
                       nz=torch.empty_like(img0) if need_noise else None, graph=None)
             if not extras:
-                self._loops[lkey] = st
+                loops[lkey] = st
         pred_x0, step_idx, nz_buf = st["pred_x0"], st["step_idx"], st["nz"]
         eps = pg.outputs["eps"]
         per = img0[0].numel()
-        table, ts_table = (self._inv_table if invert else self._table), self._ts_table
         scale = float(unconditional_guidance_scale)
-        first = 0 if invert else S - 1
+        first = 0 if invert else n_run - 1
         adv = -1 if invert else 1
 
         def reset_state():
@@ -182,7 +217,7 @@ class DDIMSampler(object):
             if cfg:
                 x_buf[b:].copy_(img0)
             step_idx.fill_(first)
-            pg.inputs["t"].fill_(int(self.ddim_timesteps[first]))
+            pg.inputs["t"].fill_(int(tsteps[first]))
 
         mnz = torch.zeros_like(img0) if mask is not None else None      # (zeros: the graph warm-up steps run before the first fill)
         sqrt_ac, sqrt_1mac = self.model.sqrt_alphas_cumprod, self.model.sqrt_one_minus_alphas_cumprod
@@ -238,8 +273,8 @@ class DDIMSampler(object):
             step = st["graph"].replay
 
         intermediates = {"x_inter": [img0], "pred_x0": [img0]}
-        for i in range(S):
-            index = S - i - 1
+        for i in range(n_run):
+            index = n_run - i - 1
             if nz_buf is not None:
                 if noise is not None:
                     nz_buf.copy_(noise[i])
@@ -255,7 +290,7 @@ class DDIMSampler(object):
                 callback(i)
             if img_callback:
                 img_callback(pred_x0, i)
-            if index % log_every_t == 0 or index == S - 1:
+            if index % log_every_t == 0 or index == n_run - 1:
                 intermediates["x_inter"].append(img.clone())
                 intermediates["pred_x0"].append(pred_x0.clone())
         out = img.clone()
@@ -267,18 +302,20 @@ class DDIMSampler(object):
     def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
                       temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
                       unconditional_guidance_scale=1., unconditional_conditioning=None, noise=None):
-        """Single step with the reference's signature (ddim.py:164-203); returns (x_prev, pred_x0)."""
-        if use_original_steps:
-            raise NotImplementedError("p_sample_ddim: only the DDIM-subsequence path is built (no shipped script sets "
-                                      "ddim_use_original_steps)")
+        """Single step with the reference's signature (ddim.py:164-203); returns (x_prev, pred_x0).  use_original_steps: `index`
+        counts the model's own timesteps (`_original_tables`)."""
         dev = x.device
         b = x.shape[0]
+        table = self._original_tables()[0] if use_original_steps else self._table
         ctx, cat = self._split_cond(c)
         cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
         if cfg:
-            uc, _ = self._split_cond(unconditional_conditioning)
-            e = self.model.apply_model(torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([uc, ctx]),
-                                       None if cat is None else torch.cat([cat] * 2))
+            uc, ucat = self._split_cond(unconditional_conditioning)
+            x2, t2 = torch.cat([x] * 2), torch.cat([t] * 2)
+            if ctx is None:       # 'concat' conditioning: the guidance halves differ in the concat tensor ([uncond | cond], as in ddim_sampling)
+                e = self.model.apply_model(x2, t2, None, torch.cat([ucat, cat]))
+            else:
+                e = self.model.apply_model(x2, t2, torch.cat([uc, ctx]), None if cat is None else torch.cat([cat] * 2))
         else:
             e = self.model.apply_model(x, t, ctx, cat)
         if score_corrector is not None:                      # ddim.py:179-181, on the guidance-combined score
@@ -295,12 +332,12 @@ class DDIMSampler(object):
         step_idx = torch.full((1,), int(index), dtype=torch.int32, device=dev)
         x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)
         L.call("ldmk_ddim_step", x.contiguous().data_ptr(), e.data_ptr(), 0 if noise is None else noise.contiguous().data_ptr(),
-               self._table.data_ptr(), step_idx.data_ptr(), float(unconditional_guidance_scale), 1 if cfg else 0,
+               table.data_ptr(), step_idx.data_ptr(), float(unconditional_guidance_scale), 1 if cfg else 0,
                x_prev.data_ptr(), pred_x0.data_ptr(), x[0].numel(), b, 0, 0, 0, 0, 0,
                torch.cuda.current_stream().cuda_stream)
         if quantize_denoised:                                # ddim.py:195-196
             q = self.model.first_stage_model.quantize(pred_x0)[0]
-            x_prev = x_prev + torch.sqrt(self._table[int(index), 1]) * (q - pred_x0)
+            x_prev = x_prev + torch.sqrt(table[int(index), 1]) * (q - pred_x0)
             pred_x0 = q
         return x_prev, pred_x0
 

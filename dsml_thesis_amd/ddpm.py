@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import schedule as S_
-from .unet import rerun_if_layernorm_guard_tripped
+from .unet import rerun_if_flags_tripped
 from .util import instantiate_from_config
 
 try:  # north_star: keep the pl.LightningModule surface when Lightning exists
@@ -316,7 +316,7 @@ class LatentDiffusion(_Base):
         return (out, x_recon) if return_x0 else out
 
     @torch.no_grad()
-    @rerun_if_layernorm_guard_tripped(lambda self: self.model.diffusion_model)
+    @rerun_if_flags_tripped(lambda self: self.model.diffusion_model)
     def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None,
                       timesteps=None, quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None,
                       log_every_t=None, noise=None, use_graph=False, mask_noise=None):
@@ -373,14 +373,13 @@ class LatentDiffusion(_Base):
         pg.ctx_program.run()
         x_buf, t_buf, eps = pg.inputs["x"], pg.inputs["t"], pg.outputs["eps"]
         tab, logvar = self._ddpm_device_tables()
-        key = (id(pg), timesteps, bool(use_graph), noise is None)
-        st = self._pl_state.get(key) if hasattr(self, "_pl_state") else None
+        key = (timesteps, bool(use_graph), noise is None)
+        loops = pg.__dict__.setdefault("_ddpm_loops", {})       # (the state lives on the program and dies with it, like ddim.py's)
+        st = loops.get(key)
         if st is None:
-            if not hasattr(self, "_pl_state"):
-                self._pl_state = {}
             st = dict(nz=torch.empty_like(img0), idx=torch.zeros(1, dtype=torch.int32, device=dev),
                       tt=torch.arange(self.num_timesteps, dtype=torch.int64, device=dev), graph=None)
-            self._pl_state[key] = st
+            loops[key] = st
         nz, idx, tt = st["nz"], st["idx"], st["tt"]
         per = img0[0].numel()
         lib = pg.lib

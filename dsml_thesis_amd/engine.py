@@ -15,9 +15,6 @@ import torch
 from . import lib as L
 
 
-_PLAN_TABLE = None
-
-
 def plan_key(a, m):
     """Shape signature of an igemm problem for the tuned-plan table (m = the row count the plan is made for)."""
     key = f"{m},{a.N},{a.K},{a.a_mode},{a.a_tf},{a.epi},{max(1, a.batch)}"
@@ -28,36 +25,25 @@ def plan_key(a, m):
     return key
 
 
-def plan_table():
-    """Tuned (tile_cfg, splitk) per problem shape: dsml_thesis_amd/igemm_plans.json, produced offline by
-    tools/autotune.py on an MI355X.  A static file, so plans (hence summation orders) are identical on every rank.
-    Indexed as {(N,K,mode,tf,epi,batch): [(M, cfg, splitk), ...] sorted by M}."""
-    global _PLAN_TABLE
-    if _PLAN_TABLE is None:
-        import json
-        import os
-        # LDMK_PLAN_TABLE: another table to A/B against the committed one (tools/autotune.py --out)
-        path = os.environ.get("LDMK_PLAN_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans.json")
-        _PLAN_TABLE = {}
-        if os.path.exists(path) and not os.environ.get("LDMK_NO_PLAN_TABLE"):
-            try:
-                with open(path) as fh:
-                    raw = json.load(fh)
-            except Exception:
-                raw = {}
-            for k, (cfg, sk) in raw.items():
-                m, rest = k.split(",", 1)
-                _PLAN_TABLE.setdefault(rest, []).append((int(m), int(cfg), int(sk)))
-            for v in _PLAN_TABLE.values():
-                v.sort()
-    return _PLAN_TABLE
-
-
-_X3_TABLE = None
+# ---- tuned launch plans ---------------------------------------------------------------------------------------------------------
+# ONE file, dsml_thesis_amd/igemm_plans.json, one section per ARITHMETIC / operand form (all produced offline on an MI355X by
+# tools/autotune.py / tools/ps_bench.py and merged by tools/merge_plans.py; a static file, so every rank makes the same choice):
+#   "f32"        (tile_cfg, splitk) per shape on the f32 matrix cores: LDS-tiled igemm, row GEMM, slab GEMM
+#   "bf16x3"     shapes measured FASTER in the fp32-accurate bf16x3 arithmetic (LDMK_COMPUTE_BF16X3) than their best f32 plan
+#   "f16x2"      plans measured in the F16X2 arithmetic itself; a shape listed under "bf16x3" only runs in F16X2 too, on that tile
+#   "ps_bf16x3"  shapes measured faster on the pre-split tiles (csrc/igemm_ps.hip: operands in the PS layout, LDS-DMA), bf16x3 planes
+#   "ps_f16x2"   the same for the two-plane F16X2 form of the pre-split tiles
+# Keys are plan_key() strings "M,N,K,a_mode,a_tf,epi,batch[,bt][,s<stride>u<upsample>]"; loaded as {rest of key: [(M, cfg, splitk)]}.
+# A/B overrides: LDMK_PLAN_TABLE / LDMK_X3_TABLE / LDMK_H2_TABLE / LDMK_PS_TABLE / LDMK_PS_H2_TABLE name a file that replaces ONE
+# section -- either a flat {key: [cfg, splitk]} file (what the tuning tools write) or another merged file, whose section is taken.
+_SECTIONS = {"f32": "LDMK_PLAN_TABLE", "bf16x3": "LDMK_X3_TABLE", "f16x2": "LDMK_H2_TABLE", "ps_bf16x3": "LDMK_PS_TABLE",
+             "ps_f16x2": "LDMK_PS_H2_TABLE"}
+_TABLES = {}
+_PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans.json")
 
 
 def split_enabled():
-    """LDMK_COMPUTE_BF16X3 (fp32-accurate GEMMs from six bf16 MFMAs, include/ldmk.h) for the shapes the x3 plan table lists;
+    """LDMK_COMPUTE_BF16X3 (fp32-accurate GEMMs from six bf16 MFMAs, include/ldmk.h) for the shapes the plan file lists;
     LDMK_SPLIT_BF16=0 keeps every GEMM on the f32 matrix-core form."""
     return os.environ.get("LDMK_SPLIT_BF16", "1") != "0"
 
@@ -68,154 +54,158 @@ def f16x2_enabled():
     return split_enabled() and os.environ.get("LDMK_F16X2", "1") != "0"
 
 
-def x3_table():
-    """{shape key: [(M, cfg, splitk)]}: shapes that tools/autotune.py --x3 measured FASTER in the bf16x3 arithmetic than their
-    best f32 plan (dsml_thesis_amd/igemm_plans_x3.json; LDMK_X3_TABLE overrides the path)."""
-    global _X3_TABLE
-    if _X3_TABLE is None:
-        import json
-        path = os.environ.get("LDMK_X3_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans_x3.json")
-        _X3_TABLE = {}
-        if os.path.exists(path) and split_enabled():
-            try:
-                with open(path) as fh:
-                    raw = json.load(fh)
-            except Exception:
-                raw = {}
-            for k, (cfg, sk) in raw.items():
-                m, rest = k.split(",", 1)
-                _X3_TABLE.setdefault(rest, []).append((int(m), int(cfg), int(sk)))
-            for v in _X3_TABLE.values():
-                v.sort()
-    return _X3_TABLE
-
-
-def x3_plan(a, m):
-    """(cfg, splitk) of the bf16x3 plan for this shape, or None: same bucket rule as tuned_plan, but only an exact or
-    within-2x row count of a shape that was measured faster in this arithmetic."""
-    rows = x3_table().get(plan_key(a, m).split(",", 1)[1])
-    if not rows:
-        return None
-    best = min(rows, key=lambda r: (abs(math.log(r[0] / m)), r[0]))
-    if max(best[0], m) > 2 * min(best[0], m):
-        return None
-    return best[1], best[2]
-
-
-_H2_TABLE = None
-
-
-def h2_table():
-    """{shape key: [(M, cfg, splitk)]}: shapes tools/autotune.py --h2 measured faster in the F16X2 arithmetic than their best f32
-    plan, with the F16X2 plan (dsml_thesis_amd/igemm_plans_h2.json; LDMK_H2_TABLE overrides the path).  A shape listed in the x3
-    table only runs in F16X2 too, on the x3 plan's tile."""
-    global _H2_TABLE
-    if _H2_TABLE is None:
-        import json
-        path = os.environ.get("LDMK_H2_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans_h2.json")
-        _H2_TABLE = {}
-        if os.path.exists(path) and f16x2_enabled():
-            try:
-                with open(path) as fh:
-                    raw = json.load(fh)
-            except Exception:
-                raw = {}
-            for k, (cfg, sk) in raw.items():
-                m, rest = k.split(",", 1)
-                _H2_TABLE.setdefault(rest, []).append((int(m), int(cfg), int(sk)))
-            for v in _H2_TABLE.values():
-                v.sort()
-    return _H2_TABLE
-
-
-def h2_plan(a, m):
-    rows = h2_table().get(plan_key(a, m).split(",", 1)[1])
-    if not rows:
-        return None
-    best = min(rows, key=lambda r: (abs(math.log(r[0] / m)), r[0]))
-    if max(best[0], m) > 2 * min(best[0], m):
-        return None
-    return best[1], best[2]
-
-
-_PS_TABLE = None
-
-
 def ps_enabled():
     """Pre-split operands (csrc/igemm_ps.hip, tile_cfg 23+): activations written in the PS layout by their producers and moved
-    memory -> LDS by LDS-DMA, for the shapes dsml_thesis_amd/igemm_plans_ps.json lists.  LDMK_PS=0 keeps the round-3 kernels."""
+    memory -> LDS by LDS-DMA, for the shapes the "ps_*" sections list.  LDMK_PS=0 keeps the round-3 kernels."""
     return split_enabled() and os.environ.get("LDMK_PS", "1") != "0"
 
 
-_PS_H2_TABLE = None
+def _section_enabled(section):
+    if section == "f32":
+        return not os.environ.get("LDMK_NO_PLAN_TABLE")
+    if section == "bf16x3":
+        return split_enabled()
+    if section == "f16x2":
+        return f16x2_enabled()
+    if section == "ps_bf16x3":
+        return ps_enabled()
+    return ps_enabled() and f16x2_enabled()
 
 
-def ps_h2_table():
-    """The same for the F16X2 form of the pre-split tiles (dsml_thesis_amd/igemm_plans_ps_h2.json; LDMK_PS_H2_TABLE overrides)."""
-    global _PS_H2_TABLE
-    if _PS_H2_TABLE is None:
+def reset_tables():
+    """Forget the loaded sections (tests and A/B tools that change the environment between programs)."""
+    _TABLES.clear()
+
+
+def table(section):
+    """{rest of key: [(M, cfg, splitk)] sorted by M} of one section of the plan file (see above); {} when its arithmetic is off."""
+    t = _TABLES.get(section)
+    if t is None:
         import json
-        path = os.environ.get("LDMK_PS_H2_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans_ps_h2.json")
-        _PS_H2_TABLE = {}
-        if os.path.exists(path) and ps_enabled() and f16x2_enabled():
+        t = {}
+        path = os.environ.get(_SECTIONS[section]) or _PLAN_FILE
+        if _section_enabled(section) and os.path.exists(path):
             try:
                 with open(path) as fh:
                     raw = json.load(fh)
             except Exception:
                 raw = {}
+            if any(k in raw for k in _SECTIONS):      # a merged file: this section of it
+                raw = raw.get(section, {})
             for k, (cfg, sk) in raw.items():
                 m, rest = k.split(",", 1)
-                _PS_H2_TABLE.setdefault(rest, []).append((int(m), int(cfg), int(sk)))
-            for v in _PS_H2_TABLE.values():
+                t.setdefault(rest, []).append((int(m), int(cfg), int(sk)))
+            for v in t.values():
                 v.sort()
-    return _PS_H2_TABLE
+        _TABLES[section] = t
+    return t
+
+
+# How far (as a ratio of row counts) a tuned plan may be carried.  Every plan of a bucket is LEGAL for every M (the split depth is
+# bounded by K and the even-tile rule by the epilogue, both part of the key), so this is a performance rule only.  Rounds 1-4 used
+# 2: a 64x64x4 job of 2-7 samples then found no split-arithmetic plan at all and silently ran the f32 program (-44 %).  Round 5
+# carries the nearest tuned plan whatever the distance (A/B against the f32 fall-back: profiles/r05_plan_coverage.txt);
+# LDMK_PLAN_MAX_RATIO=2 restores the old rule.
+PLAN_MAX_RATIO = float(os.environ.get("LDMK_PLAN_MAX_RATIO", "0")) or None
+
+
+def lookup(section, rest, m):
+    """(cfg, splitk) of the tuned shape in `section` with key `rest` whose row count is closest to m on a log scale (ties go to the
+    smaller M), or None."""
+    rows = table(section).get(rest)
+    if not rows or m <= 0:
+        return None
+    best = min(rows, key=lambda r: (abs(math.log(r[0] / m)), r[0]))
+    if PLAN_MAX_RATIO is not None and max(best[0], m) > PLAN_MAX_RATIO * min(best[0], m):
+        return None
+    return best[1], best[2]
+
+
+def _rest(a, m):
+    return plan_key(a, m).split(",", 1)[1]
+
+
+def plan_table():
+    return table("f32")
+
+
+def x3_table():
+    return table("bf16x3")
+
+
+def h2_table():
+    return table("f16x2")
 
 
 def ps_table():
-    """{shape key: [(M, cfg, splitk)]}: GEMM shapes measured faster on the pre-split tiles than on their best other plan
-    (dsml_thesis_amd/igemm_plans_ps.json; LDMK_PS_TABLE overrides the path).  Same key as the other tables (plan_key)."""
-    global _PS_TABLE
-    if _PS_TABLE is None:
-        import json
-        path = os.environ.get("LDMK_PS_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_plans_ps.json")
-        _PS_TABLE = {}
-        if os.path.exists(path) and ps_enabled():
-            try:
-                with open(path) as fh:
-                    raw = json.load(fh)
-            except Exception:
-                raw = {}
-            for k, (cfg, sk) in raw.items():
-                m, rest = k.split(",", 1)
-                _PS_TABLE.setdefault(rest, []).append((int(m), int(cfg), int(sk)))
-            for v in _PS_TABLE.values():
-                v.sort()
-    return _PS_TABLE
+    return table("ps_bf16x3")
 
 
-def ps_plan(rest, m, h2=False):
-    """(cfg, splitk) of the pre-split plan for the shape key `rest` ("N,K,mode,tf,epi,batch") at m rows, or None: exact or within
-    2x of a measured row count, like x3_plan.  h2: the table of the F16X2 form."""
-    rows = (ps_h2_table() if h2 else ps_table()).get(rest)
-    if not rows:
-        return None
-    best = min(rows, key=lambda r: (abs(math.log(r[0] / m)), r[0]))
-    if max(best[0], m) > 2 * min(best[0], m):
-        return None
-    return best[1], best[2]
+def ps_h2_table():
+    return table("ps_f16x2")
 
 
 def tuned_plan(a, m):
-    """Plan of the tuned shape with the same (N, K, prologue, epilogue) and the closest row count (log scale, at
-    most a factor 2 away; ties go to the smaller M), or None.  Every plan in a bucket is legal for every M: the
-    split depth is bounded by K and the even-tile rule by the epilogue, both part of the bucket key."""
-    rows = plan_table().get(plan_key(a, m).split(",", 1)[1])
-    if not rows:
-        return None
-    best = min(rows, key=lambda r: (abs(math.log(r[0] / m)), r[0]))
-    if max(best[0], m) > 2 * min(best[0], m):
-        return None
-    return best[1], best[2]
+    """f32 plan of the tuned shape with the same (N, K, prologue, epilogue) and the closest row count, or None (the C++ heuristic
+    decides)."""
+    return lookup("f32", _rest(a, m), m)
+
+
+def x3_plan(a, m):
+    """(cfg, splitk) of the bf16x3 plan for this shape, or None: only shapes measured faster in this arithmetic are listed."""
+    return lookup("bf16x3", _rest(a, m), m)
+
+
+def h2_plan(a, m):
+    return lookup("f16x2", _rest(a, m), m)
+
+
+def ps_plan(rest, m, h2=False):
+    """(cfg, splitk) of the pre-split plan for the shape key `rest` ("N,K,mode,tf,epi,batch") at m rows, or None.  h2: the section
+    of the F16X2 form."""
+    return lookup("ps_f16x2" if h2 else "ps_bf16x3", rest, m)
+
+
+class ArithSites:
+    """The F16X2 range flags of a model, one int32 word per SITE.  A site is a group of launches that share split operands -- a
+    convolution with its transform / statistics producer, `LN1 -> QKV -> attention -> to_out`, `LN3 -> GEGLU -> ff.net.2` -- named
+    by the reference's parameter prefix, so the same layer is the same site in every launch program of the model (any batch, any
+    shape).  Every F16X2 launch of the site points its `range_flag` at the site's word (the ABI has always taken the pointer per
+    launch); an out-of-range operand raises it and is saturated (csrc/ldmk_common.h: h2_clamp), so the rest of the evaluation stays
+    finite and raises only its own flags.  `raised()` is ONE device -> host copy; the model then DENIES the named sites -- they
+    run in the bf16x3 arithmetic from the next program build on -- and leaves the others in F16X2."""
+
+    MAX_SITES = 1024
+
+    def __init__(self, device):
+        self.flags = torch.zeros(self.MAX_SITES, device=device, dtype=torch.int32)
+        self.index = {}
+        self.denied = set()
+
+    def flag(self, name):
+        """The site's flag word (a 1-element view), or None when the site has been denied the F16X2 arithmetic."""
+        if name in self.denied:
+            return None
+        i = self.index.get(name)
+        if i is None:
+            i = self.index[name] = len(self.index)
+            assert i < self.MAX_SITES, "more arithmetic sites than flag words"
+        return self.flags[i:i + 1]
+
+    def raised(self, clear=True):
+        """Names of the sites whose flag is up (one host sync); the words are zeroed again when any was."""
+        n = len(self.index)
+        if n == 0:
+            return []
+        up = torch.nonzero(self.flags[:n].cpu()).flatten().tolist()
+        if not up:
+            return []
+        if clear:
+            self.flags.zero_()
+        names = [None] * n
+        for k, i in self.index.items():
+            names[i] = k
+        return [names[i] for i in up]
 
 
 class Program:
@@ -422,10 +412,33 @@ class Program:
 class NetBuilder:
     """Emits the recurring layer patterns of the UNet / VQGAN into a Program (NHWC activations)."""
 
-    def __init__(self, pg, n, pin=None):
+    def __init__(self, pg, n, pin=None, sites=None):
         from . import ops
         self.pg, self.n, self.pin, self.ops = pg, n, pin, ops
         self._stats = {}          # tensor data_ptr -> GroupNorm partial records [rows/32][C][3]
+        # F16X2 is decided per SITE (ArithSites): inside `with nb.site(name):` the builder's and the program's `h2_flag` are the
+        # site's flag word -- or None for a denied site, and outside any site -- and every emitter below reads them there
+        self.sites = sites
+        self.h2_flag = getattr(pg, "h2_flag", None)
+        pg.h2_flag = self.h2_flag
+
+    def site(self, name):
+        """Context in which launches are emitted in the arithmetic of site `name`: F16X2 with the site's range flag, or -- the
+        model runs without F16X2, or this site was denied it after its flag went up -- the bf16x3 / f32 forms."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            if self.sites is None:          # (a builder driven by hand -- tests, tools -- keeps whatever flag its caller set)
+                yield self.h2_flag
+                return
+            old = (self.h2_flag, self.pg.h2_flag)
+            self.h2_flag = self.pg.h2_flag = self.sites.flag(name)
+            try:
+                yield self.h2_flag
+            finally:
+                self.h2_flag, self.pg.h2_flag = old
+        return ctx()
 
     @staticmethod
     def ptr(t):
@@ -690,6 +703,10 @@ class GraphedProgram:
 
     def __init__(self, fn, warmup=2):
         self.fn = fn
+        # the warm-up launches may draw random numbers (a step that samples its own noise): the generator is put back afterwards,
+        # so a run draws the same noise whether its graph was captured now or replayed from a cache -- which is what lets a
+        # sampling run that had to be repeated in another arithmetic replay the SAME trajectory
+        rng = torch.cuda.get_rng_state()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -700,6 +717,7 @@ class GraphedProgram:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             fn()
+        torch.cuda.set_rng_state(rng)
 
     def replay(self):
         self.graph.replay()

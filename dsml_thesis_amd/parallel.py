@@ -32,12 +32,23 @@ def batch_noise(seed, lo, hi, shape):
     return torch.stack([item_noise(seed, i, shape) for i in range(lo, hi)])
 
 
+COLLECTIVES_ISSUED = 0        # all_gather_into_tensor calls this process has issued (bench.py reports it; tests count it)
+
+
 def all_gather_items(local, n_items, group=None):
     """Gather the per-rank item blocks (dim 0) into the full [n_items, ...] tensor on every rank with a single
-    all_gather (ranks pad to the common block size; the tail is trimmed)."""
+    all_gather (ranks pad to the common block size; the tail is trimmed).  One rank: nothing to gather -- unless
+    LDMK_FORCE_COLLECTIVE is set and a process group exists (bench.py sets it with LDMK_BENCH_FORCE_DIST): then the REAL
+    collective is issued over the one-rank group, so that communicator creation and `ncclAllGather` on device tensors next to a
+    live hipGraph have run on hardware before the first multi-GPU job does."""
+    import os
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    global COLLECTIVES_ISSUED
+    if not (dist.is_available() and dist.is_initialized()):
         return local[:n_items]
+    if dist.get_world_size(group) == 1 and not os.environ.get("LDMK_FORCE_COLLECTIVE"):
+        return local[:n_items]
+    COLLECTIVES_ISSUED += 1
     world = dist.get_world_size(group)
     per = -(-n_items // world)
     pad = per - local.shape[0]

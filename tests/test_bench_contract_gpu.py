@@ -107,6 +107,23 @@ def test_bench_self_launches_two_ranks_and_the_clip_checksum_does_not_depend_on_
     assert abs(shard["clip"]["checksum"] - one["clip"]["checksum"]) <= 1e-4 * abs(one["clip"]["checksum"])
 
 
+def test_rccl_rehearsal_one_rank_issues_the_real_all_gather_next_to_a_live_hipgraph():
+    """No 8-GPU node is available to this build, so the first multi-GPU job would also be the first time RCCL runs at all.  With
+    LDMK_BENCH_FORCE_DIST=1 the one-rank bench creates the nccl (= RCCL) process group, and the clip leg issues the REAL
+    `all_gather_into_tensor` on the decoded device frames inside each timed job -- between hipGraph replays of the DDIM step
+    (parallel.all_gather_items: the world-1 short cut is off under LDMK_FORCE_COLLECTIVE).  Same frames as without it."""
+    flags = ("--steps", "2", "--warmup", "1", "--batch", "2", "--latent", "32", "--no-secondary", "--no-cpu-baseline",
+             "--clip-frames", "6", "--clip-steps", "4", "--no-extras", "--clip-policy", "job")
+    plain = _run(*flags)
+    assert plain["clip"]["ranks_seen"] == 1 and plain["clip"]["collectives_issued_in_timed_jobs"] == 0 and plain["clip"]["backend"] is None
+    rccl = _run(*flags, env={"LDMK_BENCH_FORCE_DIST": "1"})
+    c = rccl["clip"]
+    assert c["backend"] == "nccl" and c["ranks_seen"] == 1 and "all_gather" in c["collective"]
+    assert c["collectives_issued_in_timed_jobs"] == len(c["seconds_of_jobs"]) == 3          # ONE collective per job
+    assert c["checksum"] == plain["clip"]["checksum"] and rccl["n_gpus"] == 1
+    assert abs(rccl["value"] - plain["value"]) < 0.5 * plain["value"]
+
+
 def test_default_line_carries_every_baseline_config():
     """The driver's one line (default legs, short timed region): configs[1] headline + its end-to-end sample() + decode at CFG
     1.0 and 3.0, configs[2] the 128-frame clip AT ITS SHIPPED DDIM-200, the reference's batch-1 autoregressive mode and its

@@ -140,15 +140,91 @@ def test_tuned_plan_table_is_legal_and_nearest():
     assert engine.tuned_plan(a, 65536) == engine.tuned_plan(a, 65536)
     near = engine.tuned_plan(a, 57344)            # batch 14: between the tuned 49152 and 65536 buckets
     assert near in (engine.tuned_plan(a, 49152), engine.tuned_plan(a, 65536))
-    assert engine.tuned_plan(a, 7) is None        # far from anything tuned: the C++ heuristic decides
+    # far from anything tuned: the nearest tuned plan is carried (round 5; rounds 1-4 gave up beyond a factor 2, which left
+    # whole batch ranges without a split-arithmetic plan) -- still a pure function of the shape
+    assert engine.tuned_plan(a, 7) == engine.tuned_plan(a, min(r[0] for r in table["320,2880,1,0,0,1"]))
+    a.N = 321
+    assert engine.tuned_plan(a, 65536) is None    # a shape nobody tuned: the C++ heuristic decides
+
+
+def test_one_plan_file_with_a_section_per_arithmetic(monkeypatch, tmp_path):
+    """dsml_thesis_amd/igemm_plans.json holds every tuned plan, one section per arithmetic / operand form; the LDMK_*_TABLE
+    overrides replace ONE section with a flat file (what the tuning tools write) or with that section of another merged file;
+    switching an arithmetic off empties its sections."""
+    import json
+    from dsml_thesis_amd import engine
+    for v in ("LDMK_SPLIT_BF16", "LDMK_F16X2", "LDMK_PS", "LDMK_NO_PLAN_TABLE", *engine._SECTIONS.values()):
+        monkeypatch.delenv(v, raising=False)
+    engine.reset_tables()
+    raw = json.load(open(engine._PLAN_FILE))
+    assert set(raw) == set(engine._SECTIONS), set(raw)
+    for sec in engine._SECTIONS:
+        assert sum(len(v) for v in engine.table(sec).values()) == len(raw[sec]) > 0, sec
+    # pre-split plans: only the tiles csrc/igemm_ps.hip implements (23..33), GEGLU on the (value, gate)-pair tiles without split-K
+    for sec in ("ps_bf16x3", "ps_f16x2"):
+        for key, rows in engine.table(sec).items():
+            n, k, mode, tf, epi, nb = (int(v) for v in key.split(",")[:6])
+            assert mode == 0 and k % 32 == 0 and n % 32 == 0
+            for m, cfg, sk in rows:
+                assert 23 <= cfg <= 33 and 1 <= sk <= k // 32 and (epi != 1 or (cfg in (25, 28, 32, 33) and sk == 1)), (key, cfg, sk)
+    # nearest row count, whatever the distance
+    rest = next(iter(engine.table("ps_f16x2")))
+    assert engine.ps_plan(rest, 3, h2=True) is not None and engine.ps_plan(rest, 1 << 22, h2=True) is not None
+    assert engine.ps_plan("31,64,0,0,0,1", 4096, h2=True) is None
+    flat = tmp_path / "flat.json"
+    flat.write_text(json.dumps({"4096,64,64,0,0,0,1": [27, 1]}))
+    monkeypatch.setenv("LDMK_PS_H2_TABLE", str(flat))
+    engine.reset_tables()
+    assert engine.ps_plan("64,64,0,0,0,1", 4096, h2=True) == (27, 1) and len(engine.table("ps_f16x2")) == 1
+    assert len(engine.table("f16x2")) > 10            # the other sections still come from the plan file
+    merged = tmp_path / "merged.json"
+    merged.write_text(json.dumps({"ps_f16x2": {"4096,96,96,0,0,0,1": [23, 2]}, "f32": {}}))
+    monkeypatch.setenv("LDMK_PS_H2_TABLE", str(merged))
+    engine.reset_tables()
+    assert engine.ps_plan("96,96,0,0,0,1", 5000, h2=True) == (23, 2)
+    monkeypatch.delenv("LDMK_PS_H2_TABLE")
+    monkeypatch.setenv("LDMK_F16X2", "0")
+    engine.reset_tables()
+    assert engine.table("f16x2") == {} and engine.table("ps_f16x2") == {} and engine.table("ps_bf16x3") and engine.table("bf16x3")
+    monkeypatch.delenv("LDMK_F16X2")
+    engine.reset_tables()
+
+
+def test_arithmetic_sites_name_flags_and_denials():
+    """engine.ArithSites (CPU tensors here): one flag word per named site, the same word for the same name in every program;
+    raised() names exactly the words that are up and clears them; a denied site gets no flag (its launches run in bf16x3)."""
+    import torch
+    from dsml_thesis_amd.engine import ArithSites, NetBuilder
+
+    class _Pg:
+        h2_flag = None
+    s = ArithSites("cpu")
+    a, b = s.flag("blk.0.attn1"), s.flag("blk.0.ff")
+    assert a.data_ptr() == s.flag("blk.0.attn1").data_ptr() != b.data_ptr() and a.numel() == 1
+    assert s.raised() == []
+    b.fill_(1)
+    assert s.raised(clear=False) == ["blk.0.ff"] and s.raised() == ["blk.0.ff"] and s.raised() == []
+    s.denied.add("blk.0.ff")
+    assert s.flag("blk.0.ff") is None and s.flag("blk.0.attn1") is not None
+    nb = NetBuilder.__new__(NetBuilder)
+    nb.pg, nb.sites, nb.h2_flag = _Pg(), s, None
+    with nb.site("blk.0.attn1") as hf:
+        assert hf is nb.h2_flag is nb.pg.h2_flag and hf.data_ptr() == a.data_ptr()
+        with nb.site("blk.0.ff") as hf2:
+            assert hf2 is None and nb.h2_flag is None and nb.pg.h2_flag is None
+        assert nb.h2_flag is hf
+    assert nb.h2_flag is None and nb.pg.h2_flag is None
+    nb.sites, nb.h2_flag = None, a                # a builder driven by hand keeps the flag its caller set
+    with nb.site("anything") as hf:
+        assert hf is a and nb.h2_flag is a
 
 
 def test_x3_plan_table_is_legal(monkeypatch):
-    """dsml_thesis_amd/igemm_plans_x3.json (tools/autotune.py --x3): the shapes that run in the fp32-accurate bf16x3 arithmetic.
+    """The bf16x3 section of the plan file (tools/autotune.py --x3): the shapes that run in the fp32-accurate bf16x3 arithmetic.
     Only the tiles that implement it (LDS-tiled 1 / 2 / 4 / 5, warp-specialised 21 / 22), never a b_trans shape, GEGLU on an
     even-TN tile without split-K, every slab at least one 32-deep chunk; LDMK_SPLIT_BF16=0 empties the table."""
     from dsml_thesis_amd import engine
-    monkeypatch.setattr(engine, "_X3_TABLE", None)
+    engine.reset_tables()
     monkeypatch.delenv("LDMK_SPLIT_BF16", raising=False)
     monkeypatch.delenv("LDMK_X3_TABLE", raising=False)
     table = engine.x3_table()
@@ -162,10 +238,10 @@ def test_x3_plan_table_is_legal(monkeypatch):
                 assert cfg in (1, 2, 22) and sk == 1
             if cfg in (21, 22):
                 assert ",s" not in key or "u0" in key          # no upsampling folded into the gather on those tiles
-    monkeypatch.setattr(engine, "_X3_TABLE", None)
+    engine.reset_tables()
     monkeypatch.setenv("LDMK_SPLIT_BF16", "0")
     assert engine.x3_table() == {} and not engine.split_enabled()
-    monkeypatch.setattr(engine, "_X3_TABLE", None)
+    engine.reset_tables()
 
 
 def test_product_side_recipe_matches_the_oracle_copy():

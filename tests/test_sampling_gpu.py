@@ -52,17 +52,20 @@ def test_ddim_sample_S4_and_graph_replay(fr):
     assert torch.equal(out, out_g2), "a cached graph replays from a clean state"
 
 
-def test_f16x2_range_fallback_inside_a_graphed_sampling_run(monkeypatch):
-    """The F16X2 range flag in a SAMPLING run under hipGraph replay (no host read inside the loop): a checkpoint whose attn1.to_k
-    weights are 3000 x larger (to_q as much smaller: same logits) finishes its DDIM run, the sampler reads the flag once, warns,
-    and repeats the run in the bf16x3 arithmetic -- bit for bit the run of a model started with LDMK_F16X2=0, graph or eager."""
+def test_f16x2_range_fallback_inside_a_graphed_sampling_run():
+    """The F16X2 range flags in a SAMPLING run under hipGraph replay (no host read inside the loop): a checkpoint whose attn1.to_k
+    weights of one block are 3000 x larger (to_q as much smaller: same logits) finishes its DDIM run, the sampler reads the flags
+    once, warns, re-plans THAT site in bf16x3 and repeats the run -- the same run: with eta = 1 and no x_T / noise given, start
+    noise and per-step noise come out of the restored generator again, so the result is bit for bit what a model that was told
+    about the site up front (deny_f16x2) samples from the same seed, graph or eager start noise alike."""
     import warnings
     from dsml_thesis_amd.ddim import DDIMSampler
+    site = "input_blocks.1.1.transformer_blocks.0.attn1"
 
     def model():
         m = make_fr_model(gain=0.25)
         sd = m.model.diffusion_model.state_dict()
-        key = "input_blocks.1.1.transformer_blocks.0.attn1.to_k.weight"
+        key = site + ".to_k.weight"
         sd[key] = sd[key] * 3000.0
         sd[key.replace("to_k", "to_q")] = sd[key.replace("to_k", "to_q")] / 3000.0
         m.model.diffusion_model.load_state_dict(sd, strict=True)
@@ -72,16 +75,29 @@ def test_f16x2_range_fallback_inside_a_graphed_sampling_run(monkeypatch):
     c, _ = _cond(m, labels=tuple(i % 7 for i in range(16)))       # (class ids of the 8-class embedder)
     unet = m.model.diffusion_model
     assert unet.f16x2
+    fired = []
     with pytest.warns(RuntimeWarning, match="F16X2"):
-        out, _ = DDIMSampler(m).sample(S=4, batch_size=16, shape=[3, 32, 32], conditioning=c, eta=0.0, x_T=xT, verbose=False, use_graph=True)
-    assert not unet.f16x2 and torch.isfinite(out).all()
-    monkeypatch.setenv("LDMK_F16X2", "0")
+        out, _ = DDIMSampler(m).sample(S=4, batch_size=16, shape=[3, 32, 32], conditioning=c, eta=0.0, x_T=xT, verbose=False, use_graph=True,
+                                       callback=fired.append)
+    st = unet.arithmetic_status()
+    assert st["f16x2"] and st["denied"] == [site] and torch.isfinite(out).all(), st
+    assert fired == [0, 1, 2, 3] * 2                               # (documented: callbacks fire during the discarded pass too)
     m0 = model()
-    assert not m0.model.diffusion_model.f16x2
+    m0.model.diffusion_model.deny_f16x2([site])
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         ref, _ = DDIMSampler(m0).sample(S=4, batch_size=16, shape=[3, 32, 32], conditioning=c, eta=0.0, x_T=xT, verbose=False, use_graph=False)
     assert torch.equal(out, ref)
+    # eta = 1, nothing pinned: the repeated pass must replay the first pass's draws
+    m1 = model()
+    torch.manual_seed(1234)
+    with pytest.warns(RuntimeWarning, match="F16X2"):
+        out1, _ = DDIMSampler(m1).sample(S=4, batch_size=16, shape=[3, 32, 32], conditioning=c, eta=1.0, verbose=False, use_graph=True)
+    torch.manual_seed(1234)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ref1, _ = DDIMSampler(m0).sample(S=4, batch_size=16, shape=[3, 32, 32], conditioning=c, eta=1.0, verbose=False, use_graph=True)
+    assert torch.isfinite(out1).all() and torch.equal(out1, ref1)
 
 
 @pytest.mark.parametrize("latent", [32, 64])

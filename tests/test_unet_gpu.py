@@ -203,13 +203,13 @@ def test_unet_split_arithmetic_routes_against_the_reference_fixtures(monkeypatch
     monkeypatch.undo()
     # (c) the f32 matrix-core program
     monkeypatch.setenv("LDMK_SPLIT_BF16", "0")
-    monkeypatch.setattr(engine, "_X3_TABLE", None)
+    engine.reset_tables()
     eps_c, n3c, _, names_c = run()
     assert n3c == 0 and "ldmk_attn_self" in names_c and not {"ldmk_attn_self_x3", "ldmk_attn_self_x3p", "ldmk_attn_self_h2", "ldmk_attn_self_h2_ps", "ldmk_attn_self_h2_tiles"} & set(names_c)
     close(eps_c, g["fr_eps"], 3e-5, 3e-5)
     assert (eps_a - eps_c).abs().max().item() < 1.5e-5
     monkeypatch.undo()
-    engine._X3_TABLE = None
+    engine.reset_tables()
 
 
 def test_folded_layernorm_guard_switches_mean_dominated_models_to_the_unfolded_prologue():
@@ -244,11 +244,23 @@ def test_folded_layernorm_guard_switches_mean_dominated_models_to_the_unfolded_p
         assert torch.equal(m2(x.cuda(), t.cuda(), context=ctx.cuda()), eps)
 
 
-def test_f16x2_range_flag_sends_the_model_back_to_bf16x3(monkeypatch):
-    """The F16X2 attention needs |K|, |V|, |scaled Q| < 1000.  A checkpoint whose attn1.to_k weights of one block are 3000 x
-    larger (and its to_q weights as much smaller) must still meet the oracle with no environment variable set: the kernels raise the range flag, the first evaluation
-    reads it, warns, drops its programs and evaluates again in the bf16x3 arithmetic -- bit for bit what a model started with
-    LDMK_F16X2=0 computes.  A well-conditioned model stays in F16X2."""
+H2_ATTN = {"ldmk_attn_self_h2", "ldmk_attn_self_h2_ps", "ldmk_attn_self_h2_tiles"}
+
+
+def _f16x2_launches(pg):
+    """(launches that run in the F16X2 arithmetic, launches that run in a split arithmetic at all) of a launch program."""
+    from dsml_thesis_amd import lib as L
+    h2 = sum(1 for c in pg.calls if (c[3] == "ldmk_igemm" and c[2].compute == L.COMPUTE_F16X2) or c[3] in H2_ATTN)
+    x3 = sum(1 for c in pg.calls if (c[3] == "ldmk_igemm" and c[2].compute == L.COMPUTE_BF16X3) or c[3] in ("ldmk_attn_self_x3", "ldmk_attn_self_x3p", "ldmk_attn_self_x3p_ps"))
+    return h2, h2 + x3
+
+
+def test_f16x2_range_flag_sends_one_site_back_to_bf16x3():
+    """The F16X2 attention needs |K|, |V|, |scaled Q| < 1000.  A checkpoint whose attn1.to_k weights of ONE block are 3000 x larger
+    (and its to_q weights as much smaller: same logits) must still meet the oracle with no environment variable set: the kernels
+    raise that site's range flag (and saturate the operand, so nothing downstream overflows), the evaluation reads the flags,
+    warns, re-plans THAT site -- LN1 -> QKV -> attention -> to_out of the block -- in bf16x3 and evaluates again; every other
+    launch stays in F16X2.  A well-conditioned model stays in F16X2 throughout."""
     import warnings
     from dsml_thesis_amd.unet import UNetModel
     x, t, ctx = rnd(43, 2, 3, 32, 32), torch.tensor([5, 700]), rnd(44, 2, 1, 512)
@@ -257,34 +269,175 @@ def test_f16x2_range_flag_sends_the_model_back_to_bf16x3(monkeypatch):
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         m(x.cuda(), t.cuda(), context=ctx.cuda())
-    assert m.f16x2 and m._h2_flag.item() == 0
-    assert {"ldmk_attn_self_h2", "ldmk_attn_self_h2_ps", "ldmk_attn_self_h2_tiles"} & {c[3] for c in m.program(2, 32, 32, 1, 0).calls}
-    key = "input_blocks.1.1.transformer_blocks.0.attn1.to_k.weight"
+    st = m.arithmetic_status()
+    assert st["f16x2"] and not st["denied"] and not st["flags_up"] and st["sites"] > 60
+    pg0 = m.program(2, 32, 32, 1, 0)
+    assert H2_ATTN & {c[3] for c in pg0.calls}
+    h2_0, split_0 = _f16x2_launches(pg0)
+    assert h2_0 == split_0 > 100               # every split-arithmetic launch of a healthy model runs in F16X2
+    site = "input_blocks.1.1.transformer_blocks.0.attn1"
+    key = site + ".to_k.weight"
     keyq = key.replace("to_k", "to_q")
     assert key in sd and keyq in sd
     # (K x 3000 with Q / 3000: the logits -- and the conditioning of the softmax -- are those of the original checkpoint)
     sd2 = {k: (v * 3000.0 if k == key else v / 3000.0 if k == keyq else v) for k, v in sd.items()}
-
-    def load():
-        m_ = UNetModel(**W.FR_UNET)
-        m_.load_state_dict(sd2, strict=True)
-        m_ = m_.cuda().eval()
-        m_.policy_batch = 16
-        return m_
-    m2 = load()
+    m2 = UNetModel(**W.FR_UNET)
+    m2.load_state_dict(sd2, strict=True)
+    m2 = m2.cuda().eval()
+    m2.policy_batch = 16
     with pytest.warns(RuntimeWarning, match="F16X2"):
         eps = m2(x.cuda(), t.cuda(), context=ctx.cuda())
-    assert not m2.f16x2
-    names = [c[3] for c in m2.program(2, 32, 32, 1, 0).calls]
-    assert not {"ldmk_attn_self_h2", "ldmk_attn_self_h2_ps", "ldmk_attn_self_h2_tiles"} & set(names) and "ldmk_attn_self_x3" in names
+    st = m2.arithmetic_status()
+    assert st["f16x2"] and st["denied"] == [site] and not st["flags_up"], st
+    pg2 = m2.program(2, 32, 32, 1, 0)
+    h2_2, split_2 = _f16x2_launches(pg2)
+    assert split_2 == split_0 and h2_0 - 4 <= h2_2 < h2_0, (h2_0, h2_2, split_2)      # the site's QKV, attention, to_out: nothing else moved
+    names0, names2 = [c[3] for c in pg0.calls], [c[3] for c in pg2.calls]
+    assert sum(n in H2_ATTN for n in names2) == sum(n in H2_ATTN for n in names0) - 1
     close(eps, O.unet_forward(sd2, W.FR_UNET, x, t, ctx), 3e-5, 3e-5)
     with warnings.catch_warnings():
         warnings.simplefilter("error")                   # decided once
         assert torch.equal(m2(x.cuda(), t.cuda(), context=ctx.cuda()), eps)
+    # a model told up front (deny_f16x2) computes the same bits without ever raising a flag
+    m3 = UNetModel(**W.FR_UNET)
+    m3.load_state_dict(sd2, strict=True)
+    m3 = m3.cuda().eval()
+    m3.policy_batch = 16
+    m3.deny_f16x2([site])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert torch.equal(m3(x.cuda(), t.cuda(), context=ctx.cuda()), eps)
+
+
+def test_f16x2_outlier_residual_channel_moves_a_few_sites_only():
+    """A checkpoint with ONE outlier channel (x 2000) in a transformer block's residual stream -- where real checkpoints keep such
+    channels: proj_in's bias here -- through the batched program.  The LayerNorm-folded projections stage that stream RAW, so the
+    sites that read it (LN1 -> QKV ..., LN3 -> GEGLU ...) leave the F16X2 range; because the staged value is saturated, not
+    overflowed, nothing behind them sees a NaN and ONE repeat settles it: the oracle is met at the unchanged 3e-5, at most 10 % of
+    the split-arithmetic launches changed arithmetic, and the step costs within 10 % of the all-F16X2 model's."""
+    import time
+    import warnings
+    from dsml_thesis_amd.unet import UNetModel
+    x, t, ctx = rnd(45, 2, 3, 32, 32), torch.tensor([3, 600]), rnd(46, 2, 1, 512)
+    m, sd = make_unet(W.FR_UNET)
+    m.policy_batch = 16
+    sd2 = dict(sd)
+    b = sd["input_blocks.2.1.proj_in.bias"].clone()
+    b[7] = 2000.0
+    sd2["input_blocks.2.1.proj_in.bias"] = b
+    m2 = UNetModel(**W.FR_UNET)
+    m2.load_state_dict(sd2, strict=True)
+    m2 = m2.cuda().eval()
+    m2.policy_batch = 16
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        eps = m2(x.cuda(), t.cuda(), context=ctx.cuda())
+    h2w = [w for w in rec if "F16X2" in str(w.message)]
+    assert 1 <= len(h2w) <= 2, [str(w.message) for w in rec]
+    st = m2.arithmetic_status()
+    assert st["f16x2"] and st["denied"] and all(d.startswith("input_blocks.2.1.") for d in st["denied"]), st
+    close(eps, O.unet_forward(sd2, W.FR_UNET, x, t, ctx), 3e-5, 3e-5)
+    h2_0, split_0 = _f16x2_launches(m.program(2, 32, 32, 1, 0))
+    h2_2, split_2 = _f16x2_launches(m2.program(2, 32, 32, 1, 0))
+    assert split_2 == split_0 and h2_2 >= 0.9 * h2_0, (h2_0, h2_2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert torch.equal(m2(x.cuda(), t.cuda(), context=ctx.cuda()), eps)
+
+    def step_ms(model):
+        pg = model.program(16, 32, 32, 1, 0)
+        pg.ctx_program.run()
+        for _ in range(3):
+            pg.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            pg.run()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 100.0
+    t_ref, t_out = min(step_ms(m) for _ in range(3)), min(step_ms(m2) for _ in range(3))
+    print(f"outlier-channel model: {t_out:.3f} ms per 16-sample step, all-F16X2 model {t_ref:.3f} ms; sites denied: {st['denied']}")
+    assert t_out <= 1.10 * t_ref, (t_out, t_ref)
+
+
+def test_f16x2_flag_is_read_on_every_forward_not_only_the_first():
+    """The range flags are data dependent: the SECOND evaluation of a cached program, on an input a million times larger, drives the
+    residual stream past 1000 where the stride-2 convolutions stage it raw.  forward() reads the flags on every call, re-plans those
+    sites and returns finite values that meet the oracle -- not the saturated garbage of the first attempt."""
+    import warnings
+    x, t, ctx = rnd(47, 2, 3, 32, 32), torch.tensor([9, 400]), rnd(48, 2, 1, 512)
+    m, sd = make_unet(W.FR_UNET)
+    m.policy_batch = 16
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        e1 = m(x.cuda(), t.cuda(), context=ctx.cuda())
+    close(e1, O.unet_forward(sd, W.FR_UNET, x, t, ctx), 3e-5, 3e-5)
+    big = x * 1.0e6
+    with pytest.warns(RuntimeWarning, match="F16X2"):
+        e2 = m(big.cuda(), t.cuda(), context=ctx.cuda())
+    st = m.arithmetic_status()
+    assert st["f16x2"] and st["denied"] and not st["flags_up"], st
+    ref = O.unet_forward(sd, W.FR_UNET, big, t, ctx)
+    assert torch.isfinite(e2).all()
+    close(e2, ref, 1e-4, 1e-4 * float(ref.abs().max()))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                   # the small input again, on the re-planned program: still the oracle's
+        close(m(x.cuda(), t.cuda(), context=ctx.cuda()), O.unet_forward(sd, W.FR_UNET, x, t, ctx), 3e-5, 3e-5)
+
+
+def _student_t_state_dict(shapes, nu=3.0, seed=0):
+    """The weight recipe of oracle/weights.py with Student-t (nu = 3) draws of the same variance in place of the Gaussian ones for
+    every matrix / convolution weight: heavy tails -- a few weights per tensor 5-20 standard deviations out, as trained
+    checkpoints have them.  Biases and norm parameters keep the recipe."""
+    import zlib
+    sd = W.synth_state_dict(shapes)
+    for k, v in sd.items():
+        if v.dim() >= 2:
+            rs = np.random.RandomState((zlib.crc32(k.encode()) ^ (seed + 12345)) & 0xFFFFFFFF)
+            tdraw = rs.standard_t(nu, size=tuple(v.shape)).astype(np.float32) / np.sqrt(nu / (nu - 2.0))
+            sd[k] = torch.from_numpy(tdraw * float(v.std()))
+    return sd
+
+
+def test_f16x2_heavy_tailed_weights_below_the_range_threshold(monkeypatch):
+    """Every parity margin of rounds 3-4 was measured on Gaussian weights.  Here the FR UNet carries Student-t (nu = 3) weights:
+    outlier weights and, through them, outlier activation channels that stay BELOW the range threshold -- where the dropped lo lo
+    term and the absolute-precision floor of F16X2 matter most.  eps must meet the oracle at the unchanged 3e-5 in F16X2, and the
+    margin is logged next to the exact-split (bf16x3) model's."""
+    import warnings
+    from dsml_thesis_amd import engine
+    from dsml_thesis_amd.unet import UNetModel
+    x, t, ctx = rnd(49, 2, 3, 32, 32), torch.tensor([11, 850]), rnd(50, 2, 1, 512)
+    sd = _student_t_state_dict(W.unet_param_shapes(W.FR_UNET))
+    big = max(float(v.abs().max() / v.std()) for v in sd.values() if v.dim() >= 2)
+    assert big > 20.0, big                                # the tails are there
+
+    def run():
+        m = UNetModel(**W.FR_UNET)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().eval()
+        m.policy_batch = 16
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")               # below the threshold: no flag, no fall-back
+            return m, m(x.cuda(), t.cuda(), context=ctx.cuda())
+    ref = O.unet_forward(sd, W.FR_UNET, x, t, ctx)
+    m, eps = run()
+    st = m.arithmetic_status()
+    assert st["f16x2"] and not st["denied"], st
+    close(eps, ref, 3e-5, 3e-5)
     monkeypatch.setenv("LDMK_F16X2", "0")
-    m3 = load()
-    assert not m3.f16x2
-    assert torch.equal(m3(x.cuda(), t.cuda(), context=ctx.cuda()), eps)
+    engine.reset_tables()
+    try:
+        m0, eps0 = run()
+        assert not m0.f16x2
+        close(eps0, ref, 3e-5, 3e-5)
+    finally:
+        monkeypatch.delenv("LDMK_F16X2")
+        engine.reset_tables()
+    d_h2, d_x3 = float((eps.cpu() - ref).abs().max()), float((eps0.cpu() - ref).abs().max())
+    print(f"heavy-tailed weights (Student-t nu=3, max |w| / std = {big:.1f}): max |eps - reference| f16x2 {d_h2:.3e}, bf16x3 {d_x3:.3e} "
+          f"(bound 3e-5 + 3e-5 |ref|, max |ref| {float(ref.abs().max()):.3f})")
+    assert d_h2 <= 3.0 * max(d_x3, 2e-6)
 
 
 def test_attention_block_golden_through_the_launch_program():

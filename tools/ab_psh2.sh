@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B on ONE box: the F16X2 step with the pre-split tiles for (a) everything in igemm_plans_ps_h2.json, (b) the transformer GEMMs only
+# A/B on ONE box: the F16X2 step with the pre-split tiles for (a) everything in the ps_f16x2 section of igemm_plans.json, (b) the transformer GEMMs only
 # (no Winograd / upsampling entries), (c) none
 python3 - <<'PY'
 import json
-t = json.load(open("dsml_thesis_amd/igemm_plans_ps_h2.json"))
+t = json.load(open("dsml_thesis_amd/igemm_plans.json"))["ps_f16x2"]
 json.dump({k: v for k, v in t.items() if k.endswith(",1")}, open("gpurun_out/ps_h2_tf_only.json", "w"))
 PY
 one() { python3 bench.py "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }

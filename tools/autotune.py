@@ -1,6 +1,8 @@
 """Offline tuning of the igemm (tile shape, split-K) plan per problem shape.
 
-    python tools/autotune.py --latent 64 --batch 16 [--latent 32 --batch 16 ...] --out dsml_thesis_amd/igemm_plans.json
+    python tools/autotune.py --case 64:16 [--case 32:16 ...] [--out gpurun_out/plans_f32.json]
+    (flat files; the sweep starts from the matching section of dsml_thesis_amd/igemm_plans.json and
+     `python tools/merge_plans.py --merge <section> <flat>` puts a result back)
 
 For every distinct igemm problem of the UNet launch program (M, N, K, conv/rows, prologue, epilogue) every legal
 (tile_cfg, splitk) pair is timed on the real buffers (HIP events, median of 5) and the fastest is recorded.
@@ -109,7 +111,7 @@ def tune(kind, latent, batch, table):
 def tune_x3(pg, xtable):
     """--x3: for every GEMM of the program whose weight has bf16x3 split images, the best LDMK_COMPUTE_BF16X3 plan against the
     plan the program runs today (f32: LDS-tiled, row GEMM or slab GEMM, as recorded); shapes where the split arithmetic wins
-    by > 3 % go to the x3 table (dsml_thesis_amd/igemm_plans_x3.json), which engine.Program.plan() consults first."""
+    by > 3 % go to the bf16x3 section of the plan file, which engine.Program.plan() consults first."""
     from dsml_thesis_amd import lib as L, ops
     from dsml_thesis_amd.engine import plan_key
     lib = pg.lib
@@ -292,7 +294,7 @@ def tune_program(pg, table):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", action="append", default=[], help="[unet|dec|enc:]latent:batch, e.g. 64:16 or dec:64:16")
-    ap.add_argument("--out", default=os.path.join(ROOT, "dsml_thesis_amd", "igemm_plans.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "plans_f32.json"), help="flat table; tools/merge_plans.py --merge f32 puts it into the plan file")
     ap.add_argument("--fresh", action="store_true")
     ap.add_argument("--rows", action="store_true", help="re-tune rows-mode shapes already in the table against the "
                     "row-GEMM wave tiles (tile_cfg 7..12)")
@@ -300,21 +302,22 @@ if __name__ == "__main__":
                     "(tile_cfg 13..16, csrc/sgemm.hip): the small-batch cases")
     ap.add_argument("--force", action="store_true", help="re-sweep shapes that are already in the table (after a kernel change)")
     ap.add_argument("--x3", action="store_true", help="sweep the bf16x3 arithmetic (LDMK_COMPUTE_BF16X3) against the plans on record; "
-                    "writes dsml_thesis_amd/igemm_plans_x3.json (or --x3-out)")
-    ap.add_argument("--x3-out", default=os.path.join(ROOT, "dsml_thesis_amd", "igemm_plans_x3.json"))
+                    "writes the flat table --x3-out (tools/merge_plans.py --merge bf16x3 / f16x2)")
+    ap.add_argument("--x3-out", default=os.path.join(ROOT, "gpurun_out", "plans_bf16x3.json"))
     ap.add_argument("--h2", action="store_true", help="the --x3 sweep in the F16X2 arithmetic (LDMK_COMPUTE_F16X2, tile_cfg 1 / 2 / 4 / 5); "
-                    "writes dsml_thesis_amd/igemm_plans_h2.json")
+                    "writes gpurun_out/plans_f16x2.json")
     a = ap.parse_args()
     if a.h2:
         a.x3, H2_MODE = True, True
-        if a.x3_out.endswith("igemm_plans_x3.json"):
-            a.x3_out = a.x3_out.replace("igemm_plans_x3.json", "igemm_plans_h2.json")
+        if a.x3_out.endswith("plans_bf16x3.json"):
+            a.x3_out = a.x3_out.replace("plans_bf16x3.json", "plans_f16x2.json")
         os.environ["LDMK_H2_TABLE"] = "/nonexistent"
         H2_FLAG = torch.zeros(1, device="cuda", dtype=torch.int32)
     if a.x3:
         # the programs must be built with their f32 plans (table on, x3 table off) but with the split images packed
         os.environ["LDMK_X3_TABLE"] = "/nonexistent"
-        X3_TABLE = json.load(open(a.x3_out)) if os.path.exists(a.x3_out) and not a.fresh else {}
+        from merge_plans import section as _section
+        X3_TABLE = {} if a.fresh else (json.load(open(a.x3_out)) if os.path.exists(a.x3_out) else _section("f16x2" if a.h2 else "bf16x3"))
         for c in a.case or ["64:16", "32:16"]:
             parts = c.split(":")
             kind = parts[0] if len(parts) == 3 else "unet"
@@ -330,8 +333,9 @@ if __name__ == "__main__":
     SLAB_RETUNE = a.slab
     FORCE = a.force
     table = {}
-    if os.path.exists(a.out) and not a.fresh:
-        table = json.load(open(a.out))
+    if not a.fresh:
+        from merge_plans import section as _section
+        table = json.load(open(a.out)) if os.path.exists(a.out) else _section("f32")
     os.environ["LDMK_NO_PLAN_TABLE"] = "1"       # the search itself must start from the heuristic plans
     for c in a.case or ["64:16", "32:16"]:
         parts = c.split(":")

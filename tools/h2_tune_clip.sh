@@ -2,7 +2,7 @@
 # F16X2 plan sweep for the 128-frame clip batch (32x32, B = 128) merged into a copy of the table, then the clip leg with both tables
 R=$GRAFT_REPO_ROOT
 cd $R
-cp dsml_thesis_amd/igemm_plans_h2.json gpurun_out/plans_h2_clip.json
+python tools/merge_plans.py --extract f16x2 gpurun_out/plans_h2_clip.json
 python3 tools/autotune.py --h2 --case 32:128 --x3-out gpurun_out/plans_h2_clip.json > gpurun_out/tune_h2_clip.txt 2>&1 || { tail -20 gpurun_out/tune_h2_clip.txt; exit 1; }
 tail -2 gpurun_out/tune_h2_clip.txt
 one() { python3 bench.py "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print((d.get('clip') or {}).get('seconds'), (d.get('clip') or {}).get('checksum'))"; }

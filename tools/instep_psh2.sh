@@ -3,7 +3,7 @@
 # per-launch profiles of the step under each table on one box, per-shape winners merged into gpurun_out/plans_ps_h2_instep.json
 R=$GRAFT_REPO_ROOT
 cd $R
-cp dsml_thesis_amd/igemm_plans_ps_h2.json gpurun_out/plans_ps_h2_instep.json
+python tools/merge_plans.py --extract ps_f16x2 gpurun_out/plans_ps_h2_instep.json
 for lat in 64 32; do
   TABLE_ENV=LDMK_PS_H2_TABLE LAT=$lat bash tools/layer_multi.sh tools/psh2_var/v2.json tools/psh2_var/v3.json
   cd $R

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-launch tables of one UNet step under the committed plan table (t0) and under each table given (t1, t2, ...), all on
 # the same box:  LAT=64 tools/layer_multi.sh A.json B.json ...   -> gpurun_out/instep$LAT/t*/per_key.json, layers.txt
-# (TABLE_ENV=LDMK_X3_TABLE: the tables are variants of dsml_thesis_amd/igemm_plans_x3.json instead)
+# (TABLE_ENV=LDMK_X3_TABLE: the tables are flat variants of the bf16x3 section instead)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 lat=${LAT:-64}

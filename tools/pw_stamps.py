@@ -1,5 +1,6 @@
 """s_memtime stamps of the warp-specialised pre-split GEMM (csrc/igemm_ps.hip, LDMK_PS_DEBUG=8): where a stage's cycles go, per role.
-   LDMK_PS_DEBUG=8 python tools/pw_stamps.py"""
+   LDMK_HIPCC_FLAGS=-DLDMK_PS_PROBES python -m dsml_thesis_amd.build && LDMK_PS_DEBUG=8 LDMK_HIPCC_FLAGS=-DLDMK_PS_PROBES python tools/pw_stamps.py
+   (the probes exist only in builds made with -DLDMK_PS_PROBES)"""
 import os
 import sys
 import numpy as np
