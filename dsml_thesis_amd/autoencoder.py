@@ -270,12 +270,12 @@ class VQModelInterface(nn.Module):
         s = pg.alloc(n, hw, hw)
         a = ops.make_igemm_args(hw, hw, c, q, c, k, s, hw, hw, b_trans=True, batch=n, a_bstride=hw * c,
                                 w_bstride=hw * c, out_bstride=hw * hw)
-        pg.igemm(a, nb.pin)
+        pg.igemm(a, nb.pin, per_sample=True)      # one problem per sample, planned as the job's batch of them
         pg.add("ldmk_softmax_rows", s.data_ptr(), n * hw, hw, float(int(c) ** (-0.5)))
         o = pg.alloc(rows, c)
         a = ops.make_igemm_args(hw, c, hw, s, hw, v, o, c, hw, batch=n, a_bstride=hw * hw, w_bstride=hw * c,
                                 out_bstride=hw * c)
-        pg.igemm(a, nb.pin)
+        pg.igemm(a, nb.pin, per_sample=True)      # one problem per sample, planned as the job's batch of them
         nb.release(s, q, k, v)
         out = nb.lin(o, P[prefix + "proj_out.weight"], sd[prefix + "proj_out.bias"], hw, residual=xr, stats=True)
         nb.release(o)

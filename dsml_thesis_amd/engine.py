@@ -107,6 +107,8 @@ def table(section):
 # carries the nearest tuned plan whatever the distance (A/B against the f32 fall-back: profiles/r05_plan_coverage.txt);
 # LDMK_PLAN_MAX_RATIO=2 restores the old rule.
 PLAN_MAX_RATIO = float(os.environ.get("LDMK_PLAN_MAX_RATIO", "0")) or None
+# direct 3x3 convolutions without a table entry run in F16X2 from this K (= 9 C_in) up, on their f32 plan's tile (Program.plan)
+H2_CONV_MIN_K = 1440 if os.environ.get("LDMK_H2_CONV_RULE", "1") != "0" else (1 << 30)
 
 
 def lookup(section, rest, m):
@@ -270,24 +272,45 @@ class Program:
             self._all.append(self._skcnt)
         return self._skcnt
 
-    def plan(self, args, scale_m=None, allow_splitk=True, batch_is_samples=True):
+    def plan(self, args, scale_m=None, allow_splitk=True, batch_is_samples=True, per_sample=False):
         """Choose (tile shape, K split) for a GEMM and pin them in `args`: for the real M, or -- with scale_m = (num, den) --
         for M*num/den rows, which pins the K-summation order so that results are bitwise independent of how a batch is
-        split across calls / ranks.  Returns (tile_cfg, splitk)."""
+        split across calls / ranks.  Returns (tile_cfg, splitk).
+        per_sample: the GEMM is one problem PER SAMPLE (args.batch = samples) also when this call happens to hold one sample: a
+        one-sample shard of a job must plan it as the job does -- a batch of problems, never looked up in the tables -- not as a
+        plain GEMM with more rows."""
         m, nbatch = args.M, args.batch
+        sample_batch = per_sample or (nbatch > 1 and batch_is_samples)
         if scale_m is not None and scale_m[0] != scale_m[1]:
-            if nbatch > 1 and batch_is_samples:   # batched GEMM (one problem per sample): the job-wide view has more problems
-                args.batch = max(1, nbatch * scale_m[0] // scale_m[1])
+            if sample_batch:                       # batched GEMM (one problem per sample): the job-wide view has more problems
+                args.batch = max(1, max(1, nbatch) * scale_m[0] // scale_m[1])
             else:
                 args.M = max(1, m * scale_m[0] // scale_m[1])
         cfg, sk = C.c_int(0), C.c_int(0)
         # bf16x3 arithmetic for the shapes measured faster in it (needs the weight's split images; decided on the policy row
         # count like every plan, so a sample's result does not depend on how the batch is sharded)
-        if (args.compute == L.COMPUTE_F32 and not args.b_trans and not args.raw_slabs and (nbatch <= 1 or not batch_is_samples)
+        if (args.compute == L.COMPUTE_F32 and not args.b_trans and not args.raw_slabs and not sample_batch
                 and args.M > 0 and (x3_table() or h2_table())):
             h2_flag = getattr(self, "h2_flag", None)
             hp = h2_plan(args, args.M) if h2_flag is not None else None       # a plan measured in the F16X2 arithmetic itself
             xp = hp if hp is not None else x3_plan(args, args.M)
+            if xp is None and h2_flag is not None and args.a_mode == L.A_CONV3X3 and args.K >= H2_CONV_MIN_K:
+                # A 3x3 convolution nobody measured in a split arithmetic (the tables hold the shapes of the B = 16 / 128 jobs; at
+                # other batches the low-resolution convolutions leave the Winograd route and show up as direct ones with
+                # K = 9 C_in of 2880-11520): long-K implicit GEMMs are matrix-bound, where three fp16 MFMAs per product beat eight
+                # f32 ones on every tile -- they take the F16X2 arithmetic on the tile and K split of their f32 plan
+                # (A/B at 64x64x4 B = 2 and 32x32x3 B = 5 / 7: profiles/r05_plan_coverage.txt; LDMK_H2_CONV_RULE=0 turns it off)
+                fp = tuned_plan(args, args.M)
+                if fp is None:
+                    c_, k_ = C.c_int(0), C.c_int(0)
+                    keep = (args.splitk_ws, args.splitk_ws_elems)
+                    if allow_splitk:
+                        args.splitk_ws, args.splitk_ws_elems = 1, 1 << 40
+                    self.lib.ldmk_igemm_plan(C.byref(args), C.byref(c_), C.byref(k_))
+                    args.splitk_ws, args.splitk_ws_elems = keep
+                    fp = (c_.value, max(1, k_.value))
+                if int(fp[0]) in (1, 2, 4, 5):
+                    xp = (int(fp[0]), int(fp[1]))
             if xp is not None:
                 from . import ops as _ops
                 saved = (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems)
@@ -302,9 +325,15 @@ class Program:
                 else:
                     ok = _ops.set_split(args)
                 if ok:
+                    # legal for the POLICY problem first (the row count every shard of the job shares: a tile that only the
+                    # smaller real problem could run must not be chosen, or a shard and the whole job would differ), then for
+                    # the real one
                     args.tile_cfg, args.splitk = int(xp[0]), int(xp[1])
                     args.splitk_ws, args.splitk_ws_elems = 1, 1 << 40
+                    args.M, args.batch = saved[0], saved[1]
                     ok = self.lib.ldmk_igemm_check(C.byref(args)) == 0
+                    args.M, args.batch = m, nbatch
+                    ok = ok and self.lib.ldmk_igemm_check(C.byref(args)) == 0
                 (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems) = saved
                 if ok:
                     args.M, args.batch = m, nbatch
@@ -316,18 +345,20 @@ class Program:
                 args.compute, args.w_split, args.w_split_ld, args.w_split_bstride = L.COMPUTE_F32, 0, 0, 0
                 args.w_scale_exp, args.range_flag = 0, 0
         # (a batch that is not per sample -- the 16 transform positions of a Winograd convolution -- is part of the plan key)
-        tuned = tuned_plan(args, args.M) if (nbatch <= 1 or not batch_is_samples) and args.M > 0 else None
+        tuned = tuned_plan(args, args.M) if not sample_batch and args.M > 0 else None
         if tuned is not None and tuned[0] > 6:
             # a row-GEMM wave tile (7..12, never splits K) or a slab-GEMM shape (13..20, small row counts): legal only with
             # the fragment-order weight copy and when the tile divides this problem (per-sample operands need
             # rows_per_sample % tile rows == 0); else the heuristic decides
             saved = (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems, args.raw_slabs)
-            args.M, args.batch, args.tile_cfg = m, nbatch, int(tuned[0])
+            args.tile_cfg = int(tuned[0])
             args.splitk = 1 if tuned[0] <= 12 else int(tuned[1])
             args.splitk_ws, args.splitk_ws_elems = 1, 1 << 40          # (validated against the real scratch below)
             if args.splitk == 1:
                 args.raw_slabs = 0                                      # an unsplit plan writes its output itself
-            if not args.w_frag or self.lib.ldmk_igemm_check(C.byref(args)) != 0:
+            ok = bool(args.w_frag) and self.lib.ldmk_igemm_check(C.byref(args)) == 0      # ... for the policy problem (see above)
+            args.M, args.batch = m, nbatch
+            if not ok or self.lib.ldmk_igemm_check(C.byref(args)) != 0:                  # ... and for the real one
                 tuned = None
             (args.M, args.batch, args.tile_cfg, args.splitk, args.splitk_ws, args.splitk_ws_elems, args.raw_slabs) = saved
         if tuned is not None:
@@ -343,10 +374,10 @@ class Program:
         args.a_split, args.a_split_ld = 0, 0          # (pre-split A belongs to the bf16x3 LDS-tiled plans, returned above)
         return args.tile_cfg, args.splitk
 
-    def igemm(self, args, scale_m=None, allow_splitk=True, batch_is_samples=True):
+    def igemm(self, args, scale_m=None, allow_splitk=True, batch_is_samples=True, per_sample=False):
         """Record a GEMM (planned here, once: see plan()); a split-K plan gets the program's shared scratch and is
         followed by its reduce launch."""
-        self.plan(args, scale_m, allow_splitk, batch_is_samples)
+        self.plan(args, scale_m, allow_splitk, batch_is_samples, per_sample)
         if args.splitk > 1:
             need = max(1, args.batch) * args.splitk * args.M * args.N
             ws = self.splitk_workspace(need)

@@ -193,6 +193,71 @@ def test_concat_conditioning_key_equals_channel_concatenated_input(fr):
     assert out.shape == (2, 4, 32, 32) and torch.isfinite(out).all()
 
 
+def test_concat_conditioning_with_guidance_single_step_equals_the_loop():
+    """`p_sample_ddim` with 'concat' conditioning AND classifier-free guidance: the halves of the doubled batch differ in the
+    concat tensor, [uncond | cond] (the reference's p_sample_ddim hands any `c` to apply_model, ddim.py:170-177; round 4 built the
+    branch into ddim_sampling only and p_sample_ddim raised a TypeError).  Chained single steps == the sampling loop, bit for bit."""
+    from dsml_thesis_amd import synth
+    from dsml_thesis_amd.ddpm import LatentDiffusion
+    from dsml_thesis_amd.ddim import DDIMSampler
+    cfg = synth.uncond_config(dict(synth.UNCOND_UNET, image_size=32, in_channels=7, out_channels=4), synth.VQ_F4_256)
+    cfg.update(conditioning_key="concat", cond_stage_config="__is_first_stage__", channels=4, image_size=32)
+    m = LatentDiffusion(**cfg)
+    synth.load_recipe(m.model.diffusion_model, gain=0.25)
+    m = m.cuda().eval()
+    x, cc, ucc = rnd(142, 2, 4, 32, 32).cuda(), rnd(143, 2, 3, 32, 32).cuda(), rnd(144, 2, 3, 32, 32).cuda()
+    s = DDIMSampler(m)
+    out, _ = s.sample(S=4, batch_size=2, shape=[4, 32, 32], conditioning=cc, eta=0.0, x_T=x, verbose=False,
+                      unconditional_guidance_scale=3.0, unconditional_conditioning=ucc)
+    img = x
+    for i, step in enumerate(np.flip(s.ddim_timesteps)):
+        ts = torch.full((2,), int(step), device="cuda", dtype=torch.long)
+        img, _ = s.p_sample_ddim(img, cc, ts, index=len(s.ddim_timesteps) - i - 1, unconditional_guidance_scale=3.0,
+                                 unconditional_conditioning=ucc)
+    assert torch.isfinite(out).all() and torch.equal(img, out)
+    # the guidance really used the unconditional concat tensor
+    out_same, _ = s.sample(S=4, batch_size=2, shape=[4, 32, 32], conditioning=cc, eta=0.0, x_T=x, verbose=False,
+                           unconditional_guidance_scale=3.0, unconditional_conditioning=cc)
+    assert not torch.equal(out, out_same)
+
+
+def test_use_original_steps_walks_the_models_own_schedule(fr):
+    """`use_original_steps` (ddim.py:127,133-134,183-186; ddim2cond.py:175-178): index counts the model's 1000 timesteps and the
+    update takes alphas_cumprod / alphas_cumprod_prev / sqrt_one_minus_alphas_cumprod / eta sqrt((1 - a_prev) / (1 - a) (1 - a / a_prev)).
+    One step against that formula in float64 on the UNet's own eps; the loop (`ddim_use_original_steps=True, timesteps=3`: steps 2,
+    1, 0, ddim.py:133) against chained single steps bit for bit, eager and hipGraph."""
+    from dsml_thesis_amd.ddim import DDIMSampler
+    c, uc = _cond(fr)
+    s = DDIMSampler(fr)
+    s.make_schedule(50, ddim_eta=1.0, verbose=False)
+    x = rnd(145, 2, 3, 32, 32).cuda()
+    nz = rnd(146, 2, 3, 32, 32).cuda()
+    idx = 437
+    ts = torch.full((2,), idx, device="cuda", dtype=torch.long)
+    xp, px0 = s.p_sample_ddim(x, c, ts, index=idx, use_original_steps=True, noise=nz)
+    e = fr.apply_model(x, ts, c).double()
+    a, ap = fr.alphas_cumprod[idx].double(), fr.alphas_cumprod_prev[idx].double()
+    sig = torch.sqrt((1 - ap) / (1 - a) * (1 - a / ap))
+    p0 = (x.double() - torch.sqrt(1 - a) * e) / torch.sqrt(a)
+    ref = torch.sqrt(ap) * p0 + torch.sqrt(1 - ap - sig ** 2) * e + sig * nz.double()
+    torch.testing.assert_close(px0.double(), p0, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(xp.double(), ref, rtol=2e-5, atol=2e-5)
+    s.make_schedule(50, ddim_eta=0.0, verbose=False)
+    out, inter = s.ddim_sampling(c, (2, 3, 32, 32), x_T=x, ddim_use_original_steps=True, timesteps=3)
+    img = x
+    for i in (2, 1, 0):
+        img, _ = s.p_sample_ddim(img, c, torch.full((2,), i, device="cuda", dtype=torch.long), index=i, use_original_steps=True)
+    assert torch.equal(out, img)
+    out_g, _ = s.ddim_sampling(c, (2, 3, 32, 32), x_T=x, ddim_use_original_steps=True, timesteps=3, use_graph=True)
+    assert torch.equal(out, out_g)
+    # `timesteps` on the DDIM subsequence: the first int(min(t / S, 1) S) - 1 entries (ddim.py:129-131)
+    sub, _ = s.ddim_sampling(c, (2, 3, 32, 32), x_T=x, timesteps=5)
+    img = x
+    for i in (3, 2, 1, 0):
+        img, _ = s.p_sample_ddim(img, c, torch.full((2,), int(s.ddim_timesteps[i]), device="cuda", dtype=torch.long), index=i)
+    assert torch.equal(sub, img)
+
+
 def _run3(fr, eta, scale, noise=None):
     from dsml_thesis_amd.ddim import DDIMSampler
     c, uc = _cond(fr)
