@@ -941,18 +941,227 @@ static int pw_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_
   return check_launch("ldmk_igemm(pw)");
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The pre-split tile as an IMPLICIT GEMM of a 3x3 convolution (round 5; F16X2, tile_cfg 23 / 24 / 26 / 27 with
+// a_mode = LDMK_A_CONV3X3 and a_ps).  The A operand is the GroupNorm-applied activation stored ONCE in the PS layout of the
+// [pixels][C] matrix (ldmk_gn_apply_ps_h2: it replaces the fp32 gn_apply pass, same bytes); the nine taps are nine per-lane
+// address sets for the same LDS-DMA instruction: lane (half, r) of the unit of output rows 32 b .. 32 b + 31 reads, for tap
+// (dy, dx), the 16 bytes of input pixel q = (n, oy stride + dy - pad, ox stride + dx - pad) -- block q / 32, row q % 32 of the
+// k-slab -- or, in the halo, an out-of-range offset that the buffer load turns into zeros.  Neighbouring lanes read neighbouring
+// pixels, i.e. neighbouring 16-byte pieces of one plane: the gather stays coalesced, no element passes through a register, and
+// nothing is split or normalised per N-tile (igemm_kernel<BF = 4> re-reads, scales and splits every input element once per tap and
+// column tile).  K order = igemm.hip's (32-channel chunk major, tap minor; ldmk_pack_conv3x3): 18 sixteen-deep stages per
+// chunk, unrolled, so the tap of a stage -- hence the VGPR holding its offsets -- is a compile-time index, and 18 % NS == 0
+// keeps the ring buffer index static too.  Same products in the same order into every accumulator as igemm_kernel<BF = 4> on
+// tile_cfg 5 / 1: bitwise equal at equal splitk (a K split must fall on chunk boundaries: splitk divides C / 32).
+template <int NWM, int NWN, int TM, int TN, bool TR>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_psc_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws) {
+  constexpr int PL = 2, NS = 3;
+  constexpr int NW = NWM * NWN;
+  constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN;
+  constexpr int FA = BM / 32, FB = BN / 32, U = FA + FB;
+  constexpr int UHI = (U + NW - 1) / NW, ULO = U / NW;
+  constexpr int AI = (FA + NW - 1) / NW;                              // A units a wave may own (its first AI units)
+  constexpr int UB = PL * 1024;
+  constexpr int STAGE = U * UB;
+  static_assert(18 % NS == 0 && PL * UHI * (NS - 1) <= 63, "ring / vmcnt");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_ps[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / NWN, wn = wave - wm * NWN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (bid % tiles_m) * BM;
+  const int n0 = (bid / tiles_m) * BN;
+  const int ks = blockIdx.y;
+
+  const int C = p.c0;
+  const int nc32 = C / 32;
+  const int c_per = (nc32 + splitk - 1) / splitk;
+  const int c_begin = ks * c_per;
+  const int c_end = min(nc32, c_begin + c_per);
+  const int Kb_in = C / 16, Kb_w = p.K / 16;
+  const int Nb = p.N / 32;
+  const long long samples = ((long long)p.M + p.rows_per_sample - 1) / p.rows_per_sample;
+  const unsigned Mb_in = (unsigned)((samples * p.in_h * p.in_w + 31) / 32);
+  const pu32x4 rs_a = ps_rsrc(p.a_ps, Mb_in * (unsigned)Kb_in * (unsigned)UB);
+  const pu32x4 rs_b = ps_rsrc(p.w_ps, (unsigned)Nb * (unsigned)Kb_w * (unsigned)UB);
+
+  // A units: per tap the byte offset of this lane's input pixel (k-slab 0, plane 0), or PS_OOB in the halo / past the last row
+  unsigned toff[AI][9];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int u = wave + NW * i;
+    const int row = m0 + 32 * u + l31;
+    const bool rok = u < FA && row < p.M;
+    const int rr = rok ? row : 0;
+    const int n = rr / p.rows_per_sample, rem = rr - n * p.rows_per_sample;
+    const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = oy * p.stride + t / 3 - p.pad_lo, ix = ox * p.stride + t % 3 - p.pad_lo;
+      const bool ok = rok && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+      const unsigned q = (unsigned)((n * p.in_h + iy) * p.in_w + ix);
+      toff[i][t] = ok ? (q >> 5) * (unsigned)Kb_in * (unsigned)UB + ((unsigned)half * 32u + (q & 31u)) * 16u : PS_OOB;
+    }
+  }
+  // B units: byte offset of the column block's first k-slab of this K range (wave-uniform), or PS_OOB
+  unsigned ubase[UHI];
+#pragma unroll
+  for (int i = 0; i < UHI; ++i) {
+    const int u = wave + NW * i;
+    const int blk = n0 / 32 + (u - FA);
+    ubase[i] = (u >= FA && u < U && blk < Nb) ? (unsigned)blk * (unsigned)Kb_w * (unsigned)UB + (unsigned)(18 * c_begin) * (unsigned)UB : PS_OOB;
+  }
+  const unsigned lane16 = lane * 16;
+  const unsigned lds0 = (unsigned)(size_t)smem_ps;
+  const bool hi_wave = wave + NW * (UHI - 1) < U;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // the DMA of stage (chunk c, position j = 2 tap + h) into ring buffer `buf`; sB = that stage's index within this K range
+  auto issue = [&](const int c, const int j, const int buf, const unsigned sB) {
+    const bool live = c < c_end;
+    const unsigned cs = (unsigned)(2 * c + (j & 1)) * (unsigned)UB;
+    const unsigned bdst = lds0 + (unsigned)buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < UHI; ++i) {
+      const int u = wave + NW * i;
+      if (u < U) {                                       // (wave-uniform)
+        if (i < AI && u < FA) {
+          const unsigned t = toff[i < AI ? i : 0][j >> 1];
+          ps_dma<PL>((live && t != PS_OOB) ? t + cs : PS_OOB, rs_a, bdst + (unsigned)u * (unsigned)UB);
+        } else {
+          ps_dma<PL>((live && ubase[i] != PS_OOB) ? lane16 + ubase[i] + sB * (unsigned)UB : PS_OOB, rs_b, bdst + (unsigned)u * (unsigned)UB);
+        }
+      }
+    }
+  };
+
+  unsigned sB = 0;
+  issue(c_begin, 0, 0, 0);
+  issue(c_begin, 1, 1, 1);
+  for (int c = c_begin; c < c_end; ++c) {
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+      if (hi_wave) ps_wait_vm<PL * UHI * (NS - 2)>(); else ps_wait_vm<PL * ULO * (NS - 2)>();
+      asm volatile("s_barrier" ::: "memory");
+      issue(j + 2 < 18 ? c : c + 1, (j + 2) % 18, (j + 2) % NS, sB + 2);
+      ++sB;
+      const unsigned char* sb = smem_ps + (j % NS) * STAGE + lane16;
+      pf16x8 a8[PL][TM];
+#pragma unroll
+      for (int g = 0; g < PL; ++g)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a8[g][i] = *reinterpret_cast<const pf16x8*>(sb + ((wm * TM + i) * PL + g) * 1024);
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        pf16x8 b8[PL];
+#pragma unroll
+        for (int g = 0; g < PL; ++g) b8[g] = *reinterpret_cast<const pf16x8*>(sb + ((FA + wn * TN + jn) * PL + g) * 1024);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          // F16X2: lo hi, hi lo, hi hi (planes: 0 = hi, 1 = lo) -- the order of igemm_kernel<BF = 4>
+          if constexpr (TR) {
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b8[0], a8[1][i], acc[i][jn], 0, 0, 0);
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b8[1], a8[0][i], acc[i][jn], 0, 0, 0);
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b8[0], a8[0][i], acc[i][jn], 0, 0, 0);
+          } else {
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8[1][i], b8[0], acc[i][jn], 0, 0, 0);
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8[0][i], b8[1], acc[i][jn], 0, 0, 0);
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8[0][i], b8[0], acc[i][jn], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  ps_wait_vm<0>();
+  ps_epilogue<TM, TN, TR, PL>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, 0, ws, lane);
+}
+
+// GroupNorm scale / shift [+ SiLU] of (the channel concat of) x0 | x1 written ONCE as the [n hw][C] matrix in the F16X2 form of
+// the PS layout -- ldmk_gn_apply with the output the conv-mode pre-split tile multiplies.  Workgroup = one 32-row block x 64
+// channels, thread = (row, 8 consecutive channels): 16-byte stores, 512-byte runs per plane.
+__global__ __launch_bounds__(256) void gn_apply_ps_h2_kernel(const float* __restrict__ x0, int c0, const float* __restrict__ x1, int c1,
+                                                             const float* __restrict__ coef, unsigned char* __restrict__ dst, long long rows,
+                                                             int hw, int silu, int* __restrict__ range_flag) {
+  const int rb = blockIdx.x, kc = blockIdx.y;
+  const int r = threadIdx.x >> 3, o = threadIdx.x & 7;
+  const long long row = (long long)rb * 32 + r;
+  const int C = c0 + c1;
+  const int k0 = kc * 64 + o * 8;
+  if (k0 >= C) return;
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+  if (row < rows) {
+    const float* src = k0 < c0 ? x0 + row * c0 + k0 : x1 + row * c1 + (k0 - c0);
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    const float* cf = coef + ((row / hw) * 2) * C + k0;
+    const float4 s0 = *reinterpret_cast<const float4*>(cf), s1 = *reinterpret_cast<const float4*>(cf + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(cf + C), h1 = *reinterpret_cast<const float4*>(cf + C + 4);
+    v0 = make_float4(fmaf(a.x, s0.x, h0.x), fmaf(a.y, s0.y, h0.y), fmaf(a.z, s0.z, h0.z), fmaf(a.w, s0.w, h0.w));
+    v1 = make_float4(fmaf(b.x, s1.x, h1.x), fmaf(b.y, s1.y, h1.y), fmaf(b.z, s1.z, h1.z), fmaf(b.w, s1.w, h1.w));
+    if (silu) {
+      v0 = make_float4(silu_f(v0.x), silu_f(v0.y), silu_f(v0.z), silu_f(v0.w));
+      v1 = make_float4(silu_f(v1.x), silu_f(v1.y), silu_f(v1.z), silu_f(v1.w));
+    }
+    if (ps_h2_out_of_range(v0) || ps_h2_out_of_range(v1)) *range_flag = 1;
+  }
+  unsigned char* d = dst + ((long long)rb * (C / 16) + (k0 >> 4)) * 2048 + ((o & 1) * 32 + r) * 16;
+  pf16x4 a0, l0, a1, l1;
+  ps_split2h(ps_scaled_sat(v0), a0, l0);
+  ps_split2h(ps_scaled_sat(v1), a1, l1);
+  *reinterpret_cast<pf16x8*>(d) = pf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+  *reinterpret_cast<pf16x8*>(d + 1024) = pf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+}
+
+template <int NWM, int NWN, int TM, int TN, bool TR>
+static int psc_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_t st) {
+  constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN;
+  constexpr size_t lds = (size_t)3 * (BM / 32 + BN / 32) * 2048;
+  static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_psc_kernel<NWM, NWN, TM, TN, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL((igemm_psc_kernel<NWM, NWN, TM, TN, TR>), dim3(tiles, splitk, 1), dim3(64 * NWM * NWN), lds, st, a, splitk, ws);
+  if (splitk > 1 && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
+  return check_launch("ldmk_igemm(ps, conv)");
+}
+
 const char* igemm_ps_unsupported(const ldmk_igemm_args& a, int pcfg, int splitk) {
   if (a.compute != LDMK_COMPUTE_BF16X3 && a.compute != LDMK_COMPUTE_F16X2) return "the pre-split tiles run the bf16x3 and the f16x2 arithmetic (compute)";
   const int pl = a.compute == LDMK_COMPUTE_F16X2 ? 2 : 3;
   if (pl == 2 && (pcfg == 6 || pcfg == 7)) return "the warp-specialised pre-split tiles (29 / 30) exist in the bf16x3 arithmetic only";
   if (pl == 2 && a.out_ps && !a.range_flag) return "out_ps in the f16x2 arithmetic needs range_flag";
   if (!a.a_ps || !a.w_ps) return "a_ps / w_ps (operands in the PS layout: ldmk_pack_ps, ldmk_ln_stats_ps, out_ps of a producer GEMM)";
-  if (a.a_mode != LDMK_A_ROWS) return "rows mode only";
+  if (a.a_mode == LDMK_A_CONV3X3) {      // the conv-mode tile (igemm_psc_kernel)
+    if (pl != 2) return "the conv-mode pre-split tile runs the f16x2 arithmetic only";
+    if (pcfg != 0 && pcfg != 1 && pcfg != 3 && pcfg != 4) return "conv mode: tile_cfg 23 / 24 / 26 / 27";
+    if (a.c1 || a.a1 || a.upsample || a.a_tf != LDMK_TF_NONE || a.out_ps || a.batch > 1 || a.epi != LDMK_EPI_NONE || a.attn_kv_out)
+      return "conv mode: one pre-normalised source (ldmk_gn_apply_ps_h2), no upsampling / prologue / out_ps / batching / GEGLU";
+    if (a.c0 % 32) return "conv mode: C_in must be a multiple of 32";
+    if ((a.c0 / 32) % splitk) return "conv mode: splitk must divide C_in / 32 (K is split on 32-channel chunk boundaries)";
+    const long long smp = ((long long)a.M + a.rows_per_sample - 1) / a.rows_per_sample;
+    if (((smp * a.in_h * a.in_w + 31) / 32) * (a.c0 / 16) * 2048 >= (1LL << 31)) return "conv mode: input of 2 GiB or more";
+  } else if (a.a_mode != LDMK_A_ROWS) {
+    return "rows mode or 3x3 convolution";
+  }
   if (a.b_trans || a.upsample || a.skip_a0 || (a.splitk_counters && !(ps_probe_bits() & 8))) return "b_trans / upsample / fused skip / in-launch combine";
   if (a.a_tf != LDMK_TF_NONE && a.a_tf != LDMK_TF_LAYERNORM_FOLDED) return "no staging prologue: a_ps is what gets multiplied";
   if (a.K % 32 || a.N % 32) return "K and N must be multiples of 32";
   const long long kb = a.K / 16;
-  if ((long long)((a.M + 31) / 32) * kb * pl * 1024 >= (1LL << 31) || (long long)(a.N / 32) * kb * pl * 1024 >= (1LL << 31)) return "an operand of 2 GiB or more";
+  if ((a.a_mode == LDMK_A_ROWS && (long long)((a.M + 31) / 32) * kb * pl * 1024 >= (1LL << 31)) || (long long)(a.N / 32) * kb * pl * 1024 >= (1LL << 31))
+    return "an operand of 2 GiB or more";
   if (a.epi == LDMK_EPI_GEGLU && (!kPsCfg[pcfg].even_tn || splitk > 1)) return "GEGLU needs a tile of (value, gate) pairs (256x256, 128x256) and no split-K";
   if (splitk > a.K / 32) return "more K slices than 32-deep chunks";
   if (a.out_ps) {
@@ -975,6 +1184,14 @@ const char* igemm_ps_unsupported(const ldmk_igemm_args& a, int pcfg, int splitk)
 int igemm_ps_dispatch(const ldmk_igemm_args& a, int pcfg, int splitk, float* ws, hipStream_t st) {
   // the transposed epilogue serves every call but those that want GroupNorm records
   const bool tr = !a.stats_out;
+  if (a.a_mode == LDMK_A_CONV3X3) {            // (unsupported() admits F16X2 on pcfg 0 / 1 / 3 / 4)
+    switch (pcfg) {
+      case 0: return tr ? psc_launch<8, 1, 1, 5, true>(a, splitk, ws, st) : psc_launch<8, 1, 1, 5, false>(a, splitk, ws, st);
+      case 1: return tr ? psc_launch<4, 2, 2, 5, true>(a, splitk, ws, st) : psc_launch<4, 2, 2, 5, false>(a, splitk, ws, st);
+      case 3: return tr ? psc_launch<4, 2, 1, 5, true>(a, splitk, ws, st) : psc_launch<4, 2, 1, 5, false>(a, splitk, ws, st);
+      default: return tr ? psc_launch<4, 1, 1, 5, true>(a, splitk, ws, st) : psc_launch<4, 1, 1, 5, false>(a, splitk, ws, st);
+    }
+  }
   if (a.compute == LDMK_COMPUTE_F16X2 && a.attn_kv_out)      // the fused QKV projection writing the attention's K / V tiles (unsupported() admits 0 / 4)
     return pcfg == 0 ? ps_launch<8, 1, 1, 5, 3, true, 2, true>(a, splitk, ws, st) : ps_launch<4, 1, 1, 5, 3, true, 2, true>(a, splitk, ws, st);
   if (a.compute == LDMK_COMPUTE_F16X2) {       // two fp16 planes per operand, three matrix instructions per product; one more ring stage fits
@@ -1079,4 +1296,18 @@ extern "C" int ldmk_ln_stats_ps_h2(const float* x, int rows, int c, float eps, f
   else if (c <= 640) hipLaunchKernelGGL((ln_stats_ps_kernel<10, 2>), grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag, range_flag);
   else hipLaunchKernelGGL((ln_stats_ps_kernel<20, 2>), grid, dim3(256), 0, st, x, rows, c, eps, stats, d, guard, flag, range_flag);
   return check_launch("ldmk_ln_stats_ps_h2");
+}
+
+extern "C" int ldmk_gn_apply_ps_h2(const float* x0, int c0, const float* x1, int c1, const float* coef, void* y_ps, int n, int hw, int silu,
+                                   int* range_flag, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(x0 && coef && y_ps && range_flag && n > 0 && hw > 0 && c0 > 0, "ldmk_gn_apply_ps_h2: bad args");
+  LDMK_REQUIRE((c1 == 0) == (x1 == nullptr), "ldmk_gn_apply_ps_h2: x1/c1 mismatch");
+  LDMK_REQUIRE(c0 % 8 == 0 && c1 % 8 == 0 && (c0 + c1) % 16 == 0, "ldmk_gn_apply_ps_h2: c0 = %d, c1 = %d must be multiples of 8, their sum of 16", c0, c1);
+  const long long rows = (long long)n * hw;
+  LDMK_REQUIRE(ldmk_ps_bytes_h2((int)rows, c0 + c1) < (1LL << 31) && rows < (1LL << 31), "ldmk_gn_apply_ps_h2: output of 2 GiB or more");
+  hipLaunchKernelGGL(gn_apply_ps_h2_kernel, dim3((unsigned)((rows + 31) / 32), (c0 + c1 + 63) / 64), dim3(256), 0, (hipStream_t)stream, x0, c0, x1, c1,
+                     coef, reinterpret_cast<unsigned char*>(y_ps), rows, hw, silu, range_flag);
+  return check_launch("ldmk_gn_apply_ps_h2");
 }

@@ -68,7 +68,11 @@ __device__ __forceinline__ float gelu_erf_f(float g) {
 // again in another arithmetic -- but it stays FINITE, so the launches behind it see plausible magnitudes and raise their own flags only
 // for their own operands: one pass names every launch that has to change arithmetic, not everything downstream of the first one
 // (an fp16 infinity would turn the rest of the network into NaNs, which trip every range check).  One v_med3_f32 per element.
+#ifdef LDMK_NO_H2_CLAMP      /* A/B builds only (what the saturation costs): profiles/r05_ab_clamp.txt */
+__device__ __forceinline__ float h2_clamp(float x) { return x; }
+#else
 __device__ __forceinline__ float h2_clamp(float x) { return __builtin_amdgcn_fmed3f(x, -999.99994f, 999.99994f); }
+#endif
 __device__ __forceinline__ float4 h2_clamp4(const float4& v) { return make_float4(h2_clamp(v.x), h2_clamp(v.y), h2_clamp(v.z), h2_clamp(v.w)); }
 
 // 64-lane butterfly reductions (wave = 64 on CDNA)

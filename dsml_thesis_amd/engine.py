@@ -111,14 +111,16 @@ PLAN_MAX_RATIO = float(os.environ.get("LDMK_PLAN_MAX_RATIO", "0")) or None
 H2_CONV_MIN_K = 1440 if os.environ.get("LDMK_H2_CONV_RULE", "1") != "0" else (1 << 30)
 
 
-def lookup(section, rest, m):
+def lookup(section, rest, m, max_ratio=None):
     """(cfg, splitk) of the tuned shape in `section` with key `rest` whose row count is closest to m on a log scale (ties go to the
-    smaller M), or None."""
+    smaller M), or None.  max_ratio: give up beyond that factor between the row counts (entries that record a ROUTE decision --
+    direct convolution against Winograd -- hold near the measured size only)."""
     rows = table(section).get(rest)
     if not rows or m <= 0:
         return None
     best = min(rows, key=lambda r: (abs(math.log(r[0] / m)), r[0]))
-    if PLAN_MAX_RATIO is not None and max(best[0], m) > PLAN_MAX_RATIO * min(best[0], m):
+    lim = max_ratio if max_ratio is not None else PLAN_MAX_RATIO
+    if lim is not None and max(best[0], m) > lim * min(best[0], m):
         return None
     return best[1], best[2]
 
@@ -162,10 +164,10 @@ def h2_plan(a, m):
     return lookup("f16x2", _rest(a, m), m)
 
 
-def ps_plan(rest, m, h2=False):
+def ps_plan(rest, m, h2=False, max_ratio=None):
     """(cfg, splitk) of the pre-split plan for the shape key `rest` ("N,K,mode,tf,epi,batch") at m rows, or None.  h2: the section
     of the F16X2 form."""
-    return lookup("ps_f16x2" if h2 else "ps_bf16x3", rest, m)
+    return lookup("ps_f16x2" if h2 else "ps_bf16x3", rest, m, max_ratio)
 
 
 class ArithSites:
@@ -573,14 +575,58 @@ class NetBuilder:
         return (cin >= self.WINO_MIN_CIN and pol_n * (h // 2) * (w // 2) >= self.WINO_MIN_TILES and h % 2 == 0
                 and w in (8, 16, 32, 64, 128) and (h * w) % 32 == 0 and (w >= 16 or (h // 2) % 2 == 0))
 
+    def ps_query_conv(self, M, N, K, stride=1):
+        """(tile_cfg, splitk) of the CONV-MODE pre-split tile (csrc/igemm_ps.hip: igemm_psc_kernel, F16X2 only) for a 3x3
+        convolution of this shape, at the plan-policy row count -- or None.  Listed in the "ps_f16x2" section under the conv key
+        (a_mode 1) when the direct convolution on pre-split operands was measured faster in the step than the shape's other route
+        (the in-register-split implicit GEMM for the 160-channel convolutions, Winograd GEMM + both transforms for the wide ones:
+        profiles/r05_ab_conv_ps.txt).  LDMK_PSC=0 turns the route off; LDMK_PSC_FORCE="cfg,splitk" forces it for every eligible
+        convolution (A/B runs)."""
+        if not ps_enabled() or self.h2_flag is None or os.environ.get("LDMK_PSC", "1") == "0":
+            return None
+        forced = os.environ.get("LDMK_PSC_FORCE")
+        if forced:
+            cfg, sk = (int(v) for v in forced.split(","))
+            cin32 = K // (9 * 32)
+            while cin32 % sk:
+                sk -= 1
+            return cfg, sk
+        m = M
+        if self.pin is not None and self.pin[0] != self.pin[1]:
+            m = max(1, M * self.pin[0] // self.pin[1])
+        return ps_plan(f"{N},{K},{L.A_CONV3X3},0,0,1" + ("" if stride == 1 else f",s{stride}u0"), m, h2=True, max_ratio=2.0)
+
     def gn_conv(self, x0, x1, h, w, gamma, beta, eps, wp, u, bias, batch_vec=None, bv_ld=0, residual=None, out=None,
-                stats=False, wf=None, u_ps=None):
+                stats=False, wf=None, u_ps=None, wp_ps=None):
         """GroupNorm(32)+SiLU of (the concat of) x0 | x1, then the 3x3 convolution with packed weights `wp` (implicit GEMM)
-        or, when `u` (ops.pack_winograd) is given and the problem is large enough, through Winograd."""
+        or, when `u` (ops.pack_winograd) is given and the problem is large enough, through Winograd -- or, `wp_ps`
+        (ops.pack_wps(wp, h2=True)) given and the shape listed (ps_query_conv), as a direct convolution on the conv-mode
+        pre-split tile: the GroupNorm-apply pass writes the activation once in the PS layout and the nine taps are LDS-DMA
+        address sets into it."""
         pg, n, ops, p_ = self.pg, self.n, self.ops, self.ptr
         c0 = x0.shape[-1]
         c1 = 0 if x1 is None else x1.shape[-1]
         cin = c0 + c1
+        cout_ = wp.shape[1]
+        plan_c = (self.ps_query_conv(n * h * w, cout_, 9 * cin)
+                  if (wp_ps is not None and cin % 32 == 0 and cout_ % 32 == 0 and c0 % 8 == 0 and c1 % 8 == 0) else None)
+        if plan_c is not None:
+            hf = self.h2_flag
+            coef = self.gn(x0, x1, h * w, gamma, beta, eps)
+            y_ps = pg.alloc_ps(n * h * w, cin)
+            pg.add("ldmk_gn_apply_ps_h2", p_(x0), c0, p_(x1), c1, p_(coef), p_(y_ps), n, h * w, 1, p_(hf))
+            self.release(coef)
+            if out is None:
+                out = pg.alloc(n, h, w, cout_)
+            a = ops.make_igemm_args(n * h * w, cout_, 9 * cin, None, cin, wp, out, cout_, h * w, conv=(h, w, h, w, 1, 1, 0), bias=bias,
+                                    residual=residual, a_ps=y_ps, w_ps=wp_ps, range_flag=hf)
+            if batch_vec is not None:
+                a.batch_vec, a.batch_vec_ld = self.ptr(batch_vec), bv_ld
+            a._algo_flops = 2.0 * (n * h * w) * cout_ * (9 * cin)
+            self._maybe_stats(a, out.view(-1, cout_), h * w, stats)
+            pg.igemm_ps(a, *plan_c)
+            pg.release(y_ps)
+            return out
         if u is None or not self.winograd_ok(cin, h, w):
             y = self.gn_act(x0, x1, h * w, gamma, beta, eps)
             res = self.conv(y.view(n, h, w, cin), None, wp, bias, h, w, batch_vec=batch_vec, bv_ld=bv_ld, residual=residual,

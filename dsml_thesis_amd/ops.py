@@ -108,6 +108,36 @@ def gn_apply(x0, x1, coef, n, hw, silu=True, out=None):
     return out
 
 
+def gn_apply_ps(x0, x1, coef, n, hw, h2_flag, silu=True, out=None):
+    """ldmk_gn_apply with the result written once in the F16X2 form of the PS layout ([n hw][c0 + c1]): the A operand of a 3x3
+    convolution on a conv-mode pre-split tile (conv3x3_ps)."""
+    c0 = x0.shape[-1]
+    c1 = 0 if x1 is None else x1.shape[-1]
+    if out is None:
+        out = ps_empty(n * hw, c0 + c1, 1, x0.device, h2=True)
+    L.call("ldmk_gn_apply_ps_h2", _ptr(x0), c0, _ptr(x1), c1, _ptr(coef), _ptr(out), n, hw, 1 if silu else 0, _ptr(h2_flag), stream())
+    return out
+
+
+def conv3x3_ps(y_ps, n, h, w_, cin, wp, wps, range_flag, bias=None, stride=1, pad_lo=1, batch_vec=None, residual=None, out=None,
+               tile_cfg=27, splitk=1, splitk_ws=None, stats_out=None):
+    """3x3 convolution on a conv-mode pre-split tile (csrc/igemm_ps.hip: igemm_psc_kernel): y_ps = the (normalised) input
+    [n h w][cin] in the F16X2 PS layout (gn_apply_ps / pack_ps), wp = pack_conv3x3 weights [9 cin][cout], wps = pack_wps(wp, h2=True)."""
+    cout = wp.shape[1]
+    oh = (h + 2 * pad_lo - 3) // stride + 1 if pad_lo == 1 else (h + 1 - 3) // stride + 1
+    ow = (w_ + 2 * pad_lo - 3) // stride + 1 if pad_lo == 1 else (w_ + 1 - 3) // stride + 1
+    if out is None:
+        out = torch.empty(n, oh, ow, cout, device=wp.device, dtype=torch.float32)
+    a = make_igemm_args(n * oh * ow, cout, 9 * cin, None, cin, wp, out, cout, oh * ow, conv=(h, w_, oh, ow, stride, pad_lo, 0), bias=bias,
+                        batch_vec=batch_vec, batch_vec_ld=0 if batch_vec is None else batch_vec.stride(0), residual=residual,
+                        tile_cfg=tile_cfg, splitk=splitk, splitk_ws=splitk_ws, a_ps=y_ps, w_ps=wps, range_flag=range_flag)
+    if stats_out is not None:
+        a.stats_out = stats_out.data_ptr()
+        a._keep = a._keep + (stats_out,)
+    igemm(a)
+    return out
+
+
 def ln_stats(x2d, eps=1e-5, out=None, split=None):
     """(mean, rstd) per row; split: a bf16 tensor [3][rows][ld] that receives the rows' exact three-way split (a_split operand)."""
     rows, c = x2d.shape

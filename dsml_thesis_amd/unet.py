@@ -256,6 +256,10 @@ def pack_gemm_copies(P, unfolded=False):
                     P[k + "#p2"] = ops.pack_wps(P[k], h2=True)
                 elif tail in ("c1#wg", "c2#wg", "w#up") and P[k].shape[1] % 32 == 0 and P[k].shape[2] % 32 == 0:
                     P[k + "#p2"] = ops.pack_wps(P[k], batch=P[k].shape[0], h2=True)
+                elif tail in ("c1", "c2") and P[k].dim() == 2 and P[k].shape[0] % (9 * 32) == 0 and P[k].shape[1] % 32 == 0:
+                    # the ResBlock convolutions for the conv-mode pre-split tile (engine.NetBuilder.ps_query_conv): pack_conv3x3's
+                    # [9 C_in][C_out] matrix is already in the tile's K order (32-channel chunk major, tap minor)
+                    P[k + "#pc2"] = ops.pack_wps(P[k], h2=True)
 
 
 def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_in, context_dim, unfolded=False, ln_flag=None):
@@ -755,7 +759,8 @@ class UNetModel(nn.Module):
             with nb_.site(prefix + "in_layers"):
                 h1 = nb_.gn_conv(x0, x1, h, w, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5,
                                  P[prefix + "c1"], P.get(prefix + "c1#wg"), sd[prefix + "in_layers.2.bias"], batch_vec=bv,
-                                 bv_ld=self._emb_total, stats=True, wf=P.get(prefix + "c1#f"), u_ps=P.get(prefix + "c1#wg" + psfx()))
+                                 bv_ld=self._emb_total, stats=True, wf=P.get(prefix + "c1#f"), u_ps=P.get(prefix + "c1#wg" + psfx()),
+                                 wp_ps=P.get(prefix + "c1#pc2"))
             g2, b2 = sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"]
             if m.cin != m.cout:
                 x0r = x0.reshape(n * hw, -1)
@@ -765,13 +770,13 @@ class UNetModel(nn.Module):
                 with nb_.site(prefix + "out_layers"):
                     out = nb_.gn_conv(h1, None, h, w, g2, b2, 1e-5, P[prefix + "c2"], P.get(prefix + "c2#wg"),
                                       sd[prefix + "out_layers.3.bias"], residual=skip, out=skip.view(n, h, w, m.cout), stats=True,
-                                      wf=P.get(prefix + "c2#f"), u_ps=P.get(prefix + "c2#wg" + psfx()))
+                                      wf=P.get(prefix + "c2#f"), u_ps=P.get(prefix + "c2#wg" + psfx()), wp_ps=P.get(prefix + "c2#pc2"))
             else:
                 assert x1 is None
                 with nb_.site(prefix + "out_layers"):
                     out = nb_.gn_conv(h1, None, h, w, g2, b2, 1e-5, P[prefix + "c2"], P.get(prefix + "c2#wg"),
                                       sd[prefix + "out_layers.3.bias"], residual=x0, stats=True, wf=P.get(prefix + "c2#f"),
-                                      u_ps=P.get(prefix + "c2#wg" + psfx()))
+                                      u_ps=P.get(prefix + "c2#wg" + psfx()), wp_ps=P.get(prefix + "c2#pc2"))
             nb_.release(h1)
             return out
 

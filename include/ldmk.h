@@ -207,6 +207,15 @@ int ldmk_pack_ps_h2(const float* src, int rows, int k, long long row_stride, lon
                     int scale_exp, int* range_flag, void* dst, void* stream);
 int ldmk_ln_stats_ps_h2(const float* x, int rows, int c, float eps, float* stats, void* dst, float guard, int* flag, int* range_flag,
                         void* stream);
+/* ldmk_gn_apply (GroupNorm scale / shift [+ SiLU] of the channel concat x0 | x1, openaimodel.py:201-203,225-227) with its result
+ * written ONCE as the [n hw][c0 + c1] matrix in the F16X2 form of the PS layout: the A operand of a 3x3 convolution on a conv-mode
+ * pre-split tile -- ldmk_igemm with a_mode = LDMK_A_CONV3X3, a_ps = this buffer (c0 = the channel count, c1 = 0, a_tf = NONE),
+ * w_ps = ldmk_pack_ps_h2 of the ldmk_pack_conv3x3 weights as X[N][K = 9 C], compute = LDMK_COMPUTE_F16X2 on tile_cfg 23 / 24 / 26 /
+ * 27, splitk a divisor of C / 32.  The nine taps are per-lane LDS-DMA addresses into this one tensor (the halo reads zeros): bitwise
+ * the result of tile_cfg 5 / 1 in LDMK_COMPUTE_F16X2 on the fp32 ldmk_gn_apply output at equal splitk.  c0, c1 multiples of 8, their
+ * sum of 16. */
+int ldmk_gn_apply_ps_h2(const float* x0, int c0, const float* x1, int c1, const float* coef, void* y_ps, int n, int hw, int silu,
+                        int* range_flag, void* stream);
 
 /* w[K][ldb] fp32 (row-major, as ldmk_igemm reads it with b_trans = 0; `batch` matrices w_bstride floats apart) -> the three
  * bf16 images [batch][3][N][ld_out] of its exact three-way split, transposed so that every output column's K run is

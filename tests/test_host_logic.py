@@ -164,11 +164,13 @@ def test_one_plan_file_with_a_section_per_arithmetic(monkeypatch, tmp_path):
     for sec in ("ps_bf16x3", "ps_f16x2"):
         for key, rows in engine.table(sec).items():
             n, k, mode, tf, epi, nb = (int(v) for v in key.split(",")[:6])
-            assert mode == 0 and k % 32 == 0 and n % 32 == 0
+            assert mode in (0, 1) and k % 32 == 0 and n % 32 == 0
             for m, cfg, sk in rows:
                 assert 23 <= cfg <= 33 and 1 <= sk <= k // 32 and (epi != 1 or (cfg in (25, 28, 32, 33) and sk == 1)), (key, cfg, sk)
+                if mode == 1:      # a 3x3 convolution on the conv-mode tile: F16X2 only, four tile shapes, K split on 32-channel chunks
+                    assert sec == "ps_f16x2" and cfg in (23, 24, 26, 27) and k % (9 * 32) == 0 and (k // (9 * 32)) % sk == 0 and tf == 0 and epi == 0
     # nearest row count, whatever the distance
-    rest = next(iter(engine.table("ps_f16x2")))
+    rest = next(k for k in engine.table("ps_f16x2") if k.split(",")[2] == "0")
     assert engine.ps_plan(rest, 3, h2=True) is not None and engine.ps_plan(rest, 1 << 22, h2=True) is not None
     assert engine.ps_plan("31,64,0,0,0,1", 4096, h2=True) is None
     flat = tmp_path / "flat.json"
