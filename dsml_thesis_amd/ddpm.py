@@ -204,9 +204,24 @@ class LatentDiffusion(_Base):
         script runs inside this scope.  The swap writes through the parameters (LitEma.copy_to / restore), so the
         kernel-layout weight copies are rebuilt on the next forward, inside the scope and again after it."""
         swapped = bool(self.use_ema)
+        unet = self.model.diffusion_model
         if swapped:
+            # name both weight sets for the UNet (UNetModel.adopt_weights): the kernel-layout copies, launch programs and captured
+            # graphs of each are built once and swapped by reference afterwards -- the copies below still write through the
+            # parameters, so everything that reads them (state_dict, the trainer) sees what the reference's scope shows
+            sig, cur = unet._signature(), getattr(unet, "_weight_token", None)
+            packed_is_current = unet._packed is not None and unet._pack_sig == sig
+            if packed_is_current and cur is not None and cur[0] == "train":
+                train_tok = cur                          # the set in use is the (unchanged) training set an earlier scope named
+            else:
+                train_tok = ("train", sig)               # new training weights (first scope, or an optimizer step since)
+                if packed_is_current:
+                    unet._weight_token = train_tok
+            ema_tok = ("ema", tuple((b.data_ptr(), b._version) for b in self.model_ema.buffers()))
             self.model_ema.store(self.model.parameters())
             self.model_ema.copy_to(self.model)
+            if next(unet.parameters()).is_cuda:
+                unet.adopt_weights(ema_tok)
             if context is not None:
                 print(f"{context}: Switched to EMA weights")
         try:
@@ -214,6 +229,8 @@ class LatentDiffusion(_Base):
         finally:
             if swapped:
                 self.model_ema.restore(self.model.parameters())
+                if next(unet.parameters()).is_cuda:
+                    unet.adopt_weights(train_tok)
                 if context is not None:
                     print(f"{context}: Restored training weights")
 

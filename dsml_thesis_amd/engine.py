@@ -101,11 +101,11 @@ def table(section):
     return t
 
 
-# How far (as a ratio of row counts) a tuned plan may be carried.  Every plan of a bucket is LEGAL for every M (the split depth is
-# bounded by K and the even-tile rule by the epilogue, both part of the key), so this is a performance rule only.  Rounds 1-4 used
-# 2: a 64x64x4 job of 2-7 samples then found no split-arithmetic plan at all and silently ran the f32 program (-44 %).  Round 5
-# carries the nearest tuned plan whatever the distance (A/B against the f32 fall-back: profiles/r05_plan_coverage.txt);
-# LDMK_PLAN_MAX_RATIO=2 restores the old rule.
+# How far (as a ratio of row counts) a tuned plan may be carried when nothing nearer exists (see choose()).  Every plan of a bucket
+# is LEGAL for every M (the split depth is bounded by K and the even-tile rule by the epilogue, both part of the key), so this is
+# a performance rule only.  Rounds 1-4 stopped at 2: jobs far from the tuned batches (16 and 128) then found no split-arithmetic
+# plan and silently ran the f32 program.  Round 5 carries the nearest tuned plan whatever the distance when no section holds a near
+# one (A/B: profiles/r05_plan_coverage.txt); LDMK_PLAN_MAX_RATIO=2 restores the old rule.
 PLAN_MAX_RATIO = float(os.environ.get("LDMK_PLAN_MAX_RATIO", "0")) or None
 # direct 3x3 convolutions without a table entry run in F16X2 from this K (= 9 C_in) up, on their f32 plan's tile (Program.plan)
 H2_CONV_MIN_K = 1440 if os.environ.get("LDMK_H2_CONV_RULE", "1") != "0" else (1 << 30)
@@ -123,6 +123,30 @@ def lookup(section, rest, m, max_ratio=None):
     if lim is not None and max(best[0], m) > lim * min(best[0], m):
         return None
     return best[1], best[2]
+
+
+NEAR_RATIO = 2.0
+# the job batches the split-arithmetic sections were swept at (tools/autotune.py --x3 / --h2, tools/ps_bench.py, tools/conv_ps_bench.py:
+# both latent sizes); the f32 section additionally holds batches 1-128
+TUNED_JOB_BATCHES = (16, 128)
+
+
+def far_from_tuned(job_batch):
+    """True when a job of this many samples is more than NEAR_RATIO away from every batch the split-arithmetic plans were measured
+    at: its shapes then have no near entry in those sections, and Program.plan() carries the nearest one whatever the distance
+    (Program.far_plans) instead of falling back to the f32 program.  Near a tuned batch the sections are complete for the job -- a
+    shape missing from them LOST its sweep there -- and only near entries count, as in rounds 1-4."""
+    return all(max(job_batch, b) > NEAR_RATIO * min(job_batch, b) for b in TUNED_JOB_BATCHES)
+
+
+def choose(section, rest, m, far=False):
+    """The plan `section` offers for shape `rest` at m rows: the entry within NEAR_RATIO of a tuned row count, or -- far: the job
+    is far from every tuned batch (far_from_tuned) -- the nearest entry at any distance (64x64x4 at B = 48: 955 -> 1097
+    sample-steps/s, 32x32x3 at B = 5 / 7: +5 / +14 %, profiles/r05_plan_coverage.txt)."""
+    p = lookup(section, rest, m, NEAR_RATIO)
+    if p is None and far:
+        p = lookup(section, rest, m)
+    return p
 
 
 def _rest(a, m):
@@ -149,25 +173,26 @@ def ps_h2_table():
     return table("ps_f16x2")
 
 
-def tuned_plan(a, m):
+def tuned_plan(a, m, far=False):
     """f32 plan of the tuned shape with the same (N, K, prologue, epilogue) and the closest row count, or None (the C++ heuristic
     decides)."""
-    return lookup("f32", _rest(a, m), m)
+    return choose("f32", _rest(a, m), m, far)
 
 
-def x3_plan(a, m):
+def x3_plan(a, m, far=False):
     """(cfg, splitk) of the bf16x3 plan for this shape, or None: only shapes measured faster in this arithmetic are listed."""
-    return lookup("bf16x3", _rest(a, m), m)
+    return choose("bf16x3", _rest(a, m), m, far)
 
 
-def h2_plan(a, m):
-    return lookup("f16x2", _rest(a, m), m)
+def h2_plan(a, m, far=False):
+    return choose("f16x2", _rest(a, m), m, far)
 
 
-def ps_plan(rest, m, h2=False, max_ratio=None):
+def ps_plan(rest, m, h2=False, max_ratio=None, far=False):
     """(cfg, splitk) of the pre-split plan for the shape key `rest` ("N,K,mode,tf,epi,batch") at m rows, or None.  h2: the section
     of the F16X2 form."""
-    return lookup("ps_f16x2" if h2 else "ps_bf16x3", rest, m, max_ratio)
+    sec = "ps_f16x2" if h2 else "ps_bf16x3"
+    return lookup(sec, rest, m, max_ratio) if max_ratio is not None else choose(sec, rest, m, far)
 
 
 class ArithSites:
@@ -294,15 +319,16 @@ class Program:
         if (args.compute == L.COMPUTE_F32 and not args.b_trans and not args.raw_slabs and not sample_batch
                 and args.M > 0 and (x3_table() or h2_table())):
             h2_flag = getattr(self, "h2_flag", None)
-            hp = h2_plan(args, args.M) if h2_flag is not None else None       # a plan measured in the F16X2 arithmetic itself
-            xp = hp if hp is not None else x3_plan(args, args.M)
+            far = bool(getattr(self, "far_plans", False))      # the job is far from every tuned batch: carry the nearest plan (choose)
+            hp = h2_plan(args, args.M, far) if h2_flag is not None else None       # a plan measured in the F16X2 arithmetic itself
+            xp = hp if hp is not None else x3_plan(args, args.M, far)
             if xp is None and h2_flag is not None and args.a_mode == L.A_CONV3X3 and args.K >= H2_CONV_MIN_K:
                 # A 3x3 convolution nobody measured in a split arithmetic (the tables hold the shapes of the B = 16 / 128 jobs; at
                 # other batches the low-resolution convolutions leave the Winograd route and show up as direct ones with
                 # K = 9 C_in of 2880-11520): long-K implicit GEMMs are matrix-bound, where three fp16 MFMAs per product beat eight
                 # f32 ones on every tile -- they take the F16X2 arithmetic on the tile and K split of their f32 plan
                 # (A/B at 64x64x4 B = 2 and 32x32x3 B = 5 / 7: profiles/r05_plan_coverage.txt; LDMK_H2_CONV_RULE=0 turns it off)
-                fp = tuned_plan(args, args.M)
+                fp = tuned_plan(args, args.M, far)
                 if fp is None:
                     c_, k_ = C.c_int(0), C.c_int(0)
                     keep = (args.splitk_ws, args.splitk_ws_elems)
@@ -347,7 +373,7 @@ class Program:
                 args.compute, args.w_split, args.w_split_ld, args.w_split_bstride = L.COMPUTE_F32, 0, 0, 0
                 args.w_scale_exp, args.range_flag = 0, 0
         # (a batch that is not per sample -- the 16 transform positions of a Winograd convolution -- is part of the plan key)
-        tuned = tuned_plan(args, args.M) if not sample_batch and args.M > 0 else None
+        tuned = tuned_plan(args, args.M, bool(getattr(self, "far_plans", False))) if not sample_batch and args.M > 0 else None
         if tuned is not None and tuned[0] > 6:
             # a row-GEMM wave tile (7..12, never splits K) or a slab-GEMM shape (13..20, small row counts): legal only with
             # the fragment-order weight copy and when the tile divides this problem (per-sample operands need
@@ -739,7 +765,8 @@ class NetBuilder:
         if self.pin is not None and self.pin[0] != self.pin[1] and per_sample:
             m = max(1, M * self.pin[0] // self.pin[1])
         # (a program in the F16X2 arithmetic has its own table: its operands are two fp16 planes, not three bf16 ones)
-        return ps_plan(f"{N},{K},{L.A_ROWS},{tf},{epi},{max(1, batch)}", m, h2=getattr(self.pg, "h2_flag", None) is not None)
+        return ps_plan(f"{N},{K},{L.A_ROWS},{tf},{epi},{max(1, batch)}", m, h2=getattr(self.pg, "h2_flag", None) is not None,
+                       far=bool(getattr(self.pg, "far_plans", False)))
 
     def lin_ps(self, plan, M, K, a_ps, wp, w_ps, bias, rows_per_sample, out=None, out_ps=None, geglu=False, stats=False, **kw):
         """Linear on a pre-split tile: a_ps = the [M][K] input in the PS layout, w_ps = ops.pack_wps(wp).  `out` None with out_ps

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
-from .engine import ArithSites, NetBuilder, Program, split_enabled as engine_split_enabled, ps_enabled as engine_ps_enabled, f16x2_enabled
+from .engine import ArithSites, NetBuilder, Program, far_from_tuned, split_enabled as engine_split_enabled, ps_enabled as engine_ps_enabled, f16x2_enabled
 
 # LayerNorm is folded algebraically through the Linear behind it (LDMK_TF_LAYERNORM_FOLDED): exact for well-conditioned rows,
 # but it subtracts mean * colsum(W') from x W' in fp32, so rows whose |mean| is many standard deviations lose accuracy
@@ -704,6 +704,31 @@ class UNetModel(nn.Module):
         self._pack_sig = self._signature()
         self._programs = {}
         self._ctx_sig = None
+        self._weight_token = None           # (adopt_weights names the set again right after its own call)
+
+    # ---- packed-weight sets by name: the EMA swap without the re-pack -------------------------------------------
+    def adopt_weights(self, token):
+        """Tell the model WHICH weights its parameters hold right now (any hashable token: LatentDiffusion.ema_scope passes
+        ('ema', version of the shadow buffers) on entry and ('train', version of the stored weights) on exit).  The first time a
+        token is seen the kernel-layout copies are packed from the parameters and kept under it -- with their launch programs and
+        captured graphs; the next time they are simply put back, so `with model.ema_scope(): sample(...)` pays for the ~18 bytes per
+        parameter of weight forms, the program builds and the graph captures ONCE, not on every entry and every exit.  At most two
+        sets are kept (the one in use and the previous one).  The caller vouches that equal tokens mean equal values; parameters
+        written without a token (an optimizer step, load_state_dict) are still caught by the version check in program()."""
+        sets = self.__dict__.setdefault("_weight_sets", {})
+        cur = getattr(self, "_weight_token", None)
+        if cur is not None and self._packed is not None and cur != token:
+            sets[cur] = (self._packed, self._sd, self._programs, self._emb_off, self._emb_total, self._ln_flag, self.ln_unfolded)
+        hit = sets.pop(token, None)
+        if hit is not None and hit[6] == self.ln_unfolded:
+            self._packed, self._sd, self._programs, self._emb_off, self._emb_total, self._ln_flag, _ = hit
+            self._ctx_sig = None
+        else:
+            self.pack_weights()
+        self._pack_sig = self._signature()
+        self._weight_token = token
+        while len(sets) > 1:                      # keep the set in use + one other
+            sets.pop(next(iter(sets)))
 
     def _walk(self):
         for i, blk in enumerate(self.input_blocks):
@@ -721,6 +746,7 @@ class UNetModel(nn.Module):
         dev = next(self.parameters()).device
         pg = Program(dev)
         pg.h2_flag = None          # (set per site by NetBuilder.site: engine.Program.plan runs a shape in F16X2 while it is a flag word)
+        pg.far_plans = far_from_tuned(policy_n)      # a job far from every tuned batch carries the nearest tuned plans (engine.choose)
         mc = self.model_channels
         emb_ch = 4 * mc
         cx = self.in_channels - c_concat
@@ -872,6 +898,8 @@ class UNetModel(nn.Module):
                 if self._ln_flag is not None:
                     self._ln_flag.zero_()       # (statistics of that run may be those of saturated operands: the repeat decides afresh)
                 self._programs.clear()
+                for st_ in self.__dict__.get("_weight_sets", {}).values():
+                    st_[2].clear()              # (the stored weight sets' programs were planned with the old denials too)
                 self.generation += 1
                 return True
             self._h2_passes = 0
@@ -880,7 +908,10 @@ class UNetModel(nn.Module):
                           "form (LayerNorm through the product) loses accuracy on them -- switching this model to the unfolded "
                           "prologue (LDMK_LN_UNFOLDED=1 starts there)", RuntimeWarning, stacklevel=3)
             self.ln_unfolded = True
+            tok = getattr(self, "_weight_token", None)
+            self.__dict__.get("_weight_sets", {}).clear()
             self.pack_weights()
+            self._weight_token = tok
             return True
         return False
 
@@ -894,6 +925,8 @@ class UNetModel(nn.Module):
         if self._sites is not None and not names <= self._sites.denied:
             self._sites.denied |= names
             self._programs.clear()
+            for st_ in self.__dict__.get("_weight_sets", {}).values():
+                st_[2].clear()
             self.generation += 1
 
     def arithmetic_status(self):

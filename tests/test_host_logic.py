@@ -140,9 +140,13 @@ def test_tuned_plan_table_is_legal_and_nearest():
     assert engine.tuned_plan(a, 65536) == engine.tuned_plan(a, 65536)
     near = engine.tuned_plan(a, 57344)            # batch 14: between the tuned 49152 and 65536 buckets
     assert near in (engine.tuned_plan(a, 49152), engine.tuned_plan(a, 65536))
-    # far from anything tuned: the nearest tuned plan is carried (round 5; rounds 1-4 gave up beyond a factor 2, which left
-    # whole batch ranges without a split-arithmetic plan) -- still a pure function of the shape
-    assert engine.tuned_plan(a, 7) == engine.tuned_plan(a, min(r[0] for r in table["320,2880,1,0,0,1"]))
+    # far from anything tuned: no plan (the C++ heuristic decides) -- unless the JOB is far from every tuned batch
+    # (engine.far_from_tuned: Program.far_plans), when the nearest tuned plan is carried whatever the distance (round 5; rounds
+    # 1-4 always gave up beyond a factor 2, which left whole batch ranges without a split-arithmetic plan)
+    assert engine.tuned_plan(a, 7) is None
+    assert engine.tuned_plan(a, 7, far=True) == engine.tuned_plan(a, min(r[0] for r in table["320,2880,1,0,0,1"]))
+    assert [engine.far_from_tuned(b) for b in (1, 2, 4, 7, 8, 16, 32, 33, 48, 63, 64, 128, 256, 257)] == \
+        [True, True, True, True, False, False, False, True, True, True, False, False, False, True]
     a.N = 321
     assert engine.tuned_plan(a, 65536) is None    # a shape nobody tuned: the C++ heuristic decides
 
@@ -171,7 +175,8 @@ def test_one_plan_file_with_a_section_per_arithmetic(monkeypatch, tmp_path):
                     assert sec == "ps_f16x2" and cfg in (23, 24, 26, 27) and k % (9 * 32) == 0 and (k // (9 * 32)) % sk == 0 and tf == 0 and epi == 0
     # nearest row count, whatever the distance
     rest = next(k for k in engine.table("ps_f16x2") if k.split(",")[2] == "0")
-    assert engine.ps_plan(rest, 3, h2=True) is not None and engine.ps_plan(rest, 1 << 22, h2=True) is not None
+    assert engine.ps_plan(rest, 3, h2=True) is None and engine.ps_plan(rest, 3, h2=True, far=True) is not None
+    assert engine.ps_plan(rest, 1 << 22, h2=True, far=True) is not None
     assert engine.ps_plan("31,64,0,0,0,1", 4096, h2=True) is None
     flat = tmp_path / "flat.json"
     flat.write_text(json.dumps({"4096,64,64,0,0,0,1": [27, 1]}))

@@ -390,7 +390,7 @@ def test_first_stage_split_arithmetic_golden(monkeypatch):
     it -- against the same reference fixtures and bounds as the f32 matrix-core form; the codebook indices stay bit-exact."""
     from dsml_thesis_amd import engine, lib as L
     from dsml_thesis_amd.engine import NetBuilder
-    monkeypatch.setattr(engine, "x3_plan", lambda a, m: (1, 1) if a.epi == L.EPI_GEGLU else (5, 1))
+    monkeypatch.setattr(engine, "x3_plan", lambda a, m, far=False: (1, 1) if a.epi == L.EPI_GEGLU else (5, 1))
     for wino in (False, True):
         if wino:
             monkeypatch.setattr(NetBuilder, "WINO_MIN_TILES", 1)
@@ -533,9 +533,18 @@ def test_ema_scope_swaps_weights_and_repacks(fr):
         assert not getattr(pg, "small_route", False)
         from dsml_thesis_amd import lib as L
         assert sum(1 for cl in pg.calls if cl[3] == "ldmk_igemm" and cl[2].compute in (L.COMPUTE_BF16X3, L.COMPUTE_F16X2)) >= 40
-        with fr.ema_scope():
-            ema16 = fr.apply_model(x, t, c[:1])
-        again16 = fr.apply_model(x, t, c[:1])
+        # the second scope re-packs NOTHING: both weight sets (kernel layouts, programs, graphs) are kept under their names and
+        # swapped by reference (UNetModel.adopt_weights) -- the shadow and the stored weights have not changed since
+        packs = []
+        orig = unet.pack_weights
+        unet.pack_weights = lambda: (packs.append(1), orig())[1]
+        try:
+            with fr.ema_scope():
+                ema16 = fr.apply_model(x, t, c[:1])
+            again16 = fr.apply_model(x, t, c[:1])
+        finally:
+            del unet.pack_weights
+        assert not packs, f"{len(packs)} re-packs in a repeated ema_scope"
     finally:
         unet.policy_batch = None
     close(ema16, ref, 1.5e-4, 1.5e-4)
@@ -575,7 +584,7 @@ def test_northstar_trajectory_in_the_split_arithmetic(monkeypatch):
     launch modes equal bit for bit."""
     from dsml_thesis_amd import engine, lib as L, synth
     from dsml_thesis_amd.ddim import DDIMSampler
-    monkeypatch.setattr(engine, "x3_plan", lambda a, m: (1, 1) if a.epi == L.EPI_GEGLU else (5, 1))
+    monkeypatch.setattr(engine, "x3_plan", lambda a, m, far=False: (1, 1) if a.epi == L.EPI_GEGLU else (5, 1))
     g = golden("g11_northstar.npz")
     m = make_fr_model(gain=0.25, unet=synth.NS_UNET, vq=synth.VQ_F4_256)
     m.model.diffusion_model.policy_batch = 16

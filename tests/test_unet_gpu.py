@@ -196,7 +196,7 @@ def test_unet_split_arithmetic_routes_against_the_reference_fixtures(monkeypatch
     assert n3 >= 40 and "ldmk_attn_self_x3" in names and {"ldmk_attn_self_h2", "ldmk_attn_self_h2_ps", "ldmk_attn_self_h2_tiles"} & set(names) and "ldmk_attn_self" not in names, (n3, ng)
     close(eps_a, g["fr_eps"], 3e-5, 3e-5)
     # (b) everything eligible
-    monkeypatch.setattr(engine, "x3_plan", lambda a, m: (1, 1) if a.epi == L.EPI_GEGLU else (5, 1))
+    monkeypatch.setattr(engine, "x3_plan", lambda a, m, far=False: (1, 1) if a.epi == L.EPI_GEGLU else (5, 1))
     eps_b, n3b, ngb, _ = run()
     assert n3b > n3 and n3b >= ngb - 4, (n3b, ngb)
     close(eps_b, g["fr_eps"], 3e-5, 3e-5)

@@ -76,7 +76,8 @@ def main():
             u_ps = ops.pack_wps(u, batch=16, h2=True)
         gamma, beta, bias = torch.ones(cin, device=dev), torch.zeros(cin, device=dev), torch.zeros(cout, device=dev)
         bv = torch.randn(n, cout, device=dev, generator=g)
-        routes = [("default", None)] + [(f"psc {c},{k}", f"{c},{k}") for c in (23, 24, 26, 27) for k in ((1, 2) if n * h * h <= 8192 else (1,))]
+        ks = [k for k in (1, 2, 4, 5) if (cin // 32) % k == 0] if n * h * h <= 16384 else [1]
+        routes = [("default", None)] + [(f"psc {c},{k}", f"{c},{k}") for c in (23, 26, 27) for k in ks]
         res = {}
         for name, force in routes:
             if force is None:

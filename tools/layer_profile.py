@@ -46,7 +46,8 @@ def dump(latent, batch, path, graph=False):
     torch.cuda.synchronize()
 
 
-KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "igemm_ws_kernel", "igemm_ps_kernel", "igemm_pw_kernel", "rgemm_kernel", "sgemm_kernel"), "ldmk_post": ("post_",),
+KERNEL_OF = {"ldmk_igemm": ("igemm_kernel", "igemm_ws_kernel", "igemm_ps_kernel", "igemm_psc_kernel", "igemm_pw_kernel", "rgemm_kernel", "sgemm_kernel"), "ldmk_post": ("post_",),
+             "ldmk_gn_apply_ps_h2": ("gn_apply_ps_h2",),
              "ldmk_attn_self_small": ("attn_small",), "ldmk_conv3x3_out_small": ("conv3x3_out_small",), "ldmk_gn_finalize": ("gn_finalize",), "ldmk_gn_apply": ("gn_apply",),
              "ldmk_gn_partial": ("gn_partial",), "ldmk_ln_stats": ("ln_stats",), "ldmk_ln_stats_guard": ("ln_stats",), "ldmk_ln_stats_split": ("ln_stats",), "ldmk_ln_stats_ps": ("ln_stats_ps",), "ldmk_ln_stats_ps_h2": ("ln_stats_ps",), "ldmk_pack_ps": ("pack_ps",), "ldmk_attn_self": ("attn_self",), "ldmk_attn_self_x3": ("attn_x3",), "ldmk_attn_self_x3p": ("attn_kv_split",), "ldmk_attn_self_x3p_ps": ("attn_kv_split",), "ldmk_attn_self_h2": ("attn_kv_split_h2",), "ldmk_attn_self_h2_ps": ("attn_kv_split_h2",), "ldmk_attn_self_h2_tiles": ("attn_h2_fwd",),
              "ldmk_attn_cross": ("attn_cross",), "ldmk_dense_small": ("dense_small",),
@@ -95,7 +96,7 @@ def join(d):
             assert "post_gnapply" in last[i]["Kernel_Name"], last[i]["Kernel_Name"]
             d_ += dur(last[i])
             i += 1
-        if (c["name"] == "ldmk_igemm" and any(k in r["Kernel_Name"] for k in ("igemm_kernel", "igemm_ws_kernel", "igemm_ps_kernel", "igemm_pw_kernel", "sgemm_kernel"))
+        if (c["name"] == "ldmk_igemm" and any(k in r["Kernel_Name"] for k in ("igemm_kernel", "igemm_ws_kernel", "igemm_ps_kernel", "igemm_psc_kernel", "igemm_pw_kernel", "sgemm_kernel"))
                 and c.get("sk", 1) > 1 and not c.get("raw")):
             assert "igemm_reduce" in last[i]["Kernel_Name"], (c, last[i]["Kernel_Name"])
             c["main_us"] = d_
