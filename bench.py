@@ -35,6 +35,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # algorithmic work per sample-step (forward hooks on the reference, 2*MAC)
 GFLOP_STEP = {32: 46.011, 64: 230.051}
 GFLOP_IGEMM = {32: 24.318 + 15.122 + 2.726, 64: 97.297 + 60.421 + 10.905}   # conv3x3 + linear + conv1x1
+# algorithmic bytes of one step: the fp32 weights read once (627.0 MB) + the in / out of every ResBlock and
+# SpatialTransformer per sample (28 MB at 32x32x3, 111 MB at 64x64x4)
+ALGO_BYTES = {32: lambda b: int(627.0e6 + b * 28e6), 64: lambda b: int(627.0e6 + b * 111e6)}
 PEAK_F32_MFMA = 157.3  # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32, dense)
 PEAK_BF16_MFMA = 2516.6  # TFLOP/s dense = 16 x the f32 matrix rate (same guide: "1/16 of BF16 MFMA", ~2.5 PF)
 
@@ -660,16 +663,23 @@ def main():
         ach = fl_exec / (t_ig * 1e-3)
         fl_alg = algorithmic_gemm_flops(run.pg) * 1e-12           # the same layers in the reference's arithmetic
         t_tr = getattr(run, "winograd_transform_ms", 0.0)
-        traffic, tnote = None, None
-        for tname in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+        traffic, tnote, tfam = None, None, None
+        for tname in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(f"latent{a.latent}_b{a.batch}", {}).get("hbm_bytes_per_step")
+                    trec = json.load(open(tpath)).get(f"latent{a.latent}_b{a.batch}", {})
                 except Exception:
-                    traffic = None
+                    trec = {}
+                if trec.get("whole_step_bytes") is not None:       # round 5: every kernel family of the step (tools/pmc_traffic.py)
+                    traffic = trec["whole_step_bytes"]
+                    tfam = {k: round(v["bytes_per_step"]) for k, v in trec["families"].items()}
+                    tnote = (f"bytes per step over EVERY launch of the step, by kernel family in `traffic_by_family`; rocprofv3 --pmc "
+                             f"FETCH_SIZE(x2)+WRITE_SIZE passes of this command (profiles/{tname}); L2<->fabric, Infinity-Cache hits included")
+                    break
+                traffic = trec.get("hbm_bytes_per_step")
                 if traffic is not None:
-                    tnote = (f"bytes per step over the GEMM family, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE passes of this "
+                    tnote = (f"bytes per step over the GEMM family only, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE passes of this "
                              f"command (profiles/{tname}); L2<->fabric, Infinity-Cache hits included")
                     break
         t_x3, n_x3 = getattr(run, "x3_ms", 0.0), getattr(run, "x3_launches", 0)
@@ -696,6 +706,10 @@ def main():
         # matrix peak; with LDMK_SPLIT_BF16=0, executed fp32 FLOPs of the whole family against the f32 matrix peak
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_F32_MFMA, 4), "basis": "f32_mfma_executed", "traffic": traffic, "traffic_note": tnote,
+                           "traffic_by_family": tfam,
+                           # the step's algorithmic bytes (fp32 weights once per step + in/out of every block per sample)
+                           "algorithmic_bytes_per_step": ALGO_BYTES[a.latent](a.batch),
+                           "traffic_over_algorithmic": round(traffic / ALGO_BYTES[a.latent](a.batch), 2) if traffic else None,
                            "kernel": "ldmk::igemm_kernel<...> + ldmk::rgemm_kernel<...> (every Conv2d / Linear launch of the step)",
                            "flops_basis": "executed: sum of 2*M*N*K (x batch) over the step's GEMM launches -- what the matrix "
                                           "cores do.  The wide 3x3 convolutions run through Winograd F(2x2,3x3), which executes 4/9 "
