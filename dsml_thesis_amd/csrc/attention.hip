@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
 // Cross attention with a short context (L <= 128).  One wave per (query row, head-group): lane l
 // handles head l/ (64/hpw)...  Simple mapping: thread <-> (query, head); K/V of the sample's
 // context for that head are read through L1/L2 (tiny: L*C floats per sample).
+template <int D>
 __global__ __launch_bounds__(256) void attn_cross_kernel(const float* __restrict__ q, int ldq,
                                                          const float* __restrict__ k, const float* __restrict__ v,
                                                          int ldkv, float* __restrict__ out, int ldo, int tokens, int L,
@@ -286,37 +287,37 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(const float* __restrict
   const int h = (int)(idx % heads);
   const long long row = idx / heads;                 // sample*tokens + token
   const int b = (int)(row / tokens);
-  const float* qp = q + row * ldq + h * AT_D;
-  float qv[AT_D];
+  const float* qp = q + row * ldq + h * D;
+  float qv[D];
 #pragma unroll
-  for (int d = 0; d < AT_D; d += 4) {
+  for (int d = 0; d < D; d += 4) {
     float4 t = *reinterpret_cast<const float4*>(qp + d);
     qv[d] = t.x; qv[d + 1] = t.y; qv[d + 2] = t.z; qv[d + 3] = t.w;
   }
-  const float* kb = k + (long long)b * L * ldkv + h * AT_D;
-  const float* vb = v + (long long)b * L * ldkv + h * AT_D;
+  const float* kb = k + (long long)b * L * ldkv + h * D;
+  const float* vb = v + (long long)b * L * ldkv + h * D;
   float m = -INFINITY, l = 0.f;
-  float acc[AT_D];
+  float acc[D];
 #pragma unroll
-  for (int d = 0; d < AT_D; ++d) acc[d] = 0.f;
+  for (int d = 0; d < D; ++d) acc[d] = 0.f;
   for (int j = 0; j < L; ++j) {
     const float* kp = kb + (long long)j * ldkv;
     float s = 0.f;
 #pragma unroll
-    for (int d = 0; d < AT_D; ++d) s = fmaf(qv[d], kp[d], s);
+    for (int d = 0; d < D; ++d) s = fmaf(qv[d], kp[d], s);
     s *= scale;
     const float mn = fmaxf(m, s);
     const float corr = __expf(m - mn), pj = __expf(s - mn);
     l = l * corr + pj;
     const float* vp = vb + (long long)j * ldkv;
 #pragma unroll
-    for (int d = 0; d < AT_D; ++d) acc[d] = fmaf(pj, vp[d], acc[d] * corr);
+    for (int d = 0; d < D; ++d) acc[d] = fmaf(pj, vp[d], acc[d] * corr);
     m = mn;
   }
   const float inv = 1.0f / l;
-  float* op = out + row * ldo + h * AT_D;
+  float* op = out + row * ldo + h * D;
 #pragma unroll
-  for (int d = 0; d < AT_D; d += 4)
+  for (int d = 0; d < D; d += 4)
     *reinterpret_cast<float4*>(op + d) = make_float4(acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv);
 }
 
@@ -394,14 +395,28 @@ extern "C" int ldmk_attn_self_lse(const float* qkv, float* out, float* lse, int 
 
 extern "C" int ldmk_attn_cross(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo,
                                int n, int tokens, int ctx_len, int heads, float scale, void* stream) {
+  return ldmk_attn_cross_d(q, ldq, k, v, ldkv, out, ldo, n, tokens, ctx_len, heads, 32, scale, stream);
+}
+
+extern "C" int ldmk_attn_cross_d(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo,
+                                 int n, int tokens, int ctx_len, int heads, int d_head, float scale, void* stream) {
   LDMK_ENTER();
   using namespace ldmk;
   LDMK_REQUIRE(q && k && v && out && n > 0 && tokens > 0 && heads > 0, "ldmk_attn_cross: bad args");
   LDMK_REQUIRE(ctx_len >= 1 && ctx_len <= 128, "ldmk_attn_cross: ctx_len=%d outside [1,128]", ctx_len);
   LDMK_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldkv % 4 == 0, "ldmk_attn_cross: leading dims must be multiples of 4");
-  long long total = (long long)n * tokens * heads;
-  hipLaunchKernelGGL(attn_cross_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, ldq,
-                     k, v, ldkv, out, ldo, tokens, ctx_len, heads, scale, total);
+  const long long total = (long long)n * tokens * heads;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+#define LDMK_XA(D) hipLaunchKernelGGL(attn_cross_kernel<D>, grid, dim3(256), 0, st, q, ldq, k, v, ldkv, out, ldo, tokens, ctx_len, heads, scale, total)
+  switch (d_head) {
+    case 32: LDMK_XA(32); break;
+    case 40: LDMK_XA(40); break;
+    case 64: LDMK_XA(64); break;
+    case 80: LDMK_XA(80); break;
+    default: LDMK_REQUIRE(false, "ldmk_attn_cross: head width %d (built: 32, 40, 64, 80)", d_head);
+  }
+#undef LDMK_XA
   return check_launch("ldmk_attn_cross");
 }
 

@@ -525,6 +525,36 @@ __global__ void permute3_kernel(const float* __restrict__ src, float* __restrict
   }
 }
 
+// Attention heads that are not 32 wide (reference kwargs num_heads / num_head_channels, openaimodel.py:542-549): the flash kernels
+// are built for d = 32; other widths go through batched GEMMs on head-major copies.  gather: token rows [n tokens][ld] with the heads
+// side by side from column col0 -> [n heads][tokens][dp], the d columns of a head zero-padded to dp (a multiple of 32: exact for
+// q k^T, and the padded columns of p v are never read back); scatter: the inverse, first d columns of each head.
+__global__ void heads_gather_kernel(const float* __restrict__ src, int ld, int col0, float* __restrict__ dst, int tokens, int heads, int d,
+                                    int dp, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % dp);
+    long long r = i / dp;
+    const int t = (int)(r % tokens);
+    r /= tokens;
+    const int h = (int)(r % heads);
+    const long long b = r / heads;
+    dst[i] = j < d ? src[(b * tokens + t) * ld + col0 + h * d + j] : 0.f;
+  }
+}
+
+__global__ void heads_scatter_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld, int tokens, int heads, int d, int dp,
+                                     long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % d);
+    long long r = i / d;
+    const int h = (int)(r % heads);
+    r /= heads;
+    const int t = (int)(r % tokens);
+    const long long b = r / tokens;
+    dst[(b * tokens + t) * ld + h * d + j] = src[((b * heads + h) * tokens + t) * dp + j];
+  }
+}
+
 // conv weight OIHW [O][I][3][3] -> igemm K order [I/32][9][32][O] (channel-chunk major, tap minor)
 __global__ void pack_conv3x3_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int I, long long total) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -856,6 +886,24 @@ extern "C" int ldmk_vq_nearest(const float* z, const float* codebook, float* zq,
     default: LDMK_REQUIRE(false, "ldmk_vq_nearest: embed dim %d unsupported (3 or 4)", dim);
   }
   return check_launch("ldmk_vq_nearest");
+}
+
+extern "C" int ldmk_heads_gather(const float* src, int ld, int col0, float* dst, int n, int tokens, int heads, int d, int dp, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(src && dst && n > 0 && tokens > 0 && heads > 0 && d > 0 && dp >= d && col0 >= 0 && ld >= col0 + heads * d,
+               "ldmk_heads_gather: bad args (ld=%d col0=%d heads=%d d=%d dp=%d)", ld, col0, heads, d, dp);
+  const long long total = (long long)n * heads * tokens * dp;
+  hipLaunchKernelGGL(heads_gather_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, ld, col0, dst, tokens, heads, d, dp, total);
+  return check_launch("ldmk_heads_gather");
+}
+
+extern "C" int ldmk_heads_scatter(const float* src, float* dst, int ld, int n, int tokens, int heads, int d, int dp, void* stream) {
+  LDMK_ENTER();
+  LDMK_REQUIRE(src && dst && n > 0 && tokens > 0 && heads > 0 && d > 0 && dp >= d && ld >= heads * d,
+               "ldmk_heads_scatter: bad args (ld=%d heads=%d d=%d dp=%d)", ld, heads, d, dp);
+  const long long total = (long long)n * tokens * heads * d;
+  hipLaunchKernelGGL(heads_scatter_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, ld, tokens, heads, d, dp, total);
+  return check_launch("ldmk_heads_scatter");
 }
 
 extern "C" int ldmk_permute3(const float* src, float* dst, int d0, int d1, int d2, int p0, int p1, int p2, void* stream) {

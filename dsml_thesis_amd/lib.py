@@ -119,6 +119,9 @@ _SIGS = {
     "ldmk_attn_self_small": (C.c_int, [_fp, C.c_int, C.c_longlong, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
     "ldmk_attn_cross": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_float, _fp]),
+    "ldmk_attn_cross_d": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _fp]),
+    "ldmk_heads_gather": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_heads_scatter": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_softmax_rows": (C.c_int, [_fp, C.c_longlong, C.c_int, C.c_float, _fp]),
     "ldmk_dense_small": (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_timestep_embedding": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp]),

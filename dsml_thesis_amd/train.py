@@ -164,6 +164,8 @@ class UNetTrainer:
             unet.pack_weights()
         if unet.context_dim is None:
             raise NotImplementedError("UNetTrainer: spatial-transformer UNets with a context only")
+        if not getattr(unet, "_heads32", True):
+            raise NotImplementedError("UNetTrainer: attention heads of width 32 only (the flash backward kernels)")
         self.unet = unet
         self.dev = next(unet.parameters()).device
         self.P = FlatParams()

@@ -155,6 +155,30 @@ def emit_self_attention(nb_, qkv, att, hw, heads, d_head, att_ps=None, kv_tiles=
     pg, n = nb_.pg, nb_.n
     scale = d_head ** -0.5
     h2_flag = getattr(nb_, "h2_flag", None)
+    if d_head != 32:
+        # Heads that are not 32 wide (reference kwargs num_heads / num_head_channels: openaimodel.py:443-469,542-549; no shipped
+        # YAML sets them -- this path exists so that such checkpoints load and meet the oracle, not for speed): per (sample, head)
+        # q k^T and p v as batched GEMMs on head-major copies, the head width zero-padded to a multiple of 32 (exact), scores
+        # materialised and normalised by ldmk_softmax_rows -- the VQGAN AttnBlock's route (autoencoder.py).  fp32 throughout.
+        assert att_ps is None and kv_tiles is None
+        ops, C_ = nb_.ops, heads * d_head
+        dp = -(-d_head // 32) * 32
+        if hw % 32:
+            raise NotImplementedError(f"attention heads of width {d_head} need a token count that is a multiple of 32 (got {hw})")
+        q, k, v = (pg.alloc(n * heads, hw, dp) for _ in range(3))
+        for i, t in enumerate((q, k, v)):
+            pg.add("ldmk_heads_gather", qkv.data_ptr(), 3 * C_, i * C_, t.data_ptr(), n, hw, heads, d_head, dp)
+        sc = pg.alloc(n * heads, hw, hw)
+        a = ops.make_igemm_args(hw, hw, dp, q, dp, k, sc, hw, hw, b_trans=True, batch=n * heads, a_bstride=hw * dp, w_bstride=hw * dp,
+                                out_bstride=hw * hw)
+        pg.igemm(a, nb_.pin, per_sample=True)
+        pg.add("ldmk_softmax_rows", sc.data_ptr(), n * heads * hw, hw, float(scale))
+        o = pg.alloc(n * heads, hw, dp)
+        a = ops.make_igemm_args(hw, dp, hw, sc, hw, v, o, dp, hw, batch=n * heads, a_bstride=hw * hw, w_bstride=hw * dp, out_bstride=hw * dp)
+        pg.igemm(a, nb_.pin, per_sample=True)
+        pg.add("ldmk_heads_scatter", o.data_ptr(), att.data_ptr(), C_, n, hw, heads, d_head, dp)
+        nb_.release(q, k, v, sc, o)
+        return
     if h2_flag is not None and kv_tiles is not None:
         # the QKV projection's epilogue already wrote K / V as the kernel's pre-split tiles (ldmk_igemm_args.attn_kv_out): no pre-pass
         pg.add("ldmk_attn_self_h2_tiles", qkv.data_ptr(), kv_tiles.data_ptr(), 0 if att is None else att.data_ptr(),
@@ -344,6 +368,7 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
         # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel.  With a pre-split plan for
         # attn1.to_out the attention kernel writes its result in the PS layout only (from its accumulators, no LDS pass)
         plan_o = (nb_.ps_query(rows, C_, C_) if (q + "o1" + psfx() in P and L_ctx == 1 and hw % 32 == 0 and os.environ.get("LDMK_ATTN_PS", "1") != "0"
+                                                 and m.d_head == 32
                                                  and (hw >= ATTN_H2_MIN_TOKENS if h2_flag is not None else attention_presplit(hw))) else None)
         att = None if plan_o is not None else pg.alloc(rows, C_)
         att_ps = pg.alloc_ps(rows, C_) if plan_o is not None else None
@@ -389,8 +414,12 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
             q2 = lin(h1, P[q + "q2_ln"], P[q + "q2_ln#b"], hw, tf=L.TF_LAYERNORM_FOLDED, row_stats=stats,
                      ln_colsum=P[q + "q2_ln#cs"], out=att, wf=P.get(q + "q2_ln#f"))
         a2 = pg.alloc(rows, C_)
-        pg.add("ldmk_attn_cross", p_(q2), C_, p_(kk), p_(vv), C_, p_(a2), C_, n, hw, L_ctx, m.heads,
-               m.d_head ** -0.5)
+        if m.d_head == 32:
+            pg.add("ldmk_attn_cross", p_(q2), C_, p_(kk), p_(vv), C_, p_(a2), C_, n, hw, L_ctx, m.heads, m.d_head ** -0.5)
+        elif m.d_head in (40, 64, 80):
+            pg.add("ldmk_attn_cross_d", p_(q2), C_, p_(kk), p_(vv), C_, p_(a2), C_, n, hw, L_ctx, m.heads, m.d_head, m.d_head ** -0.5)
+        else:
+            raise NotImplementedError(f"cross attention over a context of {L_ctx} tokens with heads of width {m.d_head} (built: 32, 40, 64, 80)")
         h2 = lin(a2, P[q + "o2"], sd[q + "attn2.to_out.0.bias"], hw, residual=h1, out=h1, wf=P.get(q + "o2#f"))
         nb_.release(att, a2)
         return h2
@@ -533,6 +562,7 @@ class UNetModel(nn.Module):
         self.context_dim, self.transformer_depth = context_dim, transformer_depth
         mc = model_channels
         emb_ch = 4 * mc
+        self._heads32 = True
         self.time_embed = _Slots(_0=_lin_params(mc, emb_ch), _2=_lin_params(emb_ch, emb_ch))
 
         def heads_for(ch):
@@ -541,8 +571,9 @@ class UNetModel(nn.Module):
             else:
                 n = ch // num_head_channels
             d = ch // n if legacy else (num_head_channels if num_head_channels != -1 else ch // n)
-            if d != 32:
-                raise NotImplementedError(f"UNetModel: attention head dim {d}; the flash kernel is built for 32")
+            if n * d != ch or d % 4:
+                raise NotImplementedError(f"UNetModel: {ch} channels do not split into {n} heads of a width that is a multiple of 4")
+            self._heads32 = self._heads32 and d == 32      # the flash kernels are built for 32; other widths: batched GEMMs
             return n, d
 
         def st(ch):
@@ -550,8 +581,9 @@ class UNetModel(nn.Module):
                 # AttentionBlock(ch, num_heads, num_head_channels = dim_head): heads = ch // num_head_channels when that is set,
                 # else num_heads (openaimodel.py:296-303,545-556; legacy: dim_head = num_head_channels)
                 n = num_heads if num_head_channels == -1 else ch // num_head_channels
-                if ch // n != 32:
-                    raise NotImplementedError(f"UNetModel: attention head dim {ch // n}; the flash kernel is built for 32")
+                if n * (ch // n) != ch or (ch // n) % 4:
+                    raise NotImplementedError(f"UNetModel: {ch} channels do not split into {n} heads of a width that is a multiple of 4")
+                self._heads32 = self._heads32 and ch // n == 32
                 return _attention_block(ch, n)
             n, d = heads_for(ch)
             return _spatial_transformer(ch, n, d, transformer_depth, context_dim)
@@ -945,7 +977,7 @@ class UNetModel(nn.Module):
         pg = self._programs.get(key)
         if pg is None:
             from . import unet_small
-            if unet_small.wants_small_route(policy_n, H, W_, L_ctx):
+            if self._heads32 and unet_small.wants_small_route(policy_n, H, W_, L_ctx):
                 # batch 1-2 (the reference's shipped talking-face mode): the program cut for few dependent launches
                 pg = unet_small.build_small(self, n, H, W_, L_ctx, c_concat, policy_n)
             else:

@@ -429,6 +429,16 @@ int ldmk_attn_self_small(const float* qkv, int nslab, long long slab_stride, flo
                          float scale, void* stream);
 int ldmk_attn_cross(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo,
                     int n, int tokens, int ctx_len, int heads, float scale, void* stream);
+/* ... and for heads that are not 32 wide (reference kwargs num_heads / num_head_channels, openaimodel.py:443-469,542-549):
+ * d_head in {32, 40, 64, 80}. */
+int ldmk_attn_cross_d(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo, int n, int tokens,
+                      int ctx_len, int heads, int d_head, float scale, void* stream);
+/* Self attention for those head widths runs as batched GEMMs (ldmk_igemm, q k^T and p v per (sample, head)) + ldmk_softmax_rows on
+ * head-major copies: ldmk_heads_gather copies the heads side by side in token rows src[n tokens][ld] from column col0 to
+ * dst[n heads][tokens][dp], each head's d columns zero-padded to dp (a multiple of 32: exact for q k^T); ldmk_heads_scatter is the
+ * inverse (first d columns).  The flash kernels (ldmk_attn_self*) stay d_head = 32. */
+int ldmk_heads_gather(const float* src, int ld, int col0, float* dst, int n, int tokens, int heads, int d, int dp, void* stream);
+int ldmk_heads_scatter(const float* src, float* dst, int ld, int n, int tokens, int heads, int d, int dp, void* stream);
 int ldmk_softmax_rows(float* x, long long rows, int cols, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -96,6 +96,23 @@ def ddim_update(x, e_t, a_t, a_prev, sigma_t, sqrt_one_minus_at, noise=None):
     return x_prev, pred_x0
 
 
+def ddim_original_tables(sched, eta):
+    """`use_original_steps` tables: talking_face/ldm/models/diffusion/ddim2cond.py:175-178 read `model.alphas_cumprod`,
+    `model.alphas_cumprod_prev`, `model.sqrt_one_minus_alphas_cumprod` and the sampler's `ddim_sigmas_for_original_num_steps`
+    = eta sqrt((1 - a_prev) / (1 - a) (1 - a / a_prev)), formed in float32 from the float32 buffers (make_schedule,
+    ddim2cond.py:31-53 / ddim.py:31-53).  (face_reenactment/.../ddim.py:186 reads the sigmas off `self.model`, which never defines
+    them: that copy raises AttributeError for use_original_steps=True.)  -> dict of four float32 tensors [T]."""
+    a, ap = sched["alphas_cumprod"].float(), sched["alphas_cumprod_prev"].float()
+    sig = eta * torch.sqrt((1 - ap) / (1 - a) * (1 - a / ap))
+    return dict(a_t=a, a_prev=ap, sigma_t=sig.float(), sqrt_one_minus_at=sched["sqrt_one_minus_alphas_cumprod"].float())
+
+
+def p_sample_ddim_original(x, e_t, index, tabs, noise=None):
+    """One `use_original_steps` update (ddim2cond.py:179-195) on the model's own timestep `index`."""
+    return ddim_update(x, e_t, tabs["a_t"][index].item(), tabs["a_prev"][index].item(), tabs["sigma_t"][index].item(),
+                       tabs["sqrt_one_minus_at"][index].item(), noise)
+
+
 def cfg_combine(e_uncond, e_cond, scale):
     """ddim.py:177."""
     return e_uncond + scale * (e_cond - e_uncond)

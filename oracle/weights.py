@@ -333,6 +333,13 @@ FR_UNET = dict(image_size=32, in_channels=3, out_channels=3, model_channels=160,
 TF_UNET = dict(FR_UNET, in_channels=9, context_dim=1024)
 # north-star variant: same code, 64x64x4 latent
 NS_UNET = dict(FR_UNET, image_size=64, in_channels=4, out_channels=4)
+# attention head widths other than 32 (reference kwargs num_heads / num_head_channels, openaimodel.py:443-469,542-549): small UNets
+# for the g14 fixtures.  num_heads = 4: legacy dim_head = ch // num_heads = 40 at 160 channels, 80 at 320; num_head_channels = 64:
+# 2 / 4 heads of 64 at 128 / 256 channels
+H40_UNET = dict(image_size=16, in_channels=3, out_channels=3, model_channels=160, attention_resolutions=[1, 2], num_res_blocks=1,
+                channel_mult=[1, 2], num_heads=4, use_spatial_transformer=True, transformer_depth=1, context_dim=512)
+H64_UNET = dict(image_size=16, in_channels=3, out_channels=3, model_channels=128, attention_resolutions=[1, 2], num_res_blocks=1,
+                channel_mult=[1, 2], num_head_channels=64, use_spatial_transformer=True, transformer_depth=1, context_dim=512)
 # BASELINE configs[0] as worded: a genuinely UNCONDITIONAL LDM (cond_stage_config "__is_unconditional__" -> conditioning_key None,
 # ddpm.py:443-444): no SpatialTransformer, AttentionBlock / QKVAttentionLegacy with 32-channel heads, no context
 UNCOND_UNET = dict(image_size=64, in_channels=4, out_channels=4, model_channels=160, attention_resolutions=[4, 2, 1],

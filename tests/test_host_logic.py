@@ -70,7 +70,7 @@ def test_unsupported_options_fail_loudly():
     from dsml_thesis_amd.unet import UNetModel
     from dsml_thesis_amd.autoencoder import VQModelInterface
     for bad in (dict(dims=3), dict(resblock_updown=True), dict(use_new_attention_order=True), dict(use_fp16=True),
-                dict(num_head_channels=64)):
+                dict(num_head_channels=48)):       # (160 channels do not split into whole heads of 48)
         with pytest.raises(NotImplementedError):
             UNetModel(**dict(W.FR_UNET, **bad))
     with pytest.raises(AssertionError):                      # openaimodel.py:474-475: context_dim needs the spatial transformer
@@ -79,8 +79,11 @@ def test_unsupported_options_fail_loudly():
     u = UNetModel(**W.UNCOND_UNET)
     assert set(u.state_dict().keys()) == set(W.unet_param_shapes(W.UNCOND_UNET).keys())
     assert u.state_dict()["middle_block.1.qkv.weight"].shape == (1920, 640, 1)
-    with pytest.raises(NotImplementedError):
-        UNetModel(**dict(W.UNCOND_UNET, num_head_channels=64))
+    # head widths other than 32 construct since round 5 (legacy: heads = ch // num_head_channels, width = ch // heads,
+    # openaimodel.py:545-549) -- the attention then runs as batched GEMMs instead of the flash kernels
+    u64 = UNetModel(**dict(W.FR_UNET, num_head_channels=64))
+    assert not u64._heads32 and u64.input_blocks[1].layers[1].heads == 2 and u64.input_blocks[1].layers[1].d_head == 80
+    assert UNetModel(**W.FR_UNET)._heads32
     with pytest.raises(NotImplementedError):
         VQModelInterface(embed_dim=3, n_embed=16, ddconfig=dict(W.VQ_F4["ddconfig"], attn_type="linear"))
 

@@ -354,3 +354,25 @@ def test_g13_unconditional_unet_and_attention_block():
     out = O.unet_forward(sd, W.UNCOND_UNET, rnd(130, 2, 4, 64, 64), torch.tensor([7, 640]), None)
     close(out, g["uncond_eps"], 1e-4, 1e-4)
     assert g["uncond_ddim50"].shape == (1, 4, 64, 64) and g["ns_ddim50"].shape == (1, 4, 64, 64)
+
+
+def test_g14_head_widths_and_original_steps():
+    """g14 (tools/make_golden.py --tree variants, the real reference): UNets whose attention heads are 40 / 80 / 64 wide (num_heads = 4,
+    num_head_channels = 64), with a one-token and a three-token context; `use_original_steps` updates of the talking-face sampler
+    (ddim2cond.py:158-195) at eta 0 / 1 on four of the model's own timesteps."""
+    g = golden("g14_variants.npz")
+    x, t, ctx, ctx3 = rnd(150, 2, 3, 16, 16), torch.tensor([11, 870]), rnd(151, 2, 1, 512), rnd(152, 2, 3, 512)
+    for tag, cfg in (("h40", W.H40_UNET), ("h64", W.H64_UNET)):
+        sd = recipe(W.unet_param_shapes(cfg))
+        lay = W.unet_layout(cfg)
+        widths = sorted({l[3] for blk in lay["input"] + [lay["middle"]] + lay["output"] for l in blk if l[0] == "st"})
+        assert widths == ([40, 80] if tag == "h40" else [64]), widths
+        close(O.unet_forward(sd, cfg, x, t, ctx), g[tag + "_eps"], 2e-5, 2e-5)
+        close(O.unet_forward(sd, cfg, x, t, ctx3), g[tag + "_eps_L3"], 2e-5, 2e-5)
+    sched = O.register_schedule(**W.SCHEDULE)
+    xs, eps = rnd(160, 2, 3, 32, 32), rnd(161, 2, 3, 32, 32)
+    for eta in (0.0, 1.0):
+        tabs = O.ddim_original_tables(sched, eta)
+        for index in (0, 1, 437, 999):
+            xp, p0 = O.p_sample_ddim_original(xs, eps, index, tabs, T(g[f"orig_eta{eta:g}_i{index}_noise"]))
+            assert np.array_equal(xp.numpy(), g[f"orig_eta{eta:g}_i{index}_x_prev"]) and np.array_equal(p0.numpy(), g[f"orig_eta{eta:g}_i{index}_pred_x0"])

@@ -242,6 +242,26 @@ def test_use_original_steps_walks_the_models_own_schedule(fr):
     ref = torch.sqrt(ap) * p0 + torch.sqrt(1 - ap - sig ** 2) * e + sig * nz.double()
     torch.testing.assert_close(px0.double(), p0, rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(xp.double(), ref, rtol=2e-5, atol=2e-5)
+    # ... and against the REAL talking-face sampler's outputs (g14: ddim2cond.DDIMSampler.p_sample_ddim(use_original_steps=True) around a
+    # model that returns a fixed eps): the update kernel on the original-step tables, eta 0 and 1, four of the 1000 timesteps
+    g = golden("g14_variants.npz")
+    xs, ef = rnd(160, 2, 3, 32, 32).cuda(), rnd(161, 2, 3, 32, 32).cuda()
+    real_apply = fr.apply_model
+    try:
+        fr.apply_model = lambda *a_, **k_: ef.clone()
+        for eta in (0.0, 1.0):
+            s.make_schedule(50, ddim_eta=eta, verbose=False)
+            for i in (0, 1, 437, 999):
+                nz_i = torch.from_numpy(g[f"orig_eta{eta:g}_i{i}_noise"]).cuda()
+                xp_i, p0_i = s.p_sample_ddim(xs, c, torch.full((2,), i, device="cuda", dtype=torch.long), index=i, use_original_steps=True,
+                                             noise=nz_i if eta else None)
+                # (pred_x0 divides by sqrt(a_t) -- 0.0098 at index 999 -- so the bound scales with the tensor: 2e-6 of max |x|)
+                top = float(np.abs(g[f"orig_eta{eta:g}_i{i}_pred_x0"]).max())
+                close(p0_i, g[f"orig_eta{eta:g}_i{i}_pred_x0"], 2e-6, 2e-6 * max(1.0, top))
+                close(xp_i, g[f"orig_eta{eta:g}_i{i}_x_prev"], 2e-6, 2e-6 * max(1.0, 0.02 * top))
+    finally:
+        del fr.apply_model
+    assert fr.apply_model.__func__ is type(fr).apply_model
     s.make_schedule(50, ddim_eta=0.0, verbose=False)
     out, inter = s.ddim_sampling(c, (2, 3, 32, 32), x_T=x, ddim_use_original_steps=True, timesteps=3)
     img = x

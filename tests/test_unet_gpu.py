@@ -133,7 +133,8 @@ def test_unet_tf_concat_golden(route):
         gemms = [c[2] for c in pg.calls if c[3] == "ldmk_igemm"]
         assert sum(1 for a in gemms if a.compute in (L.COMPUTE_BF16X3, L.COMPUTE_F16X2)) >= 40
         names = [c[3] for c in pg.calls]
-        assert sum(names.count(k) for k in ("ldmk_winograd_input", "ldmk_winograd_input_ps", "ldmk_winograd_input_ps_h2")) >= 20
+        # (Winograd, or -- the 32x32-level shapes of this batch -- the direct convolution on the conv-mode pre-split tile)
+        assert sum(names.count(k) for k in ("ldmk_winograd_input", "ldmk_winograd_input_ps", "ldmk_winograd_input_ps_h2", "ldmk_gn_apply_ps_h2")) >= 20
     x, t = rnd(71, 2, 3, 32, 32), torch.tensor([11, 756])
     c12, c34 = rnd(72, 2, 1, 1024), rnd(73, 2, 6, 32, 32)
     eps = m(x.cuda(), t.cuda(), context=c12.cuda(), c_concat=c34.cuda())
@@ -465,9 +466,32 @@ def test_every_batch_gets_split_arithmetic_plans(latent, batch):
         # the f32 cores, chosen by measurement (profiles/r05_plan_coverage.txt has the A/B against the batched F16X2 program)
         assert "ldmk_attn_self_small" in {c[3] for c in pg.calls}
     else:
-        assert split >= 0.9 * len(comp), (split, len(comp))
+        # (a batch within 2x of a tuned one runs that batch's measured program, in which a few short-K projections stay on the f32
+        #  row GEMM: 130 of 145 at B = 96 / 128; everywhere else the nearest plans are carried: 140 of 145)
+        assert split >= 0.88 * len(comp), (split, len(comp))
     assert not m.arithmetic_status()["denied"]
     close(eps[:1], O.unet_forward(sd, cfg, x1, t1, c1), 3e-5, 3e-5)
+
+
+@pytest.mark.parametrize("tag,cfg", [("h40", W.H40_UNET), ("h64", W.H64_UNET)])
+def test_unet_attention_heads_that_are_not_32_wide(tag, cfg):
+    """Reference kwargs `num_heads` / `num_head_channels` (openaimodel.py:443-469,542-549): a UNet with num_heads = 4 has heads 40 and
+    80 wide, one with num_head_channels = 64 heads of 64.  Rounds 1-4 raised NotImplementedError; now the self attention of such
+    heads runs as batched GEMMs on head-major, zero-padded copies (the flash kernels stay d = 32) and the multi-token cross
+    attention on the width-templated kernel: eps against the REAL reference's outputs (g14), one- and three-token contexts."""
+    g = golden("g14_variants.npz")
+    m, sd = make_unet(cfg)
+    assert not m._heads32
+    x, t, ctx, ctx3 = rnd(150, 2, 3, 16, 16), torch.tensor([11, 870]), rnd(151, 2, 1, 512), rnd(152, 2, 3, 512)
+    eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
+    names = [c[3] for c in m.program(2, 16, 16, 1, 0).calls]
+    assert "ldmk_heads_gather" in names and "ldmk_softmax_rows" in names and not any(n.startswith("ldmk_attn_self") for n in names)
+    close(eps, g[tag + "_eps"], 3e-5, 3e-5)
+    eps3 = m(x.cuda(), t.cuda(), context=ctx3.cuda())
+    assert "ldmk_attn_cross_d" in [c[3] for c in m.program(2, 16, 16, 3, 0).calls]
+    close(eps3, g[tag + "_eps_L3"], 3e-5, 3e-5)
+    m.policy_batch = 16                      # the batched program's plans (split arithmetic on the GEMMs around the attention)
+    close(m(x.cuda(), t.cuda(), context=ctx.cuda()), g[tag + "_eps"], 3e-5, 3e-5)
 
 
 def test_attention_block_golden_through_the_launch_program():
@@ -515,7 +539,7 @@ def test_unconditional_unet_golden(policy):
         m(x.cuda(), t.cuda(), context=torch.zeros(2, 1, 512, device="cuda"))
     with pytest.raises(NotImplementedError):
         from dsml_thesis_amd.unet import UNetModel
-        UNetModel(**dict(W.UNCOND_UNET, num_head_channels=64))
+        UNetModel(**dict(W.UNCOND_UNET, use_scale_shift_norm=True))
 
 
 def test_unet_multi_token_context_vs_oracle():

@@ -835,9 +835,68 @@ def gen_options():
     save("g12_sampler_options.npz", **g)
 
 
+def gen_variants():
+    """G14: reference kwargs the shipped YAMLs do not set but checkpoints in the wild do -- attention heads that are not 32 wide
+    (num_heads = 4 -> 40 / 80, num_head_channels = 64), from the real UNetModel -- and `use_original_steps` of the sampler from
+    the real talking_face DDIMSampler.p_sample_ddim (ddim2cond.py:158-195; the face_reenactment copy raises AttributeError there)."""
+    from tools import ref_shims
+    ref_shims.install("face_reenactment")
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    torch.set_grad_enabled(False)
+    g = {}
+    for tag, cfg in (("h40", W.H40_UNET), ("h64", W.H64_UNET)):
+        m = UNetModel(**cfg)
+        sd = load_recipe(m, seed=0, prefix_check=W.unet_param_shapes(cfg))
+        x, t, ctx = rnd(150, 2, 3, 16, 16), torch.tensor([11, 870]), rnd(151, 2, 1, 512)
+        ref = m(x, t, context=ctx)
+        check(f"UNet eps, {tag} ({cfg.get('num_heads', cfg.get('num_head_channels'))})", ref, O.unet_forward(sd, cfg, x, t, ctx), 2e-5, 2e-5)
+        g[tag + "_eps"] = ref
+        ctx3 = rnd(152, 2, 3, 512)                 # a context of several tokens: the cross attention is live
+        ref3 = m(x, t, context=ctx3)
+        check(f"UNet eps, {tag}, 3 context tokens", ref3, O.unet_forward(sd, cfg, x, t, ctx3), 2e-5, 2e-5)
+        g[tag + "_eps_L3"] = ref3
+    # ---- use_original_steps: the real sampler class of the talking-face tree around a stub model that returns a fixed eps
+    for k in [k for k in sys.modules if k == "ldm" or k.startswith("ldm.") or k.startswith("taming")]:
+        del sys.modules[k]
+    ref_shims.install("talking_face")
+    from ldm.models.diffusion.ddim2cond import DDIMSampler
+    sched = O.register_schedule(**W.SCHEDULE)
+    x, eps = rnd(160, 2, 3, 32, 32), rnd(161, 2, 3, 32, 32)
+
+    class Stub:
+        num_timesteps = 1000
+        device = torch.device("cpu")
+        betas, alphas_cumprod, alphas_cumprod_prev = sched["betas"], sched["alphas_cumprod"], sched["alphas_cumprod_prev"]
+        sqrt_one_minus_alphas_cumprod = sched["sqrt_one_minus_alphas_cumprod"]
+        parameterization = "eps"
+
+        def apply_model(self, x_, t_, c12, c34):
+            return eps
+
+    class CPUDDIM(DDIMSampler):
+        def register_buffer(self, n, a):
+            setattr(self, n, a)
+    for eta in (0.0, 1.0):
+        smp = CPUDDIM(Stub())
+        smp.make_schedule(50, ddim_eta=eta, verbose=False)
+        tabs = O.ddim_original_tables(sched, eta)
+        for index in (0, 1, 437, 999):
+            torch.manual_seed(1000 + index)
+            xp, p0 = smp.p_sample_ddim(x, {"class_label_&_audio": None, "motion_&_id": None}, torch.full((2,), index), index,
+                                       use_original_steps=True)
+            torch.manual_seed(1000 + index)
+            nz = torch.randn(x.shape)
+            mine = O.p_sample_ddim_original(x, eps, index, tabs, nz)
+            check(f"p_sample_ddim(use_original_steps) eta={eta:g} index={index}", xp, mine[0], 1e-6, 1e-6)
+            check(f"   pred_x0", p0, mine[1], 1e-6, 1e-6)
+            g[f"orig_eta{eta:g}_i{index}_x_prev"], g[f"orig_eta{eta:g}_i{index}_pred_x0"] = xp, p0
+            g[f"orig_eta{eta:g}_i{index}_noise"] = nz
+    save("g14_variants.npz", **g)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0"])
+    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants"])
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -855,6 +914,8 @@ if __name__ == "__main__":
         gen_options()
     elif a.tree == "config0":
         gen_config0()
+    elif a.tree == "variants":
+        gen_variants()
     else:
-        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0"):
+        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", tree], cwd=ROOT)

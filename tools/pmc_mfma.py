@@ -12,7 +12,8 @@ import os
 import sys
 
 # (first match wins: the bf16x3 instantiations of igemm_kernel carry BF = 3 as their 9th template argument: '..., false, false, 3, true, false>')
-FAM = ((", 2, false>(ldmk_igemm_args", "igemm f16x2, pre-split operands + LDS-DMA (igemm_ps, two fp16 planes)"),
+FAM = (("igemm_psc_kernel", "igemm f16x2, conv-mode pre-split tile: taps gathered by LDS-DMA (igemm_psc)"),
+       (", 2, false>(ldmk_igemm_args", "igemm f16x2, pre-split operands + LDS-DMA (igemm_ps, two fp16 planes)"),
        (", 2, true>(ldmk_igemm_args", "igemm f16x2, pre-split operands + LDS-DMA (igemm_ps, two fp16 planes)"),
        ("igemm_ps_kernel", "igemm bf16x3, pre-split operands + LDS-DMA (igemm_ps)"), ("igemm_pw_kernel", "igemm bf16x3, pre-split + warp-specialised (igemm_pw)"),
        ("false, 3, true", "igemm bf16x3 (six bf16 MFMAs per product)"), ("false, 4, true", "igemm f16x2 (three fp16 MFMAs per product)"), ("igemm_ws_kernel", "igemm bf16x3, warp-specialised tiles"),
