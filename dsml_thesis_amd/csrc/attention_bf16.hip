@@ -901,13 +901,19 @@ __device__ __forceinline__ void h2_softmax(f32x16& s, f32x16& o, float& m_run, f
 template <int QB>
 __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ kv, float* __restrict__ out,
                                                           unsigned char* __restrict__ out_ps, int tokens, int heads, float scale,
-                                                          int* __restrict__ range_flag) {
+                                                          int* __restrict__ range_flag, const int gx, const int remap) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem_h[2 * H2_TILE];
   static_assert(2 * H2_TILE >= 4 * 32 * BA_FS * 4, "transpose buffers alias the tile buffers");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
   const int C = heads * BA_D, ld = 3 * C;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
+  // 1-D grid, XCD-aware (round 5): workgroups are dealt round-robin over the 8 XCDs, so the query tiles of one (sample, head) --
+  // which all stream the same K / V tiles -- used to land on 8 different L2s and each fetched the stream from the fabric
+  // (5.7 GB per 64x64x4 step by FETCH_SIZE, profiles/traffic_r05.json).  xcd_remap puts consecutive ids on ONE XCD: the
+  // tiles of a head share that L2.  (remap = 0: the old order, A/B only)
+  const int nwg = gx * heads * (int)gridDim.y;
+  const int bid = remap ? xcd_remap(blockIdx.x + gx * heads * blockIdx.y, nwg) : (int)(blockIdx.x + gx * heads * blockIdx.y);
+  const int qt = bid % gx, h = (bid / gx) % heads, b = bid / (gx * heads);
+  const int q0 = qt * (128 * QB) + wave * (32 * QB);
   const float* base = qkv + (long long)b * tokens * ld;
   const bool wave_active = q0 < tokens;
   constexpr float LOG2E = 1.4426950408889634f;
@@ -1127,12 +1133,15 @@ static int attn_self_h2_any(const float* qkv, void* kv_scratch, float* out, void
                        heads, range_flag);
   static const int qb_env = [] { const char* e = getenv("LDMK_ATTN_QB"); return e ? atoi(e) : 0; }();
   const int qb = qb_env == 1 || qb_env == 2 ? qb_env : (tokens >= X3P_QB2_MIN_TOKENS ? 2 : 1);
+  static const int remap = [] { const char* e = getenv("LDMK_ATTN_XCD"); return e ? atoi(e) : 1; }();
+  const int gx = qb == 2 ? (tokens + 255) / 256 : (tokens + 127) / 128;
+  // (grid.x = query tiles x heads, grid.y = samples: the kernel linearises and re-deals the ids over the XCDs itself)
   if (qb == 2)
-    hipLaunchKernelGGL(attn_h2_fwd_kernel<2>, dim3((tokens + 255) / 256, heads, n), dim3(256), 0, st, qkv,
-                       reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale, range_flag);
+    hipLaunchKernelGGL(attn_h2_fwd_kernel<2>, dim3(gx * heads, n), dim3(256), 0, st, qkv,
+                       reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale, range_flag, gx, remap);
   else
-    hipLaunchKernelGGL(attn_h2_fwd_kernel<1>, dim3((tokens + 127) / 128, heads, n), dim3(256), 0, st, qkv,
-                       reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale, range_flag);
+    hipLaunchKernelGGL(attn_h2_fwd_kernel<1>, dim3(gx * heads, n), dim3(256), 0, st, qkv,
+                       reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale, range_flag, gx, remap);
   return check_launch("ldmk_attn_self_h2");
 }
 

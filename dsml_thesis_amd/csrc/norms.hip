@@ -203,7 +203,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// use_scale_shift_norm (openaimodel.py:267-271): h = GroupNorm(h) (1 + scale) + shift with (scale, shift) = the two halves of the
+// ResBlock's emb_layers output per sample -- folded into the GroupNorm coefficient planes: sc' = sc (1 + s), sh' = sh (1 + s) + t
+__global__ __launch_bounds__(256) void gn_coef_film_kernel(float* __restrict__ coef, const float* __restrict__ emb, int ld, int C, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int n = i / C, c = i - n * C;
+  const float s = 1.0f + emb[(long long)n * ld + c], t = emb[(long long)n * ld + C + c];
+  float* p = coef + ((long long)n * 2) * C + c;
+  const float sc = p[0], sh = p[C];
+  p[0] = sc * s;
+  p[C] = fmaf(sh, s, t);
+}
+
 }  // namespace ldmk
+
+extern "C" int ldmk_gn_coef_film(float* coef, const float* emb, int ld, int n, int c, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(coef && emb && n > 0 && c > 0 && ld >= 2 * c, "ldmk_gn_coef_film: bad args (ld=%d c=%d)", ld, c);
+  hipLaunchKernelGGL(gn_coef_film_kernel, dim3((n * c + 255) / 256), dim3(256), 0, (hipStream_t)stream, coef, emb, ld, c, n * c);
+  return check_launch("ldmk_gn_coef_film");
+}
 
 extern "C" int ldmk_gn_apply(const float* x0, int c0, const float* x1, int c1, const float* coef, float* y, int n, int hw,
                              int silu, void* stream) {

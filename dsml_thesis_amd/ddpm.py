@@ -94,8 +94,8 @@ class DiffusionWrapper(_Base):
     def forward(self, x, t, c_concat: list = None, c_crossattn: list = None):
         """ddpm.py:1404-1423.  None: the unconditional UNet, `diffusion_model(x, t)`; 'concat': channel concat only (the UNet's
         first convolution reads both tensors, nothing is materialised); 'crossattn' / 'hybrid': context (+ concat)."""
-        if self.conditioning_key == "adm":
-            raise NotImplementedError("DiffusionWrapper: conditioning_key='adm' (class-conditional `y`) is not used by the shipped configs")
+        if self.conditioning_key == "adm":                # ddpm.py:1417-1420: the conditioning IS the class label vector y
+            return self.diffusion_model(x, t, y=c_crossattn[0])
         cat = None
         if c_concat is not None and self.conditioning_key in ("concat", "hybrid", "crossattn"):
             cat = c_concat[0] if len(c_concat) == 1 else torch.cat(c_concat, 1)

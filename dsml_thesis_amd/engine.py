@@ -533,8 +533,9 @@ class NetBuilder:
             self._stats[x.data_ptr()] = p
         return p
 
-    def gn(self, x0, x1, hw, gamma, beta, eps):
-        """GroupNorm(32) statistics of (the channel concat of) NHWC tensors -> coef planes [n][2][C]."""
+    def gn(self, x0, x1, hw, gamma, beta, eps, film=None):
+        """GroupNorm(32) statistics of (the channel concat of) NHWC tensors -> coef planes [n][2][C].  film = (pointer to a
+        per-sample [n][ld] vector (scale | shift), ld): use_scale_shift_norm's `norm(h) (1 + scale) + shift` folded into the planes."""
         pg, p_ = self.pg, self.ptr
         c0 = x0.shape[-1]
         c1 = 0 if x1 is None else x1.shape[-1]
@@ -542,15 +543,17 @@ class NetBuilder:
         pb = None if x1 is None else self._partial(x1, hw)
         coef = pg.alloc(self.n, 2, c0 + c1)
         pg.add("ldmk_gn_finalize", p_(pa), c0, p_(pb), c1, self.n, hw, 32, eps, p_(gamma), p_(beta), p_(coef))
+        if film is not None:
+            pg.add("ldmk_gn_coef_film", p_(coef), film[0], film[1], self.n, c0 + c1)
         return coef
 
-    def gn_act(self, x0, x1, hw, gamma, beta, eps, silu=True):
+    def gn_act(self, x0, x1, hw, gamma, beta, eps, silu=True, film=None):
         """GroupNorm(32) [+SiLU] of (the concat of) NHWC tensors materialised once: statistics pass + one
         elementwise pass.  Returns a contiguous [n*hw][C] tensor for the consumer GEMM to read raw."""
         pg, p_ = self.pg, self.ptr
         c0 = x0.shape[-1]
         c1 = 0 if x1 is None else x1.shape[-1]
-        coef = self.gn(x0, x1, hw, gamma, beta, eps)
+        coef = self.gn(x0, x1, hw, gamma, beta, eps, film)
         y = pg.alloc(self.n * hw, c0 + c1)
         pg.add("ldmk_gn_apply", p_(x0), c0, p_(x1), c1, p_(coef), p_(y), self.n, hw, 1 if silu else 0)
         self.release(coef)
@@ -623,7 +626,7 @@ class NetBuilder:
         return ps_plan(f"{N},{K},{L.A_CONV3X3},0,0,1" + ("" if stride == 1 else f",s{stride}u0"), m, h2=True, max_ratio=2.0)
 
     def gn_conv(self, x0, x1, h, w, gamma, beta, eps, wp, u, bias, batch_vec=None, bv_ld=0, residual=None, out=None,
-                stats=False, wf=None, u_ps=None, wp_ps=None):
+                stats=False, wf=None, u_ps=None, wp_ps=None, film=None):
         """GroupNorm(32)+SiLU of (the concat of) x0 | x1, then the 3x3 convolution with packed weights `wp` (implicit GEMM)
         or, when `u` (ops.pack_winograd) is given and the problem is large enough, through Winograd -- or, `wp_ps`
         (ops.pack_wps(wp, h2=True)) given and the shape listed (ps_query_conv), as a direct convolution on the conv-mode
@@ -638,7 +641,7 @@ class NetBuilder:
                   if (wp_ps is not None and cin % 32 == 0 and cout_ % 32 == 0 and c0 % 8 == 0 and c1 % 8 == 0) else None)
         if plan_c is not None:
             hf = self.h2_flag
-            coef = self.gn(x0, x1, h * w, gamma, beta, eps)
+            coef = self.gn(x0, x1, h * w, gamma, beta, eps, film)
             y_ps = pg.alloc_ps(n * h * w, cin)
             pg.add("ldmk_gn_apply_ps_h2", p_(x0), c0, p_(x1), c1, p_(coef), p_(y_ps), n, h * w, 1, p_(hf))
             self.release(coef)
@@ -654,14 +657,14 @@ class NetBuilder:
             pg.release(y_ps)
             return out
         if u is None or not self.winograd_ok(cin, h, w):
-            y = self.gn_act(x0, x1, h * w, gamma, beta, eps)
+            y = self.gn_act(x0, x1, h * w, gamma, beta, eps, film=film)
             res = self.conv(y.view(n, h, w, cin), None, wp, bias, h, w, batch_vec=batch_vec, bv_ld=bv_ld, residual=residual,
                             out=out, stats=stats, wf=wf)
             self.release(y)
             return res
         cout = u.shape[2]
         tiles = n * (h // 2) * (w // 2)
-        coef = self.gn(x0, x1, h * w, gamma, beta, eps)
+        coef = self.gn(x0, x1, h * w, gamma, beta, eps, film)
         Mb = pg.alloc(16, tiles, cout)
         if out is None:
             out = pg.alloc(n, h, w, cout)

@@ -104,6 +104,7 @@ _SIGS = {
     "ldmk_ln_stats_ps": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp, C.c_float, _fp, _fp]),
     "ldmk_ln_stats_split": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp, C.c_int, _fp]),
     "ldmk_gn_apply": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_gn_coef_film": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_gn_apply_ps_h2": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ldmk_post": (C.c_int, [C.POINTER(PostArgs), _fp]),
     "ldmk_post_scratch_elems": (C.c_longlong, [C.POINTER(PostArgs)]),

@@ -72,14 +72,14 @@ def _norm_params(c):
     return _Params(weight=(c,), bias=(c,))
 
 
-def _res_block(cin, cout, emb_ch):
+def _res_block(cin, cout, emb_ch, scale_shift=False):
     ch = dict(in_layers=_Slots(_0=_norm_params(cin), _2=_conv_params(cin, cout, 3)),
-              emb_layers=_Slots(_1=_lin_params(emb_ch, cout)),
+              emb_layers=_Slots(_1=_lin_params(emb_ch, 2 * cout if scale_shift else cout)),      # (scale | shift), openaimodel.py:218-224
               out_layers=_Slots(_0=_norm_params(cout), _3=_conv_params(cout, cout, 3)))
     if cin != cout:
         ch["skip_connection"] = _conv_params(cin, cout, 1)
     m = _Slots(**ch)
-    m.kind, m.cin, m.cout = "res", cin, cout
+    m.kind, m.cin, m.cout, m.scale_shift = "res", cin, cout, bool(scale_shift)
     return m
 
 
@@ -103,11 +103,13 @@ def _spatial_transformer(ch, heads, d_head, depth, context_dim):
     return m
 
 
-def _attention_block(ch, heads):
-    """AttentionBlock (openaimodel.py:278-324): norm, qkv (Conv1d ch -> 3 ch, kernel 1), proj_out (Conv1d ch -> ch)."""
+def _attention_block(ch, heads, new_order=False):
+    """AttentionBlock (openaimodel.py:278-324): norm, qkv (Conv1d ch -> 3 ch, kernel 1), proj_out (Conv1d ch -> ch).
+    new_order: use_new_attention_order (QKVAttention, :379-407) -- the qkv channels are [q | k | v][head][d] instead of the legacy
+    [head][q | k | v][d]."""
     m = _Slots(norm=_norm_params(ch), qkv=_Params(weight=(3 * ch, ch, 1), bias=(3 * ch,)),
                proj_out=_Params(weight=(ch, ch, 1), bias=(ch,)))
-    m.kind, m.ch, m.heads, m.d_head = "attn", ch, heads, ch // heads
+    m.kind, m.ch, m.heads, m.d_head, m.new_order = "attn", ch, heads, ch // heads, bool(new_order)
     return m
 
 
@@ -210,9 +212,13 @@ def pack_attention_block(P, sd, prefix, m):
     rows [q of every head | k of every head | v of every head], so the output channels (and the bias) are permuted here."""
     ch, heads = m.ch, m.heads
     d = ch // heads
-    w = sd[prefix + "qkv.weight"].reshape(heads, 3, d, ch).permute(1, 0, 2, 3).reshape(3 * ch, ch).contiguous()
+    if getattr(m, "new_order", False):     # QKVAttention: [q | k | v][head][d] is the kernels' own order
+        w, bq = sd[prefix + "qkv.weight"].reshape(3 * ch, ch).contiguous(), sd[prefix + "qkv.bias"].contiguous()
+    else:
+        w = sd[prefix + "qkv.weight"].reshape(heads, 3, d, ch).permute(1, 0, 2, 3).reshape(3 * ch, ch).contiguous()
+        bq = sd[prefix + "qkv.bias"].reshape(heads, 3, d).permute(1, 0, 2).reshape(3 * ch).contiguous()
     P[prefix + "aqkv"] = ops.pack_linear(w)
-    P[prefix + "aqkv#b"] = sd[prefix + "qkv.bias"].reshape(heads, 3, d).permute(1, 0, 2).reshape(3 * ch).contiguous()
+    P[prefix + "aqkv#b"] = bq
     P[prefix + "apout"] = ops.pack_linear(sd[prefix + "proj_out.weight"].reshape(ch, ch).contiguous())
 
 
@@ -527,11 +533,10 @@ class UNetModel(nn.Module):
         # combinations the reference accepts but this path does not implement fail loudly
         if dims != 2:
             raise NotImplementedError("UNetModel: only dims=2")
-        if resblock_updown or use_scale_shift_norm or num_classes is not None or n_embed is not None:
-            raise NotImplementedError("UNetModel: resblock_updown / use_scale_shift_norm / num_classes / n_embed "
-                                      "are not part of the sampling path built here")
-        if use_new_attention_order:
-            raise NotImplementedError("UNetModel: use_new_attention_order (QKVAttention) -- the legacy order is built")
+        if resblock_updown or n_embed is not None:
+            raise NotImplementedError("UNetModel: resblock_updown / n_embed are not part of the sampling path built here")
+        if use_new_attention_order and use_spatial_transformer:
+            pass        # (QKVAttention lives in AttentionBlock only: the flag is inert with spatial transformers, openaimodel.py:379,557-570)
         if not conv_resample:
             raise NotImplementedError("UNetModel: conv_resample=False")
         if use_fp16:
@@ -560,10 +565,13 @@ class UNetModel(nn.Module):
         self.use_checkpoint, self.dtype = use_checkpoint, torch.float32
         self.num_heads, self.num_head_channels, self.num_heads_upsample = num_heads, num_head_channels, num_heads_upsample
         self.context_dim, self.transformer_depth = context_dim, transformer_depth
+        self.use_scale_shift_norm, self.use_new_attention_order = bool(use_scale_shift_norm), bool(use_new_attention_order)
         mc = model_channels
         emb_ch = 4 * mc
         self._heads32 = True
         self.time_embed = _Slots(_0=_lin_params(mc, emb_ch), _2=_lin_params(emb_ch, emb_ch))
+        if num_classes is not None:          # class-conditional ('adm') UNets: emb += label_emb(y), openaimodel.py:513-514,726-728
+            self.label_emb = _Params(weight=(int(num_classes), emb_ch))
 
         def heads_for(ch):
             if num_head_channels == -1:
@@ -584,7 +592,7 @@ class UNetModel(nn.Module):
                 if n * (ch // n) != ch or (ch // n) % 4:
                     raise NotImplementedError(f"UNetModel: {ch} channels do not split into {n} heads of a width that is a multiple of 4")
                 self._heads32 = self._heads32 and ch // n == 32
-                return _attention_block(ch, n)
+                return _attention_block(ch, n, use_new_attention_order)
             n, d = heads_for(ch)
             return _spatial_transformer(ch, n, d, transformer_depth, context_dim)
 
@@ -596,7 +604,7 @@ class UNetModel(nn.Module):
         ch, ds = mc, 1
         for level, mult in enumerate(channel_mult):
             for _ in range(num_res_blocks):
-                layers = [_res_block(ch, mult * mc, emb_ch)]
+                layers = [_res_block(ch, mult * mc, emb_ch, use_scale_shift_norm)]
                 ch = mult * mc
                 if ds in attention_resolutions:
                     layers.append(st(ch))
@@ -608,12 +616,12 @@ class UNetModel(nn.Module):
                 self.input_blocks.append(_seq(down))
                 chans.append(ch)
                 ds *= 2
-        self.middle_block = _seq(_res_block(ch, ch, emb_ch), st(ch), _res_block(ch, ch, emb_ch))
+        self.middle_block = _seq(_res_block(ch, ch, emb_ch, use_scale_shift_norm), st(ch), _res_block(ch, ch, emb_ch, use_scale_shift_norm))
         self.output_blocks = nn.ModuleList()
         for level, mult in list(enumerate(channel_mult))[::-1]:
             for i in range(num_res_blocks + 1):
                 ich = chans.pop()
-                layers = [_res_block(ch + ich, mc * mult, emb_ch)]
+                layers = [_res_block(ch + ich, mc * mult, emb_ch, use_scale_shift_norm)]
                 ch = mc * mult
                 if ds in attention_resolutions:
                     layers.append(st(ch))
@@ -703,7 +711,7 @@ class UNetModel(nn.Module):
                 emb_w.append(sd[prefix + "emb_layers.1.weight"])
                 emb_b.append(sd[prefix + "emb_layers.1.bias"])
                 self._emb_off[prefix] = off
-                off += m.cout
+                off += 2 * m.cout if m.scale_shift else m.cout
             elif m.kind == "st":
                 stp(prefix, m)
             elif m.kind == "attn":
@@ -786,7 +794,8 @@ class UNetModel(nn.Module):
         cc_in = pg.alloc(n, c_concat, H, W_) if c_concat else None
         t_in = pg.alloc(n, dtype=torch.int64)
         ctx_in = pg.alloc(n * L_ctx, self.context_dim) if L_ctx else None      # (unconditional UNet: no context)
-        pg.inputs = dict(x=x_in, c_concat=cc_in, t=t_in, context=ctx_in)
+        y_emb = pg.alloc(n, emb_ch) if self.num_classes is not None else None     # label_emb(y) rows, gathered by forward()
+        pg.inputs = dict(x=x_in, c_concat=cc_in, t=t_in, context=ctx_in, y_emb=y_emb)
         ctx_pg = Program(dev)     # context-only work: re-run only when the context changes
         ctx_pg._all = pg._all     # share accounting
         p_ = lambda t: 0 if t is None else t.data_ptr()
@@ -799,6 +808,8 @@ class UNetModel(nn.Module):
         pg.add("ldmk_dense_small", p_(temb), mc, p_(P["te0"]), p_(sd["time_embed.0.bias"]), p_(e1), emb_ch, n, mc, emb_ch, 0)
         emb = pg.alloc(n, emb_ch)
         pg.add("ldmk_dense_small", p_(e1), emb_ch, p_(P["te2"]), p_(sd["time_embed.2.bias"]), p_(emb), emb_ch, n, emb_ch, emb_ch, 1)
+        if y_emb is not None:
+            pg.add("ldmk_axpy", p_(emb), p_(y_emb), 1.0, n * emb_ch)              # emb = emb + label_emb(y), openaimodel.py:726-728
         emb_all = pg.alloc(n, self._emb_total)
         pg.add("ldmk_dense_small", p_(emb), emb_ch, p_(P["emb_all"]), p_(P["emb_all_b"]), p_(emb_all), self._emb_total, n,
                emb_ch, self._emb_total, 1)
@@ -814,9 +825,13 @@ class UNetModel(nn.Module):
             # then reads it raw -- cheaper than re-normalising every element 9 x (N/tile) times in the gather
             # (gn_conv: one elementwise GroupNorm+SiLU pass + implicit-GEMM conv, or the Winograd route for the wide levels)
             bv = emb_all.data_ptr() + 4 * self._emb_off[prefix]
+            # use_scale_shift_norm (openaimodel.py:267-271): the embedding does not add to conv1's output but modulates the second
+            # GroupNorm -- h = norm(h) (1 + scale) + shift -- which is a per-sample edit of that norm's coefficient planes
+            film = (bv, self._emb_total) if m.scale_shift else None
             with nb_.site(prefix + "in_layers"):
                 h1 = nb_.gn_conv(x0, x1, h, w, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5,
-                                 P[prefix + "c1"], P.get(prefix + "c1#wg"), sd[prefix + "in_layers.2.bias"], batch_vec=bv,
+                                 P[prefix + "c1"], P.get(prefix + "c1#wg"), sd[prefix + "in_layers.2.bias"],
+                                 batch_vec=None if film else bv,
                                  bv_ld=self._emb_total, stats=True, wf=P.get(prefix + "c1#f"), u_ps=P.get(prefix + "c1#wg" + psfx()),
                                  wp_ps=P.get(prefix + "c1#pc2"))
             g2, b2 = sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"]
@@ -828,13 +843,13 @@ class UNetModel(nn.Module):
                 with nb_.site(prefix + "out_layers"):
                     out = nb_.gn_conv(h1, None, h, w, g2, b2, 1e-5, P[prefix + "c2"], P.get(prefix + "c2#wg"),
                                       sd[prefix + "out_layers.3.bias"], residual=skip, out=skip.view(n, h, w, m.cout), stats=True,
-                                      wf=P.get(prefix + "c2#f"), u_ps=P.get(prefix + "c2#wg" + psfx()), wp_ps=P.get(prefix + "c2#pc2"))
+                                      wf=P.get(prefix + "c2#f"), u_ps=P.get(prefix + "c2#wg" + psfx()), wp_ps=P.get(prefix + "c2#pc2"), film=film)
             else:
                 assert x1 is None
                 with nb_.site(prefix + "out_layers"):
                     out = nb_.gn_conv(h1, None, h, w, g2, b2, 1e-5, P[prefix + "c2"], P.get(prefix + "c2#wg"),
                                       sd[prefix + "out_layers.3.bias"], residual=x0, stats=True, wf=P.get(prefix + "c2#f"),
-                                      u_ps=P.get(prefix + "c2#wg" + psfx()), wp_ps=P.get(prefix + "c2#pc2"))
+                                      u_ps=P.get(prefix + "c2#wg" + psfx()), wp_ps=P.get(prefix + "c2#pc2"), film=film)
             nb_.release(h1)
             return out
 
@@ -977,7 +992,8 @@ class UNetModel(nn.Module):
         pg = self._programs.get(key)
         if pg is None:
             from . import unet_small
-            if self._heads32 and unet_small.wants_small_route(policy_n, H, W_, L_ctx):
+            plain = self._heads32 and not self.use_scale_shift_norm and self.num_classes is None
+            if plain and unet_small.wants_small_route(policy_n, H, W_, L_ctx):
                 # batch 1-2 (the reference's shipped talking-face mode): the program cut for few dependent launches
                 pg = unet_small.build_small(self, n, H, W_, L_ctx, c_concat, policy_n)
             else:
@@ -991,7 +1007,7 @@ class UNetModel(nn.Module):
         `c_concat` (N, C2, H, W) is concatenated to x on the channel axis inside the first conv (the TF
         DiffusionWrapper does `torch.cat([x] + c_concat, 1)`, ddpm2cond.py:1309); passing an already
         concatenated x works too."""
-        assert y is None, "class-conditional (y) UNets are not part of this path"
+        assert (y is not None) == (self.num_classes is not None), "must specify y if and only if the model is class-conditional"   # openaimodel.py:720-722
         if context is None and self.use_spatial_transformer:
             raise L.LdmkError("UNetModel.forward: context is required (the reference raises a shape error for "
                               "context=None when context_dim != inner dim, attention.py:174-175)")
@@ -1012,6 +1028,9 @@ class UNetModel(nn.Module):
             pg.inputs["t"].copy_(timesteps.to(torch.int64))
             if L_ctx:
                 pg.inputs["context"].copy_(context.reshape(n * L_ctx, self.context_dim))
+            if y is not None:
+                assert y.shape == (n,)
+                pg.inputs["y_emb"].copy_(self.label_emb.weight.detach().float()[y.to(torch.int64)])
             pg.ctx_program.run()
             pg.run()
             if torch.cuda.is_current_stream_capturing():

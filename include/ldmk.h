@@ -326,6 +326,10 @@ int ldmk_ln_stats_split(const float* x, int rows, int C, float eps, float* stats
  *   instead of 9 x (N / tile) times inside the following 3x3 convolution's operand staging. */
 int ldmk_gn_apply(const float* x0, int c0, const float* x1, int c1, const float* coef, float* y, int n, int hw,
                   int silu, void* stream);
+/* use_scale_shift_norm (openaimodel.py:267-271: h = out_norm(h) * (1 + scale) + shift, (scale, shift) = the halves of the
+ * ResBlock's emb_layers output): folds a per-sample [n][ld] vector (scale at column 0, shift at column c) into the coefficient
+ * planes coef[n][2][c] of ldmk_gn_finalize, in place. */
+int ldmk_gn_coef_film(float* coef, const float* emb, int ld, int n, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * ldmk_post: everything that sits BETWEEN two GEMMs of a ResBlock / transformer block, as one launch -- the small-batch

@@ -148,13 +148,18 @@ def gn_silu(x, w, b, eps=1e-5, silu=True, groups=32):
     return F.silu(y) if silu else y
 
 
-def resblock(sd, p, x, emb):
-    """ResBlock._forward (no up/down, no scale-shift): openaimodel.py:255-275."""
+def resblock(sd, p, x, emb, scale_shift=False):
+    """ResBlock._forward (no up/down): openaimodel.py:255-275; scale_shift = use_scale_shift_norm (:267-271)."""
     h = gn_silu(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"])
     h = F.conv2d(h, sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=1)
     e = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"])
-    h = h + e[:, :, None, None]
-    h = gn_silu(h, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"])
+    if scale_shift:
+        scale, shift = torch.chunk(e[:, :, None, None], 2, dim=1)
+        h = F.group_norm(h.float(), 32, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"], 1e-5).type(h.dtype) * (1 + scale) + shift
+        h = F.silu(h)
+    else:
+        h = h + e[:, :, None, None]
+        h = gn_silu(h, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"])
     h = F.conv2d(h, sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
     if p + "skip_connection.weight" in sd:
         x = F.conv2d(x, sd[p + "skip_connection.weight"], sd[p + "skip_connection.bias"])
@@ -209,7 +214,7 @@ def spatial_transformer(sd, p, x, context, heads, depth=1):
     return x + x_in
 
 
-def attention_block(sd, p, x, heads):
+def attention_block(sd, p, x, heads, new_order=False):
     """AttentionBlock._forward + QKVAttentionLegacy.forward, openaimodel.py:316-324,358-372: GroupNorm32 (eps 1e-5, no
     activation), qkv Conv1d, heads split BEFORE q/k/v ([head][q|k|v][ch] channel order), q and k each scaled by ch^-1/4,
     softmax over the keys, proj_out Conv1d, residual."""
@@ -218,7 +223,10 @@ def attention_block(sd, p, x, heads):
     qkv = F.conv1d(F.group_norm(xr.float(), 32, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5).type(xr.dtype),
                    sd[p + "qkv.weight"], sd[p + "qkv.bias"])
     ch = c // heads
-    q, k, v = qkv.reshape(b * heads, 3 * ch, h * w).split(ch, dim=1)
+    if new_order:      # QKVAttention (use_new_attention_order, openaimodel.py:379-407): q | k | v first, heads inside each
+        q, k, v = (t.reshape(b * heads, ch, h * w) for t in qkv.chunk(3, dim=1))
+    else:
+        q, k, v = qkv.reshape(b * heads, 3 * ch, h * w).split(ch, dim=1)
     scale = 1 / math.sqrt(math.sqrt(ch))
     weight = torch.softmax(torch.einsum("bct,bcs->bts", q * scale, k * scale).float(), dim=-1).type(qkv.dtype)
     a = torch.einsum("bts,bcs->bct", weight, v).reshape(b, c, h * w)
@@ -232,11 +240,11 @@ def _run_layers(sd, cfg, prefix, layers, h, emb, context):
         if l[0] == "conv":
             h = F.conv2d(h, sd[p + "weight"], sd[p + "bias"], padding=1)
         elif l[0] == "res":
-            h = resblock(sd, p, h, emb)
+            h = resblock(sd, p, h, emb, bool(cfg.get("use_scale_shift_norm", False)))
         elif l[0] == "st":
             h = spatial_transformer(sd, p, h, context, l[2], cfg.get("transformer_depth", 1))
         elif l[0] == "attn":
-            h = attention_block(sd, p, h, l[2])
+            h = attention_block(sd, p, h, l[2], bool(cfg.get("use_new_attention_order", False)))
         elif l[0] == "down":   # Downsample, openaimodel.py:150-160
             h = F.conv2d(h, sd[p + "op.weight"], sd[p + "op.bias"], stride=2, padding=1)
         elif l[0] == "up":     # Upsample, openaimodel.py:107-118
@@ -245,13 +253,16 @@ def _run_layers(sd, cfg, prefix, layers, h, emb, context):
     return h
 
 
-def unet_forward(sd, cfg, x, timesteps, context=None):
-    """UNetModel.forward, openaimodel.py:710-742."""
+def unet_forward(sd, cfg, x, timesteps, context=None, y=None):
+    """UNetModel.forward, openaimodel.py:710-742 (y: class labels of a num_classes UNet, :726-728)."""
     lay = unet_layout(cfg)
     wdt = sd["time_embed.0.weight"].dtype      # float32 (the reference's self.dtype); float64 only in gradient tests
     t_emb = timestep_embedding(timesteps, cfg["model_channels"]).to(wdt)
     emb = F.linear(t_emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
     emb = F.linear(F.silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    assert (y is not None) == (cfg.get("num_classes") is not None), "must specify y if and only if the model is class-conditional"
+    if y is not None:
+        emb = emb + sd["label_emb.weight"][y]
     hs = []
     h = x.to(wdt)                              # h = x.type(self.dtype), openaimodel.py:728
     for i, layers in enumerate(lay["input"]):

@@ -21,13 +21,13 @@ import numpy as np
 
 
 # ----------------------------------------------------------------------------- key enumeration
-def _resblock(keys, p, cin, cout, emb_ch):
+def _resblock(keys, p, cin, cout, emb_ch, scale_shift=False):
     keys[p + "in_layers.0.weight"] = (cin,)
     keys[p + "in_layers.0.bias"] = (cin,)
     keys[p + "in_layers.2.weight"] = (cout, cin, 3, 3)
     keys[p + "in_layers.2.bias"] = (cout,)
-    keys[p + "emb_layers.1.weight"] = (cout, emb_ch)
-    keys[p + "emb_layers.1.bias"] = (cout,)
+    keys[p + "emb_layers.1.weight"] = ((2 if scale_shift else 1) * cout, emb_ch)      # use_scale_shift_norm: (scale | shift), openaimodel.py:218-224
+    keys[p + "emb_layers.1.bias"] = ((2 if scale_shift else 1) * cout,)
     keys[p + "out_layers.0.weight"] = (cout,)
     keys[p + "out_layers.0.bias"] = (cout,)
     keys[p + "out_layers.3.weight"] = (cout, cout, 3, 3)
@@ -146,6 +146,8 @@ def unet_param_shapes(cfg):
     keys["time_embed.0.bias"] = (emb,)
     keys["time_embed.2.weight"] = (emb, emb)
     keys["time_embed.2.bias"] = (emb,)
+    if cfg.get("num_classes") is not None:
+        keys["label_emb.weight"] = (cfg["num_classes"], emb)       # openaimodel.py:513-514
     lay = unet_layout(cfg)
 
     def emit(prefix, layers):
@@ -155,7 +157,7 @@ def unet_param_shapes(cfg):
                 keys[p + "weight"] = (l[2], l[1], 3, 3)
                 keys[p + "bias"] = (l[2],)
             elif l[0] == "res":
-                _resblock(keys, p, l[1], l[2], emb)
+                _resblock(keys, p, l[1], l[2], emb, bool(cfg.get("use_scale_shift_norm", False)))
             elif l[0] == "st":
                 _spatial_transformer(keys, p, l[1], l[2], l[3], depth, cd)
             elif l[0] == "attn":
@@ -338,6 +340,10 @@ NS_UNET = dict(FR_UNET, image_size=64, in_channels=4, out_channels=4)
 # 2 / 4 heads of 64 at 128 / 256 channels
 H40_UNET = dict(image_size=16, in_channels=3, out_channels=3, model_channels=160, attention_resolutions=[1, 2], num_res_blocks=1,
                 channel_mult=[1, 2], num_heads=4, use_spatial_transformer=True, transformer_depth=1, context_dim=512)
+# a class-conditional ('adm') UNet with the other reference kwargs no shipped YAML sets: use_scale_shift_norm (FiLM through the second
+# GroupNorm), num_classes (label embedding added to the timestep embedding), use_new_attention_order (QKVAttention)
+ADM_UNET = dict(image_size=16, in_channels=3, out_channels=3, model_channels=64, attention_resolutions=[1, 2], num_res_blocks=1,
+                channel_mult=[1, 2], num_head_channels=32, use_scale_shift_norm=True, num_classes=10, use_new_attention_order=True)
 H64_UNET = dict(image_size=16, in_channels=3, out_channels=3, model_channels=128, attention_resolutions=[1, 2], num_res_blocks=1,
                 channel_mult=[1, 2], num_head_channels=64, use_spatial_transformer=True, transformer_depth=1, context_dim=512)
 # BASELINE configs[0] as worded: a genuinely UNCONDITIONAL LDM (cond_stage_config "__is_unconditional__" -> conditioning_key None,

@@ -69,7 +69,7 @@ def test_state_dict_keys_equal_reference_enumeration():
 def test_unsupported_options_fail_loudly():
     from dsml_thesis_amd.unet import UNetModel
     from dsml_thesis_amd.autoencoder import VQModelInterface
-    for bad in (dict(dims=3), dict(resblock_updown=True), dict(use_new_attention_order=True), dict(use_fp16=True),
+    for bad in (dict(dims=3), dict(resblock_updown=True), dict(n_embed=8), dict(use_fp16=True),
                 dict(num_head_channels=48)):       # (160 channels do not split into whole heads of 48)
         with pytest.raises(NotImplementedError):
             UNetModel(**dict(W.FR_UNET, **bad))

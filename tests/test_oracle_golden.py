@@ -376,3 +376,14 @@ def test_g14_head_widths_and_original_steps():
         for index in (0, 1, 437, 999):
             xp, p0 = O.p_sample_ddim_original(xs, eps, index, tabs, T(g[f"orig_eta{eta:g}_i{index}_noise"]))
             assert np.array_equal(xp.numpy(), g[f"orig_eta{eta:g}_i{index}_x_prev"]) and np.array_equal(p0.numpy(), g[f"orig_eta{eta:g}_i{index}_pred_x0"])
+
+
+def test_g14_class_conditional_unet_with_scale_shift_norm_and_new_attention_order():
+    """g14 `adm_eps`: the real UNetModel with use_scale_shift_norm, num_classes = 10 (label embedding added to the timestep
+    embedding: the 'adm' conditioning key) and use_new_attention_order (QKVAttention) -- openaimodel.py:267-271,513-514,726-728,379-407."""
+    g = golden("g14_variants.npz")
+    sd = recipe(W.unet_param_shapes(W.ADM_UNET))
+    x, t, y = rnd(153, 2, 3, 16, 16), torch.tensor([3, 512]), torch.tensor([7, 2])
+    close(O.unet_forward(sd, W.ADM_UNET, x, t, None, y=y), g["adm_eps"], 2e-5, 2e-5)
+    with pytest.raises(AssertionError):
+        O.unet_forward(sd, W.ADM_UNET, x, t, None)

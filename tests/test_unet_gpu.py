@@ -494,6 +494,30 @@ def test_unet_attention_heads_that_are_not_32_wide(tag, cfg):
     close(m(x.cuda(), t.cuda(), context=ctx.cuda()), g[tag + "_eps"], 3e-5, 3e-5)
 
 
+def test_class_conditional_unet_with_scale_shift_norm_and_new_attention_order():
+    """Reference kwargs that raised NotImplementedError through round 4: `use_scale_shift_norm` (the timestep embedding modulates the
+    second GroupNorm of every ResBlock, openaimodel.py:267-271 -- here a per-sample edit of that norm's coefficient planes,
+    ldmk_gn_coef_film), `num_classes` (label embedding added to the timestep embedding, :513-514,726-728; DiffusionWrapper's 'adm'
+    key, ddpm.py:1417-1420) and `use_new_attention_order` (QKVAttention, :379-407).  eps against the REAL reference's output (g14)."""
+    from dsml_thesis_amd.ddpm import DiffusionWrapper
+    g = golden("g14_variants.npz")
+    m, sd = make_unet(W.ADM_UNET)
+    x, t, y = rnd(153, 2, 3, 16, 16), torch.tensor([3, 512]), torch.tensor([7, 2])
+    eps = m(x.cuda(), t.cuda(), y=y.cuda())
+    names = [c[3] for c in m.program(2, 16, 16, 0, 0).calls]
+    assert names.count("ldmk_gn_coef_film") == 8 and "ldmk_axpy" in names
+    close(eps, g["adm_eps"], 3e-5, 3e-5)
+    m.policy_batch = 16
+    close(m(x.cuda(), t.cuda(), y=y.cuda()), g["adm_eps"], 3e-5, 3e-5)
+    with pytest.raises(AssertionError, match="class-conditional"):
+        m(x.cuda(), t.cuda())
+    # through the wrapper: conditioning_key 'adm' hands the conditioning over as y
+    w = DiffusionWrapper.__new__(DiffusionWrapper)
+    torch.nn.Module.__init__(w)
+    w.diffusion_model, w.conditioning_key = m, "adm"
+    close(w(x.cuda(), t.cuda(), c_crossattn=[y.cuda()]), g["adm_eps"], 3e-5, 3e-5)
+
+
 def test_attention_block_golden_through_the_launch_program():
     """AttentionBlock(160, 5 heads x 32) at 8x8 (openaimodel.py:278-324, QKVAttentionLegacy :347-372) against the reference's
     output (g13 `attention_block`), emitted by the function UNetModel._build calls for the unconditional UNet: GroupNorm folded
@@ -539,7 +563,7 @@ def test_unconditional_unet_golden(policy):
         m(x.cuda(), t.cuda(), context=torch.zeros(2, 1, 512, device="cuda"))
     with pytest.raises(NotImplementedError):
         from dsml_thesis_amd.unet import UNetModel
-        UNetModel(**dict(W.UNCOND_UNET, use_scale_shift_norm=True))
+        UNetModel(**dict(W.UNCOND_UNET, resblock_updown=True))
 
 
 def test_unet_multi_token_context_vs_oracle():

@@ -855,6 +855,13 @@ def gen_variants():
         ref3 = m(x, t, context=ctx3)
         check(f"UNet eps, {tag}, 3 context tokens", ref3, O.unet_forward(sd, cfg, x, t, ctx3), 2e-5, 2e-5)
         g[tag + "_eps_L3"] = ref3
+    # ---- the class-conditional ('adm') UNet with use_scale_shift_norm, num_classes, use_new_attention_order (QKVAttention)
+    m = UNetModel(**W.ADM_UNET)
+    sd = load_recipe(m, seed=0, prefix_check=W.unet_param_shapes(W.ADM_UNET))
+    x, t, y = rnd(153, 2, 3, 16, 16), torch.tensor([3, 512]), torch.tensor([7, 2])
+    ref = m(x, t, y=y)
+    check("UNet eps, adm (scale-shift norm, 10 classes, QKVAttention)", ref, O.unet_forward(sd, W.ADM_UNET, x, t, None, y=y), 2e-5, 2e-5)
+    g["adm_eps"] = ref
     # ---- use_original_steps: the real sampler class of the talking-face tree around a stub model that returns a fixed eps
     for k in [k for k in sys.modules if k == "ldm" or k.startswith("ldm.") or k.startswith("taming")]:
         del sys.modules[k]
