@@ -9,6 +9,7 @@
 // the optimizer updates packed weights in place.  The output is small and the reduction long: the rows are split
 // over blockIdx.y (`splitr`) into partial slabs that a second kernel sums in a fixed order (bitwise reproducible).
 #include "ldmk_common.h"
+#include <stdlib.h>
 
 namespace ldmk {
 
@@ -207,6 +208,208 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const ldmk_wgrad_args p, con
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The bf16 weight-gradient GEMM with HARDWARE-TRANSPOSED fragment reads (round 5; BASELINE configs[4]).  The MFMA's K index is the
+// token ROW r, which is the slow index of both operands as they lie in HBM ([r][kw] and [r][n] rows).  wgrad_kernel<BF = true>
+// staged fp32 slices and gathered every bf16 fragment with eight strided ds_read_b32 + eight conversions: 96 LDS reads and 96
+// v_cvt per ten MFMAs on the 128x160 tile -- the matrix pipe idled behind them (62 us per launch, 10 ms of the 60 ms step).
+// Here the slices are rounded to bf16 ONCE while they are staged (row-major [r][col] images, 8-byte stores) and gfx950's
+// ds_read_b64_tr_b16 delivers them column-major: per 16-lane group a block of 4 rows x 16 columns, lane i receiving column i --
+// two reads make the 8 consecutive r of one column a 32x32x16 operand wants (lane = column, half-wave = which 8 rows).  Row
+// strides of 64 x odd bytes keep the four rows of a half-wave's read on disjoint banks.  Two LDS buffers, one barrier per
+// 32-row slice, the next slice's global loads in flight under the MFMAs.  Same split over blockIdx.y, same fixed-order slab
+// reduce, same output layout as wgrad_kernel; the bias gradient (column sums of dY) is accumulated in fp32 from the registers
+// the slices pass through and combined once at the end in a fixed order.
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+typedef short ws16x8 __attribute__((ext_vector_type(8)));
+constexpr int wg_tr_stride(int cols) {             // bf16 elements per LDS row: the smallest 64 x odd bytes >= 2 cols
+  int k = (cols * 2 + 63) / 64;
+  if (k % 2 == 0) ++k;
+  return k * 32;
+}
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const ldmk_wgrad_args p, const int splitr, float* __restrict__ ws) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int AS = wg_tr_stride(BM), BS = wg_tr_stride(BN);
+  constexpr int NA = BM / 32, NB = BN / 32;         // float4 per thread per 32-row slice
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) __bf16 At[2][32 * AS];
+  __shared__ __attribute__((aligned(16))) __bf16 Bt[2][32 * BS];
+  __shared__ __attribute__((aligned(16))) float4 bpart[NB * 256];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, half = lane >> 5;
+  const int tiles_m = (p.Kw + BM - 1) / BM;
+  const int m0 = (blockIdx.x % tiles_m) * BM, n0 = (blockIdx.x / tiles_m) * BN;
+  const int ks = blockIdx.y, bz = blockIdx.z;
+  const float* __restrict__ ap = p.a + (long long)bz * p.a_bstride;
+  const float* __restrict__ dyp = p.dy + (long long)bz * p.dy_bstride;
+  const bool conv = p.a_mode == LDMK_A_CONV3X3;
+  const int rps = p.out_h * p.out_w;
+  const int rps_shift = (rps & (rps - 1)) == 0 ? __ffs(rps) - 1 : -1;
+  const int ow_shift = (p.out_w & (p.out_w - 1)) == 0 ? __ffs(p.out_w) - 1 : -1;
+  const int iters_all = (p.R + 31) / 32;
+  const int it_per = (iters_all + splitr - 1) / splitr;
+  const int it_begin = ks * it_per, it_end = min(iters_all, it_begin + it_per);
+
+  int a_rl[NA], a_col[NA], a_ch[NA], a_dy[NA], a_dx[NA];
+  bool a_ok[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int idx = tid + 256 * i;
+    a_rl[i] = idx / (BM / 4);
+    a_col[i] = (idx - a_rl[i] * (BM / 4)) * 4;
+    const int kw = m0 + a_col[i];
+    a_ok[i] = kw < p.Kw;
+    if (conv) {
+      const int chunk = kw >> 5, cc = chunk / 9, tap = chunk - cc * 9;
+      a_ch[i] = cc * 32 + (kw & 31);
+      a_dy[i] = tap / 3;
+      a_dx[i] = tap - a_dy[i] * 3;
+    } else {
+      a_ch[i] = kw; a_dy[i] = 0; a_dx[i] = 0;
+    }
+  }
+  int b_rl[NB], b_col[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int idx = tid + 256 * i;
+    b_rl[i] = idx / (BN / 4);
+    b_col[i] = (idx - b_rl[i] * (BN / 4)) * 4;
+  }
+  float4 areg[NA], breg[NB], bsum[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto a_elem_ptr = [&](int r, int ch, int ddy, int ddx) -> const float* {
+    if (!conv) return ap + (long long)r * p.lda + ch;
+    int n, pix, oy, ox;
+    if (rps_shift >= 0) { n = r >> rps_shift; pix = r & (rps - 1); } else { n = r / rps; pix = r - n * rps; }
+    if (ow_shift >= 0) { oy = pix >> ow_shift; ox = pix & (p.out_w - 1); } else { oy = pix / p.out_w; ox = pix - oy * p.out_w; }
+    int iy = oy * p.stride - p.pad_lo + ddy, ix = ox * p.stride - p.pad_lo + ddx;
+    const int lim_h = p.upsample ? 2 * p.in_h : p.in_h, lim_w = p.upsample ? 2 * p.in_w : p.in_w;
+    if (iy < 0 || ix < 0 || iy >= lim_h || ix >= lim_w) return nullptr;
+    if (p.upsample) { iy >>= 1; ix >>= 1; }
+    return ap + ((long long)(n * p.in_h + iy) * p.in_w + ix) * p.c + ch;
+  };
+  auto load_slice = [&](int it) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int r = it * 32 + a_rl[i];
+      if (a_ok[i] && r < p.R) {
+        const float* src = a_elem_ptr(r, a_ch[i], a_dy[i], a_dx[i]);
+        if (src) v = *reinterpret_cast<const float4*>(src);
+      }
+      areg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int r = it * 32 + b_rl[i], n = n0 + b_col[i];
+      if (r < p.R && n < p.N) v = *reinterpret_cast<const float4*>(dyp + (long long)r * p.ldy + n);
+      breg[i] = v;
+    }
+  };
+  auto store_slice = [&](int buf) {                 // rounded to bf16 (RNE) once, here
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      *reinterpret_cast<wbf16x4*>(&At[buf][a_rl[i] * AS + a_col[i]]) = wbf16x4{(__bf16)areg[i].x, (__bf16)areg[i].y, (__bf16)areg[i].z, (__bf16)areg[i].w};
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      *reinterpret_cast<wbf16x4*>(&Bt[buf][b_rl[i] * BS + b_col[i]]) = wbf16x4{(__bf16)breg[i].x, (__bf16)breg[i].y, (__bf16)breg[i].z, (__bf16)breg[i].w};
+      bsum[i].x += breg[i].x; bsum[i].y += breg[i].y; bsum[i].z += breg[i].z; bsum[i].w += breg[i].w;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposed-read addressing: 16-lane group g = lane / 16 reads the block of rows 8 (g / 2) + {0..3} (+ 4 for the second
+  // read), columns 16 (g % 2) + {0..15} of an operand tile; lane 4 q + p of the group supplies row q, columns 4 p .. 4 p + 3
+  const int g16 = lane >> 4, j16 = lane & 15;
+  const int tr_row = 8 * (g16 >> 1) + (j16 >> 2), tr_col = 16 * (g16 & 1) + 4 * (j16 & 3);
+  const int a_off = tr_row * AS + wm * (32 * TM) + tr_col;
+  const int b_off = tr_row * BS + wn * (32 * TN) + tr_col;
+  auto tr8 = [](const __bf16* q, int stride4) -> wbf16x8 {       // rows +0..3 and +4..7 of this lane's column
+    const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ws16x4 __attribute__((address_space(3)))*)(q));
+    const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ws16x4 __attribute__((address_space(3)))*)(q + stride4));
+    return __builtin_bit_cast(wbf16x8, ws16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+  };
+
+  if (it_begin < it_end) {
+    load_slice(it_begin);
+    store_slice(0);
+  }
+  __syncthreads();
+  for (int it = it_begin; it < it_end; ++it) {
+    const int buf = (it - it_begin) & 1;
+    const bool more = it + 1 < it_end;
+    if (more) load_slice(it + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      wbf16x8 a8[TM], b8[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a8[i] = tr8(&At[buf][a_off + 16 * s * AS + 32 * i], 4 * AS);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b8[j] = tr8(&Bt[buf][b_off + 16 * s * BS + 32 * j], 4 * BS);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_slice(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int rowbase = m0 + wm * (32 * TM), colbase = n0 + wn * (32 * TN);
+  const int srows = p.Kw + (p.dbias ? 1 : 0);
+  if (p.dbias != nullptr && m0 == 0) {              // (workgroup-uniform) bias gradient: column sums of dY, fixed order
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bpart[i * 256 + tid] = bsum[i];
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float t = 0.f;
+      for (int rl = 0; rl < 32; ++rl) {
+        const int idx = rl * (BN / 4) + (tid >> 2);
+        t += reinterpret_cast<const float*>(&bpart[(idx >> 8) * 256 + (idx & 255)])[tid & 3];
+      }
+      if (splitr > 1) ws[(((long long)bz * splitr + ks) * srows + p.Kw) * p.N + n0 + tid] = t;
+      else p.dbias[n0 + tid] = p.accumulate ? p.dbias[n0 + tid] + p.alpha * t : p.alpha * t;
+    }
+  }
+  float* dst;
+  long long ld;
+  if (splitr > 1) {
+    dst = ws + ((long long)bz * splitr + ks) * srows * p.N;
+    ld = p.N;
+  } else {
+    dst = p.dw + (long long)bz * p.dw_bstride;
+    ld = p.ldw;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = colbase + j * 32 + l31;
+    if (col >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < p.Kw) {
+          float* d = dst + (long long)row * ld + col;
+          if (splitr > 1) *d = acc[i][j][r];
+          else *d = p.accumulate ? *d + p.alpha * acc[i][j][r] : p.alpha * acc[i][j][r];
+        }
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ldmk_wgrad_args p, const int splitr,
                                                            const float* __restrict__ ws) {
   const int n4 = p.N / 4;
@@ -243,7 +446,11 @@ static int launch_wgrad_t(const ldmk_wgrad_args& a, int splitr, hipStream_t st) 
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   const int tiles = ((a.Kw + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const int nb = a.batch > 1 ? a.batch : 1;
-  hipLaunchKernelGGL((wgrad_kernel<TM, TN, WM, WN, BF>), dim3(tiles, splitr, nb), dim3(256), 0, st, a, splitr, a.ws);
+  static const bool tr = [] { const char* e = getenv("LDMK_WGRAD_TR"); return !e || atoi(e) != 0; }();      // (=0: the round-2 gather, A/B only)
+  if (BF && tr)
+    hipLaunchKernelGGL((wgrad_tr_kernel<TM, TN, WM, WN>), dim3(tiles, splitr, nb), dim3(256), 0, st, a, splitr, a.ws);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<TM, TN, WM, WN, BF>), dim3(tiles, splitr, nb), dim3(256), 0, st, a, splitr, a.ws);
   if (splitr > 1) {
     long long total = (long long)(a.Kw + (a.dbias ? 1 : 0)) * (a.N / 4);
     int g = (int)((total + 255) / 256);
