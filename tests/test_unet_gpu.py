@@ -159,6 +159,7 @@ def test_unet_winograd_route_against_the_reference_fixtures(monkeypatch):
     from dsml_thesis_amd.engine import NetBuilder
     monkeypatch.setattr(NetBuilder, "WINO_MIN_TILES", 1)
     monkeypatch.setattr(NetBuilder, "UP_MIN_PIXELS", 1)
+    monkeypatch.setenv("LDMK_PSC", "0")      # (round 5: no conv-mode pre-split tile here -- this test is about the Winograd route)
     g = golden("g4_unet_fr.npz")
     m, _ = make_unet(W.FR_UNET)
     m.policy_batch = 16                      # the batched program (batch 1-2 jobs take the small-batch route)
@@ -589,9 +590,9 @@ def test_unet_rejects_unsupported():
     from dsml_thesis_amd.unet import UNetModel
     from dsml_thesis_amd import lib as L
     with pytest.raises(NotImplementedError):
-        UNetModel(**dict(W.FR_UNET, use_scale_shift_norm=True))
+        UNetModel(**dict(W.FR_UNET, resblock_updown=True))
     with pytest.raises(NotImplementedError):
-        UNetModel(**dict(W.FR_UNET, num_classes=10))
+        UNetModel(**dict(W.FR_UNET, n_embed=8))
     m, _ = make_unet(W.FR_UNET)
     with pytest.raises(L.LdmkError):
         m(torch.zeros(1, 3, 32, 32), torch.zeros(1, dtype=torch.long), context=torch.zeros(1, 1, 512))
