@@ -422,6 +422,22 @@ def end_to_end_leg(dev, latent, batch, ddim_steps=200):
                                     "decode_frames_per_s": round(batch / (t2 - t1), 1), "shape": list(x.shape)}
     res["workload"] = (f"class-conditional faces, {batch} samples, DDIM-{ddim_steps}, {latent}x{latent}x{ucfg['in_channels']} latent -> "
                        f"{x.shape[1]}x{x.shape[2]} frames, ema_scope, sample() + decode_first_stage + clamp")
+    # BASELINE configs[0] on the GPU: DDIM 50 steps, batch 1, this latent, every call inside its own ema_scope (the per-call fixed
+    # costs -- schedule, scope enter / exit, flag read -- weigh most here); the model's null-class token as conditioning
+    lab1 = torch.zeros(1, 1, dtype=torch.long, device=dev)
+    ts = []
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with model.ema_scope():
+            uc1 = model.cond_stage_model.uncond_embedding(lab1)
+            z1, _ = sampler.sample(S=50, batch_size=1, shape=[ucfg["in_channels"], latent, latent], conditioning=uc1, eta=0.0, verbose=False,
+                                   use_graph=True)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    assert torch.isfinite(z1).all()
+    res["config0_ddim50_batch1"] = {"seconds": round(min(ts[1:]), 4), "first_call_seconds": round(ts[0], 4), "ms_per_step": round(1e3 * min(ts[1:]) / 50, 3),
+                                    "workload": f"`with ema_scope(): sample(S=50, batch_size=1)` at {latent}x{latent}x{ucfg['in_channels']}, scope + schedule + 50 graph-replayed steps"}
     return res
 
 

@@ -21,6 +21,7 @@
 //     are bitwise reproducible.  That is what keeps 256 CUs busy on the low-resolution layers
 //     (M = 64 rows per sample at 8x8, K up to 9*1280).
 #include "ldmk_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 // Diagnostic build only (tools/igemm_probe.hip defines LDMK_IG_STAMPS): per-wave cycle totals of the main loop's phases
@@ -88,7 +89,7 @@ __device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf
 // B's: no split arithmetic per N-tile (a GEGLU projection re-split every A element N/BN = 8..40 times), 6 + 8 loads and
 // LDS stores per thread and slice instead of 4 + 8 loads, ~90 vector operations and 12 + 8 stores.
 template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0, bool FG = true, bool ASP = false>
-__global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int nfast) {
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   // BF = 2: plain bf16 compute (one image) with the weights PRE-PACKED like the split form's -- bf16, transposed, K-contiguous
@@ -135,8 +136,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (bid % tiles_m) * BM;
-  const int n0 = (bid / tiles_m) * BN;
+  // (nfast, round 5: the column tiles of one row tile adjacent on an XCD -- they share the A tile in its L2; csrc/igemm_ps.hip)
+  const int m0 = nfast ? (bid / tiles_n) * BM : (bid % tiles_m) * BM;
+  const int n0 = nfast ? (bid % tiles_n) * BN : (bid / tiles_m) * BN;
   const int ks = blockIdx.y;            // cross-workgroup K split index
   const int bz = blockIdx.z;
 
@@ -1148,7 +1150,10 @@ static int launch_cfg_g(const ldmk_igemm_args& a, int splitk, float* ws, hipStre
   dim3 grid(tiles, splitk, a.batch > 1 ? a.batch : 1);
   auto k = igemm_kernel<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG, ASP>;
   cfg_set_attr<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG, ASP>();
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, splitk, ws);
+  static const int nfast_env = [] { const char* e = getenv("LDMK_IG_NFAST"); return e ? atoi(e) : 1; }();
+  // tall problems only (M >> N: activations x a weight matrix); weight-gradient-like or b_trans shapes keep the old order
+  const int nfast = nfast_env && !a.b_trans && (a.N + BN - 1) / BN > 1 && (a.M + BM - 1) / BM >= 8;
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, splitk, ws, nfast);
   if (splitk > 1 && !a.splitk_counters && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
   // (splitk_counters: the last-arriving workgroup of each tile combined the slabs and ran the epilogue inside the launch;
   //  raw_slabs: the consumer sums the slabs)

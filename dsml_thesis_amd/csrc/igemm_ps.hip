@@ -432,7 +432,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
 }
 
 template <int NWM, int NWN, int TM, int TN, int NS, bool TR, int PL = 3, bool KV = false>
-__global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int dbg_arg) {
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int dbg_arg, const int nfast) {
   const int dbg = PS_PROBES ? dbg_arg : 0;        // (what-if switches: probe builds only, see PS_PROBES)
   constexpr int NW = NWM * NWN;
   constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN;
@@ -450,8 +450,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (bid % tiles_m) * BM;
-  const int n0 = (bid / tiles_m) * BN;
+  // Which operand the neighbouring workgroups of an XCD share in its L2 (round 5).  These problems are tall (M >> N): the weights
+  // are small and L2-resident whatever the order, the A tile is what every column tile re-reads -- with the column tiles of one
+  // row tile adjacent (nfast), A comes over the fabric once instead of once per column tile (GEGLU at 64x64: 5x).
+  const int m0 = nfast ? (bid / tiles_n) * BM : (bid % tiles_m) * BM;
+  const int n0 = nfast ? (bid % tiles_n) * BN : (bid / tiles_m) * BN;
   const int ks = blockIdx.y, bz = blockIdx.z;
 
   const int nkc = p.K / 32;
@@ -918,8 +921,10 @@ static int ps_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const int dbg = ps_probe_bits();
   static_assert(!KV || (size_t)NWM * NWN * 32 * 33 * 4 <= lds, "V^T transpose scratch fits the ring");
+  static const int nfast_env = [] { const char* e = getenv("LDMK_PS_NFAST"); return e ? atoi(e) : 1; }();
+  const int nfast = nfast_env && (a.N + BN - 1) / BN > 1 && (a.M + BM - 1) / BM >= 8;        // (a few row tiles only: the old order)
   hipLaunchKernelGGL((igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR, PL, KV>), dim3(tiles, splitk, a.batch > 1 ? a.batch : 1), dim3(64 * NWM * NWN), lds,
-                     st, a, splitk, ws, dbg);
+                     st, a, splitk, ws, dbg, nfast);
   if (splitk > 1 && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
   return check_launch("ldmk_igemm(ps)");
 }
@@ -955,7 +960,7 @@ static int pw_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_
 // keeps the ring buffer index static too.  Same products in the same order into every accumulator as igemm_kernel<BF = 4> on
 // tile_cfg 5 / 1: bitwise equal at equal splitk (a K split must fall on chunk boundaries: splitk divides C / 32).
 template <int NWM, int NWN, int TM, int TN, bool TR>
-__global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_psc_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws) {
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_psc_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int nfast) {
   constexpr int PL = 2, NS = 3;
   constexpr int NW = NWM * NWN;
   constexpr int BM = 32 * TM * NWM, BN = 32 * TN * NWN;
@@ -973,8 +978,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_psc_kernel(const ldmk
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (bid % tiles_m) * BM;
-  const int n0 = (bid / tiles_m) * BN;
+  const int m0 = nfast ? (bid / tiles_n) * BM : (bid % tiles_m) * BM;       // (see igemm_ps_kernel: column tiles of a row tile adjacent)
+  const int n0 = nfast ? (bid % tiles_n) * BN : (bid / tiles_m) * BN;
   const int ks = blockIdx.y;
 
   const int C = p.c0;
@@ -1133,7 +1138,9 @@ static int psc_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream
     attr = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL((igemm_psc_kernel<NWM, NWN, TM, TN, TR>), dim3(tiles, splitk, 1), dim3(64 * NWM * NWN), lds, st, a, splitk, ws);
+  static const int nfast_env = [] { const char* e = getenv("LDMK_PS_NFAST"); return e ? atoi(e) : 1; }();
+  const int nfast = nfast_env && (a.N + BN - 1) / BN > 1 && (a.M + BM - 1) / BM >= 8;
+  hipLaunchKernelGGL((igemm_psc_kernel<NWM, NWN, TM, TN, TR>), dim3(tiles, splitk, 1), dim3(64 * NWM * NWN), lds, st, a, splitk, ws, nfast);
   if (splitk > 1 && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
   return check_launch("ldmk_igemm(ps, conv)");
 }
