@@ -18,6 +18,7 @@
 //     product, provided the A operand enumerates the contraction index in the same order; the transposed image serves that
 //     order as two runs of four.
 #include "ldmk_common.h"
+#include <type_traits>
 
 namespace ldmk {
 
@@ -785,6 +786,21 @@ __device__ __forceinline__ f32x2 widen_pk_f16(unsigned u) {
   const f16x2_t v = __builtin_bit_cast(f16x2_t, u);
   return f32x2{(float)v.x, (float)v.y};
 }
+// fp16(p - h) for a pair, h = the packed fp16 images of p: p - h is exact in fp32 (h is p rounded to 11 bits), so the fused form
+// rounds once to fp16 exactly as the convert of the difference does -- v_fma_mix reads the fp16 halves in place and writes the
+// fp16 result: 2 instructions per pair instead of 2 widening converts + a packed subtract + a packed convert (the softmax side
+// of the attention loop is VALU-bound: 16 of ~150 instructions per 32-key block).  -DLDMK_H2_SPLIT_CVT: the convert form (A/B)
+__device__ __forceinline__ unsigned split_lo_pk_f16(f32x2 p, unsigned h) {
+#ifdef LDMK_H2_SPLIT_CVT
+  return cvt_pk_f16(p - widen_pk_f16(h));
+#else
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(l) : "v"(h), "v"(p.x), "v"(p.y));
+  return l;
+#endif
+}
 // 8 (already scaled) values as their two fp16 images
 __device__ __forceinline__ void split8_h2(const float* v, f16x8_t (&o)[2]) {
   u32x4a h, l;
@@ -792,7 +808,7 @@ __device__ __forceinline__ void split8_h2(const float* v, f16x8_t (&o)[2]) {
   for (int j = 0; j < 4; ++j) {
     const f32x2 p = {v[2 * j], v[2 * j + 1]};
     h[j] = cvt_pk_f16(p);
-    l[j] = cvt_pk_f16(p - widen_pk_f16(h[j]));
+    l[j] = split_lo_pk_f16(p, h[j]);
   }
   o[0] = __builtin_bit_cast(f16x8_t, h);
   o[1] = __builtin_bit_cast(f16x8_t, l);
@@ -866,7 +882,14 @@ __device__ __forceinline__ void h2_dma4(unsigned voff, const au32x4& rs, unsigne
 }
 
 // the softmax step of one 32-key block in the scaled domains: s holds 2^12 x the log2-domain scores on entry, 2^14 x the
-// probabilities on exit; m_run is kept in the scores' scaled domain, l_run sums the scaled probabilities
+// probabilities on exit; l_run sums the scaled probabilities.  The running maximum m_run lives on the INTEGER grid of the
+// unscaled log2 domain (round 5): m = ceil(2^-12 max s) >= the true maximum, so the probabilities stay <= 2^14 (the largest of a
+// row > 2^13: the fp16 images keep their precision) and
+//   - the exponent is ONE packed fma per pair, 2^-12 s + (14 - m), rounded once (14 - m is a small integer: exact) -- the
+//     subtract-then-scale form was two packed instructions and two roundings;
+//   - the rescale factor 2^(m_old - m_new) is an exact power of two (no rounding in O or l), and it is needed only when a
+//     row's maximum crosses an integer.
+// -DLDMK_H2_SOFTMAX_R4: the round-4 form (A/B)
 __device__ __forceinline__ void h2_softmax(f32x16& s, f32x16& o, float& m_run, float& l_run) {
   constexpr float INV = 1.0f / (H2_S * H2_S);
   float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
@@ -875,12 +898,21 @@ __device__ __forceinline__ void h2_softmax(f32x16& s, f32x16& o, float& m_run, f
   mx = fmaxf(mx, s[15]);
   float a, b;
   both_halves(mx, a, b);
+#ifdef LDMK_H2_SOFTMAX_R4
   const float m_new = fmaxf(fmaxf(m_run, a), b);
   const f32x2 mm2 = {m_new, m_new}, inv2 = {INV, INV}, off2 = {H2_PEXP, H2_PEXP};
+#else
+  const float m_new = fmaxf(m_run, __builtin_ceilf(fmaxf(a, b) * INV));
+  const f32x2 inv2 = {INV, INV}, off2 = {H2_PEXP - m_new, H2_PEXP - m_new};
+#endif
   f32x2 ps = {0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
+#ifdef LDMK_H2_SOFTMAX_R4
     f32x2 d = (f32x2{s[2 * i], s[2 * i + 1]} - mm2) * inv2 + off2;      // (s - m) exact, x 2^-12 exact, + 14: one rounding
+#else
+    f32x2 d = __builtin_elementwise_fma(f32x2{s[2 * i], s[2 * i + 1]}, inv2, off2);
+#endif
     d.x = __builtin_amdgcn_exp2f(d.x);
     d.y = __builtin_amdgcn_exp2f(d.y);
     s[2 * i] = d.x;
@@ -889,7 +921,11 @@ __device__ __forceinline__ void h2_softmax(f32x16& s, f32x16& o, float& m_run, f
   }
   both_halves(ps.x + ps.y, a, b);
   if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+#ifdef LDMK_H2_SOFTMAX_R4
     const float corr = __builtin_amdgcn_exp2f((m_run - m_new) * INV);
+#else
+    const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+#endif
     l_run *= corr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] *= corr;
@@ -898,10 +934,257 @@ __device__ __forceinline__ void h2_softmax(f32x16& s, f32x16& o, float& m_run, f
   l_run += a + b;
 }
 
-template <int QB>
+// One step of the PIPELINED key loop (attn_h2_fwd_kernel<2, true>): the VALU side of 32-key block b -- softmax, then the fp16
+// images of its probabilities -- with the MFMAs of its neighbours issued between the slices: first the six of P V for block b - 1
+// (operands pb / vf, into the OTHER query block's accumulator op), then the six of Q K^T for block b + 1 (into sn).  What decides
+// the order (tools/probe/valu_rate.hip, profiles/r05_valu_rate.txt): a wave's own non-packed VALU instructions run under its
+// MFMA (1 MFMA + 8 v_fma_f32: 48 clocks = the VALU side alone), a packed fp32 instruction waits for the MFMA to drain (1 MFMA +
+// 8 v_pk_fma_f32: 89 clocks), and the phase-separated loop left the matrix pipe 45 % and the VALU 61 % busy with three waves per
+// SIMD -- in sum 106 %: nothing overlapped.  Every slice is fenced (sched_barrier): the instruction order below IS the schedule.
+// The arithmetic, operation by operation and in the same order per accumulator, is that of h2_softmax / mmh3 / split8_h2: the
+// results are the same bits as the phase-separated kernel's.
+#define H2P_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define H2P_SPLIT_PAIR(H, L, I, K)                         \
+  {                                                      \
+    const f32x2 p_ = {s[2 * (K)], s[2 * (K) + 1]};       \
+    const unsigned h_ = cvt_pk_f16(p_);                  \
+    H[I] = h_;                                           \
+    L[I] = split_lo_pk_f16(p_, h_);                      \
+  }
+// (packed fp32 instructions sit at the END of a slice, behind >= 27 clocks of other work: by then the slice's MFMA has left the pipe)
+#define H2P_EXP2(K)                                        \
+  {                                                        \
+    s[2 * (K)] = __builtin_amdgcn_exp2f(d[K].x);           \
+    s[2 * (K) + 1] = __builtin_amdgcn_exp2f(d[K].y);       \
+  }
+#define H2P_SUM(K) ps += f32x2{s[2 * (K)], s[2 * (K) + 1]};
+template <bool LOADK, bool LOADV, int OFF>
+__device__ __forceinline__ void h2p_step(f32x16& s, f32x16& sn, f32x16& op, f32x16& oc, float& m_run, float& l_run, const f16x8_t (&qn)[2][2],
+                                         f16x8_t (&kf)[2][2], f16x8_t (&vf)[2][2], f16x8_t (&pb)[2][2], const unsigned char* tk,
+                                         const unsigned char* tv) {
+  constexpr float INV = 1.0f / (H2_S * H2_S);
+  if constexpr (LOADK) {                     // K of block b + 1 (its Q K^T starts at slice 6; the last reader of kf was the previous step)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) kf[t][q] = *reinterpret_cast<const f16x8_t*>(tk + (t * 2 + q) * 1024);
+  }
+  H2P_FENCE();
+  op = mmh(vf[0][1], pb[0][0], op);
+  H2P_FENCE();
+  float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+  mx = fmaxf(fmaxf(mx, s[3]), s[4]);
+  mx = fmaxf(fmaxf(mx, s[5]), s[6]);
+  mx = fmaxf(fmaxf(mx, s[7]), s[8]);
+  H2P_FENCE();
+  op = mmh(vf[0][0], pb[0][1], op);
+  H2P_FENCE();
+  mx = fmaxf(fmaxf(mx, s[9]), s[10]);
+  mx = fmaxf(fmaxf(mx, s[11]), s[12]);
+  mx = fmaxf(fmaxf(mx, s[13]), s[14]);
+  mx = fmaxf(mx, s[15]);
+  float a, b;
+  both_halves(mx, a, b);
+  H2P_FENCE();
+  op = mmh(vf[0][0], pb[0][0], op);
+  H2P_FENCE();
+  const float m_new = fmaxf(m_run, __builtin_ceilf(fmaxf(a, b) * INV));
+  const bool moved = __builtin_amdgcn_ballot_w64(m_new != m_run) != 0;
+  const f32x2 inv2 = {INV, INV}, off2 = {(float)OFF - m_new, (float)OFF - m_new};
+  f32x2 d[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d[k] = __builtin_elementwise_fma(f32x2{s[2 * k], s[2 * k + 1]}, inv2, off2);
+  H2P_FENCE();
+  op = mmh(vf[1][1], pb[1][0], op);
+  H2P_FENCE();
+  H2P_EXP2(0) H2P_EXP2(1)
+#pragma unroll
+  for (int k = 4; k < 6; ++k) d[k] = __builtin_elementwise_fma(f32x2{s[2 * k], s[2 * k + 1]}, inv2, off2);
+  H2P_FENCE();
+  op = mmh(vf[1][0], pb[1][1], op);
+  H2P_FENCE();
+  H2P_EXP2(2) H2P_EXP2(3)
+#pragma unroll
+  for (int k = 6; k < 8; ++k) d[k] = __builtin_elementwise_fma(f32x2{s[2 * k], s[2 * k + 1]}, inv2, off2);
+  f32x2 ps = {0.f, 0.f};
+  H2P_SUM(0) H2P_SUM(1)
+  H2P_FENCE();
+  op = mmh(vf[1][0], pb[1][0], op);
+  H2P_FENCE();
+  H2P_EXP2(4) H2P_EXP2(5)
+  H2P_SUM(2) H2P_SUM(3)
+  H2P_FENCE();
+  if constexpr (LOADV) {                     // V of block b (its P V runs in the next step; the six MFMAs above were vf's last readers)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) vf[t][q] = *reinterpret_cast<const f16x8_t*>(tv + (t * 2 + q) * 1024);
+  }
+  {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    sn = mmh(kf[0][1], qn[0][0], zero);
+  }
+  H2P_FENCE();
+  H2P_EXP2(6) H2P_EXP2(7)
+  H2P_SUM(4) H2P_SUM(5)
+  H2P_FENCE();
+  u32x4a h0, l0, h1, l1;
+  sn = mmh(kf[0][0], qn[0][1], sn);
+  H2P_FENCE();
+  H2P_SPLIT_PAIR(h0, l0, 0, 0)
+  H2P_SUM(6) H2P_SUM(7)
+  both_halves(ps.x + ps.y, a, b);
+  H2P_FENCE();
+  sn = mmh(kf[0][0], qn[0][0], sn);
+  H2P_FENCE();
+  if (moved) {
+    const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+    l_run *= corr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oc[r] *= corr;
+    m_run = m_new;
+  }
+  l_run += a + b;
+  H2P_SPLIT_PAIR(h0, l0, 1, 1)
+  H2P_FENCE();
+  sn = mmh(kf[1][1], qn[1][0], sn);
+  H2P_FENCE();
+  H2P_SPLIT_PAIR(h0, l0, 2, 2)
+  H2P_SPLIT_PAIR(h0, l0, 3, 3)
+  H2P_FENCE();
+  sn = mmh(kf[1][0], qn[1][1], sn);
+  H2P_FENCE();
+  H2P_SPLIT_PAIR(h1, l1, 0, 4)
+  H2P_SPLIT_PAIR(h1, l1, 1, 5)
+  H2P_FENCE();
+  sn = mmh(kf[1][0], qn[1][0], sn);
+  H2P_FENCE();
+  H2P_SPLIT_PAIR(h1, l1, 2, 6)
+  H2P_SPLIT_PAIR(h1, l1, 3, 7)
+  pb[0][0] = __builtin_bit_cast(f16x8_t, h0);
+  pb[0][1] = __builtin_bit_cast(f16x8_t, l0);
+  pb[1][0] = __builtin_bit_cast(f16x8_t, h1);
+  pb[1][1] = __builtin_bit_cast(f16x8_t, l1);
+  H2P_FENCE();
+}
+
+// The same step with a LAZY running maximum (LDMK_ATTN_PIPE=2): the probabilities of block b are taken against the maximum the row
+// already has -- no maximum over the block, no wait for it before the first exponential -- and the row sum, which the step needs
+// anyway, says whether that was good enough: the probabilities are scaled by 2^OFF (OFF = 8 here, also in the exact steps of the
+// first tile, which sets the maxima), a block whose scores stay under the running maximum sums to <= 32 x 2^8 = 2^13, and only a
+// row sum >= 2^15 (a score more than two binary orders above everything seen so far) sends the wave down the slow path: raise the
+// row's maximum by the excess exponent and scale this block's probabilities, O and l by that power of two -- exact.  fp16's range
+// is safe either way (every probability < its row sum < 2^15), and the two fp16 images keep 22 bits of anything within 2^-9 of
+// the row's largest.  13 of ~80 VALU instructions per block less, and the head of the dependent chain (maximum -> exponent) gone.
+template <bool LOADK, bool LOADV, int OFF>
+__device__ __forceinline__ void h2p_step_lazy(f32x16& s, f32x16& sn, f32x16& op, f32x16& oc, float& m_run, float& l_run, const f16x8_t (&qn)[2][2],
+                                              f16x8_t (&kf)[2][2], f16x8_t (&vf)[2][2], f16x8_t (&pb)[2][2], const unsigned char* tk,
+                                              const unsigned char* tv) {
+  constexpr float INV = 1.0f / (H2_S * H2_S);
+  if constexpr (LOADK) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) kf[t][q] = *reinterpret_cast<const f16x8_t*>(tk + (t * 2 + q) * 1024);
+  }
+  const float c = (float)OFF - m_run;
+  const f32x2 inv2 = {INV, INV}, off2 = {c, c};
+  f32x2 d[8];
+  H2P_FENCE();
+  op = mmh(vf[0][1], pb[0][0], op);
+  H2P_FENCE();
+  d[0] = f32x2{__builtin_fmaf(s[0], INV, c), __builtin_fmaf(s[1], INV, c)};          // (not packed: these run under the MFMA)
+  d[1] = f32x2{__builtin_fmaf(s[2], INV, c), __builtin_fmaf(s[3], INV, c)};
+  H2P_FENCE();
+  op = mmh(vf[0][0], pb[0][1], op);
+  H2P_FENCE();
+  H2P_EXP2(0) H2P_EXP2(1)
+#pragma unroll
+  for (int k = 2; k < 8; ++k) d[k] = __builtin_elementwise_fma(f32x2{s[2 * k], s[2 * k + 1]}, inv2, off2);
+  H2P_FENCE();
+  op = mmh(vf[0][0], pb[0][0], op);
+  H2P_FENCE();
+  H2P_EXP2(2) H2P_EXP2(3)
+  f32x2 ps = {0.f, 0.f};
+  H2P_SUM(0) H2P_SUM(1)
+  H2P_FENCE();
+  op = mmh(vf[1][1], pb[1][0], op);
+  H2P_FENCE();
+  H2P_EXP2(4) H2P_EXP2(5)
+  H2P_SUM(2) H2P_SUM(3)
+  H2P_FENCE();
+  op = mmh(vf[1][0], pb[1][1], op);
+  H2P_FENCE();
+  H2P_EXP2(6) H2P_EXP2(7)
+  H2P_SUM(4) H2P_SUM(5)
+  H2P_FENCE();
+  op = mmh(vf[1][0], pb[1][0], op);
+  H2P_FENCE();
+  H2P_SUM(6) H2P_SUM(7)
+  float a, b;
+  both_halves(ps.x + ps.y, a, b);
+  float rs = a + b;                                               // the row's sum over this block's 32 keys (both half-lanes hold it)
+  if (__builtin_amdgcn_ballot_w64(!(rs < 32768.f)) != 0) {        // (rare; also catches a NaN)
+    const int e = (int)((__float_as_uint(rs) >> 23) & 0xffu) - 127;           // rs in [2^e, 2^(e + 1))
+    const int up = rs < 32768.f ? 0 : e - 12;                                 // rows under the bound stay; the others land in [2^12, 2^13)
+    const float corr = __builtin_ldexpf(1.0f, -up);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] *= corr; oc[r] *= corr; }
+    l_run *= corr;
+    rs *= corr;
+    m_run += (float)up;
+  }
+  l_run += rs;
+  H2P_FENCE();
+  if constexpr (LOADV) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) vf[t][q] = *reinterpret_cast<const f16x8_t*>(tv + (t * 2 + q) * 1024);
+  }
+  {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    sn = mmh(kf[0][1], qn[0][0], zero);
+  }
+  H2P_FENCE();
+  u32x4a h0, l0, h1, l1;
+  H2P_SPLIT_PAIR(h0, l0, 0, 0)
+  H2P_SPLIT_PAIR(h0, l0, 1, 1)
+  H2P_FENCE();
+  sn = mmh(kf[0][0], qn[0][1], sn);
+  H2P_FENCE();
+  H2P_SPLIT_PAIR(h0, l0, 2, 2)
+  H2P_SPLIT_PAIR(h0, l0, 3, 3)
+  H2P_FENCE();
+  sn = mmh(kf[0][0], qn[0][0], sn);
+  H2P_FENCE();
+  H2P_SPLIT_PAIR(h1, l1, 0, 4)
+  H2P_FENCE();
+  sn = mmh(kf[1][1], qn[1][0], sn);
+  H2P_FENCE();
+  H2P_SPLIT_PAIR(h1, l1, 1, 5)
+  H2P_FENCE();
+  sn = mmh(kf[1][0], qn[1][1], sn);
+  H2P_FENCE();
+  H2P_SPLIT_PAIR(h1, l1, 2, 6)
+  H2P_FENCE();
+  sn = mmh(kf[1][0], qn[1][0], sn);
+  H2P_FENCE();
+  H2P_SPLIT_PAIR(h1, l1, 3, 7)
+  pb[0][0] = __builtin_bit_cast(f16x8_t, h0);
+  pb[0][1] = __builtin_bit_cast(f16x8_t, l0);
+  pb[1][0] = __builtin_bit_cast(f16x8_t, h1);
+  pb[1][1] = __builtin_bit_cast(f16x8_t, l1);
+  H2P_FENCE();
+}
+
+// QB = query blocks of 32 per wave; PIPE (QB = 2, tokens a multiple of 256): the pipelined key loop, h2p_step (1) / with the lazy
+// running maximum from the second tile on, h2p_step_lazy (2)
+template <int QB, int PIPE>
 __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ kv, float* __restrict__ out,
                                                           unsigned char* __restrict__ out_ps, int tokens, int heads, float scale,
                                                           int* __restrict__ range_flag, const int gx, const int remap) {
+  static_assert(PIPE == 0 || QB == 2, "the pipelined loop alternates two query blocks");
   __shared__ __attribute__((aligned(1024))) unsigned char smem_h[2 * H2_TILE];
   static_assert(2 * H2_TILE >= 4 * 32 * BA_FS * 4, "transpose buffers alias the tile buffers");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
@@ -955,6 +1238,60 @@ __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restric
   auto fetch = [&](int kt) {                      // LDS-DMA of tile kt into buffer kt & 1 (tiles past the end: out of range, zeros)
     h2_dma4((unsigned)kt * (unsigned)H2_TILE + woff, rs, lds0 + (unsigned)(kt & 1) * H2_TILE + (unsigned)wave * 4096u);
   };
+  if constexpr (PIPE != 0) {
+    // block order (sub 0, q 0), (sub 0, q 1), (sub 1, q 0), (sub 1, q 1) per 64-key tile; step b: VALU of block b, MFMAs of P V (b - 1)
+    // and Q K^T (b + 1).  K / V fragments are read from LDS once per 32 keys and kept for both query blocks.  Tile kt + 1 must
+    // have landed before the last step of tile kt (its Q K^T reads K of tile kt + 1): the fetch of tile kt + 2 is issued there,
+    // behind the barrier that also says every wave has read the last fragment of tile kt -- two buffers, as before.
+    f32x16 sa, sb;
+    f16x8_t kf[2][2], vf[2][2], pb[2][2];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    fetch(1);
+    {
+      const unsigned char* tb = smem_h + lane * 16;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          kf[t][q] = *reinterpret_cast<const f16x8_t*>(tb + (t * 2 + q) * 1024);
+          vf[t][q] = __builtin_bit_cast(f16x8_t, u32x4a{0u, 0u, 0u, 0u});        // (the first step's P V: zeros times zeros onto zeros)
+          pb[t][q] = vf[t][q];
+        }
+      sa = mmh3(kf[0], qf[0][0], zero);
+      sa = mmh3(kf[1], qf[0][1], sa);
+    }
+    constexpr int OFF = PIPE == 2 ? 8 : (int)H2_PEXP;
+    auto tile = [&](const int kt, auto lazy) {
+      constexpr bool LZ = decltype(lazy)::value;
+      const unsigned char* cur = smem_h + (kt & 1) * H2_TILE + lane * 16;
+      const unsigned char* nxt = smem_h + ((kt + 1) & 1) * H2_TILE + lane * 16;
+      if constexpr (LZ) {
+        h2p_step_lazy<false, true, OFF>(sa, sb, o[1], o[0], m_run[0], l_run[0], qf[1], kf, vf, pb, nullptr, cur + 8 * 1024);
+        h2p_step_lazy<true, false, OFF>(sb, sa, o[0], o[1], m_run[1], l_run[1], qf[0], kf, vf, pb, cur + 4 * 1024, nullptr);
+        h2p_step_lazy<false, true, OFF>(sa, sb, o[1], o[0], m_run[0], l_run[0], qf[1], kf, vf, pb, nullptr, cur + 12 * 1024);
+      } else {
+        h2p_step<false, true, OFF>(sa, sb, o[1], o[0], m_run[0], l_run[0], qf[1], kf, vf, pb, nullptr, cur + 8 * 1024);          // V, keys 0-31
+        h2p_step<true, false, OFF>(sb, sa, o[0], o[1], m_run[1], l_run[1], qf[0], kf, vf, pb, cur + 4 * 1024, nullptr);          // K, keys 32-63
+        h2p_step<false, true, OFF>(sa, sb, o[1], o[0], m_run[0], l_run[0], qf[1], kf, vf, pb, nullptr, cur + 12 * 1024);         // V, keys 32-63
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      fetch(kt + 2);                                                                  // (past the end: out of range, zeros)
+      if constexpr (LZ) h2p_step_lazy<true, false, OFF>(sb, sa, o[0], o[1], m_run[1], l_run[1], qf[0], kf, vf, pb, nxt, nullptr);
+      else h2p_step<true, false, OFF>(sb, sa, o[0], o[1], m_run[1], l_run[1], qf[0], kf, vf, pb, nxt, nullptr);              // K, keys 0-31 of tile kt + 1
+    };
+    if constexpr (PIPE == 2) {
+      tile(0, std::false_type{});                            // the first tile sets the running maxima
+      for (int kt = 1; kt < ntiles; ++kt) tile(kt, std::true_type{});
+    } else {
+      for (int kt = 0; kt < ntiles; ++kt) tile(kt, std::false_type{});
+    }
+    o[1] = mmh3(vf[0], pb[0], o[1]);           // P V of the last block
+    o[1] = mmh3(vf[1], pb[1], o[1]);
+  } else {
   fetch(0);
   for (int kt = 0; kt < ntiles; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1005,6 +1342,7 @@ __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restric
         }
       }
     }
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1136,12 +1474,18 @@ static int attn_self_h2_any(const float* qkv, void* kv_scratch, float* out, void
   static const int remap = [] { const char* e = getenv("LDMK_ATTN_XCD"); return e ? atoi(e) : 1; }();
   const int gx = qb == 2 ? (tokens + 255) / 256 : (tokens + 127) / 128;
   // (grid.x = query tiles x heads, grid.y = samples: the kernel linearises and re-deals the ids over the XCDs itself)
-  if (qb == 2)
-    hipLaunchKernelGGL(attn_h2_fwd_kernel<2>, dim3(gx * heads, n), dim3(256), 0, st, qkv,
-                       reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale, range_flag, gx, remap);
-  else
-    hipLaunchKernelGGL(attn_h2_fwd_kernel<1>, dim3(gx * heads, n), dim3(256), 0, st, qkv,
-                       reinterpret_cast<const unsigned char*>(kv_scratch), out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale, range_flag, gx, remap);
+  // the pipelined key loop wherever every wave has whole tiles (tokens a multiple of 256), with the lazy running maximum
+  // (h2p_step_lazy).  LDMK_ATTN_PIPE=1: pipelined with the exact maximum per block (the same bits as the phase-separated loop),
+  // LDMK_ATTN_PIPE=0: the phase-separated loop (A/B: profiles/r05_ab_attn_pipe.txt)
+  static const int pipe_env = [] { const char* e = getenv("LDMK_ATTN_PIPE"); return e ? atoi(e) : 2; }();
+#define LDMK_ATTN_H2_LAUNCH(QB_, PIPE_)                                                                                                    \
+  hipLaunchKernelGGL((attn_h2_fwd_kernel<QB_, PIPE_>), dim3(gx * heads, n), dim3(256), 0, st, qkv, reinterpret_cast<const unsigned char*>(kv_scratch), \
+                     out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale, range_flag, gx, remap)
+  if (qb == 2 && pipe_env == 2 && tokens % 256 == 0) LDMK_ATTN_H2_LAUNCH(2, 2);
+  else if (qb == 2 && pipe_env != 0 && tokens % 256 == 0) LDMK_ATTN_H2_LAUNCH(2, 1);
+  else if (qb == 2) LDMK_ATTN_H2_LAUNCH(2, 0);
+  else LDMK_ATTN_H2_LAUNCH(1, 0);
+#undef LDMK_ATTN_H2_LAUNCH
   return check_launch("ldmk_attn_self_h2");
 }
 

@@ -26,6 +26,7 @@ def main():
     tot = 0.0
     for lvl, (heads, calls) in enumerate(((5, 5), (10, 5), (20, 6))):
         tokens = (a.latent >> lvl) ** 2
+        torch.manual_seed(17 + lvl)
         qkv = torch.randn(a.batch * tokens, 3 * heads * 32, device="cuda")
         out = torch.empty(a.batch * tokens, heads * 32, device="cuda")
         if a.mode == "x3p":
@@ -39,6 +40,13 @@ def main():
             t = timeit(lambda: L.call("ldmk_attn_self_h2", qkv.data_ptr(), kv.data_ptr(), out.data_ptr(), flag.data_ptr(), a.batch, tokens, heads,
                                       32 ** -0.5, ops.stream()))
             assert int(flag.item()) == 0
+            nb = min(a.batch, 2)         # accuracy against float64 on the first two samples
+            q, k, v = (t.reshape(nb, tokens, heads, 32).permute(0, 2, 1, 3).double() for t in qkv[:nb * tokens].split(heads * 32, dim=1))
+            ref = (torch.softmax(q @ k.transpose(-1, -2) * 32 ** -0.5, dim=-1) @ v).permute(0, 2, 1, 3).reshape(nb * tokens, heads * 32)
+            err = (out[:nb * tokens].double() - ref).abs().max().item()
+            print(f"   max |error| against float64 {err:.3e} (max |ref| {ref.abs().max().item():.3f})")
+            import hashlib          # (two builds on one box: the digests say whether the results are the same bits)
+            print("   digest out", hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:16], "kv", hashlib.sha1(kv.cpu().numpy().tobytes()).hexdigest()[:16])
         else:
             t = timeit(lambda: ops.attn_self(qkv, a.batch, tokens, heads, out=out, x3=a.mode == "x3"))
         gf = 4.0 * tokens * tokens * 32 * heads * a.batch * 1e-9
