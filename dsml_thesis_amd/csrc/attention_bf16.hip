@@ -1079,7 +1079,7 @@ __device__ __forceinline__ void h2p_step(f32x16& s, f32x16& sn, f32x16& op, f32x
 template <bool LOADK, bool LOADV, int OFF>
 __device__ __forceinline__ void h2p_step_lazy(f32x16& s, f32x16& sn, f32x16& op, f32x16& oc, float& m_run, float& l_run, const f16x8_t (&qn)[2][2],
                                               f16x8_t (&kf)[2][2], f16x8_t (&vf)[2][2], f16x8_t (&pb)[2][2], const unsigned char* tk,
-                                              const unsigned char* tv) {
+                                              const unsigned char* tv, bool& bad) {
   constexpr float INV = 1.0f / (H2_S * H2_S);
   if constexpr (LOADK) {
 #pragma unroll
@@ -1124,7 +1124,20 @@ __device__ __forceinline__ void h2p_step_lazy(f32x16& s, f32x16& sn, f32x16& op,
   float a, b;
   both_halves(ps.x + ps.y, a, b);
   float rs = a + b;                                               // the row's sum over this block's 32 keys (both half-lanes hold it)
-  if (__builtin_amdgcn_ballot_w64(!(rs < 32768.f)) != 0) {        // (rare; also catches a NaN)
+  if (__builtin_amdgcn_ballot_w64(!(rs < 32768.f)) != 0) {        // (rare)
+    // a score >= 120 binary orders above the row's maximum overflows the fp32 exponential itself: such a block is outside this
+    // kernel's range like an operand outside fp16's -- the launch's range flag goes up (the caller computes the site again in
+    // another arithmetic, whose kernel takes the exact maximum first) and the probabilities are clamped so that the result, wrong
+    // either way, stays finite (ldmk_common.h, h2_clamp)
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      bad |= s[r] > 0x1p100f;
+      s[r] = fminf(s[r], 0x1p100f);
+      t += s[r];
+    }
+    both_halves(t, a, b);
+    rs = a + b;
     const int e = (int)((__float_as_uint(rs) >> 23) & 0xffu) - 127;           // rs in [2^e, 2^(e + 1))
     const int up = rs < 32768.f ? 0 : e - 12;                                 // rows under the bound stay; the others land in [2^12, 2^13)
     const float corr = __builtin_ldexpf(1.0f, -up);
@@ -1269,9 +1282,9 @@ __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restric
       const unsigned char* cur = smem_h + (kt & 1) * H2_TILE + lane * 16;
       const unsigned char* nxt = smem_h + ((kt + 1) & 1) * H2_TILE + lane * 16;
       if constexpr (LZ) {
-        h2p_step_lazy<false, true, OFF>(sa, sb, o[1], o[0], m_run[0], l_run[0], qf[1], kf, vf, pb, nullptr, cur + 8 * 1024);
-        h2p_step_lazy<true, false, OFF>(sb, sa, o[0], o[1], m_run[1], l_run[1], qf[0], kf, vf, pb, cur + 4 * 1024, nullptr);
-        h2p_step_lazy<false, true, OFF>(sa, sb, o[1], o[0], m_run[0], l_run[0], qf[1], kf, vf, pb, nullptr, cur + 12 * 1024);
+        h2p_step_lazy<false, true, OFF>(sa, sb, o[1], o[0], m_run[0], l_run[0], qf[1], kf, vf, pb, nullptr, cur + 8 * 1024, bad);
+        h2p_step_lazy<true, false, OFF>(sb, sa, o[0], o[1], m_run[1], l_run[1], qf[0], kf, vf, pb, cur + 4 * 1024, nullptr, bad);
+        h2p_step_lazy<false, true, OFF>(sa, sb, o[1], o[0], m_run[0], l_run[0], qf[1], kf, vf, pb, nullptr, cur + 12 * 1024, bad);
       } else {
         h2p_step<false, true, OFF>(sa, sb, o[1], o[0], m_run[0], l_run[0], qf[1], kf, vf, pb, nullptr, cur + 8 * 1024);          // V, keys 0-31
         h2p_step<true, false, OFF>(sb, sa, o[0], o[1], m_run[1], l_run[1], qf[0], kf, vf, pb, cur + 4 * 1024, nullptr);          // K, keys 32-63
@@ -1280,7 +1293,7 @@ __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restric
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
       fetch(kt + 2);                                                                  // (past the end: out of range, zeros)
-      if constexpr (LZ) h2p_step_lazy<true, false, OFF>(sb, sa, o[0], o[1], m_run[1], l_run[1], qf[0], kf, vf, pb, nxt, nullptr);
+      if constexpr (LZ) h2p_step_lazy<true, false, OFF>(sb, sa, o[0], o[1], m_run[1], l_run[1], qf[0], kf, vf, pb, nxt, nullptr, bad);
       else h2p_step<true, false, OFF>(sb, sa, o[0], o[1], m_run[1], l_run[1], qf[0], kf, vf, pb, nxt, nullptr);              // K, keys 0-31 of tile kt + 1
     };
     if constexpr (PIPE == 2) {
@@ -1291,6 +1304,9 @@ __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restric
     }
     o[1] = mmh3(vf[0], pb[0], o[1]);           // P V of the last block
     o[1] = mmh3(vf[1], pb[1], o[1]);
+    if constexpr (PIPE == 2) {
+      if (bad) *range_flag = 1;                // (h2p_step_lazy: a block overflowed the fp32 exponential)
+    }
   } else {
   fetch(0);
   for (int kt = 0; kt < ntiles; ++kt) {

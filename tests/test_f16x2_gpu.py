@@ -57,6 +57,45 @@ def test_f16x2_attention_peaked_and_flat_rows(ops):
         _f16x2_class(_err(y32, ref), _err(yh, ref), 2e-6)
 
 
+@pytest.mark.parametrize("order", ["rising", "falling", "steps", "peaked", "overflow"])
+@pytest.mark.parametrize("tokens", [2048, 4096])
+def test_f16x2_attention_lazy_running_maximum(ops, tokens, order):
+    """The pipelined key loop (tokens % 256 == 0, two query blocks per wave) takes each 32-key block's probabilities against the
+    maximum the row already has and raises it only when the block's row sum says so (csrc/attention_bf16.hip, h2p_step_lazy).
+    Scores that RISE with the key index cross that bound over and over -- by a little per block, by whole binary orders at a step
+    -- and scores that fall never do; one-hot rows (4 x random: score gaps of tens of binary orders) leave every other probability
+    at the bottom of fp16's range.  Same bar as the exact-maximum kernel: the accuracy class of the fp32 kernel against float64.
+    "overflow" (12 x random: a key 120 binary orders above everything the row has seen overflows the fp32 exponential): outside the
+    kernel's range -- the range flag goes up and the result stays finite, like an operand outside fp16's range."""
+    n, heads = 1, 2
+    C_ = heads * 32
+    g = torch.Generator().manual_seed(560)
+    q = torch.randn(n * tokens, C_, generator=g)
+    v = torch.randn(n * tokens, C_, generator=g)
+    t = torch.arange(tokens, dtype=torch.float32)
+    if order in ("peaked", "overflow"):
+        mult = 4.0 if order == "peaked" else 12.0
+        k = mult * torch.randn(n * tokens, C_, generator=g)
+        q = mult * q
+    else:
+        ramp = {"rising": t / tokens, "falling": 1.0 - t / tokens, "steps": torch.floor(t / 300.0) / (tokens / 300.0)}[order]
+        # every query's score against key t grows by up to ~60 (natural-log units) over the sequence: k_t = ramp_t * 60 * sqrt(32) q_dir
+        qdir = torch.nn.functional.normalize(q.reshape(tokens, heads, 32).mean(0), dim=-1)          # (heads, 32)
+        q = 0.3 * q + qdir.reshape(1, C_)                                                            # all queries lean the same way
+        k = 0.3 * torch.randn(n * tokens, C_, generator=g) + (ramp[:, None] * 60.0 * 32 ** 0.5) * qdir.reshape(1, C_)
+    qkv = torch.cat([q, k, v], dim=1).cuda()
+    ref = _attention_ref(qkv, n, tokens, heads)
+    flag = torch.zeros(1, device="cuda", dtype=torch.int32)
+    y32 = ops.attn_self(qkv, n, tokens, heads)
+    yh = ops.attn_self(qkv, n, tokens, heads, h2_flag=flag)
+    assert bool(torch.isfinite(yh).all())
+    if order == "overflow":
+        assert int(flag.item()) == 1
+        return
+    assert int(flag.item()) == 0
+    _f16x2_class(_err(y32, ref), _err(yh, ref), 2e-6)
+
+
 @pytest.mark.parametrize("where", ["k", "v", "q"])
 def test_f16x2_attention_raises_the_range_flag(ops, where):
     """|K|, |V| or the pre-scaled |Q| of 1000 or more (x 2^6 leaves fp16): the flag goes up (the caller repeats the product in
