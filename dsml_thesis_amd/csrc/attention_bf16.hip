@@ -786,21 +786,7 @@ __device__ __forceinline__ f32x2 widen_pk_f16(unsigned u) {
   const f16x2_t v = __builtin_bit_cast(f16x2_t, u);
   return f32x2{(float)v.x, (float)v.y};
 }
-// fp16(p - h) for a pair, h = the packed fp16 images of p: p - h is exact in fp32 (h is p rounded to 11 bits), so the fused form
-// rounds once to fp16 exactly as the convert of the difference does -- v_fma_mix reads the fp16 halves in place and writes the
-// fp16 result: 2 instructions per pair instead of 2 widening converts + a packed subtract + a packed convert (the softmax side
-// of the attention loop is VALU-bound: 16 of ~150 instructions per 32-key block).  -DLDMK_H2_SPLIT_CVT: the convert form (A/B)
-__device__ __forceinline__ unsigned split_lo_pk_f16(f32x2 p, unsigned h) {
-#ifdef LDMK_H2_SPLIT_CVT
-  return cvt_pk_f16(p - widen_pk_f16(h));
-#else
-  unsigned l;
-  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-      : "=&v"(l) : "v"(h), "v"(p.x), "v"(p.y));
-  return l;
-#endif
-}
+__device__ __forceinline__ unsigned split_lo_pk_f16(f32x2 p, unsigned h) { return h2_lo_pair(h, p.x, p.y); }      // (ldmk_common.h)
 // 8 (already scaled) values as their two fp16 images
 __device__ __forceinline__ void split8_h2(const float* v, f16x8_t (&o)[2]) {
   u32x4a h, l;
@@ -890,6 +876,7 @@ __device__ __forceinline__ void h2_dma4(unsigned voff, const au32x4& rs, unsigne
 //   - the rescale factor 2^(m_old - m_new) is an exact power of two (no rounding in O or l), and it is needed only when a
 //     row's maximum crosses an integer.
 // -DLDMK_H2_SOFTMAX_R4: the round-4 form (A/B)
+template <int OFF = 14>
 __device__ __forceinline__ void h2_softmax(f32x16& s, f32x16& o, float& m_run, float& l_run) {
   constexpr float INV = 1.0f / (H2_S * H2_S);
   float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
@@ -903,7 +890,7 @@ __device__ __forceinline__ void h2_softmax(f32x16& s, f32x16& o, float& m_run, f
   const f32x2 mm2 = {m_new, m_new}, inv2 = {INV, INV}, off2 = {H2_PEXP, H2_PEXP};
 #else
   const float m_new = fmaxf(m_run, __builtin_ceilf(fmaxf(a, b) * INV));
-  const f32x2 inv2 = {INV, INV}, off2 = {H2_PEXP - m_new, H2_PEXP - m_new};
+  const f32x2 inv2 = {INV, INV}, off2 = {(float)OFF - m_new, (float)OFF - m_new};
 #endif
   f32x2 ps = {0.f, 0.f};
 #pragma unroll
@@ -934,6 +921,38 @@ __device__ __forceinline__ void h2_softmax(f32x16& s, f32x16& o, float& m_run, f
   l_run += a + b;
 }
 
+// LAZY running maximum (the pipelined loop, from the second 64-key tile of a row on): the probabilities of a block are taken against the
+// maximum the row ALREADY has -- no maximum over the block, no wait for it before the first exponential -- and the row sum, which
+// the loop needs anyway, says whether that was good enough.  Probabilities are scaled by 2^OFF with OFF = 8 (also in the exact
+// block that sets the maxima): a block whose scores stay under the running maximum sums to <= 32 x 2^8 = 2^13, and only a row sum
+// >= 2^15 -- a score more than two binary orders above everything seen so far -- sends the wave down h2_lazy_raise: the row's
+// maximum goes up by the excess exponent and this block's probabilities, O and l are scaled by that power of two -- exact.
+// fp16's range is safe either way (every probability < its row sum < 2^15) and the two fp16 images keep 22 bits of anything within
+// 2^-9 of the row's largest.  13 of ~80 VALU instructions per block less, and the head of the dependent chain (maximum ->
+// exponent) is gone.  A score >= 120 binary orders above the row's maximum overflows the fp32 exponential itself: such a block is
+// outside this kernel's range like an operand outside fp16's -- the launch's range flag goes up (the caller computes the site again
+// in bf16x3, whose kernel takes the exact maximum first) and the probabilities are clamped so that the result, wrong either way,
+// stays finite (ldmk_common.h, h2_clamp).
+constexpr int H2_LAZY_OFF = 8;
+__device__ __forceinline__ void h2_lazy_raise(f32x16& s, f32x16& o, float& m_run, float& l_run, float& rs, bool& bad) {
+  float t = 0.f, a, b;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    bad |= s[r] > 0x1p100f;
+    s[r] = fminf(s[r], 0x1p100f);
+    t += s[r];
+  }
+  both_halves(t, a, b);
+  rs = a + b;
+  const int e = (int)((__float_as_uint(rs) >> 23) & 0xffu) - 127;           // rs in [2^e, 2^(e + 1))
+  const int up = rs < 32768.f ? 0 : e - 12;                                 // rows under the bound stay; the others land in [2^12, 2^13)
+  const float corr = __builtin_ldexpf(1.0f, -up);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s[r] *= corr; o[r] *= corr; }
+  l_run *= corr;
+  rs *= corr;
+  m_run += (float)up;
+}
 // One step of the PIPELINED key loop (attn_h2_fwd_kernel<2, true>): the VALU side of 32-key block b -- softmax, then the fp16
 // images of its probabilities -- with the MFMAs of its neighbours issued between the slices: first the six of P V for block b - 1
 // (operands pb / vf, into the OTHER query block's accumulator op), then the six of Q K^T for block b + 1 (into sn).  What decides
@@ -1068,14 +1087,7 @@ __device__ __forceinline__ void h2p_step(f32x16& s, f32x16& sn, f32x16& op, f32x
   H2P_FENCE();
 }
 
-// The same step with a LAZY running maximum (LDMK_ATTN_PIPE=2): the probabilities of block b are taken against the maximum the row
-// already has -- no maximum over the block, no wait for it before the first exponential -- and the row sum, which the step needs
-// anyway, says whether that was good enough: the probabilities are scaled by 2^OFF (OFF = 8 here, also in the exact steps of the
-// first tile, which sets the maxima), a block whose scores stay under the running maximum sums to <= 32 x 2^8 = 2^13, and only a
-// row sum >= 2^15 (a score more than two binary orders above everything seen so far) sends the wave down the slow path: raise the
-// row's maximum by the excess exponent and scale this block's probabilities, O and l by that power of two -- exact.  fp16's range
-// is safe either way (every probability < its row sum < 2^15), and the two fp16 images keep 22 bits of anything within 2^-9 of
-// the row's largest.  13 of ~80 VALU instructions per block less, and the head of the dependent chain (maximum -> exponent) gone.
+// The same step with the lazy running maximum (above)
 template <bool LOADK, bool LOADV, int OFF>
 __device__ __forceinline__ void h2p_step_lazy(f32x16& s, f32x16& sn, f32x16& op, f32x16& oc, float& m_run, float& l_run, const f16x8_t (&qn)[2][2],
                                               f16x8_t (&kf)[2][2], f16x8_t (&vf)[2][2], f16x8_t (&pb)[2][2], const unsigned char* tk,
@@ -1124,29 +1136,7 @@ __device__ __forceinline__ void h2p_step_lazy(f32x16& s, f32x16& sn, f32x16& op,
   float a, b;
   both_halves(ps.x + ps.y, a, b);
   float rs = a + b;                                               // the row's sum over this block's 32 keys (both half-lanes hold it)
-  if (__builtin_amdgcn_ballot_w64(!(rs < 32768.f)) != 0) {        // (rare)
-    // a score >= 120 binary orders above the row's maximum overflows the fp32 exponential itself: such a block is outside this
-    // kernel's range like an operand outside fp16's -- the launch's range flag goes up (the caller computes the site again in
-    // another arithmetic, whose kernel takes the exact maximum first) and the probabilities are clamped so that the result, wrong
-    // either way, stays finite (ldmk_common.h, h2_clamp)
-    float t = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      bad |= s[r] > 0x1p100f;
-      s[r] = fminf(s[r], 0x1p100f);
-      t += s[r];
-    }
-    both_halves(t, a, b);
-    rs = a + b;
-    const int e = (int)((__float_as_uint(rs) >> 23) & 0xffu) - 127;           // rs in [2^e, 2^(e + 1))
-    const int up = rs < 32768.f ? 0 : e - 12;                                 // rows under the bound stay; the others land in [2^12, 2^13)
-    const float corr = __builtin_ldexpf(1.0f, -up);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] *= corr; oc[r] *= corr; }
-    l_run *= corr;
-    rs *= corr;
-    m_run += (float)up;
-  }
+  if (__builtin_amdgcn_ballot_w64(!(rs < 32768.f)) != 0) h2_lazy_raise(s, oc, m_run, l_run, rs, bad);      // (rare)
   l_run += rs;
   H2P_FENCE();
   if constexpr (LOADV) {
@@ -1191,13 +1181,14 @@ __device__ __forceinline__ void h2p_step_lazy(f32x16& s, f32x16& sn, f32x16& op,
   H2P_FENCE();
 }
 
-// QB = query blocks of 32 per wave; PIPE (QB = 2, tokens a multiple of 256): the pipelined key loop, h2p_step (1) / with the lazy
-// running maximum from the second tile on, h2p_step_lazy (2)
-template <int QB, int PIPE>
+// QB = query blocks of 32 per wave; PIPE (QB = 2, tokens a multiple of 256): the pipelined key loop, h2p_step; LAZY: the lazy
+// running maximum (h2p_step_lazy) behind the exact first tile of every row -- pipelined loop only: in the phase-separated loop it
+// measured neutral (profiles/r05_ab_attn_mix.txt) and both forms inlined cost a wave per SIMD
+template <int QB, int PIPE, bool LAZY>
 __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ kv, float* __restrict__ out,
                                                           unsigned char* __restrict__ out_ps, int tokens, int heads, float scale,
                                                           int* __restrict__ range_flag, const int gx, const int remap) {
-  static_assert(PIPE == 0 || QB == 2, "the pipelined loop alternates two query blocks");
+  static_assert((PIPE == 0 && !LAZY) || QB == 2, "the pipelined loop alternates two query blocks");
   __shared__ __attribute__((aligned(1024))) unsigned char smem_h[2 * H2_TILE];
   static_assert(2 * H2_TILE >= 4 * 32 * BA_FS * 4, "transpose buffers alias the tile buffers");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
@@ -1276,7 +1267,7 @@ __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restric
       sa = mmh3(kf[0], qf[0][0], zero);
       sa = mmh3(kf[1], qf[0][1], sa);
     }
-    constexpr int OFF = PIPE == 2 ? 8 : (int)H2_PEXP;
+    constexpr int OFF = LAZY ? H2_LAZY_OFF : (int)H2_PEXP;
     auto tile = [&](const int kt, auto lazy) {
       constexpr bool LZ = decltype(lazy)::value;
       const unsigned char* cur = smem_h + (kt & 1) * H2_TILE + lane * 16;
@@ -1296,7 +1287,7 @@ __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restric
       if constexpr (LZ) h2p_step_lazy<true, false, OFF>(sb, sa, o[0], o[1], m_run[1], l_run[1], qf[0], kf, vf, pb, nxt, nullptr, bad);
       else h2p_step<true, false, OFF>(sb, sa, o[0], o[1], m_run[1], l_run[1], qf[0], kf, vf, pb, nxt, nullptr);              // K, keys 0-31 of tile kt + 1
     };
-    if constexpr (PIPE == 2) {
+    if constexpr (LAZY) {
       tile(0, std::false_type{});                            // the first tile sets the running maxima
       for (int kt = 1; kt < ntiles; ++kt) tile(kt, std::true_type{});
     } else {
@@ -1304,8 +1295,8 @@ __global__ __launch_bounds__(256) void attn_h2_fwd_kernel(const float* __restric
     }
     o[1] = mmh3(vf[0], pb[0], o[1]);           // P V of the last block
     o[1] = mmh3(vf[1], pb[1], o[1]);
-    if constexpr (PIPE == 2) {
-      if (bad) *range_flag = 1;                // (h2p_step_lazy: a block overflowed the fp32 exponential)
+    if constexpr (LAZY) {
+      if (bad) *range_flag = 1;                // (h2_lazy_raise: a block overflowed the fp32 exponential)
     }
   } else {
   fetch(0);
@@ -1490,17 +1481,18 @@ static int attn_self_h2_any(const float* qkv, void* kv_scratch, float* out, void
   static const int remap = [] { const char* e = getenv("LDMK_ATTN_XCD"); return e ? atoi(e) : 1; }();
   const int gx = qb == 2 ? (tokens + 255) / 256 : (tokens + 127) / 128;
   // (grid.x = query tiles x heads, grid.y = samples: the kernel linearises and re-deals the ids over the XCDs itself)
-  // the pipelined key loop wherever every wave has whole tiles (tokens a multiple of 256), with the lazy running maximum
-  // (h2p_step_lazy).  LDMK_ATTN_PIPE=1: pipelined with the exact maximum per block (the same bits as the phase-separated loop),
+  // the pipelined key loop with the lazy running maximum wherever every wave has whole tiles (two query blocks per wave, tokens a
+  // multiple of 256).  LDMK_ATTN_PIPE=1: pipelined with the exact maximum per block (the same bits as the phase-separated loop),
   // LDMK_ATTN_PIPE=0: the phase-separated loop (A/B: profiles/r05_ab_attn_pipe.txt)
   static const int pipe_env = [] { const char* e = getenv("LDMK_ATTN_PIPE"); return e ? atoi(e) : 2; }();
-#define LDMK_ATTN_H2_LAUNCH(QB_, PIPE_)                                                                                                    \
-  hipLaunchKernelGGL((attn_h2_fwd_kernel<QB_, PIPE_>), dim3(gx * heads, n), dim3(256), 0, st, qkv, reinterpret_cast<const unsigned char*>(kv_scratch), \
+#define LDMK_ATTN_H2_LAUNCH(QB_, PIPE_, LAZY_)                                                                                                    \
+  hipLaunchKernelGGL((attn_h2_fwd_kernel<QB_, PIPE_, LAZY_>), dim3(gx * heads, n), dim3(256), 0, st, qkv, reinterpret_cast<const unsigned char*>(kv_scratch), \
                      out, reinterpret_cast<unsigned char*>(out_ps), tokens, heads, scale, range_flag, gx, remap)
-  if (qb == 2 && pipe_env == 2 && tokens % 256 == 0) LDMK_ATTN_H2_LAUNCH(2, 2);
-  else if (qb == 2 && pipe_env != 0 && tokens % 256 == 0) LDMK_ATTN_H2_LAUNCH(2, 1);
-  else if (qb == 2) LDMK_ATTN_H2_LAUNCH(2, 0);
-  else LDMK_ATTN_H2_LAUNCH(1, 0);
+  const bool piped = qb == 2 && pipe_env != 0 && tokens % 256 == 0;
+  if (piped && pipe_env == 2) LDMK_ATTN_H2_LAUNCH(2, 1, true);
+  else if (piped) LDMK_ATTN_H2_LAUNCH(2, 1, false);
+  else if (qb == 2) LDMK_ATTN_H2_LAUNCH(2, 0, false);
+  else LDMK_ATTN_H2_LAUNCH(1, 0, false);
 #undef LDMK_ATTN_H2_LAUNCH
   return check_launch("ldmk_attn_self_h2");
 }

@@ -46,9 +46,11 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {          // round
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float H2_A_SCALE = 64.f;            // 2^LDMK_F16X2_A_EXP
-__device__ __forceinline__ void split2h(const float4& v, f16x4& h, f16x4& l) {     // v already scaled
+__device__ __forceinline__ void split2h(const float4& v, f16x4& h, f16x4& l) {     // v already scaled; lo: h2_lo_pair (ldmk_common.h)
   h = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-  l = f16x4{(_Float16)(v.x - (float)h[0]), (_Float16)(v.y - (float)h[1]), (_Float16)(v.z - (float)h[2]), (_Float16)(v.w - (float)h[3])};
+  typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
+  const u32x2h hu = __builtin_bit_cast(u32x2h, h);
+  l = __builtin_bit_cast(f16x4, u32x2h{h2_lo_pair(hu.x, v.x, v.y), h2_lo_pair(hu.y, v.z, v.w)});
 }
 __device__ __forceinline__ bool h2_out_of_range(const float4& v) {                 // |x| >= LDMK_F16X2_RANGE, inf or NaN
   constexpr unsigned LIM = 0x447a0000u;       // 1000.0f

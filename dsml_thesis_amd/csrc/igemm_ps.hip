@@ -91,7 +91,9 @@ typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
 constexpr float PS_H2_SCALE = 64.f;            // 2^LDMK_F16X2_A_EXP
 __device__ __forceinline__ void ps_split2h(const float4& v, pf16x4& h, pf16x4& l) {       // v already scaled; the split of igemm.hip's split2h
   h = pf16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-  l = pf16x4{(_Float16)(v.x - (float)h[0]), (_Float16)(v.y - (float)h[1]), (_Float16)(v.z - (float)h[2]), (_Float16)(v.w - (float)h[3])};
+  typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
+  const pu32x2 hu = __builtin_bit_cast(pu32x2, h);
+  l = __builtin_bit_cast(pf16x4, pu32x2{h2_lo_pair(hu.x, v.x, v.y), h2_lo_pair(hu.y, v.z, v.w)});
 }
 __device__ __forceinline__ bool ps_h2_out_of_range(const float4& v) {                       // |x| >= LDMK_F16X2_RANGE, inf or NaN
   constexpr unsigned LIM = 0x447a0000u;

@@ -75,6 +75,26 @@ __device__ __forceinline__ float h2_clamp(float x) { return __builtin_amdgcn_fme
 #endif
 __device__ __forceinline__ float4 h2_clamp4(const float4& v) { return make_float4(h2_clamp(v.x), h2_clamp(v.y), h2_clamp(v.z), h2_clamp(v.w)); }
 
+// LDMK_COMPUTE_F16X2: the LOW fp16 image of a pair, fp16(x' - hi), hi = the packed fp16 images of (x, y).  x' - hi is exact in fp32
+// (hi is x' rounded to 11 bits), so v_fma_mix -- which reads the fp16 halves of hi in place and writes an fp16 half -- rounds once,
+// exactly as converting the fp32 difference does: 2 instructions per pair instead of 2 widening converts + subtract(s) + a packed
+// convert, and none of them a packed fp32 instruction (those wait for the wave's own MFMAs to drain and run at 40 % next to
+// another wave's: tools/probe/valu_rate.hip, profiles/r05_valu_rate.txt).  -DLDMK_H2_SPLIT_CVT: the convert form (A/B)
+__device__ __forceinline__ unsigned h2_lo_pair(unsigned h, float x, float y) {
+#ifdef LDMK_H2_SPLIT_CVT
+  typedef _Float16 h2_f16x2 __attribute__((ext_vector_type(2)));
+  const h2_f16x2 hv = __builtin_bit_cast(h2_f16x2, h);
+  const h2_f16x2 lv = {(_Float16)(x - (float)hv.x), (_Float16)(y - (float)hv.y)};
+  return __builtin_bit_cast(unsigned, lv);
+#else
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(l) : "v"(h), "v"(x), "v"(y));
+  return l;
+#endif
+}
+
 // 64-lane butterfly reductions (wave = 64 on CDNA)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
