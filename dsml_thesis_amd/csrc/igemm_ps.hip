@@ -128,13 +128,25 @@ __device__ __attribute__((aligned(16))) const float kPsZeros[4] = {0.f, 0.f, 0.f
 // half-lanes, one v_permlane32_swap per register pairs them up.  A V^T fragment wants lane = d: one pass through a per-wave LDS
 // scratch (`kv_ts`, 32 x 33 floats; the ring is free by then).
 constexpr int PS_KV_TILE = 16 * 1024;          // = H2_TILE of csrc/attention_bf16.hip
-template <int TM, int TN, bool TR, int PL = 3, bool KV = false>
+// the folded LayerNorm of one accumulator value + bias: rstd (acc - mean colsum) + b with the roundings of igemm.hip / rgemm.hip --
+// one fma, one multiply, one add.  Contraction is switched off here: in the general epilogue a select sits between the multiply
+// and the add, in the lean one nothing does, and the compiler would fuse them into a second fma (one rounding less: other bits).
+__device__ __forceinline__ float ps_lnf_bias(float acc, float mean, float cs, float rstd, float bias) {
+#pragma clang fp contract(off)
+  const float t = __builtin_fmaf(-mean, cs, acc) * rstd;
+  return t + bias;
+}
+// LEAN (transposed form; chosen per wave when the whole wave tile is inside M x N and the launch folds a LayerNorm and has neither
+// a residual nor a per-sample vector -- the GEGLU and QKV projections): no row / column predicates, no loads of the absent
+// operands, no select around the LayerNorm arithmetic.  The GEGLU
+// epilogue was ~3000 vector instructions per wave for 64 outputs per lane, a third of them addressing and predication.
+template <int TM, int TN, bool TR, int PL = 3, bool KV = false, bool LEAN = false>
 __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&acc)[TM][TN], const int rowbase, const int colbase,
                                             const int splitk, const int ks, const int bz, float* __restrict__ ws, const int lane,
                                             float* __restrict__ kv_ts = nullptr) {
   const int l31 = lane & 31, half = lane >> 5;
   const float alpha = p.alpha;
-  const bool lnf = p.a_tf == LDMK_TF_LAYERNORM_FOLDED;
+  const bool lnf = LEAN || p.a_tf == LDMK_TF_LAYERNORM_FOLDED;          // (LEAN: dispatched only with the folded LayerNorm -- no select per value)
   const float2* __restrict__ stats2 = reinterpret_cast<const float2*>(p.row_stats);
 
   if constexpr (TR) {
@@ -166,10 +178,11 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
     const float* __restrict__ bip = p.bias ? p.bias : kPsZeros;
     const float* __restrict__ rsp = p.residual ? p.residual + (long long)bz * p.out_bstride : kPsZeros;
     const unsigned mcs = lnf ? ~0u : 0u, mbi = p.bias ? ~0u : 0u, mrs = p.residual ? ~0u : 0u, mbv = p.batch_vec ? ~0u : 0u;
+    bool bad_ps = false;            // a PS output outside the F16X2 range: one store of the flag at the end, not a branch per 4 values
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = rowbase + 32 * i + l31;
-      const bool rok = row < p.M;
+      const bool rok = LEAN || row < p.M;
       const int rr = rok ? row : p.M - 1;
       float mean = 0.f, rstd = 1.f;
       if (lnf) { const float2 st = stats2[rr]; mean = st.x; rstd = st.y; }
@@ -184,7 +197,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
           if (geglu && jj == 1) break;
           const int jt = j + jj;
           const int ctile = colbase + 32 * jt;
-          if (ctile >= p.N) continue;
+          if (!LEAN && ctile >= p.N) continue;
           const int otile = geglu ? (ctile >> 1) : ctile;            // first output column of this tile
           float kvv[KV ? 16 : 1];                                    // KV: the finished values of a K / V tile (column 8 q + 4 half + e at [4 q + e])
           const bool kv_tile = KV && ctile >= p.N / 3;
@@ -196,8 +209,10 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
             const unsigned c = (unsigned)(ctile + 8 * q + 4 * half), oc = (unsigned)(otile + 8 * q + 4 * half);
             cs[q] = *reinterpret_cast<const float4*>(csp + (c & mcs));
             bi[q] = *reinterpret_cast<const float4*>(bip + (c & mbi));
-            bv[q] = *reinterpret_cast<const float4*>(bvp + (oc & mbv));
-            rs[q] = *reinterpret_cast<const float4*>(rsp + ((rowoff + oc) & mrs));
+            if constexpr (!LEAN) {
+              bv[q] = *reinterpret_cast<const float4*>(bvp + (oc & mbv));
+              rs[q] = *reinterpret_cast<const float4*>(rsp + ((rowoff + oc) & mrs));
+            }
             if constexpr (TN % 2 == 0) {
               if (geglu) {
                 csg[q] = *reinterpret_cast<const float4*>(csp + ((c + 32) & mcs));
@@ -209,27 +224,41 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
           for (int q = qh; q < qh + 2; ++q) {
             float4 v = make_float4(acc[i][jt][4 * q] * alpha, acc[i][jt][4 * q + 1] * alpha, acc[i][jt][4 * q + 2] * alpha,
                                    acc[i][jt][4 * q + 3] * alpha);
-            if (lnf) {      // same arithmetic as igemm.hip / rgemm.hip / igemm_reduce_kernel
-              v.x = fmaf(-mean, cs[q].x, v.x) * rstd; v.y = fmaf(-mean, cs[q].y, v.y) * rstd;
-              v.z = fmaf(-mean, cs[q].z, v.z) * rstd; v.w = fmaf(-mean, cs[q].w, v.w) * rstd;
+            if constexpr (LEAN) {
+              v.x = ps_lnf_bias(v.x, mean, cs[q].x, rstd, bi[q].x); v.y = ps_lnf_bias(v.y, mean, cs[q].y, rstd, bi[q].y);
+              v.z = ps_lnf_bias(v.z, mean, cs[q].z, rstd, bi[q].z); v.w = ps_lnf_bias(v.w, mean, cs[q].w, rstd, bi[q].w);
+            } else {
+              if (lnf) {      // same arithmetic as igemm.hip / rgemm.hip / igemm_reduce_kernel
+                v.x = fmaf(-mean, cs[q].x, v.x) * rstd; v.y = fmaf(-mean, cs[q].y, v.y) * rstd;
+                v.z = fmaf(-mean, cs[q].z, v.z) * rstd; v.w = fmaf(-mean, cs[q].w, v.w) * rstd;
+              }
+              v.x += bi[q].x; v.y += bi[q].y; v.z += bi[q].z; v.w += bi[q].w;
             }
-            v.x += bi[q].x; v.y += bi[q].y; v.z += bi[q].z; v.w += bi[q].w;
             if constexpr (TN % 2 == 0) {
               if (geglu) {
                 constexpr int TNm1 = TN - 1;
                 const int jg = jt + 1 < TN ? jt + 1 : TNm1;       // (jt + 1 < TN whenever this branch runs)
                 float4 g = make_float4(acc[i][jg][4 * q] * alpha, acc[i][jg][4 * q + 1] * alpha, acc[i][jg][4 * q + 2] * alpha,
                                        acc[i][jg][4 * q + 3] * alpha);
-                if (lnf) {
-                  g.x = fmaf(-mean, csg[q].x, g.x) * rstd; g.y = fmaf(-mean, csg[q].y, g.y) * rstd;
-                  g.z = fmaf(-mean, csg[q].z, g.z) * rstd; g.w = fmaf(-mean, csg[q].w, g.w) * rstd;
+                if constexpr (LEAN) {
+                  g.x = ps_lnf_bias(g.x, mean, csg[q].x, rstd, big[q].x); g.y = ps_lnf_bias(g.y, mean, csg[q].y, rstd, big[q].y);
+                  g.z = ps_lnf_bias(g.z, mean, csg[q].z, rstd, big[q].z); g.w = ps_lnf_bias(g.w, mean, csg[q].w, rstd, big[q].w);
+                } else {
+                  if (lnf) {
+                    g.x = fmaf(-mean, csg[q].x, g.x) * rstd; g.y = fmaf(-mean, csg[q].y, g.y) * rstd;
+                    g.z = fmaf(-mean, csg[q].z, g.z) * rstd; g.w = fmaf(-mean, csg[q].w, g.w) * rstd;
+                  }
+                  g.x += big[q].x; g.y += big[q].y; g.z += big[q].z; g.w += big[q].w;
                 }
-                g.x += big[q].x; g.y += big[q].y; g.z += big[q].z; g.w += big[q].w;
                 v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w);
               }
             }
-            v.x += bv[q].x; v.y += bv[q].y; v.z += bv[q].z; v.w += bv[q].w;
-            v.x += rs[q].x; v.y += rs[q].y; v.z += rs[q].z; v.w += rs[q].w;
+            if constexpr (LEAN) {       // (the two absent operands add +0 twice: once is the same bits, -0 -> +0 included)
+              v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f;
+            } else {
+              v.x += bv[q].x; v.y += bv[q].y; v.z += bv[q].z; v.w += bv[q].w;
+              v.x += rs[q].x; v.y += rs[q].y; v.z += rs[q].z; v.w += rs[q].w;
+            }
             if constexpr (KV) {
               if (kv_tile) { kvv[4 * q] = v.x; kvv[4 * q + 1] = v.y; kvv[4 * q + 2] = v.z; kvv[4 * q + 3] = v.w; }
             }
@@ -245,7 +274,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
                   *reinterpret_cast<pbf16x4*>(d + 1024) = m;
                   *reinterpret_cast<pbf16x4*>(d + 2048) = l;
                 } else {
-                  if (ps_h2_out_of_range(v)) *p.range_flag = 1;
+                  bad_ps |= ps_h2_out_of_range(v);
                   pf16x4 h, l;
                   ps_split2h(ps_scaled_sat(v), h, l);
                   *reinterpret_cast<pf16x4*>(d) = h;
@@ -256,7 +285,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
           }
           }
           if constexpr (KV) {
-            if (kv_tile && rowbase + 32 * i < p.M) {
+            if (kv_tile && (LEAN || rowbase + 32 * i < p.M)) {
               const int Cq = p.N / 3;
               const int sec = ctile / Cq;                            // 1 = K, 2 = V
               const int hh = (ctile - sec * Cq) >> 5;
@@ -318,6 +347,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
         }
       }
     }
+    if (bad_ps) *p.range_flag = 1;
     return;
   } else {
     // ---- epilogue, lane = column (igemm_ws.hip's).  C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -455,8 +485,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
   // Which operand the neighbouring workgroups of an XCD share in its L2 (round 5).  These problems are tall (M >> N): the weights
   // are small and L2-resident whatever the order, the A tile is what every column tile re-reads -- with the column tiles of one
   // row tile adjacent (nfast), A comes over the fabric once instead of once per column tile (GEGLU at 64x64: 5x).
-  const int m0 = nfast ? (bid / tiles_n) * BM : (bid % tiles_m) * BM;
-  const int n0 = nfast ? (bid % tiles_n) * BN : (bid / tiles_m) * BN;
+  const int m0 = (nfast & 1) ? (bid / tiles_n) * BM : (bid % tiles_m) * BM;
+  const int n0 = (nfast & 1) ? (bid % tiles_n) * BN : (bid / tiles_m) * BN;
   const int ks = blockIdx.y, bz = blockIdx.z;
 
   const int nkc = p.K / 32;
@@ -587,12 +617,20 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
     if (keep == 12345.678f && ws) ws[0] = keep;
     return;
   }
+  // (wave-uniform: the lean epilogue for a wave tile that lies inside M x N when there is no residual / per-sample vector)
+  const bool lean = TR && !(nfast & 2) && splitk == 1 && p.a_tf == LDMK_TF_LAYERNORM_FOLDED && !p.residual && !p.batch_vec && m0 + (wm + 1) * 32 * TM <= p.M &&
+                    n0 + (wn + 1) * 32 * TN <= p.N;
   if constexpr (KV) {
     __syncthreads();            // every wave is done with the ring: its memory becomes the per-wave V^T transpose scratch
-    ps_epilogue<TM, TN, TR, PL, true>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane,
-                                       reinterpret_cast<float*>(smem_ps) + wave * (32 * 33));
+    if (lean)
+      ps_epilogue<TM, TN, TR, PL, true, TR>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane,
+                                            reinterpret_cast<float*>(smem_ps) + wave * (32 * 33));
+    else
+      ps_epilogue<TM, TN, TR, PL, true>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane,
+                                         reinterpret_cast<float*>(smem_ps) + wave * (32 * 33));
   } else {
-    ps_epilogue<TM, TN, TR, PL>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+    if (lean) ps_epilogue<TM, TN, TR, PL, false, TR>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+    else ps_epilogue<TM, TN, TR, PL>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
   }
 }
 
@@ -924,7 +962,8 @@ static int ps_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream_
   const int dbg = ps_probe_bits();
   static_assert(!KV || (size_t)NWM * NWN * 32 * 33 * 4 <= lds, "V^T transpose scratch fits the ring");
   static const int nfast_env = [] { const char* e = getenv("LDMK_PS_NFAST"); return e ? atoi(e) : 1; }();
-  const int nfast = nfast_env && (a.N + BN - 1) / BN > 1 && (a.M + BM - 1) / BM >= 8;        // (a few row tiles only: the old order)
+  static const int lean_env = [] { const char* e = getenv("LDMK_PS_LEAN"); return e ? atoi(e) : 1; }();     // (0: the general epilogue everywhere, A/B)
+  const int nfast = (nfast_env && (a.N + BN - 1) / BN > 1 && (a.M + BM - 1) / BM >= 8 ? 1 : 0) | (lean_env ? 0 : 2);   // (a few row tiles only: the old order)
   hipLaunchKernelGGL((igemm_ps_kernel<NWM, NWN, TM, TN, NS, TR, PL, KV>), dim3(tiles, splitk, a.batch > 1 ? a.batch : 1), dim3(64 * NWM * NWN), lds,
                      st, a, splitk, ws, dbg, nfast);
   if (splitk > 1 && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
