@@ -136,17 +136,27 @@ __device__ __forceinline__ float ps_lnf_bias(float acc, float mean, float cs, fl
   const float t = __builtin_fmaf(-mean, cs, acc) * rstd;
   return t + bias;
 }
-// LEAN (transposed form; chosen per wave when the whole wave tile is inside M x N and the launch folds a LayerNorm and has neither
-// a residual nor a per-sample vector -- the GEGLU and QKV projections): no row / column predicates, no loads of the absent
-// operands, no select around the LayerNorm arithmetic.  The GEGLU
+// the same for a launch without a folded LayerNorm: alpha acc + b (+ 0 for the absent per-sample vector) + residual, each its own
+// rounding as in the general epilogue (where the `if (lnf)` select sits between the multiply and the first add)
+__device__ __forceinline__ float ps_bias_res(float acc_alpha, float bias, float res) {
+#pragma clang fp contract(off)
+  float t = acc_alpha + bias;
+  t = t + 0.f;
+  return t + res;
+}
+// LEAN != 0 (transposed form; chosen per wave when the whole wave tile is inside M x N, no split-K, no per-sample vector): no row /
+// column predicates, no loads of absent operands, no select around the LayerNorm arithmetic -- the operand set is a template
+// argument: 1 = folded LayerNorm, no residual (the GEGLU and QKV projections), 2 = residual, no LayerNorm (attn.to_out, ff.net.2),
+// 3 = neither (Winograd planes, upsampling phases).  Same arithmetic, rounding by rounding, as the general form (0).  The GEGLU
 // epilogue was ~3000 vector instructions per wave for 64 outputs per lane, a third of them addressing and predication.
-template <int TM, int TN, bool TR, int PL = 3, bool KV = false, bool LEAN = false>
+template <int TM, int TN, bool TR, int PL = 3, bool KV = false, int LEAN = 0>
 __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&acc)[TM][TN], const int rowbase, const int colbase,
                                             const int splitk, const int ks, const int bz, float* __restrict__ ws, const int lane,
                                             float* __restrict__ kv_ts = nullptr) {
   const int l31 = lane & 31, half = lane >> 5;
   const float alpha = p.alpha;
-  const bool lnf = LEAN || p.a_tf == LDMK_TF_LAYERNORM_FOLDED;          // (LEAN: dispatched only with the folded LayerNorm -- no select per value)
+  constexpr bool L_ANY = LEAN != 0, L_LNF = LEAN == 1, L_RS = LEAN == 2;
+  const bool lnf = L_ANY ? L_LNF : p.a_tf == LDMK_TF_LAYERNORM_FOLDED;      // (lean forms: compile-time -- no select per value)
   const float2* __restrict__ stats2 = reinterpret_cast<const float2*>(p.row_stats);
 
   if constexpr (TR) {
@@ -182,7 +192,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = rowbase + 32 * i + l31;
-      const bool rok = LEAN || row < p.M;
+      const bool rok = L_ANY || row < p.M;
       const int rr = rok ? row : p.M - 1;
       float mean = 0.f, rstd = 1.f;
       if (lnf) { const float2 st = stats2[rr]; mean = st.x; rstd = st.y; }
@@ -197,7 +207,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
           if (geglu && jj == 1) break;
           const int jt = j + jj;
           const int ctile = colbase + 32 * jt;
-          if (!LEAN && ctile >= p.N) continue;
+          if (!L_ANY && ctile >= p.N) continue;
           const int otile = geglu ? (ctile >> 1) : ctile;            // first output column of this tile
           float kvv[KV ? 16 : 1];                                    // KV: the finished values of a K / V tile (column 8 q + 4 half + e at [4 q + e])
           const bool kv_tile = KV && ctile >= p.N / 3;
@@ -207,15 +217,17 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
 #pragma unroll
           for (int q = qh; q < qh + 2; ++q) {                        // their operands are all requested before the first use
             const unsigned c = (unsigned)(ctile + 8 * q + 4 * half), oc = (unsigned)(otile + 8 * q + 4 * half);
-            cs[q] = *reinterpret_cast<const float4*>(csp + (c & mcs));
+            if constexpr (!L_ANY || L_LNF) cs[q] = *reinterpret_cast<const float4*>(csp + (c & mcs));
             bi[q] = *reinterpret_cast<const float4*>(bip + (c & mbi));
-            if constexpr (!LEAN) {
+            if constexpr (!L_ANY) {
               bv[q] = *reinterpret_cast<const float4*>(bvp + (oc & mbv));
               rs[q] = *reinterpret_cast<const float4*>(rsp + ((rowoff + oc) & mrs));
+            } else if constexpr (L_RS) {
+              rs[q] = *reinterpret_cast<const float4*>(rsp + (rowoff + oc));
             }
             if constexpr (TN % 2 == 0) {
               if (geglu) {
-                csg[q] = *reinterpret_cast<const float4*>(csp + ((c + 32) & mcs));
+                if constexpr (!L_ANY || L_LNF) csg[q] = *reinterpret_cast<const float4*>(csp + ((c + 32) & mcs));
                 big[q] = *reinterpret_cast<const float4*>(bip + ((c + 32) & mbi));
               }
             }
@@ -224,9 +236,10 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
           for (int q = qh; q < qh + 2; ++q) {
             float4 v = make_float4(acc[i][jt][4 * q] * alpha, acc[i][jt][4 * q + 1] * alpha, acc[i][jt][4 * q + 2] * alpha,
                                    acc[i][jt][4 * q + 3] * alpha);
-            if constexpr (LEAN) {
+            if constexpr (L_LNF) {
               v.x = ps_lnf_bias(v.x, mean, cs[q].x, rstd, bi[q].x); v.y = ps_lnf_bias(v.y, mean, cs[q].y, rstd, bi[q].y);
               v.z = ps_lnf_bias(v.z, mean, cs[q].z, rstd, bi[q].z); v.w = ps_lnf_bias(v.w, mean, cs[q].w, rstd, bi[q].w);
+            } else if constexpr (L_ANY) {        // (bias, +0, residual: in ps_bias_res below, once the GEGLU gate is through)
             } else {
               if (lnf) {      // same arithmetic as igemm.hip / rgemm.hip / igemm_reduce_kernel
                 v.x = fmaf(-mean, cs[q].x, v.x) * rstd; v.y = fmaf(-mean, cs[q].y, v.y) * rstd;
@@ -240,7 +253,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
                 const int jg = jt + 1 < TN ? jt + 1 : TNm1;       // (jt + 1 < TN whenever this branch runs)
                 float4 g = make_float4(acc[i][jg][4 * q] * alpha, acc[i][jg][4 * q + 1] * alpha, acc[i][jg][4 * q + 2] * alpha,
                                        acc[i][jg][4 * q + 3] * alpha);
-                if constexpr (LEAN) {
+                if constexpr (L_LNF) {
                   g.x = ps_lnf_bias(g.x, mean, csg[q].x, rstd, big[q].x); g.y = ps_lnf_bias(g.y, mean, csg[q].y, rstd, big[q].y);
                   g.z = ps_lnf_bias(g.z, mean, csg[q].z, rstd, big[q].z); g.w = ps_lnf_bias(g.w, mean, csg[q].w, rstd, big[q].w);
                 } else {
@@ -253,8 +266,12 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
                 v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w);
               }
             }
-            if constexpr (LEAN) {       // (the two absent operands add +0 twice: once is the same bits, -0 -> +0 included)
+            if constexpr (L_LNF) {      // (the two absent operands add +0 twice: once is the same bits, -0 -> +0 included)
               v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f;
+            } else if constexpr (L_ANY) {
+              const float4 r4 = L_RS ? rs[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+              v.x = ps_bias_res(v.x, bi[q].x, r4.x); v.y = ps_bias_res(v.y, bi[q].y, r4.y);
+              v.z = ps_bias_res(v.z, bi[q].z, r4.z); v.w = ps_bias_res(v.w, bi[q].w, r4.w);
             } else {
               v.x += bv[q].x; v.y += bv[q].y; v.z += bv[q].z; v.w += bv[q].w;
               v.x += rs[q].x; v.y += rs[q].y; v.z += rs[q].z; v.w += rs[q].w;
@@ -285,7 +302,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
           }
           }
           if constexpr (KV) {
-            if (kv_tile && (LEAN || rowbase + 32 * i < p.M)) {
+            if (kv_tile && (L_ANY || rowbase + 32 * i < p.M)) {
               const int Cq = p.N / 3;
               const int sec = ctile / Cq;                            // 1 = K, 2 = V
               const int hh = (ctile - sec * Cq) >> 5;
@@ -617,19 +634,24 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
     if (keep == 12345.678f && ws) ws[0] = keep;
     return;
   }
-  // (wave-uniform: the lean epilogue for a wave tile that lies inside M x N when there is no residual / per-sample vector)
-  const bool lean = TR && !(nfast & 2) && splitk == 1 && p.a_tf == LDMK_TF_LAYERNORM_FOLDED && !p.residual && !p.batch_vec && m0 + (wm + 1) * 32 * TM <= p.M &&
-                    n0 + (wn + 1) * 32 * TN <= p.N;
+  // (wave-uniform: a lean epilogue for a wave tile that lies inside M x N; which one by the launch's operand set)
+  int lean = 0;
+  if (TR && !(nfast & 2) && splitk == 1 && !p.batch_vec && m0 + (wm + 1) * 32 * TM <= p.M && n0 + (wn + 1) * 32 * TN <= p.N) {
+    const bool lf = p.a_tf == LDMK_TF_LAYERNORM_FOLDED;
+    lean = lf ? (p.residual ? 0 : 1) : (p.epi == LDMK_EPI_GEGLU ? 0 : (p.residual ? 2 : 3));
+  }
   if constexpr (KV) {
     __syncthreads();            // every wave is done with the ring: its memory becomes the per-wave V^T transpose scratch
-    if (lean)
-      ps_epilogue<TM, TN, TR, PL, true, TR>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane,
-                                            reinterpret_cast<float*>(smem_ps) + wave * (32 * 33));
+    if (lean == 1)
+      ps_epilogue<TM, TN, TR, PL, true, TR ? 1 : 0>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane,
+                                                    reinterpret_cast<float*>(smem_ps) + wave * (32 * 33));
     else
       ps_epilogue<TM, TN, TR, PL, true>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane,
                                          reinterpret_cast<float*>(smem_ps) + wave * (32 * 33));
   } else {
-    if (lean) ps_epilogue<TM, TN, TR, PL, false, TR>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+    if (lean == 1) ps_epilogue<TM, TN, TR, PL, false, TR ? 1 : 0>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+    else if (lean == 2) ps_epilogue<TM, TN, TR, PL, false, TR ? 2 : 0>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+    else if (lean == 3) ps_epilogue<TM, TN, TR, PL, false, TR ? 3 : 0>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
     else ps_epilogue<TM, TN, TR, PL>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
   }
 }
