@@ -144,10 +144,24 @@ __device__ __forceinline__ float ps_bias_res(float acc_alpha, float bias, float 
   t = t + 0.f;
   return t + res;
 }
+// lane = column form: alpha acc + bias [+ per-sample vector | + residual], each addition its own rounding as in the general form
+__device__ __forceinline__ float ps_col_finish(float acc_alpha, float bias) {
+#pragma clang fp contract(off)
+  return acc_alpha + bias;
+}
+__device__ __forceinline__ float ps_col_finish(float acc_alpha, float bias, float extra) {
+#pragma clang fp contract(off)
+  const float t = acc_alpha + bias;
+  return t + extra;
+}
 // LEAN != 0 (transposed form; chosen per wave when the whole wave tile is inside M x N, no split-K, no per-sample vector): no row /
 // column predicates, no loads of absent operands, no select around the LayerNorm arithmetic -- the operand set is a template
 // argument: 1 = folded LayerNorm, no residual (the GEGLU and QKV projections), 2 = residual, no LayerNorm (attn.to_out, ff.net.2),
-// 3 = neither (Winograd planes, upsampling phases).  Same arithmetic, rounding by rounding, as the general form (0).  The GEGLU
+// 3 = neither (Winograd planes, upsampling phases).  Lane = column form (the convolutions: bias, then the time-embedding vector
+// or the skip connection, GroupNorm records): 1 = per-sample vector, 2 = residual, 3 = neither -- there every element of the
+// general form sits behind its own row predicate and operand branches, so each residual load waited for itself (577 s_waitcnt in
+// the 160 -> 160 convolution's kernel); the lean form asks for the 16 residuals of a tile at once.  Same arithmetic, rounding by
+// rounding, as the general form (0).  The GEGLU
 // epilogue was ~3000 vector instructions per wave for 64 outputs per lane, a third of them addressing and predication.
 template <int TM, int TN, bool TR, int PL = 3, bool KV = false, int LEAN = 0>
 __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&acc)[TM][TN], const int rowbase, const int colbase,
@@ -422,6 +436,53 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
       }
       return;
     }
+    if constexpr (LEAN != 0) {
+      // (dispatch: whole wave tile inside M x N, no split-K, no folded LayerNorm, 32-row tiles inside one sample)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = colbase + j * 32 + l31;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int r0 = rowbase + i * 32 + 4 * half;
+          const unsigned obase = (unsigned)r0 * (unsigned)p.ldc + (unsigned)col;
+          float extra[16];
+          if constexpr (LEAN == 1) {
+            const float vec = p.batch_vec[(long long)((rowbase + i * 32) / p.rows_per_sample) * p.batch_vec_ld + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) extra[r] = vec;
+          } else if constexpr (LEAN == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) extra[r] = resp[obase + (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ldc)];
+          }
+          float vals[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float t = acc[i][j][r] * alpha;
+            if constexpr (LEAN == 3) vals[r] = ps_col_finish(t, bv);
+            else vals[r] = ps_col_finish(t, bv, extra[r]);
+            outp[obase + (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ldc)] = vals[r];
+          }
+          if (p.stats_out) {
+            const float shift = __shfl(vals[0], l31, 64);      // row 0 of the tile
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float d = vals[r] - shift;
+              sm += d;
+              sq = fmaf(d, d, sq);
+            }
+            sm += __shfl_xor(sm, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (half == 0) {
+              float* d = p.stats_out + ((long long)((rowbase + i * 32) >> 5) * p.N + col) * 3;
+              d[0] = shift; d[1] = sm; d[2] = sq;
+            }
+          }
+        }
+      }
+      return;
+    }
     const bool tile_in_sample = p.rows_per_sample % 32 == 0;
     int smp[TM];
 #pragma unroll
@@ -477,6 +538,20 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
         }
       }
     }
+  }
+}
+
+// which lean epilogue (ps_epilogue's LEAN) a wave tile ending at (row_end, col_end) may take; 0 = the general one
+template <bool TR>
+__device__ __forceinline__ int ps_lean_form(const ldmk_igemm_args& p, const int splitk, const bool off, const int row_end, const int col_end) {
+  if (off || splitk != 1 || row_end > p.M || col_end > p.N) return 0;
+  const bool lf = p.a_tf == LDMK_TF_LAYERNORM_FOLDED, geglu = p.epi == LDMK_EPI_GEGLU;
+  if constexpr (TR) {
+    if (p.batch_vec) return 0;
+    return lf ? (p.residual ? 0 : 1) : (geglu ? 0 : (p.residual ? 2 : 3));
+  } else {
+    if (lf || geglu || (p.batch_vec && (p.residual || p.rows_per_sample % 32 != 0))) return 0;
+    return p.batch_vec ? 1 : (p.residual ? 2 : 3);
   }
 }
 
@@ -635,11 +710,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
     return;
   }
   // (wave-uniform: a lean epilogue for a wave tile that lies inside M x N; which one by the launch's operand set)
-  int lean = 0;
-  if (TR && !(nfast & 2) && splitk == 1 && !p.batch_vec && m0 + (wm + 1) * 32 * TM <= p.M && n0 + (wn + 1) * 32 * TN <= p.N) {
-    const bool lf = p.a_tf == LDMK_TF_LAYERNORM_FOLDED;
-    lean = lf ? (p.residual ? 0 : 1) : (p.epi == LDMK_EPI_GEGLU ? 0 : (p.residual ? 2 : 3));
-  }
+  const int lean = ps_lean_form<TR>(p, splitk, (nfast & 2) != 0, m0 + (wm + 1) * 32 * TM, n0 + (wn + 1) * 32 * TN);
   if constexpr (KV) {
     __syncthreads();            // every wave is done with the ring: its memory becomes the per-wave V^T transpose scratch
     if (lean == 1)
@@ -649,9 +720,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
       ps_epilogue<TM, TN, TR, PL, true>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane,
                                          reinterpret_cast<float*>(smem_ps) + wave * (32 * 33));
   } else {
-    if (lean == 1) ps_epilogue<TM, TN, TR, PL, false, TR ? 1 : 0>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
-    else if (lean == 2) ps_epilogue<TM, TN, TR, PL, false, TR ? 2 : 0>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
-    else if (lean == 3) ps_epilogue<TM, TN, TR, PL, false, TR ? 3 : 0>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+    if (lean == 1) ps_epilogue<TM, TN, TR, PL, false, 1>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+    else if (lean == 2) ps_epilogue<TM, TN, TR, PL, false, 2>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+    else if (lean == 3) ps_epilogue<TM, TN, TR, PL, false, 3>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
     else ps_epilogue<TM, TN, TR, PL>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
   }
 }
@@ -1041,8 +1112,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_psc_kernel(const ldmk
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = nfast ? (bid / tiles_n) * BM : (bid % tiles_m) * BM;       // (see igemm_ps_kernel: column tiles of a row tile adjacent)
-  const int n0 = nfast ? (bid % tiles_n) * BN : (bid / tiles_m) * BN;
+  const int m0 = (nfast & 1) ? (bid / tiles_n) * BM : (bid % tiles_m) * BM;       // (see igemm_ps_kernel: column tiles of a row tile adjacent)
+  const int n0 = (nfast & 1) ? (bid % tiles_n) * BN : (bid / tiles_m) * BN;
   const int ks = blockIdx.y;
 
   const int C = p.c0;
@@ -1152,7 +1223,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_psc_kernel(const ldmk
     }
   }
   ps_wait_vm<0>();
-  ps_epilogue<TM, TN, TR, PL>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, 0, ws, lane);
+  const int lean = ps_lean_form<TR>(p, splitk, (nfast & 2) != 0, m0 + (wm + 1) * 32 * TM, n0 + (wn + 1) * 32 * TN);
+  if (lean == 1) ps_epilogue<TM, TN, TR, PL, false, 1>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, 0, ws, lane);
+  else if (lean == 2) ps_epilogue<TM, TN, TR, PL, false, 2>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, 0, ws, lane);
+  else if (lean == 3) ps_epilogue<TM, TN, TR, PL, false, 3>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, 0, ws, lane);
+  else ps_epilogue<TM, TN, TR, PL>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, 0, ws, lane);
 }
 
 // GroupNorm scale / shift [+ SiLU] of (the channel concat of) x0 | x1 written ONCE as the [n hw][C] matrix in the F16X2 form of
@@ -1202,7 +1277,8 @@ static int psc_launch(const ldmk_igemm_args& a, int splitk, float* ws, hipStream
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   static const int nfast_env = [] { const char* e = getenv("LDMK_PS_NFAST"); return e ? atoi(e) : 1; }();
-  const int nfast = nfast_env && (a.N + BN - 1) / BN > 1 && (a.M + BM - 1) / BM >= 8;
+  static const int lean_env = [] { const char* e = getenv("LDMK_PS_LEAN"); return e ? atoi(e) : 1; }();
+  const int nfast = (nfast_env && (a.N + BN - 1) / BN > 1 && (a.M + BM - 1) / BM >= 8 ? 1 : 0) | (lean_env ? 0 : 2);
   hipLaunchKernelGGL((igemm_psc_kernel<NWM, NWN, TM, TN, TR>), dim3(tiles, splitk, 1), dim3(64 * NWM * NWN), lds, st, a, splitk, ws, nfast);
   if (splitk > 1 && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
   return check_launch("ldmk_igemm(ps, conv)");
