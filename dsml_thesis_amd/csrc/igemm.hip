@@ -90,6 +90,70 @@ __device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf
 // statistics pass, ldmk_ln_stats_split) -- rows mode, one source, no staging prologue.  Its staging is then a 16-byte copy like
 // B's: no split arithmetic per N-tile (a GEGLU projection re-split every A element N/BN = 8..40 times), 6 + 8 loads and
 // LDS stores per thread and slice instead of 4 + 8 loads, ~90 vector operations and 12 + 8 stores.
+// The lean form of the epilogue below (F16X2 launches, one wave tile wholly inside M x N, no split-K, no folded LayerNorm, no
+// GEGLU, 32-row tiles inside one sample): no per-element row predicate and operand branches -- in the general form every
+// residual load sits in its own basic block and waits for itself -- and the operand set is a template argument: 1 = per-sample
+// vector, 2 = residual, 3 = neither.  Same arithmetic, rounding by rounding (csrc/igemm_ps.hip has the same pair of forms).
+__device__ __forceinline__ float ig_col_finish(float acc_alpha, float bias) {
+#pragma clang fp contract(off)
+  return acc_alpha + bias;
+}
+__device__ __forceinline__ float ig_col_finish(float acc_alpha, float bias, float extra) {
+#pragma clang fp contract(off)
+  const float t = acc_alpha + bias;
+  return t + extra;
+}
+template <int TM, int TN, int LEAN>
+__device__ __forceinline__ void ig_lean_epilogue(const ldmk_igemm_args& p, f32x16 (&acc)[TM][TN], const int rowbase, const int colbase, const int bz,
+                                                 const int l31, const int half) {
+  float* __restrict__ outp = p.out + (long long)bz * p.out_bstride;
+  const float* __restrict__ resp = p.residual + (long long)bz * p.out_bstride;      // (LEAN == 2 only)
+  const float alpha = p.alpha;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = colbase + j * 32 + l31;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r0 = rowbase + i * 32 + 4 * half;
+      const unsigned obase = (unsigned)r0 * (unsigned)p.ldc + (unsigned)col;
+      float extra[16];
+      if constexpr (LEAN == 1) {
+        const float vec = p.batch_vec[(long long)((rowbase + i * 32) / p.rows_per_sample) * p.batch_vec_ld + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) extra[r] = vec;
+      } else if constexpr (LEAN == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) extra[r] = resp[obase + (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ldc)];
+      }
+      float vals[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = acc[i][j][r] * alpha;
+        if constexpr (LEAN == 3) vals[r] = ig_col_finish(t, bv);
+        else vals[r] = ig_col_finish(t, bv, extra[r]);
+        outp[obase + (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ldc)] = vals[r];
+      }
+      if (p.stats_out) {
+        const float shift = __shfl(vals[0], l31, 64);      // row 0 of the tile
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = vals[r] - shift;
+          sm += d;
+          sq = fmaf(d, d, sq);
+        }
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if (half == 0) {
+          float* d = p.stats_out + ((long long)((rowbase + i * 32) >> 5) * p.N + col) * 3;
+          d[0] = shift; d[1] = sm; d[2] = sq;
+        }
+      }
+    }
+  }
+}
+
 template <int TM, int TN, int WM, int WN, int WK, int KS, bool DB, bool BT, int BF = 0, bool FG = true, bool ASP = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, const int splitk, float* __restrict__ ws, const int nfast) {
   constexpr int BM = 32 * TM * WM;
@@ -139,8 +203,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   // (nfast, round 5: the column tiles of one row tile adjacent on an XCD -- they share the A tile in its L2; csrc/igemm_ps.hip)
-  const int m0 = nfast ? (bid / tiles_n) * BM : (bid % tiles_m) * BM;
-  const int n0 = nfast ? (bid % tiles_n) * BN : (bid / tiles_m) * BN;
+  const int m0 = (nfast & 1) ? (bid / tiles_n) * BM : (bid % tiles_m) * BM;
+  const int n0 = (nfast & 1) ? (bid % tiles_n) * BN : (bid / tiles_m) * BN;
   const int ks = blockIdx.y;            // cross-workgroup K split index
   const int bz = blockIdx.z;
 
@@ -820,6 +884,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   } else if (wk != 0) {
     return;
   }
+  if constexpr (BF == 4) {
+    // (wave-uniform; LDMK_IG_LEAN=0 -> bit 1 of nfast: the general form everywhere, A/B)
+    if (!(nfast & 2) && splitk == 1 && p.a_tf != LDMK_TF_LAYERNORM_FOLDED && p.epi != LDMK_EPI_GEGLU && rowbase + 32 * TM <= p.M &&
+        colbase + 32 * TN <= p.N && !(p.batch_vec && (p.residual || p.rows_per_sample % 32 != 0))) {
+      if (p.batch_vec) ig_lean_epilogue<TM, TN, 1>(p, acc, rowbase, colbase, bz, l31, half);
+      else if (p.residual) ig_lean_epilogue<TM, TN, 2>(p, acc, rowbase, colbase, bz, l31, half);
+      else ig_lean_epilogue<TM, TN, 3>(p, acc, rowbase, colbase, bz, l31, half);
+      return;
+    }
+  }
   float* __restrict__ outp = p.out + (long long)bz * p.out_bstride;
   const float* resp = p.residual ? p.residual + (long long)bz * p.out_bstride : nullptr;
   const float alpha = p.alpha;
@@ -1154,7 +1228,8 @@ static int launch_cfg_g(const ldmk_igemm_args& a, int splitk, float* ws, hipStre
   cfg_set_attr<TM, TN, WM, WN, WK, KS, DB, BT, BF, FG, ASP>();
   static const int nfast_env = [] { const char* e = getenv("LDMK_IG_NFAST"); return e ? atoi(e) : 1; }();
   // tall problems only (M >> N: activations x a weight matrix); weight-gradient-like or b_trans shapes keep the old order
-  const int nfast = nfast_env && !a.b_trans && (a.N + BN - 1) / BN > 1 && (a.M + BM - 1) / BM >= 8;
+  static const int lean_env = [] { const char* e = getenv("LDMK_IG_LEAN"); return e ? atoi(e) : 1; }();      // (0: the general epilogue everywhere, A/B)
+  const int nfast = (nfast_env && !a.b_trans && (a.N + BN - 1) / BN > 1 && (a.M + BM - 1) / BM >= 8 ? 1 : 0) | (lean_env ? 0 : 2);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a, splitk, ws, nfast);
   if (splitk > 1 && !a.splitk_counters && !a.raw_slabs) return launch_splitk_reduce(a, splitk, ws, st);
   // (splitk_counters: the last-arriving workgroup of each tile combined the slabs and ran the epilogue inside the launch;
