@@ -90,7 +90,7 @@ __device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf
 // statistics pass, ldmk_ln_stats_split) -- rows mode, one source, no staging prologue.  Its staging is then a 16-byte copy like
 // B's: no split arithmetic per N-tile (a GEGLU projection re-split every A element N/BN = 8..40 times), 6 + 8 loads and
 // LDS stores per thread and slice instead of 4 + 8 loads, ~90 vector operations and 12 + 8 stores.
-// The lean form of the epilogue below (F16X2 launches, one wave tile wholly inside M x N, no split-K, no folded LayerNorm, no
+// The lean form of the epilogue below (one wave tile wholly inside M x N, no split-K, no folded LayerNorm, no
 // GEGLU, 32-row tiles inside one sample): no per-element row predicate and operand branches -- in the general form every
 // residual load sits in its own basic block and waits for itself -- and the operand set is a template argument: 1 = per-sample
 // vector, 2 = residual, 3 = neither.  Same arithmetic, rounding by rounding (csrc/igemm_ps.hip has the same pair of forms).
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   } else if (wk != 0) {
     return;
   }
-  if constexpr (BF == 4) {
+  {
     // (wave-uniform; LDMK_IG_LEAN=0 -> bit 1 of nfast: the general form everywhere, A/B)
     if (!(nfast & 2) && splitk == 1 && p.a_tf != LDMK_TF_LAYERNORM_FOLDED && p.epi != LDMK_EPI_GEGLU && rowbase + 32 * TM <= p.M &&
         colbase + 32 * TN <= p.N && !(p.batch_vec && (p.residual || p.rows_per_sample % 32 != 0))) {
