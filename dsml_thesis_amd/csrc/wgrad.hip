@@ -420,10 +420,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ldmk_wgrad_args
   float* outp = p.dw + (long long)bz * p.dw_bstride;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int row = (int)(i / n4), col = (int)(i - (long long)row * n4) * 4;
-    float4 s = *reinterpret_cast<const float4*>(slab0 + (long long)row * p.N + col);
-    for (int k = 1; k < splitr; ++k) {
-      const float4 t = *reinterpret_cast<const float4*>(slab0 + ((long long)k * srows + row) * p.N + col);
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    // eight slabs requested at a time, summed in slab order (the split runs to dozens of slabs: one load per trip, each waiting
+    // for itself, made this kernel a chain of memory round trips)
+    const float* sp = slab0 + (long long)row * p.N + col;
+    const long long sstride = (long long)srows * p.N;
+    float4 s = *reinterpret_cast<const float4*>(sp);
+    for (int k0 = 1; k0 < splitr; k0 += 8) {
+      float4 t[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) t[kk] = *reinterpret_cast<const float4*>(sp + (long long)min(k0 + kk, splitr - 1) * sstride);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+        if (k0 + kk < splitr) { s.x += t[kk].x; s.y += t[kk].y; s.z += t[kk].z; s.w += t[kk].w; }
     }
     s.x *= p.alpha; s.y *= p.alpha; s.z *= p.alpha; s.w *= p.alpha;
     float* d = row < p.Kw ? outp + (long long)row * p.ldw + col : p.dbias + col;
