@@ -107,7 +107,7 @@ template <int TM, int TN, int LEAN>
 __device__ __forceinline__ void ig_lean_epilogue(const ldmk_igemm_args& p, f32x16 (&acc)[TM][TN], const int rowbase, const int colbase, const int bz,
                                                  const int l31, const int half) {
   float* __restrict__ outp = p.out + (long long)bz * p.out_bstride;
-  const float* __restrict__ resp = p.residual + (long long)bz * p.out_bstride;      // (LEAN == 2 only)
+  const float* __restrict__ resp = LEAN == 2 ? p.residual + (long long)bz * p.out_bstride : nullptr;
   const float alpha = p.alpha;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
