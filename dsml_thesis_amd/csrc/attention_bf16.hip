@@ -876,7 +876,6 @@ __device__ __forceinline__ void h2_dma4(unsigned voff, const au32x4& rs, unsigne
 //   - the rescale factor 2^(m_old - m_new) is an exact power of two (no rounding in O or l), and it is needed only when a
 //     row's maximum crosses an integer.
 // -DLDMK_H2_SOFTMAX_R4: the round-4 form (A/B)
-template <int OFF = 14>
 __device__ __forceinline__ void h2_softmax(f32x16& s, f32x16& o, float& m_run, float& l_run) {
   constexpr float INV = 1.0f / (H2_S * H2_S);
   float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
@@ -890,7 +889,7 @@ __device__ __forceinline__ void h2_softmax(f32x16& s, f32x16& o, float& m_run, f
   const f32x2 mm2 = {m_new, m_new}, inv2 = {INV, INV}, off2 = {H2_PEXP, H2_PEXP};
 #else
   const float m_new = fmaxf(m_run, __builtin_ceilf(fmaxf(a, b) * INV));
-  const f32x2 inv2 = {INV, INV}, off2 = {(float)OFF - m_new, (float)OFF - m_new};
+  const f32x2 inv2 = {INV, INV}, off2 = {H2_PEXP - m_new, H2_PEXP - m_new};
 #endif
   f32x2 ps = {0.f, 0.f};
 #pragma unroll
@@ -1180,6 +1179,11 @@ __device__ __forceinline__ void h2p_step_lazy(f32x16& s, f32x16& sn, f32x16& op,
   pb[1][1] = __builtin_bit_cast(f16x8_t, l1);
   H2P_FENCE();
 }
+
+#undef H2P_SUM
+#undef H2P_EXP2
+#undef H2P_SPLIT_PAIR
+#undef H2P_FENCE
 
 // QB = query blocks of 32 per wave; PIPE (QB = 2, tokens a multiple of 256): the pipelined key loop, h2p_step; LAZY: the lazy
 // running maximum (h2p_step_lazy) behind the exact first tile of every row -- pipelined loop only: in the phase-separated loop it
