@@ -93,7 +93,7 @@ __device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf
 // The lean form of the epilogue below (one wave tile wholly inside M x N, no split-K, no folded LayerNorm, no
 // GEGLU, 32-row tiles inside one sample): no per-element row predicate and operand branches -- in the general form every
 // residual load sits in its own basic block and waits for itself -- and the operand set is a template argument: 1 = per-sample
-// vector, 2 = residual, 3 = neither.  Same arithmetic, rounding by rounding (csrc/igemm_ps.hip has the same pair of forms).
+// vector, 2 = residual, 3 = neither, 4 = both.  Same arithmetic, rounding by rounding (csrc/igemm_ps.hip has the same pair of forms).
 __device__ __forceinline__ float ig_col_finish(float acc_alpha, float bias) {
 #pragma clang fp contract(off)
   return acc_alpha + bias;
@@ -103,11 +103,17 @@ __device__ __forceinline__ float ig_col_finish(float acc_alpha, float bias, floa
   const float t = acc_alpha + bias;
   return t + extra;
 }
+__device__ __forceinline__ float ig_col_finish(float acc_alpha, float bias, float vec, float res) {
+#pragma clang fp contract(off)
+  float t = acc_alpha + bias;
+  t = t + vec;
+  return t + res;
+}
 template <int TM, int TN, int LEAN>
 __device__ __forceinline__ void ig_lean_epilogue(const ldmk_igemm_args& p, f32x16 (&acc)[TM][TN], const int rowbase, const int colbase, const int bz,
                                                  const int l31, const int half) {
   float* __restrict__ outp = p.out + (long long)bz * p.out_bstride;
-  const float* __restrict__ resp = LEAN == 2 ? p.residual + (long long)bz * p.out_bstride : nullptr;
+  const float* __restrict__ resp = (LEAN == 2 || LEAN == 4) ? p.residual + (long long)bz * p.out_bstride : nullptr;
   const float alpha = p.alpha;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -117,12 +123,9 @@ __device__ __forceinline__ void ig_lean_epilogue(const ldmk_igemm_args& p, f32x1
     for (int i = 0; i < TM; ++i) {
       const int r0 = rowbase + i * 32 + 4 * half;
       const unsigned obase = (unsigned)r0 * (unsigned)p.ldc + (unsigned)col;
-      float extra[16];
-      if constexpr (LEAN == 1) {
-        const float vec = p.batch_vec[(long long)((rowbase + i * 32) / p.rows_per_sample) * p.batch_vec_ld + col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) extra[r] = vec;
-      } else if constexpr (LEAN == 2) {
+      float extra[16], vec = 0.f;
+      if constexpr (LEAN == 1 || LEAN == 4) vec = p.batch_vec[(long long)((rowbase + i * 32) / p.rows_per_sample) * p.batch_vec_ld + col];
+      if constexpr (LEAN == 2 || LEAN == 4) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) extra[r] = resp[obase + (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ldc)];
       }
@@ -131,7 +134,9 @@ __device__ __forceinline__ void ig_lean_epilogue(const ldmk_igemm_args& p, f32x1
       for (int r = 0; r < 16; ++r) {
         const float t = acc[i][j][r] * alpha;
         if constexpr (LEAN == 3) vals[r] = ig_col_finish(t, bv);
-        else vals[r] = ig_col_finish(t, bv, extra[r]);
+        else if constexpr (LEAN == 1) vals[r] = ig_col_finish(t, bv, vec);
+        else if constexpr (LEAN == 2) vals[r] = ig_col_finish(t, bv, extra[r]);
+        else vals[r] = ig_col_finish(t, bv, vec, extra[r]);
         outp[obase + (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ldc)] = vals[r];
       }
       if (p.stats_out) {
@@ -887,8 +892,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ldmk_igemm_args p, con
   {
     // (wave-uniform; LDMK_IG_LEAN=0 -> bit 1 of nfast: the general form everywhere, A/B)
     if (!(nfast & 2) && splitk == 1 && p.a_tf != LDMK_TF_LAYERNORM_FOLDED && p.epi != LDMK_EPI_GEGLU && rowbase + 32 * TM <= p.M &&
-        colbase + 32 * TN <= p.N && !(p.batch_vec && (p.residual || p.rows_per_sample % 32 != 0))) {
-      if (p.batch_vec) ig_lean_epilogue<TM, TN, 1>(p, acc, rowbase, colbase, bz, l31, half);
+        colbase + 32 * TN <= p.N && !(p.batch_vec && p.rows_per_sample % 32 != 0)) {
+      if (p.batch_vec && p.residual) ig_lean_epilogue<TM, TN, 4>(p, acc, rowbase, colbase, bz, l31, half);
+      else if (p.batch_vec) ig_lean_epilogue<TM, TN, 1>(p, acc, rowbase, colbase, bz, l31, half);
       else if (p.residual) ig_lean_epilogue<TM, TN, 2>(p, acc, rowbase, colbase, bz, l31, half);
       else ig_lean_epilogue<TM, TN, 3>(p, acc, rowbase, colbase, bz, l31, half);
       return;

@@ -138,10 +138,10 @@ __device__ __forceinline__ float ps_lnf_bias(float acc, float mean, float cs, fl
 }
 // the same for a launch without a folded LayerNorm: alpha acc + b (+ 0 for the absent per-sample vector) + residual, each its own
 // rounding as in the general epilogue (where the `if (lnf)` select sits between the multiply and the first add)
-__device__ __forceinline__ float ps_bias_res(float acc_alpha, float bias, float res) {
+__device__ __forceinline__ float ps_bias_res(float acc_alpha, float bias, float vec, float res) {
 #pragma clang fp contract(off)
   float t = acc_alpha + bias;
-  t = t + 0.f;
+  t = t + vec;                 // (the per-sample vector, or +0 where the general form adds its zero)
   return t + res;
 }
 // lane = column form: alpha acc + bias [+ per-sample vector | + residual], each addition its own rounding as in the general form
@@ -154,11 +154,18 @@ __device__ __forceinline__ float ps_col_finish(float acc_alpha, float bias, floa
   const float t = acc_alpha + bias;
   return t + extra;
 }
+__device__ __forceinline__ float ps_col_finish(float acc_alpha, float bias, float vec, float res) {
+#pragma clang fp contract(off)
+  float t = acc_alpha + bias;
+  t = t + vec;
+  return t + res;
+}
 // LEAN != 0 (transposed form; chosen per wave when the whole wave tile is inside M x N, no split-K, no per-sample vector): no row /
 // column predicates, no loads of absent operands, no select around the LayerNorm arithmetic -- the operand set is a template
 // argument: 1 = folded LayerNorm, no residual (the GEGLU and QKV projections), 2 = residual, no LayerNorm (attn.to_out, ff.net.2),
-// 3 = neither (Winograd planes, upsampling phases).  Lane = column form (the convolutions: bias, then the time-embedding vector
-// or the skip connection, GroupNorm records): 1 = per-sample vector, 2 = residual, 3 = neither -- there every element of the
+// 3 = neither (Winograd planes, upsampling phases), 4 = residual + per-sample vector (attn1.to_out carrying the single-token
+// cross-attention vector).  Lane = column form (the convolutions: bias, then the time-embedding vector
+// or the skip connection, GroupNorm records): 1 = per-sample vector, 2 = residual, 3 = neither, 4 = both -- there every element of the
 // general form sits behind its own row predicate and operand branches, so each residual load waited for itself (577 s_waitcnt in
 // the 160 -> 160 convolution's kernel); the lean form asks for the 16 residuals of a tile at once.  Same arithmetic, rounding by
 // rounding, as the general form (0).  The GEGLU
@@ -169,7 +176,7 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
                                             float* __restrict__ kv_ts = nullptr) {
   const int l31 = lane & 31, half = lane >> 5;
   const float alpha = p.alpha;
-  constexpr bool L_ANY = LEAN != 0, L_LNF = LEAN == 1, L_RS = LEAN == 2;
+  constexpr bool L_ANY = LEAN != 0, L_LNF = LEAN == 1, L_RS = LEAN == 2 || LEAN == 4, L_BV = LEAN == 4;
   const bool lnf = L_ANY ? L_LNF : p.a_tf == LDMK_TF_LAYERNORM_FOLDED;      // (lean forms: compile-time -- no select per value)
   const float2* __restrict__ stats2 = reinterpret_cast<const float2*>(p.row_stats);
 
@@ -236,8 +243,9 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
             if constexpr (!L_ANY) {
               bv[q] = *reinterpret_cast<const float4*>(bvp + (oc & mbv));
               rs[q] = *reinterpret_cast<const float4*>(rsp + ((rowoff + oc) & mrs));
-            } else if constexpr (L_RS) {
-              rs[q] = *reinterpret_cast<const float4*>(rsp + (rowoff + oc));
+            } else {
+              if constexpr (L_RS) rs[q] = *reinterpret_cast<const float4*>(rsp + (rowoff + oc));
+              if constexpr (L_BV) bv[q] = *reinterpret_cast<const float4*>(bvp + oc);
             }
             if constexpr (TN % 2 == 0) {
               if (geglu) {
@@ -283,9 +291,9 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
             if constexpr (L_LNF) {      // (the two absent operands add +0 twice: once is the same bits, -0 -> +0 included)
               v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f;
             } else if constexpr (L_ANY) {
-              const float4 r4 = L_RS ? rs[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-              v.x = ps_bias_res(v.x, bi[q].x, r4.x); v.y = ps_bias_res(v.y, bi[q].y, r4.y);
-              v.z = ps_bias_res(v.z, bi[q].z, r4.z); v.w = ps_bias_res(v.w, bi[q].w, r4.w);
+              const float4 r4 = L_RS ? rs[q] : make_float4(0.f, 0.f, 0.f, 0.f), b4 = L_BV ? bv[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+              v.x = ps_bias_res(v.x, bi[q].x, b4.x, r4.x); v.y = ps_bias_res(v.y, bi[q].y, b4.y, r4.y);
+              v.z = ps_bias_res(v.z, bi[q].z, b4.z, r4.z); v.w = ps_bias_res(v.w, bi[q].w, b4.w, r4.w);
             } else {
               v.x += bv[q].x; v.y += bv[q].y; v.z += bv[q].z; v.w += bv[q].w;
               v.x += rs[q].x; v.y += rs[q].y; v.z += rs[q].z; v.w += rs[q].w;
@@ -446,12 +454,9 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
         for (int i = 0; i < TM; ++i) {
           const int r0 = rowbase + i * 32 + 4 * half;
           const unsigned obase = (unsigned)r0 * (unsigned)p.ldc + (unsigned)col;
-          float extra[16];
-          if constexpr (LEAN == 1) {
-            const float vec = p.batch_vec[(long long)((rowbase + i * 32) / p.rows_per_sample) * p.batch_vec_ld + col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) extra[r] = vec;
-          } else if constexpr (LEAN == 2) {
+          float extra[16], vec = 0.f;
+          if constexpr (LEAN == 1 || LEAN == 4) vec = p.batch_vec[(long long)((rowbase + i * 32) / p.rows_per_sample) * p.batch_vec_ld + col];
+          if constexpr (LEAN == 2 || LEAN == 4) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) extra[r] = resp[obase + (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ldc)];
           }
@@ -460,7 +465,9 @@ __device__ __forceinline__ void ps_epilogue(const ldmk_igemm_args& p, f32x16 (&a
           for (int r = 0; r < 16; ++r) {
             const float t = acc[i][j][r] * alpha;
             if constexpr (LEAN == 3) vals[r] = ps_col_finish(t, bv);
-            else vals[r] = ps_col_finish(t, bv, extra[r]);
+            else if constexpr (LEAN == 1) vals[r] = ps_col_finish(t, bv, vec);
+            else if constexpr (LEAN == 2) vals[r] = ps_col_finish(t, bv, extra[r]);
+            else vals[r] = ps_col_finish(t, bv, vec, extra[r]);
             outp[obase + (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ldc)] = vals[r];
           }
           if (p.stats_out) {
@@ -546,12 +553,14 @@ template <bool TR>
 __device__ __forceinline__ int ps_lean_form(const ldmk_igemm_args& p, const int splitk, const bool off, const int row_end, const int col_end) {
   if (off || splitk != 1 || row_end > p.M || col_end > p.N) return 0;
   const bool lf = p.a_tf == LDMK_TF_LAYERNORM_FOLDED, geglu = p.epi == LDMK_EPI_GEGLU;
+  if (p.batch_vec && p.rows_per_sample % 32 != 0) return 0;      // (a 32-row tile inside one sample)
   if constexpr (TR) {
-    if (p.batch_vec) return 0;
-    return lf ? (p.residual ? 0 : 1) : (geglu ? 0 : (p.residual ? 2 : 3));
+    if (lf) return p.residual || p.batch_vec ? 0 : 1;
+    if (geglu || (p.batch_vec && !p.residual)) return 0;
+    return p.batch_vec ? 4 : (p.residual ? 2 : 3);
   } else {
-    if (lf || geglu || (p.batch_vec && (p.residual || p.rows_per_sample % 32 != 0))) return 0;
-    return p.batch_vec ? 1 : (p.residual ? 2 : 3);
+    if (lf || geglu) return 0;
+    return p.batch_vec ? (p.residual ? 4 : 1) : (p.residual ? 2 : 3);
   }
 }
 
@@ -723,6 +732,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_ps_kernel(const ldmk_
     if (lean == 1) ps_epilogue<TM, TN, TR, PL, false, 1>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
     else if (lean == 2) ps_epilogue<TM, TN, TR, PL, false, 2>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
     else if (lean == 3) ps_epilogue<TM, TN, TR, PL, false, 3>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
+    else if (lean == 4) ps_epilogue<TM, TN, TR, PL, false, 4>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
     else ps_epilogue<TM, TN, TR, PL>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, bz, ws, lane);
   }
 }
@@ -1227,6 +1237,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void igemm_psc_kernel(const ldmk
   if (lean == 1) ps_epilogue<TM, TN, TR, PL, false, 1>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, 0, ws, lane);
   else if (lean == 2) ps_epilogue<TM, TN, TR, PL, false, 2>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, 0, ws, lane);
   else if (lean == 3) ps_epilogue<TM, TN, TR, PL, false, 3>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, 0, ws, lane);
+  else if (lean == 4) ps_epilogue<TM, TN, TR, PL, false, 4>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, 0, ws, lane);
   else ps_epilogue<TM, TN, TR, PL>(p, acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, splitk, ks, 0, ws, lane);
 }
 
