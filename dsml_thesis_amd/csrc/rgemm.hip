@@ -278,54 +278,69 @@ __global__ __launch_bounds__(256) void rgemm_kernel(const ldmk_igemm_args p, con
   // use it has a residual)
   constexpr int RSETS = lnf ? 1 : 2;
   float rv[RSETS][16];                                          // residual of the tile in work / of the next one
-  auto load_residual = [&](auto T) {
-    constexpr int t = decltype(T)::value, i = t / TN, j = t % TN;
-    const unsigned obase = (unsigned)rlane * p.ldc + col0 + j * 32 + l31;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dr = min(i * 32 + (r & 3) + 8 * (r >> 2), p.M - 1 - rlane);
-      rv[t % RSETS][r] = resp[obase + (unsigned)(dr * p.ldc)];
-    }
-  };
-  if (RSETS == 2 && resp) load_residual(std::integral_constant<int, 0>{});
-  static_for<0, TM * TN>([&](auto T) {
-    constexpr int t = decltype(T)::value, i = t / TN, j = t % TN;
-    const int col = col0 + j * 32 + l31;
-    const unsigned obase = (unsigned)rlane * p.ldc + col;
-    if constexpr (RSETS == 1) {
-      if (resp) load_residual(T);
-    } else if constexpr (t + 1 < TM * TN) {
-      if (resp) load_residual(std::integral_constant<int, t + 1>{});
-    }
-    float vals[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-      float v = acc[i][j][r] * alpha;
-      if constexpr (lnf) v = fmaf(-st[i][r].x, cs[j], v) * st[i][r].y;
-      v += bias[j];                                             // same association as igemm.hip
-      if (bvec) v += vec[j];
-      if (resp) v += rv[t % RSETS][r];
-      vals[r] = v;
-      if (rlane + dr < p.M) outp[obase + (unsigned)(dr * p.ldc)] = v;
-    }
-    if (p.stats_out && row0 + i * 32 < p.M) {
-      const float shift = __shfl(vals[0], l31, 64);           // row 0 of the 32-row tile
-      float sm = 0.f, sq = 0.f;
+  // FULL (wave-uniform: the wave's 32 TM rows lie inside M) and HASR / HASV (a residual / a per-sample vector is present) are
+  // compile-time in the body below: no row predicate around every store, no operand branches between them (round 5, as in the
+  // lean epilogues of igemm.hip / igemm_ps.hip; same arithmetic, same order)
+  auto finish = [&](auto FULL_, auto HASR_, auto HASV_) {
+    constexpr bool FULL = decltype(FULL_)::value, HASR = decltype(HASR_)::value, HASV = decltype(HASV_)::value;
+    auto load_residual = [&](auto T) {
+      constexpr int t = decltype(T)::value, i = t / TN, j = t % TN;
+      const unsigned obase = (unsigned)rlane * p.ldc + col0 + j * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float d = vals[r] - shift;
-        sm += d;
-        sq = fmaf(d, d, sq);
+        const int dr0 = i * 32 + (r & 3) + 8 * (r >> 2);
+        const int dr = FULL ? dr0 : min(dr0, p.M - 1 - rlane);
+        rv[t % RSETS][r] = resp[obase + (unsigned)(dr * p.ldc)];
       }
-      sm += __shfl_xor(sm, 32, 64);
-      sq += __shfl_xor(sq, 32, 64);
-      if (half == 0) {
-        float* d = p.stats_out + ((long long)((row0 + i * 32) >> 5) * p.N + col) * 3;
-        d[0] = shift; d[1] = sm; d[2] = sq;
+    };
+    if constexpr (RSETS == 2 && HASR) load_residual(std::integral_constant<int, 0>{});
+    static_for<0, TM * TN>([&](auto T) {
+      constexpr int t = decltype(T)::value, i = t / TN, j = t % TN;
+      const int col = col0 + j * 32 + l31;
+      const unsigned obase = (unsigned)rlane * p.ldc + col;
+      if constexpr (HASR) {
+        if constexpr (RSETS == 1) load_residual(T);
+        else if constexpr (t + 1 < TM * TN) load_residual(std::integral_constant<int, t + 1>{});
       }
-    }
-  });
+      float vals[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r] * alpha;
+        if constexpr (lnf) v = fmaf(-st[i][r].x, cs[j], v) * st[i][r].y;
+        v += bias[j];                                             // same association as igemm.hip
+        if constexpr (HASV) v += vec[j];
+        if constexpr (HASR) v += rv[t % RSETS][r];
+        vals[r] = v;
+        if (FULL || rlane + dr < p.M) outp[obase + (unsigned)(dr * p.ldc)] = v;
+      }
+      if (p.stats_out && (FULL || row0 + i * 32 < p.M)) {
+        const float shift = __shfl(vals[0], l31, 64);           // row 0 of the 32-row tile
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = vals[r] - shift;
+          sm += d;
+          sq = fmaf(d, d, sq);
+        }
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if (half == 0) {
+          float* d = p.stats_out + ((long long)((row0 + i * 32) >> 5) * p.N + col) * 3;
+          d[0] = shift; d[1] = sm; d[2] = sq;
+        }
+      }
+    });
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  const bool full = row0 + 32 * TM <= p.M;
+  if (full && resp && !bvec) finish(T_{}, T_{}, F_{});
+  else if (full && !resp && !bvec) finish(T_{}, F_{}, F_{});
+  else if (resp && bvec) finish(F_{}, T_{}, T_{});
+  else if (resp) finish(F_{}, T_{}, F_{});
+  else if (bvec) finish(F_{}, F_{}, T_{});
+  else finish(F_{}, F_{}, F_{});
   RG_STAMP(3);
 }
 
