@@ -203,6 +203,38 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// resblock_updown (openaimodel.py:207-216,256-261): the parameter-free Upsample / Downsample of a ResBlock(up=True / down=True), NHWC.
+// up: y[n][2h][2w][c] = x[n][h][w][c] (F.interpolate(scale_factor=2, mode="nearest"), :110-118); down: y[n][h][w][c] = mean of the
+// 2x2 block of x[n][2h][2w][c] (avg_pool2d(2, 2), :143-160; summed row-major like ATen's loop, then / 4).  (h, w) is the SMALLER grid
+// either way; one thread per 4 channels of a small-grid pixel.  HBM-bound: 5/4 of the large tensor's bytes.
+__global__ __launch_bounds__(256) void resample2_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int C, int up,
+                                                        long long total4) {
+  const int c4n = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const long long pix = i / c4n;
+    const int xx = (int)(pix % w);
+    const long long t = pix / w;
+    const int yy = (int)(t % h);
+    const long long n = t / h;
+    const long long big = (((n * 2 * h + 2 * yy) * 2 * w) + 2 * xx) * C + c;      // top-left element of the 2x2 block
+    const long long row = (long long)2 * w * C;
+    if (up) {
+      const float4 v = *reinterpret_cast<const float4*>(x + pix * C + c);
+      *reinterpret_cast<float4*>(y + big) = v;
+      *reinterpret_cast<float4*>(y + big + C) = v;
+      *reinterpret_cast<float4*>(y + big + row) = v;
+      *reinterpret_cast<float4*>(y + big + row + C) = v;
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(x + big), b = *reinterpret_cast<const float4*>(x + big + C);
+      const float4 d = *reinterpret_cast<const float4*>(x + big + row), e = *reinterpret_cast<const float4*>(x + big + row + C);
+      const float4 o = make_float4((((a.x + b.x) + d.x) + e.x) * 0.25f, (((a.y + b.y) + d.y) + e.y) * 0.25f,
+                                   (((a.z + b.z) + d.z) + e.z) * 0.25f, (((a.w + b.w) + d.w) + e.w) * 0.25f);
+      *reinterpret_cast<float4*>(y + pix * C + c) = o;
+    }
+  }
+}
+
 // use_scale_shift_norm (openaimodel.py:267-271): h = GroupNorm(h) (1 + scale) + shift with (scale, shift) = the two halves of the
 // ResBlock's emb_layers output per sample -- folded into the GroupNorm coefficient planes: sc' = sc (1 + s), sh' = sh (1 + s) + t
 __global__ __launch_bounds__(256) void gn_coef_film_kernel(float* __restrict__ coef, const float* __restrict__ emb, int ld, int C, int total) {
@@ -224,6 +256,17 @@ extern "C" int ldmk_gn_coef_film(float* coef, const float* emb, int ld, int n, i
   LDMK_REQUIRE(coef && emb && n > 0 && c > 0 && ld >= 2 * c, "ldmk_gn_coef_film: bad args (ld=%d c=%d)", ld, c);
   hipLaunchKernelGGL(gn_coef_film_kernel, dim3((n * c + 255) / 256), dim3(256), 0, (hipStream_t)stream, coef, emb, ld, c, n * c);
   return check_launch("ldmk_gn_coef_film");
+}
+
+extern "C" int ldmk_resample2(const float* x, float* y, int n, int h, int w, int c, int up, void* stream) {
+  LDMK_ENTER();
+  using namespace ldmk;
+  LDMK_REQUIRE(x && y && x != y && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "ldmk_resample2: bad args (C%%4==0, out of place)");
+  const long long total4 = (long long)n * h * w * (c / 4);
+  long long g = (total4 + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(resample2_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, y, h, w, c, up ? 1 : 0, total4);
+  return check_launch("ldmk_resample2");
 }
 
 extern "C" int ldmk_gn_apply(const float* x0, int c0, const float* x1, int c1, const float* coef, float* y, int n, int hw,

@@ -160,6 +160,7 @@ _SIGS = {
     "ldmk_colsum_splits": (C.c_int, [C.c_int]),
     "ldmk_colsum": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp]),
     "ldmk_sumpool2": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ldmk_resample2": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ldmk_silu": (C.c_int, [_fp, _fp, C.c_longlong, _fp]),
     "ldmk_silu_bwd": (C.c_int, [_fp, _fp, _fp, C.c_longlong, _fp]),
     "ldmk_axpy": (C.c_int, [_fp, _fp, C.c_float, C.c_longlong, _fp]),

@@ -168,6 +168,8 @@ class UNetTrainer:
             raise NotImplementedError("UNetTrainer: attention heads of width 32 only (the flash backward kernels)")
         if getattr(unet, "use_scale_shift_norm", False) or unet.num_classes is not None:
             raise NotImplementedError("UNetTrainer: use_scale_shift_norm / num_classes UNets are built for sampling only")
+        if getattr(unet, "resblock_updown", False):
+            raise NotImplementedError("UNetTrainer: resblock_updown UNets are built for sampling only")
         self.unet = unet
         self.dev = next(unet.parameters()).device
         self.P = FlatParams()

@@ -72,14 +72,16 @@ def _norm_params(c):
     return _Params(weight=(c,), bias=(c,))
 
 
-def _res_block(cin, cout, emb_ch, scale_shift=False):
+def _res_block(cin, cout, emb_ch, scale_shift=False, updown=None):
+    """ResBlock parameters (openaimodel.py:176-253).  updown = "up" / "down": ResBlock(up=True / down=True) of resblock_updown --
+    h_upd / x_upd are parameter-free (:207-216), so the state-dict keys are those of a plain block."""
     ch = dict(in_layers=_Slots(_0=_norm_params(cin), _2=_conv_params(cin, cout, 3)),
               emb_layers=_Slots(_1=_lin_params(emb_ch, 2 * cout if scale_shift else cout)),      # (scale | shift), openaimodel.py:218-224
               out_layers=_Slots(_0=_norm_params(cout), _3=_conv_params(cout, cout, 3)))
     if cin != cout:
         ch["skip_connection"] = _conv_params(cin, cout, 1)
     m = _Slots(**ch)
-    m.kind, m.cin, m.cout, m.scale_shift = "res", cin, cout, bool(scale_shift)
+    m.kind, m.cin, m.cout, m.scale_shift, m.updown = "res", cin, cout, bool(scale_shift), updown
     return m
 
 
@@ -533,8 +535,8 @@ class UNetModel(nn.Module):
         # combinations the reference accepts but this path does not implement fail loudly
         if dims != 2:
             raise NotImplementedError("UNetModel: only dims=2")
-        if resblock_updown or n_embed is not None:
-            raise NotImplementedError("UNetModel: resblock_updown / n_embed are not part of the sampling path built here")
+        if n_embed is not None:
+            raise NotImplementedError("UNetModel: n_embed (the id-predictor head) is not part of the sampling path built here")
         if use_new_attention_order and use_spatial_transformer:
             pass        # (QKVAttention lives in AttentionBlock only: the flag is inert with spatial transformers, openaimodel.py:379,557-570)
         if not conv_resample:
@@ -566,6 +568,7 @@ class UNetModel(nn.Module):
         self.num_heads, self.num_head_channels, self.num_heads_upsample = num_heads, num_head_channels, num_heads_upsample
         self.context_dim, self.transformer_depth = context_dim, transformer_depth
         self.use_scale_shift_norm, self.use_new_attention_order = bool(use_scale_shift_norm), bool(use_new_attention_order)
+        self.resblock_updown = bool(resblock_updown)
         mc = model_channels
         emb_ch = 4 * mc
         self._heads32 = True
@@ -611,8 +614,11 @@ class UNetModel(nn.Module):
                 self.input_blocks.append(_seq(*layers))
                 chans.append(ch)
             if level != len(channel_mult) - 1:
-                down = _Slots(op=_conv_params(ch, ch, 3))
-                down.kind, down.ch = "down", ch
+                if resblock_updown:              # ResBlock(ch, ..., out_channels=ch, down=True), openaimodel.py:570-584
+                    down = _res_block(ch, ch, emb_ch, use_scale_shift_norm, updown="down")
+                else:
+                    down = _Slots(op=_conv_params(ch, ch, 3))
+                    down.kind, down.ch = "down", ch
                 self.input_blocks.append(_seq(down))
                 chans.append(ch)
                 ds *= 2
@@ -626,8 +632,11 @@ class UNetModel(nn.Module):
                 if ds in attention_resolutions:
                     layers.append(st(ch))
                 if level and i == num_res_blocks:
-                    up = _Slots(conv=_conv_params(ch, ch, 3))
-                    up.kind, up.ch = "up", ch
+                    if resblock_updown:          # ResBlock(ch, ..., out_channels=ch, up=True), openaimodel.py:660-674
+                        up = _res_block(ch, ch, emb_ch, use_scale_shift_norm, updown="up")
+                    else:
+                        up = _Slots(conv=_conv_params(ch, ch, 3))
+                        up.kind, up.ch = "up", ch
                     layers.append(up)
                     ds //= 2
                 self.output_blocks.append(_seq(*layers))
@@ -784,6 +793,9 @@ class UNetModel(nn.Module):
     def _build(self, n, H, W_, L_ctx, c_concat, policy_n):
         P, sd = self._packed, self._sd
         dev = next(self.parameters()).device
+        if self.resblock_updown and (H % (1 << (len(self.channel_mult) - 1)) or W_ % (1 << (len(self.channel_mult) - 1))):
+            raise L.LdmkError(f"UNetModel(resblock_updown): {H}x{W_} input -- avg_pool2d(2, 2) of an odd grid drops its last row / column "
+                              "in the reference and the skip shapes stop matching on the way up; use even sizes at every level")
         pg = Program(dev)
         pg.h2_flag = None          # (set per site by NetBuilder.site: engine.Program.plan runs a shape in F16X2 while it is a flag word)
         pg.far_plans = far_from_tuned(policy_n)      # a job far from every tuned batch carries the nearest tuned plans (engine.choose)
@@ -828,6 +840,8 @@ class UNetModel(nn.Module):
             # use_scale_shift_norm (openaimodel.py:267-271): the embedding does not add to conv1's output but modulates the second
             # GroupNorm -- h = norm(h) (1 + scale) + shift -- which is a per-sample edit of that norm's coefficient planes
             film = (bv, self._emb_total) if m.scale_shift else None
+            if m.updown:
+                return res_block_updown(prefix, m, x0, h, w, bv, film)
             with nb_.site(prefix + "in_layers"):
                 h1 = nb_.gn_conv(x0, x1, h, w, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5,
                                  P[prefix + "c1"], P.get(prefix + "c1#wg"), sd[prefix + "in_layers.2.bias"],
@@ -853,6 +867,33 @@ class UNetModel(nn.Module):
             nb_.release(h1)
             return out
 
+        def res_block_updown(prefix, m, x, h, w, bv, film):
+            """ResBlock(up=True / down=True) (resblock_updown, openaimodel.py:256-261): SiLU(GroupNorm(x)) and x itself go through
+            the parameter-free Upsample (nearest x2) / Downsample (avg_pool2d(2, 2)) -- one ldmk_resample2 pass each -- before the
+            first convolution and on the skip path; cin == cout, so the skip is the identity.  The first convolution reads the
+            resampled activation raw (direct implicit GEMM), the second half is the plain block's."""
+            up = m.updown == "up"
+            assert m.cin == m.cout and (up or (h % 2 == 0 and w % 2 == 0))      # (out_channels == channels, openaimodel.py:573,663)
+            oh, ow = (2 * h, 2 * w) if up else (h // 2, w // 2)
+            sh_, sw_ = (h, w) if up else (oh, ow)              # ldmk_resample2 takes the SMALLER grid
+            a = nb_.gn_act(x, None, h * w, sd[prefix + "in_layers.0.weight"], sd[prefix + "in_layers.0.bias"], 1e-5)
+            a_r = pg.alloc(n, oh, ow, m.cin)
+            pg.add("ldmk_resample2", p_(a), p_(a_r), n, sh_, sw_, m.cin, 1 if up else 0)
+            nb_.release(a)
+            x_r = pg.alloc(n, oh, ow, m.cin)
+            pg.add("ldmk_resample2", p_(x), p_(x_r), n, sh_, sw_, m.cin, 1 if up else 0)
+            with nb_.site(prefix + "in_layers"):
+                h1 = conv(a_r, None, P[prefix + "c1"], sd[prefix + "in_layers.2.bias"], oh, ow, batch_vec=None if film else bv,
+                          bv_ld=self._emb_total, stats=True, wf=P.get(prefix + "c1#f"))
+            nb_.release(a_r)
+            with nb_.site(prefix + "out_layers"):
+                out = nb_.gn_conv(h1, None, oh, ow, sd[prefix + "out_layers.0.weight"], sd[prefix + "out_layers.0.bias"], 1e-5,
+                                  P[prefix + "c2"], P.get(prefix + "c2#wg"), sd[prefix + "out_layers.3.bias"], residual=x_r,
+                                  out=x_r, stats=True, wf=P.get(prefix + "c2#f"), u_ps=P.get(prefix + "c2#wg" + psfx()),
+                                  wp_ps=P.get(prefix + "c2#pc2"), film=film)
+            nb_.release(h1)
+            return out
+
         def spatial_tf(prefix, m, x, h, w):
             return emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_in, self.context_dim,
                                             unfolded=self.ln_unfolded, ln_flag=self._ln_flag)
@@ -865,6 +906,8 @@ class UNetModel(nn.Module):
                 p = f"{prefix}{j}."
                 if m.kind == "res":
                     out = res_block(p, m, cur0, cur1, h, w)
+                    if m.updown:
+                        h, w = (2 * h, 2 * w) if m.updown == "up" else (h // 2, w // 2)
                 elif m.kind == "st":
                     out = spatial_tf(p, m, cur0, h, w)
                 elif m.kind == "attn":
@@ -992,7 +1035,7 @@ class UNetModel(nn.Module):
         pg = self._programs.get(key)
         if pg is None:
             from . import unet_small
-            plain = self._heads32 and not self.use_scale_shift_norm and self.num_classes is None
+            plain = self._heads32 and not self.use_scale_shift_norm and self.num_classes is None and not self.resblock_updown
             if plain and unet_small.wants_small_route(policy_n, H, W_, L_ctx):
                 # batch 1-2 (the reference's shipped talking-face mode): the program cut for few dependent launches
                 pg = unet_small.build_small(self, n, H, W_, L_ctx, c_concat, policy_n)

@@ -326,6 +326,11 @@ int ldmk_ln_stats_split(const float* x, int rows, int C, float eps, float* stats
  *   instead of 9 x (N / tile) times inside the following 3x3 convolution's operand staging. */
 int ldmk_gn_apply(const float* x0, int c0, const float* x1, int c1, const float* coef, float* y, int n, int hw,
                   int silu, void* stream);
+/* ldmk_resample2: the parameter-free resampling of a ResBlock(up=True / down=True) (resblock_updown, openaimodel.py:207-216,
+ *   256-261), NHWC fp32, out of place.  (h, w) is the SMALLER of the two grids.  up != 0: y[n][2h][2w][c] = x[n][h][w][c]
+ *   (Upsample(use_conv=False): F.interpolate(scale_factor=2, mode="nearest"), :110-118); up == 0: y[n][h][w][c] = mean of the
+ *   2x2 block of x[n][2h][2w][c] (Downsample(use_conv=False): avg_pool2d(2, 2), :143-160).  C % 4 == 0. */
+int ldmk_resample2(const float* x, float* y, int n, int h, int w, int c, int up, void* stream);
 /* use_scale_shift_norm (openaimodel.py:267-271: h = out_norm(h) * (1 + scale) + shift, (scale, shift) = the halves of the
  * ResBlock's emb_layers output): folds a per-sample [n][ld] vector (scale at column 0, shift at column c) into the coefficient
  * planes coef[n][2][c] of ldmk_gn_finalize, in place. */

@@ -148,9 +148,16 @@ def gn_silu(x, w, b, eps=1e-5, silu=True, groups=32):
     return F.silu(y) if silu else y
 
 
-def resblock(sd, p, x, emb, scale_shift=False):
-    """ResBlock._forward (no up/down): openaimodel.py:255-275; scale_shift = use_scale_shift_norm (:267-271)."""
+def resblock(sd, p, x, emb, scale_shift=False, updown=None):
+    """ResBlock._forward: openaimodel.py:255-275; scale_shift = use_scale_shift_norm (:267-271); updown = "up" / "down": the
+    ResBlock(up=True / down=True) of resblock_updown (:256-261) -- h_upd / x_upd are Upsample / Downsample WITHOUT a convolution
+    (:207-216: nearest x2, :110-118, and avg_pool2d(2, 2), :143-160), applied to SiLU(GroupNorm(x)) before the first convolution
+    and to x on the skip path."""
     h = gn_silu(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"])
+    if updown == "up":
+        h, x = F.interpolate(h, scale_factor=2, mode="nearest"), F.interpolate(x, scale_factor=2, mode="nearest")
+    elif updown == "down":
+        h, x = F.avg_pool2d(h, 2, 2), F.avg_pool2d(x, 2, 2)
     h = F.conv2d(h, sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=1)
     e = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"])
     if scale_shift:
@@ -241,6 +248,8 @@ def _run_layers(sd, cfg, prefix, layers, h, emb, context):
             h = F.conv2d(h, sd[p + "weight"], sd[p + "bias"], padding=1)
         elif l[0] == "res":
             h = resblock(sd, p, h, emb, bool(cfg.get("use_scale_shift_norm", False)))
+        elif l[0] in ("res_down", "res_up"):      # resblock_updown, openaimodel.py:570-584,660-674
+            h = resblock(sd, p, h, emb, bool(cfg.get("use_scale_shift_norm", False)), updown=l[0][4:])
         elif l[0] == "st":
             h = spatial_transformer(sd, p, h, context, l[2], cfg.get("transformer_depth", 1))
         elif l[0] == "attn":

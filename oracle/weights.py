@@ -82,7 +82,9 @@ def unet_layout(cfg):
 
     Returns dict(input=[...], middle=[...], output=[...]) where each entry is a list of
     layer tuples: ("conv", cin, cout) | ("res", cin, cout) | ("st", ch, heads, d_head) |
-    ("down", ch) | ("up", ch) | ("attn", ch, heads, d_head).  The spatial-transformer configuration the shipped YAMLs use
+    ("down", ch) | ("up", ch) | ("attn", ch, heads, d_head) | ("res_down", ch, ch) | ("res_up", ch, ch) -- the last two are the
+    ResBlock(down=True) / ResBlock(up=True) that stand where Downsample / Upsample would with resblock_updown=True
+    (openaimodel.py:570-584,660-674).  The spatial-transformer configuration the shipped YAMLs use
     (use_spatial_transformer=True, num_head_channels set, legacy=True) and the unconditional variant
     (use_spatial_transformer=False: AttentionBlock / QKVAttentionLegacy, openaimodel.py:549-559) are covered.
     """
@@ -95,6 +97,7 @@ def unet_layout(cfg):
 
     st = cfg.get("use_spatial_transformer", False)
     kind = "st" if st else "attn"
+    updown = bool(cfg.get("resblock_updown", False))
 
     def heads(ch):
         if nhc == -1:
@@ -115,7 +118,7 @@ def unet_layout(cfg):
             inp.append(layers)
             chans.append(ch)
         if level != len(mult) - 1:
-            inp.append([("down", ch)])
+            inp.append([("res_down", ch, ch) if updown else ("down", ch)])
             chans.append(ch)
             ds *= 2
     n, d = heads(ch)
@@ -130,7 +133,7 @@ def unet_layout(cfg):
                 n, d = heads(ch)
                 layers.append((kind, ch, n, d))
             if level and i == nrb:
-                layers.append(("up", ch))
+                layers.append(("res_up", ch, ch) if updown else ("up", ch))
                 ds //= 2
             out.append(layers)
     return dict(input=inp, middle=mid, output=out, final_ch=ch)
@@ -156,7 +159,7 @@ def unet_param_shapes(cfg):
             if l[0] == "conv":
                 keys[p + "weight"] = (l[2], l[1], 3, 3)
                 keys[p + "bias"] = (l[2],)
-            elif l[0] == "res":
+            elif l[0] in ("res", "res_down", "res_up"):     # (h_upd / x_upd of an up / down ResBlock carry no parameters)
                 _resblock(keys, p, l[1], l[2], emb, bool(cfg.get("use_scale_shift_norm", False)))
             elif l[0] == "st":
                 _spatial_transformer(keys, p, l[1], l[2], l[3], depth, cd)
@@ -346,6 +349,11 @@ ADM_UNET = dict(image_size=16, in_channels=3, out_channels=3, model_channels=64,
                 channel_mult=[1, 2], num_head_channels=32, use_scale_shift_norm=True, num_classes=10, use_new_attention_order=True)
 H64_UNET = dict(image_size=16, in_channels=3, out_channels=3, model_channels=128, attention_resolutions=[1, 2], num_res_blocks=1,
                 channel_mult=[1, 2], num_head_channels=64, use_spatial_transformer=True, transformer_depth=1, context_dim=512)
+# resblock_updown (openaimodel.py:570-584,660-674): ResBlock(down=True) / ResBlock(up=True) instead of Downsample / Upsample -- on the
+# shipped spatial-transformer UNet with one ResBlock per level (two of each at 32x32) and, together with use_scale_shift_norm, on
+# the class-conditional one
+UPDOWN_UNET = dict(FR_UNET, num_res_blocks=1, resblock_updown=True)
+UPDOWN_ADM_UNET = dict(ADM_UNET, resblock_updown=True)
 # BASELINE configs[0] as worded: a genuinely UNCONDITIONAL LDM (cond_stage_config "__is_unconditional__" -> conditioning_key None,
 # ddpm.py:443-444): no SpatialTransformer, AttentionBlock / QKVAttentionLegacy with 32-channel heads, no context
 UNCOND_UNET = dict(image_size=64, in_channels=4, out_channels=4, model_channels=160, attention_resolutions=[4, 2, 1],

@@ -69,7 +69,7 @@ def test_state_dict_keys_equal_reference_enumeration():
 def test_unsupported_options_fail_loudly():
     from dsml_thesis_amd.unet import UNetModel
     from dsml_thesis_amd.autoencoder import VQModelInterface
-    for bad in (dict(dims=3), dict(resblock_updown=True), dict(n_embed=8), dict(use_fp16=True),
+    for bad in (dict(dims=3), dict(n_embed=8), dict(use_fp16=True),
                 dict(num_head_channels=48)):       # (160 channels do not split into whole heads of 48)
         with pytest.raises(NotImplementedError):
             UNetModel(**dict(W.FR_UNET, **bad))
@@ -84,6 +84,11 @@ def test_unsupported_options_fail_loudly():
     u64 = UNetModel(**dict(W.FR_UNET, num_head_channels=64))
     assert not u64._heads32 and u64.input_blocks[1].layers[1].heads == 2 and u64.input_blocks[1].layers[1].d_head == 80
     assert UNetModel(**W.FR_UNET)._heads32
+    # resblock_updown constructs since round 5: ResBlocks (same keys as a plain block) where Downsample / Upsample would stand
+    ud = UNetModel(**W.UPDOWN_UNET)
+    assert set(ud.state_dict().keys()) == set(W.unet_param_shapes(W.UPDOWN_UNET).keys())
+    assert [m.updown for _, m in ud._walk() if m.kind == "res" and m.updown] == ["down", "down", "up", "up"]
+    assert not any(m.kind in ("down", "up") for _, m in ud._walk())
     with pytest.raises(NotImplementedError):
         VQModelInterface(embed_dim=3, n_embed=16, ddconfig=dict(W.VQ_F4["ddconfig"], attn_type="linear"))
 

@@ -387,3 +387,21 @@ def test_g14_class_conditional_unet_with_scale_shift_norm_and_new_attention_orde
     close(O.unet_forward(sd, W.ADM_UNET, x, t, None, y=y), g["adm_eps"], 2e-5, 2e-5)
     with pytest.raises(AssertionError):
         O.unet_forward(sd, W.ADM_UNET, x, t, None)
+
+
+def test_g15_resblock_updown():
+    """g15 (tools/make_golden.py --tree updown, the real reference): `resblock_updown=True` -- ResBlock(down=True) / ResBlock(up=True)
+    where Downsample / Upsample would stand (openaimodel.py:570-584,660-674; _forward :256-261: avg_pool2d(2, 2) / nearest x2 on
+    SiLU(GroupNorm(x)) and on the skip path) -- on the shipped spatial-transformer UNet (one ResBlock per level, 32x32) and, with
+    use_scale_shift_norm, on the class-conditional UNet."""
+    g = golden("g15_updown.npz")
+    lay = W.unet_layout(W.UPDOWN_UNET)
+    kinds = [l[0] for blk in lay["input"] + lay["output"] for l in blk]
+    assert kinds.count("res_down") == 2 and kinds.count("res_up") == 2 and "down" not in kinds and "up" not in kinds
+    sd = recipe(W.unet_param_shapes(W.UPDOWN_UNET))
+    assert not any(k.endswith("op.weight") or k.endswith(".conv.weight") for k in sd)       # (no Downsample / Upsample convolutions)
+    t, ctx = torch.tensor([5, 640]), rnd(171, 2, 1, 512)
+    close(O.unet_forward(sd, W.UPDOWN_UNET, rnd(170, 2, 3, 32, 32), t, ctx), g["ud_eps"], 2e-5, 2e-5)
+    sd = recipe(W.unet_param_shapes(W.UPDOWN_ADM_UNET))
+    x, t, y = rnd(173, 2, 3, 16, 16), torch.tensor([3, 512]), torch.tensor([7, 2])
+    close(O.unet_forward(sd, W.UPDOWN_ADM_UNET, x, t, None, y=y), g["ud_adm_eps"], 2e-5, 2e-5)

@@ -637,3 +637,39 @@ def test_unet_non_square_ragged_token_counts_vs_oracle():
     eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
     ref = O.unet_forward(sd, W.FR_UNET, x, t, ctx)
     close(eps, ref, 1e-4, 1e-4)
+
+
+def test_unet_resblock_updown():
+    """Reference kwarg `resblock_updown` (openaimodel.py:570-584,660-674), the last UNetModel kwarg that raised NotImplementedError:
+    ResBlock(down=True) / ResBlock(up=True) stand where Downsample / Upsample would; their parameter-free avg_pool2d(2, 2) /
+    nearest x2 (:207-216,256-261) run as one ldmk_resample2 pass on SiLU(GroupNorm(x)) and one on the skip path.  eps against the
+    REAL reference's outputs (g15): the shipped spatial-transformer UNet with one ResBlock per level at 32x32, and the
+    class-conditional UNet with use_scale_shift_norm; with the batch's own plans and with the batched job's (policy_batch = 16)."""
+    from dsml_thesis_amd import lib as L
+    from dsml_thesis_amd import ops
+    g = golden("g15_updown.npz")
+    # the resampling passes on their own, against torch
+    x = rnd(174, 2, 6, 10, 8).cuda()                         # NHWC [n][h][w][c], c % 4 == 0
+    up, dn = torch.empty(2, 12, 20, 8, device="cuda"), torch.empty(2, 3, 5, 8, device="cuda")
+    L.call("ldmk_resample2", x.data_ptr(), up.data_ptr(), 2, 6, 10, 8, 1, ops.stream())
+    L.call("ldmk_resample2", x.data_ptr(), dn.data_ptr(), 2, 3, 5, 8, 0, ops.stream())
+    nchw = x.permute(0, 3, 1, 2)
+    assert torch.equal(up.permute(0, 3, 1, 2), torch.nn.functional.interpolate(nchw, scale_factor=2, mode="nearest"))
+    close(dn.permute(0, 3, 1, 2), torch.nn.functional.avg_pool2d(nchw, 2, 2).cpu(), 1e-6, 1e-7)
+    # the UNets
+    m, sd = make_unet(W.UPDOWN_UNET)
+    x, t, ctx = rnd(170, 2, 3, 32, 32), torch.tensor([5, 640]), rnd(171, 2, 1, 512)
+    eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
+    names = [c[3] for c in m.program(2, 32, 32, 1, 0).calls]
+    assert names.count("ldmk_resample2") == 8                # 2 down + 2 up blocks, two passes each
+    assert not any(k.endswith("op.weight") or k.endswith(".conv.weight") for k in m.state_dict())
+    close(eps, g["ud_eps"], 3e-5, 3e-5)
+    m.policy_batch = 16
+    close(m(x.cuda(), t.cuda(), context=ctx.cuda()), g["ud_eps"], 3e-5, 3e-5)
+    m, sd = make_unet(W.UPDOWN_ADM_UNET)
+    x, t, y = rnd(173, 2, 3, 16, 16), torch.tensor([3, 512]), torch.tensor([7, 2])
+    close(m(x.cuda(), t.cuda(), y=y.cuda()), g["ud_adm_eps"], 3e-5, 3e-5)
+    m.policy_batch = 16
+    close(m(x.cuda(), t.cuda(), y=y.cuda()), g["ud_adm_eps"], 3e-5, 3e-5)
+    with pytest.raises(L.LdmkError, match="even sizes"):
+        m(rnd(175, 2, 3, 15, 15).cuda(), t.cuda(), y=y.cuda())      # the down block would meet an odd grid: refused before any launch

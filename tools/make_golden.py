@@ -901,9 +901,32 @@ def gen_variants():
     save("g14_variants.npz", **g)
 
 
+def gen_updown():
+    """G15: `resblock_updown=True` from the real UNetModel (openaimodel.py:570-584,660-674): the shipped spatial-transformer UNet (one ResBlock per
+    level) with ResBlock(down=True) / ResBlock(up=True) between its three levels, and the class-conditional UNet with use_scale_shift_norm on top."""
+    from tools import ref_shims
+    ref_shims.install("face_reenactment")
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    torch.set_grad_enabled(False)
+    g = {}
+    m = UNetModel(**W.UPDOWN_UNET)
+    sd = load_recipe(m, seed=0, prefix_check=W.unet_param_shapes(W.UPDOWN_UNET))
+    x, t, ctx = rnd(170, 2, 3, 32, 32), torch.tensor([5, 640]), rnd(171, 2, 1, 512)
+    ref = m(x, t, context=ctx)
+    check("UNet eps, resblock_updown (spatial transformers, 32x32)", ref, O.unet_forward(sd, W.UPDOWN_UNET, x, t, ctx), 2e-5, 2e-5)
+    g["ud_eps"] = ref
+    m = UNetModel(**W.UPDOWN_ADM_UNET)
+    sd = load_recipe(m, seed=0, prefix_check=W.unet_param_shapes(W.UPDOWN_ADM_UNET))
+    x, t, y = rnd(173, 2, 3, 16, 16), torch.tensor([3, 512]), torch.tensor([7, 2])
+    ref = m(x, t, y=y)
+    check("UNet eps, resblock_updown + scale-shift norm (adm)", ref, O.unet_forward(sd, W.UPDOWN_ADM_UNET, x, t, None, y=y), 2e-5, 2e-5)
+    g["ud_adm_eps"] = ref
+    save("g15_updown.npz", **g)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants"])
+    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants", "updown"])
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -923,6 +946,8 @@ if __name__ == "__main__":
         gen_config0()
     elif a.tree == "variants":
         gen_variants()
+    elif a.tree == "updown":
+        gen_updown()
     else:
-        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants"):
+        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants", "updown"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", tree], cwd=ROOT)
