@@ -149,7 +149,15 @@ class DDIMSampler(object):
         ctx, cat = self._split_cond(cond)
         cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
         nb = 2 * b if cfg else b
-        if cfg:
+        y_in = None
+        if getattr(self.model.model, "conditioning_key", None) == "adm":
+            # class-conditional model (ddpm.py:1417-1419): the conditioning is the label vector y, which reaches the UNet as rows of
+            # its label embedding added to the timestep embedding -- constant over the run, written once into the program's
+            # `y_emb` input; guidance doubles it as [uncond | cond] like any conditioning (ddim.py:175)
+            y_in = ctx if not cfg else torch.cat([self._split_cond(unconditional_conditioning)[0], ctx])
+            assert y_in is not None and y_in.dim() == 1 and cat is None, "conditioning_key 'adm': conditioning = class labels (B,)"
+            ctx_in, cat_in = None, None
+        elif cfg:
             uc, ucat = self._split_cond(unconditional_conditioning)
             if ctx is None:                                # 'concat' conditioning: the guidance halves differ in the concat tensor
                 ctx_in, cat_in = None, torch.cat([ucat, cat])
@@ -168,6 +176,8 @@ class DDIMSampler(object):
             pg.inputs["context"].copy_(ctx_in.reshape(nb * L_ctx, -1))
         if ncat:
             pg.inputs["c_concat"].copy_(cat_in)
+        if y_in is not None:
+            pg.inputs["y_emb"].copy_(unet.label_emb.weight.detach().float()[y_in.to(dev, torch.int64)])
         pg.ctx_program.run()                               # context-only projections: once per sample() call
         img = x_buf[:b]                                    # the latent lives in the UNet's input buffer
         img.copy_(img0)

@@ -380,6 +380,10 @@ class LatentDiffusion(_Base):
         else:
             ctx, cat = (torch.cat(cond, 1) if isinstance(cond, (list, tuple)) else cond), None      # (None: unconditional)
         unet = self.model.diffusion_model
+        y = None
+        if self.model.conditioning_key == "adm":          # class labels: rows of the label embedding, constant over the run (ddpm.py:1417-1419)
+            y, ctx = ctx, None
+            assert y is not None and y.dim() == 1 and cat is None, "conditioning_key 'adm': cond = class labels (B,)"
         ncat = 0 if cat is None else cat.shape[1]
         L_ctx = 0 if ctx is None else ctx.shape[1]
         pg = unet.program(b, shape[2], shape[3], L_ctx, ncat)
@@ -387,6 +391,8 @@ class LatentDiffusion(_Base):
             pg.inputs["context"].copy_(ctx.reshape(b * L_ctx, -1))
         if ncat:
             pg.inputs["c_concat"].copy_(cat)
+        if y is not None:
+            pg.inputs["y_emb"].copy_(unet.label_emb.weight.detach().float()[y.to(dev, torch.int64)])
         pg.ctx_program.run()
         x_buf, t_buf, eps = pg.inputs["x"], pg.inputs["t"], pg.outputs["eps"]
         tab, logvar = self._ddpm_device_tables()

@@ -288,6 +288,8 @@ def unet_forward(sd, cfg, x, timesteps, context=None, y=None):
 def apply_model(sd, cfg, x, t, c_crossattn=None, c_concat=None):
     """DiffusionWrapper.forward: ddpm.py:1404-1423 ('crossattn'); TF ddpm2cond.py:1307-1315
     (concat on channels *and* cross-attention)."""
+    if cfg.get("num_classes") is not None:             # conditioning_key 'adm' (ddpm.py:1417-1419): the conditioning IS y
+        return unet_forward(sd, cfg, x, t, None, y=c_crossattn[0])
     if c_concat is not None:
         x = torch.cat([x] + list(c_concat), dim=1)
     cc = None if c_crossattn is None else torch.cat(list(c_crossattn), 1)

@@ -405,3 +405,16 @@ def test_g15_resblock_updown():
     sd = recipe(W.unet_param_shapes(W.UPDOWN_ADM_UNET))
     x, t, y = rnd(173, 2, 3, 16, 16), torch.tensor([3, 512]), torch.tensor([7, 2])
     close(O.unet_forward(sd, W.UPDOWN_ADM_UNET, x, t, None, y=y), g["ud_adm_eps"], 2e-5, 2e-5)
+
+
+def test_g15_class_conditional_model_under_the_samplers():
+    """g15 `adm_*`: the real LatentDiffusion(conditioning_key='adm') under the real DDIMSampler.sample (plain / CFG 3) and
+    p_sample_loop -- the labels travel as c_crossattn = [y] and reach the UNet as y (ddpm.py:893-994,1417-1419)."""
+    g = golden("g15_updown.npz")
+    cfg = W.UPDOWN_ADM_UNET
+    sd = recipe(W.unet_param_shapes(cfg), gain=0.25)
+    sched = O.register_schedule(**W.SCHEDULE)
+    xT, y, uy = rnd(176, 2, 3, 16, 16), torch.tensor([7, 2]), torch.tensor([0, 0])
+    close(O.ddim_sample(sd, cfg, sched, 4, xT, cond=y), g["adm_ddim4"], 1e-4, 1e-4)
+    close(O.ddim_sample(sd, cfg, sched, 4, xT, cond=y, scale=3.0, uncond=uy), g["adm_ddim4_cfg3"], 1e-4, 1e-4)
+    close(O.p_sample_loop(sd, cfg, sched, xT, cond=y, timesteps=3, noise=list(T(g["adm_ddpm3_noise"]))), g["adm_ddpm3"], 1e-4, 1e-4)

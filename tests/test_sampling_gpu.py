@@ -725,3 +725,44 @@ def test_p_sample_loop_graph_and_full_length(fr):
     assert torch.equal(d1, d2)
     out = fr.sample(c, batch_size=2, x_T=xT, use_graph=True)              # LatentDiffusion.sample -> 1000 steps
     assert out.shape == (2, 3, 32, 32) and torch.isfinite(out).all()
+
+
+def test_class_conditional_model_through_the_samplers():
+    """conditioning_key 'adm' under the samplers (ddpm.py:1417-1419: the conditioning IS the class-label vector y): a real-surface
+    LatentDiffusion around the class-conditional UNet (use_scale_shift_norm, resblock_updown), DDIMSampler.sample plain and with
+    classifier-free guidance (labels doubled as [uncond | cond], ddim.py:175) -- eager == hipGraph bitwise -- and p_sample_loop,
+    against the REAL reference's outputs (g15: LatentDiffusion(conditioning_key='adm') + DDIMSampler from /root/reference).  The
+    label-embedding rows are written once per run into the launch program's `y_emb` input; through round 5's first session only
+    apply_model / p_sample_ddim knew the key and the loops failed on the 1-D labels."""
+    from dsml_thesis_amd.ddim import DDIMSampler
+    from dsml_thesis_amd.ddpm import LatentDiffusion
+    from dsml_thesis_amd.synth import fr_config, load_recipe
+    g = golden("g15_updown.npz")
+    cfg = fr_config(unet=W.UPDOWN_ADM_UNET)
+    cfg.update(conditioning_key="adm")
+    m = LatentDiffusion(**cfg)
+    load_recipe(m.model.diffusion_model, gain=0.25)
+    m = m.cuda().eval()
+    assert m.model.conditioning_key == "adm"
+    xT, y, uy = rnd(176, 2, 3, 16, 16).cuda(), torch.tensor([7, 2]).cuda(), torch.tensor([0, 0]).cuda()
+    kw = dict(S=4, batch_size=2, shape=[3, 16, 16], conditioning=y, eta=0.0, x_T=xT, verbose=False)
+    s = DDIMSampler(m)
+    out, _ = s.sample(**kw)
+    close(out, g["adm_ddim4"], 1.5e-4, 1.5e-4)
+    out_g, _ = s.sample(use_graph=True, **kw)
+    assert torch.equal(out, out_g)
+    cfg3 = dict(unconditional_guidance_scale=3.0, unconditional_conditioning=uy)
+    out3, _ = s.sample(**kw, **cfg3)
+    close(out3, g["adm_ddim4_cfg3"], 1.5e-4, 1.5e-4)
+    out3g, _ = s.sample(use_graph=True, **kw, **cfg3)
+    assert torch.equal(out3, out3g) and not torch.equal(out3, out)
+    # one step with the reference's signature goes through apply_model -> DiffusionWrapper('adm')
+    s.make_schedule(4, ddim_eta=0.0, verbose=False)
+    t3 = torch.full((2,), int(s.ddim_timesteps[3]), device="cuda", dtype=torch.long)
+    x1, _ = s.p_sample_ddim(xT, y, t3, 3)
+    x1c, _ = s.p_sample_ddim(xT, y, t3, 3, **cfg3)
+    assert torch.isfinite(x1).all() and torch.isfinite(x1c).all() and not torch.equal(x1, x1c)
+    out = m.p_sample_loop(y, (2, 3, 16, 16), x_T=xT, timesteps=3, verbose=False, noise=list(T(g["adm_ddpm3_noise"]).cuda()))
+    close(out, g["adm_ddpm3"], 1e-4, 1e-4)
+    with pytest.raises(AssertionError, match="class labels"):
+        s.sample(**dict(kw, conditioning=torch.zeros(2, 1, 512).cuda()))

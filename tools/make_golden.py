@@ -903,7 +903,8 @@ def gen_variants():
 
 def gen_updown():
     """G15: `resblock_updown=True` from the real UNetModel (openaimodel.py:570-584,660-674): the shipped spatial-transformer UNet (one ResBlock per
-    level) with ResBlock(down=True) / ResBlock(up=True) between its three levels, and the class-conditional UNet with use_scale_shift_norm on top."""
+    level) with ResBlock(down=True) / ResBlock(up=True) between its three levels, and the class-conditional UNet with use_scale_shift_norm on top -- the latter
+    also inside a real LatentDiffusion(conditioning_key='adm') under the real DDIMSampler.sample (plain, CFG) and p_sample_loop."""
     from tools import ref_shims
     ref_shims.install("face_reenactment")
     from ldm.modules.diffusionmodules.openaimodel import UNetModel
@@ -921,6 +922,43 @@ def gen_updown():
     ref = m(x, t, y=y)
     check("UNet eps, resblock_updown + scale-shift norm (adm)", ref, O.unet_forward(sd, W.UPDOWN_ADM_UNET, x, t, None, y=y), 2e-5, 2e-5)
     g["ud_adm_eps"] = ref
+    # ---- the samplers around a class-conditional model: a real LatentDiffusion with conditioning_key 'adm' (the class labels go
+    # through apply_model as c_crossattn = [y] and reach the UNet as y, ddpm.py:893-994,1417-1419), the real DDIMSampler.sample
+    # (plain and with classifier-free guidance, ddim.py:164-177: y doubled as [uncond | cond]) and p_sample_loop
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    unet_cfg = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(W.UPDOWN_ADM_UNET))
+    fs_cfg = dict(target="ldm.models.autoencoder.VQModelInterface",
+                  params=dict(embed_dim=3, n_embed=16384, ddconfig=dict(W.VQ_F4["ddconfig"]),
+                              lossconfig=dict(target="torch.nn.Identity")))
+    cond_cfg = dict(target="ldm.modules.encoders.modules.ClassEmbedder3",
+                    params=dict(embed_dim=512, n_classes=8, key="class_label", p_uncond=0.2))
+    ld = LatentDiffusion(first_stage_config=fs_cfg, cond_stage_config=cond_cfg, num_timesteps_cond=1,
+                         cond_stage_key="class_label", cond_stage_trainable=True,
+                         conditioning_key="adm", unet_config=unet_cfg, image_size=16, channels=3,
+                         first_stage_key="image", log_every_t=200, monitor="val_loss_ema", **W.SCHEDULE)
+    assert ld.model.conditioning_key == "adm"
+    usd = load_recipe(ld.model.diffusion_model, seed=0, gain=0.25, prefix_check=W.unet_param_shapes(W.UPDOWN_ADM_UNET))   # (gain as in g5)
+    sched = O.register_schedule(**W.SCHEDULE)
+
+    class CPUDDIM(DDIMSampler):
+        def register_buffer(self, n, a):
+            setattr(self, n, a)
+    xT, uy = rnd(176, 2, 3, 16, 16), torch.tensor([0, 0])
+    ref, _ = CPUDDIM(ld).sample(S=4, batch_size=2, shape=[3, 16, 16], conditioning=y, eta=0.0, x_T=xT, verbose=False)
+    check("adm DDIMSampler.sample S=4", ref, O.ddim_sample(usd, W.UPDOWN_ADM_UNET, sched, 4, xT, cond=y), 1e-4, 1e-4)
+    g["adm_ddim4"] = ref
+    ref, _ = CPUDDIM(ld).sample(S=4, batch_size=2, shape=[3, 16, 16], conditioning=y, eta=0.0, x_T=xT, verbose=False,
+                                unconditional_guidance_scale=3.0, unconditional_conditioning=uy)
+    check("adm DDIMSampler.sample S=4, CFG 3", ref, O.ddim_sample(usd, W.UPDOWN_ADM_UNET, sched, 4, xT, cond=y, scale=3.0, uncond=uy),
+          1e-4, 1e-4)
+    g["adm_ddim4_cfg3"] = ref
+    torch.manual_seed(6)
+    ref = ld.p_sample_loop(y, (2, 3, 16, 16), x_T=xT, timesteps=3, verbose=False)
+    torch.manual_seed(6)
+    nz = [torch.randn(xT.shape) for _ in range(3)]
+    check("adm p_sample_loop T=3", ref, O.p_sample_loop(usd, W.UPDOWN_ADM_UNET, sched, xT, cond=y, timesteps=3, noise=nz), 1e-4, 1e-4)
+    g["adm_ddpm3"], g["adm_ddpm3_noise"] = ref, torch.stack(nz)
     save("g15_updown.npz", **g)
 
 
