@@ -295,6 +295,51 @@ class LatentDiffusion(_Base):
             self._ddpm_tables = (tab, self.posterior_log_variance_clipped.contiguous())
         return self._ddpm_tables
 
+    # ---- the posterior pieces with the reference's names and return values (ddpm.py:203-228,1049-1078).  The sampling loops do
+    # not go through them -- one step is the UNet program + ldmk_ddpm_step -- they are here for scripts that call them directly:
+    # elementwise device work on the registered schedule buffers, `extract_into_tensor` (util.py:96-99) as a gather.
+    @staticmethod
+    def _extract(a, t, x):
+        return a.gather(-1, t.to(torch.int64)).reshape((t.shape[0],) + (1,) * (x.dim() - 1))
+
+    def q_mean_variance(self, x_start, t):
+        """q(x_t | x_0): (mean, variance, log_variance), ddpm.py:203-213."""
+        ex = lambda a: self._extract(a, t, x_start)
+        return ex(self.sqrt_alphas_cumprod) * x_start, ex(1.0 - self.alphas_cumprod), ex(self.log_one_minus_alphas_cumprod)
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        """ddpm.py:215-219."""
+        return self._extract(self.sqrt_recip_alphas_cumprod, t, x_t) * x_t - self._extract(self.sqrt_recipm1_alphas_cumprod, t, x_t) * noise
+
+    def q_posterior(self, x_start, x_t, t):
+        """q(x_{t-1} | x_t, x_0): (mean, variance, clipped log variance), ddpm.py:221-228."""
+        ex = lambda a: self._extract(a, t, x_t)
+        mean = ex(self.posterior_mean_coef1) * x_start + ex(self.posterior_mean_coef2) * x_t
+        return mean, ex(self.posterior_variance), ex(self.posterior_log_variance_clipped)
+
+    @torch.no_grad()
+    def p_mean_variance(self, x, c, t, clip_denoised: bool, return_codebook_ids=False, quantize_denoised=False, return_x0=False,
+                        score_corrector=None, corrector_kwargs=None):
+        """ddpm.py:1049-1078: (model_mean, posterior_variance, posterior_log_variance[, x_recon]) from one UNet evaluation."""
+        if return_codebook_ids:
+            raise NotImplementedError("p_mean_variance: return_codebook_ids needs the id-predictor head (n_embed), not built")
+        model_out = self.apply_model(x, t, c)
+        if score_corrector is not None:
+            assert self.parameterization == "eps"
+            model_out = score_corrector.modify_score(self, model_out, x, t, c, **(corrector_kwargs or {}))
+        if self.parameterization == "eps":
+            x_recon = self.predict_start_from_noise(x, t=t, noise=model_out)
+        elif self.parameterization == "x0":
+            x_recon = model_out
+        else:
+            raise NotImplementedError()
+        if clip_denoised:
+            x_recon = x_recon.clamp(-1., 1.)
+        if quantize_denoised:
+            x_recon = self.first_stage_model.quantize(x_recon)[0]
+        out = self.q_posterior(x_start=x_recon, x_t=x, t=t)
+        return out + (x_recon,) if return_x0 else out
+
     @torch.no_grad()
     def p_sample(self, x, c, t, clip_denoised=False, repeat_noise=False, return_codebook_ids=False,
                  quantize_denoised=False, return_x0=False, temperature=1., noise_dropout=0., score_corrector=None,

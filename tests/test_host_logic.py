@@ -340,3 +340,29 @@ def test_shipped_yaml_instantiates_and_matches_the_enumerated_layout(which):
     assert {k for k in sd if k.startswith("first_stage_model.")} == set(vq_keys)
     assert type(model).__name__ == {"fr": "LatentDiffusion", "fr_clip": "LatentDiffusionCLIP", "tf": "LatentDiffusion2Cond"}[which]
     assert model.num_timesteps == 1000 and model.channels == 3 and model.image_size == 32
+
+
+def test_posterior_helpers_carry_the_reference_formulas():
+    """LatentDiffusion.q_mean_variance / predict_start_from_noise / q_posterior (ddpm.py:203-228) are host-visible elementwise
+    work on the registered schedule buffers (no kernel): against the oracle's schedule tables and its p_sample update
+    (oracle.ddpm_update = predict_start_from_noise -> q_posterior -> mean + sigma z, ddpm.py:1049-1109)."""
+    from helpers import fr_config
+    from dsml_thesis_amd.ddpm import LatentDiffusion
+    from oracle import ldm_oracle as O
+    m = LatentDiffusion(**fr_config(unet=dict(W.FR_UNET, model_channels=32, channel_mult=[1], attention_resolutions=[1])))
+    sched = O.register_schedule(**W.SCHEDULE)
+    rs = np.random.RandomState(5)
+    x, eps, nz = (torch.from_numpy(rs.standard_normal((3, 3, 8, 8)).astype(np.float32)) for _ in range(3))
+    t = torch.tensor([0, 417, 999])
+    g = lambda name: sched[name].gather(-1, t).reshape(3, 1, 1, 1)
+    x0 = m.predict_start_from_noise(x, t, eps)
+    assert torch.equal(x0, g("sqrt_recip_alphas_cumprod") * x - g("sqrt_recipm1_alphas_cumprod") * eps)
+    mean, var, logvar = m.q_posterior(x0, x, t)
+    assert mean.shape == x.shape and var.shape == (3, 1, 1, 1) and torch.equal(logvar, g("posterior_log_variance_clipped"))
+    assert torch.equal(var, g("posterior_variance"))
+    nonzero = (1 - (t == 0).float()).reshape(3, 1, 1, 1)
+    assert torch.equal(mean + nonzero * (0.5 * logvar).exp() * nz, O.ddpm_update(sched, x, eps, t, nz))
+    qm, qv, qlv = m.q_mean_variance(x, t)
+    assert torch.equal(qm, g("sqrt_alphas_cumprod") * x) and torch.equal(qv, 1.0 - g("alphas_cumprod"))
+    torch.testing.assert_close(qlv, torch.log(qv), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(m.q_sample(x, t, nz), qm + qv.sqrt() * nz, rtol=1e-6, atol=1e-6)      # (q_sample draws from that q)
