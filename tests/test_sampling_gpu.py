@@ -772,7 +772,7 @@ def test_p_mean_variance_with_the_reference_signature(fr):
     """LatentDiffusion.p_mean_variance (ddpm.py:1049-1078) -- one UNet evaluation, then predict_start_from_noise and q_posterior on
     the schedule buffers -- returns what the fused ldmk_ddpm_step of p_sample / p_sample_loop consumes: mean + sigma z equals
     p_sample on the same noise (to rounding: the kernel fuses the arithmetic), and the oracle's update on the oracle's eps."""
-    c, _ = _cond(fr)
+    c = _cond(fr)[0].detach()
     x, nz = rnd(60, 2, 3, 32, 32).cuda(), rnd(61, 2, 3, 32, 32).cuda()
     t = torch.tensor([0, 640], device="cuda")
     mean, var, logvar, x0 = fr.p_mean_variance(x, c, t, clip_denoised=False, return_x0=True)
@@ -782,7 +782,8 @@ def test_p_mean_variance_with_the_reference_signature(fr):
     close(fr.p_sample(x, c, t, noise=nz), step.cpu(), 1e-5, 1e-5)
     sd = {k: v.detach().cpu() for k, v in fr.model.diffusion_model.state_dict().items()}
     sched = O.register_schedule(**W.SCHEDULE)
-    eps = O.unet_forward(sd, W.FR_UNET, x.cpu(), t.cpu(), c.cpu())
+    with torch.no_grad():
+        eps = O.unet_forward(sd, W.FR_UNET, x.cpu(), t.cpu(), c.cpu())
     close(step, O.ddpm_update(sched, x.cpu(), eps, t.cpu(), nz.cpu()), 1e-4, 1e-4)
     xc = fr.p_mean_variance(x, c, t, clip_denoised=True, return_x0=True)[3]
     assert float(xc.abs().max()) <= 1.0 and len(fr.p_mean_variance(x, c, t, clip_denoised=False)) == 3
