@@ -127,7 +127,7 @@ class DDIMSampler(object):
                       unconditional_guidance_scale=1., unconditional_conditioning=None, noise=None,
                       use_graph=False, policy_batch=None, return_x_inter_only=False, invert=False, mask=None, x0=None,
                       quantize_denoised=False, temperature=1., noise_dropout=0., score_corrector=None,
-                      corrector_kwargs=None, mask_noise=None, ddim_use_original_steps=False, timesteps=None, **kwargs):
+                      corrector_kwargs=None, mask_noise=None, ddim_use_original_steps=False, timesteps=None, n_steps=None, **kwargs):
         """invert=True runs the forward DDIM (inversion) direction: index 0 -> S-1 with q_sample_ddim's update.
         ddim_use_original_steps / timesteps: ddim.py:127-134 -- every step of the model's own schedule (`timesteps`: only its first
         so many), or the first `int(min(timesteps / S, 1) S) - 1` entries of the DDIM subsequence.
@@ -202,6 +202,9 @@ class DDIMSampler(object):
         elif timesteps is not None:
             assert not invert
             n_run = int(min(timesteps / S, 1) * S) - 1       # ddim.py:129-131
+        if n_steps is not None:                              # decode(): exactly the first n_steps entries of the schedule in use
+            assert not invert and timesteps is None
+            n_run = int(n_steps)
         assert 0 < n_run <= S, (n_run, S)
         # loop state (buffers, the captured step) lives ON the launch program it was captured over and dies with it: when the model
         # drops its programs (a re-pack, an arithmetic fall-back) nothing keeps the old workspace or its hipGraph alive, and a
@@ -350,6 +353,39 @@ class DDIMSampler(object):
             x_prev = x_prev + torch.sqrt(table[int(index), 1]) * (q - pred_x0)
             pred_x0 = q
         return x_prev, pred_x0
+
+    # ------------------------------------------------------------------------------------------ img2img (SDEdit) pair
+    @torch.no_grad()
+    def stochastic_encode(self, x0, t, use_original_steps=False, noise=None):
+        """ddim.py:205-219 / ddim2cond.py:198-212: x_t = sqrt(a[t]) x0 + sqrt(1 - a[t]) noise with `t` indexing the DDIM subsequence
+        of the last make_schedule -- or, use_original_steps, the model's own timesteps.  One ldmk_q_sample launch.  The tables are
+        the SAMPLER's (float32 roots of the float32 alphas, make_schedule :35-36,47-50), not the model's float64-rounded buffers."""
+        dev = self.model.device
+        x0 = x0.to(dev, torch.float32).contiguous()
+        if use_original_steps:
+            ac = self.model.alphas_cumprod.to(dev, torch.float32)
+            a, b = torch.sqrt(ac), torch.sqrt(1. - ac)
+        else:
+            a = torch.sqrt(self.ddim_alphas.to(dev, torch.float32)).contiguous()
+            b = torch.as_tensor(np.asarray(self.ddim_sqrt_one_minus_alphas), dtype=torch.float32).to(dev).contiguous()
+        t = t.to(dev, torch.int64).contiguous()
+        assert t.shape == (x0.shape[0],) and int(t.max()) < a.shape[0] and int(t.min()) >= 0, "stochastic_encode: t out of the table"
+        noise = torch.randn_like(x0) if noise is None else noise.to(dev, torch.float32).contiguous()
+        out = torch.empty_like(x0)
+        L.call("ldmk_q_sample", x0.data_ptr(), noise.data_ptr(), t.data_ptr(), a.data_ptr(), b.data_ptr(), out.data_ptr(),
+               x0.shape[0], x0[0].numel(), torch.cuda.current_stream().cuda_stream)
+        return out
+
+    @torch.no_grad()
+    def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,
+               use_original_steps=False, use_graph=False, noise=None):
+        """ddim2cond.py:230-250: the DDIM updates of the first `t_start` entries of the schedule in use (the subsequence of the last
+        make_schedule, or the model's own timesteps), from index t_start - 1 down to 0 -- the device-resident loop of
+        ddim_sampling started there.  `noise`: optional per-step list for eta > 0 (parity with a seeded reference run)."""
+        out, _ = self.ddim_sampling(cond, tuple(x_latent.shape), x_T=x_latent, unconditional_guidance_scale=unconditional_guidance_scale,
+                                    unconditional_conditioning=unconditional_conditioning,
+                                    ddim_use_original_steps=use_original_steps, n_steps=int(t_start), use_graph=use_graph, noise=noise)
+        return out
 
     # ------------------------------------------------------------------------------------------ latent manipulation
     @torch.no_grad()

@@ -348,6 +348,41 @@ def ddim_sample(sd, cfg, sched, S, x_T, cond=None, c_concat=None, eta=0.0, scale
     return (img, traj) if return_all else img
 
 
+def stochastic_encode(sched, S, x0, t, noise, use_original_steps=False):
+    """DDIMSampler.stochastic_encode, ddim.py:205-219 / ddim2cond.py:198-212: q_sample on the DDIM subsequence's alphas (t indexes
+    the S entries of the subsequence) or, use_original_steps, on the model's own schedule (eta does not enter)."""
+    if use_original_steps:
+        # the SAMPLER's buffers (make_schedule, ddim.py:35-36): float32 square roots of the float32 alphas_cumprod, one ulp
+        # away from the model's own buffers in places (those are rounded from float64 roots)
+        a, b = torch.sqrt(sched["alphas_cumprod"]), torch.sqrt(1. - sched["alphas_cumprod"])
+    else:
+        tab = make_ddim_tables(sched["alphas_cumprod"], make_ddim_timesteps(S, sched["betas"].shape[0]), 0.0)
+        a, b = torch.sqrt(torch.as_tensor(tab["a_t"])), torch.as_tensor(tab["sqrt_one_minus_at"])
+    sh = (x0.shape[0], 1, 1, 1)
+    return a.gather(-1, t).reshape(sh) * x0 + b.gather(-1, t).reshape(sh) * noise
+
+
+def ddim_decode(sd, cfg, sched, S, x_latent, t_start, cond=None, c_concat=None, eta=0.0, scale=1.0, uncond=None, noise=None):
+    """DDIMSampler.decode, ddim2cond.py:230-250 (the second half of an img2img / SDEdit edit): the DDIM updates of the FIRST t_start
+    entries of the subsequence, from index t_start - 1 down to 0, through p_sample_ddim."""
+    ts = make_ddim_timesteps(S, sched["betas"].shape[0])
+    tab = make_ddim_tables(sched["alphas_cumprod"], ts, eta)
+    img, b = x_latent, x_latent.shape[0]
+    for i, step in enumerate(np.flip(ts[:t_start])):
+        index = t_start - i - 1
+        t = torch.full((b,), int(step), dtype=torch.long)
+        cc = None if c_concat is None else [c_concat]
+        if uncond is None or scale == 1.0:
+            e_t = apply_model(sd, cfg, img, t, None if cond is None else [cond], cc)
+        else:
+            cc2 = None if c_concat is None else [torch.cat([c_concat] * 2)]
+            e_u, e_c = apply_model(sd, cfg, torch.cat([img] * 2), torch.cat([t] * 2), [torch.cat([uncond, cond])], cc2).chunk(2)
+            e_t = cfg_combine(e_u, e_c, scale)
+        img, _ = ddim_update(img, e_t, tab["a_t"][index], tab["a_prev"][index], tab["sigma_t"][index], tab["sqrt_one_minus_at"][index],
+                             None if noise is None else noise[i])
+    return img
+
+
 def make_ddim_timesteps_strength(num_ddim, num_ddpm=1000, strength=1.0):
     """compute_latents.py:52-73 (strength-scaled 'uniform' schedule of the latent-manipulation scripts)."""
     ts = np.linspace(0, 1, num_ddim) * int(num_ddpm * strength)

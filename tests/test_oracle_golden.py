@@ -418,3 +418,19 @@ def test_g15_class_conditional_model_under_the_samplers():
     close(O.ddim_sample(sd, cfg, sched, 4, xT, cond=y), g["adm_ddim4"], 1e-4, 1e-4)
     close(O.ddim_sample(sd, cfg, sched, 4, xT, cond=y, scale=3.0, uncond=uy), g["adm_ddim4_cfg3"], 1e-4, 1e-4)
     close(O.p_sample_loop(sd, cfg, sched, xT, cond=y, timesteps=3, noise=list(T(g["adm_ddpm3_noise"]))), g["adm_ddpm3"], 1e-4, 1e-4)
+
+
+def test_g16_stochastic_encode_and_decode():
+    """g16 (tools/make_golden.py --tree sdedit): the real talking-face DDIMSampler.stochastic_encode / decode (ddim2cond.py:198-250)
+    around the real LatentDiffusion -- encode bit for bit (the sampler's own float32-root tables), the three-step decodes at 1e-4."""
+    g = golden("g16_sdedit.npz")
+    sched = O.register_schedule(**W.SCHEDULE)
+    x0, nz = rnd(180, 2, 3, 32, 32), rnd(181, 2, 3, 32, 32)
+    c12, c34 = rnd(182, 2, 1, 1024), rnd(183, 2, 6, 32, 32)
+    assert np.array_equal(O.stochastic_encode(sched, 5, x0, torch.tensor([3, 1]), nz).numpy(), g["enc"])
+    assert np.array_equal(O.stochastic_encode(sched, 5, x0, torch.tensor([640, 7]), nz, use_original_steps=True).numpy(), g["enc_orig"])
+    sd = recipe(W.unet_param_shapes(W.TF_UNET), gain=0.25)
+    x_lat = O.stochastic_encode(sched, 5, x0, torch.tensor([2, 2]), nz)
+    close(O.ddim_decode(sd, W.TF_UNET, sched, 5, x_lat, 3, cond=c12, c_concat=c34), g["dec3"], 1e-4, 1e-4)
+    close(O.ddim_decode(sd, W.TF_UNET, sched, 5, x_lat, 3, cond=c12, c_concat=c34, eta=1.0, noise=list(T(g["dec3_eta1_noise"]))),
+          g["dec3_eta1"], 1e-4, 1e-4)

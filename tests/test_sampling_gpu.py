@@ -787,3 +787,32 @@ def test_p_mean_variance_with_the_reference_signature(fr):
     close(step, O.ddpm_update(sched, x.cpu(), eps, t.cpu(), nz.cpu()), 1e-4, 1e-4)
     xc = fr.p_mean_variance(x, c, t, clip_denoised=True, return_x0=True)[3]
     assert float(xc.abs().max()) <= 1.0 and len(fr.p_mean_variance(x, c, t, clip_denoised=False)) == 3
+
+
+def test_stochastic_encode_and_decode_img2img_pair():
+    """DDIMSampler.stochastic_encode / decode (ddim.py:205-219, ddim2cond.py:198-250; the SDEdit-style img2img pair) against the
+    REAL talking-face sampler around the real LatentDiffusion (g16): encode on the DDIM subsequence and on the model's own steps
+    (one ldmk_q_sample launch, the sampler's float32-root tables), decode = the device-resident DDIM loop started at index
+    t_start - 1 -- eta 0 eager == hipGraph bitwise, eta 1 with the reference's seeded draws replayed."""
+    from dsml_thesis_amd.ddim import DDIMSampler
+    g = golden("g16_sdedit.npz")
+    m = make_tf_model(gain=0.25, seq_len=3)
+    x0, nz = rnd(180, 2, 3, 32, 32).cuda(), rnd(181, 2, 3, 32, 32).cuda()
+    cond = {"class_label_&_audio": rnd(182, 2, 1, 1024).cuda(), "motion_&_id": rnd(183, 2, 6, 32, 32).cuda()}
+    s = DDIMSampler(m)
+    s.make_schedule(5, ddim_eta=0.0, verbose=False)
+    close(s.stochastic_encode(x0, torch.tensor([3, 1]), noise=nz), g["enc"], 1e-6, 1e-6)
+    close(s.stochastic_encode(x0, torch.tensor([640, 7]).cuda(), use_original_steps=True, noise=nz), g["enc_orig"], 1e-6, 1e-6)
+    torch.manual_seed(0)
+    assert not torch.equal(s.stochastic_encode(x0, torch.tensor([3, 1])), s.stochastic_encode(x0, torch.tensor([3, 1])))   # own draws
+    with pytest.raises(AssertionError, match="out of the table"):
+        s.stochastic_encode(x0, torch.tensor([5, 0]))
+    x_lat = s.stochastic_encode(x0, torch.tensor([2, 2]), noise=nz)
+    dec = s.decode(x_lat, cond, 3)
+    close(dec, g["dec3"], 1.5e-4, 1.5e-4)
+    assert torch.equal(dec, s.decode(x_lat, cond, 3, use_graph=True))
+    full, _ = s.ddim_sampling(cond, tuple(x_lat.shape), x_T=x_lat)
+    assert not torch.equal(full, dec)                          # (all five entries is another trajectory)
+    s1 = DDIMSampler(m)
+    s1.make_schedule(5, ddim_eta=1.0, verbose=False)
+    close(s1.decode(x_lat, cond, 3, noise=list(T(g["dec3_eta1_noise"]).cuda())), g["dec3_eta1"], 1.5e-4, 1.5e-4)

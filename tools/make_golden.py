@@ -962,9 +962,70 @@ def gen_updown():
     save("g15_updown.npz", **g)
 
 
+def gen_sdedit():
+    """G16: the sampler's img2img pair from the real talking-face DDIMSampler (ddim2cond.py:198-250) around the real LatentDiffusion:
+    stochastic_encode (q_sample on the DDIM subsequence / on the model's own schedule) and decode (the DDIM updates of the first
+    t_start entries of the subsequence), eta 0 and eta 1 with the reference's own seeded draws replayed and stored."""
+    from tools import ref_shims
+    ref_shims.install("talking_face")
+    from ldm.models.diffusion.ddim2cond import DDIMSampler
+    from ldm.models.diffusion.ddpm2cond import LatentDiffusion
+    torch.set_grad_enabled(False)
+    sched = O.register_schedule(**W.SCHEDULE)
+    unet_cfg = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(W.TF_UNET))
+    fs_cfg = dict(target="ldm.models.autoencoder.VQModelInterface",
+                  params=dict(embed_dim=3, n_embed=16384, ddconfig=dict(W.VQ_F4["ddconfig"]),
+                              lossconfig=dict(target="torch.nn.Identity")))
+    c1_cfg = dict(target="ldm.modules.encoders.modules.ClassEmbedder",
+                  params=dict(embed_dim=256, n_classes=8, key="class_label", p_uncond=0.2))
+    c2_cfg = dict(target="ldm.modules.encoders.modules.Conv1DTemporalAttention",
+                  params=dict(seq_len=3, subspace_dim=768, subspace2hidden=False))
+    ld = LatentDiffusion(first_stage_config=fs_cfg, cond_stage_config_1=c1_cfg, cond_stage_config_2=c2_cfg,
+                         num_timesteps_cond=1, cond_stage_key_1="class_label", cond_stage_key_2="audio",
+                         cond_stage_trainable=True, conditioning_key="crossattn", unet_config=unet_cfg,
+                         image_size=32, channels=3, first_stage_key="image", log_every_t=200,
+                         monitor="val_loss_ema", **W.SCHEDULE)
+
+    class CPUDDIM(DDIMSampler):
+        def register_buffer(self, n, a):
+            setattr(self, n, a)
+    usd = load_recipe(ld.model.diffusion_model, seed=0, gain=0.25, prefix_check=W.unet_param_shapes(W.TF_UNET))
+    g = {}
+    S = 5
+    x0, nz = rnd(180, 2, 3, 32, 32), rnd(181, 2, 3, 32, 32)
+    c12, c34 = rnd(182, 2, 1, 1024), rnd(183, 2, 6, 32, 32)
+    cond = {"class_label_&_audio": c12, "motion_&_id": c34}
+    smp = CPUDDIM(ld)
+    smp.make_schedule(S, ddim_eta=0.0, verbose=False)
+    t = torch.tensor([3, 1])
+    enc = smp.stochastic_encode(x0, t, noise=nz)
+    check("stochastic_encode (DDIM subsequence)", enc, O.stochastic_encode(sched, S, x0, t, nz), 1e-6, 1e-6)
+    g["enc"] = enc
+    t_o = torch.tensor([640, 7])
+    enc_o = smp.stochastic_encode(x0, t_o, use_original_steps=True, noise=nz)
+    check("stochastic_encode (original steps)", enc_o, O.stochastic_encode(sched, S, x0, t_o, nz, use_original_steps=True), 1e-6, 1e-6)
+    g["enc_orig"] = enc_o
+    t3 = torch.tensor([2, 2])                    # encode to index 2, decode the first 3 entries: an SDEdit edit of strength 3 / 5
+    x_lat = smp.stochastic_encode(x0, t3, noise=nz)
+    dec = smp.decode(x_lat, cond, 3)
+    mine = O.ddim_decode(usd, W.TF_UNET, sched, S, O.stochastic_encode(sched, S, x0, t3, nz), 3, cond=c12, c_concat=c34)
+    check("decode t_start=3 of S=5, eta 0", dec, mine, 1e-4, 1e-4)
+    g["dec3"] = dec
+    smp1 = CPUDDIM(ld)
+    smp1.make_schedule(S, ddim_eta=1.0, verbose=False)
+    torch.manual_seed(8)
+    dec1 = smp1.decode(x_lat, cond, 3)
+    torch.manual_seed(8)
+    dn = [torch.randn(x0.shape) for _ in range(3)]
+    mine = O.ddim_decode(usd, W.TF_UNET, sched, S, x_lat, 3, cond=c12, c_concat=c34, eta=1.0, noise=dn)
+    check("decode t_start=3 of S=5, eta 1", dec1, mine, 1e-4, 1e-4)
+    g["dec3_eta1"], g["dec3_eta1_noise"] = dec1, torch.stack(dn)
+    save("g16_sdedit.npz", **g)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants", "updown"])
+    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants", "updown", "sdedit"])
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -986,6 +1047,8 @@ if __name__ == "__main__":
         gen_variants()
     elif a.tree == "updown":
         gen_updown()
+    elif a.tree == "sdedit":
+        gen_sdedit()
     else:
-        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants", "updown"):
+        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants", "updown", "sdedit"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", tree], cwd=ROOT)
