@@ -403,6 +403,24 @@ class DDIMSampler(object):
         return img, x_lat, x0
 
     @torch.no_grad()
+    def latent_manipulation(self, c_src, c_trg, S, batch_size, shape, x0=None, eta=0., unconditional_guidance_scale=1.,
+                            unconditional_conditioning=None, strength=1.0, x_T=None, verbose=True, use_graph=False, **kwargs):
+        """The emotion edit of face_reenactment/latent_manipulation.py:420-490: DDIM inversion of x0 under the SOURCE conditioning
+        (`q_sample_ddim`, :377-418), regeneration under the TARGET conditioning, both on the strength-scaled schedule and on the
+        device-resident loop (the two directions are two captured steps of the same launch program).  Returns (img, x_latent, x0)."""
+        assert c_src is not None and c_trg is not None
+        assert x0 is not None
+        assert x_T is None
+        assert eta == 0
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose, strength=strength)
+        size = (batch_size,) + tuple(shape)
+        kw = dict(unconditional_guidance_scale=unconditional_guidance_scale,
+                  unconditional_conditioning=unconditional_conditioning, use_graph=use_graph)
+        x_lat, _ = self.ddim_sampling(c_src, size, x_T=x0, invert=True, **kw)
+        img, _ = self.ddim_sampling(c_trg, size, x_T=x_lat, **kw)
+        return img, x_lat, x0
+
+    @torch.no_grad()
     def ddim_tuned_sampling(self, S, batch_size, shape, x_lat, cond, eta=0., unconditional_guidance_scale=1.,
                             unconditional_conditioning=None, strength=1.0, verbose=True, use_graph=False, **kwargs):
         """Reverse DDIM from a precomputed latent on the strength-scaled schedule

@@ -389,9 +389,10 @@ def make_ddim_timesteps_strength(num_ddim, num_ddpm=1000, strength=1.0):
     return np.asarray([1] + [int(s) for s in list(ts)][1:])
 
 
-def ddim_invert_and_regenerate(sd, cfg, sched, S, x0, cond, strength=0.5, scale=1.0, uncond=None):
+def ddim_invert_and_regenerate(sd, cfg, sched, S, x0, cond, strength=0.5, scale=1.0, uncond=None, cond_trg=None):
     """DDIMSampler.compute_latents + q_sample_ddim, compute_latents.py:297-406: forward DDIM (inversion) over the
-    strength-scaled timesteps, then the reverse loop.  Returns (img, x_latent)."""
+    strength-scaled timesteps, then the reverse loop.  Returns (img, x_latent).  cond_trg: DDIMSampler.latent_manipulation
+    (latent_manipulation.py:420-490) -- the same two loops, inverted under `cond` (c_src), regenerated under `cond_trg`."""
     ts = make_ddim_timesteps_strength(S, sched["betas"].shape[0], strength)
     ac = torch.as_tensor(sched["alphas_cumprod"], dtype=torch.float32)
     alphas = ac[ts]                                                        # f32 tensor
@@ -400,10 +401,11 @@ def ddim_invert_and_regenerate(sd, cfg, sched, S, x0, cond, strength=0.5, scale=
     s1m_prev = np.sqrt(1.0 - alphas_prev)                                  # f64
     b = x0.shape[0]
 
-    def eps_of(x, t):
+    def eps_of(x, t, c=None):
+        c = cond if c is None else c
         if uncond is None or scale == 1.0:
-            return apply_model(sd, cfg, x, t, [cond])
-        e_u, e_c = apply_model(sd, cfg, torch.cat([x] * 2), torch.cat([t] * 2), [torch.cat([uncond, cond])]).chunk(2)
+            return apply_model(sd, cfg, x, t, [c])
+        e_u, e_c = apply_model(sd, cfg, torch.cat([x] * 2), torch.cat([t] * 2), [torch.cat([uncond, c])]).chunk(2)
         return cfg_combine(e_u, e_c, scale)
 
     f32 = lambda v: torch.tensor(float(v), dtype=torch.float32)
@@ -419,7 +421,7 @@ def ddim_invert_and_regenerate(sd, cfg, sched, S, x0, cond, strength=0.5, scale=
     for i, step in enumerate(np.flip(ts)):                                 # reverse DDIM, :351-360 (eta = 0)
         index = S - i - 1
         t = torch.full((b,), int(step), dtype=torch.long)
-        e = eps_of(img, t)
+        e = eps_of(img, t, cond_trg)
         img, _ = ddim_update(img, e, alphas[index].item(), np.float32(alphas_prev[index]), 0.0, s1m[index])
     return img, x_lat
 

@@ -434,3 +434,18 @@ def test_g16_stochastic_encode_and_decode():
     close(O.ddim_decode(sd, W.TF_UNET, sched, 5, x_lat, 3, cond=c12, c_concat=c34), g["dec3"], 1e-4, 1e-4)
     close(O.ddim_decode(sd, W.TF_UNET, sched, 5, x_lat, 3, cond=c12, c_concat=c34, eta=1.0, noise=list(T(g["dec3_eta1_noise"]))),
           g["dec3_eta1"], 1e-4, 1e-4)
+
+
+def test_g17_latent_manipulation():
+    """g17 (tools/make_golden.py --tree manip): DDIMSampler.latent_manipulation of the driver script latent_manipulation.py
+    (:420-490) on the real LatentDiffusion -- inversion under the source label, regeneration under the target label."""
+    g = golden("g17_manipulation.npz")
+    sched = O.register_schedule(**W.SCHEDULE)
+    sd = recipe(W.unet_param_shapes(W.FR_UNET), gain=0.25)
+    x0, c_src, c_trg, uc = rnd(190, 2, 3, 32, 32), T(g["c_src"]), T(g["c_trg"]), T(g["uc"])
+    img, lat = O.ddim_invert_and_regenerate(sd, W.FR_UNET, sched, 4, x0, c_src, strength=0.5, cond_trg=c_trg)
+    close(lat, g["xlat_cfg1"], 1e-4, 1e-4)
+    close(img, g["img_cfg1"], 1e-4, 1e-4)
+    img3, lat3 = O.ddim_invert_and_regenerate(sd, W.FR_UNET, sched, 4, x0, c_src, strength=0.5, scale=3.0, uncond=uc, cond_trg=c_trg)
+    close(lat3, g["xlat_cfg3"], 1e-4, 1e-4)
+    close(img3, g["img_cfg3"], 1e-4, 1e-4)

@@ -816,3 +816,33 @@ def test_stochastic_encode_and_decode_img2img_pair():
     s1 = DDIMSampler(m)
     s1.make_schedule(5, ddim_eta=1.0, verbose=False)
     close(s1.decode(x_lat, cond, 3, noise=list(T(g["dec3_eta1_noise"]).cuda())), g["dec3_eta1"], 1.5e-4, 1.5e-4)
+
+
+def test_latent_manipulation_source_to_target_label(fr):
+    """DDIMSampler.latent_manipulation (face_reenactment/latent_manipulation.py:420-490): inversion under the source
+    label's conditioning, regeneration under the target label's, against the driver script's own sampler class around the real
+    LatentDiffusion (g17), plain and CFG 3; eager == hipGraph bitwise; target == source is compute_latents."""
+    from dsml_thesis_amd.ddim import DDIMSampler
+    g = golden("g17_manipulation.npz")
+    c_src, uc = _cond(fr, (1, 6))
+    c_trg, _ = _cond(fr, (3, 0))
+    c_src, c_trg, uc = c_src.detach(), c_trg.detach(), uc.detach()
+    close(c_src, g["c_src"], 0, 0)
+    close(c_trg, g["c_trg"], 0, 0)
+    x0 = rnd(190, 2, 3, 32, 32).cuda()
+    s = DDIMSampler(fr)
+    for tag, scale in (("cfg1", 1.0), ("cfg3", 3.0)):
+        kw = dict(S=4, batch_size=2, shape=[3, 32, 32], x0=x0, strength=0.5, verbose=False, unconditional_guidance_scale=scale,
+                  unconditional_conditioning=uc if scale != 1.0 else None)
+        img, lat, x0_ = s.latent_manipulation(c_src, c_trg, **kw)
+        assert x0_ is x0
+        close(lat, g[f"xlat_{tag}"], 1e-4, 1e-4)
+        close(img, g[f"img_{tag}"], 1.5e-4, 1.5e-4)
+        img_g, lat_g, _ = s.latent_manipulation(c_src, c_trg, use_graph=True, **kw)
+        assert torch.equal(lat, lat_g) and torch.equal(img, img_g)
+    same, lat_s, _ = s.latent_manipulation(c_src, c_src, **kw)
+    ref, lat_r, _ = s.compute_latents(S=4, batch_size=2, shape=[3, 32, 32], conditioning=c_src, x0=x0, strength=0.5, verbose=False,
+                                      unconditional_guidance_scale=3.0, unconditional_conditioning=uc)
+    assert torch.equal(same, ref) and torch.equal(lat_s, lat_r) and not torch.equal(same, img)
+    with pytest.raises(AssertionError):
+        s.latent_manipulation(c_src, c_trg, **dict(kw, eta=1.0))

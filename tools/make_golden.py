@@ -1023,9 +1023,56 @@ def gen_sdedit():
     save("g16_sdedit.npz", **g)
 
 
+def gen_manip():
+    """G17: DDIMSampler.latent_manipulation of the driver script face_reenactment/latent_manipulation.py (:420-490; importable under
+    the same stand-ins as compute_latents.py): DDIM inversion of x0 under the SOURCE label's conditioning, regeneration under the
+    TARGET label's -- the emotion edit -- on the real LatentDiffusion, plain and with classifier-free guidance."""
+    from tools import ref_shims
+    ref_shims.install("face_reenactment")
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    import latent_manipulation as lm
+    torch.set_grad_enabled(False)
+    unet_cfg = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(W.FR_UNET))
+    fs_cfg = dict(target="ldm.models.autoencoder.VQModelInterface",
+                  params=dict(embed_dim=3, n_embed=16384, ddconfig=dict(W.VQ_F4["ddconfig"]),
+                              lossconfig=dict(target="torch.nn.Identity")))
+    cond_cfg = dict(target="ldm.modules.encoders.modules.ClassEmbedder3",
+                    params=dict(embed_dim=512, n_classes=8, key="class_label", p_uncond=0.2))
+    ld = LatentDiffusion(first_stage_config=fs_cfg, cond_stage_config=cond_cfg, num_timesteps_cond=1,
+                         cond_stage_key="class_label", cond_stage_trainable=True,
+                         conditioning_key="crossattn", unet_config=unet_cfg, image_size=32, channels=3,
+                         first_stage_key="image", log_every_t=200, monitor="val_loss_ema", **W.SCHEDULE)
+    sched = O.register_schedule(**W.SCHEDULE)
+    usd = load_recipe(ld.model.diffusion_model, seed=0, gain=0.25, prefix_check=W.unet_param_shapes(W.FR_UNET))
+    load_recipe(ld.cond_stage_model, seed=0)
+    c_src = ld.cond_stage_model.embedding(torch.tensor([[1], [6]]))
+    c_trg = ld.cond_stage_model.embedding(torch.tensor([[3], [0]]))
+    uc = ld.cond_stage_model.uncond_embedding(torch.zeros(2, 1, dtype=torch.long))
+
+    class CPUManip(lm.DDIMSampler):
+        def register_buffer(self, n, a):
+            setattr(self, n, a)
+    smp = CPUManip(ld)
+    x0 = rnd(190, 2, 3, 32, 32)
+    g = {}
+    for tag, scale in (("cfg1", 1.0), ("cfg3", 3.0)):
+        img, xlat, _ = smp.latent_manipulation(c_src, c_trg, S=4, batch_size=2, shape=[3, 32, 32], x0=x0, eta=0.0, verbose=False,
+                                               strength=0.5, unconditional_guidance_scale=scale,
+                                               unconditional_conditioning=uc if scale != 1.0 else None)
+        mimg, mlat = O.ddim_invert_and_regenerate(usd, W.FR_UNET, sched, 4, x0, c_src, strength=0.5, scale=scale,
+                                                  uncond=uc if scale != 1.0 else None, cond_trg=c_trg)
+        check(f"manipulation: inverted latent {tag}", xlat, mlat, 1e-4, 1e-4)
+        check(f"manipulation: edited {tag}", img, mimg, 1e-4, 1e-4)
+        g[f"xlat_{tag}"], g[f"img_{tag}"] = xlat, img
+    same, _, _ = smp.latent_manipulation(c_src, c_src, S=4, batch_size=2, shape=[3, 32, 32], x0=x0, eta=0.0, verbose=False, strength=0.5)
+    print("  edit moves the image by", float((g["img_cfg1"] - same).abs().max()))
+    g["c_src"], g["c_trg"], g["uc"] = c_src, c_trg, uc
+    save("g17_manipulation.npz", **g)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants", "updown", "sdedit"])
+    ap.add_argument("--tree", choices=["face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants", "updown", "sdedit", "manip"])
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -1049,6 +1096,8 @@ if __name__ == "__main__":
         gen_updown()
     elif a.tree == "sdedit":
         gen_sdedit()
+    elif a.tree == "manip":
+        gen_manip()
     else:
-        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants", "updown", "sdedit"):
+        for tree in ("face_reenactment", "talking_face", "train", "diffclip", "northstar", "options", "config0", "variants", "updown", "sdedit", "manip"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", tree], cwd=ROOT)
