@@ -8,13 +8,15 @@ import os
 import subprocess
 import sys
 
+from . import switches
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.environ.get("LDMK_LIB_OUT") or os.path.join(HERE, "libldmk.so")      # (LDMK_LIB_OUT: an A/B build next to the shipped one)
+LIB = switches.get("LDMK_LIB_OUT") or os.path.join(HERE, "libldmk.so")      # (LDMK_LIB_OUT: an A/B build next to the shipped one)
 SOURCES = ["igemm.hip", "rgemm.hip", "norms.hip", "attention.hip", "small.hip", "wgrad.hip", "backward.hip", "attention_bwd.hip", "winograd.hip", "post.hip", "sgemm.hip", "attention_small.hip", "attention_bf16.hip", "igemm_ws.hip", "igemm_ps.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
 # probe builds only (tools/ps_probe.sh, tools/pw_stamps.py: LDMK_HIPCC_FLAGS=-DLDMK_PS_PROBES): extra flags are part of the digest
-FLAGS += os.environ.get("LDMK_HIPCC_FLAGS", "").split()
+FLAGS += switches.get("LDMK_HIPCC_FLAGS", "").split()
 # The attention kernels run their softmax on the MFMA results: keep the accumulators in VGPRs (MFMA VGPR form) instead of
 # AGPRs, otherwise every score / output tile costs a v_accvgpr_read + v_accvgpr_write round trip per register
 # (208 such moves per key tile in the forward kernel).  The GEMM kernels only touch their accumulators in the epilogue.

@@ -13,6 +13,7 @@ import os
 import torch
 
 from . import lib as L
+from . import switches
 
 
 def plan_key(a, m):
@@ -45,24 +46,24 @@ _PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "igemm_pla
 def split_enabled():
     """LDMK_COMPUTE_BF16X3 (fp32-accurate GEMMs from six bf16 MFMAs, include/ldmk.h) for the shapes the plan file lists;
     LDMK_SPLIT_BF16=0 keeps every GEMM on the f32 matrix-core form."""
-    return os.environ.get("LDMK_SPLIT_BF16", "1") != "0"
+    return switches.get("LDMK_SPLIT_BF16", "1") != "0"
 
 
 def f16x2_enabled():
     """The F16X2 arithmetic (include/ldmk.h: fp32-accurate products from three fp16 matrix instructions per term, operands scaled
     into fp16's range, a device flag raised when one leaves it) where a kernel offers it; LDMK_F16X2=0 keeps the bf16x3 forms."""
-    return split_enabled() and os.environ.get("LDMK_F16X2", "1") != "0"
+    return split_enabled() and switches.get("LDMK_F16X2", "1") != "0"
 
 
 def ps_enabled():
     """Pre-split operands (csrc/igemm_ps.hip, tile_cfg 23+): activations written in the PS layout by their producers and moved
     memory -> LDS by LDS-DMA, for the shapes the "ps_*" sections list.  LDMK_PS=0 keeps the round-3 kernels."""
-    return split_enabled() and os.environ.get("LDMK_PS", "1") != "0"
+    return split_enabled() and switches.get("LDMK_PS", "1") != "0"
 
 
 def _section_enabled(section):
     if section == "f32":
-        return not os.environ.get("LDMK_NO_PLAN_TABLE")
+        return not switches.get("LDMK_NO_PLAN_TABLE")
     if section == "bf16x3":
         return split_enabled()
     if section == "f16x2":
@@ -106,9 +107,9 @@ def table(section):
 # a performance rule only.  Rounds 1-4 stopped at 2: jobs far from the tuned batches (16 and 128) then found no split-arithmetic
 # plan and silently ran the f32 program.  Round 5 carries the nearest tuned plan whatever the distance when no section holds a near
 # one (A/B: profiles/r05_plan_coverage.txt); LDMK_PLAN_MAX_RATIO=2 restores the old rule.
-PLAN_MAX_RATIO = float(os.environ.get("LDMK_PLAN_MAX_RATIO", "0")) or None
+PLAN_MAX_RATIO = float(switches.get("LDMK_PLAN_MAX_RATIO", "0")) or None
 # direct 3x3 convolutions without a table entry run in F16X2 from this K (= 9 C_in) up, on their f32 plan's tile (Program.plan)
-H2_CONV_MIN_K = 1440 if os.environ.get("LDMK_H2_CONV_RULE", "1") != "0" else (1 << 30)
+H2_CONV_MIN_K = 1440 if switches.get("LDMK_H2_CONV_RULE", "1") != "0" else (1 << 30)
 
 
 def lookup(section, rest, m, max_ratio=None):
@@ -417,7 +418,7 @@ class Program:
             # first version (one atomic load per element) 476 -> 446 at 64x64x4 B=16, 1657 -> 1231 at 32x32x3, 249 -> 141
             # at B=1; with the loads batched (64 in flight per wave) 1720 -> 1614 at 32x32x3 and 252 -> 249 at B=1.
             # LDMK_SPLITK_IN_LAUNCH=1 turns it on.
-            if os.environ.get("LDMK_SPLITK_IN_LAUNCH"):
+            if switches.get("LDMK_SPLITK_IN_LAUNCH"):
                 cnt = self.splitk_counters()
                 args.splitk_counters, args.splitk_counters_len = cnt.data_ptr(), cnt.numel()
         self.calls.append((self.lib.ldmk_igemm, (C.byref(args),), args, "ldmk_igemm"))
@@ -592,13 +593,13 @@ class NetBuilder:
     # 256 tiles up (640->640 at 16x16, B = 16: 243+8 -> 165 us); loses at 160 channels (transform traffic) and at batch 1.
     # (the two environment overrides exist for A/B experiments only).  Tiles: 1024 -> 256 is +2.3 % at 32x32x3 B = 16 (the
     # 640-channel level has 256 tiles there); 64 tiles (batch 1) loses 7 %.
-    WINO_MIN_TILES = int(os.environ.get("LDMK_WINO_MIN_TILES", "256"))
+    WINO_MIN_TILES = int(switches.get("LDMK_WINO_MIN_TILES", "256"))
     UP_MIN_PIXELS = 1024
-    WINO_MIN_CIN = int(os.environ.get("LDMK_WINO_MIN_CIN", "320"))
+    WINO_MIN_CIN = int(switches.get("LDMK_WINO_MIN_CIN", "320"))
 
     def winograd_ok(self, cin, h, w):
         import os
-        if os.environ.get("LDMK_NO_WINOGRAD"):
+        if switches.get("LDMK_NO_WINOGRAD"):
             return False
         pol_n = self.pin[0] if self.pin else self.n
         return (cin >= self.WINO_MIN_CIN and pol_n * (h // 2) * (w // 2) >= self.WINO_MIN_TILES and h % 2 == 0
@@ -611,9 +612,9 @@ class NetBuilder:
         (the in-register-split implicit GEMM for the 160-channel convolutions, Winograd GEMM + both transforms for the wide ones:
         profiles/r05_ab_conv_ps.txt).  LDMK_PSC=0 turns the route off; LDMK_PSC_FORCE="cfg,splitk" forces it for every eligible
         convolution (A/B runs)."""
-        if not ps_enabled() or self.h2_flag is None or os.environ.get("LDMK_PSC", "1") == "0":
+        if not ps_enabled() or self.h2_flag is None or switches.get("LDMK_PSC", "1") == "0":
             return None
-        forced = os.environ.get("LDMK_PSC_FORCE")
+        forced = switches.get("LDMK_PSC_FORCE")
         if forced:
             cfg, sk = (int(v) for v in forced.split(","))
             cin32 = K // (9 * 32)
@@ -712,7 +713,7 @@ class NetBuilder:
         pg, n, ops, p_ = self.pg, self.n, self.ops, self.ptr
         c = x.shape[-1]
         pol_n = self.pin[0] if self.pin else n
-        if (w4 is None or os.environ.get("LDMK_NO_WINOGRAD") or c < self.WINO_MIN_CIN or pol_n * h * w < self.UP_MIN_PIXELS
+        if (w4 is None or switches.get("LDMK_NO_WINOGRAD") or c < self.WINO_MIN_CIN or pol_n * h * w < self.UP_MIN_PIXELS
                 or w not in (8, 16, 32, 64)):
             return self.conv(x, None, wp, bias, h, w, upsample=True, stats=stats)
         cout = w4.shape[2]

@@ -3,9 +3,11 @@ call fails, this raises -- the product path is the HIP path or nothing."""
 import ctypes as C
 import os
 
+from . import switches
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LDMK_LIBRARY: another build of the same library (A/B timing of a kernel change on one box); still no fallback
-LIB_PATH = os.environ.get("LDMK_LIBRARY") or os.path.join(_HERE, "libldmk.so")
+LIB_PATH = switches.get("LDMK_LIBRARY") or os.path.join(_HERE, "libldmk.so")
 
 A_ROWS, A_CONV3X3 = 0, 1
 TF_NONE, TF_AFFINE, TF_AFFINE_SILU, TF_LAYERNORM, TF_LAYERNORM_FOLDED = 0, 1, 2, 3, 4
@@ -206,8 +208,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if os.environ.get("LDMK_ATTN_QT"):          # A/B hook: query tiles per wave of the staged attention kernel (1 / 2)
-        lib.ldmk_attn_force_qt(int(os.environ["LDMK_ATTN_QT"]))
+    if switches.get("LDMK_ATTN_QT"):          # A/B hook: query tiles per wave of the staged attention kernel (1 / 2)
+        lib.ldmk_attn_force_qt(int(switches.get("LDMK_ATTN_QT")))
     _lib = lib
     return lib
 

@@ -11,6 +11,8 @@ sharded result is bitwise equal to the single-GPU one.
 import numpy as np
 import torch
 
+from . import switches
+
 
 def shard_range(n_items, world_size, rank):
     """Contiguous partition: rank r owns [r*ceil(N/G), min(N, (r+1)*ceil(N/G)))  (SURVEY §8e)."""
@@ -46,7 +48,7 @@ def all_gather_items(local, n_items, group=None):
     global COLLECTIVES_ISSUED
     if not (dist.is_available() and dist.is_initialized()):
         return local[:n_items]
-    if dist.get_world_size(group) == 1 and not os.environ.get("LDMK_FORCE_COLLECTIVE"):
+    if dist.get_world_size(group) == 1 and not switches.get("LDMK_FORCE_COLLECTIVE"):
         return local[:n_items]
     COLLECTIVES_ISSUED += 1
     world = dist.get_world_size(group)

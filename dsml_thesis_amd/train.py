@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from . import lib as L
+from . import switches
 from . import ops
 from . import train_ops as T
 from .engine import tuned_plan
@@ -74,7 +75,7 @@ def repack_bf16_weights():
 
 def _bf16_image(a, dev):
     """The pre-packed bf16 image of this forward GEMM's weight, or None on first sight (it is registered for the next pass)."""
-    if _WT16 is None or a.b_trans or a.batch > 1 or a.K % 8 or os.environ.get("LDMK_TRAIN_NO_PACKED_W") or not _WT16.owns(a.w):
+    if _WT16 is None or a.b_trans or a.batch > 1 or a.K % 8 or switches.get("LDMK_TRAIN_NO_PACKED_W") or not _WT16.owns(a.w):
         return None
     hit = _WT16.images.get(a.w)
     if hit is not None and hit[2:] == (a.K, a.N, a.ldb):
@@ -102,7 +103,7 @@ def gemm(a, dev):
     if plan is not None and max(1, a.batch) * plan[1] * a.M * a.N <= ws.numel():
         a.tile_cfg, a.splitk = plan
     a.splitk_ws, a.splitk_ws_elems = ws.data_ptr(), ws.numel()
-    if os.environ.get("LDMK_SPLITK_IN_LAUNCH"):       # off by default: slower than the reduce launch (engine.Program.igemm)
+    if switches.get("LDMK_SPLITK_IN_LAUNCH"):       # off by default: slower than the reduce launch (engine.Program.igemm)
         cnt = _SK_CNT.get(dev)
         if cnt is None:
             cnt = _SK_CNT[dev] = torch.zeros(16384, device=dev, dtype=torch.int32)

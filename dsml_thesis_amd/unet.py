@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import lib as L
+from . import switches
 from . import ops
 from .engine import ArithSites, NetBuilder, Program, far_from_tuned, split_enabled as engine_split_enabled, ps_enabled as engine_ps_enabled, f16x2_enabled
 
@@ -24,21 +25,21 @@ from .engine import ArithSites, NetBuilder, Program, far_from_tuned, split_enabl
 # pass raises a device flag for rows beyond LN_GUARD_RATIO; UNetModel reads it once per program (and once per sampling run) and
 # rebuilds itself with the unfolded prologue (LayerNorm applied while the A operand is staged), with a warning.
 # LDMK_LN_UNFOLDED=1 starts every model in the unfolded form (A/B switch).
-LN_GUARD_RATIO = float(os.environ.get("LDMK_LN_GUARD_RATIO", "4.0"))
+LN_GUARD_RATIO = float(switches.get("LDMK_LN_GUARD_RATIO", "4.0"))
 
 
 # self attention with K / V pre-split by a pre-pass (csrc/attention_bf16.hip: attn_x3p_fwd_kernel): the pre-pass costs one sweep
 # over K and V (and a launch), the key loop saves its K / V splits tokens / 128 times.  Measured in the 64x64x4 step, B = 16
 # (profiles/r04_layers64.txt, kernel + pre-pass against ldmk_attn_self_x3): 4096 tokens 1062 -> 994 us per call, 1024 tokens
 # 145 -> 152, 256 tokens 28 -> 38: it pays from a few thousand tokens per sample.
-ATTN_PRESPLIT_MIN_TOKENS = int(os.environ.get("LDMK_ATTN_PRESPLIT_MIN_TOKENS", "2048"))
+ATTN_PRESPLIT_MIN_TOKENS = int(switches.get("LDMK_ATTN_PRESPLIT_MIN_TOKENS", "2048"))
 # the F16X2 attention (ldmk_attn_self_h2; it always runs the K / V pre-pass).  Kernel + pre-pass against ldmk_attn_self_x3, B = 16
 # (profiles/r04_ab_attn.txt): 4096 tokens 1127 -> 695 us, 1024 tokens 183 -> 122, 256 tokens 38.9 -> 39.4
-ATTN_H2_MIN_TOKENS = int(os.environ.get("LDMK_ATTN_H2_MIN_TOKENS", "512"))
+ATTN_H2_MIN_TOKENS = int(switches.get("LDMK_ATTN_H2_MIN_TOKENS", "512"))
 
 
 def ln_unfolded_default():
-    return bool(os.environ.get("LDMK_LN_UNFOLDED"))
+    return bool(switches.get("LDMK_LN_UNFOLDED"))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -146,7 +147,7 @@ def pack_spatial_transformer(P, sd, prefix, m):
 
 
 def attention_presplit(hw):
-    return engine_split_enabled() and hw >= ATTN_PRESPLIT_MIN_TOKENS and os.environ.get("LDMK_ATTN_PRESPLIT", "1") != "0"
+    return engine_split_enabled() and hw >= ATTN_PRESPLIT_MIN_TOKENS and switches.get("LDMK_ATTN_PRESPLIT", "1") != "0"
 
 
 def emit_self_attention(nb_, qkv, att, hw, heads, d_head, att_ps=None, kv_tiles=None):
@@ -366,7 +367,7 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
             kv_state["tiles"] = None
             kvt = None
             if (h2_flag is not None and hw >= ATTN_H2_MIN_TOKENS and hw % 64 == 0 and m.d_head == 32
-                    and os.environ.get("LDMK_QKV_TILES", "1") != "0"):
+                    and switches.get("LDMK_QKV_TILES", "1") != "0"):
                 kvt = pg.alloc(pg.lib.ldmk_attn_kv_split_h2_bytes(n, hw, m.heads), dtype=torch.uint8)
             qkv = ln_lin(hcur, q + "qkv_ln", False, attn_kv=None if kvt is None else (kvt, hw, m.heads))
             if kvt is not None and kv_state["tiles"] is None:
@@ -375,7 +376,7 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
         # both attention products in the fp32-accurate bf16x3 arithmetic (24 bf16 MFMAs of 32 cycles per 32 keys
         # instead of 32 fp32 ones of 64); LDMK_SPLIT_BF16=0 keeps the f32 matrix-core kernel.  With a pre-split plan for
         # attn1.to_out the attention kernel writes its result in the PS layout only (from its accumulators, no LDS pass)
-        plan_o = (nb_.ps_query(rows, C_, C_) if (q + "o1" + psfx() in P and L_ctx == 1 and hw % 32 == 0 and os.environ.get("LDMK_ATTN_PS", "1") != "0"
+        plan_o = (nb_.ps_query(rows, C_, C_) if (q + "o1" + psfx() in P and L_ctx == 1 and hw % 32 == 0 and switches.get("LDMK_ATTN_PS", "1") != "0"
                                                  and m.d_head == 32
                                                  and (hw >= ATTN_H2_MIN_TOKENS if h2_flag is not None else attention_presplit(hw))) else None)
         att = None if plan_o is not None else pg.alloc(rows, C_)
@@ -449,7 +450,7 @@ def emit_spatial_transformer(nb_, ctx_pg, P, sd, prefix, m, x, h, w, L_ctx, ctx_
             #  output, the lane = column form of the kernel, and loses to the row GEMM in the step: 951.5 vs 959.6 sample-steps/s with
             #  attn1.to_out off as well, A/B on one box; LDMK_POUT_PS=1 turns it on.  A split-K ff.net.2 has no PS epilogue.)
             plan_p = (nb_.ps_query(rows, m.ch, C_) if (last and prefix + "pout" + psfx() in P and plan_f[1] <= 1
-                                                       and os.environ.get("LDMK_POUT_PS", "0") == "1") else None)
+                                                       and switches.get("LDMK_POUT_PS", "0") == "1") else None)
             hc_ps = pg.alloc_ps(rows, C_) if plan_p is not None else None
             hcur = nb_.lin_ps(plan_f, rows, Nf, f_ps, P[q + "ff2"], P[q + "ff2" + psfx()], sd[q + "ff.net.2.bias"], hw, out=h2, residual=h2,
                               out_ps=hc_ps)

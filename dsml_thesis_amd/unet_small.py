@@ -26,17 +26,18 @@ import os
 import torch
 
 from . import lib as L
+from . import switches
 from . import ops
 from .engine import Program
 
-SMALL_ROWS = int(os.environ.get("LDMK_SMALL_ROWS", "4096"))
+SMALL_ROWS = int(switches.get("LDMK_SMALL_ROWS", "4096"))
 
 
 def wants_small_route(policy_n, H, W_, L_ctx):
     """Decided on the JOB's batch (policy_n), like the tile plans: a sample's result does not depend on how a batch is
     sharded.  One-token contexts only (all shipped configs); longer contexts keep the batched program."""
     return (L_ctx == 1 and policy_n * H * W_ <= SMALL_ROWS and H % 8 == 0 and W_ % 8 == 0
-            and not os.environ.get("LDMK_NO_SMALL_ROUTE"))
+            and not switches.get("LDMK_NO_SMALL_ROUTE"))
 
 
 @torch.no_grad()

@@ -366,3 +366,38 @@ def test_posterior_helpers_carry_the_reference_formulas():
     assert torch.equal(qm, g("sqrt_alphas_cumprod") * x) and torch.equal(qv, 1.0 - g("alphas_cumprod"))
     torch.testing.assert_close(qlv, torch.log(qv), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(m.q_sample(x, t, nz), qm + qv.sqrt() * nz, rtol=1e-6, atol=1e-6)      # (q_sample draws from that q)
+
+
+def test_every_environment_switch_is_registered_and_documented():
+    """dsml_thesis_amd/switches.py is the one table of `LDMK_*` environment switches: every read in the package goes through
+    switches.get (no raw os.environ read of an LDMK_ name is left), with the default the table documents; every getenv in the
+    library's sources and every read in bench.py names a registered switch; the table names nothing that is no longer read; and
+    docs/SWITCHES.md is the table's own rendering."""
+    import glob
+    import os
+    import re
+    from dsml_thesis_amd import switches as S
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = set()
+    for path in sorted(glob.glob(os.path.join(root, "dsml_thesis_amd", "*.py"))):
+        src = open(path).read()
+        if not path.endswith("switches.py"):
+            assert not re.search(r'os\.environ(\.get\(|\[)\s*"LDMK_', src), f"raw environment read of an LDMK_ switch in {path}"
+        for name, default in re.findall(r'switches\.get\("(LDMK_[A-Z0-9_]+)"(?:,\s*"([^"]*)")?\)', src):
+            assert name in S.SWITCHES, (name, path)
+            seen.add(name)
+            table_default = S.SWITCHES[name][0]
+            assert (default or None) == (table_default or None), (name, path, default, table_default)
+    for path in sorted(glob.glob(os.path.join(root, "dsml_thesis_amd", "csrc", "*"))):
+        if path.endswith((".hip", ".h")):
+            for name in re.findall(r'getenv\("(LDMK_[A-Z0-9_]+)"\)', open(path).read()):
+                assert name in S.PROBE_ONLY or S.SWITCHES.get(name, (None, None))[1] == "library", (name, path)
+                seen.add(name)
+    for name in re.findall(r'os\.environ\.get\("(LDMK_[A-Z0-9_]+)"', open(os.path.join(root, "bench.py")).read()):
+        assert name in S.SWITCHES, (name, "bench.py")
+        seen.add(name)
+    stale = set(S.SWITCHES) - seen
+    assert not stale, f"registered but never read: {sorted(stale)}"
+    with pytest.raises(KeyError):
+        S.get("LDMK_NOT_A_SWITCH")
+    assert open(os.path.join(root, "docs", "SWITCHES.md")).read().strip() == S.table_markdown().strip()
