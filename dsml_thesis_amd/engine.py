@@ -84,7 +84,7 @@ def table(section):
     if t is None:
         import json
         t = {}
-        path = os.environ.get(_SECTIONS[section]) or _PLAN_FILE
+        path = switches.get(_SECTIONS[section]) or _PLAN_FILE
         if _section_enabled(section) and os.path.exists(path):
             try:
                 with open(path) as fh:

@@ -49,6 +49,12 @@ SWITCHES = {
     "LDMK_NO_PLAN_TABLE": (None, "plan", "set: ignore igemm_plans.json (the library's built-in tile heuristic plans every GEMM)"),
     "LDMK_PLAN_MAX_RATIO": ("0", "plan", "> 0: a tuned plan is used only within this ratio of its tuned row count (0: nearest at any "
                             "distance)"),
+    "LDMK_PLAN_TABLE": (None, "plan", "a file that replaces the `f32` section of igemm_plans.json (a flat {key: [cfg, splitk]} file as "
+                        "the tuning tools write it, or another merged file whose section is taken)"),
+    "LDMK_X3_TABLE": (None, "plan", "the same for the `bf16x3` section"),
+    "LDMK_H2_TABLE": (None, "plan", "the same for the `f16x2` section"),
+    "LDMK_PS_TABLE": (None, "plan", "the same for the `ps_bf16x3` section (pre-split tiles)"),
+    "LDMK_PS_H2_TABLE": (None, "plan", "the same for the `ps_f16x2` section (pre-split tiles, F16X2)"),
     # ---- runtime / build
     "LDMK_LIBRARY": (None, "runtime", "path of the libldmk.so to load instead of the in-tree one"),
     "LDMK_FORCE_COLLECTIVE": (None, "runtime", "set: parallel.all_gather_items issues the real all-gather at world size 1 too (RCCL "

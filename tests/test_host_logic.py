@@ -388,6 +388,13 @@ def test_every_environment_switch_is_registered_and_documented():
             seen.add(name)
             table_default = S.SWITCHES[name][0]
             assert (default or None) == (table_default or None), (name, path, default, table_default)
+    from dsml_thesis_amd import engine
+    for name in engine._SECTIONS.values():                 # (read under a computed name: engine.table)
+        assert name in S.SWITCHES, name
+        seen.add(name)
+    for path in sorted(glob.glob(os.path.join(root, "dsml_thesis_amd", "*.py"))):      # no environment read under a computed name is left raw
+        if not path.endswith(("switches.py", "build.py")):
+            assert "os.environ" not in open(path).read(), f"raw environment access in {path}"
     for path in sorted(glob.glob(os.path.join(root, "dsml_thesis_amd", "csrc", "*"))):
         if path.endswith((".hip", ".h")):
             for name in re.findall(r'getenv\("(LDMK_[A-Z0-9_]+)"\)', open(path).read()):
