@@ -80,8 +80,23 @@ class DDIMSampler(object):
         return tab, ts, np.arange(self.ddpm_num_timesteps)
 
     # ------------------------------------------------------------------------------------------
+    def _is_adm(self):
+        return getattr(self.model.model, "conditioning_key", None) == "adm"
+
+    @staticmethod
+    def _labels(cond):
+        """conditioning_key 'adm': the class-label vector y (B,) out of whatever form apply_model accepts (ddpm.py:893-994 wraps a
+        tensor as c_crossattn = [y]; DiffusionWrapper takes c_crossattn[0], :1417-1419)."""
+        if isinstance(cond, dict):
+            cond = cond.get("c_crossattn")
+        if isinstance(cond, (list, tuple)):
+            cond = cond[0]
+        return cond
+
     def _split_cond(self, cond):
-        """-> (crossattn context (B,L,D), c_concat (B,C,H,W) or None)."""
+        """-> (crossattn context (B,L,D), c_concat (B,C,H,W) or None); 'adm': (class labels (B,), None)."""
+        if self._is_adm():
+            return self._labels(cond), None
         if isinstance(cond, dict):
             if C12 in cond:                      # TF sampler conditioning, ddim2cond.py:165
                 return cond[C12], cond[C34]
@@ -150,7 +165,7 @@ class DDIMSampler(object):
         cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
         nb = 2 * b if cfg else b
         y_in = None
-        if getattr(self.model.model, "conditioning_key", None) == "adm":
+        if self._is_adm():
             # class-conditional model (ddpm.py:1417-1419): the conditioning is the label vector y, which reaches the UNet as rows of
             # its label embedding added to the timestep embedding -- constant over the run, written once into the program's
             # `y_emb` input; guidance doubles it as [uncond | cond] like any conditioning (ddim.py:175)

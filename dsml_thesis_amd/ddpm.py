@@ -415,7 +415,10 @@ class LatentDiffusion(_Base):
                 if img_callback:
                     img_callback(img, i)
             return (img, intermediates) if return_intermediates else img
-        if isinstance(cond, dict):
+        if self.model.conditioning_key == "adm":          # labels in any form apply_model accepts: y, [y], {"c_crossattn": [y]}
+            ctx = cond.get("c_crossattn") if isinstance(cond, dict) else cond
+            ctx, cat = (ctx[0] if isinstance(ctx, (list, tuple)) else ctx), None
+        elif isinstance(cond, dict):
             ctx = cond.get("c_crossattn")
             cat = cond.get("c_concat")
             ctx = torch.cat(ctx, 1) if isinstance(ctx, (list, tuple)) else ctx

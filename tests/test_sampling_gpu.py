@@ -751,6 +751,10 @@ def test_class_conditional_model_through_the_samplers():
     close(out, g["adm_ddim4"], 1.5e-4, 1.5e-4)
     out_g, _ = s.sample(use_graph=True, **kw)
     assert torch.equal(out, out_g)
+    for form in ([y], {"c_crossattn": [y]}):               # the other forms apply_model accepts for the labels (ddpm.py:893-994)
+        assert torch.equal(s.sample(**dict(kw, conditioning=form))[0], out)
+    assert torch.equal(m.p_sample_loop([y], (2, 3, 16, 16), x_T=xT, timesteps=2, verbose=False, noise=list(T(g["adm_ddpm3_noise"]).cuda())),
+                       m.p_sample_loop(y, (2, 3, 16, 16), x_T=xT, timesteps=2, verbose=False, noise=list(T(g["adm_ddpm3_noise"]).cuda())))
     cfg3 = dict(unconditional_guidance_scale=3.0, unconditional_conditioning=uy)
     out3, _ = s.sample(**kw, **cfg3)
     close(out3, g["adm_ddim4_cfg3"], 1.5e-4, 1.5e-4)
