@@ -201,8 +201,8 @@ class LatentDiffusion(_Base):
     @contextmanager
     def ema_scope(self, context=None):
         """ddpm.py:171-184: sample with the EMA weights, then put the training weights back.  Every reference sampling
-        script runs inside this scope.  The swap writes through the parameters (LitEma.copy_to / restore), so the
-        kernel-layout weight copies are rebuilt on the next forward, inside the scope and again after it."""
+        script runs inside this scope.  The swap writes through the parameters (LitEma.copy_to / restore) as the reference's
+        does; the UNet's kernel-layout copies of either weight set are packed once and swapped by name (see below)."""
         swapped = bool(self.use_ema)
         unet = self.model.diffusion_model
         if swapped:

@@ -43,7 +43,6 @@ def all_gather_items(local, n_items, group=None):
     LDMK_FORCE_COLLECTIVE is set and a process group exists (bench.py sets it with LDMK_BENCH_FORCE_DIST): then the REAL
     collective is issued over the one-rank group, so that communicator creation and `ncclAllGather` on device tensors next to a
     live hipGraph have run on hardware before the first multi-GPU job does."""
-    import os
     import torch.distributed as dist
     global COLLECTIVES_ISSUED
     if not (dist.is_available() and dist.is_initialized()):
