@@ -564,7 +564,7 @@ def test_unconditional_unet_golden(policy):
         m(x.cuda(), t.cuda(), context=torch.zeros(2, 1, 512, device="cuda"))
     with pytest.raises(NotImplementedError):
         from dsml_thesis_amd.unet import UNetModel
-        UNetModel(**dict(W.UNCOND_UNET, resblock_updown=True))
+        UNetModel(**dict(W.UNCOND_UNET, n_embed=8))
 
 
 def test_unet_multi_token_context_vs_oracle():
@@ -590,9 +590,10 @@ def test_unet_rejects_unsupported():
     from dsml_thesis_amd.unet import UNetModel
     from dsml_thesis_amd import lib as L
     with pytest.raises(NotImplementedError):
-        UNetModel(**dict(W.FR_UNET, resblock_updown=True))
+        UNetModel(**dict(W.FR_UNET, dims=3))
     with pytest.raises(NotImplementedError):
         UNetModel(**dict(W.FR_UNET, n_embed=8))
+    assert UNetModel(**dict(W.FR_UNET, resblock_updown=True)).resblock_updown      # (built since round 5: test_unet_resblock_updown)
     m, _ = make_unet(W.FR_UNET)
     with pytest.raises(L.LdmkError):
         m(torch.zeros(1, 3, 32, 32), torch.zeros(1, dtype=torch.long), context=torch.zeros(1, 1, 512))
