@@ -1045,6 +1045,14 @@ class UNetModel(nn.Module):
             self._programs[key] = pg
         return pg
 
+    def convert_to_fp16(self):
+        """openaimodel.py:694-700 casts the torso to float16; this path is fp32 storage with fp32-class products."""
+        raise NotImplementedError("UNetModel.convert_to_fp16: fp32 only (reference precision; use_fp16 is refused the same way)")
+
+    def convert_to_fp32(self):
+        """openaimodel.py:702-708: the torso back to float32 -- it never leaves it here."""
+        return None
+
     @torch.no_grad()
     def forward(self, x, timesteps=None, context=None, y=None, c_concat=None, **kwargs):
         """x: (N, C, H, W) fp32 NCHW; timesteps: (N,) int64; context: (N, L, context_dim).

@@ -89,6 +89,9 @@ def test_unsupported_options_fail_loudly():
     assert set(ud.state_dict().keys()) == set(W.unet_param_shapes(W.UPDOWN_UNET).keys())
     assert [m.updown for _, m in ud._walk() if m.kind == "res" and m.updown] == ["down", "down", "up", "up"]
     assert not any(m.kind in ("down", "up") for _, m in ud._walk())
+    assert ud.convert_to_fp32() is None                      # (openaimodel.py:702-708: a no-op on an fp32 model)
+    with pytest.raises(NotImplementedError):
+        ud.convert_to_fp16()
     with pytest.raises(NotImplementedError):
         VQModelInterface(embed_dim=3, n_embed=16, ddconfig=dict(W.VQ_F4["ddconfig"], attn_type="linear"))
 
