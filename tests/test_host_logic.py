@@ -411,3 +411,32 @@ def test_every_environment_switch_is_registered_and_documented():
     with pytest.raises(KeyError):
         S.get("LDMK_NOT_A_SWITCH")
     assert open(os.path.join(root, "docs", "SWITCHES.md")).read().strip() == S.table_markdown().strip()
+
+
+def test_sampler_conditioning_forms():
+    """DDIMSampler._split_cond (host logic, no kernel): every form the reference's apply_model accepts (ddpm.py:893-994) maps to
+    (cross-attention context, channel concat) -- or, for conditioning_key 'adm', to the class-label vector (ddpm.py:1417-1419)."""
+    from dsml_thesis_amd.ddim import DDIMSampler, C12, C34
+
+    class Wrapper:
+        conditioning_key = "crossattn"
+
+    class Model:
+        num_timesteps = 1000
+        device = torch.device("cpu")
+        model = Wrapper()
+    s = DDIMSampler(Model())
+    ctx, cat, y = torch.zeros(2, 1, 512), torch.zeros(2, 6, 8, 8), torch.tensor([7, 2])
+    assert s._split_cond(ctx)[0] is ctx and s._split_cond(ctx)[1] is None
+    assert s._split_cond([ctx, ctx])[0].shape == (2, 2, 512)                    # lists are concatenated on the token axis
+    a, b = s._split_cond({"c_crossattn": [ctx], "c_concat": [cat, cat]})
+    assert a.shape == (2, 1, 512) and b.shape == (2, 12, 8, 8)
+    a, b = s._split_cond({C12: ctx, C34: cat})                                  # the talking-face sampler's dict (ddim2cond.py:165)
+    assert a is ctx and b is cat
+    assert s._split_cond(None) == (None, None)
+    Wrapper.conditioning_key = "concat"
+    assert s._split_cond(cat)[0] is None and s._split_cond(cat)[1] is cat
+    Wrapper.conditioning_key = "adm"
+    for form in (y, [y], {"c_crossattn": [y]}):
+        lab, none = s._split_cond(form)
+        assert lab is y and none is None
